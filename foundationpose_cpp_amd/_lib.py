@@ -1,0 +1,92 @@
+"""ctypes loader for libfoundationpose_amd.so (the C ABI of include/foundationpose_amd.h).
+
+The library is the product: there is NO CPU fallback.  If it is missing or cannot be loaded this module raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfoundationpose_amd.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+# every symbol include/foundationpose_amd.h declares
+SYMBOLS = [
+    "fp_create", "fp_destroy", "fp_last_error", "fp_set_inplane_steps", "fp_num_hypotheses",
+    "fp_register", "fp_track", "fp_register_ex", "fp_track_ex",
+    "fp_upload_frame", "fp_get_xyz_map", "fp_get_hyp_poses", "fp_filter_depth",
+    "fp_render_and_transform", "fp_debug_rasterize", "fp_refiner_infer", "fp_scorer_infer",
+    "fp_refine_post_process", "fp_argmax", "fp_register_shard_begin", "fp_register_shard_finish",
+    "fp_profile_enable", "fp_profile_reset", "fp_profile_report", "fp_stream", "fp_synchronize",
+]
+
+
+class FpMesh(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("num_vertices", C.c_int), ("num_faces", C.c_int),
+                ("vertices", C.c_void_p), ("normals", C.c_void_p), ("texcoords", C.c_void_p),
+                ("faces", C.c_void_p), ("texture", C.c_void_p), ("tex_height", C.c_int),
+                ("tex_width", C.c_int), ("diameter", C.c_float), ("center", C.c_float * 3)]
+
+
+def build(verbose: bool = False) -> str:
+    """Compile the HIP sources for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    cmd = ["make", "-C", CSRC, "-j8"]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if verbose or res.returncode != 0:
+        print(res.stdout[-4000:])
+        print(res.stderr[-8000:])
+    if res.returncode != 0:
+        raise RuntimeError("building libfoundationpose_amd.so failed")
+    return LIB_PATH
+
+
+_LIB = None
+
+
+def lib() -> C.CDLL:
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(there is no CPU fallback)")
+    L = C.CDLL(LIB_PATH)
+    for s in SYMBOLS:
+        getattr(L, s)  # raises AttributeError if the library does not export the symbol
+    L.fp_create.restype = C.c_void_p
+    L.fp_create.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int]
+    L.fp_destroy.argtypes = [C.c_void_p]
+    L.fp_destroy.restype = None
+    L.fp_last_error.restype = C.c_char_p
+    L.fp_stream.restype = C.c_void_p
+    L.fp_stream.argtypes = [C.c_void_p]
+    vp, ci, cf, cs = C.c_void_p, C.c_int, C.c_float, C.c_char_p
+    sigs = {
+        "fp_set_inplane_steps": [vp, ci], "fp_num_hypotheses": [vp],
+        "fp_register": [vp, vp, vp, vp, ci, ci, cs, ci, vp],
+        "fp_track": [vp, vp, vp, ci, ci, vp, cs, ci, vp],
+        "fp_register_ex": [vp, vp, vp, vp, ci, ci, ci, cs, ci, vp],
+        "fp_track_ex": [vp, vp, vp, ci, ci, ci, vp, cs, ci, vp],
+        "fp_upload_frame": [vp, vp, vp, ci, ci, ci], "fp_get_xyz_map": [vp, vp],
+        "fp_get_hyp_poses": [vp, vp, ci, vp, vp], "fp_filter_depth": [vp, vp, vp],
+        "fp_render_and_transform": [vp, cs, vp, ci, cf, vp, vp, ci],
+        "fp_debug_rasterize": [vp, cs, vp, ci, cf, vp, vp],
+        "fp_refiner_infer": [vp, vp, vp, ci, ci, vp, vp], "fp_scorer_infer": [vp, vp, vp, ci, ci, vp],
+        "fp_refine_post_process": [vp, cs, vp, vp, vp, ci, vp], "fp_argmax": [vp, vp, ci, vp],
+        "fp_register_shard_begin": [vp, vp, vp, vp, ci, ci, ci, cs, ci, ci, ci, vp, vp],
+        "fp_register_shard_finish": [vp, vp, vp, ci, vp, vp, vp],
+        "fp_profile_enable": [vp, ci], "fp_profile_reset": [vp], "fp_profile_report": [vp, vp, ci],
+        "fp_synchronize": [vp],
+    }
+    for name, at in sigs.items():
+        f = getattr(L, name)
+        f.argtypes = at
+        f.restype = C.c_int
+    _LIB = L
+    return L
+
+
+def last_error() -> str:
+    return (lib().fp_last_error() or b"").decode("utf-8", "replace")

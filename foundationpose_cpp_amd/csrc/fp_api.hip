@@ -1,0 +1,761 @@
+// fp_api.hip -- the C ABI (include/foundationpose_amd.h) and the host-side orchestration that mirrors
+// detection_6d::FoundationPose (reference D6F/src/foundationpose.cpp:108-458), MI355X-first:
+//   * all per-hypothesis host work of the reference (crop windows, bbox, projection, pose update, arg-max) runs
+//     on the device, so a Register is one stream of launches with a single D2H of the winning pose;
+//   * render/crop kernels write the networks' fp16 input tensor directly (no fp32 blob, no concat pass);
+//   * device buffers are allocated once per model and grown on demand (no per-call hipMalloc).
+#include "../../include/foundationpose_amd.h"
+
+#include <algorithm>
+#include <array>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+
+#include "fp_internal.h"
+#include "fp_nn.h"
+
+namespace fp {
+
+static thread_local std::string g_last_error;
+void set_error(const std::string &msg) { g_last_error = msg; }
+
+// ------------------------------------------------------------------------------------------------
+// Profiler
+// ------------------------------------------------------------------------------------------------
+ProfEntry &Profiler::get(const char *name) {
+  for (auto &e : entries)
+    if (e.name == name) return e;
+  entries.emplace_back();
+  entries.back().name = name;
+  return entries.back();
+}
+hipEvent_t Profiler::ev() {
+  if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+  hipEvent_t e;
+  (void)hipEventCreate(&e);
+  return e;
+}
+void Profiler::begin(hipStream_t s, const char *name, double flops, double bytes) {
+  // entries is a vector: take the index, pointers may move
+  ProfEntry &e = get(name);
+  e.calls++; e.flops += flops; e.bytes += bytes;
+  cur = &e;
+  cur_start = ev();
+  (void)hipEventRecord(cur_start, s);
+}
+void Profiler::end(hipStream_t s) {
+  hipEvent_t stop = ev();
+  (void)hipEventRecord(stop, s);
+  cur->pending.emplace_back(cur_start, stop);
+  cur = nullptr;
+}
+void Profiler::collect() {
+  for (auto &e : entries) {
+    for (auto &pr : e.pending) {
+      (void)hipEventSynchronize(pr.second);
+      float ms = 0;
+      (void)hipEventElapsedTime(&ms, pr.first, pr.second);
+      e.ms += ms;
+      pool.push_back(pr.first);
+      pool.push_back(pr.second);
+    }
+    e.pending.clear();
+  }
+}
+void Profiler::reset() {
+  collect();
+  entries.clear();
+}
+
+// ------------------------------------------------------------------------------------------------
+// a7: rotation grid (D6F/src/foundationpose_sampling.cpp:56-121,178-237); 42 icosphere views x inplane_steps
+// ------------------------------------------------------------------------------------------------
+namespace {
+struct V3 { float x, y, z; };
+V3 normalized(V3 p) {
+  float n2 = p.x * p.x + p.y * p.y + p.z * p.z;
+  if (n2 > 0.0f) { float n = std::sqrt(n2); p.x /= n; p.y /= n; p.z /= n; }
+  return p;
+}
+std::vector<V3> icosphere(unsigned min_views) {
+  std::vector<V3> verts;
+  std::vector<std::array<int, 3>> faces;
+  std::map<int64_t, int> cache;
+  float t = (float)((1.0 + std::sqrt(5.0)) / 2.0);
+  const float init[12][3] = {{-1, t, 0}, {1, t, 0}, {-1, -t, 0}, {1, -t, 0}, {0, -1, t}, {0, 1, t},
+                             {0, -1, -t}, {0, 1, -t}, {t, 0, -1}, {t, 0, 1}, {-t, 0, -1}, {-t, 0, 1}};
+  for (auto &p : init) verts.push_back(normalized(V3{p[0], p[1], p[2]}));
+  const int f0[20][3] = {{0, 11, 5}, {0, 5, 1}, {0, 1, 7}, {0, 7, 10}, {0, 10, 11}, {1, 5, 9}, {5, 11, 4},
+                         {11, 10, 2}, {10, 7, 6}, {7, 1, 8}, {3, 9, 4}, {3, 4, 2}, {3, 2, 6}, {3, 6, 8},
+                         {3, 8, 9}, {4, 9, 5}, {2, 4, 11}, {6, 2, 10}, {8, 6, 7}, {9, 8, 1}};
+  for (auto &f : f0) faces.push_back({f[0], f[1], f[2]});
+  auto middle = [&](int i, int j) {
+    int64_t sm = std::min(i, j), gr = std::max(i, j), key = (sm << 32) + gr;
+    auto it = cache.find(key);
+    if (it != cache.end()) return it->second;
+    V3 a = verts[i], b = verts[j];
+    verts.push_back(normalized(V3{(a.x + b.x) / 2.0f, (a.y + b.y) / 2.0f, (a.z + b.z) / 2.0f}));
+    cache[key] = (int)verts.size() - 1;
+    return (int)verts.size() - 1;
+  };
+  while (verts.size() < min_views) {
+    std::vector<std::array<int, 3>> nf;
+    for (auto &f : faces) {
+      int a = f[0], b = f[1], c = f[2];
+      int ab = middle(a, b), bc = middle(b, c), ca = middle(c, a);
+      nf.push_back({a, ab, ca}); nf.push_back({b, bc, ab}); nf.push_back({c, ca, bc}); nf.push_back({ab, bc, ca});
+    }
+    faces.swap(nf);
+  }
+  return verts;
+}
+}  // namespace
+
+std::vector<float> make_rotation_grid(int min_views, int inplane_steps) {
+  std::vector<float> out;
+  auto verts = icosphere((unsigned)min_views);
+  const double step = 360.0 / inplane_steps;
+  for (auto &pos : verts) {
+    V3 z = normalized(V3{-pos.x, -pos.y, -pos.z});
+    V3 up{0, 0, 1};
+    V3 x{up.y * z.z - up.z * z.y, up.z * z.x - up.x * z.z, up.x * z.y - up.y * z.x};
+    if (x.x == 0.0f && x.y == 0.0f && x.z == 0.0f) x = V3{1, 0, 0};
+    x = normalized(x);
+    V3 y = normalized(V3{z.y * x.z - z.z * x.y, z.z * x.x - z.x * x.z, z.x * x.y - z.y * x.x});
+    // cam_in_ob rotation columns x,y,z ; translation pos
+    for (int k = 0; k < inplane_steps; k++) {
+      float a = (float)((k * step) * M_PI / 180.0f);
+      float s = std::sin(a), c = std::cos(a);
+      // R = [x y z] * Rz(a): columns
+      double cx[3] = {(double)(x.x * c + y.x * s), (double)(x.y * c + y.y * s), (double)(x.z * c + y.z * s)};
+      double cy[3] = {(double)(x.x * -s + y.x * c), (double)(x.y * -s + y.y * c), (double)(x.z * -s + y.z * c)};
+      double cz[3] = {(double)z.x * ((1.0f - c) + c), (double)z.y * ((1.0f - c) + c), (double)z.z * ((1.0f - c) + c)};
+      double tt[3] = {pos.x, pos.y, pos.z};
+      // ob_in_cam = inverse: rotation R^T (rows = columns of R), translation -R^T t
+      float o[16];
+      const double *cols[3] = {cx, cy, cz};
+      for (int r = 0; r < 3; r++)
+        for (int cc = 0; cc < 3; cc++) o[cc * 4 + r] = (float)cols[r][cc];
+      for (int r = 0; r < 3; r++) o[12 + r] = (float)(-(cols[r][0] * tt[0] + cols[r][1] * tt[1] + cols[r][2] * tt[2]));
+      o[3] = o[7] = o[11] = 0; o[15] = 1;
+      out.insert(out.end(), o, o + 16);
+    }
+  }
+  return out;
+}
+
+// GuessTranslation (D6F/src/foundationpose_sampling.cpp:250-298) on host buffers
+static int guess_translation(const float *depth, const uint8_t *mask, int H, int W, const float *K, float min_depth,
+                             float center[3]) {
+  int umin = W, umax = -1, vmin = H, vmax = -1;
+  std::vector<float> vals;
+  for (int i = 0; i < H; i++)
+    for (int j = 0; j < W; j++)
+      if (mask[(size_t)i * W + j] > 0) {
+        umin = std::min(umin, j); umax = std::max(umax, j);
+        vmin = std::min(vmin, i); vmax = std::max(vmax, i);
+        float d = depth[(size_t)i * W + j];
+        if (d >= min_depth) vals.push_back(d);
+      }
+  FP_CHECK(umax >= 0, "[FoundationposeSampling] Mask is all zero.");
+  FP_CHECK(!vals.empty(), "[FoundationposeSampling] No valid value in mask.");
+  float uc = (float)((umin + umax) / 2.0), vc = (float)((vmin + vmax) / 2.0);
+  size_t n = vals.size();
+  float zc;
+  std::nth_element(vals.begin(), vals.begin() + n / 2, vals.end());
+  float hi = vals[n / 2];
+  if (n % 2 == 0) {
+    float lo = *std::max_element(vals.begin(), vals.begin() + n / 2);
+    zc = (float)((lo + hi) / 2.0);
+  } else {
+    zc = hi;
+  }
+  // K.inverse() * (uc,vc,1) * zc : cofactor inverse in float
+  const float *m = K;
+  float c00 = m[4] * m[8] - m[5] * m[7], c01 = m[5] * m[6] - m[3] * m[8], c02 = m[3] * m[7] - m[4] * m[6];
+  float det = m[0] * c00 + m[1] * c01 + m[2] * c02, id = 1.0f / det;
+  float Ki[9] = {c00 * id, (m[2] * m[7] - m[1] * m[8]) * id, (m[1] * m[5] - m[2] * m[4]) * id,
+                 c01 * id, (m[0] * m[8] - m[2] * m[6]) * id, (m[2] * m[3] - m[0] * m[5]) * id,
+                 c02 * id, (m[1] * m[6] - m[0] * m[7]) * id, (m[0] * m[4] - m[1] * m[3]) * id};
+  for (int r = 0; r < 3; r++) {
+    float s = Ki[r * 3] * uc;
+    s = s + Ki[r * 3 + 1] * vc;
+    s = s + Ki[r * 3 + 2] * 1.0f;
+    center[r] = s * zc;
+  }
+  return 0;
+}
+
+template <typename T>
+static int dev_alloc(T **p, size_t count) {
+  FP_HIP_OK(hipMalloc((void **)p, std::max<size_t>(count, 1) * sizeof(T)));
+  return 0;
+}
+template <typename T>
+static void dev_free(T *&p) {
+  if (p) (void)hipFree(p);
+  p = nullptr;
+}
+
+}  // namespace fp
+
+using namespace fp;
+
+struct Target {
+  std::string name;
+  DeviceMesh mesh;
+};
+
+struct fp_model {
+  hipStream_t stream = nullptr;
+  Profiler prof;
+  float K[9];
+  int max_h = 1080, max_w = 1920;
+  int inplane_steps = 6;
+  std::vector<Target> targets;
+  std::vector<float> grid_host;  // [n_hyp*16]
+
+  // frame
+  int H = 0, W = 0;
+  uint8_t *rgb_own = nullptr;
+  float *depth_own = nullptr;
+  const uint8_t *rgb = nullptr;   // device
+  const float *depth = nullptr;   // device
+  float *erode = nullptr, *bilat = nullptr, *xyz = nullptr;
+  std::vector<float> bilat_host;
+  std::vector<uint8_t> mask_host;
+  size_t frame_cap = 0;
+
+  // per-hypothesis scratch
+  int cap = 0;
+  size_t vert_cap = 0;
+  PoseRec *recs = nullptr;
+  float *poses_dev = nullptr;
+  float4 *clip = nullptr, *attr = nullptr;
+  __half *nn_in = nullptr;                  // [2*cap,80,80,32]
+  float *blob_a = nullptr, *blob_b = nullptr;  // [cap,160,160,6] f32 (blob-mode entry points only)
+  float *trans_dev = nullptr, *rot_dev = nullptr, *scores_dev = nullptr, *feat_dev = nullptr;
+  int *argmax_dev = nullptr;
+  int32_t *dbg_tri = nullptr;
+  float *dbg_rast = nullptr;
+
+  Net *refiner = nullptr, *scorer = nullptr;
+  NNScratch *ws = nullptr;
+
+  Target *find(const char *name) {
+    for (auto &t : targets)
+      if (t.name == name) return &t;
+    return nullptr;
+  }
+  int n_hyp() const { return 42 * inplane_steps; }
+};
+
+static int ensure_capacity(fp_model *m, int N, size_t V) {
+  if (N > m->cap) {
+    dev_free(m->recs); dev_free(m->poses_dev); dev_free(m->nn_in); dev_free(m->blob_a); dev_free(m->blob_b);
+    dev_free(m->trans_dev); dev_free(m->rot_dev); dev_free(m->scores_dev); dev_free(m->feat_dev);
+    dev_free(m->clip); dev_free(m->attr); dev_free(m->dbg_tri); dev_free(m->dbg_rast);
+    m->vert_cap = 0;
+    int cap = std::max(N, 8);
+    if (dev_alloc(&m->recs, cap)) return 1;
+    if (dev_alloc(&m->poses_dev, (size_t)cap * 16)) return 1;
+    if (dev_alloc(&m->nn_in, (size_t)2 * cap * FP_CROP_HW * FP_CROP_HW * 8)) return 1;
+    if (dev_alloc(&m->trans_dev, (size_t)cap * 3)) return 1;
+    if (dev_alloc(&m->rot_dev, (size_t)cap * 3)) return 1;
+    if (dev_alloc(&m->scores_dev, (size_t)cap)) return 1;
+    if (dev_alloc(&m->feat_dev, (size_t)cap * 512)) return 1;
+    m->cap = cap;
+  }
+  if ((size_t)m->cap * V > m->vert_cap) {
+    dev_free(m->clip); dev_free(m->attr);
+    if (dev_alloc(&m->clip, (size_t)m->cap * V)) return 1;
+    if (dev_alloc(&m->attr, (size_t)m->cap * V)) return 1;
+    m->vert_cap = (size_t)m->cap * V;
+  }
+  return 0;
+}
+
+static int ensure_blobs(fp_model *m) {
+  size_t n = (size_t)m->cap * FP_CROP_HW * FP_CROP_HW * 6;
+  if (!m->blob_a && dev_alloc(&m->blob_a, n)) return 1;
+  if (!m->blob_b && dev_alloc(&m->blob_b, n)) return 1;
+  return 0;
+}
+
+static int check_frame_args(fp_model *m, int H, int W, const char *target_name, Target **t) {
+  // CheckInputArguments (D6F/src/foundationpose.cpp:155-179)
+  FP_CHECK(m != nullptr, "[FoundationPose] null model");
+  FP_CHECK(H > 0 && W > 0 && H <= m->max_h && W <= m->max_w, "[FoundationPose] Got rgb/depth/mask with unexpected size !");
+  if (target_name) {
+    *t = m->find(target_name);
+    FP_CHECK(*t != nullptr,
+             "[FoundationPose] Register Got Invalid `target_name` which was not provided to FoundationPose instance!!!");
+  }
+  return 0;
+}
+
+// render + crop for N poses already in m->poses_dev; writes the fp16 network input (both halves) or fp32 blobs
+static int render_and_crop(fp_model *m, Target *t, int N, float crop_ratio, OutMode mode, void *out_a, void *out_b,
+                           int32_t *dbg_tri, float *dbg_rast) {
+  hipStream_t s = m->stream;
+  const size_t out_bytes = (mode == OUT_F32X6 ? 24.0 : 16.0) * FP_CROP_HW * FP_CROP_HW;
+  {
+    ProfScope ps(&m->prof, s, "pose_setup");
+    launch_pose_setup(s, m->poses_dev, N, m->K, m->H, m->W, crop_ratio, t->mesh.diameter, m->recs);
+  }
+  if (out_a) {
+    {
+      ProfScope ps(&m->prof, s, "vertex", 0, (double)N * t->mesh.V * 32.0 + t->mesh.V * 24.0);
+      launch_vertex(s, t->mesh, m->recs, N, m->clip, m->attr);
+    }
+    ProfScope ps(&m->prof, s, "raster_shade", 0, (double)N * (out_bytes + t->mesh.V * 32.0 + t->mesh.F * 12.0));
+    launch_raster_shade(s, t->mesh, m->recs, N, m->clip, m->attr, mode, out_a, dbg_tri, dbg_rast);
+  }
+  if (out_b) {
+    ProfScope ps(&m->prof, s, "crop_warp", 0, (double)N * out_bytes);
+    launch_crop(s, m->rgb, m->depth, m->H, m->W, m->K, m->recs, N, t->mesh.diameter, mode, out_b);
+  }
+  FP_HIP_OK(hipGetLastError());
+  return 0;
+}
+
+extern "C" {
+
+const char *fp_last_error(void) { return g_last_error.c_str(); }
+
+fp_model *fp_create(const fp_mesh *meshes, int n_meshes, const float K[9], const char *refiner_weights,
+                    const char *scorer_weights, int max_h, int max_w) {
+  if (!meshes || n_meshes <= 0 || !K) { set_error("[FoundationPose] fp_create: invalid arguments"); return nullptr; }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+    set_error("[FoundationPose] no HIP device available (this library has no CPU path)");
+    return nullptr;
+  }
+  std::unique_ptr<fp_model> m(new fp_model());
+  std::memcpy(m->K, K, sizeof(float) * 9);
+  if (max_h > 0) m->max_h = max_h;
+  if (max_w > 0) m->max_w = max_w;
+  if (hipStreamCreate(&m->stream) != hipSuccess) { set_error("[FoundationPose] Failed to create stream"); return nullptr; }
+  for (int i = 0; i < n_meshes; i++) {
+    const fp_mesh &src = meshes[i];
+    if (!src.vertices || !src.normals || !src.texcoords || !src.faces || !src.texture || src.num_vertices <= 0 ||
+        src.num_faces <= 0 || src.tex_height <= 0 || src.tex_width <= 0) {
+      set_error("[FoundationPose Renderer] Failed to load textured mesh!!!");
+      fp_destroy(m.release());
+      return nullptr;
+    }
+    Target t;
+    t.name = src.name ? src.name : "";
+    DeviceMesh &d = t.mesh;
+    d.V = src.num_vertices; d.F = src.num_faces; d.TH = src.tex_height; d.TW = src.tex_width;
+    d.diameter = src.diameter;
+    std::memcpy(d.center, src.center, sizeof(float) * 3);
+    // LoadTexturedMesh (D6F/src/foundationpose_render.cpp:381-509): centre vertices, flip v
+    std::vector<float> v((size_t)d.V * 3), uv((size_t)d.V * 2);
+    for (int k = 0; k < d.V; k++) {
+      for (int c = 0; c < 3; c++) v[(size_t)k * 3 + c] = src.vertices[(size_t)k * 3 + c] - src.center[c];
+      uv[(size_t)k * 2] = src.texcoords[(size_t)k * 2];
+      uv[(size_t)k * 2 + 1] = 1 - src.texcoords[(size_t)k * 2 + 1];
+    }
+    std::vector<int32_t> f((size_t)d.F * 3);
+    for (size_t k = 0; k < f.size(); k++) f[k] = (int32_t)src.faces[k];
+    bool ok = !dev_alloc(&d.verts, v.size()) && !dev_alloc(&d.normals, v.size()) && !dev_alloc(&d.uvs, uv.size()) &&
+              !dev_alloc(&d.faces, f.size()) && !dev_alloc(&d.tex, (size_t)d.TH * d.TW * 3);
+    ok = ok && hipMemcpy(d.verts, v.data(), v.size() * 4, hipMemcpyHostToDevice) == hipSuccess;
+    ok = ok && hipMemcpy(d.normals, src.normals, v.size() * 4, hipMemcpyHostToDevice) == hipSuccess;
+    ok = ok && hipMemcpy(d.uvs, uv.data(), uv.size() * 4, hipMemcpyHostToDevice) == hipSuccess;
+    ok = ok && hipMemcpy(d.faces, f.data(), f.size() * 4, hipMemcpyHostToDevice) == hipSuccess;
+    ok = ok && hipMemcpy(d.tex, src.texture, (size_t)d.TH * d.TW * 3, hipMemcpyHostToDevice) == hipSuccess;
+    m->targets.push_back(t);
+    if (!ok) {
+      set_error("[FoundationPose Renderer] Failed to prepare buffer!!!");
+      fp_destroy(m.release());
+      return nullptr;
+    }
+  }
+  m->grid_host = make_rotation_grid(40, m->inplane_steps);
+  m->ws = nn_scratch_create();
+  std::string err;
+  if (refiner_weights) {
+    m->refiner = net_load(refiner_weights, false, &err);
+    if (!m->refiner) { set_error("[FoundationPose] Failed to load refiner weights: " + err); fp_destroy(m.release()); return nullptr; }
+  }
+  if (scorer_weights) {
+    m->scorer = net_load(scorer_weights, true, &err);
+    if (!m->scorer) { set_error("[FoundationPose] Failed to load scorer weights: " + err); fp_destroy(m.release()); return nullptr; }
+  }
+  if (hipMalloc((void **)&m->argmax_dev, sizeof(int)) != hipSuccess) { fp_destroy(m.release()); return nullptr; }
+  return m.release();
+}
+
+void fp_destroy(fp_model *m) {
+  if (!m) return;
+  if (m->stream) (void)hipStreamSynchronize(m->stream);
+  m->prof.reset();
+  for (auto &t : m->targets) {
+    dev_free(t.mesh.verts); dev_free(t.mesh.normals); dev_free(t.mesh.uvs); dev_free(t.mesh.faces); dev_free(t.mesh.tex);
+  }
+  dev_free(m->rgb_own); dev_free(m->depth_own); dev_free(m->erode); dev_free(m->bilat); dev_free(m->xyz);
+  dev_free(m->recs); dev_free(m->poses_dev); dev_free(m->clip); dev_free(m->attr); dev_free(m->nn_in);
+  dev_free(m->blob_a); dev_free(m->blob_b); dev_free(m->trans_dev); dev_free(m->rot_dev); dev_free(m->scores_dev);
+  dev_free(m->feat_dev); dev_free(m->argmax_dev); dev_free(m->dbg_tri); dev_free(m->dbg_rast);
+  if (m->refiner) net_free(m->refiner);
+  if (m->scorer) net_free(m->scorer);
+  if (m->ws) nn_scratch_free(m->ws);
+  if (m->stream) (void)hipStreamDestroy(m->stream);
+  delete m;
+}
+
+int fp_set_inplane_steps(fp_model *m, int steps) {
+  FP_CHECK(m && steps >= 1 && steps <= 360, "[FoundationPose] fp_set_inplane_steps: invalid arguments");
+  m->inplane_steps = steps;
+  m->grid_host = make_rotation_grid(40, steps);
+  return 0;
+}
+int fp_num_hypotheses(const fp_model *m) { return m ? m->n_hyp() : 0; }
+void *fp_stream(fp_model *m) { return m ? (void *)m->stream : nullptr; }
+int fp_synchronize(fp_model *m) {
+  FP_CHECK(m, "null model");
+  FP_HIP_OK(hipStreamSynchronize(m->stream));
+  return 0;
+}
+
+int fp_upload_frame(fp_model *m, const void *rgb, const void *depth, int memspace, int H, int W) {
+  Target *t = nullptr;
+  if (check_frame_args(m, H, W, nullptr, &t)) return 1;
+  FP_CHECK(rgb && depth, "[FoundationPose] Got INVALID rgb/depth ptr");
+  size_t px = (size_t)H * W;
+  if (px > m->frame_cap) {
+    dev_free(m->rgb_own); dev_free(m->depth_own); dev_free(m->erode); dev_free(m->bilat); dev_free(m->xyz);
+    if (dev_alloc(&m->rgb_own, px * 3) || dev_alloc(&m->depth_own, px) || dev_alloc(&m->erode, px) ||
+        dev_alloc(&m->bilat, px))
+      return 1;
+    m->frame_cap = px;
+  }
+  m->H = H; m->W = W;
+  if (memspace == FP_DEVICE) {
+    m->rgb = (const uint8_t *)rgb;
+    m->depth = (const float *)depth;
+  } else {
+    ProfScope ps(&m->prof, m->stream, "h2d_frame", 0, (double)px * 7);
+    FP_HIP_OK(hipMemcpyAsync(m->rgb_own, rgb, px * 3, hipMemcpyHostToDevice, m->stream));
+    FP_HIP_OK(hipMemcpyAsync(m->depth_own, depth, px * 4, hipMemcpyHostToDevice, m->stream));
+    m->rgb = m->rgb_own;
+    m->depth = m->depth_own;
+  }
+  return 0;
+}
+
+int fp_get_xyz_map(fp_model *m, float *xyz_host) {
+  FP_CHECK(m && m->depth && xyz_host, "[FoundationPose] fp_get_xyz_map: no frame uploaded");
+  size_t px = (size_t)m->H * m->W;
+  if (!m->xyz && dev_alloc(&m->xyz, m->frame_cap * 3)) return 1;
+  launch_depth_to_xyz(m->stream, m->depth, m->H, m->W, m->K, m->xyz);
+  FP_HIP_OK(hipMemcpyAsync(xyz_host, m->xyz, px * 12, hipMemcpyDeviceToHost, m->stream));
+  FP_HIP_OK(hipStreamSynchronize(m->stream));
+  return 0;
+}
+
+static int run_depth_filters(fp_model *m) {
+  {
+    ProfScope ps(&m->prof, m->stream, "erode_depth", 0, (double)m->H * m->W * 8);
+    launch_erode(m->stream, m->depth, m->erode, m->H, m->W);
+  }
+  {
+    ProfScope ps(&m->prof, m->stream, "bilateral_depth", 0, (double)m->H * m->W * 8);
+    launch_bilateral(m->stream, m->erode, m->bilat, m->H, m->W);
+  }
+  return 0;
+}
+
+int fp_filter_depth(fp_model *m, float *eroded_out, float *bilateral_out) {
+  FP_CHECK(m && m->depth, "[FoundationPose] fp_filter_depth: no frame uploaded");
+  size_t px = (size_t)m->H * m->W;
+  run_depth_filters(m);
+  if (eroded_out) FP_HIP_OK(hipMemcpyAsync(eroded_out, m->erode, px * 4, hipMemcpyDeviceToHost, m->stream));
+  if (bilateral_out) FP_HIP_OK(hipMemcpyAsync(bilateral_out, m->bilat, px * 4, hipMemcpyDeviceToHost, m->stream));
+  FP_HIP_OK(hipStreamSynchronize(m->stream));
+  return 0;
+}
+
+// GetHypPoses (D6F/src/foundationpose_sampling.cpp:344-394) -> m->poses_dev[0..n) and optional host copy
+static int sample_hypotheses(fp_model *m, const void *mask, int memspace, std::vector<float> &poses) {
+  FP_CHECK(m->depth != nullptr && mask != nullptr, "[FoudationPoseSampler] Got INVALID depth/mask ptr on device!!!");
+  size_t px = (size_t)m->H * m->W;
+  run_depth_filters(m);
+  m->bilat_host.resize(px);
+  {
+    ProfScope ps(&m->prof, m->stream, "d2h_filtered_depth", 0, (double)px * 4);
+    FP_HIP_OK(hipMemcpyAsync(m->bilat_host.data(), m->bilat, px * 4, hipMemcpyDeviceToHost, m->stream));
+  }
+  const uint8_t *mask_h = (const uint8_t *)mask;
+  if (memspace == FP_DEVICE) {
+    m->mask_host.resize(px);
+    FP_HIP_OK(hipMemcpyAsync(m->mask_host.data(), mask, px, hipMemcpyDeviceToHost, m->stream));
+    mask_h = m->mask_host.data();
+  }
+  FP_HIP_OK(hipStreamSynchronize(m->stream));
+  float center[3];
+  if (guess_translation(m->bilat_host.data(), mask_h, m->H, m->W, m->K, FP_MIN_DEPTH, center)) return 1;
+  poses = m->grid_host;
+  for (size_t i = 0; i < poses.size() / 16; i++) {
+    poses[i * 16 + 12] = center[0]; poses[i * 16 + 13] = center[1]; poses[i * 16 + 14] = center[2];
+  }
+  return 0;
+}
+
+int fp_get_hyp_poses(fp_model *m, const void *mask, int memspace, float *poses_out, int *n_out) {
+  FP_CHECK(m && poses_out, "[FoundationPose] fp_get_hyp_poses: invalid arguments");
+  std::vector<float> poses;
+  if (sample_hypotheses(m, mask, memspace, poses)) return 1;
+  std::memcpy(poses_out, poses.data(), poses.size() * sizeof(float));
+  if (n_out) *n_out = (int)(poses.size() / 16);
+  return 0;
+}
+
+static int upload_poses(fp_model *m, Target *t, const float *poses, int N) {
+  if (ensure_capacity(m, N, (size_t)t->mesh.V)) return 1;
+  FP_HIP_OK(hipMemcpyAsync(m->poses_dev, poses, (size_t)N * 64, hipMemcpyHostToDevice, m->stream));
+  return 0;
+}
+
+int fp_render_and_transform(fp_model *m, const char *target_name, const float *poses, int N, float crop_ratio,
+                            float *render_out, float *transf_out, int out_memspace) {
+  FP_CHECK(m && poses && N > 0, "[FoundationposeRender] The transform matrix vector is empty");
+  FP_CHECK(m->depth != nullptr, "[FoundationPose] fp_render_and_transform: no frame uploaded");
+  Target *t = m->find(target_name ? target_name : "");
+  FP_CHECK(t != nullptr, "[FoundationPose] unknown target_name");
+  if (upload_poses(m, t, poses, N)) return 1;
+  const size_t bytes = (size_t)N * FP_CROP_HW * FP_CROP_HW * 6 * sizeof(float);
+  float *a = render_out, *b = transf_out;
+  if (out_memspace == FP_HOST) {
+    if (ensure_blobs(m)) return 1;
+    a = render_out ? m->blob_a : nullptr;
+    b = transf_out ? m->blob_b : nullptr;
+  }
+  if (render_and_crop(m, t, N, crop_ratio, OUT_F32X6, a, b, nullptr, nullptr)) return 1;
+  if (out_memspace == FP_HOST) {
+    if (render_out) FP_HIP_OK(hipMemcpyAsync(render_out, a, bytes, hipMemcpyDeviceToHost, m->stream));
+    if (transf_out) FP_HIP_OK(hipMemcpyAsync(transf_out, b, bytes, hipMemcpyDeviceToHost, m->stream));
+  }
+  FP_HIP_OK(hipStreamSynchronize(m->stream));
+  return 0;
+}
+
+int fp_debug_rasterize(fp_model *m, const char *target_name, const float *poses, int N, float crop_ratio,
+                       int32_t *tri_id, float *rast_out) {
+  FP_CHECK(m && poses && N > 0, "[FoundationposeRender] The transform matrix vector is empty");
+  FP_CHECK(m->H > 0, "[FoundationPose] fp_debug_rasterize: no frame uploaded (image size unknown)");
+  Target *t = m->find(target_name ? target_name : "");
+  FP_CHECK(t != nullptr, "[FoundationPose] unknown target_name");
+  if (upload_poses(m, t, poses, N)) return 1;
+  if (ensure_blobs(m)) return 1;
+  size_t px = (size_t)m->cap * FP_CROP_HW * FP_CROP_HW;
+  if (!m->dbg_tri && dev_alloc(&m->dbg_tri, px)) return 1;
+  if (!m->dbg_rast && dev_alloc(&m->dbg_rast, px * 4)) return 1;
+  if (render_and_crop(m, t, N, crop_ratio, OUT_F32X6, m->blob_a, nullptr, m->dbg_tri, m->dbg_rast)) return 1;
+  size_t n = (size_t)N * FP_CROP_HW * FP_CROP_HW;
+  if (tri_id) FP_HIP_OK(hipMemcpyAsync(tri_id, m->dbg_tri, n * 4, hipMemcpyDeviceToHost, m->stream));
+  if (rast_out) FP_HIP_OK(hipMemcpyAsync(rast_out, m->dbg_rast, n * 16, hipMemcpyDeviceToHost, m->stream));
+  FP_HIP_OK(hipStreamSynchronize(m->stream));
+  return 0;
+}
+
+// blob-mode network entry points: f32 NHWC [N,160,160,6] -> packed fp16 input
+static int pack_blobs(fp_model *m, const float *render_input, const float *transf_input, int memspace, int N) {
+  FP_CHECK(render_input && transf_input && N > 0, "[FoundationPose] null network input");
+  if (ensure_capacity(m, N, 0)) return 1;
+  const size_t px = (size_t)N * FP_CROP_HW * FP_CROP_HW;
+  const float *a = render_input, *b = transf_input;
+  if (memspace == FP_HOST) {
+    if (ensure_blobs(m)) return 1;
+    FP_HIP_OK(hipMemcpyAsync(m->blob_a, render_input, px * 24, hipMemcpyHostToDevice, m->stream));
+    FP_HIP_OK(hipMemcpyAsync(m->blob_b, transf_input, px * 24, hipMemcpyHostToDevice, m->stream));
+    a = m->blob_a; b = m->blob_b;
+  }
+  launch_pack_f32x6_to_f16x8(m->stream, a, m->nn_in, px);
+  launch_pack_f32x6_to_f16x8(m->stream, b, m->nn_in + px * 8, px);
+  return 0;
+}
+
+int fp_refiner_infer(fp_model *m, const float *render_input, const float *transf_input, int memspace, int N,
+                     float *trans_out, float *rot_out) {
+  FP_CHECK(m && m->refiner, "[FoundationPose] refiner weights not loaded");
+  if (pack_blobs(m, render_input, transf_input, memspace, N)) return 1;
+  if (refiner_forward(m->stream, &m->prof, m->refiner, m->ws, m->nn_in, N, m->trans_dev, m->rot_dev)) return 1;
+  FP_HIP_OK(hipMemcpyAsync(trans_out, m->trans_dev, (size_t)N * 12, hipMemcpyDeviceToHost, m->stream));
+  FP_HIP_OK(hipMemcpyAsync(rot_out, m->rot_dev, (size_t)N * 12, hipMemcpyDeviceToHost, m->stream));
+  FP_HIP_OK(hipStreamSynchronize(m->stream));
+  return 0;
+}
+
+int fp_scorer_infer(fp_model *m, const float *render_input, const float *transf_input, int memspace, int N,
+                    float *scores_out) {
+  FP_CHECK(m && m->scorer, "[FoundationPose] scorer weights not loaded");
+  if (pack_blobs(m, render_input, transf_input, memspace, N)) return 1;
+  if (scorer_features(m->stream, &m->prof, m->scorer, m->ws, m->nn_in, N, m->feat_dev)) return 1;
+  if (scorer_head(m->stream, &m->prof, m->scorer, m->ws, m->feat_dev, N, m->scores_dev)) return 1;
+  FP_HIP_OK(hipMemcpyAsync(scores_out, m->scores_dev, (size_t)N * 4, hipMemcpyDeviceToHost, m->stream));
+  FP_HIP_OK(hipStreamSynchronize(m->stream));
+  return 0;
+}
+
+int fp_refine_post_process(fp_model *m, const char *target_name, const float *poses, const float *trans,
+                           const float *rot, int N, float *poses_out) {
+  FP_CHECK(m && poses && trans && rot && poses_out && N > 0, "[FoundationPose] fp_refine_post_process: invalid arguments");
+  Target *t = m->find(target_name ? target_name : "");
+  FP_CHECK(t != nullptr, "[FoundationPose] unknown target_name");
+  if (ensure_capacity(m, N, 0)) return 1;
+  FP_HIP_OK(hipMemcpyAsync(m->poses_dev, poses, (size_t)N * 64, hipMemcpyHostToDevice, m->stream));
+  FP_HIP_OK(hipMemcpyAsync(m->trans_dev, trans, (size_t)N * 12, hipMemcpyHostToDevice, m->stream));
+  FP_HIP_OK(hipMemcpyAsync(m->rot_dev, rot, (size_t)N * 12, hipMemcpyHostToDevice, m->stream));
+  launch_pose_update(m->stream, m->poses_dev, m->trans_dev, m->rot_dev, N, t->mesh.diameter);
+  FP_HIP_OK(hipMemcpyAsync(poses_out, m->poses_dev, (size_t)N * 64, hipMemcpyDeviceToHost, m->stream));
+  FP_HIP_OK(hipStreamSynchronize(m->stream));
+  return 0;
+}
+
+int fp_argmax(fp_model *m, const float *scores, int N, int *index_out) {
+  FP_CHECK(m && scores && index_out && N > 0, "[FoundationPose] fp_argmax: invalid arguments");
+  if (ensure_capacity(m, N, 0)) return 1;
+  FP_HIP_OK(hipMemcpyAsync(m->scores_dev, scores, (size_t)N * 4, hipMemcpyHostToDevice, m->stream));
+  launch_argmax(m->stream, m->scores_dev, N, m->argmax_dev);
+  FP_HIP_OK(hipMemcpyAsync(index_out, m->argmax_dev, 4, hipMemcpyDeviceToHost, m->stream));
+  FP_HIP_OK(hipStreamSynchronize(m->stream));
+  return 0;
+}
+
+// one refine iteration over m->poses_dev[0..N): RefinePreProcess + SyncInfer + RefinePostProcess, all on device
+static int refine_iteration(fp_model *m, Target *t, int N) {
+  const size_t half = (size_t)N * FP_CROP_HW * FP_CROP_HW * 8;
+  if (render_and_crop(m, t, N, 1.2f /* refine_mode_crop_ratio_ foundationpose.cpp:87 */, OUT_F16X8, m->nn_in,
+                      m->nn_in + half, nullptr, nullptr))
+    return 1;
+  if (refiner_forward(m->stream, &m->prof, m->refiner, m->ws, m->nn_in, N, m->trans_dev, m->rot_dev)) return 1;
+  ProfScope ps(&m->prof, m->stream, "pose_update");
+  launch_pose_update(m->stream, m->poses_dev, m->trans_dev, m->rot_dev, N, t->mesh.diameter);
+  return 0;
+}
+
+int fp_register_shard_begin(fp_model *m, const void *rgb, const void *depth, const void *mask, int memspace, int H,
+                            int W, const char *target_name, int refine_itr, int shard_begin, int shard_count,
+                            float **feat_dev, float **poses_dev) {
+  Target *t = nullptr;
+  if (check_frame_args(m, H, W, target_name ? target_name : "", &t)) return 1;
+  FP_CHECK(m->refiner && m->scorer, "[FoundationPose] refiner/scorer weights not loaded");
+  FP_CHECK(mask != nullptr, "[FoundationPose] Register needs a mask");
+  const int n_all = m->n_hyp();
+  FP_CHECK(shard_begin >= 0 && shard_count > 0 && shard_begin + shard_count <= n_all,
+           "[FoundationPose] hypothesis shard out of range");
+  if (fp_upload_frame(m, rgb, depth, memspace, H, W)) return 1;
+  std::vector<float> poses;
+  if (sample_hypotheses(m, mask, memspace, poses)) {
+    set_error(std::string("[FoundationPose] Failed to generate hyp poses!!! ") + g_last_error);
+    return 1;
+  }
+  const int N = shard_count;
+  if (upload_poses(m, t, poses.data() + (size_t)shard_begin * 16, N)) return 1;
+  for (int it = 0; it < refine_itr; it++)
+    if (refine_iteration(m, t, N)) return 1;
+  const size_t half = (size_t)N * FP_CROP_HW * FP_CROP_HW * 8;
+  if (render_and_crop(m, t, N, 1.1f /* score_mode_crop_ratio_ foundationpose.cpp:88 */, OUT_F16X8, m->nn_in,
+                      m->nn_in + half, nullptr, nullptr))
+    return 1;
+  if (scorer_features(m->stream, &m->prof, m->scorer, m->ws, m->nn_in, N, m->feat_dev)) return 1;
+  if (feat_dev) *feat_dev = m->feat_dev;
+  if (poses_dev) *poses_dev = m->poses_dev;
+  return 0;
+}
+
+int fp_register_shard_finish(fp_model *m, const float *all_feat_dev, const float *all_poses_dev, int N_total,
+                             float out_pose[16], int *best_index, float *scores_host) {
+  FP_CHECK(m && m->scorer && all_feat_dev && all_poses_dev && N_total > 0 && out_pose,
+           "[FoundationPose] fp_register_shard_finish: invalid arguments");
+  float *scores = m->scores_dev;
+  float *scores_tmp = nullptr;
+  if (N_total > m->cap) {
+    if (dev_alloc(&scores_tmp, (size_t)N_total)) return 1;
+    scores = scores_tmp;
+  }
+  int rc = scorer_head(m->stream, &m->prof, m->scorer, m->ws, all_feat_dev, N_total, scores);
+  if (!rc) {
+    ProfScope ps(&m->prof, m->stream, "argmax");
+    launch_argmax(m->stream, scores, N_total, m->argmax_dev);
+  }
+  int idx = 0;
+  if (!rc && hipMemcpyAsync(&idx, m->argmax_dev, 4, hipMemcpyDeviceToHost, m->stream) != hipSuccess) rc = 1;
+  if (!rc && scores_host &&
+      hipMemcpyAsync(scores_host, scores, (size_t)N_total * 4, hipMemcpyDeviceToHost, m->stream) != hipSuccess)
+    rc = 1;
+  if (!rc && hipStreamSynchronize(m->stream) != hipSuccess) rc = 1;
+  if (!rc && hipMemcpy(out_pose, all_poses_dev + (size_t)idx * 16, 64, hipMemcpyDeviceToHost) != hipSuccess) rc = 1;
+  if (scores_tmp) (void)hipFree(scores_tmp);
+  if (rc && g_last_error.empty()) set_error("[FoundationPose] fp_register_shard_finish failed");
+  if (best_index) *best_index = idx;
+  return rc;
+}
+
+int fp_register_ex(fp_model *m, const void *rgb, const void *depth, const void *mask, int memspace, int H, int W,
+                   const char *target_name, int refine_itr, float out_pose[16]) {
+  FP_CHECK(m != nullptr, "[FoundationPose] null model");
+  float *feat = nullptr, *poses = nullptr;
+  if (fp_register_shard_begin(m, rgb, depth, mask, memspace, H, W, target_name, refine_itr, 0, m->n_hyp(), &feat,
+                              &poses))
+    return 1;
+  return fp_register_shard_finish(m, feat, poses, m->n_hyp(), out_pose, nullptr, nullptr);
+}
+
+int fp_register(fp_model *m, const uint8_t *rgb, const float *depth, const uint8_t *mask, int H, int W,
+                const char *target_name, int refine_itr, float out_pose[16]) {
+  return fp_register_ex(m, rgb, depth, mask, FP_HOST, H, W, target_name, refine_itr, out_pose);
+}
+
+int fp_track_ex(fp_model *m, const void *rgb, const void *depth, int memspace, int H, int W, const float hyp_pose[16],
+                const char *target_name, int refine_itr, float out_pose[16]) {
+  Target *t = nullptr;
+  if (check_frame_args(m, H, W, target_name ? target_name : "", &t)) return 1;
+  FP_CHECK(m->refiner, "[FoundationPose] refiner weights not loaded");
+  FP_CHECK(hyp_pose && out_pose, "[FoundationPose] Track: null pose");
+  if (fp_upload_frame(m, rgb, depth, memspace, H, W)) return 1;
+  if (upload_poses(m, t, hyp_pose, 1)) return 1;
+  for (int it = 0; it < refine_itr; it++)
+    if (refine_iteration(m, t, 1)) return 1;
+  FP_HIP_OK(hipMemcpyAsync(out_pose, m->poses_dev, 64, hipMemcpyDeviceToHost, m->stream));
+  FP_HIP_OK(hipStreamSynchronize(m->stream));
+  return 0;
+}
+
+int fp_track(fp_model *m, const uint8_t *rgb, const float *depth, int H, int W, const float hyp_pose[16],
+             const char *target_name, int refine_itr, float out_pose[16]) {
+  return fp_track_ex(m, rgb, depth, FP_HOST, H, W, hyp_pose, target_name, refine_itr, out_pose);
+}
+
+int fp_profile_enable(fp_model *m, int on) {
+  FP_CHECK(m, "null model");
+  m->prof.on = on != 0;
+  return 0;
+}
+int fp_profile_reset(fp_model *m) {
+  FP_CHECK(m, "null model");
+  (void)hipStreamSynchronize(m->stream);
+  m->prof.reset();
+  return 0;
+}
+int fp_profile_report(fp_model *m, char *buf, int buf_len) {
+  FP_CHECK(m && buf && buf_len > 0, "fp_profile_report: invalid arguments");
+  (void)hipStreamSynchronize(m->stream);
+  m->prof.collect();
+  std::string out;
+  char line[256];
+  for (auto &e : m->prof.entries) {
+    std::snprintf(line, sizeof(line), "%s %ld %.6f %.6e %.6e\n", e.name.c_str(), e.calls, e.ms, e.flops, e.bytes);
+    out += line;
+  }
+  std::snprintf(buf, (size_t)buf_len, "%s", out.c_str());
+  return 0;
+}
+
+}  // extern "C"

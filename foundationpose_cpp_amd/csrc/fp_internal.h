@@ -1,0 +1,119 @@
+// Internal declarations shared by the HIP translation units of libfoundationpose_amd.so (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#define FP_CROP_HW 160
+#define FP_MIN_DEPTH 0.001f  // FoundationPoseRenderer min_depth (foundationpose_render.hpp:26)
+#define FP_MAX_DEPTH 4.0f    // FoundationPoseRenderer max_depth (foundationpose_render.hpp:27)
+
+namespace fp {
+
+// ---------------------------------------------------------------------------------------------
+// error plumbing: C ABI returns 0 / non-zero + fp_last_error()
+// ---------------------------------------------------------------------------------------------
+void set_error(const std::string &msg);
+#define FP_HIP_OK(expr)                                                                              \
+  do {                                                                                               \
+    hipError_t _e = (expr);                                                                          \
+    if (_e != hipSuccess) {                                                                          \
+      fp::set_error(std::string(#expr) + " failed: " + hipGetErrorString(_e));                       \
+      return 1;                                                                                      \
+    }                                                                                                \
+  } while (0)
+#define FP_CHECK(cond, msg)                                                                          \
+  do {                                                                                               \
+    if (!(cond)) {                                                                                   \
+      fp::set_error(msg);                                                                            \
+      return 1;                                                                                      \
+    }                                                                                                \
+  } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// profiling: optional HIP-event bracket around every launch, accumulated per kernel family
+// ---------------------------------------------------------------------------------------------
+struct ProfEntry {
+  std::string name;
+  long calls = 0;
+  double flops = 0, bytes = 0;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+  double ms = 0;
+};
+struct Profiler {
+  bool on = false;
+  std::vector<ProfEntry> entries;
+  std::vector<hipEvent_t> pool;
+  ProfEntry &get(const char *name);
+  hipEvent_t ev();
+  void begin(hipStream_t s, const char *name, double flops, double bytes);
+  void end(hipStream_t s);
+  void collect();
+  void reset();
+  ProfEntry *cur = nullptr;
+  hipEvent_t cur_start = nullptr;
+};
+struct ProfScope {
+  Profiler *p;
+  hipStream_t s;
+  ProfScope(Profiler *p_, hipStream_t s_, const char *name, double flops = 0, double bytes = 0) : p(p_), s(s_) {
+    if (p && p->on) p->begin(s, name, flops, bytes);
+  }
+  ~ProfScope() {
+    if (p && p->on) p->end(s);
+  }
+};
+
+// ---------------------------------------------------------------------------------------------
+// geometry kernels (fp_geometry.hip)
+// ---------------------------------------------------------------------------------------------
+
+// Per-hypothesis record produced by the pose-setup kernel; everything the reference computes on the host per
+// pose (ComputeCropWindowTF, ConstructBBox2D, ProjectMatrixFromIntrinsics, foundationpose_render.cpp:25-186,590).
+struct PoseRec {
+  float M[16];     // Proj * GLcam * pose, column-major
+  float pose[16];  // column-major
+  float a00, a11, a30, a31;  // generate_pose_clip remap (foundationpose_render.cu:382-384)
+  float m0, m2, m4, m5;      // inverse crop transform: src = (m0*x + m2, m4*y + m5)
+  float tf[9];               // forward crop transform, row-major (debug / tests)
+  float bbox[4];
+};
+
+struct DeviceMesh {
+  int V = 0, F = 0, TH = 0, TW = 0;
+  float diameter = 0;
+  float center[3] = {0, 0, 0};
+  float *verts = nullptr;    // [V,3] centred
+  float *normals = nullptr;  // [V,3]
+  float *uvs = nullptr;      // [V,2] (u, 1-v)
+  int32_t *faces = nullptr;  // [F,3]
+  uint8_t *tex = nullptr;    // [TH,TW,3]
+};
+
+enum OutMode { OUT_F32X6 = 0, OUT_F16X8 = 1 };
+
+void launch_pose_setup(hipStream_t s, const float *poses_dev, int N, const float *K9_host, int img_h, int img_w,
+                       float crop_ratio, float diameter, PoseRec *recs);
+void launch_vertex(hipStream_t s, const DeviceMesh &m, const PoseRec *recs, int N, float4 *clip, float4 *attr);
+void launch_raster_shade(hipStream_t s, const DeviceMesh &m, const PoseRec *recs, int N, const float4 *clip,
+                         const float4 *attr, OutMode mode, void *out, int32_t *tri_id_dbg, float *rast_dbg);
+void launch_crop(hipStream_t s, const uint8_t *rgb, const float *depth, int H, int W, const float *K9_host,
+                 const PoseRec *recs, int N, float diameter, OutMode mode, void *out);
+void launch_depth_to_xyz(hipStream_t s, const float *depth, int H, int W, const float *K9_host, float *xyz);
+void launch_erode(hipStream_t s, const float *depth, float *out, int H, int W);
+void launch_bilateral(hipStream_t s, const float *depth, float *out, int H, int W);
+// device-side refine post process: poses updated in place from trans/rot [N,3] (foundationpose.cpp:360-406)
+void launch_pose_update(hipStream_t s, float *poses, const float *trans, const float *rot, int N, float diameter);
+// first-max arg-max over scores[N] -> *index (foundationpose_decoder.cu:24-35)
+void launch_argmax(hipStream_t s, const float *scores, int N, int *index_dev);
+// f32 [N,160,160,6] -> f16 [N,160,160,8] (blob-mode entry points feeding the f16 networks)
+void launch_pack_f32x6_to_f16x8(hipStream_t s, const float *in, __half *out, size_t pixels);
+
+// host helpers (fp_host.cpp part of fp_api.hip)
+std::vector<float> make_rotation_grid(int min_views, int inplane_steps);
+
+}  // namespace fp

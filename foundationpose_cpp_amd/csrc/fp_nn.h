@@ -1,0 +1,30 @@
+// Refine-net / score-net on MFMA (fp_nn.hip): replaces the two opaque TensorRT engines of the reference
+// (refiner_core_->SyncInfer foundationpose.cpp:206-208,254-256; scorer_core_->SyncInfer :218-220).
+#pragma once
+
+#include "fp_internal.h"
+
+namespace fp {
+
+struct Net;        // packed weights of one network, resident in HBM
+struct NNScratch;  // activation buffers, grown on demand
+
+// Reads a packed weight file (tools/pack_weights.py, "FPW1" format: fp32 tensors in PyTorch layout, BatchNorm
+// already folded into conv weight+bias) and re-lays it out for the MFMA kernels (fp16, [Cout][KH][KW][Cin]).
+Net *net_load(const char *path, bool is_scorer, std::string *err);
+void net_free(Net *);
+
+NNScratch *nn_scratch_create();
+void nn_scratch_free(NNScratch *);
+
+// Network input: nn_in = f16 [2N,80,80,32]: space-to-depth(2x2) view of the NHWC [2N,160,160,8] tensor
+// (channels r,g,b,x,y,z,0,0), rendered crops A in images [0,N), observed crops B in [N,2N).
+// Outputs are device pointers.
+int refiner_forward(hipStream_t s, Profiler *prof, const Net *net, NNScratch *ws, const __half *nn_in, int N,
+                    float *trans_dev /*[N,3]*/, float *rot_dev /*[N,3]*/);
+int scorer_features(hipStream_t s, Profiler *prof, const Net *net, NNScratch *ws, const __half *nn_in, int N,
+                    float *feat_dev /*[N,512]*/);
+int scorer_head(hipStream_t s, Profiler *prof, const Net *net, NNScratch *ws, const float *feats_dev, int n_total,
+                float *scores_dev /*[n_total]*/);
+
+}  // namespace fp

@@ -1,0 +1,137 @@
+/*
+ * foundationpose_amd.h -- C ABI of the MI355X-native FoundationPose Register/Track hot path.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no torch / OpenCV / Eigen types.
+ * Every entry point names the reference interface it replaces (path:line under zz990099/foundationpose_cpp,
+ * D6F = detection_6d_foundationpose).  INTEGRATION.md shows the C++ shim that puts the reference's own
+ * `detection_6d::Base6DofDetectionModel` header on top of these calls.
+ *
+ * Conventions
+ *   - 4x4 poses are COLUMN-MAJOR float[16] (Eigen::Matrix4f::data()), translation at [12..14].
+ *   - K is ROW-MAJOR float[9].
+ *   - rgb: u8 [H,W,3] RGB order; depth: f32 [H,W] metres; mask: u8 [H,W], >0 = object.
+ *   - returned poses are CENTRED-mesh -> camera, exactly like the reference (D6F/src/foundationpose_render.cpp:396-398);
+ *     use the mesh centre to convert (D6F/include/detection_6d_foundationpose/mesh_loader.hpp:75-81).
+ *   - every function returning int returns 0 on success, non-zero on failure; fp_last_error() describes it
+ *     (the reference returns bool + a glog line, D6F/src/foundationpose_utils.hpp:76-84).
+ *   - not re-entrant per model (like the reference: one renderer / scratch set per target,
+ *     D6F/src/foundationpose.cpp:103-105).
+ *   - memspace arguments: FP_HOST pointers are ordinary host memory, FP_DEVICE pointers are HIP device memory on
+ *     the model's device (lets callers keep frames resident in HBM).
+ */
+#ifndef FOUNDATIONPOSE_AMD_H
+#define FOUNDATIONPOSE_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FP_HOST 0
+#define FP_DEVICE 1
+
+#define FP_CROP 160            /* crop_window_H/W, D6F/src/foundationpose.cpp:34-35 */
+#define FP_NUM_HYP_DEFAULT 252 /* score_mode_poses_num_, D6F/src/foundationpose.cpp:85 */
+
+typedef struct fp_model fp_model;
+
+/* What detection_6d::BaseMeshLoader exposes (D6F/include/detection_6d_foundationpose/mesh_loader.hpp:25-61). */
+typedef struct fp_mesh {
+  const char *name;          /* GetName() */
+  int num_vertices;          /* GetMeshNumVertices() */
+  int num_faces;             /* GetMeshNumFaces() */
+  const float *vertices;     /* GetMeshVertices()       [V,3], mesh frame (NOT centred) */
+  const float *normals;      /* GetMeshVertexNormals()  [V,3] */
+  const float *texcoords;    /* GetMeshTextureCoords()  [V,2] = (u,v) as loaded (v is flipped internally) */
+  const uint32_t *faces;     /* GetMeshTriangleFaces()  [F,3] */
+  const uint8_t *texture;    /* GetTextureMap()         [tex_height,tex_width,3] RGB u8 */
+  int tex_height, tex_width;
+  float diameter;            /* GetMeshDiameter() */
+  float center[3];           /* GetMeshModelCenter() */
+} fp_mesh;
+
+/* ---- construction: CreateFoundationPoseModel (D6F/include/.../foundationpose.hpp:99-105, src/foundationpose.cpp:108-153,448-458).
+ * refiner_weights / scorer_weights: paths of packed weight files (tools/pack_weights.py; replaces the TensorRT
+ * engines of simple_tests/src/test_foundationpose.cpp:13-14).  NULL = geometry-only model (NN entry points fail). */
+fp_model *fp_create(const fp_mesh *meshes, int n_meshes, const float K[9], const char *refiner_weights,
+                    const char *scorer_weights, int max_input_image_height, int max_input_image_width);
+void fp_destroy(fp_model *m);
+const char *fp_last_error(void);
+/* number of in-plane rotations per icosphere view: 6 -> 252 hypotheses (reference), 24 -> 1008 (SURVEY.md §8a note). */
+int fp_set_inplane_steps(fp_model *m, int steps);
+int fp_num_hypotheses(const fp_model *m);
+
+/* ---- Base6DofDetectionModel::Register / Track (D6F/include/.../foundationpose.hpp:36-41,59-64; src/foundationpose.cpp:181-265). */
+int fp_register(fp_model *m, const uint8_t *rgb, const float *depth, const uint8_t *mask, int H, int W,
+                const char *target_name, int refine_itr, float out_pose[16]);
+int fp_track(fp_model *m, const uint8_t *rgb, const float *depth, int H, int W, const float hyp_pose[16],
+             const char *target_name, int refine_itr, float out_pose[16]);
+/* same, frame already resident in HBM (memspace FP_DEVICE for rgb/depth/mask) */
+int fp_register_ex(fp_model *m, const void *rgb, const void *depth, const void *mask, int memspace, int H, int W,
+                   const char *target_name, int refine_itr, float out_pose[16]);
+int fp_track_ex(fp_model *m, const void *rgb, const void *depth, int memspace, int H, int W,
+                const float hyp_pose[16], const char *target_name, int refine_itr, float out_pose[16]);
+
+/* ---- stage-level operators (what the reference's orchestrator calls; used by the parity tests) ---- */
+
+/* UploadDataToDevice + convert_depth_to_xyz_map (src/foundationpose.cpp:267-315, src/foundationpose_utils.cu:3-32). */
+int fp_upload_frame(fp_model *m, const void *rgb, const void *depth, int memspace, int H, int W);
+/* optional readback of the xyz map [H,W,3] f32 (pixels with depth < 0.001 are 0). */
+int fp_get_xyz_map(fp_model *m, float *xyz_host);
+
+/* FoundationPoseSampler::GetHypPoses (src/foundationpose_sampling.hpp:18-22, .cpp:344-394) on the uploaded frame.
+ * poses_out: host [fp_num_hypotheses()*16]. Fails on empty mask / no valid depth like the reference (.cpp:269,278). */
+int fp_get_hyp_poses(fp_model *m, const void *mask, int memspace, float *poses_out, int *n_out);
+/* erode_depth / bilateral_filter_depth (src/foundationpose_sampling.cu:172-204) on the uploaded frame; host outputs [H,W]. */
+int fp_filter_depth(fp_model *m, float *eroded_out, float *bilateral_out);
+
+/* FoundationPoseRenderer::RenderAndTransform (src/foundationpose_render.hpp:29-37, .cpp:814-857):
+ * poses host [N*16]; render_out / transf_out: [N,160,160,6] f32 NHWC in `out_memspace` (either may be NULL). */
+int fp_render_and_transform(fp_model *m, const char *target_name, const float *poses, int N, float crop_ratio,
+                            float *render_out, float *transf_out, int out_memspace);
+/* debug view of the rasteriser (CR::CudaRaster colour buffer + nvdiffrast rast_out, src/foundationpose_render.cu:184-232):
+ * tri_id host [N,160,160] i32 (triangle index+1, raster/y-up order), rast_out host [N,160,160,4] f32; either may be NULL. */
+int fp_debug_rasterize(fp_model *m, const char *target_name, const float *poses, int N, float crop_ratio,
+                       int32_t *tri_id, float *rast_out);
+
+/* refiner_core_->SyncInfer (src/foundationpose.cpp:206-208; blobs :78-81): inputs [N,160,160,6] f32 NHWC,
+ * outputs host trans[N,3], rot[N,3]. */
+int fp_refiner_infer(fp_model *m, const float *render_input, const float *transf_input, int memspace, int N,
+                     float *trans_out, float *rot_out);
+/* scorer_core_->SyncInfer (src/foundationpose.cpp:218-220; blob :83): outputs host scores[N]. */
+int fp_scorer_infer(fp_model *m, const float *render_input, const float *transf_input, int memspace, int N,
+                    float *scores_out);
+/* RefinePostProcess (src/foundationpose.cpp:360-406): host in/out. */
+int fp_refine_post_process(fp_model *m, const char *target_name, const float *poses, const float *trans,
+                           const float *rot, int N, float *poses_out);
+/* getMaxScoreIndex (src/foundationpose_decoder.cu:24-35): first maximum wins. scores host [N]. */
+int fp_argmax(fp_model *m, const float *scores, int N, int *index_out);
+
+/* ---- hypothesis sharding over GPUs (new).  One process per GPU calls:
+ *   fp_register_shard_begin : sampler (redundant on every rank) + refine + score trunk for hypotheses
+ *                             [shard_begin, shard_begin+shard_count) of the fp_num_hypotheses() grid;
+ *                             leaves pooled score features [shard_count,512] f32 and refined poses [shard_count,16]
+ *                             in device buffers returned through feat_dev / poses_dev;
+ *   (caller all-gathers both over RCCL);
+ *   fp_register_shard_finish: cross-hypothesis attention + Linear + arg-max over all N gathered rows. */
+int fp_register_shard_begin(fp_model *m, const void *rgb, const void *depth, const void *mask, int memspace, int H,
+                            int W, const char *target_name, int refine_itr, int shard_begin, int shard_count,
+                            float **feat_dev, float **poses_dev);
+int fp_register_shard_finish(fp_model *m, const float *all_feat_dev, const float *all_poses_dev, int N_total,
+                             float out_pose[16], int *best_index, float *scores_host /* may be NULL */);
+
+/* ---- measurement hooks ---- */
+/* When enabled, every kernel launch is bracketed with HIP events on the model's stream and accumulated per kernel
+ * family; fp_profile_report writes "name calls total_ms flops bytes" lines. */
+int fp_profile_enable(fp_model *m, int on);
+int fp_profile_reset(fp_model *m);
+int fp_profile_report(fp_model *m, char *buf, int buf_len);
+/* stream used for all launches (hipStream_t as void*), so callers can order their own work / events. */
+void *fp_stream(fp_model *m);
+int fp_synchronize(fp_model *m);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

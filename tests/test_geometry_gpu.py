@@ -1,0 +1,159 @@
+"""Parity of the HIP geometry path (C ABI) against the CPU oracle on the same seeded inputs.
+
+Bar: integer work (the rasteriser's triangle-id buffer) is BIT-EXACT; float tensors are compared with the tolerance
+written at each assert (both sides evaluate the same float expression order; residual differences come from
+expf/tanhf/sinf implementations and are <= a few ulp).
+"""
+import numpy as np
+import pytest
+
+from foundationpose_cpp_amd import FoundationPose, synthetic as syn
+from oracle import fp_oracle as fo
+
+pytestmark = pytest.mark.gpu
+
+F32_TOL = dict(rtol=0, atol=2e-6)   # render / crop tensors live in [-4,4]; 2e-6 abs ~ a few ulp
+
+
+@pytest.fixture(scope="module")
+def model(syn_mesh):
+    m = FoundationPose(syn_mesh, syn.intrinsics())
+    yield m
+    m.close()
+
+
+@pytest.fixture(scope="module")
+def hyp(model, syn_scene):
+    model.upload_frame(syn_scene.rgb, syn_scene.depth)
+    poses = model.get_hyp_poses(syn_scene.mask)
+    assert poses is not None and poses.shape == (252, 4, 4)
+    return poses
+
+
+def test_rotation_grid_and_translation_match_oracle(hyp, syn_scene):
+    ref = syn.from_colmajor(fo.get_hyp_poses(syn_scene.depth, syn_scene.mask, syn_scene.K))
+    np.testing.assert_allclose(hyp[:, :3, :3], ref[:, :3, :3], atol=1e-6)
+    np.testing.assert_allclose(hyp[:, :3, 3], ref[:, :3, 3], rtol=1e-5)
+
+
+def test_depth_filters_and_xyz(model, syn_scene):
+    model.upload_frame(syn_scene.rgb, syn_scene.depth)
+    e, b = model.filter_depth()
+    np.testing.assert_array_equal(e, fo.erode_depth(syn_scene.depth))      # compare / count only: bit exact
+    np.testing.assert_allclose(b, fo.bilateral_filter_depth(fo.erode_depth(syn_scene.depth)), rtol=2e-6, atol=0)
+    np.testing.assert_array_equal(model.xyz_map(), fo.depth_to_xyz(syn_scene.depth, syn_scene.K))
+
+
+@pytest.mark.parametrize("crop_ratio", [1.2, 1.1])
+def test_render_and_transform_parity_252(model, hyp, syn_mesh, syn_scene, crop_ratio):
+    model.upload_frame(syn_scene.rgb, syn_scene.depth)
+    om = fo.OracleMesh(syn_mesh)
+    p16 = syn.to_colmajor(hyp)
+    ref_a, ref_tri, ref_rast = fo.render(om, p16, syn_scene.K, (480, 640), crop_ratio, debug=True)
+    ref_b = fo.crop(syn_scene.rgb, syn_scene.depth, syn_scene.K, p16, crop_ratio, syn_mesh.diameter)
+    tri, rast = model.debug_rasterize(syn_mesh.name, hyp, crop_ratio)
+    assert (ref_tri > 0).sum() > 252 * 2000
+    np.testing.assert_array_equal(tri, ref_tri)                             # integer raster: bit exact
+    np.testing.assert_allclose(rast, ref_rast, rtol=0, atol=2e-6)
+    a, b = model.render_and_transform(syn_mesh.name, hyp, crop_ratio)
+    np.testing.assert_allclose(a, ref_a, **F32_TOL)
+    np.testing.assert_allclose(b, ref_b, **F32_TOL)
+
+
+def test_render_gt_pose_and_untextured(syn_scene):
+    mesh = syn.make_mesh(textured=False, name="plain")
+    m = FoundationPose(mesh, syn.intrinsics())
+    m.upload_frame(syn_scene.rgb, syn_scene.depth)
+    poses = np.stack([syn_scene.gt_pose, syn.perturb_pose(syn_scene.gt_pose)])
+    a, b = m.render_and_transform("plain", poses, 1.2)
+    ref_a = fo.render(fo.OracleMesh(mesh), syn.to_colmajor(poses), syn_scene.K, (480, 640), 1.2)
+    np.testing.assert_allclose(a, ref_a, **F32_TOL)
+    m.close()
+
+
+def test_render_edge_cases(syn_mesh, syn_scene):
+    """object partly outside the image / crossing the near plane (frustum-clip path) / far away / 1 hypothesis"""
+    m = FoundationPose(syn_mesh, syn.intrinsics())
+    m.upload_frame(syn_scene.rgb, syn_scene.depth)
+    om = fo.OracleMesh(syn_mesh)
+    R = syn.random_rotation(11)
+    cases = [(0.45, 0.3, 0.7), (0.0, 0.0, 0.12), (0.0, 0.0, 0.05), (0.3, -0.2, 5.0), (-0.6, 0.0, 0.7)]
+    poses = np.stack([syn.pose_matrix(R, t) for t in cases])
+    for i in range(len(poses)):                      # also exercises N=1
+        p = poses[i:i + 1]
+        tri, _ = m.debug_rasterize(syn_mesh.name, p, 1.2)
+        a, b = m.render_and_transform(syn_mesh.name, p, 1.2)
+        ra, rtri, _ = fo.render(om, syn.to_colmajor(p), syn_scene.K, (480, 640), 1.2, debug=True)
+        rb = fo.crop(syn_scene.rgb, syn_scene.depth, syn_scene.K, syn.to_colmajor(p), 1.2, syn_mesh.diameter)
+        np.testing.assert_array_equal(tri, rtri)
+        np.testing.assert_allclose(a, ra, **F32_TOL)
+        np.testing.assert_allclose(b, rb, **F32_TOL)
+    m.close()
+
+
+def test_big_triangle_clip_path_bit_exact(syn_scene):
+    v = np.array([[-5, -5, 2.0], [5, -5, 2.0], [0, 5, -3.0], [0.3, 0.3, 0.1]], np.float32)
+    mesh = syn.Mesh("big", v, np.tile(np.array([[0, 0, -1]], np.float32), (4, 1)), np.zeros((4, 2), np.float32),
+                    np.array([[0, 1, 2], [0, 1, 3]], np.int32), np.full((2, 2, 3), 100, np.uint8), diameter=0.2,
+                    center=np.zeros(3, np.float32))
+    m = FoundationPose(mesh, syn.intrinsics())
+    m.upload_frame(syn_scene.rgb, syn_scene.depth)
+    pose = np.eye(4, dtype=np.float32)
+    pose[2, 3] = 1.0
+    tri, _ = m.debug_rasterize("big", pose[None], 1.2)
+    _, rtri, _ = fo.render(fo.OracleMesh(mesh), syn.to_colmajor(pose[None]), syn_scene.K, (480, 640), 1.2, debug=True)
+    assert (rtri > 0).sum() > 1000
+    np.testing.assert_array_equal(tri, rtri)
+    m.close()
+
+
+def test_image_sizes_and_errors(syn_mesh):
+    m = FoundationPose(syn_mesh, syn.intrinsics(1280, 720), max_input_image_height=720, max_input_image_width=1280)
+    sc = syn.make_scene(syn_mesh, 1280, 720)
+    m.upload_frame(sc.rgb, sc.depth)
+    poses = m.get_hyp_poses(sc.mask)
+    ref = syn.from_colmajor(fo.get_hyp_poses(sc.depth, sc.mask, sc.K))
+    np.testing.assert_allclose(poses[:, :3, 3], ref[:, :3, 3], rtol=1e-5)
+    a, b = m.render_and_transform(syn_mesh.name, poses[:8], 1.1)
+    om = fo.OracleMesh(syn_mesh)
+    np.testing.assert_allclose(a, fo.render(om, syn.to_colmajor(poses[:8]), sc.K, (720, 1280), 1.1), **F32_TOL)
+    np.testing.assert_allclose(b, fo.crop(sc.rgb, sc.depth, sc.K, syn.to_colmajor(poses[:8]), 1.1, syn_mesh.diameter), **F32_TOL)
+    # reference error behaviour: empty mask -> False (foundationpose_sampling.cpp:269), message kept
+    assert m.get_hyp_poses(np.zeros_like(sc.mask)) is None and "Mask is all zero" in m.last_error
+    # no valid depth under the mask (:278)
+    m.upload_frame(sc.rgb, np.zeros_like(sc.depth))
+    assert m.get_hyp_poses(sc.mask) is None and "No valid value" in m.last_error
+    # oversize frame (CheckInputArguments foundationpose.cpp:171-172)
+    big = np.zeros((1000, 1280), np.float32)
+    with pytest.raises(Exception, match="unexpected size"):
+        m.upload_frame(np.zeros((1000, 1280, 3), np.uint8), big)
+    m.close()
+
+
+def test_1008_hypothesis_grid(syn_mesh, syn_scene):
+    m = FoundationPose(syn_mesh, syn.intrinsics())
+    m.set_inplane_steps(24)
+    assert m.num_hypotheses == 1008
+    m.upload_frame(syn_scene.rgb, syn_scene.depth)
+    poses = m.get_hyp_poses(syn_scene.mask)
+    ref = syn.from_colmajor(fo.get_hyp_poses(syn_scene.depth, syn_scene.mask, syn_scene.K, inplane_step=15))
+    assert poses.shape == (1008, 4, 4)
+    np.testing.assert_allclose(poses[:, :3, :3], ref[:, :3, :3], atol=1e-6)
+    m.close()
+
+
+def test_pose_update_and_argmax(model, syn_mesh):
+    rng = np.random.default_rng(0)
+    poses = np.stack([syn.pose_matrix(syn.random_rotation(i), rng.normal(size=3)) for i in range(300)])
+    trans = rng.normal(size=(300, 3)).astype(np.float32)
+    rot = (rng.normal(size=(300, 3)) * 2).astype(np.float32)
+    rot[0] = 0
+    trans[0] = 0
+    out = model.refine_post_process(syn_mesh.name, poses, trans, rot)
+    ref = syn.from_colmajor(fo.refine_post_process(syn.to_colmajor(poses), trans, rot, syn_mesh.diameter))
+    np.testing.assert_allclose(out, ref, atol=1e-6)
+    np.testing.assert_array_equal(out[0], poses[0])
+    s = rng.normal(size=1008).astype(np.float32)
+    s[[17, 500, 900]] = s.max() + 1
+    assert model.argmax(s) == 17 == fo.argmax(s)
+    assert model.argmax(s[:1]) == 0
