@@ -1,0 +1,225 @@
+"""Parity of the MFMA networks against the PyTorch fp32 reference (oracle/nets_torch.py) with identical weights.
+
+Floating point: the HIP path stores activations/weights in fp16 and accumulates in fp32 (the reference's TensorRT
+engines are fp16 too, tools/cvt_onnx2trt.bash:3-15 `--fp16`).  Tolerances are written at each assert.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from foundationpose_cpp_amd import FoundationPose, _lib, synthetic as syn, weights as W
+from oracle import fp_oracle as fo
+from oracle import nets_torch as NT
+
+pytestmark = pytest.mark.gpu
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _h(a):  # fp16 round trip (what the device stores)
+    return np.asarray(a, np.float32).astype(np.float16).astype(np.float32)
+
+
+def _conv_hip(x, w_oihw, bias, stride, pad, relu, res=None, split=0):
+    L = _lib.lib()
+    NB, H, Wd, Cin = x.shape
+    Cout, _, KH, KW = w_oihw.shape
+    OH = (H + 2 * pad - KH) // stride + 1
+    OW = (Wd + 2 * pad - KW) // stride + 1
+    if KH == 4 and pad == 2 and stride == 1:      # the kernel's space-to-depth stem mode (pad 2 before, 1 after)
+        OH, OW = H, Wd
+    wk = np.ascontiguousarray(w_oihw.transpose(0, 2, 3, 1), np.float32)
+    out = np.zeros((NB, OH, OW, Cout) if split == 0 else (NB - split, OH, OW, 2 * Cout), np.float32)
+    x = np.ascontiguousarray(x, np.float32)
+    b = np.ascontiguousarray(bias, np.float32)
+    r = np.ascontiguousarray(res, np.float32) if res is not None else None
+    rc = L.fpt_conv(_p(x), _p(wk), _p(b), _p(r) if r is not None else None, NB, H, Wd, Cin, Cout, KH, KW, stride, pad,
+                    OH, OW, int(relu), split, _p(out), 1, None)
+    assert rc == 0, _lib.last_error()
+    return out
+
+
+def _conv_ref(x, w, bias, stride, pad, relu, res=None):
+    y = torch.nn.functional.conv2d(torch.from_numpy(_h(x)).permute(0, 3, 1, 2), torch.from_numpy(_h(w)),
+                                   torch.from_numpy(np.asarray(bias, np.float32)), stride, pad).permute(0, 2, 3, 1)
+    if res is not None:
+        y = y + torch.from_numpy(_h(res))
+    if relu:
+        y = torch.relu(y)
+    return y.numpy()
+
+
+@pytest.mark.parametrize("shape", [
+    # NB, H, W, Cin, Cout, k, stride, relu, use_res
+    (3, 40, 40, 128, 128, 3, 1, True, True),      # encodeA res block; M = 4800 (not a multiple of 128)
+    (2, 80, 80, 64, 128, 3, 2, True, False),      # encodeA.1 stride 2
+    (2, 40, 40, 256, 512, 3, 2, True, False),     # encodeAB.2
+    (1, 20, 20, 512, 512, 3, 1, False, True),     # encodeAB 512 block
+    (1, 400, 1, 512, 1536, 1, 1, False, False),   # QKV projection as 1x1 conv
+    (1, 7, 1, 512, 512, 1, 1, False, False),      # tiny M (cross attention over 7 hypotheses)
+    (2, 9, 11, 64, 64, 3, 1, True, False),        # BN=64 tile path, ragged image
+])
+def test_conv_igemm_matches_torch(shape):
+    NB, H, Wd, Cin, Cout, k, stride, relu, use_res = shape
+    rng = np.random.default_rng(1)
+    x = rng.normal(size=(NB, H, Wd, Cin)).astype(np.float32)
+    w = (rng.normal(size=(Cout, Cin, k, k)) / np.sqrt(Cin * k * k)).astype(np.float32)
+    b = rng.normal(size=Cout).astype(np.float32)
+    pad = (k - 1) // 2
+    OH = (H + 2 * pad - k) // stride + 1
+    OW = (Wd + 2 * pad - k) // stride + 1
+    res = rng.normal(size=(NB, OH, OW, Cout)).astype(np.float32) if use_res else None
+    got = _conv_hip(x, w, b, stride, pad, relu, res)
+    ref = _conv_ref(x, w, b, stride, pad, relu, res)
+    # fp32 accumulate of fp16 products, output rounded to fp16: |err| <= 2^-11 |y| + accumulation-order noise
+    np.testing.assert_allclose(got, ref, rtol=2e-3, atol=2e-3)
+
+
+def test_conv_transpose_detecting_and_split_store():
+    # asymmetric weights/inputs (a transposed fragment layout cannot pass) + the a|b channel-concat epilogue
+    NB, H, Cin, Cout = 4, 8, 128, 128
+    x = np.zeros((NB, H, H, Cin), np.float32)
+    x[..., :] = np.arange(Cin)[None, None, None, :] / Cin
+    x += np.arange(NB)[:, None, None, None] * 0.5 + np.arange(H)[None, :, None, None] * 0.01
+    w = np.zeros((Cout, Cin, 3, 3), np.float32)
+    for co in range(Cout):
+        w[co, (co * 7) % Cin, co % 3, (co // 3) % 3] = 1.0 + co / Cout
+    b = np.linspace(-1, 1, Cout).astype(np.float32)
+    got = _conv_hip(x, w, b, 1, 1, False, None, split=2)
+    ref = _conv_ref(x, w, b, 1, 1, False)
+    ref_cat = np.concatenate([ref[:2], ref[2:]], axis=-1)      # torch.cat((x[:bs], x[bs:]), 1)
+    np.testing.assert_allclose(got, ref_cat, rtol=2e-3, atol=2e-3)
+
+
+def test_stem_space_to_depth_equals_7x7_stride2():
+    # the 7x7/s2/p3 stem is evaluated as a 4x4/s1 conv over the space-to-depth input (fp_nn.hip make_stem)
+    rng = np.random.default_rng(2)
+    x = rng.uniform(-1, 1, size=(2, 160, 160, 6)).astype(np.float32)
+    w = (rng.normal(size=(64, 6, 7, 7)) / np.sqrt(6 * 49)).astype(np.float32)
+    b = rng.normal(size=64).astype(np.float32)
+    ref = _conv_ref(x, w, b, 2, 3, True)
+    x8 = np.concatenate([x, np.zeros((2, 160, 160, 2), np.float32)], -1)
+    s2d = x8.reshape(2, 80, 2, 80, 2, 8).transpose(0, 1, 3, 2, 4, 5).reshape(2, 80, 80, 32)
+    ws = np.zeros((64, 32, 4, 4), np.float32)
+    for a in range(4):
+        for bb in range(4):
+            for dy in range(2):
+                for dx in range(2):
+                    kh, kw = 2 * a + dy - 1, 2 * bb + dx - 1
+                    if kh >= 0 and kw >= 0:
+                        ws[:, (dy * 2 + dx) * 8:(dy * 2 + dx) * 8 + 6, a, bb] = w[:, :, kh, kw]
+    got = _conv_hip(s2d, ws, b, 1, 2, True)          # pad 2 + KH 4 + stride 1 -> the kernel's s2d stem mode (80x80 out)
+    np.testing.assert_allclose(got, ref, rtol=2e-3, atol=2e-3)
+
+
+@pytest.mark.parametrize("B,T", [(2, 400), (1, 252), (1, 7), (3, 33), (1, 1)])
+def test_attention_matches_torch(B, T):
+    rng = np.random.default_rng(3)
+    qkv = (rng.normal(size=(B, T, 1536)) * 1.5).astype(np.float32)
+    qkv[0, T // 2, :512] *= 4            # a spiked query row exercises the online-softmax rescale
+    out = np.zeros((B, T, 512), np.float32)
+    assert _lib.lib().fpt_attention(_p(qkv), B, T, _p(out)) == 0, _lib.last_error()
+    q, k, v = [torch.from_numpy(_h(qkv[..., i * 512:(i + 1) * 512])).reshape(B, T, 4, 128).permute(0, 2, 1, 3) for i in range(3)]
+    ref = torch.nn.functional.scaled_dot_product_attention(q, k, v).permute(0, 2, 1, 3).reshape(B, T, 512).numpy()
+    np.testing.assert_allclose(out, ref, rtol=5e-3, atol=5e-3)   # P is rounded to fp16 before the PV MFMA
+
+
+@pytest.fixture(scope="module")
+def nets(tmp_path_factory):
+    d = tmp_path_factory.mktemp("w")
+    rp, sp = str(d / "refiner.fpw"), str(d / "scorer.fpw")
+    rs = W.pack_synthetic("refiner", rp)
+    ss = W.pack_synthetic("scorer", sp)
+    return rp, sp, NT.build("refiner", rs), NT.build("scorer", ss)
+
+
+@pytest.fixture(scope="module")
+def model(nets, syn_mesh):
+    m = FoundationPose(syn_mesh, syn.intrinsics(), nets[0], nets[1])
+    yield m
+    m.close()
+
+
+def _blobs(model, syn_mesh, syn_scene, n, crop_ratio):
+    model.upload_frame(syn_scene.rgb, syn_scene.depth)
+    poses = model.get_hyp_poses(syn_scene.mask)[:n]
+    a, b = model.render_and_transform(syn_mesh.name, poses, crop_ratio)
+    return poses, a, b
+
+
+def test_refiner_matches_torch(model, nets, syn_mesh, syn_scene):
+    poses, a, b = _blobs(model, syn_mesh, syn_scene, 6, 1.2)
+    trans, rot = model.refiner_infer(a, b)
+    with torch.no_grad():
+        rt, rr = nets[2](torch.from_numpy(a), torch.from_numpy(b))
+    # 13 fp16 conv layers + transformer: relative error budget ~1e-2 of the output scale (|trans|,|rot| ~ 0.1)
+    np.testing.assert_allclose(trans, rt.numpy(), rtol=2e-2, atol=2e-3)
+    np.testing.assert_allclose(rot, rr.numpy(), rtol=2e-2, atol=2e-3)
+
+
+def test_scorer_matches_torch(model, nets, syn_mesh, syn_scene):
+    poses, a, b = _blobs(model, syn_mesh, syn_scene, 9, 1.1)
+    scores = model.scorer_infer(a, b)
+    with torch.no_grad():
+        ref = nets[3](torch.from_numpy(a), torch.from_numpy(b)).numpy()
+    np.testing.assert_allclose(scores, ref, rtol=2e-2, atol=3e-3)
+
+
+def _oracle_register(nets, mesh, scene, n_hyp):
+    """Register restated with the oracle geometry + torch networks (foundationpose.cpp:181-228)."""
+    om = fo.OracleMesh(mesh)
+    poses = fo.get_hyp_poses(scene.depth, scene.mask, scene.K)[:n_hyp]
+    a = fo.render(om, poses, scene.K, scene.depth.shape, 1.2)
+    b = fo.crop(scene.rgb, scene.depth, scene.K, poses, 1.2, mesh.diameter)
+    with torch.no_grad():
+        t, r = nets[2](torch.from_numpy(a), torch.from_numpy(b))
+    refined = fo.refine_post_process(poses, t.numpy(), r.numpy(), mesh.diameter)
+    a = fo.render(om, refined, scene.K, scene.depth.shape, 1.1)
+    b = fo.crop(scene.rgb, scene.depth, scene.K, refined, 1.1, mesh.diameter)
+    with torch.no_grad():
+        s = nets[3](torch.from_numpy(a), torch.from_numpy(b)).numpy()
+    return syn.from_colmajor(refined), s
+
+
+def _pose_err(a, b):
+    dR = a[:3, :3] @ b[:3, :3].T
+    ang = np.degrees(np.arccos(np.clip((np.trace(dR) - 1) / 2, -1, 1)))
+    return ang, np.linalg.norm(a[:3, 3] - b[:3, 3])
+
+
+def test_track_end_to_end(model, nets, syn_mesh, syn_scene):
+    hyp = syn.perturb_pose(syn_scene.gt_pose)
+    ok, pose = model.Track(syn_scene.rgb, syn_scene.depth, hyp, syn_mesh.name)
+    assert ok, model.last_error
+    om = fo.OracleMesh(syn_mesh)
+    p16 = syn.to_colmajor(hyp[None])
+    a = fo.render(om, p16, syn_scene.K, (480, 640), 1.2)
+    b = fo.crop(syn_scene.rgb, syn_scene.depth, syn_scene.K, p16, 1.2, syn_mesh.diameter)
+    with torch.no_grad():
+        t, r = nets[2](torch.from_numpy(a), torch.from_numpy(b))
+    ref = syn.from_colmajor(fo.refine_post_process(p16, t.numpy(), r.numpy(), syn_mesh.diameter))[0]
+    ang, dist = _pose_err(pose, ref)
+    assert ang < 0.1 and dist < 1e-4, (ang, dist)      # north_star bar is 1 deg / 1 mm; fp16 path lands far inside
+    # reference error behaviour: unknown target -> False
+    ok, _ = model.Track(syn_scene.rgb, syn_scene.depth, hyp, "nope")
+    assert not ok and "target_name" in model.last_error
+
+
+def test_register_end_to_end_252(model, nets, syn_mesh, syn_scene):
+    ok, pose = model.Register(syn_scene.rgb, syn_scene.depth, syn_scene.mask, syn_mesh.name)
+    assert ok, model.last_error
+    refined, scores = _oracle_register(nets, syn_mesh, syn_scene, 252)
+    # the returned pose must be one of the oracle's refined hypotheses (within fp16 noise) ...
+    errs = [_pose_err(pose, r) for r in refined]
+    idx = int(np.argmin([e[0] + 1e3 * e[1] for e in errs]))
+    assert errs[idx][0] < 0.1 and errs[idx][1] < 1e-4, errs[idx]
+    # ... and its oracle score must be the oracle's maximum up to the score tolerance (ties broken by fp16 noise)
+    assert scores[idx] >= scores.max() - 5e-3, (idx, scores[idx], scores.max(), int(scores.argmax()))
+    # mismatching sizes -> False like CheckInputArguments
+    ok, _ = model.Register(syn_scene.rgb, syn_scene.depth[:100], syn_scene.mask, syn_mesh.name)
+    assert not ok
