@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""bench.py -- pose-hypotheses/sec of the Register hot path on MI355X (BASELINE.json metric).
+
+A "step" is one Register over one batch of synthetic input (SURVEY.md §8d scene, 640x480, refine_itr = 1):
+sampler -> render+crop (ratio 1.2) -> refine-net -> pose update -> render+crop (ratio 1.1) -> score-net -> arg-max,
+with the frame (rgb, depth, mask) already resident in HBM when the timed region starts.
+
+  N = 1  : workload = BASELINE.json configs[2] "Register, N=252 hypotheses, 640x480, single MI355X, fp16".
+  N > 1  : one process per GPU (torch.distributed.run), WEAK scaling: every rank refines+scores 252 hypotheses of a
+           252*N grid (42 views x 6N in-plane steps), ONE RCCL all-gather of the pooled score features [252,512]
+           (+ poses), then every rank runs the cross-hypothesis attention + arg-max redundantly.
+           `--hyps 1008` selects BASELINE.json configs[3] (1008 hypotheses sharded over the ranks = strong scaling).
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline     -- dominant kernel (conv_igemm_kernel, MFMA-bound): algorithmic FLOPs of its launches in one step /
+                  their HIP-event durations on the library's stream, vs the 2.5 PFLOP/s dense fp16 MFMA peak.
+  cpu_baseline -- the oracle (C/OpenMP geometry + PyTorch-CPU fp32 networks), N = 8 Register, on the host cores.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP16_TFLOPS = 2500.0   # MI355X dense fp16/bf16 MFMA peak (MI355X_MICROARCH.md)
+BASELINE_HYP_S = 705.6      # reference README.md:37-41: Register 2.8 fps x 252 on RTX 4060 (TensorRT fp16)
+
+
+def cpu_baseline(mesh, scene, states, n_hyp=8, reps=1):
+    """Register (refine_itr=1) over n_hyp hypotheses with the CPU oracle; returns hypotheses/s."""
+    import torch
+    from oracle import fp_oracle as fo
+    from oracle import nets_torch as NT
+    refiner, scorer = NT.build("refiner", states[0]), NT.build("scorer", states[1])
+    om = fo.OracleMesh(mesh)
+    threads = fo.num_threads()
+    torch.set_num_threads(threads)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        poses = fo.get_hyp_poses(scene.depth, scene.mask, scene.K)[:n_hyp]
+        a = fo.render(om, poses, scene.K, scene.depth.shape, 1.2)
+        b = fo.crop(scene.rgb, scene.depth, scene.K, poses, 1.2, mesh.diameter)
+        with torch.no_grad():
+            t, r = refiner(torch.from_numpy(a), torch.from_numpy(b))
+        refined = fo.refine_post_process(poses, t.numpy(), r.numpy(), mesh.diameter)
+        a = fo.render(om, refined, scene.K, scene.depth.shape, 1.1)
+        b = fo.crop(scene.rgb, scene.depth, scene.K, refined, 1.1, mesh.diameter)
+        with torch.no_grad():
+            s = scorer(torch.from_numpy(a), torch.from_numpy(b)).numpy()
+        fo.argmax(s)
+    dt = time.perf_counter() - t0
+    return dict(value=round(n_hyp * reps / dt, 3), unit="hypotheses/s", cores=threads, kind="port",
+                sample=f"{reps} x Register N={n_hyp} 640x480 refine_itr=1 (oracle C/OpenMP geometry + PyTorch-CPU fp32 "
+                       f"networks, {dt:.1f} s); the reference has no CPU path for this (SURVEY.md §8d)")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--hyps", type=int, default=0, help="total hypotheses (default 252 per GPU, weak scaling)")
+    ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--height", type=int, default=480)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--track", action="store_true", help="measure Track fps (N=1 hypothesis) instead of Register")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from foundationpose_cpp_amd import FoundationPose, synthetic as syn, weights as W
+    from foundationpose_cpp_amd.distributed import HipShardBackend, sharded_register
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP library has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    mesh = syn.make_mesh()
+    scene = syn.make_scene(mesh, args.width, args.height)
+    with tempfile.TemporaryDirectory() as d:
+        rp, sp = os.path.join(d, f"r{rank}.fpw"), os.path.join(d, f"s{rank}.fpw")
+        states = (W.pack_synthetic("refiner", rp), W.pack_synthetic("scorer", sp))
+        model = FoundationPose(mesh, scene.K, rp, sp, max_input_image_height=max(1080, args.height),
+                               max_input_image_width=max(1920, args.width))
+
+    n_total = args.hyps if args.hyps > 0 else 252 * world
+    assert n_total % 42 == 0, "--hyps must be a multiple of 42 (icosphere views)"
+    model.set_inplane_steps(n_total // 42)
+    rgb = torch.from_numpy(scene.rgb).to(dev)
+    depth = torch.from_numpy(scene.depth).to(dev)
+    mask = torch.from_numpy(scene.mask).to(dev)
+    H, Wd = scene.depth.shape
+    backend = HipShardBackend(model, dev)
+    out_pose = np.zeros(16, np.float32)
+    hyp16 = syn.to_colmajor(syn.perturb_pose(scene.gt_pose))
+
+    def step():
+        if args.track:
+            model._must(model._L.fp_track_ex(model.handle, C.c_void_p(rgb.data_ptr()), C.c_void_p(depth.data_ptr()), 1,
+                                             H, Wd, hyp16.ctypes.data_as(C.c_void_p), mesh.name.encode(), 1,
+                                             out_pose.ctypes.data_as(C.c_void_p)))
+        elif world == 1:
+            model._must(model._L.fp_register_ex(model.handle, C.c_void_p(rgb.data_ptr()), C.c_void_p(depth.data_ptr()),
+                                                C.c_void_p(mask.data_ptr()), 1, H, Wd, mesh.name.encode(), 1,
+                                                out_pose.ctypes.data_as(C.c_void_p)))
+        else:
+            sharded_register(backend, dist, n_total, rgb, depth, mask, H, Wd, mesh.name, 1)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # per-kernel-family event timing of ONE extra step (outside the timed region)
+    model.profile(True)
+    model.profile_reset()
+    step()
+    prof = model.profile_report()
+    model.profile(False)
+
+    if rank == 0:
+        units = 1 if args.track else n_total
+        ms = dt / args.steps * 1e3
+        conv = {k: v for k, v in prof.items() if k.startswith("conv_") or k.startswith("gemm_")}
+        conv_flops = sum(v["flops"] for v in conv.values())
+        conv_ms = sum(v["ms"] for v in conv.values())
+        conv_calls = sum(v["calls"] for v in conv.values())
+        achieved = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+        stages = {k: round(v["ms"], 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}
+        res = {
+            "metric": "Track fps (N=1)" if args.track else "pose-hypotheses/sec (Register N=252, 640x480)",
+            "value": round(units * args.steps / dt, 2),
+            "unit": "frames/s" if args.track else "hypotheses/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
+            "higher_is_better": True,
+            "scaling": "weak" if args.hyps == 0 else "strong",
+            "vs_baseline": None if args.track else round(units * args.steps / dt / BASELINE_HYP_S, 3),
+            "dtype": "f16", "data": "synthetic",
+            "config": {
+                "workload": (f"Track N=1 {Wd}x{H}" if args.track else
+                             f"Register N={n_total} hypotheses ({n_total // world}/GPU) {Wd}x{H} refine_itr=1"),
+                "mesh": "synthetic ellipsoid V=2562 F=5120, 512x512 texture", "weights": "synthetic (seed 7)",
+                "parallelism": f"hyp-shard x{world}" if world > 1 else "single GPU",
+                "collective": "1 RCCL all-gather [n_local,528] f32 per Register" if world > 1 else "none",
+                "baseline": "reference README.md:37-41 Register 2.8 fps x 252 = 705.6 hyp/s on RTX 4060 (TensorRT fp16)",
+            },
+            "roofline": {
+                "bound": "mfma", "kernel": "conv_igemm_kernel (all conv + linear layers)",
+                "achieved": round(achieved, 1), "peak": PEAK_FP16_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(achieved / PEAK_FP16_TFLOPS, 4),
+                "launches_per_step": conv_calls, "algorithmic_gflop_per_step": round(conv_flops / 1e9, 1),
+                "avg_launch_ms": round(conv_ms / max(conv_calls, 1), 4), "traffic": None,
+            },
+            "stage_ms": stages,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            res["cpu_baseline"] = cpu_baseline(mesh, scene, states)
+        print(json.dumps(res))
+    model.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -412,6 +412,7 @@ struct ConvLayer {
   __half *w = nullptr;
   float *bias = nullptr;
   int Cin = 0, Cout = 0, KH = 0, KW = 0, stride = 1, pad = 0;
+  int algo_K = 0;  // algorithmic reduction length for FLOP accounting (the s2d stem pads 7x7x6=294 to 512)
 };
 struct LinearF32 {
   float *w = nullptr, *b = nullptr;
@@ -502,7 +503,7 @@ static bool make_stem(Net *net, const std::map<std::string, HostTensor> &m, cons
           }
   L->w = upload(net, hw);
   L->bias = upload(net, b->data);
-  L->Cin = 32; L->Cout = 64; L->KH = 4; L->KW = 4; L->stride = 1; L->pad = 2;
+  L->Cin = 32; L->Cout = 64; L->KH = 4; L->KW = 4; L->stride = 1; L->pad = 2; L->algo_K = 7 * 7 * 6;
   return L->w && L->bias;
 }
 
@@ -682,7 +683,7 @@ static int run_conv(const Ctx &c, const char *tag, const ConvLayer &L, const __h
   p.out_ld = split_imgs > 0 ? 2 * L.Cout : L.Cout;
   p.res_ld = L.Cout;
   FP_CHECK((1 << p.cin_log2) == L.Cin && p.Ktot % 64 == 0 && (L.Cout % 64) == 0, "conv shape not supported by the MFMA kernel");
-  double flops = 2.0 * (double)p.M * p.Cout * p.Ktot;
+  double flops = 2.0 * (double)p.M * p.Cout * (L.algo_K > 0 ? L.algo_K : p.Ktot);
   double bytes = ((double)NB * H * W * L.Cin + (double)p.M * p.Cout * (res ? 2 : 1) + (double)p.Cout * p.Ktot) * 2.0;
   if (!g_conv_attr_done) {
     FP_HIP_OK(hipFuncSetAttribute((const void *)conv_igemm_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (128 * 128 + 128 * 128)));
