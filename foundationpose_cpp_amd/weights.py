@@ -145,3 +145,14 @@ def pack_synthetic(kind: str, path: str, seed: int = 7) -> dict:
     st = make_synthetic_state(kind, seed)
     write_fpw(path, fold_batchnorm(st))
     return st
+
+
+if __name__ == "__main__":
+    import argparse
+    ap = argparse.ArgumentParser(description="pack refine-net / score-net weights into the FPW1 container")
+    ap.add_argument("--synthetic", nargs=2, metavar=("KIND", "OUT"), help="KIND = refiner|scorer")
+    ap.add_argument("--seed", type=int, default=7)
+    a = ap.parse_args()
+    if a.synthetic:
+        pack_synthetic(a.synthetic[0], a.synthetic[1], a.seed)
+        print("wrote", a.synthetic[1])

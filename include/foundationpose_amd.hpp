@@ -1,0 +1,91 @@
+// foundationpose_amd.hpp -- dependency-free C++17 RAII wrapper over the C ABI (foundationpose_amd.h).
+// Mirrors detection_6d::Base6DofDetectionModel (reference detection_6d_foundationpose/include/
+// detection_6d_foundationpose/foundationpose.hpp:16-77) with plain structs instead of cv::Mat / Eigen types, so it
+// builds where OpenCV and Eigen do not exist (the MI355X image).  detection_6d_foundationpose_amd.hpp layers the
+// reference's exact signatures on top when those headers are present.
+#pragma once
+
+#include <array>
+#include <cstdint>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "foundationpose_amd.h"
+
+namespace fp_amd {
+
+using Pose = std::array<float, 16>;  // column-major 4x4 (Eigen::Matrix4f::data())
+
+struct ImageU8 { const uint8_t *data; int rows, cols, channels; };
+struct ImageF32 { const float *data; int rows, cols; };
+
+struct Mesh {  // what BaseMeshLoader's getters return (mesh_loader.hpp:25-61)
+  std::string name;
+  std::vector<float> vertices, normals, texcoords;  // [V,3], [V,3], [V,2]
+  std::vector<uint32_t> faces;                      // [F,3]
+  std::vector<uint8_t> texture;                     // [TH,TW,3] RGB
+  int tex_height = 0, tex_width = 0;
+  float diameter = 0;
+  float center[3] = {0, 0, 0};
+};
+
+class FoundationPose {
+public:
+  // CreateFoundationPoseModel (foundationpose.hpp:99-105); throws std::runtime_error like the reference constructor
+  FoundationPose(const std::vector<Mesh> &meshes, const float K[9], const std::string &refiner_weights,
+                 const std::string &scorer_weights, int max_h = 1080, int max_w = 1920) {
+    std::vector<fp_mesh> cm(meshes.size());
+    for (size_t i = 0; i < meshes.size(); i++) {
+      const Mesh &m = meshes[i];
+      cm[i].name = m.name.c_str();
+      cm[i].num_vertices = (int)(m.vertices.size() / 3);
+      cm[i].num_faces = (int)(m.faces.size() / 3);
+      cm[i].vertices = m.vertices.data(); cm[i].normals = m.normals.data(); cm[i].texcoords = m.texcoords.data();
+      cm[i].faces = m.faces.data(); cm[i].texture = m.texture.data();
+      cm[i].tex_height = m.tex_height; cm[i].tex_width = m.tex_width;
+      cm[i].diameter = m.diameter;
+      for (int k = 0; k < 3; k++) cm[i].center[k] = m.center[k];
+    }
+    h_ = fp_create(cm.data(), (int)cm.size(), K, refiner_weights.empty() ? nullptr : refiner_weights.c_str(),
+                   scorer_weights.empty() ? nullptr : scorer_weights.c_str(), max_h, max_w);
+    if (!h_) throw std::runtime_error(std::string("[FoundationPose] Failed to Construct FoundationPose, ex : ") + fp_last_error());
+  }
+  ~FoundationPose() { fp_destroy(h_); }
+  FoundationPose(const FoundationPose &) = delete;
+  FoundationPose &operator=(const FoundationPose &) = delete;
+
+  // Register (foundationpose.hpp:36-41): false on failure, message in last_error()
+  bool Register(const ImageU8 &rgb, const ImageF32 &depth, const ImageU8 &mask, const std::string &target_name,
+                Pose &out_pose_in_mesh, size_t refine_itr = 1) {
+    if (rgb.rows != depth.rows || rgb.cols != depth.cols || mask.rows != depth.rows || mask.cols != depth.cols) {
+      err_ = "[FoundationPose] Got rgb/depth/mask with different size!";
+      return false;
+    }
+    return ok(fp_register(h_, rgb.data, depth.data, mask.data, depth.rows, depth.cols, target_name.c_str(),
+                          (int)refine_itr, out_pose_in_mesh.data()));
+  }
+  // Track (foundationpose.hpp:59-64)
+  bool Track(const ImageU8 &rgb, const ImageF32 &depth, const Pose &hyp_pose_in_mesh, const std::string &target_name,
+             Pose &out_pose_in_mesh, size_t refine_itr = 1) {
+    if (rgb.rows != depth.rows || rgb.cols != depth.cols) {
+      err_ = "[FoundationPose] Got rgb/depth/mask with different size!";
+      return false;
+    }
+    return ok(fp_track(h_, rgb.data, depth.data, depth.rows, depth.cols, hyp_pose_in_mesh.data(), target_name.c_str(),
+                       (int)refine_itr, out_pose_in_mesh.data()));
+  }
+  const std::string &last_error() const { return err_; }
+  fp_model *handle() { return h_; }
+
+private:
+  bool ok(int rc) {
+    err_ = rc ? fp_last_error() : "";
+    return rc == 0;
+  }
+  fp_model *h_ = nullptr;
+  std::string err_;
+};
+
+}  // namespace fp_amd
