@@ -235,7 +235,7 @@ struct fp_model {
   PoseRec *recs = nullptr;
   float *poses_dev = nullptr;
   float4 *clip = nullptr, *attr = nullptr;
-  __half *nn_in = nullptr;                  // [2*cap,80,80,32]
+  __half *nn_in = nullptr;                  // [2*cap,84,84,32] (s2d, zero border 2)
   float *blob_a = nullptr, *blob_b = nullptr;  // [cap,160,160,6] f32 (blob-mode entry points only)
   float *trans_dev = nullptr, *rot_dev = nullptr, *scores_dev = nullptr, *feat_dev = nullptr;
   int *argmax_dev = nullptr;
@@ -262,7 +262,9 @@ static int ensure_capacity(fp_model *m, int N, size_t V) {
     int cap = std::max(N, 8);
     if (dev_alloc(&m->recs, cap)) return 1;
     if (dev_alloc(&m->poses_dev, (size_t)cap * 16)) return 1;
-    if (dev_alloc(&m->nn_in, (size_t)2 * cap * FP_CROP_HW * FP_CROP_HW * 8)) return 1;
+    if (dev_alloc(&m->nn_in, (size_t)2 * cap * FP_NN_IN_IMG_HALFS)) return 1;
+    // zero borders are written once here; the raster / crop kernels only ever store image interiors
+    FP_HIP_OK(hipMemsetAsync(m->nn_in, 0, (size_t)2 * cap * FP_NN_IN_IMG_HALFS * sizeof(__half), m->stream));
     if (dev_alloc(&m->trans_dev, (size_t)cap * 3)) return 1;
     if (dev_alloc(&m->rot_dev, (size_t)cap * 3)) return 1;
     if (dev_alloc(&m->scores_dev, (size_t)cap)) return 1;
@@ -577,7 +579,7 @@ static int pack_blobs(fp_model *m, const float *render_input, const float *trans
     a = m->blob_a; b = m->blob_b;
   }
   launch_pack_f32x6_to_f16x8(m->stream, a, m->nn_in, px);
-  launch_pack_f32x6_to_f16x8(m->stream, b, m->nn_in + px * 8, px);
+  launch_pack_f32x6_to_f16x8(m->stream, b, m->nn_in + (size_t)N * FP_NN_IN_IMG_HALFS, px);
   return 0;
 }
 
@@ -630,7 +632,7 @@ int fp_argmax(fp_model *m, const float *scores, int N, int *index_out) {
 
 // one refine iteration over m->poses_dev[0..N): RefinePreProcess + SyncInfer + RefinePostProcess, all on device
 static int refine_iteration(fp_model *m, Target *t, int N) {
-  const size_t half = (size_t)N * FP_CROP_HW * FP_CROP_HW * 8;
+  const size_t half = (size_t)N * FP_NN_IN_IMG_HALFS;
   if (render_and_crop(m, t, N, 1.2f /* refine_mode_crop_ratio_ foundationpose.cpp:87 */, OUT_F16X8, m->nn_in,
                       m->nn_in + half, nullptr, nullptr))
     return 1;
@@ -660,7 +662,7 @@ int fp_register_shard_begin(fp_model *m, const void *rgb, const void *depth, con
   if (upload_poses(m, t, poses.data() + (size_t)shard_begin * 16, N)) return 1;
   for (int it = 0; it < refine_itr; it++)
     if (refine_iteration(m, t, N)) return 1;
-  const size_t half = (size_t)N * FP_CROP_HW * FP_CROP_HW * 8;
+  const size_t half = (size_t)N * FP_NN_IN_IMG_HALFS;
   if (render_and_crop(m, t, N, 1.1f /* score_mode_crop_ratio_ foundationpose.cpp:88 */, OUT_F16X8, m->nn_in,
                       m->nn_in + half, nullptr, nullptr))
     return 1;

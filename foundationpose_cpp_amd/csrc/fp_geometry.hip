@@ -38,11 +38,14 @@ struct K9 { float k[9]; };
 
 __device__ __forceinline__ float clampf(float f, float a, float b) { return fmaxf(a, fminf(f, b)); }
 
-// fp16 network-input layout: space-to-depth(2x2) of NHWC [N,160,160,8] -> [N,80,80,32]; in 16-byte units the
-// pixel (n,y,x) lands at ((n*80 + y/2)*80 + x/2)*4 + (y&1)*2 + (x&1).  This turns the 7x7 stride-2 stem
-// convolution into a 4x4 stride-1 convolution with Cin = 32 that the generic MFMA implicit-GEMM kernel handles.
+// fp16 network-input layout: space-to-depth(2x2) of NHWC [N,160,160,8] -> [N,80,80,32], stored with a physical zero
+// border of FP_NN_IN_BORDER s2d-pixels ([N,84,84,32]); in 16-byte units the pixel (n,y,x) lands at
+// ((n*84 + y/2 + 2)*84 + x/2 + 2)*4 + (y&1)*2 + (x&1).  This turns the 7x7 stride-2 stem convolution into a 4x4
+// stride-1 convolution with Cin = 32 that the generic MFMA implicit-GEMM kernel runs without bounds checks.
 __device__ __forceinline__ size_t s2d_index(size_t n, int y, int x) {
-  return ((n * (CROP / 2) + (size_t)(y >> 1)) * (CROP / 2) + (size_t)(x >> 1)) * 4 + (size_t)((y & 1) * 2 + (x & 1));
+  constexpr int P = CROP / 2 + 2 * FP_NN_IN_BORDER;
+  return ((n * P + (size_t)((y >> 1) + FP_NN_IN_BORDER)) * P + (size_t)((x >> 1) + FP_NN_IN_BORDER)) * 4 +
+         (size_t)((y & 1) * 2 + (x & 1));
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -9,6 +9,9 @@
 #include <vector>
 
 #define FP_CROP_HW 160
+#define FP_NN_IN_BORDER 2  // zero border (in space-to-depth pixels) around each network-input image
+// halfs per network-input image: [84,84,32]
+#define FP_NN_IN_IMG_HALFS ((size_t)(FP_CROP_HW / 2 + 2 * FP_NN_IN_BORDER) * (FP_CROP_HW / 2 + 2 * FP_NN_IN_BORDER) * 32)
 #define FP_MIN_DEPTH 0.001f  // FoundationPoseRenderer min_depth (foundationpose_render.hpp:26)
 #define FP_MAX_DEPTH 4.0f    // FoundationPoseRenderer max_depth (foundationpose_render.hpp:27)
 

@@ -44,17 +44,36 @@ static constexpr int EMBED = 512, HEADS = 4, HDIM = 128;
 // implicit-GEMM convolution
 // =================================================================================================
 
+// LDS-DMA issued from inline asm: hipcc neither counts these loads nor inserts its conservative `s_waitcnt vmcnt(0)`
+// in front of a new LDS-DMA while an older one is in flight (it cannot tell the LDS stages apart), so the counted
+// waits in conv_igemm3_kernel are authoritative.  M0 (LDS destination base) is saved and restored inside the statement
+// (cdna_hip_programming.md §5.7).  lds_addr must be wave-uniform; the 16 bytes land at lds_addr + lane*16.
+__device__ __forceinline__ void glds16_asm(const void *gsrc, unsigned lds_addr) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(lds_addr)
+               : "memory");
+}
+
 struct ConvParams {
-  const __half *in;     // [NB,H,W,Cin]
-  const __half *w;      // [Cout][KH*KW*Cin]
+  const __half *in;     // [NB, H+2*ipad, W+2*ipad, Cin]  (zero border of width ipad >= pad is physically present)
+  const __half *w;      // [Cout][K] in kernel K order (relayout_k)
   const float *bias;    // [Cout]
-  const __half *res;    // optional residual, same indexing as out (ld = res_ld)
-  __half *out;
-  const __half *zeros;  // >= 16 B of zeros: source for padded taps / rows beyond M
-  int NB, H, W, Cin, cin_log2, OH, OW, Cout, KH, KW, stride, pad;
+  const __half *res;    // optional residual [NB, OH+2*rpad, OW+2*rpad, res_ld]
+  __half *out;          // [NB', OH+2*opad, OW+2*opad, out_ld]
+  int NB, H, W, Cin, OH, OW, Cout, KH, KW, stride, pad;
+  int ipad, opad, rpad;
   int M, Ktot, relu, out_ld, res_ld, split_imgs;
+  int ntaps;  // KH*KW; for Cin >= 64 the K order is (64-channel chunk outer, tap inner) so the taps of a chunk
+              // are consecutive K-steps and their overlapping input pixels are re-read while still L2-resident
+  // byte offset of K-step kt's X slab relative to a row's (tap 0, channel 0) address; host-filled, read with s_load
+  unsigned koff[80];
 };
 
+// Activations carry a physical zero border, so the K loop has no bounds checks, no selects and no divergent
+// branches: a tap's operand address is (wave-uniform tap/chunk offset in SGPRs) + (per-lane row offset fixed for the
+// whole kernel), which is exactly the saddr + voffset form of global_load_lds.
 template <int BN>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -62,62 +81,62 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
   constexpr int XB = BM * 128;  // bytes per X stage (128 rows x 64 halfs)
   constexpr int WB = BN * 128;
   constexpr int STAGE = XB + WB;
-  constexpr int NREP = BN / 32;  // 16-channel tiles per wave (wave tile = 64 pixels x BN/2 channels)
+  constexpr int NREP = BN / 32;     // 16-channel tiles per wave (wave tile = 64 pixels x BN/2 channels)
   constexpr int WPIECES = BN / 32;  // 8-row pieces of the W tile per wave
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave & 1, wn = wave >> 1;
   const int n_tiles = p.Cout / BN;
-  const int mt = blockIdx.x / n_tiles, nt = blockIdx.x - mt * n_tiles;
+  // XCD-aware tile order: hardware places workgroup b on XCD b%8 (speed-only assumption).  Remap so each XCD walks a
+  // contiguous range of logical tiles: the n-tiles of one m-tile (same X rows) and neighbouring m-tiles (shared halo
+  // rows) hit the same private L2.  Bijective for any grid size.
+  int logical;
+  {
+    const int nblk = gridDim.x, b = blockIdx.x;
+    const int xcd = b & 7, within = b >> 3, q = nblk >> 3, r = nblk & 7;
+    logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
+  }
+  const int mt = logical / n_tiles, nt = logical - mt * n_tiles;
   const int m0 = mt * BM, n0 = nt * BN;
+  const int ohw = p.OH * p.OW;
+  const int IHp = p.H + 2 * p.ipad, IWp = p.W + 2 * p.ipad;
 
   // ---- staging roles: piece = 8 rows x 128 B; lane -> row (lane>>3), slot (lane&7); source chunk is swizzled
   const int srow = lane >> 3;
   const int g = (lane & 7) ^ srow;  // source 16-B chunk within the 64-wide K step
-  int xbase[4], ihw0[4];
-  bool xvalid[4];
-  const int ohw = p.OH * p.OW;
+  unsigned xoff[4];                 // byte offset of (row's input pixel at tap (0,0), chunk 0) + g*16
 #pragma unroll
   for (int i = 0; i < 4; i++) {
-    int row = (wave * 4 + i) * 8 + srow;
-    int m = m0 + row;
-    xvalid[i] = m < p.M;
-    int mm = xvalid[i] ? m : 0;
-    int img = mm / ohw;
-    int rem = mm - img * ohw;
+    int m = min(m0 + (wave * 4 + i) * 8 + srow, p.M - 1);  // rows past M re-read the last pixel (never stored)
+    int img = m / ohw;
+    int rem = m - img * ohw;
     int oh = rem / p.OW, ow = rem - oh * p.OW;
-    int ih0 = oh * p.stride - p.pad, iw0 = ow * p.stride - p.pad;
-    xbase[i] = ((img * p.H + ih0) * p.W + iw0) * p.Cin;
-    ihw0[i] = (ih0 << 16) | (iw0 & 0xFFFF);
+    int ih0 = oh * p.stride - p.pad + p.ipad, iw0 = ow * p.stride - p.pad + p.ipad;
+    xoff[i] = (unsigned)(((img * IHp + ih0) * IWp + iw0) * p.Cin + g * 8) * 2u;
   }
-  const __half *wsrc[WPIECES];
+  unsigned woffv[WPIECES];
 #pragma unroll
   for (int i = 0; i < WPIECES; i++) {
     int row = (wave * WPIECES + i) * 8 + srow;
-    wsrc[i] = p.w + (size_t)(n0 + row) * p.Ktot + g * 8;
+    woffv[i] = (unsigned)((n0 + row) * p.Ktot + g * 8) * 2u;
   }
+  const unsigned char *in_b = reinterpret_cast<const unsigned char *>(p.in);
+  const unsigned char *w_b = reinterpret_cast<const unsigned char *>(p.w);
 
   auto stage = [&](int kt, int buf) {
     unsigned char *xs = smem + buf * STAGE;
     unsigned char *ws = xs + XB;
-    int k = kt * 64 + g * 8;
-    int tap = k >> p.cin_log2;
-    int c = k & (p.Cin - 1);
-    int kh = tap / p.KW, kw = tap - kh * p.KW;
-    int koff = (kh * p.W + kw) * p.Cin + c;
+    const unsigned char *xb = in_b + p.koff[kt];
+    const unsigned char *wb = w_b + (size_t)kt * 128;
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-      int ih = (ihw0[i] >> 16) + kh, iw = (int)(short)(ihw0[i] & 0xFFFF) + kw;
-      bool ok = xvalid[i] && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
-      const __half *src = ok ? (p.in + (xbase[i] + koff)) : p.zeros;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+    for (int i = 0; i < 4; i++)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(xb + xoff[i]),
                                        (__attribute__((address_space(3))) void *)(xs + (wave * 4 + i) * 1024), 16, 0, 0);
-    }
 #pragma unroll
-    for (int i = 0; i < WPIECES; i++) {
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(wsrc[i] + kt * 64),
+    for (int i = 0; i < WPIECES; i++)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(wb + woffv[i]),
                                        (__attribute__((address_space(3))) void *)(ws + (wave * WPIECES + i) * 1024), 16, 0, 0);
-    }
   };
 
   f4 acc[NREP][4];
@@ -128,55 +147,212 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
 
   // fragment read offsets (bytes) inside a stage; slot = chunk ^ (row&7), row&7 == lane&7
   const int frow = lane & 15, fk = lane >> 4;
-  int xoff[2], woff[2];
+  int xfo[2], wfo[2];
 #pragma unroll
   for (int ks = 0; ks < 2; ks++) {
     int slot = (ks * 4 + fk) ^ (lane & 7);
-    xoff[ks] = (wm * 64 + frow) * 128 + slot * 16;
-    woff[ks] = XB + (wn * (BN / 2) + frow) * 128 + slot * 16;
+    xfo[ks] = (wm * 64 + frow) * 128 + slot * 16;
+    wfo[ks] = XB + (wn * (BN / 2) + frow) * 128 + slot * 16;
   }
 
-  const int KT = p.Ktot >> 6;
-  stage(0, 0);
-  __syncthreads();
-  for (int kt = 0; kt < KT; kt++) {
-    const int buf = kt & 1;
-    if (kt + 1 < KT) stage(kt + 1, buf ^ 1);
+  auto compute = [&](int buf) {
     const unsigned char *sb = smem + buf * STAGE;
 #pragma unroll
     for (int ks = 0; ks < 2; ks++) {
       h8 xf[4], wf[NREP];
 #pragma unroll
-      for (int mi = 0; mi < 4; mi++) xf[mi] = *reinterpret_cast<const h8 *>(sb + xoff[ks] + mi * 16 * 128);
+      for (int mi = 0; mi < 4; mi++) xf[mi] = *reinterpret_cast<const h8 *>(sb + xfo[ks] + mi * 16 * 128);
 #pragma unroll
-      for (int ni = 0; ni < NREP; ni++) wf[ni] = *reinterpret_cast<const h8 *>(sb + woff[ks] + ni * 16 * 128);
+      for (int ni = 0; ni < NREP; ni++) wf[ni] = *reinterpret_cast<const h8 *>(sb + wfo[ks] + ni * 16 * 128);
 #pragma unroll
       for (int ni = 0; ni < NREP; ni++)
 #pragma unroll
         for (int mi = 0; mi < 4; mi++)
           acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ni], xf[mi], acc[ni][mi], 0, 0, 0);
     }
+  };
+
+  const int KT = p.Ktot >> 6;
+  stage(0, 0);
+  __syncthreads();
+  // steady state is branch-free (stage next tile, compute current tile, one barrier); the last tile is peeled
+  for (int kt = 0; kt < KT - 1; kt++) {
+    stage(kt + 1, (kt + 1) & 1);
+    compute(kt & 1);
     __syncthreads();
   }
+  compute((KT - 1) & 1);
 
   // ---- epilogue: lane owns channels cb..cb+3 (cb = 4*(lane>>4)) of pixel (lane&15) in each 16x16 tile
+  const int OHp = p.OH + 2 * p.opad, OWp = p.OW + 2 * p.opad;
+  const int RHp = p.OH + 2 * p.rpad, RWp = p.OW + 2 * p.rpad;
 #pragma unroll
   for (int mi = 0; mi < 4; mi++) {
     int m = m0 + wm * 64 + mi * 16 + (lane & 15);
     if (m >= p.M) continue;
-    size_t opix = (size_t)m;
-    int choff = 0;
-    if (p.split_imgs > 0) {
-      int img = m / ohw;
-      if (img >= p.split_imgs) { opix = (size_t)m - (size_t)p.split_imgs * ohw; choff = p.Cout; }
-    }
+    int img = m / ohw;
+    int rem = m - img * ohw;
+    int oh = rem / p.OW, ow = rem - oh * p.OW;
+    int choff = 0, oimg = img;
+    if (p.split_imgs > 0 && img >= p.split_imgs) { oimg = img - p.split_imgs; choff = p.Cout; }
+    size_t opix = ((size_t)oimg * OHp + oh + p.opad) * OWp + ow + p.opad;
+    size_t rpix = ((size_t)img * RHp + oh + p.rpad) * RWp + ow + p.rpad;
 #pragma unroll
     for (int ni = 0; ni < NREP; ni++) {
       int n = n0 + wn * (BN / 2) + ni * 16 + (lane >> 4) * 4;
       float4 bv = *reinterpret_cast<const float4 *>(p.bias + n);
       float v0 = acc[ni][mi][0] + bv.x, v1 = acc[ni][mi][1] + bv.y, v2 = acc[ni][mi][2] + bv.z, v3 = acc[ni][mi][3] + bv.w;
       if (p.res) {
-        h4 r = *reinterpret_cast<const h4 *>(p.res + (size_t)m * p.res_ld + n);
+        h4 r = *reinterpret_cast<const h4 *>(p.res + rpix * p.res_ld + n);
+        v0 += (float)r[0]; v1 += (float)r[1]; v2 += (float)r[2]; v3 += (float)r[3];
+      }
+      if (p.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+      h4 o = {(_Float16)v0, (_Float16)v1, (_Float16)v2, (_Float16)v3};
+      *reinterpret_cast<h4 *>(p.out + opix * p.out_ld + choff + n) = o;
+    }
+  }
+}
+
+// -------------------------------------------------------------------------------------------------
+// Large-problem variant: 256 pixels x BN channels per workgroup, 8 waves (4 along pixels x 2 along channels, the
+// same 64 x BN/2 wave tile as above), THREE LDS stages and a prefetch distance of two K-steps.  The LDS-DMA loads are
+// kept in flight across the barrier: per K-step each wave issues G = 4 + BN/64 global_load_lds, so
+// `s_waitcnt vmcnt(G)` before the (raw) barrier retires exactly the tile about to be consumed and leaves the next
+// tile's loads outstanding (cdna_hip_programming.md "Pipelining across barriers").  One barrier per K-step orders
+// both hazards: RAW (every wave waited for its own pieces of tile kt) and WAR (every wave finished reading tile
+// kt-1 before anyone overwrites its buffer with tile kt+2).
+// -------------------------------------------------------------------------------------------------
+template <int BN>
+__global__ __launch_bounds__(512, 2) void conv_igemm3_kernel(const ConvParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int BM = 256;
+  constexpr int XB = BM * 128;
+  constexpr int WB = BN * 128;
+  constexpr int STAGE = XB + WB;
+  constexpr int NREP = BN / 32;
+  constexpr int WPIECES = BN / 64;  // 8-row pieces of the W tile per wave (8 waves)
+  constexpr int G = 4 + WPIECES;    // LDS-DMA instructions per wave per K-step
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave & 3, wn = wave >> 2;
+  const int n_tiles = p.Cout / BN;
+  int logical;
+  {
+    const int nblk = gridDim.x, b = blockIdx.x;
+    const int xcd = b & 7, within = b >> 3, q = nblk >> 3, r = nblk & 7;
+    logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
+  }
+  const int mt = logical / n_tiles, nt = logical - mt * n_tiles;
+  const int m0 = mt * BM, n0 = nt * BN;
+  const int ohw = p.OH * p.OW;
+  const int IHp = p.H + 2 * p.ipad, IWp = p.W + 2 * p.ipad;
+
+  const int srow = lane >> 3;
+  const int g = (lane & 7) ^ srow;
+  unsigned xoff[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    int m = min(m0 + (wave * 4 + i) * 8 + srow, p.M - 1);
+    int img = m / ohw;
+    int rem = m - img * ohw;
+    int oh = rem / p.OW, ow = rem - oh * p.OW;
+    int ih0 = oh * p.stride - p.pad + p.ipad, iw0 = ow * p.stride - p.pad + p.ipad;
+    xoff[i] = (unsigned)(((img * IHp + ih0) * IWp + iw0) * p.Cin + g * 8) * 2u;
+  }
+  unsigned woffv[WPIECES];
+#pragma unroll
+  for (int i = 0; i < WPIECES; i++) {
+    int row = (wave * WPIECES + i) * 8 + srow;
+    woffv[i] = (unsigned)((n0 + row) * p.Ktot + g * 8) * 2u;
+  }
+  const unsigned char *in_b = reinterpret_cast<const unsigned char *>(p.in);
+  const unsigned char *w_b = reinterpret_cast<const unsigned char *>(p.w);
+  const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
+
+  auto stage = [&](int kt, int buf) {
+    const unsigned xs = lds_base + buf * STAGE;
+    const unsigned ws = xs + XB;
+    const unsigned char *xb = in_b + p.koff[kt];
+    const unsigned char *wb = w_b + (size_t)kt * 128;
+#pragma unroll
+    for (int i = 0; i < 4; i++) glds16_asm(xb + xoff[i], xs + (wave * 4 + i) * 1024);
+#pragma unroll
+    for (int i = 0; i < WPIECES; i++) glds16_asm(wb + woffv[i], ws + (wave * WPIECES + i) * 1024);
+  };
+
+  f4 acc[NREP][4];
+#pragma unroll
+  for (int a = 0; a < NREP; a++)
+#pragma unroll
+    for (int b = 0; b < 4; b++) acc[a][b] = (f4){0.f, 0.f, 0.f, 0.f};
+
+  const int frow = lane & 15, fk = lane >> 4;
+  int xfo[2], wfo[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ks++) {
+    int slot = (ks * 4 + fk) ^ (lane & 7);
+    xfo[ks] = (wm * 64 + frow) * 128 + slot * 16;
+    wfo[ks] = XB + (wn * (BN / 2) + frow) * 128 + slot * 16;
+  }
+
+  auto compute = [&](int buf) {
+    const unsigned char *sb = smem + buf * STAGE;
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++) {
+      h8 xf[4], wf[NREP];
+#pragma unroll
+      for (int mi = 0; mi < 4; mi++) xf[mi] = *reinterpret_cast<const h8 *>(sb + xfo[ks] + mi * 16 * 128);
+#pragma unroll
+      for (int ni = 0; ni < NREP; ni++) wf[ni] = *reinterpret_cast<const h8 *>(sb + wfo[ks] + ni * 16 * 128);
+#pragma unroll
+      for (int ni = 0; ni < NREP; ni++)
+#pragma unroll
+        for (int mi = 0; mi < 4; mi++)
+          acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ni], xf[mi], acc[ni][mi], 0, 0, 0);
+    }
+  };
+
+  const int KT = p.Ktot >> 6;  // >= 8 for every layer of the networks
+  stage(0, 0);
+  stage(1, 1);
+  int rb = 0, wb3 = 2;  // stage being read / written
+  for (int kt = 0; kt < KT - 2; kt++) {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");  // tile kt landed (this wave's pieces); tile kt+1 in flight
+    __builtin_amdgcn_s_barrier();
+    stage(kt + 2, wb3);
+    compute(rb);
+    rb = (rb == 2) ? 0 : rb + 1;
+    wb3 = (wb3 == 2) ? 0 : wb3 + 1;
+  }
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");
+  __builtin_amdgcn_s_barrier();
+  compute(rb);
+  rb = (rb == 2) ? 0 : rb + 1;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  compute(rb);
+
+  const int OHp = p.OH + 2 * p.opad, OWp = p.OW + 2 * p.opad;
+  const int RHp = p.OH + 2 * p.rpad, RWp = p.OW + 2 * p.rpad;
+#pragma unroll
+  for (int mi = 0; mi < 4; mi++) {
+    int m = m0 + wm * 64 + mi * 16 + (lane & 15);
+    if (m >= p.M) continue;
+    int img = m / ohw;
+    int rem = m - img * ohw;
+    int oh = rem / p.OW, ow = rem - oh * p.OW;
+    int choff = 0, oimg = img;
+    if (p.split_imgs > 0 && img >= p.split_imgs) { oimg = img - p.split_imgs; choff = p.Cout; }
+    size_t opix = ((size_t)oimg * OHp + oh + p.opad) * OWp + ow + p.opad;
+    size_t rpix = ((size_t)img * RHp + oh + p.rpad) * RWp + ow + p.rpad;
+#pragma unroll
+    for (int ni = 0; ni < NREP; ni++) {
+      int n = n0 + wn * (BN / 2) + ni * 16 + (lane >> 4) * 4;
+      float4 bv = *reinterpret_cast<const float4 *>(p.bias + n);
+      float v0 = acc[ni][mi][0] + bv.x, v1 = acc[ni][mi][1] + bv.y, v2 = acc[ni][mi][2] + bv.z, v3 = acc[ni][mi][3] + bv.w;
+      if (p.res) {
+        h4 r = *reinterpret_cast<const h4 *>(p.res + rpix * p.res_ld + n);
         v0 += (float)r[0]; v1 += (float)r[1]; v2 += (float)r[2]; v3 += (float)r[3];
       }
       if (p.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
@@ -337,14 +513,21 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const __half *__restrict
   reinterpret_cast<h8 *>(y + row * EMBED)[lane] = r;
 }
 
-// out[b,c] = mean_t x[b,t,c]  (f32 out); block per b, thread per channel pair
-__global__ __launch_bounds__(256) void token_mean_kernel(const __half *__restrict__ x, float *__restrict__ out, int T) {
+// out[b,c] = mean_t x[b,t,c]  (f32 out, pre-zeroed); block per (b, token chunk), thread per channel pair
+__global__ __launch_bounds__(256) void token_mean_kernel(const __half *__restrict__ x, float *__restrict__ out, int T,
+                                                         int tchunk) {
   int b = blockIdx.x, c = threadIdx.x;
+  int t0 = blockIdx.y * tchunk, t1 = min(T, t0 + tchunk);
   const h2 *src = reinterpret_cast<const h2 *>(x + (size_t)b * T * EMBED) + c;
   float s0 = 0.f, s1 = 0.f;
-  for (int t = 0; t < T; t++) { h2 v = src[(size_t)t * (EMBED / 2)]; s0 += (float)v[0]; s1 += (float)v[1]; }
-  out[(size_t)b * EMBED + c * 2] = s0 / (float)T;
-  out[(size_t)b * EMBED + c * 2 + 1] = s1 / (float)T;
+  for (int t = t0; t < t1; t++) { h2 v = src[(size_t)t * (EMBED / 2)]; s0 += (float)v[0]; s1 += (float)v[1]; }
+  if (gridDim.y == 1) {
+    out[(size_t)b * EMBED + c * 2] = s0 / (float)T;
+    out[(size_t)b * EMBED + c * 2 + 1] = s1 / (float)T;
+  } else {
+    atomicAdd(&out[(size_t)b * EMBED + c * 2], s0 / (float)T);
+    atomicAdd(&out[(size_t)b * EMBED + c * 2 + 1], s1 / (float)T);
+  }
 }
 
 // y[b,o] = bias[o] + sum_c x[b,c] W[o,c]   (f32; one wave per output)
@@ -440,7 +623,6 @@ struct Net {
   MHA att, att_cross;                // scorer
   LinearF32 score_lin;
   __half *pe = nullptr;     // [400,512]
-  __half *zeros = nullptr;  // 256 B
   std::vector<void *> allocs;
   ~Net() {
     for (void *p : allocs) (void)hipFree(p);
@@ -463,7 +645,19 @@ static bool get(const std::map<std::string, HostTensor> &m, const std::string &n
   return true;
 }
 
-// PyTorch conv weight [Cout,Cin,KH,KW] -> [Cout][KH][KW][Cin] fp16
+// [Cout][tap][Cin] -> kernel K order: for Cin >= 64 [Cout][Cin/64][tap][64], otherwise unchanged
+static std::vector<__half> relayout_k(const std::vector<__half> &w, int Cout, int ntaps, int Cin) {
+  if (Cin < 64 || ntaps == 1) return w;
+  std::vector<__half> o(w.size());
+  const int nch = Cin / 64;
+  for (int co = 0; co < Cout; co++)
+    for (int t = 0; t < ntaps; t++)
+      for (int ci = 0; ci < Cin; ci++)
+        o[(((size_t)co * nch + ci / 64) * ntaps + t) * 64 + (ci % 64)] = w[((size_t)co * ntaps + t) * Cin + ci];
+  return o;
+}
+
+// PyTorch conv weight [Cout,Cin,KH,KW] -> [Cout][KH][KW][Cin] fp16 -> kernel K order
 static bool make_conv(Net *net, const std::map<std::string, HostTensor> &m, const std::string &prefix, int stride,
                       ConvLayer *L, std::string *err) {
   const HostTensor *w, *b;
@@ -476,7 +670,7 @@ static bool make_conv(Net *net, const std::map<std::string, HostTensor> &m, cons
       for (int kh = 0; kh < KH; kh++)
         for (int kw = 0; kw < KW; kw++)
           hw[(((size_t)co * KH + kh) * KW + kw) * Ci + ci] = __float2half(w->data[(((size_t)co * Ci + ci) * KH + kh) * KW + kw]);
-  L->w = upload(net, hw);
+  L->w = upload(net, relayout_k(hw, Co, KH * KW, Ci));
   L->bias = upload(net, b->data);
   L->Cin = Ci; L->Cout = Co; L->KH = KH; L->KW = KW; L->stride = stride; L->pad = (KH - 1) / 2;
   return L->w && L->bias;
@@ -586,9 +780,7 @@ Net *net_load(const char *path, bool is_scorer, std::string *err) {
         pe[(size_t)t * EMBED + 2 * i + 1] = __float2half(std::cos((float)t * div));
       }
     net->pe = upload(net.get(), pe);
-    std::vector<__half> z(128, __float2half(0.f));
-    net->zeros = upload(net.get(), z);
-    ok = net->pe && net->zeros;
+    ok = net->pe != nullptr;
     if (!ok) *err = "device allocation failed";
   }
   if (!ok) return nullptr;
@@ -619,23 +811,26 @@ struct NNScratch {
 NNScratch *nn_scratch_create() { return new NNScratch(); }
 void nn_scratch_free(NNScratch *w) { delete w; }
 
-// per-hypothesis activation sizes (halfs)
-static constexpr size_t SZ_STEM = 2ull * 80 * 80 * 64;
-static constexpr size_t SZ_128 = 2ull * 40 * 40 * 128;
-static constexpr size_t SZ_256 = 40ull * 40 * 256;
-static constexpr size_t SZ_512 = 20ull * 20 * 512;
+// per-hypothesis activation sizes (halfs); conv inputs carry their physical zero border
+static constexpr size_t SZ_STEM = 2ull * 82 * 82 * 64;   // stem out, read by the 3x3/s2 conv (border 1)
+static constexpr size_t SZ_128 = 2ull * 42 * 42 * 128;
+static constexpr size_t SZ_256 = 42ull * 42 * 256;
+static constexpr size_t SZ_512 = 22ull * 22 * 512;
+static constexpr size_t SZ_TOK = 400ull * 512;            // token buffers (no border)
 static constexpr size_t SZ_QKV = 400ull * 1536;
-static constexpr size_t PER_HYP = SZ_STEM + 3 * SZ_128 + 3 * SZ_256 + 3 * SZ_512 + SZ_QKV + 4 * SZ_512;
+static constexpr size_t PER_HYP = SZ_STEM + 3 * SZ_128 + 3 * SZ_256 + 3 * SZ_512 + SZ_QKV + 4 * SZ_TOK;
 
-static int ensure_scratch(NNScratch *ws, int N) {
+static int ensure_scratch(NNScratch *ws, int N, hipStream_t s) {
   if (N <= ws->cap) return 0;
   if (ws->buf) (void)hipFree(ws->buf);
   if (ws->f32) (void)hipFree(ws->f32);
   ws->buf = nullptr; ws->f32 = nullptr; ws->cap = 0;
   int cap = std::max(N, 8);
-  // + room for the cross-attention buffers (N x (512 + 1536 + 512 + 512) halfs) which is < one hypothesis' worth
   FP_HIP_OK(hipMalloc((void **)&ws->buf, (size_t)cap * PER_HYP * sizeof(__half)));
   FP_HIP_OK(hipMalloc((void **)&ws->f32, (size_t)cap * EMBED * sizeof(float)));
+  // the zero borders are written here once and never again: every producer stores interiors only, and the arena is
+  // carved by CAPACITY (not by the current N), so an image slot's border never moves
+  FP_HIP_OK(hipMemsetAsync(ws->buf, 0, (size_t)cap * PER_HYP * sizeof(__half), s));
   ws->cap = cap;
   return 0;
 }
@@ -656,7 +851,6 @@ static int ensure_head_scratch(NNScratch *ws, int n_total) {
 // launch helpers
 // =================================================================================================
 
-static int ilog2(int v) { int l = 0; while ((1 << l) < v) l++; return l; }
 
 struct Ctx {
   hipStream_t s;
@@ -665,39 +859,76 @@ struct Ctx {
 };
 
 static bool g_conv_attr_done = false;
+static int g_conv_variant = 0;  // 0 auto, 1 force the 128-pixel 2-stage kernel, 2 force the 256-pixel 3-stage kernel (A/B hook)
 
-static int run_conv(const Ctx &c, const char *tag, const ConvLayer &L, const __half *in, int NB, int H, int W, __half *out,
-                    bool relu, const __half *res = nullptr, int split_imgs = 0) {
+// in: [NB, H+2*ipad, W+2*ipad, Cin]; out: [.., OH+2*opad, OW+2*opad, ..]; res: border rpad
+static int run_conv(const Ctx &c, const char *tag, const ConvLayer &L, const __half *in, int NB, int H, int W, int ipad,
+                    __half *out, int opad, bool relu, const __half *res = nullptr, int rpad = 0, int split_imgs = 0) {
   ConvParams p;
-  p.in = in; p.w = L.w; p.bias = L.bias; p.res = res; p.out = out; p.zeros = c.net->zeros;
-  p.NB = NB; p.H = H; p.W = W; p.Cin = L.Cin; p.cin_log2 = ilog2(L.Cin);
+  p.in = in; p.w = L.w; p.bias = L.bias; p.res = res; p.out = out;
+  p.NB = NB; p.H = H; p.W = W; p.Cin = L.Cin;
   p.KH = L.KH; p.KW = L.KW; p.stride = L.stride; p.pad = L.pad;
+  p.ipad = ipad; p.opad = opad; p.rpad = rpad;
   p.OH = (H + 2 * L.pad - L.KH) / L.stride + 1;
   p.OW = (W + 2 * L.pad - L.KW) / L.stride + 1;
   if (L.KH == 4 && L.pad == 2 && L.stride == 1) { p.OH = H; p.OW = W; }  // s2d stem: asymmetric padding (2 before, 1 after)
   p.Cout = L.Cout;
   p.M = NB * p.OH * p.OW;
   p.Ktot = L.KH * L.KW * L.Cin;
+  p.ntaps = L.KH * L.KW;
   p.relu = relu ? 1 : 0;
   p.split_imgs = split_imgs;
   p.out_ld = split_imgs > 0 ? 2 * L.Cout : L.Cout;
   p.res_ld = L.Cout;
-  FP_CHECK((1 << p.cin_log2) == L.Cin && p.Ktot % 64 == 0 && (L.Cout % 64) == 0, "conv shape not supported by the MFMA kernel");
+  FP_CHECK(ipad >= L.pad && (L.Cin == 32 || L.Cin % 64 == 0) && p.Ktot % 64 == 0 && (L.Cout % 64) == 0 &&
+               (L.Cin != 32 || L.KW % 2 == 0) && p.Ktot / 64 <= 80,
+           "conv shape not supported by the MFMA kernel");
+  {
+    // K order: Cin >= 64 -> (64-channel chunk outer, tap inner); Cin == 32 (s2d stem) -> two horizontally adjacent taps
+    // (128 contiguous bytes) per K-step.  koff = byte offset of the K-step's X slab from the row's (tap 0, ch 0) address.
+    const int IWp = W + 2 * ipad;
+    for (int kt = 0; kt < p.Ktot / 64; kt++) {
+      int kh, kw, ch;
+      if (L.Cin >= 64) { ch = kt / p.ntaps; int tap = kt % p.ntaps; kh = tap / L.KW; kw = tap % L.KW; }
+      else { ch = 0; int tap = 2 * kt; kh = tap / L.KW; kw = tap % L.KW; }
+      p.koff[kt] = (unsigned)(((kh * IWp + kw) * L.Cin + ch * 64) * 2);
+    }
+  }
   double flops = 2.0 * (double)p.M * p.Cout * (L.algo_K > 0 ? L.algo_K : p.Ktot);
   double bytes = ((double)NB * H * W * L.Cin + (double)p.M * p.Cout * (res ? 2 : 1) + (double)p.Cout * p.Ktot) * 2.0;
+  constexpr int LDS3_128 = 3 * (256 * 128 + 128 * 128), LDS3_64 = 3 * (256 * 128 + 64 * 128);
   if (!g_conv_attr_done) {
     FP_HIP_OK(hipFuncSetAttribute((const void *)conv_igemm_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (128 * 128 + 128 * 128)));
     FP_HIP_OK(hipFuncSetAttribute((const void *)conv_igemm_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (128 * 128 + 64 * 128)));
+    FP_HIP_OK(hipFuncSetAttribute((const void *)conv_igemm3_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS3_128));
+    FP_HIP_OK(hipFuncSetAttribute((const void *)conv_igemm3_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS3_64));
     g_conv_attr_done = true;
   }
   ProfScope ps(c.prof, c.s, tag, flops, bytes);
   int mtiles = (p.M + 127) / 128;
+  const int KT = p.Ktot / 64;
+  // large problems: 256-pixel tiles, 3-stage LDS-DMA pipeline (needs >= 3 K-steps and enough tiles to fill 256 CUs)
+  const int big_tiles = ((p.M + 255) / 256) * (L.Cout % 128 == 0 ? L.Cout / 128 : L.Cout / 64);
+  if (g_conv_variant != 1 && KT >= 3 && (big_tiles >= 512 || g_conv_variant == 2)) {
+    int mt2 = (p.M + 255) / 256;
+    if (L.Cout % 128 == 0)
+      hipLaunchKernelGGL(conv_igemm3_kernel<128>, dim3(mt2 * (L.Cout / 128)), dim3(512), LDS3_128, c.s, p);
+    else
+      hipLaunchKernelGGL(conv_igemm3_kernel<64>, dim3(mt2 * (L.Cout / 64)), dim3(512), LDS3_64, c.s, p);
+    return 0;
+  }
   if (L.Cout % 128 == 0) {
     hipLaunchKernelGGL(conv_igemm_kernel<128>, dim3(mtiles * (L.Cout / 128)), dim3(256), 2 * (128 * 128 + 128 * 128), c.s, p);
   } else {
     hipLaunchKernelGGL(conv_igemm_kernel<64>, dim3(mtiles * (L.Cout / 64)), dim3(256), 2 * (128 * 128 + 64 * 128), c.s, p);
   }
   return 0;
+}
+
+// plain GEMM rows x Cin -> rows x Cout (Linear layer) on unpadded buffers
+static int run_gemm(const Ctx &c, const char *tag, const ConvLayer &L, const __half *in, int rows, __half *out, bool relu,
+                    const __half *res = nullptr) {
+  return run_conv(c, tag, L, in, rows, 1, 1, 0, out, 0, relu, res, 0, 0);
 }
 
 static int run_attention(const Ctx &c, const __half *qkv, __half *out, int B, int T) {
@@ -720,73 +951,85 @@ static void run_small_linear(const Ctx &c, const float *x, const LinearF32 &L, f
 
 static void run_token_mean(const Ctx &c, const __half *x, float *out, int B, int T) {
   ProfScope ps(c.prof, c.s, "token_mean", 0, (double)B * T * EMBED * 2.0);
-  hipLaunchKernelGGL(token_mean_kernel, dim3(B), dim3(256), 0, c.s, x, out, T);
+  const int tchunk = 25;
+  const int ny = (T + tchunk - 1) / tchunk;
+  if (ny > 1) (void)hipMemsetAsync(out, 0, (size_t)B * EMBED * sizeof(float), c.s);
+  hipLaunchKernelGGL(token_mean_kernel, dim3(B, ny), dim3(256), 0, c.s, x, out, T, tchunk);
 }
 
-// shared CNN trunk: nn_in [2N,80,80,32] -> tokens [N,400,512] (+ positional embedding), returned in *tokens
-static int run_trunk(const Ctx &c, NNScratch *ws, const __half *nn_in, int N, __half **tokens, __half **free0, __half **free1) {
-  const Net *net = c.net;
+// arena carve (by capacity, see ensure_scratch)
+struct Arena {
+  __half *stem, *x128[3], *x256[3], *x512[3], *tokens, *qkv, *att, *y1, *y2;
+};
+static Arena carve(NNScratch *ws) {
+  Arena a;
+  const size_t cap = (size_t)ws->cap;
   __half *p = ws->buf;
-  __half *stem = p; p += (size_t)N * SZ_STEM;
-  __half *x128[3]; for (int i = 0; i < 3; i++) { x128[i] = p; p += (size_t)N * SZ_128; }
-  __half *x256[3]; for (int i = 0; i < 3; i++) { x256[i] = p; p += (size_t)N * SZ_256; }
-  __half *x512[3]; for (int i = 0; i < 3; i++) { x512[i] = p; p += (size_t)N * SZ_512; }
+  a.stem = p; p += cap * SZ_STEM;
+  for (int i = 0; i < 3; i++) { a.x128[i] = p; p += cap * SZ_128; }
+  for (int i = 0; i < 3; i++) { a.x256[i] = p; p += cap * SZ_256; }
+  for (int i = 0; i < 3; i++) { a.x512[i] = p; p += cap * SZ_512; }
+  a.tokens = p; p += cap * SZ_TOK;
+  a.qkv = p; p += cap * SZ_QKV;
+  a.att = p; p += cap * SZ_TOK;
+  a.y1 = p; p += cap * SZ_TOK;
+  a.y2 = p; p += cap * SZ_TOK;
+  return a;
+}
+
+// shared CNN trunk: nn_in [2N,84,84,32] (s2d, border 2) -> tokens [N,400,512] + positional embedding
+static int run_trunk(const Ctx &c, const Arena &a, const __half *nn_in, int N) {
+  const Net *net = c.net;
   const int NB2 = 2 * N;
-  if (run_conv(c, "conv_stem", net->a0, nn_in, NB2, 80, 80, stem, true)) return 1;
-  if (run_conv(c, "conv_a1", net->a1, stem, NB2, 80, 80, x128[0], true)) return 1;
+  if (run_conv(c, "conv_stem", net->a0, nn_in, NB2, 80, 80, 2, a.stem, 1, true)) return 1;
+  if (run_conv(c, "conv_a1", net->a1, a.stem, NB2, 80, 80, 1, a.x128[0], 1, true)) return 1;
   // encodeA residual blocks @40x40x128; the last conv writes the a|b channel concat directly
-  if (run_conv(c, "conv_128", net->ra[0][0], x128[0], NB2, 40, 40, x128[1], true)) return 1;
-  if (run_conv(c, "conv_128", net->ra[0][1], x128[1], NB2, 40, 40, x128[2], true, x128[0])) return 1;
-  if (run_conv(c, "conv_128", net->ra[1][0], x128[2], NB2, 40, 40, x128[1], true)) return 1;
-  if (run_conv(c, "conv_128", net->ra[1][1], x128[1], NB2, 40, 40, x256[0], true, x128[2], N)) return 1;
+  if (run_conv(c, "conv_128", net->ra[0][0], a.x128[0], NB2, 40, 40, 1, a.x128[1], 1, true)) return 1;
+  if (run_conv(c, "conv_128", net->ra[0][1], a.x128[1], NB2, 40, 40, 1, a.x128[2], 1, true, a.x128[0], 1)) return 1;
+  if (run_conv(c, "conv_128", net->ra[1][0], a.x128[2], NB2, 40, 40, 1, a.x128[1], 1, true)) return 1;
+  if (run_conv(c, "conv_128", net->ra[1][1], a.x128[1], NB2, 40, 40, 1, a.x256[0], 1, true, a.x128[2], 1, N)) return 1;
   // encodeAB
-  if (run_conv(c, "conv_256", net->rb[0][0], x256[0], N, 40, 40, x256[1], true)) return 1;
-  if (run_conv(c, "conv_256", net->rb[0][1], x256[1], N, 40, 40, x256[2], true, x256[0])) return 1;
-  if (run_conv(c, "conv_256", net->rb[1][0], x256[2], N, 40, 40, x256[1], true)) return 1;
-  if (run_conv(c, "conv_256", net->rb[1][1], x256[1], N, 40, 40, x256[0], true, x256[2])) return 1;
-  if (run_conv(c, "conv_b2", net->b2, x256[0], N, 40, 40, x512[0], true)) return 1;
-  if (run_conv(c, "conv_512", net->rc[0][0], x512[0], N, 20, 20, x512[1], true)) return 1;
-  if (run_conv(c, "conv_512", net->rc[0][1], x512[1], N, 20, 20, x512[2], true, x512[0])) return 1;
-  if (run_conv(c, "conv_512", net->rc[1][0], x512[2], N, 20, 20, x512[1], true)) return 1;
-  if (run_conv(c, "conv_512", net->rc[1][1], x512[1], N, 20, 20, x512[0], true, x512[2])) return 1;
+  if (run_conv(c, "conv_256", net->rb[0][0], a.x256[0], N, 40, 40, 1, a.x256[1], 1, true)) return 1;
+  if (run_conv(c, "conv_256", net->rb[0][1], a.x256[1], N, 40, 40, 1, a.x256[2], 1, true, a.x256[0], 1)) return 1;
+  if (run_conv(c, "conv_256", net->rb[1][0], a.x256[2], N, 40, 40, 1, a.x256[1], 1, true)) return 1;
+  if (run_conv(c, "conv_256", net->rb[1][1], a.x256[1], N, 40, 40, 1, a.x256[0], 1, true, a.x256[2], 1)) return 1;
+  if (run_conv(c, "conv_b2", net->b2, a.x256[0], N, 40, 40, 1, a.x512[0], 1, true)) return 1;
+  if (run_conv(c, "conv_512", net->rc[0][0], a.x512[0], N, 20, 20, 1, a.x512[1], 1, true)) return 1;
+  if (run_conv(c, "conv_512", net->rc[0][1], a.x512[1], N, 20, 20, 1, a.x512[2], 1, true, a.x512[0], 1)) return 1;
+  if (run_conv(c, "conv_512", net->rc[1][0], a.x512[2], N, 20, 20, 1, a.x512[1], 1, true)) return 1;
+  // last conv writes the un-bordered token tensor [N,400,512]
+  if (run_conv(c, "conv_512", net->rc[1][1], a.x512[1], N, 20, 20, 1, a.tokens, 0, true, a.x512[2], 1)) return 1;
   {
     size_t rows = (size_t)N * 400;
     ProfScope ps(c.prof, c.s, "add_pos_embed", 0, (double)rows * EMBED * 4.0);
     size_t chunks = rows * (EMBED / 8);
-    hipLaunchKernelGGL(add_pos_embed_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, c.s, x512[0], net->pe, 400, rows);
+    hipLaunchKernelGGL(add_pos_embed_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, c.s, a.tokens, net->pe, 400, rows);
   }
-  *tokens = x512[0];
-  *free0 = x512[1];
-  *free1 = x512[2];
   return 0;
 }
 
 int refiner_forward(hipStream_t s, Profiler *prof, const Net *net, NNScratch *ws, const __half *nn_in, int N,
                     float *trans_dev, float *rot_dev) {
   FP_CHECK(net && !net->scorer, "refiner_forward: wrong network");
-  if (ensure_scratch(ws, N)) return 1;
+  if (ensure_scratch(ws, N, s)) return 1;
   Ctx c{s, prof, net};
-  __half *x, *t0, *t1;
-  if (run_trunk(c, ws, nn_in, N, &x, &t0, &t1)) return 1;
-  __half *tail = ws->buf + (size_t)N * (SZ_STEM + 3 * SZ_128 + 3 * SZ_256 + 3 * SZ_512);
-  __half *qkv = tail; tail += (size_t)N * SZ_QKV;
-  __half *att = tail; tail += (size_t)N * SZ_512;
-  __half *y1 = tail; tail += (size_t)N * SZ_512;
-  __half *y2 = tail; tail += (size_t)N * SZ_512;
+  const Arena a = carve(ws);
+  if (run_trunk(c, a, nn_in, N)) return 1;
+  const __half *x = a.tokens;
   const size_t rows = (size_t)N * 400;
   const EncLayer *heads[2] = {&net->trans, &net->rot};
   float *outs[2] = {trans_dev, rot_dev};
   for (int i = 0; i < 2; i++) {
     const EncLayer &L = *heads[i];
     // post-norm TransformerEncoderLayer: x1 = LN1(x + SA(x)); x2 = LN2(x1 + W2 relu(W1 x1))
-    if (run_conv(c, "gemm_qkv", L.att.in_proj, x, (int)rows, 1, 1, qkv, false)) return 1;
-    if (run_attention(c, qkv, att, N, 400)) return 1;
-    if (run_conv(c, "gemm_512", L.att.out_proj, att, (int)rows, 1, 1, y1, false, x)) return 1;  // + residual x
-    run_layernorm(c, y1, L.ln1, y2, rows);                                                       // x1 = y2
-    if (run_conv(c, "gemm_512", L.lin1, y2, (int)rows, 1, 1, y1, true)) return 1;
-    if (run_conv(c, "gemm_512", L.lin2, y1, (int)rows, 1, 1, att, false, y2)) return 1;          // + residual x1
-    run_layernorm(c, att, L.ln2, y1, rows);
-    run_token_mean(c, y1, ws->f32, N, 400);
+    if (run_gemm(c, "gemm_qkv", L.att.in_proj, x, (int)rows, a.qkv, false)) return 1;
+    if (run_attention(c, a.qkv, a.att, N, 400)) return 1;
+    if (run_gemm(c, "gemm_512", L.att.out_proj, a.att, (int)rows, a.y1, false, x)) return 1;  // + residual x
+    run_layernorm(c, a.y1, L.ln1, a.y2, rows);                                               // x1 = y2
+    if (run_gemm(c, "gemm_512", L.lin1, a.y2, (int)rows, a.y1, true)) return 1;
+    if (run_gemm(c, "gemm_512", L.lin2, a.y1, (int)rows, a.att, false, a.y2)) return 1;       // + residual x1
+    run_layernorm(c, a.att, L.ln2, a.y1, rows);
+    run_token_mean(c, a.y1, ws->f32, N, 400);
     run_small_linear(c, ws->f32, L.head, outs[i], N);  // Linear(512,3) commutes with the token mean
   }
   FP_HIP_OK(hipGetLastError());
@@ -795,18 +1038,15 @@ int refiner_forward(hipStream_t s, Profiler *prof, const Net *net, NNScratch *ws
 
 int scorer_features(hipStream_t s, Profiler *prof, const Net *net, NNScratch *ws, const __half *nn_in, int N, float *feat_dev) {
   FP_CHECK(net && net->scorer, "scorer_features: wrong network");
-  if (ensure_scratch(ws, N)) return 1;
+  if (ensure_scratch(ws, N, s)) return 1;
   Ctx c{s, prof, net};
-  __half *x, *t0, *t1;
-  if (run_trunk(c, ws, nn_in, N, &x, &t0, &t1)) return 1;
-  __half *tail = ws->buf + (size_t)N * (SZ_STEM + 3 * SZ_128 + 3 * SZ_256 + 3 * SZ_512);
-  __half *qkv = tail; tail += (size_t)N * SZ_QKV;
-  __half *att = tail;
+  const Arena a = carve(ws);
+  if (run_trunk(c, a, nn_in, N)) return 1;
   const size_t rows = (size_t)N * 400;
-  if (run_conv(c, "gemm_qkv", net->att.in_proj, x, (int)rows, 1, 1, qkv, false)) return 1;
-  if (run_attention(c, qkv, att, N, 400)) return 1;
+  if (run_gemm(c, "gemm_qkv", net->att.in_proj, a.tokens, (int)rows, a.qkv, false)) return 1;
+  if (run_attention(c, a.qkv, a.att, N, 400)) return 1;
   // feature = mean_t(out_proj(att)) = out_proj(mean_t(att))  (out_proj is affine) -> 512x512 GEMV per hypothesis
-  run_token_mean(c, att, ws->f32, N, 400);
+  run_token_mean(c, a.att, ws->f32, N, 400);
   run_small_linear(c, ws->f32, net->att.out_proj_f32, feat_dev, N);
   FP_HIP_OK(hipGetLastError());
   return 0;
@@ -828,15 +1068,15 @@ int scorer_head(hipStream_t s, Profiler *prof, const Net *net, NNScratch *ws, co
     hipLaunchKernelGGL(cast_f32_f16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c.s, feats_dev, xf, n);
   }
   // att_cross: sequence = the N hypotheses, batch 1
-  if (run_conv(c, "gemm_cross", net->att_cross.in_proj, xf, N, 1, 1, qkv, false)) return 1;
+  if (run_gemm(c, "gemm_cross", net->att_cross.in_proj, xf, N, qkv, false)) return 1;
   if (run_attention(c, qkv, att, 1, N)) return 1;
   // out_proj through the same MFMA GEMM (M = N rows), then Linear(512,1) in f32
-  if (run_conv(c, "gemm_cross", net->att_cross.out_proj, att, N, 1, 1, xf, false)) return 1;
+  if (run_gemm(c, "gemm_cross", net->att_cross.out_proj, att, N, xf, false)) return 1;
   {
     // Linear(512,1) on fp16 rows: widen to f32 first (tiny)
     ProfScope ps(c.prof, c.s, "score_linear", 2.0 * N * EMBED, 0);
     // token_mean with T = 1 is a plain fp16 -> f32 copy of each row
-    hipLaunchKernelGGL(token_mean_kernel, dim3(N), dim3(256), 0, c.s, xf, o32, 1);
+    hipLaunchKernelGGL(token_mean_kernel, dim3(N, 1), dim3(256), 0, c.s, xf, o32, 1, 1);
   }
   run_small_linear(c, o32, net->score_lin, scores_dev, N);
   FP_HIP_OK(hipGetLastError());
@@ -865,30 +1105,38 @@ std::vector<__half> to_half(const float *src, size_t n) {
 
 extern "C" {
 
+void fpt_set_conv_variant(int v) { fp::g_conv_variant = v; }
+
 // x [NB,H,W,Cin] NHWC f32, w [Cout,KH,KW,Cin] f32 (already in kernel layout), bias [Cout], res (optional) [NB,OH,OW,Cout]
 // -> out f32 [NB,OH,OW,Cout] (or, with split_imgs > 0, [NB-split,OH,OW,2*Cout]).  iters > 1: returns mean ms in *ms_out.
 int fpt_conv(const float *x, const float *w, const float *bias, const float *res, int NB, int H, int W, int Cin, int Cout,
              int KH, int KW, int stride, int pad, int OH, int OW, int relu, int split_imgs, float *out, int iters,
              float *ms_out) {
   using namespace fp;
-  size_t nx = (size_t)NB * H * W * Cin, nw = (size_t)Cout * KH * KW * Cin;
+  const int ip = pad;  // physical input border
+  const int Hp = H + 2 * ip, Wp = W + 2 * ip;
+  size_t nx = (size_t)NB * Hp * Wp * Cin, nw = (size_t)Cout * KH * KW * Cin;
   size_t M = (size_t)NB * OH * OW;
   size_t nout = M * Cout;
-  DevBuf<__half> dx(nx), dw(nw), dres(nout), dout(nout * 2), dz(128);
+  DevBuf<__half> dx(nx), dw(nw), dres(nout), dout(nout * 2);
   DevBuf<float> db(Cout);
-  FP_CHECK(dx.p && dw.p && dres.p && dout.p && dz.p && db.p, "fpt_conv: allocation failed");
-  auto hx = to_half(x, nx), hw = to_half(w, nw);
+  FP_CHECK(dx.p && dw.p && dres.p && dout.p && db.p, "fpt_conv: allocation failed");
+  std::vector<__half> hx(nx, __float2half(0.f));
+  for (int n = 0; n < NB; n++)
+    for (int y = 0; y < H; y++)
+      for (int xx = 0; xx < W; xx++)
+        for (int c = 0; c < Cin; c++)
+          hx[(((size_t)n * Hp + y + ip) * Wp + xx + ip) * Cin + c] = __float2half(x[(((size_t)n * H + y) * W + xx) * Cin + c]);
+  auto hw = relayout_k(to_half(w, nw), Cout, KH * KW, Cin);
   FP_HIP_OK(hipMemcpy(dx.p, hx.data(), nx * 2, hipMemcpyHostToDevice));
   FP_HIP_OK(hipMemcpy(dw.p, hw.data(), nw * 2, hipMemcpyHostToDevice));
   FP_HIP_OK(hipMemcpy(db.p, bias, (size_t)Cout * 4, hipMemcpyHostToDevice));
-  FP_HIP_OK(hipMemset(dz.p, 0, 256));
   FP_HIP_OK(hipMemset(dout.p, 0, nout * 4));
   if (res) {
     auto hr = to_half(res, nout);
     FP_HIP_OK(hipMemcpy(dres.p, hr.data(), nout * 2, hipMemcpyHostToDevice));
   }
   Net net;
-  net.zeros = dz.p;
   ConvLayer L;
   L.w = dw.p; L.bias = db.p; L.Cin = Cin; L.Cout = Cout; L.KH = KH; L.KW = KW; L.stride = stride; L.pad = pad;
   Ctx c{nullptr, nullptr, &net};
@@ -896,12 +1144,12 @@ int fpt_conv(const float *x, const float *w, const float *bias, const float *res
   hipEvent_t e0, e1;
   FP_HIP_OK(hipEventCreate(&e0));
   FP_HIP_OK(hipEventCreate(&e1));
-  if (run_conv(c, "t", L, dx.p, NB, H, W, dout.p, relu != 0, res ? dres.p : nullptr, split_imgs)) return 1;
+  if (run_conv(c, "t", L, dx.p, NB, H, W, ip, dout.p, 0, relu != 0, res ? dres.p : nullptr, 0, split_imgs)) return 1;
   FP_HIP_OK(hipDeviceSynchronize());
   if (iters > 1) {
     FP_HIP_OK(hipEventRecord(e0, nullptr));
     for (int i = 0; i < iters; i++)
-      if (run_conv(c, "t", L, dx.p, NB, H, W, dout.p, relu != 0, res ? dres.p : nullptr, split_imgs)) return 1;
+      if (run_conv(c, "t", L, dx.p, NB, H, W, ip, dout.p, 0, relu != 0, res ? dres.p : nullptr, 0, split_imgs)) return 1;
     FP_HIP_OK(hipEventRecord(e1, nullptr));
     FP_HIP_OK(hipEventSynchronize(e1));
     float ms = 0;

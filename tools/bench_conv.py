@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of conv_igemm_kernel on the layer shapes of one Register (per-GPU batch N hypotheses).
+Random fp16 data (guide rule 25: never zero-filled).  Uses the fpt_conv hook of the library (tests-only symbol)."""
+import argparse
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from foundationpose_cpp_amd import _lib  # noqa: E402
+
+SHAPES = [  # name, images-per-hyp, H, W, Cin, Cout, k, stride, pad, launches per Register
+    ("stem(s2d)", 2, 80, 80, 32, 64, 4, 1, 2, 2),
+    ("a1 3x3s2 64->128", 2, 80, 80, 64, 128, 3, 2, 1, 2),
+    ("128 3x3", 2, 40, 40, 128, 128, 3, 1, 1, 8),
+    ("256 3x3", 1, 40, 40, 256, 256, 3, 1, 1, 8),
+    ("b2 3x3s2 256->512", 1, 40, 40, 256, 512, 3, 2, 1, 2),
+    ("512 3x3", 1, 20, 20, 512, 512, 3, 1, 1, 8),
+    ("qkv 512->1536", 400, 1, 1, 512, 1536, 1, 1, 0, 3),
+    ("lin 512->512", 400, 1, 1, 512, 512, 1, 1, 0, 6),
+]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--hyps", type=int, default=126)
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--variant", type=int, default=0, help="0 auto, 1 = 128-px 2-stage kernel, 2 = 256-px 3-stage kernel")
+    a = ap.parse_args()
+    L = _lib.lib()
+    L.fpt_set_conv_variant(a.variant)
+    rng = np.random.default_rng(0)
+    tot_ms = tot_fl = 0.0
+    for name, ipn, H, W, Cin, Cout, k, stride, pad, launches in SHAPES:
+        NB = ipn * a.hyps
+        x = rng.standard_normal((NB, H, W, Cin), dtype=np.float32)
+        w = (rng.standard_normal((Cout, k, k, Cin), dtype=np.float32) / np.sqrt(Cin * k * k)).astype(np.float32)
+        b = rng.standard_normal(Cout, dtype=np.float32)
+        OH = (H + 2 * pad - k) // stride + 1
+        OW = (W + 2 * pad - k) // stride + 1
+        if k == 4:
+            OH, OW = H, W
+        out = np.zeros((NB, OH, OW, Cout), np.float32)
+        ms = C.c_float(0)
+        p = lambda t: t.ctypes.data_as(C.c_void_p)  # noqa: E731
+        rc = L.fpt_conv(p(x), p(w), p(b), None, NB, H, W, Cin, Cout, k, k, stride, pad, OH, OW, 1, 0, p(out), a.iters,
+                        C.byref(ms))
+        assert rc == 0, _lib.last_error()
+        fl = 2.0 * NB * OH * OW * Cout * k * k * Cin
+        print(f"{name:22s} M={NB * OH * OW:8d} K={k * k * Cin:5d} N={Cout:5d}  {ms.value * 1e3:9.1f} us  {fl / ms.value / 1e9:8.1f} TF/s")
+        tot_ms += ms.value * launches
+        tot_fl += fl * launches
+    print(f"weighted (per-Register mix): {tot_fl / tot_ms / 1e9:.1f} TF/s, {tot_ms:.3f} ms for N={a.hyps}")
+
+
+if __name__ == "__main__":
+    main()
