@@ -1,2 +1,2 @@
 """foundationpose_cpp_amd -- MI355X-native FoundationPose Register/Track hot path."""
-from .api import FoundationPose, FoundationPoseError  # noqa: F401
+from .api import FoundationPose, FoundationPoseError, load_mesh  # noqa: F401

@@ -20,6 +20,7 @@ SYMBOLS = [
     "fp_render_and_transform", "fp_debug_rasterize", "fp_refiner_infer", "fp_scorer_infer",
     "fp_refine_post_process", "fp_argmax", "fp_register_shard_begin", "fp_register_shard_finish",
     "fp_profile_enable", "fp_profile_reset", "fp_profile_report", "fp_stream", "fp_synchronize",
+    "fp_mesh_load_obj", "fp_mesh_free", "fp_mesh_view", "fp_mesh_orient_bounds",
 ]
 
 
@@ -62,6 +63,12 @@ def lib() -> C.CDLL:
     L.fp_last_error.restype = C.c_char_p
     L.fp_stream.restype = C.c_void_p
     L.fp_stream.argtypes = [C.c_void_p]
+    L.fp_mesh_load_obj.restype = C.c_void_p
+    L.fp_mesh_load_obj.argtypes = [C.c_char_p, C.c_char_p]
+    L.fp_mesh_free.restype = None
+    L.fp_mesh_free.argtypes = [C.c_void_p]
+    L.fp_mesh_view.restype = C.POINTER(FpMesh)
+    L.fp_mesh_view.argtypes = [C.c_void_p]
     vp, ci, cf, cs = C.c_void_p, C.c_int, C.c_float, C.c_char_p
     sigs = {
         "fp_set_inplane_steps": [vp, ci], "fp_num_hypotheses": [vp],
@@ -78,7 +85,7 @@ def lib() -> C.CDLL:
         "fp_register_shard_begin": [vp, vp, vp, vp, ci, ci, ci, cs, ci, ci, ci, vp, vp],
         "fp_register_shard_finish": [vp, vp, vp, ci, vp, vp, vp],
         "fp_profile_enable": [vp, ci], "fp_profile_reset": [vp], "fp_profile_report": [vp, vp, ci],
-        "fp_synchronize": [vp],
+        "fp_synchronize": [vp], "fp_mesh_orient_bounds": [vp, vp, vp],
     }
     for name, at in sigs.items():
         f = getattr(L, name)

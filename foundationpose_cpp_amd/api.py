@@ -28,6 +28,36 @@ def _p(a):
     return a.ctypes.data_as(C.c_void_p) if a is not None else None
 
 
+def load_mesh(name: str, mesh_file_path: str) -> Mesh:
+    """CreateAssimpMeshLoader(name, path) (mesh_loader.hpp:92-93): OBJ + MTL + PNG through the C ABI.
+    Raises FoundationPoseError where the reference throws (empty path, unreadable file, no UVs).
+    Extra attributes: .orient_bounds [4,4], .dimension [3] (GetOrientBounds / GetObjectDimension)."""
+    L = _lib.lib()
+    h = L.fp_mesh_load_obj(name.encode(), mesh_file_path.encode())
+    if not h:
+        raise FoundationPoseError(_lib.last_error())
+    try:
+        v = L.fp_mesh_view(h).contents
+        nv, nf = v.num_vertices, v.num_faces
+
+        def arr(ptr, ctype, shape, dtype):
+            n = int(np.prod(shape))
+            return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ctype)), shape=(n,)).astype(dtype).reshape(shape).copy()
+
+        mesh = Mesh(name, arr(v.vertices, C.c_float, (nv, 3), np.float32), arr(v.normals, C.c_float, (nv, 3), np.float32),
+                    arr(v.texcoords, C.c_float, (nv, 2), np.float32), arr(v.faces, C.c_uint32, (nf, 3), np.int32),
+                    arr(v.texture, C.c_uint8, (v.tex_height, v.tex_width, 3), np.uint8), diameter=float(v.diameter),
+                    center=np.array(list(v.center), np.float32))
+        ob = np.zeros(16, np.float32)
+        dim = np.zeros(3, np.float32)
+        L.fp_mesh_orient_bounds(h, _p(ob), _p(dim))
+        mesh.orient_bounds = from_colmajor(ob)
+        mesh.dimension = dim
+        return mesh
+    finally:
+        L.fp_mesh_free(h)
+
+
 class FoundationPose:
     """CreateFoundationPoseModel (foundationpose.hpp:99-105) equivalent."""
 

@@ -1,0 +1,354 @@
+// fp_mesh_loader.cpp -- dependency-free mesh loading for the BaseMeshLoader contract.
+//
+// Replaces AssimpMeshLoader (reference detection_6d_foundationpose/src/mesh_loader/assimp_mesh_loader.cpp:116-295,
+// API detection_6d_foundationpose/include/detection_6d_foundationpose/mesh_loader.hpp:15-93) without assimp / OpenCV /
+// Eigen: Wavefront OBJ + MTL (map_Kd) + PNG (zlib inflate) in, the twelve getters' data out.
+//   * first mesh only, polygons fan-triangulated (aiProcess_Triangulate), face-vertex tuples (v,vt,vn) that are
+//     identical share one vertex in order of first use (the documented stand-in for aiProcess_JoinIdenticalVertices,
+//     whose exact vertex order is unpinned -- SURVEY.md §8c);
+//   * diameter = max pairwise vertex distance (:47-60), centre = AABB centre (:16-45,179-180), PCA OBB (:62-114);
+//   * UVs are mandatory (throws in the reference :182-185 -> error here); missing/unreadable texture -> 2x2
+//     (100,100,100) (:217-222); texture is returned RGB (imread BGR + cvtColor BGR2RGB, :216,223).
+//   * meshes without normals get area-weighted vertex normals (the reference would dereference a null mNormals).
+#include <zlib.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <sstream>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "../../include/foundationpose_amd.h"
+#include "fp_internal.h"
+
+namespace {
+
+// ---------------------------------------------------------------- PNG ------------------------------------------------
+bool inflate_all(const std::vector<uint8_t> &in, std::vector<uint8_t> &out, size_t expect) {
+  out.resize(expect);
+  z_stream zs;
+  std::memset(&zs, 0, sizeof(zs));
+  if (inflateInit(&zs) != Z_OK) return false;
+  zs.next_in = const_cast<Bytef *>(in.data());
+  zs.avail_in = (uInt)in.size();
+  zs.next_out = out.data();
+  zs.avail_out = (uInt)out.size();
+  int rc = inflate(&zs, Z_FINISH);
+  size_t got = zs.total_out;
+  inflateEnd(&zs);
+  return (rc == Z_STREAM_END || rc == Z_OK || rc == Z_BUF_ERROR) && got == expect;
+}
+
+uint32_t be32(const uint8_t *p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; }
+
+// 8-bit, non-interlaced PNG of colour type 0 (grey), 2 (RGB), 3 (palette), 4 (grey+alpha), 6 (RGBA) -> RGB u8
+bool load_png_rgb(const std::string &path, std::vector<uint8_t> &rgb, int &H, int &W) {
+  std::ifstream f(path, std::ios::binary);
+  if (!f) return false;
+  std::vector<uint8_t> buf((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+  static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
+  if (buf.size() < 33 || std::memcmp(buf.data(), sig, 8) != 0) return false;
+  size_t pos = 8;
+  int depth = 0, ctype = 0, interlace = 0;
+  std::vector<uint8_t> idat, plte;
+  W = H = 0;
+  while (pos + 12 <= buf.size()) {
+    uint32_t len = be32(&buf[pos]);
+    std::string type((const char *)&buf[pos + 4], 4);
+    if (pos + 12 + len > buf.size()) return false;
+    const uint8_t *d = &buf[pos + 8];
+    if (type == "IHDR") {
+      W = (int)be32(d); H = (int)be32(d + 4); depth = d[8]; ctype = d[9]; interlace = d[12];
+    } else if (type == "PLTE") {
+      plte.assign(d, d + len);
+    } else if (type == "IDAT") {
+      idat.insert(idat.end(), d, d + len);
+    } else if (type == "IEND") {
+      break;
+    }
+    pos += 12 + len;
+  }
+  if (W <= 0 || H <= 0 || depth != 8 || interlace != 0) return false;
+  int ch = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
+  if (!ch) return false;
+  size_t stride = (size_t)W * ch;
+  std::vector<uint8_t> raw;
+  if (!inflate_all(idat, raw, (stride + 1) * H)) return false;
+  std::vector<uint8_t> img(stride * H);
+  for (int y = 0; y < H; y++) {
+    const uint8_t *src = &raw[(stride + 1) * y];
+    uint8_t ft = src[0];
+    uint8_t *dst = &img[stride * y];
+    const uint8_t *up = y ? &img[stride * (y - 1)] : nullptr;
+    for (size_t x = 0; x < stride; x++) {
+      int a = x >= (size_t)ch ? dst[x - ch] : 0, b = up ? up[x] : 0, c = (up && x >= (size_t)ch) ? up[x - ch] : 0;
+      int v = src[1 + x];
+      switch (ft) {
+        case 0: break;
+        case 1: v += a; break;
+        case 2: v += b; break;
+        case 3: v += (a + b) >> 1; break;
+        case 4: {
+          int p = a + b - c, pa = std::abs(p - a), pb = std::abs(p - b), pc = std::abs(p - c);
+          v += (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
+          break;
+        }
+        default: return false;
+      }
+      dst[x] = (uint8_t)v;
+    }
+  }
+  rgb.resize((size_t)W * H * 3);
+  for (size_t i = 0; i < (size_t)W * H; i++) {
+    const uint8_t *p = &img[i * ch];
+    uint8_t r, g, b;
+    if (ctype == 0 || ctype == 4) { r = g = b = p[0]; }
+    else if (ctype == 3) {
+      if ((size_t)p[0] * 3 + 2 >= plte.size()) return false;
+      r = plte[p[0] * 3]; g = plte[p[0] * 3 + 1]; b = plte[p[0] * 3 + 2];
+    } else { r = p[0]; g = p[1]; b = p[2]; }
+    rgb[i * 3] = r; rgb[i * 3 + 1] = g; rgb[i * 3 + 2] = b;
+  }
+  return true;
+}
+
+// ---------------------------------------------------------------- 3x3 symmetric eigen (Jacobi) ------------------------
+void eigen_sym3(const double A_in[9], double evals[3], double evecs[9] /* columns, row-major storage */) {
+  double A[9];
+  std::memcpy(A, A_in, sizeof(A));
+  double V[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  for (int sweep = 0; sweep < 64; sweep++) {
+    double off = A[1] * A[1] + A[2] * A[2] + A[5] * A[5];
+    if (off < 1e-30) break;
+    for (int p = 0; p < 2; p++)
+      for (int q = p + 1; q < 3; q++) {
+        double apq = A[p * 3 + q];
+        if (std::fabs(apq) < 1e-300) continue;
+        double theta = (A[q * 3 + q] - A[p * 3 + p]) / (2 * apq);
+        double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1));
+        double c = 1 / std::sqrt(t * t + 1), s = t * c;
+        for (int k = 0; k < 3; k++) {  // A <- A J
+          double akp = A[k * 3 + p], akq = A[k * 3 + q];
+          A[k * 3 + p] = c * akp - s * akq; A[k * 3 + q] = s * akp + c * akq;
+        }
+        for (int k = 0; k < 3; k++) {  // A <- J^T A
+          double apk = A[p * 3 + k], aqk = A[q * 3 + k];
+          A[p * 3 + k] = c * apk - s * aqk; A[q * 3 + k] = s * apk + c * aqk;
+        }
+        for (int k = 0; k < 3; k++) {
+          double vkp = V[k * 3 + p], vkq = V[k * 3 + q];
+          V[k * 3 + p] = c * vkp - s * vkq; V[k * 3 + q] = s * vkp + c * vkq;
+        }
+      }
+  }
+  int idx[3] = {0, 1, 2};
+  std::sort(idx, idx + 3, [&](int a, int b) { return A[a * 3 + a] < A[b * 3 + b]; });  // ascending, like Eigen
+  for (int j = 0; j < 3; j++) {
+    evals[j] = A[idx[j] * 3 + idx[j]];
+    for (int k = 0; k < 3; k++) evecs[k * 3 + j] = V[k * 3 + idx[j]];
+  }
+}
+
+std::string dirname_of(const std::string &p) {
+  size_t s = p.find_last_of("/\\");
+  return s == std::string::npos ? std::string(".") : p.substr(0, s);
+}
+
+}  // namespace
+
+struct fp_loaded_mesh {
+  std::string name;
+  std::vector<float> vertices, normals, texcoords;
+  std::vector<uint32_t> faces;
+  std::vector<uint8_t> texture;
+  int th = 0, tw = 0;
+  float diameter = 0;
+  float center[3] = {0, 0, 0};
+  float obb[16];  // column-major
+  float dim[3];
+  fp_mesh view;
+};
+
+extern "C" {
+
+fp_loaded_mesh *fp_mesh_load_obj(const char *name, const char *mesh_file_path) {
+  if (!mesh_file_path || !*mesh_file_path) { fp::set_error("[AssimpMeshLoader] Got empty mesh_file_path !"); return nullptr; }
+  std::ifstream f(mesh_file_path);
+  if (!f) { fp::set_error(std::string("[AssimpMeshLoader] Failed to read mesh file: ") + mesh_file_path); return nullptr; }
+  std::vector<std::array<float, 3>> pos, nrm;
+  std::vector<std::array<float, 2>> uv;
+  struct Corner { int v, t, n; };
+  std::vector<std::array<Corner, 3>> tris;
+  std::string mtllib, usemtl, line;
+  bool first_object_done = false;
+  while (std::getline(f, line)) {
+    if (!line.empty() && line.back() == '\r') line.pop_back();
+    std::istringstream ss(line);
+    std::string tag;
+    if (!(ss >> tag) || tag[0] == '#') continue;
+    if (tag == "v") { std::array<float, 3> p{}; ss >> p[0] >> p[1] >> p[2]; pos.push_back(p); }
+    else if (tag == "vn") { std::array<float, 3> p{}; ss >> p[0] >> p[1] >> p[2]; nrm.push_back(p); }
+    else if (tag == "vt") { std::array<float, 2> p{}; ss >> p[0] >> p[1]; uv.push_back(p); }
+    else if (tag == "mtllib") { std::getline(ss >> std::ws, mtllib); }
+    else if (tag == "usemtl") { if (usemtl.empty()) ss >> usemtl; }
+    else if (tag == "o" || tag == "g") { if (!tris.empty()) first_object_done = true; }
+    else if (tag == "f") {
+      if (first_object_done) continue;  // only mMeshes[0] (assimp_mesh_loader.cpp:176)
+      std::vector<Corner> cs;
+      std::string tok;
+      while (ss >> tok) {
+        Corner c{0, 0, 0};
+        int field = 0;
+        size_t start = 0;
+        for (size_t i = 0; i <= tok.size(); i++)
+          if (i == tok.size() || tok[i] == '/') {
+            std::string part = tok.substr(start, i - start);
+            int val = part.empty() ? 0 : std::atoi(part.c_str());
+            if (field == 0) c.v = val; else if (field == 1) c.t = val; else if (field == 2) c.n = val;
+            field++; start = i + 1;
+          }
+        auto fix = [](int idx, size_t n) { return idx > 0 ? idx - 1 : (idx < 0 ? (int)n + idx : -1); };
+        c.v = fix(c.v, pos.size()); c.t = fix(c.t, uv.size()); c.n = fix(c.n, nrm.size());
+        cs.push_back(c);
+      }
+      for (size_t i = 2; i < cs.size(); i++) tris.push_back({cs[0], cs[i - 1], cs[i]});
+    }
+  }
+  if (tris.empty() || pos.empty()) { fp::set_error(std::string("[AssimpMeshLoader] Failed to read mesh file: ") + mesh_file_path); return nullptr; }
+  auto *m = new fp_loaded_mesh();
+  m->name = name ? name : "";
+  std::map<std::tuple<int, int, int>, uint32_t> seen;
+  bool has_uv = true, has_n = true;
+  for (auto &t : tris)
+    for (auto &c : t) {
+      if (c.v < 0 || c.v >= (int)pos.size()) { delete m; fp::set_error("[AssimpMeshLoader] Failed to read mesh file: bad vertex index"); return nullptr; }
+      if (c.t < 0 || c.t >= (int)uv.size()) has_uv = false;
+      if (c.n < 0 || c.n >= (int)nrm.size()) has_n = false;
+    }
+  if (!has_uv) { delete m; fp::set_error("[AssimpMeshLoader] Got invalid texturecoords!"); return nullptr; }
+  for (auto &t : tris)
+    for (auto &c : t) {
+      auto key = std::make_tuple(c.v, c.t, has_n ? c.n : -1);
+      auto it = seen.find(key);
+      uint32_t id;
+      if (it == seen.end()) {
+        id = (uint32_t)(m->vertices.size() / 3);
+        seen[key] = id;
+        for (int k = 0; k < 3; k++) m->vertices.push_back(pos[c.v][k]);
+        for (int k = 0; k < 2; k++) m->texcoords.push_back(uv[c.t][k]);
+        for (int k = 0; k < 3; k++) m->normals.push_back(has_n ? nrm[c.n][k] : 0.0f);
+      } else {
+        id = it->second;
+      }
+      m->faces.push_back(id);
+    }
+  const size_t V = m->vertices.size() / 3;
+  if (!has_n) {  // area-weighted vertex normals
+    for (size_t fi = 0; fi + 2 < m->faces.size(); fi += 3) {
+      const float *a = &m->vertices[m->faces[fi] * 3], *b = &m->vertices[m->faces[fi + 1] * 3], *c = &m->vertices[m->faces[fi + 2] * 3];
+      float e1[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]}, e2[3] = {c[0] - a[0], c[1] - a[1], c[2] - a[2]};
+      float n[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
+      for (int k = 0; k < 3; k++)
+        for (int j = 0; j < 3; j++) m->normals[m->faces[fi + k] * 3 + j] += n[j];
+    }
+    for (size_t v = 0; v < V; v++) {
+      float *n = &m->normals[v * 3];
+      float l = std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+      if (l > 0) { n[0] /= l; n[1] /= l; n[2] /= l; }
+    }
+  }
+  // CalcMeshDiameter (:47-60): float, O(V^2)
+  {
+    float best = 0.0f;
+    const float *v = m->vertices.data();
+    for (size_t i = 0; i < V; i++)
+      for (size_t j = i + 1; j < V; j++) {
+        float dx = v[i * 3] - v[j * 3], dy = v[i * 3 + 1] - v[j * 3 + 1], dz = v[i * 3 + 2] - v[j * 3 + 2];
+        float d = dx * dx + dy * dy + dz * dz;
+        if (d > best) best = d;
+      }
+    m->diameter = std::sqrt(best);
+  }
+  // FindMinMaxVertex + centre (:16-45,179-180)
+  {
+    float mn[3], mx[3];
+    for (int k = 0; k < 3; k++) mn[k] = mx[k] = m->vertices[k];
+    for (size_t i = 0; i < V; i++)
+      for (int k = 0; k < 3; k++) { mn[k] = std::min(mn[k], m->vertices[i * 3 + k]); mx[k] = std::max(mx[k], m->vertices[i * 3 + k]); }
+    for (int k = 0; k < 3; k++) m->center[k] = (float)((mx[k] + mn[k]) / 2.0);
+  }
+  // ComputeOBB (:62-114): mean, covariance / V, eigen-decomposition (ascending), extents of R^T v
+  {
+    double mean[3] = {0, 0, 0};
+    for (size_t i = 0; i < V; i++) for (int k = 0; k < 3; k++) mean[k] += m->vertices[i * 3 + k];
+    for (int k = 0; k < 3; k++) mean[k] /= (double)V;
+    double cov[9] = {0};
+    for (size_t i = 0; i < V; i++) {
+      double d[3] = {m->vertices[i * 3] - mean[0], m->vertices[i * 3 + 1] - mean[1], m->vertices[i * 3 + 2] - mean[2]};
+      for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) cov[a * 3 + b] += d[a] * d[b];
+    }
+    for (double &c : cov) c /= (double)V;
+    double ev[3], R[9];
+    eigen_sym3(cov, ev, R);
+    double mn[3] = {1e300, 1e300, 1e300}, mx[3] = {-1e300, -1e300, -1e300};
+    for (size_t i = 0; i < V; i++)
+      for (int j = 0; j < 3; j++) {
+        double pr = R[0 * 3 + j] * m->vertices[i * 3] + R[1 * 3 + j] * m->vertices[i * 3 + 1] + R[2 * 3 + j] * m->vertices[i * 3 + 2];
+        mn[j] = std::min(mn[j], pr); mx[j] = std::max(mx[j], pr);
+      }
+    for (int j = 0; j < 3; j++) m->dim[j] = (float)(mx[j] - mn[j]);
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) m->obb[c * 4 + r] = (float)R[r * 3 + c];
+    for (int r = 0; r < 3; r++) { m->obb[12 + r] = (float)mean[r]; m->obb[r * 4 + 3] = 0; }
+    m->obb[15] = 1;
+  }
+  // texture: MTL map_Kd of the first used material (or the first map_Kd found)
+  {
+    std::string tex_path;
+    if (!mtllib.empty()) {
+      std::ifstream mf(dirname_of(mesh_file_path) + "/" + mtllib);
+      std::string cur, l2, first_map;
+      while (mf && std::getline(mf, l2)) {
+        if (!l2.empty() && l2.back() == '\r') l2.pop_back();
+        std::istringstream ss(l2);
+        std::string tag;
+        if (!(ss >> tag)) continue;
+        if (tag == "newmtl") ss >> cur;
+        else if (tag == "map_Kd") {
+          std::string p;
+          std::getline(ss >> std::ws, p);
+          if (first_map.empty()) first_map = p;
+          if (tex_path.empty() && (usemtl.empty() || cur == usemtl)) tex_path = p;
+        }
+      }
+      if (tex_path.empty()) tex_path = first_map;
+      if (!tex_path.empty()) tex_path = dirname_of(mesh_file_path) + "/" + tex_path;
+    }
+    if (tex_path.empty() || !load_png_rgb(tex_path, m->texture, m->th, m->tw)) {
+      m->th = m->tw = 2;  // default texture map (:217-222)
+      m->texture.assign(12, 100);
+    }
+  }
+  m->view = fp_mesh{m->name.c_str(), (int)V, (int)(m->faces.size() / 3), m->vertices.data(), m->normals.data(),
+                    m->texcoords.data(), m->faces.data(), m->texture.data(), m->th, m->tw, m->diameter,
+                    {m->center[0], m->center[1], m->center[2]}};
+  return m;
+}
+
+void fp_mesh_free(fp_loaded_mesh *m) { delete m; }
+
+const fp_mesh *fp_mesh_view(const fp_loaded_mesh *m) { return m ? &m->view : nullptr; }
+
+int fp_mesh_orient_bounds(const fp_loaded_mesh *m, float orient_bounds[16], float dimension[3]) {
+  if (!m) { fp::set_error("null mesh"); return 1; }
+  if (orient_bounds) std::memcpy(orient_bounds, m->obb, sizeof(float) * 16);
+  if (dimension) std::memcpy(dimension, m->dim, sizeof(float) * 3);
+  return 0;
+}
+
+}  // extern "C"

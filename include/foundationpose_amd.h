@@ -51,6 +51,17 @@ typedef struct fp_mesh {
   float center[3];           /* GetMeshModelCenter() */
 } fp_mesh;
 
+/* ---- mesh loading: CreateAssimpMeshLoader(name, mesh_file_path) (mesh_loader.hpp:92-93, src/mesh_loader/assimp_mesh_loader.cpp:159-228)
+ * without assimp/OpenCV: Wavefront OBJ + MTL map_Kd + 8-bit PNG.  Returns NULL (+ fp_last_error) where the reference throws:
+ * empty path, unreadable file, no texture coordinates.  Missing texture -> 2x2 (100,100,100) like the reference. */
+typedef struct fp_loaded_mesh fp_loaded_mesh;
+fp_loaded_mesh *fp_mesh_load_obj(const char *name, const char *mesh_file_path);
+void fp_mesh_free(fp_loaded_mesh *mesh);
+/* all BaseMeshLoader getters as one fp_mesh view (valid until fp_mesh_free) */
+const fp_mesh *fp_mesh_view(const fp_loaded_mesh *mesh);
+/* GetOrientBounds() (column-major 4x4: PCA axes | vertex mean) and GetObjectDimension() */
+int fp_mesh_orient_bounds(const fp_loaded_mesh *mesh, float orient_bounds[16], float dimension[3]);
+
 /* ---- construction: CreateFoundationPoseModel (D6F/include/.../foundationpose.hpp:99-105, src/foundationpose.cpp:108-153,448-458).
  * refiner_weights / scorer_weights: paths of packed weight files (tools/pack_weights.py; replaces the TensorRT
  * engines of simple_tests/src/test_foundationpose.cpp:13-14).  NULL = geometry-only model (NN entry points fail). */

@@ -31,6 +31,26 @@ struct Mesh {  // what BaseMeshLoader's getters return (mesh_loader.hpp:25-61)
   float center[3] = {0, 0, 0};
 };
 
+// CreateAssimpMeshLoader(name, path) equivalent (mesh_loader.hpp:92-93): OBJ + MTL + PNG; throws like the reference
+inline Mesh LoadObjMesh(const std::string &name, const std::string &mesh_file_path, float *orient_bounds16 = nullptr,
+                        float *dimension3 = nullptr) {
+  fp_loaded_mesh *h = fp_mesh_load_obj(name.c_str(), mesh_file_path.c_str());
+  if (!h) throw std::runtime_error(fp_last_error());
+  const fp_mesh *v = fp_mesh_view(h);
+  Mesh m;
+  m.name = name;
+  m.vertices.assign(v->vertices, v->vertices + (size_t)v->num_vertices * 3);
+  m.normals.assign(v->normals, v->normals + (size_t)v->num_vertices * 3);
+  m.texcoords.assign(v->texcoords, v->texcoords + (size_t)v->num_vertices * 2);
+  m.faces.assign(v->faces, v->faces + (size_t)v->num_faces * 3);
+  m.texture.assign(v->texture, v->texture + (size_t)v->tex_height * v->tex_width * 3);
+  m.tex_height = v->tex_height; m.tex_width = v->tex_width; m.diameter = v->diameter;
+  for (int k = 0; k < 3; k++) m.center[k] = v->center[k];
+  fp_mesh_orient_bounds(h, orient_bounds16, dimension3);
+  fp_mesh_free(h);
+  return m;
+}
+
 class FoundationPose {
 public:
   // CreateFoundationPoseModel (foundationpose.hpp:99-105); throws std::runtime_error like the reference constructor

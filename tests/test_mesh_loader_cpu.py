@@ -1,0 +1,112 @@
+"""Mesh loader (C ABI fp_mesh_load_obj) against an independent numpy/PIL restatement of AssimpMeshLoader's contract
+(reference detection_6d_foundationpose/src/mesh_loader/assimp_mesh_loader.cpp:16-114,159-228).  Pure host code: runs on CPU."""
+import os
+
+import numpy as np
+import pytest
+from PIL import Image
+
+from foundationpose_cpp_amd import FoundationPoseError, load_mesh, synthetic as syn
+from oracle import fp_oracle as fo
+
+
+def _write_obj(d, mesh, with_normals=True, with_uv=True, texture="tex.png", quads=False):
+    v, n, uv, f = mesh.vertices, mesh.normals, mesh.texcoords, mesh.faces
+    with open(os.path.join(d, "m.mtl"), "w") as fh:
+        fh.write("newmtl mat0\nKd 1 1 1\n" + (f"map_Kd {texture}\n" if texture else ""))
+    with open(os.path.join(d, "m.obj"), "w") as fh:
+        fh.write("# test\nmtllib m.mtl\no first\n")
+        for p in v:
+            fh.write("v %.9g %.9g %.9g\n" % tuple(p))
+        if with_uv:
+            for p in uv:
+                fh.write("vt %.9g %.9g\n" % tuple(p))
+        if with_normals:
+            for p in n:
+                fh.write("vn %.9g %.9g %.9g\n" % tuple(p))
+        fh.write("usemtl mat0\n")
+        for a, b, c in f + 1:
+            def tok(i):
+                return f"{i}/{i if with_uv else ''}/{i if with_normals else ''}" if (with_uv or with_normals) else f"{i}"
+            fh.write(f"f {tok(a)} {tok(b)} {tok(c)}\n")
+        if quads:
+            fh.write("f 1/1/1 2/2/2 3/3/3 4/4/4\n")
+        fh.write("o second\nf 1/1/1 2/2/2 3/3/3\n")       # later objects are ignored (mMeshes[0] only)
+    return os.path.join(d, "m.obj")
+
+
+@pytest.fixture()
+def small_mesh():
+    return syn.make_mesh(subdiv=2, offset=(0.01, -0.02, 0.03))   # 162 vertices, off-centre
+
+
+def test_roundtrip_matches_source_and_reference_statistics(tmp_path, small_mesh):
+    Image.fromarray(small_mesh.texture).save(tmp_path / "tex.png")
+    m = load_mesh("obj", _write_obj(str(tmp_path), small_mesh))
+    # vertices are emitted in order of first use by the faces (identical (v,vt,vn) tuples merged), so compare per corner
+    assert len(m.vertices) == len(small_mesh.vertices) and m.faces.shape == small_mesh.faces.shape
+    np.testing.assert_allclose(m.vertices[m.faces], small_mesh.vertices[small_mesh.faces], rtol=1e-6)
+    np.testing.assert_allclose(m.normals[m.faces], small_mesh.normals[small_mesh.faces], rtol=1e-6)
+    np.testing.assert_allclose(m.texcoords[m.faces], small_mesh.texcoords[small_mesh.faces], rtol=1e-6)
+    first_use = np.unique(m.faces.ravel(), return_index=True)[1]
+    assert (np.diff(first_use) > 0).all()                                   # ids are assigned in order of first use
+    np.testing.assert_array_equal(m.texture, small_mesh.texture)            # PNG decode (RGB, filters) bit exact
+    # CalcMeshDiameter / FindMinMaxVertex vs the oracle restatement
+    assert m.diameter == pytest.approx(fo.mesh_diameter(m.vertices), rel=1e-6)
+    np.testing.assert_allclose(m.center, fo.mesh_center(m.vertices), atol=1e-7)
+    # ComputeOBB: PCA of the vertex cloud, eigenvalues ascending, dimension = extent along each axis
+    v = m.vertices.astype(np.float64)
+    mean = v.mean(0)
+    cov = (v - mean).T @ (v - mean) / len(v)
+    w, R = np.linalg.eigh(cov)
+    got_R = m.orient_bounds[:3, :3].astype(np.float64)
+    np.testing.assert_allclose(m.orient_bounds[:3, 3], mean, atol=1e-6)
+    np.testing.assert_allclose(np.abs(got_R.T @ R), np.eye(3), atol=1e-4)    # same axes up to sign
+    np.testing.assert_allclose(got_R.T @ got_R, np.eye(3), atol=1e-6)
+    proj = v @ got_R
+    np.testing.assert_allclose(m.dimension, proj.max(0) - proj.min(0), rtol=1e-5)
+    assert m.dimension[0] <= m.dimension[1] <= m.dimension[2]                # ascending eigenvalues: ellipsoid axes
+
+
+def test_png_variants_and_fallback_texture(tmp_path, small_mesh):
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, size=(37, 53, 3), dtype=np.uint8)
+    for mode, name in (("RGB", "a.png"), ("RGBA", "b.png"), ("L", "c.png"), ("P", "d.png")):
+        im = Image.fromarray(img).convert(mode)
+        im.save(tmp_path / name)
+        m = load_mesh("obj", _write_obj(str(tmp_path), small_mesh, texture=name))
+        np.testing.assert_array_equal(m.texture, np.asarray(Image.open(tmp_path / name).convert("RGB")))
+    # missing file / no map_Kd -> 2x2 (100,100,100) (assimp_mesh_loader.cpp:217-222)
+    for tex in ("nope.png", None):
+        m = load_mesh("obj", _write_obj(str(tmp_path), small_mesh, texture=tex))
+        assert m.texture.shape == (2, 2, 3) and (m.texture == 100).all()
+
+
+def test_error_behaviour_and_edge_cases(tmp_path, small_mesh):
+    with pytest.raises(FoundationPoseError, match="empty mesh_file_path"):
+        load_mesh("x", "")
+    with pytest.raises(FoundationPoseError, match="Failed to read mesh file"):
+        load_mesh("x", str(tmp_path / "missing.obj"))
+    with pytest.raises(FoundationPoseError, match="invalid texturecoords"):
+        load_mesh("x", _write_obj(str(tmp_path), small_mesh, with_uv=False))
+    # no normals in the file -> area-weighted vertex normals (unit length, outward for the convex test mesh)
+    m = load_mesh("x", _write_obj(str(tmp_path), small_mesh, with_normals=False))
+    np.testing.assert_allclose(np.linalg.norm(m.normals, axis=1), 1, atol=1e-5)
+    c = m.vertices - m.center
+    assert ((m.normals * c).sum(1) > 0).all()
+    # polygon faces are fan-triangulated (aiProcess_Triangulate)
+    m = load_mesh("x", _write_obj(str(tmp_path), small_mesh, quads=True))
+    assert len(m.faces) == len(small_mesh.faces) + 2
+    quad = small_mesh.vertices[:4]
+    np.testing.assert_allclose(m.vertices[m.faces[-2]], quad[[0, 1, 2]], rtol=1e-6)
+    np.testing.assert_allclose(m.vertices[m.faces[-1]], quad[[0, 2, 3]], rtol=1e-6)
+
+
+def test_shared_position_distinct_uv_splits_vertex(tmp_path):
+    # one position used with two different uvs -> two vertices (tuple-identity merge rule)
+    with open(tmp_path / "s.obj", "w") as fh:
+        fh.write("v 0 0 0\nv 1 0 0\nv 0 1 0\nv 1 1 0\nvt 0 0\nvt 1 0\nvt 0 1\nvt 0.5 0.5\nvn 0 0 1\n"
+                 "f 1/1/1 2/2/1 3/3/1\nf 2/4/1 4/1/1 3/3/1\n")
+    m = load_mesh("s", str(tmp_path / "s.obj"))
+    assert len(m.vertices) == 5 and len(m.faces) == 2
+    np.testing.assert_array_equal(m.faces, [[0, 1, 2], [3, 4, 2]])
