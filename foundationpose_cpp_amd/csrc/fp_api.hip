@@ -300,8 +300,10 @@ static int check_frame_args(fp_model *m, int H, int W, const char *target_name, 
 }
 
 // render + crop for N poses already in m->poses_dev; writes the fp16 network input (both halves) or fp32 blobs
+// n_crop: number of observed crops to produce (N, or 1 when every hypothesis shares the same translation)
 static int render_and_crop(fp_model *m, Target *t, int N, float crop_ratio, OutMode mode, void *out_a, void *out_b,
-                           int32_t *dbg_tri, float *dbg_rast) {
+                           int32_t *dbg_tri, float *dbg_rast, int n_crop = -1) {
+  if (n_crop < 0) n_crop = N;
   hipStream_t s = m->stream;
   const size_t out_bytes = (mode == OUT_F32X6 ? 24.0 : 16.0) * FP_CROP_HW * FP_CROP_HW;
   {
@@ -317,8 +319,8 @@ static int render_and_crop(fp_model *m, Target *t, int N, float crop_ratio, OutM
     launch_raster_shade(s, t->mesh, m->recs, N, m->clip, m->attr, mode, out_a, dbg_tri, dbg_rast);
   }
   if (out_b) {
-    ProfScope ps(&m->prof, s, "crop_warp", 0, (double)N * out_bytes);
-    launch_crop(s, m->rgb, m->depth, m->H, m->W, m->K, m->recs, N, t->mesh.diameter, mode, out_b);
+    ProfScope ps(&m->prof, s, "crop_warp", 0, (double)n_crop * out_bytes);
+    launch_crop(s, m->rgb, m->depth, m->H, m->W, m->K, m->recs, n_crop, t->mesh.diameter, mode, out_b);
   }
   FP_HIP_OK(hipGetLastError());
   return 0;
@@ -631,12 +633,15 @@ int fp_argmax(fp_model *m, const float *scores, int N, int *index_out) {
 }
 
 // one refine iteration over m->poses_dev[0..N): RefinePreProcess + SyncInfer + RefinePostProcess, all on device
-static int refine_iteration(fp_model *m, Target *t, int N) {
+// shared_b: all N poses have the same translation (fresh sampler output), so the observed crop -- which depends only on
+// the translation (foundationpose_render.cpp:59, foundationpose_render.cu:78-80) -- is computed and encoded once.
+static int refine_iteration(fp_model *m, Target *t, int N, bool shared_b) {
   const size_t half = (size_t)N * FP_NN_IN_IMG_HALFS;
   if (render_and_crop(m, t, N, 1.2f /* refine_mode_crop_ratio_ foundationpose.cpp:87 */, OUT_F16X8, m->nn_in,
-                      m->nn_in + half, nullptr, nullptr))
+                      m->nn_in + half, nullptr, nullptr, shared_b ? 1 : N))
     return 1;
-  if (refiner_forward(m->stream, &m->prof, m->refiner, m->ws, m->nn_in, N, m->trans_dev, m->rot_dev)) return 1;
+  if (refiner_forward(m->stream, &m->prof, m->refiner, m->ws, m->nn_in, N, m->trans_dev, m->rot_dev, shared_b ? 1 : 0))
+    return 1;
   ProfScope ps(&m->prof, m->stream, "pose_update");
   launch_pose_update(m->stream, m->poses_dev, m->trans_dev, m->rot_dev, N, t->mesh.diameter);
   return 0;
@@ -661,7 +666,7 @@ int fp_register_shard_begin(fp_model *m, const void *rgb, const void *depth, con
   const int N = shard_count;
   if (upload_poses(m, t, poses.data() + (size_t)shard_begin * 16, N)) return 1;
   for (int it = 0; it < refine_itr; it++)
-    if (refine_iteration(m, t, N)) return 1;
+    if (refine_iteration(m, t, N, it == 0 && N > 1)) return 1;  // sampler output: one translation for all hypotheses
   const size_t half = (size_t)N * FP_NN_IN_IMG_HALFS;
   if (render_and_crop(m, t, N, 1.1f /* score_mode_crop_ratio_ foundationpose.cpp:88 */, OUT_F16X8, m->nn_in,
                       m->nn_in + half, nullptr, nullptr))
@@ -724,7 +729,7 @@ int fp_track_ex(fp_model *m, const void *rgb, const void *depth, int memspace, i
   if (fp_upload_frame(m, rgb, depth, memspace, H, W)) return 1;
   if (upload_poses(m, t, hyp_pose, 1)) return 1;
   for (int it = 0; it < refine_itr; it++)
-    if (refine_iteration(m, t, 1)) return 1;
+    if (refine_iteration(m, t, 1, false)) return 1;
   FP_HIP_OK(hipMemcpyAsync(out_pose, m->poses_dev, 64, hipMemcpyDeviceToHost, m->stream));
   FP_HIP_OK(hipStreamSynchronize(m->stream));
   return 0;

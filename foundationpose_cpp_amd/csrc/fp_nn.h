@@ -20,8 +20,9 @@ void nn_scratch_free(NNScratch *);
 // Network input: nn_in = f16 [2N,80,80,32]: space-to-depth(2x2) view of the NHWC [2N,160,160,8] tensor
 // (channels r,g,b,x,y,z,0,0), rendered crops A in images [0,N), observed crops B in [N,2N).
 // Outputs are device pointers.
+// shared_b != 0: all N hypotheses share ONE observed crop, stored as image N of nn_in (Register's first refine iteration)
 int refiner_forward(hipStream_t s, Profiler *prof, const Net *net, NNScratch *ws, const __half *nn_in, int N,
-                    float *trans_dev /*[N,3]*/, float *rot_dev /*[N,3]*/);
+                    float *trans_dev /*[N,3]*/, float *rot_dev /*[N,3]*/, int shared_b = 0);
 int scorer_features(hipStream_t s, Profiler *prof, const Net *net, NNScratch *ws, const __half *nn_in, int N,
                     float *feat_dev /*[N,512]*/);
 int scorer_head(hipStream_t s, Profiler *prof, const Net *net, NNScratch *ws, const float *feats_dev, int n_total,

@@ -545,6 +545,23 @@ __global__ __launch_bounds__(256) void small_linear_kernel(const float *__restri
   if (lane == 0) y[widx] = s + bias[o];
 }
 
+// cat[i][:, :, C:2C] = cat[0][:, :, C:2C] for i in 1..N-1 (bordered [N,HP,WP,2C] tensor, interior pixels only).
+// Used when every hypothesis shares one observed crop (Register's first refine iteration: the sampler gives all 252
+// poses the same translation, foundationpose_sampling.cpp:388-391, so transf_input is identical for all of them).
+__global__ void broadcast_b_kernel(__half *__restrict__ cat, int N, int HP, int WP, int H, int W, int pad, int C) {
+  const int chunks = C / 8;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t per_img = (size_t)H * W * chunks;
+  if (i >= per_img * (size_t)(N - 1)) return;
+  int img = 1 + (int)(i / per_img);
+  size_t r = i - (size_t)(img - 1) * per_img;
+  int pix = (int)(r / chunks), ch = (int)(r - (size_t)pix * chunks);
+  int y = pix / W, x = pix - y * W;
+  size_t off = (((size_t)(y + pad)) * WP + (x + pad)) * (2 * C) + C + ch * 8;
+  const size_t img_stride = (size_t)HP * WP * 2 * C;
+  *reinterpret_cast<h8 *>(cat + (size_t)img * img_stride + off) = *reinterpret_cast<const h8 *>(cat + off);
+}
+
 __global__ void cast_f32_f16_kernel(const float *__restrict__ in, __half *__restrict__ out, size_t n) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = __float2half(in[i]);
@@ -978,9 +995,10 @@ static Arena carve(NNScratch *ws) {
 }
 
 // shared CNN trunk: nn_in [2N,84,84,32] (s2d, border 2) -> tokens [N,400,512] + positional embedding
-static int run_trunk(const Ctx &c, const Arena &a, const __half *nn_in, int N) {
+// n_b = number of observed-crop (B) images following the N rendered (A) images: N, or 1 when all hypotheses share it
+static int run_trunk(const Ctx &c, const Arena &a, const __half *nn_in, int N, int n_b) {
   const Net *net = c.net;
-  const int NB2 = 2 * N;
+  const int NB2 = N + n_b;
   if (run_conv(c, "conv_stem", net->a0, nn_in, NB2, 80, 80, 2, a.stem, 1, true)) return 1;
   if (run_conv(c, "conv_a1", net->a1, a.stem, NB2, 80, 80, 1, a.x128[0], 1, true)) return 1;
   // encodeA residual blocks @40x40x128; the last conv writes the a|b channel concat directly
@@ -988,6 +1006,11 @@ static int run_trunk(const Ctx &c, const Arena &a, const __half *nn_in, int N) {
   if (run_conv(c, "conv_128", net->ra[0][1], a.x128[1], NB2, 40, 40, 1, a.x128[2], 1, true, a.x128[0], 1)) return 1;
   if (run_conv(c, "conv_128", net->ra[1][0], a.x128[2], NB2, 40, 40, 1, a.x128[1], 1, true)) return 1;
   if (run_conv(c, "conv_128", net->ra[1][1], a.x128[1], NB2, 40, 40, 1, a.x256[0], 1, true, a.x128[2], 1, N)) return 1;
+  if (n_b == 1 && N > 1) {  // image N landed in cat[0][..,128:256]; replicate it for the other hypotheses
+    ProfScope ps(c.prof, c.s, "broadcast_b", 0, (double)N * 1600 * 256);
+    size_t total = (size_t)(N - 1) * 1600 * 16;
+    hipLaunchKernelGGL(broadcast_b_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c.s, a.x256[0], N, 42, 42, 40, 40, 1, 128);
+  }
   // encodeAB
   if (run_conv(c, "conv_256", net->rb[0][0], a.x256[0], N, 40, 40, 1, a.x256[1], 1, true)) return 1;
   if (run_conv(c, "conv_256", net->rb[0][1], a.x256[1], N, 40, 40, 1, a.x256[2], 1, true, a.x256[0], 1)) return 1;
@@ -1009,12 +1032,12 @@ static int run_trunk(const Ctx &c, const Arena &a, const __half *nn_in, int N) {
 }
 
 int refiner_forward(hipStream_t s, Profiler *prof, const Net *net, NNScratch *ws, const __half *nn_in, int N,
-                    float *trans_dev, float *rot_dev) {
+                    float *trans_dev, float *rot_dev, int shared_b) {
   FP_CHECK(net && !net->scorer, "refiner_forward: wrong network");
   if (ensure_scratch(ws, N, s)) return 1;
   Ctx c{s, prof, net};
   const Arena a = carve(ws);
-  if (run_trunk(c, a, nn_in, N)) return 1;
+  if (run_trunk(c, a, nn_in, N, shared_b ? 1 : N)) return 1;
   const __half *x = a.tokens;
   const size_t rows = (size_t)N * 400;
   const EncLayer *heads[2] = {&net->trans, &net->rot};
@@ -1041,7 +1064,7 @@ int scorer_features(hipStream_t s, Profiler *prof, const Net *net, NNScratch *ws
   if (ensure_scratch(ws, N, s)) return 1;
   Ctx c{s, prof, net};
   const Arena a = carve(ws);
-  if (run_trunk(c, a, nn_in, N)) return 1;
+  if (run_trunk(c, a, nn_in, N, N)) return 1;
   const size_t rows = (size_t)N * 400;
   if (run_gemm(c, "gemm_qkv", net->att.in_proj, a.tokens, (int)rows, a.qkv, false)) return 1;
   if (run_attention(c, a.qkv, a.att, N, 400)) return 1;

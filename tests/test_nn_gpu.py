@@ -223,3 +223,28 @@ def test_register_end_to_end_252(model, nets, syn_mesh, syn_scene):
     # mismatching sizes -> False like CheckInputArguments
     ok, _ = model.Register(syn_scene.rgb, syn_scene.depth[:100], syn_scene.mask, syn_mesh.name)
     assert not ok
+
+
+def test_register_two_refine_iterations_matches_oracle(model, nets, syn_mesh, syn_scene):
+    """refine_itr = 2: iteration 0 uses the shared observed crop (one translation for all hypotheses), iteration 1 the
+    per-hypothesis crops; both must agree with the oracle pipeline that always computes every crop."""
+    n = 252
+    ok, pose = model.Register(syn_scene.rgb, syn_scene.depth, syn_scene.mask, syn_mesh.name, refine_itr=2)
+    assert ok, model.last_error
+    om = fo.OracleMesh(syn_mesh)
+    poses = fo.get_hyp_poses(syn_scene.depth, syn_scene.mask, syn_scene.K)[:n]
+    for _ in range(2):
+        a = fo.render(om, poses, syn_scene.K, syn_scene.depth.shape, 1.2)
+        b = fo.crop(syn_scene.rgb, syn_scene.depth, syn_scene.K, poses, 1.2, syn_mesh.diameter)
+        with torch.no_grad():
+            t, r = nets[2](torch.from_numpy(a), torch.from_numpy(b))
+        poses = fo.refine_post_process(poses, t.numpy(), r.numpy(), syn_mesh.diameter)
+    a = fo.render(om, poses, syn_scene.K, syn_scene.depth.shape, 1.1)
+    b = fo.crop(syn_scene.rgb, syn_scene.depth, syn_scene.K, poses, 1.1, syn_mesh.diameter)
+    with torch.no_grad():
+        s = nets[3](torch.from_numpy(a), torch.from_numpy(b)).numpy()
+    refined = syn.from_colmajor(poses)
+    errs = [_pose_err(pose, r) for r in refined]
+    idx = int(np.argmin([e[0] + 1e3 * e[1] for e in errs]))
+    assert errs[idx][0] < 0.2 and errs[idx][1] < 2e-4, errs[idx]
+    assert s[idx] >= s.max() - 5e-3
