@@ -69,12 +69,13 @@ struct ConvParams {
               // are consecutive K-steps and their overlapping input pixels are re-read while still L2-resident
   // byte offset of K-step kt's X slab relative to a row's (tap 0, channel 0) address; host-filled, read with s_load
   unsigned koff[80];
+  unsigned long long *clk;  // optional clock probe: per block {cycles0, realtime0, cycles1, realtime1}
 };
 
 // Activations carry a physical zero border, so the K loop has no bounds checks, no selects and no divergent
 // branches: a tap's operand address is (wave-uniform tap/chunk offset in SGPRs) + (per-lane row offset fixed for the
 // whole kernel), which is exactly the saddr + voffset form of global_load_lds.
-template <int BN>
+template <int BN, int VAR = 0>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int BM = 128;
@@ -87,6 +88,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave & 1, wn = wave >> 1;
+  if (p.clk && tid == 0) { p.clk[blockIdx.x * 4] = __builtin_readcyclecounter(); p.clk[blockIdx.x * 4 + 1] = wall_clock64(); }
   const int n_tiles = p.Cout / BN;
   // XCD-aware tile order: hardware places workgroup b on XCD b%8 (speed-only assumption).  Remap so each XCD walks a
   // contiguous range of logical tiles: the n-tiles of one m-tile (same X rows) and neighbouring m-tiles (shared halo
@@ -157,6 +159,27 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
 
   auto compute = [&](int buf) {
     const unsigned char *sb = smem + buf * STAGE;
+    if (VAR & 2) {
+      // all 16 fragment reads of the K-step are issued up front: only the first LDS round trip is exposed
+      h8 xf[2][4], wf[2][NREP];
+#pragma unroll
+      for (int ks = 0; ks < 2; ks++) {
+#pragma unroll
+        for (int mi = 0; mi < 4; mi++) xf[ks][mi] = *reinterpret_cast<const h8 *>(sb + xfo[ks] + mi * 16 * 128);
+#pragma unroll
+        for (int ni = 0; ni < NREP; ni++) wf[ks][ni] = *reinterpret_cast<const h8 *>(sb + wfo[ks] + ni * 16 * 128);
+      }
+      if (VAR & 1) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+        for (int ni = 0; ni < NREP; ni++)
+#pragma unroll
+          for (int mi = 0; mi < 4; mi++)
+            acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ks][ni], xf[ks][mi], acc[ni][mi], 0, 0, 0);
+      if (VAR & 1) __builtin_amdgcn_s_setprio(0);
+      return;
+    }
 #pragma unroll
     for (int ks = 0; ks < 2; ks++) {
       h8 xf[4], wf[NREP];
@@ -164,11 +187,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
       for (int mi = 0; mi < 4; mi++) xf[mi] = *reinterpret_cast<const h8 *>(sb + xfo[ks] + mi * 16 * 128);
 #pragma unroll
       for (int ni = 0; ni < NREP; ni++) wf[ni] = *reinterpret_cast<const h8 *>(sb + wfo[ks] + ni * 16 * 128);
+      if (VAR & 1) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int ni = 0; ni < NREP; ni++)
 #pragma unroll
         for (int mi = 0; mi < 4; mi++)
           acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ni], xf[mi], acc[ni][mi], 0, 0, 0);
+      if (VAR & 1) __builtin_amdgcn_s_setprio(0);
     }
   };
 
@@ -183,6 +208,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
   }
   compute((KT - 1) & 1);
 
+  if (p.clk && tid == 0) { p.clk[blockIdx.x * 4 + 2] = __builtin_readcyclecounter(); p.clk[blockIdx.x * 4 + 3] = wall_clock64(); }
   // ---- epilogue: lane owns channels cb..cb+3 (cb = 4*(lane>>4)) of pixel (lane&15) in each 16x16 tile
   const int OHp = p.OH + 2 * p.opad, OWp = p.OW + 2 * p.opad;
   const int RHp = p.OH + 2 * p.rpad, RWp = p.OW + 2 * p.rpad;
@@ -236,6 +262,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm3_kernel(const ConvParams p)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave & 3, wn = wave >> 2;
+  if (p.clk && tid == 0) { p.clk[blockIdx.x * 4] = __builtin_readcyclecounter(); p.clk[blockIdx.x * 4 + 1] = wall_clock64(); }
   const int n_tiles = p.Cout / BN;
   int logical;
   {
@@ -298,19 +325,23 @@ __global__ __launch_bounds__(512, 2) void conv_igemm3_kernel(const ConvParams p)
 
   auto compute = [&](int buf) {
     const unsigned char *sb = smem + buf * STAGE;
+    h8 xf[2][4], wf[2][NREP];
 #pragma unroll
     for (int ks = 0; ks < 2; ks++) {
-      h8 xf[4], wf[NREP];
 #pragma unroll
-      for (int mi = 0; mi < 4; mi++) xf[mi] = *reinterpret_cast<const h8 *>(sb + xfo[ks] + mi * 16 * 128);
+      for (int mi = 0; mi < 4; mi++) xf[ks][mi] = *reinterpret_cast<const h8 *>(sb + xfo[ks] + mi * 16 * 128);
 #pragma unroll
-      for (int ni = 0; ni < NREP; ni++) wf[ni] = *reinterpret_cast<const h8 *>(sb + wfo[ks] + ni * 16 * 128);
+      for (int ni = 0; ni < NREP; ni++) wf[ks][ni] = *reinterpret_cast<const h8 *>(sb + wfo[ks] + ni * 16 * 128);
+    }
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++)
 #pragma unroll
       for (int ni = 0; ni < NREP; ni++)
 #pragma unroll
         for (int mi = 0; mi < 4; mi++)
-          acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ni], xf[mi], acc[ni][mi], 0, 0, 0);
-    }
+          acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ks][ni], xf[ks][mi], acc[ni][mi], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
   };
 
   const int KT = p.Ktot >> 6;  // >= 8 for every layer of the networks
@@ -332,6 +363,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm3_kernel(const ConvParams p)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   compute(rb);
+  if (p.clk && tid == 0) { p.clk[blockIdx.x * 4 + 2] = __builtin_readcyclecounter(); p.clk[blockIdx.x * 4 + 3] = wall_clock64(); }
 
   const int OHp = p.OH + 2 * p.opad, OWp = p.OW + 2 * p.opad;
   const int RHp = p.OH + 2 * p.rpad, RWp = p.OW + 2 * p.rpad;
@@ -390,21 +422,32 @@ __global__ __launch_bounds__(256) void attention_kernel(const __half *__restrict
   const float scale = 0.08838834764831845f;  // 1/sqrt(128)
 
   const int nkb = (T + 31) / 32;
-  for (int kb = 0; kb < nkb; kb++) {
-    // cooperative K / V^T tile load
+  // staging roles.  K: thread -> (key = idx>>4, 16-B chunk = idx&15): coalesced 256-B rows.  V: thread -> (key = idx&31,
+  // chunk = idx>>5) so the 2-byte transposed LDS writes of one instruction cover 32 consecutive keys of one d row
+  // (bank-conflict free; the previous key-major mapping was a 16-way conflict on every ds_write_b16).
+  h8 kreg[2], vreg[2];
+  auto load_tile = [&](int kb) {
 #pragma unroll
     for (int j = 0; j < 2; j++) {
       int idx = tid + j * 256;
-      int key = idx >> 4, chunk = idx & 15;
-      int krow = min(kb * 32 + key, T - 1);
-      const __half *src = base + (size_t)krow * rowstride + h * HDIM + chunk * 8;
-      h8 kv = *reinterpret_cast<const h8 *>(src + EMBED);
-      h8 vv = *reinterpret_cast<const h8 *>(src + 2 * EMBED);
-      *reinterpret_cast<h8 *>(&Ks[key * KS + chunk * 8]) = kv;
+      int krow = min(kb * 32 + (idx >> 4), T - 1);
+      kreg[j] = *reinterpret_cast<const h8 *>(base + (size_t)krow * rowstride + EMBED + h * HDIM + (idx & 15) * 8);
+      int vrow = min(kb * 32 + (idx & 31), T - 1);
+      vreg[j] = *reinterpret_cast<const h8 *>(base + (size_t)vrow * rowstride + 2 * EMBED + h * HDIM + (idx >> 5) * 8);
+    }
+  };
+  load_tile(0);
+  for (int kb = 0; kb < nkb; kb++) {
 #pragma unroll
-      for (int e = 0; e < 8; e++) Vt[(chunk * 8 + e) * VS + key] = vv[e];
+    for (int j = 0; j < 2; j++) {
+      int idx = tid + j * 256;
+      *reinterpret_cast<h8 *>(&Ks[(idx >> 4) * KS + (idx & 15) * 8]) = kreg[j];
+      int key = idx & 31, chunk = idx >> 5;
+#pragma unroll
+      for (int e = 0; e < 8; e++) Vt[(chunk * 8 + e) * VS + key] = vreg[j][e];
     }
     __syncthreads();
+    if (kb + 1 < nkb) load_tile(kb + 1);  // next tile's global loads fly under this tile's MFMAs
     // S^T tiles: st[kt][r] = S[key = kt*16 + g*4 + r][q = li]
     f4 st[2];
 #pragma unroll
@@ -876,12 +919,14 @@ struct Ctx {
 };
 
 static bool g_conv_attr_done = false;
+static unsigned long long *g_clk_probe = nullptr;
 static int g_conv_variant = 0;  // 0 auto, 1 force the 128-pixel 2-stage kernel, 2 force the 256-pixel 3-stage kernel (A/B hook)
 
 // in: [NB, H+2*ipad, W+2*ipad, Cin]; out: [.., OH+2*opad, OW+2*opad, ..]; res: border rpad
 static int run_conv(const Ctx &c, const char *tag, const ConvLayer &L, const __half *in, int NB, int H, int W, int ipad,
                     __half *out, int opad, bool relu, const __half *res = nullptr, int rpad = 0, int split_imgs = 0) {
   ConvParams p;
+  p.clk = g_clk_probe;
   p.in = in; p.w = L.w; p.bias = L.bias; p.res = res; p.out = out;
   p.NB = NB; p.H = H; p.W = W; p.Cin = L.Cin;
   p.KH = L.KH; p.KW = L.KW; p.stride = L.stride; p.pad = L.pad;
@@ -915,8 +960,11 @@ static int run_conv(const Ctx &c, const char *tag, const ConvLayer &L, const __h
   double bytes = ((double)NB * H * W * L.Cin + (double)p.M * p.Cout * (res ? 2 : 1) + (double)p.Cout * p.Ktot) * 2.0;
   constexpr int LDS3_128 = 3 * (256 * 128 + 128 * 128), LDS3_64 = 3 * (256 * 128 + 64 * 128);
   if (!g_conv_attr_done) {
-    FP_HIP_OK(hipFuncSetAttribute((const void *)conv_igemm_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (128 * 128 + 128 * 128)));
-    FP_HIP_OK(hipFuncSetAttribute((const void *)conv_igemm_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (128 * 128 + 64 * 128)));
+    FP_HIP_OK(hipFuncSetAttribute((const void *)conv_igemm_kernel<128, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (128 * 128 + 128 * 128)));
+    FP_HIP_OK(hipFuncSetAttribute((const void *)conv_igemm_kernel<128, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (128 * 128 + 128 * 128)));
+    FP_HIP_OK(hipFuncSetAttribute((const void *)conv_igemm_kernel<128, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (128 * 128 + 128 * 128)));
+    FP_HIP_OK(hipFuncSetAttribute((const void *)conv_igemm_kernel<128, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (128 * 128 + 128 * 128)));
+    FP_HIP_OK(hipFuncSetAttribute((const void *)conv_igemm_kernel<64, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (128 * 128 + 64 * 128)));
     FP_HIP_OK(hipFuncSetAttribute((const void *)conv_igemm3_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS3_128));
     FP_HIP_OK(hipFuncSetAttribute((const void *)conv_igemm3_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS3_64));
     g_conv_attr_done = true;
@@ -926,7 +974,10 @@ static int run_conv(const Ctx &c, const char *tag, const ConvLayer &L, const __h
   const int KT = p.Ktot / 64;
   // large problems: 256-pixel tiles, 3-stage LDS-DMA pipeline (needs >= 3 K-steps and enough tiles to fill 256 CUs)
   const int big_tiles = ((p.M + 255) / 256) * (L.Cout % 128 == 0 ? L.Cout / 128 : L.Cout / 64);
-  if (g_conv_variant != 1 && KT >= 3 && (big_tiles >= 512 || g_conv_variant == 2)) {
+  (void)big_tiles;
+  // measured (tools/bench_conv.py, N=126): the 128-px 2-stage kernel beats the 256-px 3-stage one on every layer
+  // (756-769 vs 703-709 TF/s weighted), so the latter is only reachable through the A/B hook
+  if (g_conv_variant == 2 && KT >= 3) {
     int mt2 = (p.M + 255) / 256;
     if (L.Cout % 128 == 0)
       hipLaunchKernelGGL(conv_igemm3_kernel<128>, dim3(mt2 * (L.Cout / 128)), dim3(512), LDS3_128, c.s, p);
@@ -935,9 +986,17 @@ static int run_conv(const Ctx &c, const char *tag, const ConvLayer &L, const __h
     return 0;
   }
   if (L.Cout % 128 == 0) {
-    hipLaunchKernelGGL(conv_igemm_kernel<128>, dim3(mtiles * (L.Cout / 128)), dim3(256), 2 * (128 * 128 + 128 * 128), c.s, p);
+    const dim3 grid(mtiles * (L.Cout / 128));
+    const int lds = 2 * (128 * 128 + 128 * 128);
+    switch (g_conv_variant) {
+      case 11: hipLaunchKernelGGL((conv_igemm_kernel<128, 1>), grid, dim3(256), lds, c.s, p); break;
+      case 12: hipLaunchKernelGGL((conv_igemm_kernel<128, 2>), grid, dim3(256), lds, c.s, p); break;
+      case 13: hipLaunchKernelGGL((conv_igemm_kernel<128, 3>), grid, dim3(256), lds, c.s, p); break;
+      case 10: hipLaunchKernelGGL((conv_igemm_kernel<128, 0>), grid, dim3(256), lds, c.s, p); break;
+      default: hipLaunchKernelGGL((conv_igemm_kernel<128, 3>), grid, dim3(256), lds, c.s, p); break;
+    }
   } else {
-    hipLaunchKernelGGL(conv_igemm_kernel<64>, dim3(mtiles * (L.Cout / 64)), dim3(256), 2 * (128 * 128 + 64 * 128), c.s, p);
+    hipLaunchKernelGGL((conv_igemm_kernel<64, 3>), dim3(mtiles * (L.Cout / 64)), dim3(256), 2 * (128 * 128 + 64 * 128), c.s, p);
   }
   return 0;
 }
@@ -1129,6 +1188,31 @@ std::vector<__half> to_half(const float *src, size_t n) {
 extern "C" {
 
 void fpt_set_conv_variant(int v) { fp::g_conv_variant = v; }
+
+// clock probe: allocate room for `blocks` records, run convs, then read back mean shader MHz and mean main-loop cycles
+int fpt_clk_probe(int blocks, double *mhz_out, double *loop_cycles_out) {
+  using namespace fp;
+  if (blocks > 0) {
+    if (g_clk_probe) (void)hipFree(g_clk_probe);
+    FP_HIP_OK(hipMalloc((void **)&g_clk_probe, (size_t)blocks * 32));
+    FP_HIP_OK(hipMemset(g_clk_probe, 0, (size_t)blocks * 32));
+    return 0;
+  }
+  FP_CHECK(g_clk_probe, "no probe");
+  int n = -blocks;
+  std::vector<unsigned long long> h((size_t)n * 4);
+  FP_HIP_OK(hipDeviceSynchronize());
+  FP_HIP_OK(hipMemcpy(h.data(), g_clk_probe, h.size() * 8, hipMemcpyDeviceToHost));
+  double sc = 0, sr = 0; int cnt = 0;
+  for (int i = 0; i < n; i++) {
+    if (h[i * 4 + 3] > h[i * 4 + 1]) { sc += (double)(h[i * 4 + 2] - h[i * 4]); sr += (double)(h[i * 4 + 3] - h[i * 4 + 1]); cnt++; }
+  }
+  if (mhz_out) *mhz_out = sr > 0 ? sc / sr * 100.0 : 0;  // wall_clock64 ticks at 100 MHz
+  if (loop_cycles_out) *loop_cycles_out = cnt ? sc / cnt : 0;
+  (void)hipFree(g_clk_probe);
+  g_clk_probe = nullptr;
+  return 0;
+}
 
 // x [NB,H,W,Cin] NHWC f32, w [Cout,KH,KW,Cin] f32 (already in kernel layout), bias [Cout], res (optional) [NB,OH,OW,Cout]
 // -> out f32 [NB,OH,OW,Cout] (or, with split_imgs > 0, [NB-split,OH,OW,2*Cout]).  iters > 1: returns mean ms in *ms_out.
