@@ -21,6 +21,7 @@ namespace fp {
 
 static thread_local std::string g_last_error;
 void set_error(const std::string &msg) { g_last_error = msg; }
+unsigned long g_alloc_epoch = 0;
 
 // ------------------------------------------------------------------------------------------------
 // Profiler
@@ -245,6 +246,18 @@ struct fp_model {
   Net *refiner = nullptr, *scorer = nullptr;
   NNScratch *ws = nullptr;
 
+  // Track is launch-bound (~60 short kernels): after one eager call (allocations settle) the launch chain is captured
+  // into a hipGraph and replayed.  The graph bakes buffer addresses, so it is keyed by g_alloc_epoch.
+  struct TrackGraph {
+    hipGraphExec_t exec = nullptr;
+    hipGraph_t graph = nullptr;
+    Target *target = nullptr;
+    int H = 0, W = 0, itr = 0;
+    unsigned long epoch = 0;
+    int eager_calls = 0;
+  } tg;
+  bool use_graphs = true;
+
   Target *find(const char *name) {
     for (auto &t : targets)
       if (t.name == name) return &t;
@@ -253,8 +266,11 @@ struct fp_model {
   int n_hyp() const { return 42 * inplane_steps; }
 };
 
+static void drop_track_graph(fp_model *m);
+
 static int ensure_capacity(fp_model *m, int N, size_t V) {
   if (N > m->cap) {
+    g_alloc_epoch++;
     dev_free(m->recs); dev_free(m->poses_dev); dev_free(m->nn_in); dev_free(m->blob_a); dev_free(m->blob_b);
     dev_free(m->trans_dev); dev_free(m->rot_dev); dev_free(m->scores_dev); dev_free(m->feat_dev);
     dev_free(m->clip); dev_free(m->attr); dev_free(m->dbg_tri); dev_free(m->dbg_rast);
@@ -272,6 +288,7 @@ static int ensure_capacity(fp_model *m, int N, size_t V) {
     m->cap = cap;
   }
   if ((size_t)m->cap * V > m->vert_cap) {
+    g_alloc_epoch++;
     dev_free(m->clip); dev_free(m->attr);
     if (dev_alloc(&m->clip, (size_t)m->cap * V)) return 1;
     if (dev_alloc(&m->attr, (size_t)m->cap * V)) return 1;
@@ -398,6 +415,7 @@ fp_model *fp_create(const fp_mesh *meshes, int n_meshes, const float K[9], const
 void fp_destroy(fp_model *m) {
   if (!m) return;
   if (m->stream) (void)hipStreamSynchronize(m->stream);
+  drop_track_graph(m);
   m->prof.reset();
   for (auto &t : m->targets) {
     dev_free(t.mesh.verts); dev_free(t.mesh.normals); dev_free(t.mesh.uvs); dev_free(t.mesh.faces); dev_free(t.mesh.tex);
@@ -433,6 +451,7 @@ int fp_upload_frame(fp_model *m, const void *rgb, const void *depth, int memspac
   FP_CHECK(rgb && depth, "[FoundationPose] Got INVALID rgb/depth ptr");
   size_t px = (size_t)H * W;
   if (px > m->frame_cap) {
+    g_alloc_epoch++;
     dev_free(m->rgb_own); dev_free(m->depth_own); dev_free(m->erode); dev_free(m->bilat); dev_free(m->xyz);
     if (dev_alloc(&m->rgb_own, px * 3) || dev_alloc(&m->depth_own, px) || dev_alloc(&m->erode, px) ||
         dev_alloc(&m->bilat, px))
@@ -720,16 +739,70 @@ int fp_register(fp_model *m, const uint8_t *rgb, const float *depth, const uint8
   return fp_register_ex(m, rgb, depth, mask, FP_HOST, H, W, target_name, refine_itr, out_pose);
 }
 
+static void drop_track_graph(fp_model *m) {
+  if (m->tg.exec) (void)hipGraphExecDestroy(m->tg.exec);
+  if (m->tg.graph) (void)hipGraphDestroy(m->tg.graph);
+  m->tg.exec = nullptr; m->tg.graph = nullptr; m->tg.eager_calls = 0;
+}
+
 int fp_track_ex(fp_model *m, const void *rgb, const void *depth, int memspace, int H, int W, const float hyp_pose[16],
                 const char *target_name, int refine_itr, float out_pose[16]) {
   Target *t = nullptr;
   if (check_frame_args(m, H, W, target_name ? target_name : "", &t)) return 1;
   FP_CHECK(m->refiner, "[FoundationPose] refiner weights not loaded");
   FP_CHECK(hyp_pose && out_pose, "[FoundationPose] Track: null pose");
-  if (fp_upload_frame(m, rgb, depth, memspace, H, W)) return 1;
+  const bool graphable = m->use_graphs && !m->prof.on && refine_itr >= 1;
+  if (graphable) {
+    // the graph reads the frame from the model's own buffers, so a caller's device frame is copied in (2 MB D2D)
+    if (memspace == FP_DEVICE) {
+      // size the owned buffers without copying, then D2D
+      size_t px0 = (size_t)H * W;
+      if (px0 > m->frame_cap) {
+        g_alloc_epoch++;
+        dev_free(m->rgb_own); dev_free(m->depth_own); dev_free(m->erode); dev_free(m->bilat); dev_free(m->xyz);
+        if (dev_alloc(&m->rgb_own, px0 * 3) || dev_alloc(&m->depth_own, px0) || dev_alloc(&m->erode, px0) || dev_alloc(&m->bilat, px0)) return 1;
+        m->frame_cap = px0;
+      }
+      m->H = H; m->W = W; m->rgb = m->rgb_own; m->depth = m->depth_own;
+    } else if (fp_upload_frame(m, rgb, depth, FP_HOST, H, W)) {
+      return 1;
+    }
+    if (memspace == FP_DEVICE) {
+      const size_t px = (size_t)H * W;
+      FP_HIP_OK(hipMemcpyAsync(m->rgb_own, rgb, px * 3, hipMemcpyDeviceToDevice, m->stream));
+      FP_HIP_OK(hipMemcpyAsync(m->depth_own, depth, px * 4, hipMemcpyDeviceToDevice, m->stream));
+    }
+  } else {
+    if (fp_upload_frame(m, rgb, depth, memspace, H, W)) return 1;
+  }
   if (upload_poses(m, t, hyp_pose, 1)) return 1;
-  for (int it = 0; it < refine_itr; it++)
-    if (refine_iteration(m, t, 1, false)) return 1;
+  auto &g = m->tg;
+  const bool same = g.target == t && g.H == H && g.W == W && g.itr == refine_itr && g.epoch == g_alloc_epoch;
+  if (graphable && same && g.exec) {
+    FP_HIP_OK(hipGraphLaunch(g.exec, m->stream));
+  } else if (graphable && same && g.eager_calls >= 1) {
+    // second call with stable allocations: capture and run
+    drop_track_graph(m);
+    FP_HIP_OK(hipStreamBeginCapture(m->stream, hipStreamCaptureModeThreadLocal));
+    int rc = 0;
+    for (int it = 0; it < refine_itr && !rc; it++) rc = refine_iteration(m, t, 1, false);
+    hipError_t e = hipStreamEndCapture(m->stream, &g.graph);
+    if (rc || e != hipSuccess || hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0) != hipSuccess) {
+      drop_track_graph(m);
+      m->use_graphs = false;  // fall back to eager launches for good
+      for (int it = 0; it < refine_itr; it++)
+        if (refine_iteration(m, t, 1, false)) return 1;
+    } else {
+      g.eager_calls = 1;
+      FP_HIP_OK(hipGraphLaunch(g.exec, m->stream));
+    }
+  } else {
+    if (!same) { drop_track_graph(m); g.target = t; g.H = H; g.W = W; g.itr = refine_itr; }
+    for (int it = 0; it < refine_itr; it++)
+      if (refine_iteration(m, t, 1, false)) return 1;
+    g.epoch = g_alloc_epoch;  // allocations made by this eager call are now settled
+    g.eager_calls = graphable ? g.eager_calls + 1 : 0;
+  }
   FP_HIP_OK(hipMemcpyAsync(out_pose, m->poses_dev, 64, hipMemcpyDeviceToHost, m->stream));
   FP_HIP_OK(hipStreamSynchronize(m->stream));
   return 0;

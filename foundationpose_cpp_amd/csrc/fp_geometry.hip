@@ -31,8 +31,9 @@ namespace fp {
 #define CR_DEPTH_MAX (0xFFFFFFFFu - (2200u << 3))
 
 static constexpr int CROP = FP_CROP_HW;
-static constexpr int STRIP_ROWS = 40;
-static constexpr int NSTRIPS = CROP / STRIP_ROWS;
+// rows of the 160-row viewport owned by one workgroup: 40 (4 strips/hypothesis) for large batches, 8 (20 strips) when
+// the batch alone cannot fill the chip (Track: N = 1).  The shading pass is a chain of dependent loads per pixel, so
+// its latency is hidden by workgroup count, not by work per thread.
 
 struct K9 { float k[9]; };
 
@@ -216,6 +217,7 @@ __device__ __forceinline__ bool edge_covers(int ox, int oy, int dx, int dy) {
 }
 
 // snap + setup + rasterise one (sub)triangle into the strip's LDS z-buffer
+template <int STRIP_ROWS>
 __device__ __forceinline__ void raster_one(float4 v0, float4 v1, float4 v2, unsigned color, int row0,
                                            unsigned long long *zbuf) {
   const float vs = (float)(CROP << (CR_SUBPIXEL_LOG2 - 1));
@@ -309,6 +311,7 @@ __device__ __forceinline__ int clip_poly_plane(float *out, const float *in, int 
 }
 
 // rare path: triangle crosses the depth range or leaves the S16 snap range -> clip against the frustum and fan
+template <int STRIP_ROWS>
 __device__ __noinline__ void raster_clipped(float4 v0, float4 v1, float4 v2, unsigned color, int row0,
                                             unsigned long long *zbuf) {
   float bary[18], temp[18];
@@ -336,13 +339,13 @@ __device__ __noinline__ void raster_clipped(float4 v0, float4 v1, float4 v2, uns
   FP_BARY_PT(c1, 1);
   for (int i = 2; i < num; i++) {
     FP_BARY_PT(c2, i);
-    raster_one(c0, c1, c2, color, row0, zbuf);
+    raster_one<STRIP_ROWS>(c0, c1, c2, color, row0, zbuf);
     c1 = c2;
   }
 #undef FP_BARY_PT
 }
 
-template <int MODE>
+template <int MODE, int STRIP_ROWS>
 __global__ __launch_bounds__(256) void raster_shade_kernel(
     const int32_t *__restrict__ faces, int F, int V, const float *__restrict__ uvs, const uint8_t *__restrict__ tex,
     int TH, int TW, float downscale, const PoseRec *__restrict__ recs, const float4 *__restrict__ clip_all,
@@ -381,8 +384,8 @@ __global__ __launch_bounds__(256) void raster_shade_kernel(
       const int aabbLimit = (1 << (CR_MAXVIEWPORT_LOG2 + CR_SUBPIXEL_LOG2)) - 1;
       fast = (loxy >= -32768 && hixy <= 32767 && hixy - loxy <= aabbLimit);
     }
-    if (fast) raster_one(v0, v1, v2, (unsigned)(f + 1), row0, zbuf);
-    else raster_clipped(v0, v1, v2, (unsigned)(f + 1), row0, zbuf);
+    if (fast) raster_one<STRIP_ROWS>(v0, v1, v2, (unsigned)(f + 1), row0, zbuf);
+    else raster_clipped<STRIP_ROWS>(v0, v1, v2, (unsigned)(f + 1), row0, zbuf);
   }
   __syncthreads();
 
@@ -475,17 +478,29 @@ __global__ __launch_bounds__(256) void raster_shade_kernel(
   }
 }
 
-void launch_raster_shade(hipStream_t s, const DeviceMesh &m, const PoseRec *recs, int N, const float4 *clip,
-                         const float4 *attr, OutMode mode, void *out, int32_t *tri_id_dbg, float *rast_dbg) {
+template <int STRIP_ROWS>
+static void launch_raster_shade_t(hipStream_t s, const DeviceMesh &m, const PoseRec *recs, int N, const float4 *clip,
+                                  const float4 *attr, OutMode mode, void *out, int32_t *tri_id_dbg, float *rast_dbg) {
   size_t lds = (size_t)STRIP_ROWS * CROP * sizeof(unsigned long long);
-  dim3 grid(NSTRIPS, N), block(256);
+  dim3 grid(CROP / STRIP_ROWS, N), block(256);
   float downscale = m.diameter / 2;
   if (mode == OUT_F32X6)
-    hipLaunchKernelGGL(raster_shade_kernel<OUT_F32X6>, grid, block, lds, s, m.faces, m.F, m.V, m.uvs, m.tex, m.TH, m.TW,
-                       downscale, recs, clip, attr, out, tri_id_dbg, rast_dbg);
+    hipLaunchKernelGGL((raster_shade_kernel<OUT_F32X6, STRIP_ROWS>), grid, block, lds, s, m.faces, m.F, m.V, m.uvs, m.tex,
+                       m.TH, m.TW, downscale, recs, clip, attr, out, tri_id_dbg, rast_dbg);
   else
-    hipLaunchKernelGGL(raster_shade_kernel<OUT_F16X8>, grid, block, lds, s, m.faces, m.F, m.V, m.uvs, m.tex, m.TH, m.TW,
-                       downscale, recs, clip, attr, out, tri_id_dbg, rast_dbg);
+    hipLaunchKernelGGL((raster_shade_kernel<OUT_F16X8, STRIP_ROWS>), grid, block, lds, s, m.faces, m.F, m.V, m.uvs, m.tex,
+                       m.TH, m.TW, downscale, recs, clip, attr, out, tri_id_dbg, rast_dbg);
+}
+
+static int g_strip_rows_override = 0;
+void set_raster_strip_rows(int r) { g_strip_rows_override = r; }
+
+void launch_raster_shade(hipStream_t s, const DeviceMesh &m, const PoseRec *recs, int N, const float4 *clip,
+                         const float4 *attr, OutMode mode, void *out, int32_t *tri_id_dbg, float *rast_dbg) {
+  int rows = g_strip_rows_override ? g_strip_rows_override : (N * 4 >= 512 ? 40 : (N * 8 >= 512 ? 20 : 8));
+  if (rows == 40) launch_raster_shade_t<40>(s, m, recs, N, clip, attr, mode, out, tri_id_dbg, rast_dbg);
+  else if (rows == 20) launch_raster_shade_t<20>(s, m, recs, N, clip, attr, mode, out, tri_id_dbg, rast_dbg);
+  else launch_raster_shade_t<8>(s, m, recs, N, clip, attr, mode, out, tri_id_dbg, rast_dbg);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -21,6 +21,8 @@ namespace fp {
 // error plumbing: C ABI returns 0 / non-zero + fp_last_error()
 // ---------------------------------------------------------------------------------------------
 void set_error(const std::string &msg);
+// bumped whenever a device buffer that kernels may have baked into a captured hipGraph is (re)allocated
+extern unsigned long g_alloc_epoch;
 #define FP_HIP_OK(expr)                                                                              \
   do {                                                                                               \
     hipError_t _e = (expr);                                                                          \
@@ -104,6 +106,7 @@ void launch_pose_setup(hipStream_t s, const float *poses_dev, int N, const float
 void launch_vertex(hipStream_t s, const DeviceMesh &m, const PoseRec *recs, int N, float4 *clip, float4 *attr);
 void launch_raster_shade(hipStream_t s, const DeviceMesh &m, const PoseRec *recs, int N, const float4 *clip,
                          const float4 *attr, OutMode mode, void *out, int32_t *tri_id_dbg, float *rast_dbg);
+void set_raster_strip_rows(int rows);  // 0 = automatic (A/B hook)
 void launch_crop(hipStream_t s, const uint8_t *rgb, const float *depth, int H, int W, const float *K9_host,
                  const PoseRec *recs, int N, float diameter, OutMode mode, void *out);
 void launch_depth_to_xyz(hipStream_t s, const float *depth, int H, int W, const float *K9_host, float *xyz);

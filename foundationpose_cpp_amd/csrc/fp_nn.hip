@@ -69,6 +69,8 @@ struct ConvParams {
               // are consecutive K-steps and their overlapping input pixels are re-read while still L2-resident
   // byte offset of K-step kt's X slab relative to a row's (tap 0, channel 0) address; host-filled, read with s_load
   unsigned koff[80];
+  int ksplit, kt_per;     // split-K (small problems): K-steps [split*kt_per, ...) per workgroup, fp32 partial slabs
+  float *partial;         // [ksplit][M][Cout]
   unsigned long long *clk;  // optional clock probe: per block {cycles0, realtime0, cycles1, realtime1}
 };
 
@@ -99,6 +101,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
     const int xcd = b & 7, within = b >> 3, q = nblk >> 3, r = nblk & 7;
     logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
   }
+  const int split = logical % p.ksplit;
+  logical /= p.ksplit;
   const int mt = logical / n_tiles, nt = logical - mt * n_tiles;
   const int m0 = mt * BM, n0 = nt * BN;
   const int ohw = p.OH * p.OW;
@@ -197,18 +201,33 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
     }
   };
 
-  const int KT = p.Ktot >> 6;
-  stage(0, 0);
+  const int k_begin = split * p.kt_per, k_end = min(p.Ktot >> 6, k_begin + p.kt_per);
+  stage(k_begin, 0);
   __syncthreads();
   // steady state is branch-free (stage next tile, compute current tile, one barrier); the last tile is peeled
-  for (int kt = 0; kt < KT - 1; kt++) {
-    stage(kt + 1, (kt + 1) & 1);
-    compute(kt & 1);
+  int buf = 0;
+  for (int kt = k_begin; kt < k_end - 1; kt++) {
+    stage(kt + 1, buf ^ 1);
+    compute(buf);
     __syncthreads();
+    buf ^= 1;
   }
-  compute((KT - 1) & 1);
+  compute(buf);
 
   if (p.clk && tid == 0) { p.clk[blockIdx.x * 4 + 2] = __builtin_readcyclecounter(); p.clk[blockIdx.x * 4 + 3] = wall_clock64(); }
+  if (p.ksplit > 1) {  // split-K: raw fp32 partial slab, reduced (+ bias / residual / ReLU) by conv_splitk_reduce_kernel
+#pragma unroll
+    for (int mi = 0; mi < 4; mi++) {
+      int m = m0 + wm * 64 + mi * 16 + (lane & 15);
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int ni = 0; ni < NREP; ni++) {
+        int n = n0 + wn * (BN / 2) + ni * 16 + (lane >> 4) * 4;
+        *reinterpret_cast<f4 *>(p.partial + ((size_t)split * p.M + m) * p.Cout + n) = acc[ni][mi];
+      }
+    }
+    return;
+  }
   // ---- epilogue: lane owns channels cb..cb+3 (cb = 4*(lane>>4)) of pixel (lane&15) in each 16x16 tile
   const int OHp = p.OH + 2 * p.opad, OWp = p.OW + 2 * p.opad;
   const int RHp = p.OH + 2 * p.rpad, RWp = p.OW + 2 * p.rpad;
@@ -392,6 +411,35 @@ __global__ __launch_bounds__(512, 2) void conv_igemm3_kernel(const ConvParams p)
       *reinterpret_cast<h4 *>(p.out + opix * p.out_ld + choff + n) = o;
     }
   }
+}
+
+// split-K reduction + the conv epilogue: out = relu(sum_s partial[s] + bias + res); thread = (pixel, 4 channels)
+__global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvParams p) {
+  const int nq = p.Cout / 4;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)p.M * nq) return;
+  const int m = (int)(i / nq), n = (int)(i - (size_t)m * nq) * 4;
+  f4 a = *reinterpret_cast<const f4 *>(p.partial + (size_t)m * p.Cout + n);
+  for (int sp = 1; sp < p.ksplit; sp++) a += *reinterpret_cast<const f4 *>(p.partial + ((size_t)sp * p.M + m) * p.Cout + n);
+  float4 bv = *reinterpret_cast<const float4 *>(p.bias + n);
+  float v0 = a[0] + bv.x, v1 = a[1] + bv.y, v2 = a[2] + bv.z, v3 = a[3] + bv.w;
+  const int ohw = p.OH * p.OW;
+  int img = m / ohw;
+  int rem = m - img * ohw;
+  int oh = rem / p.OW, ow = rem - oh * p.OW;
+  const int OHp = p.OH + 2 * p.opad, OWp = p.OW + 2 * p.opad;
+  const int RHp = p.OH + 2 * p.rpad, RWp = p.OW + 2 * p.rpad;
+  if (p.res) {
+    size_t rpix = ((size_t)img * RHp + oh + p.rpad) * RWp + ow + p.rpad;
+    h4 r = *reinterpret_cast<const h4 *>(p.res + rpix * p.res_ld + n);
+    v0 += (float)r[0]; v1 += (float)r[1]; v2 += (float)r[2]; v3 += (float)r[3];
+  }
+  if (p.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+  int choff = 0, oimg = img;
+  if (p.split_imgs > 0 && img >= p.split_imgs) { oimg = img - p.split_imgs; choff = p.Cout; }
+  size_t opix = ((size_t)oimg * OHp + oh + p.opad) * OWp + ow + p.opad;
+  h4 o = {(_Float16)v0, (_Float16)v1, (_Float16)v2, (_Float16)v3};
+  *reinterpret_cast<h4 *>(p.out + opix * p.out_ld + choff + n) = o;
 }
 
 // =================================================================================================
@@ -886,6 +934,7 @@ static int ensure_scratch(NNScratch *ws, int N, hipStream_t s) {
   if (ws->f32) (void)hipFree(ws->f32);
   ws->buf = nullptr; ws->f32 = nullptr; ws->cap = 0;
   int cap = std::max(N, 8);
+  g_alloc_epoch++;
   FP_HIP_OK(hipMalloc((void **)&ws->buf, (size_t)cap * PER_HYP * sizeof(__half)));
   FP_HIP_OK(hipMalloc((void **)&ws->f32, (size_t)cap * EMBED * sizeof(float)));
   // the zero borders are written here once and never again: every producer stores interiors only, and the arena is
@@ -920,6 +969,8 @@ struct Ctx {
 
 static bool g_conv_attr_done = false;
 static unsigned long long *g_clk_probe = nullptr;
+static float *g_splitk_ws = nullptr;  // fp32 partial slabs for split-K (grown on demand; process lifetime)
+static size_t g_splitk_cap = 0;
 static int g_conv_variant = 0;  // 0 auto, 1 force the 128-pixel 2-stage kernel, 2 force the 256-pixel 3-stage kernel (A/B hook)
 
 // in: [NB, H+2*ipad, W+2*ipad, Cin]; out: [.., OH+2*opad, OW+2*opad, ..]; res: border rpad
@@ -969,9 +1020,31 @@ static int run_conv(const Ctx &c, const char *tag, const ConvLayer &L, const __h
     FP_HIP_OK(hipFuncSetAttribute((const void *)conv_igemm3_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS3_64));
     g_conv_attr_done = true;
   }
-  ProfScope ps(c.prof, c.s, tag, flops, bytes);
   int mtiles = (p.M + 127) / 128;
   const int KT = p.Ktot / 64;
+  // split-K for small problems (Track, N <= ~8): a 128x128 tile count far below the 512 workgroup slots of the chip
+  // would leave most CUs idle while a few walk up to 72 K-steps; give every CU a slice instead
+  p.ksplit = 1; p.kt_per = KT; p.partial = nullptr;
+  {
+    const int tiles = mtiles * (L.Cout % 128 == 0 ? L.Cout / 128 : L.Cout / 64);
+    if (tiles <= 96 && KT >= 8 && g_conv_variant != 2) {
+      int S = std::min(std::max(256 / tiles, 1), KT / 2);
+      if (S > 1) {
+        p.kt_per = (KT + S - 1) / S;
+        p.ksplit = (KT + p.kt_per - 1) / p.kt_per;
+        size_t need = (size_t)p.ksplit * p.M * p.Cout;
+        if (need > g_splitk_cap) {
+          if (g_splitk_ws) (void)hipFree(g_splitk_ws);
+          g_splitk_ws = nullptr; g_splitk_cap = 0;
+          g_alloc_epoch++;
+          FP_HIP_OK(hipMalloc((void **)&g_splitk_ws, need * sizeof(float)));
+          g_splitk_cap = need;
+        }
+        p.partial = g_splitk_ws;
+      }
+    }
+  }
+  ProfScope ps(c.prof, c.s, tag, flops, bytes);
   // large problems: 256-pixel tiles, 3-stage LDS-DMA pipeline (needs >= 3 K-steps and enough tiles to fill 256 CUs)
   const int big_tiles = ((p.M + 255) / 256) * (L.Cout % 128 == 0 ? L.Cout / 128 : L.Cout / 64);
   (void)big_tiles;
@@ -986,7 +1059,7 @@ static int run_conv(const Ctx &c, const char *tag, const ConvLayer &L, const __h
     return 0;
   }
   if (L.Cout % 128 == 0) {
-    const dim3 grid(mtiles * (L.Cout / 128));
+    const dim3 grid(mtiles * (L.Cout / 128) * p.ksplit);
     const int lds = 2 * (128 * 128 + 128 * 128);
     switch (g_conv_variant) {
       case 11: hipLaunchKernelGGL((conv_igemm_kernel<128, 1>), grid, dim3(256), lds, c.s, p); break;
@@ -996,7 +1069,11 @@ static int run_conv(const Ctx &c, const char *tag, const ConvLayer &L, const __h
       default: hipLaunchKernelGGL((conv_igemm_kernel<128, 3>), grid, dim3(256), lds, c.s, p); break;
     }
   } else {
-    hipLaunchKernelGGL((conv_igemm_kernel<64, 3>), dim3(mtiles * (L.Cout / 64)), dim3(256), 2 * (128 * 128 + 64 * 128), c.s, p);
+    hipLaunchKernelGGL((conv_igemm_kernel<64, 3>), dim3(mtiles * (L.Cout / 64) * p.ksplit), dim3(256), 2 * (128 * 128 + 64 * 128), c.s, p);
+  }
+  if (p.ksplit > 1) {
+    size_t quads = (size_t)p.M * (p.Cout / 4);
+    hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, c.s, p);
   }
   return 0;
 }
@@ -1188,6 +1265,7 @@ std::vector<__half> to_half(const float *src, size_t n) {
 extern "C" {
 
 void fpt_set_conv_variant(int v) { fp::g_conv_variant = v; }
+void fpt_set_raster_strip_rows(int r) { fp::set_raster_strip_rows(r); }
 
 // clock probe: allocate room for `blocks` records, run convs, then read back mean shader MHz and mean main-loop cycles
 int fpt_clk_probe(int blocks, double *mhz_out, double *loop_cycles_out) {
