@@ -69,10 +69,60 @@ struct ConvParams {
               // are consecutive K-steps and their overlapping input pixels are re-read while still L2-resident
   // byte offset of K-step kt's X slab relative to a row's (tap 0, channel 0) address; host-filled, read with s_load
   unsigned koff[80];
+  int m_begin;            // first output row handled by this launch (hybrid 256^2 + 128^2 launches)
   int ksplit, kt_per;     // split-K (small problems): K-steps [split*kt_per, ...) per workgroup, fp32 partial slabs
   float *partial;         // [ksplit][M][Cout]
   unsigned long long *clk;  // optional clock probe: per block {cycles0, realtime0, cycles1, realtime1}
 };
+
+// Epilogue shared by every conv schedule.  acc[ni][mi] holds D^T tiles: lane owns channels n_base + ni*16 + 4*(lane>>4)
+// .. +3 of pixel m_base + mi*16 + (lane&15).  All bias and residual loads are issued BEFORE the first store: on CDNA4
+// stores also count in vmcnt, so a load issued behind a store cannot be waited for without draining the store, and the
+// naive per-tile load -> add -> store order serialises into one memory round trip per tile (32 per wave for the
+// 256 x 256 tile: 15-25 us of a 75 us workgroup).
+template <int MI, int NI>
+__device__ __forceinline__ void conv_epilogue(const ConvParams &p, f4 (&acc)[NI][MI], int m_base, int n_base, int lane) {
+  const int ohw = p.OH * p.OW;
+  const int OHp = p.OH + 2 * p.opad, OWp = p.OW + 2 * p.opad;
+  const int RHp = p.OH + 2 * p.rpad, RWp = p.OW + 2 * p.rpad;
+  const int nl = n_base + (lane >> 4) * 4;
+  float4 bv[NI];
+#pragma unroll
+  for (int ni = 0; ni < NI; ni++) bv[ni] = *reinterpret_cast<const float4 *>(p.bias + nl + ni * 16);
+  size_t oofs[MI];
+  bool ok[MI];
+  h4 rv[NI][MI];
+#pragma unroll
+  for (int mi = 0; mi < MI; mi++) {
+    int m = m_base + mi * 16 + (lane & 15);
+    ok[mi] = m < p.M;
+    int mm = ok[mi] ? m : 0;
+    int img = mm / ohw;
+    int rem = mm - img * ohw;
+    int oh = rem / p.OW, ow = rem - oh * p.OW;
+    int choff = 0, oimg = img;
+    if (p.split_imgs > 0 && img >= p.split_imgs) { oimg = img - p.split_imgs; choff = p.Cout; }
+    oofs[mi] = (((size_t)oimg * OHp + oh + p.opad) * OWp + ow + p.opad) * p.out_ld + choff;
+    if (p.res) {
+      size_t rpix = ((size_t)img * RHp + oh + p.rpad) * RWp + ow + p.rpad;
+#pragma unroll
+      for (int ni = 0; ni < NI; ni++)
+        rv[ni][mi] = ok[mi] ? *reinterpret_cast<const h4 *>(p.res + rpix * p.res_ld + nl + ni * 16) : (h4){0, 0, 0, 0};
+    }
+  }
+#pragma unroll
+  for (int mi = 0; mi < MI; mi++) {
+    if (!ok[mi]) continue;
+#pragma unroll
+    for (int ni = 0; ni < NI; ni++) {
+      float v0 = acc[ni][mi][0] + bv[ni].x, v1 = acc[ni][mi][1] + bv[ni].y, v2 = acc[ni][mi][2] + bv[ni].z, v3 = acc[ni][mi][3] + bv[ni].w;
+      if (p.res) { v0 += (float)rv[ni][mi][0]; v1 += (float)rv[ni][mi][1]; v2 += (float)rv[ni][mi][2]; v3 += (float)rv[ni][mi][3]; }
+      if (p.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+      h4 o = {(_Float16)v0, (_Float16)v1, (_Float16)v2, (_Float16)v3};
+      *reinterpret_cast<h4 *>(p.out + oofs[mi] + nl + ni * 16) = o;
+    }
+  }
+}
 
 // Activations carry a physical zero border, so the K loop has no bounds checks, no selects and no divergent
 // branches: a tap's operand address is (wave-uniform tap/chunk offset in SGPRs) + (per-lane row offset fixed for the
@@ -104,7 +154,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
   const int split = logical % p.ksplit;
   logical /= p.ksplit;
   const int mt = logical / n_tiles, nt = logical - mt * n_tiles;
-  const int m0 = mt * BM, n0 = nt * BN;
+  const int m0 = p.m_begin + mt * BM, n0 = nt * BN;
   const int ohw = p.OH * p.OW;
   const int IHp = p.H + 2 * p.ipad, IWp = p.W + 2 * p.ipad;
 
@@ -173,6 +223,16 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
 #pragma unroll
         for (int ni = 0; ni < NREP; ni++) wf[ks][ni] = *reinterpret_cast<const h8 *>(sb + wfo[ks] + ni * 16 * 128);
       }
+      if (VAR & 8) {  // ablation: no MFMAs, fragments kept live
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) {
+#pragma unroll
+          for (int mi = 0; mi < 4; mi++) asm volatile("" ::"v"(xf[ks][mi]));
+#pragma unroll
+          for (int ni = 0; ni < NREP; ni++) asm volatile("" ::"v"(wf[ks][ni]));
+        }
+        return;
+      }
       if (VAR & 1) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int ks = 0; ks < 2; ks++)
@@ -207,7 +267,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
   // steady state is branch-free (stage next tile, compute current tile, one barrier); the last tile is peeled
   int buf = 0;
   for (int kt = k_begin; kt < k_end - 1; kt++) {
-    stage(kt + 1, buf ^ 1);
+    if (!(VAR & 4)) stage(kt + 1, buf ^ 1);  // VAR&4: ablation (stale LDS, timing only)
     compute(buf);
     __syncthreads();
     buf ^= 1;
@@ -229,33 +289,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
     return;
   }
   // ---- epilogue: lane owns channels cb..cb+3 (cb = 4*(lane>>4)) of pixel (lane&15) in each 16x16 tile
-  const int OHp = p.OH + 2 * p.opad, OWp = p.OW + 2 * p.opad;
-  const int RHp = p.OH + 2 * p.rpad, RWp = p.OW + 2 * p.rpad;
-#pragma unroll
-  for (int mi = 0; mi < 4; mi++) {
-    int m = m0 + wm * 64 + mi * 16 + (lane & 15);
-    if (m >= p.M) continue;
-    int img = m / ohw;
-    int rem = m - img * ohw;
-    int oh = rem / p.OW, ow = rem - oh * p.OW;
-    int choff = 0, oimg = img;
-    if (p.split_imgs > 0 && img >= p.split_imgs) { oimg = img - p.split_imgs; choff = p.Cout; }
-    size_t opix = ((size_t)oimg * OHp + oh + p.opad) * OWp + ow + p.opad;
-    size_t rpix = ((size_t)img * RHp + oh + p.rpad) * RWp + ow + p.rpad;
-#pragma unroll
-    for (int ni = 0; ni < NREP; ni++) {
-      int n = n0 + wn * (BN / 2) + ni * 16 + (lane >> 4) * 4;
-      float4 bv = *reinterpret_cast<const float4 *>(p.bias + n);
-      float v0 = acc[ni][mi][0] + bv.x, v1 = acc[ni][mi][1] + bv.y, v2 = acc[ni][mi][2] + bv.z, v3 = acc[ni][mi][3] + bv.w;
-      if (p.res) {
-        h4 r = *reinterpret_cast<const h4 *>(p.res + rpix * p.res_ld + n);
-        v0 += (float)r[0]; v1 += (float)r[1]; v2 += (float)r[2]; v3 += (float)r[3];
-      }
-      if (p.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
-      h4 o = {(_Float16)v0, (_Float16)v1, (_Float16)v2, (_Float16)v3};
-      *reinterpret_cast<h4 *>(p.out + opix * p.out_ld + choff + n) = o;
-    }
-  }
+  conv_epilogue<4, NREP>(p, acc, m0 + wm * 64, n0 + wn * (BN / 2), lane);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -384,33 +418,401 @@ __global__ __launch_bounds__(512, 2) void conv_igemm3_kernel(const ConvParams p)
   compute(rb);
   if (p.clk && tid == 0) { p.clk[blockIdx.x * 4 + 2] = __builtin_readcyclecounter(); p.clk[blockIdx.x * 4 + 3] = wall_clock64(); }
 
-  const int OHp = p.OH + 2 * p.opad, OWp = p.OW + 2 * p.opad;
-  const int RHp = p.OH + 2 * p.rpad, RWp = p.OW + 2 * p.rpad;
+  conv_epilogue<4, NREP>(p, acc, m0 + wm * 64, n0 + wn * (BN / 2), lane);
+}
+
+// -------------------------------------------------------------------------------------------------
+// Ping-pong variant: 256 pixels x BN channels per workgroup, 8 waves = two groups of 4 (each group owns 128 pixel
+// rows with the usual 2x2 arrangement of 64 x BN/2 wave tiles, the W tile is shared).  The groups run in strict
+// anti-phase: while group 0 pulls its 16 operand fragments of K-step kt from LDS into registers and issues the LDS-DMA
+// for K-step kt+2, group 1 issues the 32 MFMAs of K-step kt-1 from registers only, and vice versa.  Each SIMD hosts one
+// wave of either group, so its matrix pipe always has a pure-MFMA wave to run.  Three LDS stages; loads stay in
+// flight across the barriers (counted vmcnt, raw s_barrier); two barriers per K-step.
+// -------------------------------------------------------------------------------------------------
+template <int BN>
+__global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int BM = 256;
+  constexpr int XB = BM * 128;
+  constexpr int WB = BN * 128;
+  constexpr int STAGE = XB + WB;
+  constexpr int NREP = BN / 32;
+  constexpr int WPIECES = BN / 64;
+  constexpr int G = 4 + WPIECES;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2;                 // 0 / 1: pixel rows [grp*128, +128)
+  const int wq = wave & 3, wm = wq & 1, wn = wq >> 1;
+  const int n_tiles = p.Cout / BN;
+  int logical;
+  {
+    const int nblk = gridDim.x, b = blockIdx.x;
+    const int xcd = b & 7, within = b >> 3, q = nblk >> 3, r = nblk & 7;
+    logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
+  }
+  const int mt = logical / n_tiles, nt = logical - mt * n_tiles;
+  const int m0 = mt * BM, n0 = nt * BN;
+  const int ohw = p.OH * p.OW;
+  const int IHp = p.H + 2 * p.ipad, IWp = p.W + 2 * p.ipad;
+
+  const int srow = lane >> 3;
+  const int g = (lane & 7) ^ srow;
+  unsigned xoff[4];
 #pragma unroll
-  for (int mi = 0; mi < 4; mi++) {
-    int m = m0 + wm * 64 + mi * 16 + (lane & 15);
-    if (m >= p.M) continue;
+  for (int i = 0; i < 4; i++) {
+    int m = min(m0 + (wave * 4 + i) * 8 + srow, p.M - 1);
     int img = m / ohw;
     int rem = m - img * ohw;
     int oh = rem / p.OW, ow = rem - oh * p.OW;
-    int choff = 0, oimg = img;
-    if (p.split_imgs > 0 && img >= p.split_imgs) { oimg = img - p.split_imgs; choff = p.Cout; }
-    size_t opix = ((size_t)oimg * OHp + oh + p.opad) * OWp + ow + p.opad;
-    size_t rpix = ((size_t)img * RHp + oh + p.rpad) * RWp + ow + p.rpad;
+    int ih0 = oh * p.stride - p.pad + p.ipad, iw0 = ow * p.stride - p.pad + p.ipad;
+    xoff[i] = (unsigned)(((img * IHp + ih0) * IWp + iw0) * p.Cin + g * 8) * 2u;
+  }
+  unsigned woffv[WPIECES];
 #pragma unroll
-    for (int ni = 0; ni < NREP; ni++) {
-      int n = n0 + wn * (BN / 2) + ni * 16 + (lane >> 4) * 4;
-      float4 bv = *reinterpret_cast<const float4 *>(p.bias + n);
-      float v0 = acc[ni][mi][0] + bv.x, v1 = acc[ni][mi][1] + bv.y, v2 = acc[ni][mi][2] + bv.z, v3 = acc[ni][mi][3] + bv.w;
-      if (p.res) {
-        h4 r = *reinterpret_cast<const h4 *>(p.res + rpix * p.res_ld + n);
-        v0 += (float)r[0]; v1 += (float)r[1]; v2 += (float)r[2]; v3 += (float)r[3];
+  for (int i = 0; i < WPIECES; i++) {
+    int row = (wave * WPIECES + i) * 8 + srow;
+    woffv[i] = (unsigned)((n0 + row) * p.Ktot + g * 8) * 2u;
+  }
+  const unsigned char *in_b = reinterpret_cast<const unsigned char *>(p.in);
+  const unsigned char *w_b = reinterpret_cast<const unsigned char *>(p.w);
+  const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
+
+  auto stage = [&](int kt, int buf) {
+    const unsigned xs = lds_base + buf * STAGE;
+    const unsigned ws = xs + XB;
+    const unsigned char *xb = in_b + p.koff[kt];
+    const unsigned char *wb = w_b + (size_t)kt * 128;
+#pragma unroll
+    for (int i = 0; i < 4; i++) glds16_asm(xb + xoff[i], xs + (wave * 4 + i) * 1024);
+#pragma unroll
+    for (int i = 0; i < WPIECES; i++) glds16_asm(wb + woffv[i], ws + (wave * WPIECES + i) * 1024);
+  };
+
+  f4 acc[NREP][4];
+#pragma unroll
+  for (int a = 0; a < NREP; a++)
+#pragma unroll
+    for (int b = 0; b < 4; b++) acc[a][b] = (f4){0.f, 0.f, 0.f, 0.f};
+
+  const int frow = lane & 15, fk = lane >> 4;
+  int xfo[2], wfo[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ks++) {
+    int slot = (ks * 4 + fk) ^ (lane & 7);
+    xfo[ks] = (grp * 128 + wm * 64 + frow) * 128 + slot * 16;
+    wfo[ks] = XB + (wn * (BN / 2) + frow) * 128 + slot * 16;
+  }
+
+  h8 xf[2][4], wf[2][NREP];
+  auto ldfrags = [&](int buf) {
+    const unsigned char *sb = smem + buf * STAGE;
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++) {
+#pragma unroll
+      for (int mi = 0; mi < 4; mi++) xf[ks][mi] = *reinterpret_cast<const h8 *>(sb + xfo[ks] + mi * 16 * 128);
+#pragma unroll
+      for (int ni = 0; ni < NREP; ni++) wf[ks][ni] = *reinterpret_cast<const h8 *>(sb + wfo[ks] + ni * 16 * 128);
+    }
+  };
+  auto mfmas = [&]() {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+      for (int ni = 0; ni < NREP; ni++)
+#pragma unroll
+        for (int mi = 0; mi < 4; mi++)
+          acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ks][ni], xf[ks][mi], acc[ni][mi], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+  };
+#define FP_PP_BARRIER()                  \
+  do {                                   \
+    __builtin_amdgcn_s_barrier();        \
+    __builtin_amdgcn_sched_barrier(0);   \
+  } while (0)
+
+  const int KT = p.Ktot >> 6;  // >= 8
+  stage(0, 0);
+  stage(1, 1);
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");  // tile 0 landed (this wave's pieces)
+  FP_PP_BARRIER();
+  int rb = 0, wb3 = 2;
+  if (grp == 0) {
+    for (int kt = 0; kt < KT; kt++) {
+      // even slot: LDS -> registers for K-step kt, prefetch K-step kt+2
+      ldfrags(rb);
+      if (kt + 2 < KT) stage(kt + 2, wb3);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      FP_PP_BARRIER();
+      // odd slot: MFMAs from registers
+      mfmas();
+      if (kt + 2 < KT) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");  // tile kt+1 landed, kt+2 in flight
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      FP_PP_BARRIER();
+      rb = (rb == 2) ? 0 : rb + 1;
+      wb3 = (wb3 == 2) ? 0 : wb3 + 1;
+    }
+  } else {
+    for (int kt = 0; kt < KT; kt++) {
+      // even slot: MFMAs of K-step kt-1
+      if (kt > 0) mfmas();
+      FP_PP_BARRIER();
+      // odd slot: LDS -> registers for K-step kt, prefetch K-step kt+2
+      ldfrags(rb);
+      if (kt + 2 < KT) {
+        stage(kt + 2, wb3);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
-      if (p.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
-      h4 o = {(_Float16)v0, (_Float16)v1, (_Float16)v2, (_Float16)v3};
-      *reinterpret_cast<h4 *>(p.out + opix * p.out_ld + choff + n) = o;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      FP_PP_BARRIER();
+      rb = (rb == 2) ? 0 : rb + 1;
+      wb3 = (wb3 == 2) ? 0 : wb3 + 1;
+    }
+    mfmas();
+  }
+#undef FP_PP_BARRIER
+
+  conv_epilogue<4, NREP>(p, acc, m0 + grp * 128 + wm * 64, n0 + wn * (BN / 2), lane);
+}
+
+// -------------------------------------------------------------------------------------------------
+// 256 x 256 tile.  Ablation of the 128 x 128 kernel (tools/bench_conv.py variants 17/21/25) shows its K-step is bound
+// by the global -> LDS path, not by the matrix pipe: with the MFMAs removed a K-step still takes ~1360 cycles against
+// ~1050 with the loads removed, i.e. the two co-resident workgroups pull 64 KB per K-step at ~47 B/clk/CU, the L2 ->
+// CU ceiling.  A 256 x 256 tile moves the same 64 KB per K-step for TWICE the MFMA work, which puts the K-step back
+// under the matrix pipe.  8 waves (2 along pixels x 4 along channels), wave tile 128 x 64 (32 accumulators), BK = 64,
+// two 64-KB LDS stages, one workgroup per CU.  Needs Cout % 256 == 0.
+// -------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512, 2) void conv_big_kernel(const ConvParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int BM = 256, BN = 256;
+  constexpr int XB = BM * 128, WB = BN * 128, STAGE = XB + WB;
+  constexpr int MI = 8, NI = 4;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave & 1, wn = wave >> 1;
+  const int n_tiles = p.Cout / BN;
+  int logical;
+  {
+    const int nblk = gridDim.x, b = blockIdx.x;
+    const int xcd = b & 7, within = b >> 3, q = nblk >> 3, r = nblk & 7;
+    logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
+  }
+  const int mt = logical / n_tiles, nt = logical - mt * n_tiles;
+  const int m0 = mt * BM, n0 = nt * BN;
+  const int ohw = p.OH * p.OW;
+  const int IHp = p.H + 2 * p.ipad, IWp = p.W + 2 * p.ipad;
+
+  const int srow = lane >> 3;
+  const int g = (lane & 7) ^ srow;
+  unsigned xoff[4], woffv[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    int m = min(m0 + (wave * 4 + i) * 8 + srow, p.M - 1);
+    int img = m / ohw;
+    int rem = m - img * ohw;
+    int oh = rem / p.OW, ow = rem - oh * p.OW;
+    int ih0 = oh * p.stride - p.pad + p.ipad, iw0 = ow * p.stride - p.pad + p.ipad;
+    xoff[i] = (unsigned)(((img * IHp + ih0) * IWp + iw0) * p.Cin + g * 8) * 2u;
+    int row = (wave * 4 + i) * 8 + srow;
+    woffv[i] = (unsigned)((n0 + row) * p.Ktot + g * 8) * 2u;
+  }
+  const unsigned char *in_b = reinterpret_cast<const unsigned char *>(p.in);
+  const unsigned char *w_b = reinterpret_cast<const unsigned char *>(p.w);
+  const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
+
+  auto stage = [&](int kt, int buf) {
+    const unsigned xs = lds_base + buf * STAGE;
+    const unsigned ws = xs + XB;
+    const unsigned char *xb = in_b + p.koff[kt];
+    const unsigned char *wb = w_b + (size_t)kt * 128;
+#pragma unroll
+    for (int i = 0; i < 4; i++) glds16_asm(xb + xoff[i], xs + (wave * 4 + i) * 1024);
+#pragma unroll
+    for (int i = 0; i < 4; i++) glds16_asm(wb + woffv[i], ws + (wave * 4 + i) * 1024);
+  };
+
+  f4 acc[NI][MI];
+#pragma unroll
+  for (int a = 0; a < NI; a++)
+#pragma unroll
+    for (int b = 0; b < MI; b++) acc[a][b] = (f4){0.f, 0.f, 0.f, 0.f};
+
+  const int frow = lane & 15, fk = lane >> 4;
+  int xfo[2], wfo[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ks++) {
+    int slot = (ks * 4 + fk) ^ (lane & 7);
+    xfo[ks] = (wm * 128 + frow) * 128 + slot * 16;
+    wfo[ks] = XB + (wn * 64 + frow) * 128 + slot * 16;
+  }
+
+  auto compute = [&](int buf) {
+    const unsigned char *sb = smem + buf * STAGE;
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++) {
+      h8 xf[MI], wf[NI];
+#pragma unroll
+      for (int mi = 0; mi < MI; mi++) xf[mi] = *reinterpret_cast<const h8 *>(sb + xfo[ks] + mi * 16 * 128);
+#pragma unroll
+      for (int ni = 0; ni < NI; ni++) wf[ni] = *reinterpret_cast<const h8 *>(sb + wfo[ks] + ni * 16 * 128);
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int ni = 0; ni < NI; ni++)
+#pragma unroll
+        for (int mi = 0; mi < MI; mi++)
+          acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ni], xf[mi], acc[ni][mi], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+    }
+  };
+
+  const int KT = p.Ktot >> 6;
+  stage(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  int buf = 0;
+  for (int kt = 0; kt < KT - 1; kt++) {
+    stage(kt + 1, buf ^ 1);
+    compute(buf);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    buf ^= 1;
+  }
+  compute(buf);
+
+  conv_epilogue<MI, NI>(p, acc, m0 + wm * 128, n0 + wn * 64, lane);
+}
+
+// Ping-pong schedule of the 256 x 256 tile (see the slot comment inside).
+__global__ __launch_bounds__(512, 2) void conv_big_pp_kernel(const ConvParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int BM = 256, BN = 256;
+  constexpr int XB = BM * 128, WB = BN * 128, STAGE = XB + WB;
+  constexpr int MI = 8, NI = 4;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;  // wm doubles as the ping-pong group: waves w and w+4 share a SIMD
+  const int n_tiles = p.Cout / BN;
+  int logical;
+  {
+    const int nblk = gridDim.x, b = blockIdx.x;
+    const int xcd = b & 7, within = b >> 3, q = nblk >> 3, r = nblk & 7;
+    logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
+  }
+  const int mt = logical / n_tiles, nt = logical - mt * n_tiles;
+  const int m0 = mt * BM, n0 = nt * BN;
+  const int ohw = p.OH * p.OW;
+  const int IHp = p.H + 2 * p.ipad, IWp = p.W + 2 * p.ipad;
+
+  const int srow = lane >> 3;
+  const int g = (lane & 7) ^ srow;
+  unsigned xoff[4], woffv[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    int m = min(m0 + (wave * 4 + i) * 8 + srow, p.M - 1);
+    int img = m / ohw;
+    int rem = m - img * ohw;
+    int oh = rem / p.OW, ow = rem - oh * p.OW;
+    int ih0 = oh * p.stride - p.pad + p.ipad, iw0 = ow * p.stride - p.pad + p.ipad;
+    xoff[i] = (unsigned)(((img * IHp + ih0) * IWp + iw0) * p.Cin + g * 8) * 2u;
+    int row = (wave * 4 + i) * 8 + srow;
+    woffv[i] = (unsigned)((n0 + row) * p.Ktot + g * 8) * 2u;
+  }
+  const unsigned char *in_b = reinterpret_cast<const unsigned char *>(p.in);
+  const unsigned char *w_b = reinterpret_cast<const unsigned char *>(p.w);
+  const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
+
+  auto stage = [&](int kt, int buf) {
+    const unsigned xs = lds_base + buf * STAGE;
+    const unsigned ws = xs + XB;
+    const unsigned char *xb = in_b + p.koff[kt];
+    const unsigned char *wb = w_b + (size_t)kt * 128;
+#pragma unroll
+    for (int i = 0; i < 4; i++) glds16_asm(xb + xoff[i], xs + (wave * 4 + i) * 1024);
+#pragma unroll
+    for (int i = 0; i < 4; i++) glds16_asm(wb + woffv[i], ws + (wave * 4 + i) * 1024);
+  };
+
+  f4 acc[NI][MI];
+#pragma unroll
+  for (int a = 0; a < NI; a++)
+#pragma unroll
+    for (int b = 0; b < MI; b++) acc[a][b] = (f4){0.f, 0.f, 0.f, 0.f};
+
+  const int frow = lane & 15, fk = lane >> 4;
+  int xfo[2], wfo[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ks++) {
+    int slot = (ks * 4 + fk) ^ (lane & 7);
+    xfo[ks] = (wm * 128 + frow) * 128 + slot * 16;
+    wfo[ks] = XB + (wn * 64 + frow) * 128 + slot * 16;
+  }
+
+  h8 xf[MI], wf[NI];
+  auto ld = [&](int buf, int ks) {
+    const unsigned char *sb = smem + buf * STAGE;
+#pragma unroll
+    for (int mi = 0; mi < MI; mi++) xf[mi] = *reinterpret_cast<const h8 *>(sb + xfo[ks] + mi * 16 * 128);
+#pragma unroll
+    for (int ni = 0; ni < NI; ni++) wf[ni] = *reinterpret_cast<const h8 *>(sb + wfo[ks] + ni * 16 * 128);
+  };
+  auto mfmas = [&]() {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ni = 0; ni < NI; ni++)
+#pragma unroll
+      for (int mi = 0; mi < MI; mi++)
+        acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ni], xf[mi], acc[ni][mi], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+  };
+#define FP_BAR()                         \
+  do {                                   \
+    __builtin_amdgcn_s_barrier();        \
+    __builtin_amdgcn_sched_barrier(0);   \
+  } while (0)
+#define FP_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#define FP_VM0() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+
+  // Slots of ~32 MFMAs: group 0 runs L0 M0 L1 M1 per K-step, group 1 the same one slot later, so on every SIMD one
+  // wave issues MFMAs from registers while its partner refills fragments from LDS / issues the next tile's LDS-DMA.
+  const int KT = p.Ktot >> 6;
+  stage(0, 0);
+  FP_VM0();
+  FP_BAR();
+  int buf = 0;
+  if (wm == 0) {
+    for (int kt = 0; kt < KT; kt++) {
+      ld(buf, 0);
+      if (kt + 1 < KT) stage(kt + 1, buf ^ 1);
+      FP_LGKM0(); FP_BAR();
+      mfmas(); FP_BAR();
+      ld(buf, 1); FP_LGKM0(); FP_BAR();
+      mfmas(); FP_VM0(); FP_BAR();
+      buf ^= 1;
+    }
+    FP_BAR();
+  } else {
+    FP_BAR();
+    for (int kt = 0; kt < KT; kt++) {
+      ld(buf, 0);
+      if (kt + 1 < KT) stage(kt + 1, buf ^ 1);
+      FP_LGKM0(); FP_BAR();
+      mfmas(); FP_BAR();
+      ld(buf, 1); FP_LGKM0(); FP_VM0(); FP_BAR();
+      mfmas(); FP_BAR();
+      buf ^= 1;
     }
   }
+#undef FP_BAR
+#undef FP_LGKM0
+#undef FP_VM0
+
+  conv_epilogue<MI, NI>(p, acc, m0 + wm * 128, n0 + wn * 64, lane);
 }
 
 // split-K reduction + the conv epilogue: out = relu(sum_s partial[s] + bias + res); thread = (pixel, 4 channels)
@@ -1015,9 +1417,16 @@ static int run_conv(const Ctx &c, const char *tag, const ConvLayer &L, const __h
     FP_HIP_OK(hipFuncSetAttribute((const void *)conv_igemm_kernel<128, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (128 * 128 + 128 * 128)));
     FP_HIP_OK(hipFuncSetAttribute((const void *)conv_igemm_kernel<128, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (128 * 128 + 128 * 128)));
     FP_HIP_OK(hipFuncSetAttribute((const void *)conv_igemm_kernel<128, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (128 * 128 + 128 * 128)));
+    FP_HIP_OK(hipFuncSetAttribute((const void *)conv_igemm_kernel<128, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (128 * 128 + 128 * 128)));
+    FP_HIP_OK(hipFuncSetAttribute((const void *)conv_igemm_kernel<128, 11>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (128 * 128 + 128 * 128)));
+    FP_HIP_OK(hipFuncSetAttribute((const void *)conv_igemm_kernel<128, 15>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (128 * 128 + 128 * 128)));
     FP_HIP_OK(hipFuncSetAttribute((const void *)conv_igemm_kernel<64, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (128 * 128 + 64 * 128)));
     FP_HIP_OK(hipFuncSetAttribute((const void *)conv_igemm3_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS3_128));
     FP_HIP_OK(hipFuncSetAttribute((const void *)conv_igemm3_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS3_64));
+    FP_HIP_OK(hipFuncSetAttribute((const void *)conv_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 * 128 + 256 * 128)));
+    FP_HIP_OK(hipFuncSetAttribute((const void *)conv_big_pp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 * 128 + 256 * 128)));
+    FP_HIP_OK(hipFuncSetAttribute((const void *)conv_pp_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS3_128));
+    FP_HIP_OK(hipFuncSetAttribute((const void *)conv_pp_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS3_64));
     g_conv_attr_done = true;
   }
   int mtiles = (p.M + 127) / 128;
@@ -1050,6 +1459,31 @@ static int run_conv(const Ctx &c, const char *tag, const ConvLayer &L, const __h
   (void)big_tiles;
   // measured (tools/bench_conv.py, N=126): the 128-px 2-stage kernel beats the 256-px 3-stage one on every layer
   // (756-769 vs 703-709 TF/s weighted), so the latter is only reachable through the A/B hook
+  p.m_begin = 0;
+  if ((g_conv_variant == 4 || g_conv_variant == 5 || g_conv_variant == 0) && L.Cout % 256 == 0 && p.ksplit == 1 && KT >= 2) {
+    // 256x256 tiles for as many FULL rounds of the 256 CUs as the problem has, the remaining rows on 128x128 tiles
+    const int nt2 = L.Cout / 256;
+    const int mt_all = p.M / 256;                         // whole 256-row m-tiles
+    const int mt_big = (mt_all * nt2 / 256) * 256 / nt2;  // m-tiles covered by full rounds
+    if (mt_big > 0) {
+      const int lds_big = 2 * (256 * 128 + 256 * 128);
+      ConvParams pb = p;
+      pb.M = mt_big * 256;                                // rows [0, mt_big*256)
+      if (g_conv_variant == 4) hipLaunchKernelGGL(conv_big_kernel, dim3(mt_big * nt2), dim3(512), lds_big, c.s, pb);
+      else hipLaunchKernelGGL(conv_big_pp_kernel, dim3(mt_big * nt2), dim3(512), lds_big, c.s, pb);
+      p.m_begin = mt_big * 256;
+      if (p.m_begin >= p.M) return 0;
+      mtiles = (p.M - p.m_begin + 127) / 128;
+    }
+  }
+  if (g_conv_variant == 3 && KT >= 3 && p.ksplit == 1) {
+    int mt2 = (p.M + 255) / 256;
+    if (L.Cout % 128 == 0)
+      hipLaunchKernelGGL(conv_pp_kernel<128>, dim3(mt2 * (L.Cout / 128)), dim3(512), LDS3_128, c.s, p);
+    else
+      hipLaunchKernelGGL(conv_pp_kernel<64>, dim3(mt2 * (L.Cout / 64)), dim3(512), LDS3_64, c.s, p);
+    return 0;
+  }
   if (g_conv_variant == 2 && KT >= 3) {
     int mt2 = (p.M + 255) / 256;
     if (L.Cout % 128 == 0)
@@ -1066,6 +1500,9 @@ static int run_conv(const Ctx &c, const char *tag, const ConvLayer &L, const __h
       case 12: hipLaunchKernelGGL((conv_igemm_kernel<128, 2>), grid, dim3(256), lds, c.s, p); break;
       case 13: hipLaunchKernelGGL((conv_igemm_kernel<128, 3>), grid, dim3(256), lds, c.s, p); break;
       case 10: hipLaunchKernelGGL((conv_igemm_kernel<128, 0>), grid, dim3(256), lds, c.s, p); break;
+      case 17: hipLaunchKernelGGL((conv_igemm_kernel<128, 7>), grid, dim3(256), lds, c.s, p); break;   // no loads
+      case 21: hipLaunchKernelGGL((conv_igemm_kernel<128, 11>), grid, dim3(256), lds, c.s, p); break;  // no MFMAs
+      case 25: hipLaunchKernelGGL((conv_igemm_kernel<128, 15>), grid, dim3(256), lds, c.s, p); break;  // neither
       default: hipLaunchKernelGGL((conv_igemm_kernel<128, 3>), grid, dim3(256), lds, c.s, p); break;
     }
   } else {

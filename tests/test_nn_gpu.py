@@ -80,6 +80,35 @@ def test_conv_igemm_matches_torch(shape):
     np.testing.assert_allclose(got, ref, rtol=2e-3, atol=2e-3)
 
 
+@pytest.mark.parametrize("variant", [2, 3, 4, 5])
+def test_conv_alternative_schedules_match_torch(variant):
+    """the 256-pixel 3-stage (2) and ping-pong (3) schedules of the same implicit GEMM (A/B hooks)"""
+    L = _lib.lib()
+    rng = np.random.default_rng(5)
+    try:
+        L.fpt_set_conv_variant(variant)
+        for (NB, H, Cin, Cout, k, stride, use_res) in [(9, 40, 128, 128, 3, 1, True), (5, 40, 256, 256, 3, 1, False),
+                                                       (70, 20, 512, 512, 3, 1, True), (90, 40, 256, 256, 3, 1, True), (3, 80, 64, 128, 3, 2, False),
+                                                       (40, 400, 512, 1536, 1, 1, False), (5, 80, 32, 64, 4, 1, False)]:
+            W_ = 1 if k == 1 else H
+            x = rng.normal(size=(NB, H, W_, Cin)).astype(np.float32)
+            w = (rng.normal(size=(Cout, Cin, k, k)) / np.sqrt(Cin * k * k)).astype(np.float32)
+            b = rng.normal(size=Cout).astype(np.float32)
+            pad = 2 if k == 4 else (k - 1) // 2
+            OH = H if k == 4 else (H + 2 * pad - k) // stride + 1
+            OW = W_ if k == 4 else (W_ + 2 * pad - k) // stride + 1
+            res = rng.normal(size=(NB, OH, OW, Cout)).astype(np.float32) if use_res else None
+            got = _conv_hip(x, w, b, stride, pad, True, res)
+            if k == 4:    # asymmetric-padding stem mode: reference = pad (2,1)
+                xt = torch.nn.functional.pad(torch.from_numpy(_h(x)).permute(0, 3, 1, 2), (2, 1, 2, 1))
+                ref = torch.relu(torch.nn.functional.conv2d(xt, torch.from_numpy(_h(w)), torch.from_numpy(b))).permute(0, 2, 3, 1).numpy()
+            else:
+                ref = _conv_ref(x, w, b, stride, pad, True, res)
+            np.testing.assert_allclose(got, ref, rtol=2e-3, atol=2e-3)
+    finally:
+        L.fpt_set_conv_variant(0)
+
+
 def test_conv_transpose_detecting_and_split_store():
     # asymmetric weights/inputs (a transposed fragment layout cannot pass) + the a|b channel-concat epilogue
     NB, H, Cin, Cout = 4, 8, 128, 128
