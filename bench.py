@@ -12,8 +12,10 @@ with the frame (rgb, depth, mask) already resident in HBM when the timed region 
            `--hyps 1008` selects BASELINE.json configs[3] (1008 hypotheses sharded over the ranks = strong scaling).
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline     -- dominant kernel (conv_igemm_kernel, MFMA-bound): algorithmic FLOPs of its launches in one step /
-                  their HIP-event durations on the library's stream, vs the 2.5 PFLOP/s dense fp16 MFMA peak.
+  roofline     -- dominant kernel (the conv/linear implicit-GEMM kernel with the largest share of the step, MFMA-bound):
+                  algorithmic FLOPs of its launches in one step / their HIP-event durations on the library's stream
+                  (fp_profile_*), vs the 2.5 PFLOP/s dense fp16 MFMA peak; `traffic` = fabric bytes per launch from the
+                  committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (profiles/, corrected as the guide prescribes).
   cpu_baseline -- the oracle (C/OpenMP geometry + PyTorch-CPU fp32 networks), N = 8 Register, on the host cores.
 """
 import argparse
@@ -33,7 +35,7 @@ PEAK_FP16_TFLOPS = 2500.0   # MI355X dense fp16/bf16 MFMA peak (MI355X_MICROARCH
 BASELINE_HYP_S = 705.6      # reference README.md:37-41: Register 2.8 fps x 252 on RTX 4060 (TensorRT fp16)
 
 
-def cpu_baseline(mesh, scene, states, n_hyp=8, reps=1):
+def cpu_baseline(mesh, scene, states, n_hyp=8, reps=8):
     """Register (refine_itr=1) over n_hyp hypotheses with the CPU oracle; returns hypotheses/s."""
     import torch
     from oracle import fp_oracle as fo
@@ -149,12 +151,30 @@ def main():
     if rank == 0:
         units = 1 if args.track else n_total
         ms = dt / args.steps * 1e3
+        # profiler keys are "<layer>/<kernel symbol>" for the conv family, "<kernel family>" otherwise
         conv = {k: v for k, v in prof.items() if k.startswith("conv_") or k.startswith("gemm_")}
         conv_flops = sum(v["flops"] for v in conv.values())
         conv_ms = sum(v["ms"] for v in conv.values())
-        conv_calls = sum(v["calls"] for v in conv.values())
-        achieved = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
-        stages = {k: round(v["ms"], 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}
+        by_sym = {}
+        for k, v in conv.items():
+            sym = k.split("/", 1)[1] if "/" in k else k
+            a = by_sym.setdefault(sym, dict(ms=0.0, flops=0.0, bytes=0.0, calls=0))
+            for f in ("ms", "flops", "bytes", "calls"):
+                a[f] += v[f]
+        dom, dv = max(by_sym.items(), key=lambda kv: kv[1]["ms"]) if by_sym else ("none", dict(ms=0, flops=0, bytes=0, calls=1))
+        achieved = dv["flops"] / (dv["ms"] * 1e-3) / 1e12 if dv["ms"] > 0 else 0.0
+        family = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+        stages = {}
+        for k, v in prof.items():
+            stages[k.split("/", 1)[0]] = stages.get(k.split("/", 1)[0], 0.0) + v["ms"]
+        stages = {k: round(v, 3) for k, v in sorted(stages.items(), key=lambda kv: -kv[1])}
+        traffic, traffic_src = None, None
+        pmc_path = os.path.join(ROOT, "profiles", "r01b_register_n252_pmc_hbm.json")
+        if os.path.exists(pmc_path) and not args.track and world == 1:
+            pmc = json.load(open(pmc_path))
+            for name, rec in pmc.items():
+                if dom.split("<")[0] in name:
+                    traffic, traffic_src = round(rec["traffic_bytes_per_launch"]), os.path.relpath(pmc_path, ROOT)
         res = {
             "metric": "Track fps (N=1)" if args.track else "pose-hypotheses/sec (Register N=252, 640x480)",
             "value": round(units * args.steps / dt, 2),
@@ -173,11 +193,16 @@ def main():
                 "baseline": "reference README.md:37-41 Register 2.8 fps x 252 = 705.6 hyp/s on RTX 4060 (TensorRT fp16)",
             },
             "roofline": {
-                "bound": "mfma", "kernel": "conv_igemm_kernel (all conv + linear layers)",
+                "bound": "mfma", "kernel": dom,
                 "achieved": round(achieved, 1), "peak": PEAK_FP16_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / PEAK_FP16_TFLOPS, 4),
-                "launches_per_step": conv_calls, "algorithmic_gflop_per_step": round(conv_flops / 1e9, 1),
-                "avg_launch_ms": round(conv_ms / max(conv_calls, 1), 4), "traffic": None,
+                "launches_per_step": dv["calls"], "algorithmic_gflop_per_launch": round(dv["flops"] / max(dv["calls"], 1) / 1e9, 1),
+                "avg_launch_ms": round(dv["ms"] / max(dv["calls"], 1), 4),
+                "algorithmic_bytes_per_launch": round(dv["bytes"] / max(dv["calls"], 1)),
+                "traffic": traffic, "traffic_source": traffic_src,
+                "conv_family": {"achieved": round(family, 1), "frac": round(family / PEAK_FP16_TFLOPS, 4),
+                                "gflop_per_step": round(conv_flops / 1e9, 1), "ms_per_step": round(conv_ms, 3),
+                                "kernels_ms": {k2: round(v2["ms"], 3) for k2, v2 in by_sym.items()}},
             },
             "stage_ms": stages,
         }

@@ -1453,7 +1453,7 @@ static int run_conv(const Ctx &c, const char *tag, const ConvLayer &L, const __h
       }
     }
   }
-  ProfScope ps(c.prof, c.s, tag, flops, bytes);
+  const std::string tg(tag);
   // large problems: 256-pixel tiles, 3-stage LDS-DMA pipeline (needs >= 3 K-steps and enough tiles to fill 256 CUs)
   const int big_tiles = ((p.M + 255) / 256) * (L.Cout % 128 == 0 ? L.Cout / 128 : L.Cout / 64);
   (void)big_tiles;
@@ -1469,14 +1469,20 @@ static int run_conv(const Ctx &c, const char *tag, const ConvLayer &L, const __h
       const int lds_big = 2 * (256 * 128 + 256 * 128);
       ConvParams pb = p;
       pb.M = mt_big * 256;                                // rows [0, mt_big*256)
-      if (g_conv_variant == 4) hipLaunchKernelGGL(conv_big_kernel, dim3(mt_big * nt2), dim3(512), lds_big, c.s, pb);
-      else hipLaunchKernelGGL(conv_big_pp_kernel, dim3(mt_big * nt2), dim3(512), lds_big, c.s, pb);
+      const double frac = (double)pb.M / (double)p.M;
+      {
+        ProfScope ps(c.prof, c.s, (tg + (g_conv_variant == 4 ? "/conv_big_kernel" : "/conv_big_pp_kernel")).c_str(), flops * frac, bytes * frac);
+        if (g_conv_variant == 4) hipLaunchKernelGGL(conv_big_kernel, dim3(mt_big * nt2), dim3(512), lds_big, c.s, pb);
+        else hipLaunchKernelGGL(conv_big_pp_kernel, dim3(mt_big * nt2), dim3(512), lds_big, c.s, pb);
+      }
+      flops *= (1.0 - frac); bytes *= (1.0 - frac);
       p.m_begin = mt_big * 256;
       if (p.m_begin >= p.M) return 0;
       mtiles = (p.M - p.m_begin + 127) / 128;
     }
   }
   if (g_conv_variant == 3 && KT >= 3 && p.ksplit == 1) {
+    ProfScope ps(c.prof, c.s, (tg + "/conv_pp_kernel").c_str(), flops, bytes);
     int mt2 = (p.M + 255) / 256;
     if (L.Cout % 128 == 0)
       hipLaunchKernelGGL(conv_pp_kernel<128>, dim3(mt2 * (L.Cout / 128)), dim3(512), LDS3_128, c.s, p);
@@ -1485,6 +1491,7 @@ static int run_conv(const Ctx &c, const char *tag, const ConvLayer &L, const __h
     return 0;
   }
   if (g_conv_variant == 2 && KT >= 3) {
+    ProfScope ps(c.prof, c.s, (tg + "/conv_igemm3_kernel").c_str(), flops, bytes);
     int mt2 = (p.M + 255) / 256;
     if (L.Cout % 128 == 0)
       hipLaunchKernelGGL(conv_igemm3_kernel<128>, dim3(mt2 * (L.Cout / 128)), dim3(512), LDS3_128, c.s, p);
@@ -1493,6 +1500,7 @@ static int run_conv(const Ctx &c, const char *tag, const ConvLayer &L, const __h
     return 0;
   }
   if (L.Cout % 128 == 0) {
+    ProfScope ps(c.prof, c.s, (tg + "/conv_igemm_kernel<128>").c_str(), flops, bytes);
     const dim3 grid(mtiles * (L.Cout / 128) * p.ksplit);
     const int lds = 2 * (128 * 128 + 128 * 128);
     switch (g_conv_variant) {
@@ -1506,9 +1514,11 @@ static int run_conv(const Ctx &c, const char *tag, const ConvLayer &L, const __h
       default: hipLaunchKernelGGL((conv_igemm_kernel<128, 3>), grid, dim3(256), lds, c.s, p); break;
     }
   } else {
+    ProfScope ps(c.prof, c.s, (tg + "/conv_igemm_kernel<64>").c_str(), flops, bytes);
     hipLaunchKernelGGL((conv_igemm_kernel<64, 3>), dim3(mtiles * (L.Cout / 64) * p.ksplit), dim3(256), 2 * (128 * 128 + 64 * 128), c.s, p);
   }
   if (p.ksplit > 1) {
+    ProfScope ps(c.prof, c.s, (tg + "/conv_splitk_reduce_kernel").c_str(), 0, 0);
     size_t quads = (size_t)p.M * (p.Cout / 4);
     hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, c.s, p);
   }
