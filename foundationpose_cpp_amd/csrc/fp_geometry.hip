@@ -31,7 +31,7 @@ namespace fp {
 #define CR_DEPTH_MAX (0xFFFFFFFFu - (2200u << 3))
 
 static constexpr int CROP = FP_CROP_HW;
-// rows of the 160-row viewport owned by one workgroup: 40 (4 strips/hypothesis) for large batches, 8 (20 strips) when
+// rows of the 160-row viewport owned by one workgroup: 20 (8 strips/hypothesis) for large batches, 8 (20 strips) when
 // the batch alone cannot fill the chip (Track: N = 1).  The shading pass is a chain of dependent loads per pixel, so
 // its latency is hidden by workgroup count, not by work per thread.
 
@@ -497,7 +497,7 @@ void set_raster_strip_rows(int r) { g_strip_rows_override = r; }
 
 void launch_raster_shade(hipStream_t s, const DeviceMesh &m, const PoseRec *recs, int N, const float4 *clip,
                          const float4 *attr, OutMode mode, void *out, int32_t *tri_id_dbg, float *rast_dbg) {
-  int rows = g_strip_rows_override ? g_strip_rows_override : (N * 4 >= 512 ? 40 : (N * 8 >= 512 ? 20 : 8));
+  int rows = g_strip_rows_override ? g_strip_rows_override : (N >= 64 ? 20 : 8);  // A/B: tools/ab_raster_strips.py
   if (rows == 40) launch_raster_shade_t<40>(s, m, recs, N, clip, attr, mode, out, tri_id_dbg, rast_dbg);
   else if (rows == 20) launch_raster_shade_t<20>(s, m, recs, N, clip, attr, mode, out, tri_id_dbg, rast_dbg);
   else launch_raster_shade_t<8>(s, m, recs, N, clip, attr, mode, out, tri_id_dbg, rast_dbg);
