@@ -88,8 +88,10 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the HIP library has no CPU path")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    force_shard = os.environ.get("FP_BENCH_FORCE_SHARD", "0") == "1"   # exercise the N>1 code path on one GPU
+    if world > 1 or force_shard:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     mesh = syn.make_mesh()
@@ -116,7 +118,7 @@ def main():
             model._must(model._L.fp_track_ex(model.handle, C.c_void_p(rgb.data_ptr()), C.c_void_p(depth.data_ptr()), 1,
                                              H, Wd, hyp16.ctypes.data_as(C.c_void_p), mesh.name.encode(), 1,
                                              out_pose.ctypes.data_as(C.c_void_p)))
-        elif world == 1:
+        elif world == 1 and not force_shard:
             model._must(model._L.fp_register_ex(model.handle, C.c_void_p(rgb.data_ptr()), C.c_void_p(depth.data_ptr()),
                                                 C.c_void_p(mask.data_ptr()), 1, H, Wd, mesh.name.encode(), 1,
                                                 out_pose.ctypes.data_as(C.c_void_p)))
@@ -210,7 +212,7 @@ def main():
             res["cpu_baseline"] = cpu_baseline(mesh, scene, states)
         print(json.dumps(res))
     model.close()
-    if world > 1:
+    if world > 1 or force_shard:
         dist.destroy_process_group()
 
 

@@ -688,6 +688,7 @@ __global__ __launch_bounds__(512, 2) void conv_big_kernel(const ConvParams p) {
 }
 
 // Ping-pong schedule of the 256 x 256 tile (see the slot comment inside).
+template <int ABL>
 __global__ __launch_bounds__(512, 2) void conv_big_pp_kernel(const ConvParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int BM = 256, BN = 256;
@@ -727,13 +728,17 @@ __global__ __launch_bounds__(512, 2) void conv_big_pp_kernel(const ConvParams p)
   const unsigned char *w_b = reinterpret_cast<const unsigned char *>(p.w);
   const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
 
-  auto stage = [&](int kt, int buf) {
+  // the 8 LDS-DMA instructions of a K-step are issued in two halves (X pieces in the wave's L0 slot, W pieces at the
+  // head of its M0 slot) so the address path (64 B/clk/CU) sees them spread over three slots instead of bunched in two
+  auto stage_x = [&](int kt, int buf) {
     const unsigned xs = lds_base + buf * STAGE;
-    const unsigned ws = xs + XB;
     const unsigned char *xb = in_b + p.koff[kt];
-    const unsigned char *wb = w_b + (size_t)kt * 128;
 #pragma unroll
     for (int i = 0; i < 4; i++) glds16_asm(xb + xoff[i], xs + (wave * 4 + i) * 1024);
+  };
+  auto stage_w = [&](int kt, int buf) {
+    const unsigned ws = lds_base + buf * STAGE + XB;
+    const unsigned char *wb = w_b + (size_t)kt * 128;
 #pragma unroll
     for (int i = 0; i < 4; i++) glds16_asm(wb + woffv[i], ws + (wave * 4 + i) * 1024);
   };
@@ -762,6 +767,13 @@ __global__ __launch_bounds__(512, 2) void conv_big_pp_kernel(const ConvParams p)
     for (int ni = 0; ni < NI; ni++) wf[ni] = *reinterpret_cast<const h8 *>(sb + wfo[ks] + ni * 16 * 128);
   };
   auto mfmas = [&]() {
+    if (ABL & 2) {  // ablation: keep fragments live, no MFMAs
+#pragma unroll
+      for (int mi = 0; mi < MI; mi++) asm volatile("" ::"v"(xf[mi]));
+#pragma unroll
+      for (int ni = 0; ni < NI; ni++) asm volatile("" ::"v"(wf[ni]));
+      return;
+    }
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int ni = 0; ni < NI; ni++)
@@ -781,15 +793,18 @@ __global__ __launch_bounds__(512, 2) void conv_big_pp_kernel(const ConvParams p)
   // Slots of ~32 MFMAs: group 0 runs L0 M0 L1 M1 per K-step, group 1 the same one slot later, so on every SIMD one
   // wave issues MFMAs from registers while its partner refills fragments from LDS / issues the next tile's LDS-DMA.
   const int KT = p.Ktot >> 6;
-  stage(0, 0);
+  stage_x(0, 0);
+  stage_w(0, 0);
   FP_VM0();
   FP_BAR();
+  if (p.clk && tid == 0) { p.clk[blockIdx.x * 4] = __builtin_readcyclecounter(); p.clk[blockIdx.x * 4 + 1] = wall_clock64(); }
   int buf = 0;
   if (wm == 0) {
     for (int kt = 0; kt < KT; kt++) {
       ld(buf, 0);
-      if (kt + 1 < KT) stage(kt + 1, buf ^ 1);
+      if (kt + 1 < KT && !(ABL & 1)) stage_x(kt + 1, buf ^ 1);
       FP_LGKM0(); FP_BAR();
+      if (kt + 1 < KT && !(ABL & 1)) stage_w(kt + 1, buf ^ 1);
       mfmas(); FP_BAR();
       ld(buf, 1); FP_LGKM0(); FP_BAR();
       mfmas(); FP_VM0(); FP_BAR();
@@ -800,8 +815,9 @@ __global__ __launch_bounds__(512, 2) void conv_big_pp_kernel(const ConvParams p)
     FP_BAR();
     for (int kt = 0; kt < KT; kt++) {
       ld(buf, 0);
-      if (kt + 1 < KT) stage(kt + 1, buf ^ 1);
+      if (kt + 1 < KT && !(ABL & 1)) stage_x(kt + 1, buf ^ 1);
       FP_LGKM0(); FP_BAR();
+      if (kt + 1 < KT && !(ABL & 1)) stage_w(kt + 1, buf ^ 1);
       mfmas(); FP_BAR();
       ld(buf, 1); FP_LGKM0(); FP_VM0(); FP_BAR();
       mfmas(); FP_BAR();
@@ -811,6 +827,7 @@ __global__ __launch_bounds__(512, 2) void conv_big_pp_kernel(const ConvParams p)
 #undef FP_BAR
 #undef FP_LGKM0
 #undef FP_VM0
+  if (p.clk && tid == 0) { p.clk[blockIdx.x * 4 + 2] = __builtin_readcyclecounter(); p.clk[blockIdx.x * 4 + 3] = wall_clock64(); }
 
   conv_epilogue<MI, NI>(p, acc, m0 + wm * 128, n0 + wn * 64, lane);
 }
@@ -1006,21 +1023,19 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const __half *__restrict
   reinterpret_cast<h8 *>(y + row * EMBED)[lane] = r;
 }
 
-// out[b,c] = mean_t x[b,t,c]  (f32 out, pre-zeroed); block per (b, token chunk), thread per channel pair
-__global__ __launch_bounds__(256) void token_mean_kernel(const __half *__restrict__ x, float *__restrict__ out, int T,
-                                                         int tchunk) {
-  int b = blockIdx.x, c = threadIdx.x;
-  int t0 = blockIdx.y * tchunk, t1 = min(T, t0 + tchunk);
-  const h2 *src = reinterpret_cast<const h2 *>(x + (size_t)b * T * EMBED) + c;
-  float s0 = 0.f, s1 = 0.f;
-  for (int t = t0; t < t1; t++) { h2 v = src[(size_t)t * (EMBED / 2)]; s0 += (float)v[0]; s1 += (float)v[1]; }
-  if (gridDim.y == 1) {
-    out[(size_t)b * EMBED + c * 2] = s0 / (float)T;
-    out[(size_t)b * EMBED + c * 2 + 1] = s1 / (float)T;
-  } else {
-    atomicAdd(&out[(size_t)b * EMBED + c * 2], s0 / (float)T);
-    atomicAdd(&out[(size_t)b * EMBED + c * 2 + 1], s1 / (float)T);
-  }
+// out[b,c] = mean_t x[b,t,c]  (f32 out).  Deterministic (no atomics: the arg-max over near-tied scores must not depend
+// on summation order): block = (b, 64-channel group); 4 waves each sum a quarter of the tokens, lane = channel, fixed
+// order combine through LDS.
+__global__ __launch_bounds__(256) void token_mean_kernel(const __half *__restrict__ x, float *__restrict__ out, int T) {
+  __shared__ float part[4][64];
+  const int b = blockIdx.x, cg = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const __half *src = x + (size_t)b * T * EMBED + cg * 64 + lane;
+  const int per = (T + 3) / 4, t0 = wave * per, t1 = min(T, t0 + per);
+  float s = 0.f;
+  for (int t = t0; t < t1; t++) s += __half2float(src[(size_t)t * EMBED]);
+  part[wave][lane] = s;
+  __syncthreads();
+  if (wave == 0) out[(size_t)b * EMBED + cg * 64 + lane] = (((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane]) / (float)T;
 }
 
 // y[b,o] = bias[o] + sum_c x[b,c] W[o,c]   (f32; one wave per output)
@@ -1373,7 +1388,8 @@ static bool g_conv_attr_done = false;
 static unsigned long long *g_clk_probe = nullptr;
 static float *g_splitk_ws = nullptr;  // fp32 partial slabs for split-K (grown on demand; process lifetime)
 static size_t g_splitk_cap = 0;
-static int g_conv_variant = 0;  // 0 auto, 1 force the 128-pixel 2-stage kernel, 2 force the 256-pixel 3-stage kernel (A/B hook)
+static int g_conv_variant = 0;
+static int g_conv_ablate = 0;  // timing-only ablations of conv_big_pp_kernel: 1 no loads, 2 no MFMAs, 3 neither  // 0 auto, 1 force the 128-pixel 2-stage kernel, 2 force the 256-pixel 3-stage kernel (A/B hook)
 
 // in: [NB, H+2*ipad, W+2*ipad, Cin]; out: [.., OH+2*opad, OW+2*opad, ..]; res: border rpad
 static int run_conv(const Ctx &c, const char *tag, const ConvLayer &L, const __half *in, int NB, int H, int W, int ipad,
@@ -1424,7 +1440,10 @@ static int run_conv(const Ctx &c, const char *tag, const ConvLayer &L, const __h
     FP_HIP_OK(hipFuncSetAttribute((const void *)conv_igemm3_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS3_128));
     FP_HIP_OK(hipFuncSetAttribute((const void *)conv_igemm3_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS3_64));
     FP_HIP_OK(hipFuncSetAttribute((const void *)conv_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 * 128 + 256 * 128)));
-    FP_HIP_OK(hipFuncSetAttribute((const void *)conv_big_pp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 * 128 + 256 * 128)));
+    FP_HIP_OK(hipFuncSetAttribute((const void *)conv_big_pp_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 * 128 + 256 * 128)));
+    FP_HIP_OK(hipFuncSetAttribute((const void *)conv_big_pp_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 * 128 + 256 * 128)));
+    FP_HIP_OK(hipFuncSetAttribute((const void *)conv_big_pp_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 * 128 + 256 * 128)));
+    FP_HIP_OK(hipFuncSetAttribute((const void *)conv_big_pp_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 * 128 + 256 * 128)));
     FP_HIP_OK(hipFuncSetAttribute((const void *)conv_pp_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS3_128));
     FP_HIP_OK(hipFuncSetAttribute((const void *)conv_pp_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS3_64));
     g_conv_attr_done = true;
@@ -1473,7 +1492,10 @@ static int run_conv(const Ctx &c, const char *tag, const ConvLayer &L, const __h
       {
         ProfScope ps(c.prof, c.s, (tg + (g_conv_variant == 4 ? "/conv_big_kernel" : "/conv_big_pp_kernel")).c_str(), flops * frac, bytes * frac);
         if (g_conv_variant == 4) hipLaunchKernelGGL(conv_big_kernel, dim3(mt_big * nt2), dim3(512), lds_big, c.s, pb);
-        else hipLaunchKernelGGL(conv_big_pp_kernel, dim3(mt_big * nt2), dim3(512), lds_big, c.s, pb);
+        else if (g_conv_ablate == 1) hipLaunchKernelGGL(conv_big_pp_kernel<1>, dim3(mt_big * nt2), dim3(512), lds_big, c.s, pb);
+        else if (g_conv_ablate == 2) hipLaunchKernelGGL(conv_big_pp_kernel<2>, dim3(mt_big * nt2), dim3(512), lds_big, c.s, pb);
+        else if (g_conv_ablate == 3) hipLaunchKernelGGL(conv_big_pp_kernel<3>, dim3(mt_big * nt2), dim3(512), lds_big, c.s, pb);
+        else hipLaunchKernelGGL(conv_big_pp_kernel<0>, dim3(mt_big * nt2), dim3(512), lds_big, c.s, pb);
       }
       flops *= (1.0 - frac); bytes *= (1.0 - frac);
       p.m_begin = mt_big * 256;
@@ -1551,10 +1573,7 @@ static void run_small_linear(const Ctx &c, const float *x, const LinearF32 &L, f
 
 static void run_token_mean(const Ctx &c, const __half *x, float *out, int B, int T) {
   ProfScope ps(c.prof, c.s, "token_mean", 0, (double)B * T * EMBED * 2.0);
-  const int tchunk = 25;
-  const int ny = (T + tchunk - 1) / tchunk;
-  if (ny > 1) (void)hipMemsetAsync(out, 0, (size_t)B * EMBED * sizeof(float), c.s);
-  hipLaunchKernelGGL(token_mean_kernel, dim3(B, ny), dim3(256), 0, c.s, x, out, T, tchunk);
+  hipLaunchKernelGGL(token_mean_kernel, dim3(B, EMBED / 64), dim3(256), 0, c.s, x, out, T);
 }
 
 // arena carve (by capacity, see ensure_scratch)
@@ -1682,7 +1701,7 @@ int scorer_head(hipStream_t s, Profiler *prof, const Net *net, NNScratch *ws, co
     // Linear(512,1) on fp16 rows: widen to f32 first (tiny)
     ProfScope ps(c.prof, c.s, "score_linear", 2.0 * N * EMBED, 0);
     // token_mean with T = 1 is a plain fp16 -> f32 copy of each row
-    hipLaunchKernelGGL(token_mean_kernel, dim3(N, 1), dim3(256), 0, c.s, xf, o32, 1, 1);
+    hipLaunchKernelGGL(token_mean_kernel, dim3(N, EMBED / 64), dim3(256), 0, c.s, xf, o32, 1);
   }
   run_small_linear(c, o32, net->score_lin, scores_dev, N);
   FP_HIP_OK(hipGetLastError());
@@ -1712,6 +1731,7 @@ std::vector<__half> to_half(const float *src, size_t n) {
 extern "C" {
 
 void fpt_set_conv_variant(int v) { fp::g_conv_variant = v; }
+void fpt_set_conv_ablate(int v) { fp::g_conv_ablate = v; }
 void fpt_set_raster_strip_rows(int r) { fp::set_raster_strip_rows(r); }
 
 // clock probe: allocate room for `blocks` records, run convs, then read back mean shader MHz and mean main-loop cycles

@@ -277,3 +277,41 @@ def test_register_two_refine_iterations_matches_oracle(model, nets, syn_mesh, sy
     idx = int(np.argmin([e[0] + 1e3 * e[1] for e in errs]))
     assert errs[idx][0] < 0.2 and errs[idx][1] < 2e-4, errs[idx]
     assert s[idx] >= s.max() - 5e-3
+
+
+def test_sharded_register_single_rank_matches_plain_register(model, syn_mesh, syn_scene):
+    """fp_register_shard_begin/finish through the torch.distributed helper (world size 1, RCCL backend) must return
+    the same pose as fp_register; a 2-shard emulation (two begin calls + concatenated gather) must agree as well."""
+    import socket
+    import torch.distributed as dist
+    from foundationpose_cpp_amd.distributed import HipShardBackend, shard_range, sharded_register
+    ok, pose = model.Register(syn_scene.rgb, syn_scene.depth, syn_scene.mask, syn_mesh.name)
+    assert ok
+    dev = torch.device("cuda", 0)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        os.environ["MASTER_PORT"] = str(s.getsockname()[1])
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        rgb, depth, mask = (torch.from_numpy(a).to(dev) for a in (syn_scene.rgb, syn_scene.depth, syn_scene.mask))
+        be = HipShardBackend(model, dev)
+        p16, idx = sharded_register(be, dist, 252, rgb, depth, mask, 480, 640, syn_mesh.name, 1)
+        np.testing.assert_allclose(syn.from_colmajor(p16), pose, atol=1e-6)
+        # emulate two ranks on one GPU: shard 0 and shard 1 computed one after the other, then "gathered"
+        feats, poses = [], []
+        for r in range(2):
+            b, c = shard_range(252, 2, r)
+            f, p = be.shard_begin(rgb, depth, mask, 480, 640, syn_mesh.name, 1, b, c)
+            feats.append(f.clone()); poses.append(p.clone())
+        p16b, idxb = be.shard_finish(torch.cat(feats).contiguous(), torch.cat(poses).contiguous())
+        assert idxb == idx
+        np.testing.assert_allclose(p16b, p16, atol=1e-6)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_register_is_deterministic(model, syn_mesh, syn_scene):
+    poses = [model.Register(syn_scene.rgb, syn_scene.depth, syn_scene.mask, syn_mesh.name)[1] for _ in range(3)]
+    np.testing.assert_array_equal(poses[0], poses[1])
+    np.testing.assert_array_equal(poses[0], poses[2])

@@ -27,12 +27,14 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--hyps", type=int, default=126)
     ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--ablate", type=int, default=0)
     ap.add_argument("--only", default="")
     ap.add_argument("--clock", action="store_true")
     ap.add_argument("--variant", type=int, default=0, help="0 auto, 1 = 128-px 2-stage kernel, 2 = 256-px 3-stage kernel")
     a = ap.parse_args()
     L = _lib.lib()
     L.fpt_set_conv_variant(a.variant)
+    L.fpt_set_conv_ablate(a.ablate)
     rng = np.random.default_rng(0)
     tot_ms = tot_fl = 0.0
     shapes = [sh for sh in SHAPES if not a.only or a.only in sh[0]]
@@ -57,7 +59,7 @@ def main():
             assert L.fpt_clk_probe(nblk, None, None) == 0
             L.fpt_conv(p(x), p(w), p(b), None, NB, H, W, Cin, Cout, k, k, stride, pad, OH, OW, 1, 0, p(out), 3, C.byref(ms))
             mhz, cyc = C.c_double(0), C.c_double(0)
-            L.fpt_clk_probe(-min(nblk, ((NB * OH * OW + 127) // 128) * max(Cout // 128, 1)), C.byref(mhz), C.byref(cyc))
+            L.fpt_clk_probe(-min(nblk, 512), C.byref(mhz), C.byref(cyc))
             print(f"   clock probe: {mhz.value:7.0f} MHz shader clock, {cyc.value:9.0f} cycles per block main loop")
         print(f"{name:22s} M={NB * OH * OW:8d} K={k * k * Cin:5d} N={Cout:5d}  {ms.value * 1e3:9.1f} us  {fl / ms.value / 1e9:8.1f} TF/s")
         tot_ms += ms.value * launches
