@@ -69,6 +69,7 @@ struct ConvParams {
               // are consecutive K-steps and their overlapping input pixels are re-read while still L2-resident
   // byte offset of K-step kt's X slab relative to a row's (tap 0, channel 0) address; host-filled, read with s_load
   unsigned koff[80];
+  unsigned koff32[160];  // same per 32-wide K-step (conv_pp32_kernel)
   int m_begin;            // first output row handled by this launch (hybrid 256^2 + 128^2 launches)
   int ksplit, kt_per;     // split-K (small problems): K-steps [split*kt_per, ...) per workgroup, fp32 partial slabs
   float *partial;         // [ksplit][M][Cout]
@@ -832,6 +833,158 @@ __global__ __launch_bounds__(512, 2) void conv_big_pp_kernel(const ConvParams p)
   conv_epilogue<MI, NI>(p, acc, m0 + wm * 128, n0 + wn * 64, lane);
 }
 
+// -------------------------------------------------------------------------------------------------
+// conv_pp32_kernel<BM,BN>: the ping-pong schedule on 32-wide K-steps with a ring of FOUR LDS stages.
+// Ablation of conv_big_pp_kernel (64-wide K-steps, 2 stages) shows it is bound by the latency of the global -> LDS
+// path: with the MFMAs removed a K-step still takes ~2190 cycles (64 KB in flight per CU), against ~1970 with the loads
+// removed.  Halving the K-step and doubling the ring keeps the same 128 KB of LDS but lets three K-steps (96 KB) be in
+// flight, with ~5 slots between issue and first use instead of ~3.
+//   tile BM x BN, 8 waves = (BM/128) x (BN/64), wave tile 128 px x 64 ch (32 accumulators); (256,256) and (512,128).
+//   stage = [BM + BN rows][64 B]; a DMA piece is 16 rows x 64 B; slot = chunk ^ G[(row>>2)&3], G = {0,2,3,1}, is
+//   conflict-free for the four 16-lane groups of ds_read_b128 with 64-byte rows (checked by enumeration).
+// -------------------------------------------------------------------------------------------------
+template <int BM, int BN>
+__global__ __launch_bounds__(512, 2) void conv_pp32_kernel(const ConvParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int WM = BM / 128, WN = BN / 64;
+  static_assert(WM * WN == 8, "8 waves");
+  constexpr int XP = BM / 16, WP = BN / 16, PER = (XP + WP) / 8;  // DMA pieces per stage / per wave
+  constexpr int XB = XP * 1024, STAGE = (XP + WP) * 1024, NST = 4;
+  constexpr int MI = 8, NI = 4;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2;  // waves w and w+4 share a SIMD: the two ping-pong groups
+  const int wm = wave / WN, wn = wave - wm * WN;
+  const int n_tiles = p.Cout / BN;
+  int logical;
+  {
+    const int nblk = gridDim.x, b = blockIdx.x;
+    const int xcd = b & 7, within = b >> 3, q = nblk >> 3, r = nblk & 7;
+    logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
+  }
+  const int mt = logical / n_tiles, nt = logical - mt * n_tiles;
+  const int m0 = mt * BM, n0 = nt * BN;
+  const int ohw = p.OH * p.OW;
+  const int IHp = p.H + 2 * p.ipad, IWp = p.W + 2 * p.ipad;
+
+  // DMA roles: piece = wave + 8*i; lane -> (row = lane>>2, slot = lane&3); source chunk = slot ^ G[(row>>2)&3]
+  const int prow = lane >> 2;
+  const int gsel = (prow >> 2) & 3;
+  const int gch = (lane & 3) ^ ((0x78 >> (gsel * 2)) & 3);  // G = {0,2,3,1} packed two bits each = 0x78
+  unsigned poff[PER];
+#pragma unroll
+  for (int i = 0; i < PER; i++) {
+    const int piece = wave + 8 * i;
+    if (piece < XP) {
+      int m = min(m0 + piece * 16 + prow, p.M - 1);
+      int img = m / ohw;
+      int rem = m - img * ohw;
+      int oh = rem / p.OW, ow = rem - oh * p.OW;
+      int ih0 = oh * p.stride - p.pad + p.ipad, iw0 = ow * p.stride - p.pad + p.ipad;
+      poff[i] = (unsigned)(((img * IHp + ih0) * IWp + iw0) * p.Cin + gch * 8) * 2u;
+    } else {
+      int row = (piece - XP) * 16 + prow;
+      poff[i] = (unsigned)((n0 + row) * p.Ktot + gch * 8) * 2u;
+    }
+  }
+  const unsigned char *in_b = reinterpret_cast<const unsigned char *>(p.in);
+  const unsigned char *w_b = reinterpret_cast<const unsigned char *>(p.w);
+  const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
+
+  auto stage = [&](int st, int buf) {
+    const unsigned sb = lds_base + buf * STAGE;
+    const unsigned char *xb = in_b + p.koff32[st];
+    const unsigned char *wb = w_b + (size_t)st * 64;
+#pragma unroll
+    for (int i = 0; i < PER; i++) {
+      const int piece = wave + 8 * i;
+      glds16_asm((piece < XP ? xb : wb) + poff[i], sb + piece * 1024);
+    }
+  };
+
+  f4 acc[NI][MI];
+#pragma unroll
+  for (int a = 0; a < NI; a++)
+#pragma unroll
+    for (int b = 0; b < MI; b++) acc[a][b] = (f4){0.f, 0.f, 0.f, 0.f};
+
+  // fragment addresses: row-in-tile r, chunk kg = lane>>4, slot = kg ^ G[(r>>2)&3]; (r>>2)&3 == ((lane&15)>>2)
+  const int fsel = (lane & 15) >> 2;
+  const int fslot = (lane >> 4) ^ ((0x78 >> (fsel * 2)) & 3);
+  const int xfo = (wm * 128 + (lane & 15)) * 64 + fslot * 16;
+  const int wfo = XB + (wn * 64 + (lane & 15)) * 64 + fslot * 16;
+
+  h8 xf[MI], wf[NI];
+  auto ld = [&](int buf) {
+    const unsigned char *sb = smem + buf * STAGE;
+#pragma unroll
+    for (int mi = 0; mi < MI; mi++) xf[mi] = *reinterpret_cast<const h8 *>(sb + xfo + mi * 16 * 64);
+#pragma unroll
+    for (int ni = 0; ni < NI; ni++) wf[ni] = *reinterpret_cast<const h8 *>(sb + wfo + ni * 16 * 64);
+  };
+  auto mfmas = [&]() {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ni = 0; ni < NI; ni++)
+#pragma unroll
+      for (int mi = 0; mi < MI; mi++)
+        acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ni], xf[mi], acc[ni][mi], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+  };
+#define FP_BAR()                         \
+  do {                                   \
+    __builtin_amdgcn_s_barrier();        \
+    __builtin_amdgcn_sched_barrier(0);   \
+  } while (0)
+#define FP_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#define FP_VM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+  // after the (optional) issue for step s+3, make sure this wave's pieces of step s+1 have landed
+#define FP_WAIT_NEXT(s)                                  \
+  do {                                                   \
+    if ((s) + 3 < S) FP_VM(2 * PER);                     \
+    else if ((s) + 2 < S) FP_VM(PER);                    \
+    else FP_VM(0);                                       \
+  } while (0)
+
+  const int S = p.Ktot >> 5;  // 32-wide K-steps, >= 16 for every layer
+  stage(0, 0);
+  stage(1, 1);
+  stage(2, 2);
+  FP_VM(2 * PER);
+  FP_BAR();
+  int rb = 0, wb = 3;
+  if (grp == 0) {
+    for (int s = 0; s < S; s++) {
+      ld(rb);
+      if (s + 3 < S) stage(s + 3, wb);
+      FP_LGKM0(); FP_BAR();
+      mfmas();
+      FP_WAIT_NEXT(s);
+      FP_BAR();
+      rb = (rb + 1) & 3; wb = (wb + 1) & 3;
+    }
+    FP_BAR();
+  } else {
+    FP_BAR();
+    for (int s = 0; s < S; s++) {
+      ld(rb);
+      if (s + 3 < S) stage(s + 3, wb);
+      FP_LGKM0();
+      FP_WAIT_NEXT(s);
+      FP_BAR();
+      mfmas();
+      FP_BAR();
+      rb = (rb + 1) & 3; wb = (wb + 1) & 3;
+    }
+  }
+#undef FP_BAR
+#undef FP_LGKM0
+#undef FP_VM
+#undef FP_WAIT_NEXT
+  conv_epilogue<MI, NI>(p, acc, m0 + wm * 128, n0 + wn * 64, lane);
+}
+
 // split-K reduction + the conv epilogue: out = relu(sum_s partial[s] + bias + res); thread = (pixel, 4 channels)
 __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvParams p) {
   const int nq = p.Cout / 4;
@@ -1423,6 +1576,7 @@ static int run_conv(const Ctx &c, const char *tag, const ConvLayer &L, const __h
       if (L.Cin >= 64) { ch = kt / p.ntaps; int tap = kt % p.ntaps; kh = tap / L.KW; kw = tap % L.KW; }
       else { ch = 0; int tap = 2 * kt; kh = tap / L.KW; kw = tap % L.KW; }
       p.koff[kt] = (unsigned)(((kh * IWp + kw) * L.Cin + ch * 64) * 2);
+      if (2 * kt + 1 < 160) { p.koff32[2 * kt] = p.koff[kt]; p.koff32[2 * kt + 1] = p.koff[kt] + 64; }
     }
   }
   double flops = 2.0 * (double)p.M * p.Cout * (L.algo_K > 0 ? L.algo_K : p.Ktot);
@@ -1440,6 +1594,8 @@ static int run_conv(const Ctx &c, const char *tag, const ConvLayer &L, const __h
     FP_HIP_OK(hipFuncSetAttribute((const void *)conv_igemm3_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS3_128));
     FP_HIP_OK(hipFuncSetAttribute((const void *)conv_igemm3_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS3_64));
     FP_HIP_OK(hipFuncSetAttribute((const void *)conv_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 * 128 + 256 * 128)));
+    FP_HIP_OK(hipFuncSetAttribute((const void *)conv_pp32_kernel<256, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * (256 + 256) * 64));
+    FP_HIP_OK(hipFuncSetAttribute((const void *)conv_pp32_kernel<512, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * (512 + 128) * 64));
     FP_HIP_OK(hipFuncSetAttribute((const void *)conv_big_pp_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 * 128 + 256 * 128)));
     FP_HIP_OK(hipFuncSetAttribute((const void *)conv_big_pp_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 * 128 + 256 * 128)));
     FP_HIP_OK(hipFuncSetAttribute((const void *)conv_big_pp_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 * 128 + 256 * 128)));
@@ -1479,6 +1635,30 @@ static int run_conv(const Ctx &c, const char *tag, const ConvLayer &L, const __h
   // measured (tools/bench_conv.py, N=126): the 128-px 2-stage kernel beats the 256-px 3-stage one on every layer
   // (756-769 vs 703-709 TF/s weighted), so the latter is only reachable through the A/B hook
   p.m_begin = 0;
+  if (((g_conv_variant == 0 && L.Cout == 128) || (g_conv_variant == 6 && (L.Cout % 256 == 0 || L.Cout == 128))) && p.ksplit == 1 &&
+      KT >= 4 && KT <= 80) {
+    // ping-pong tiles (conv_pp32_kernel) for as many FULL rounds of the 256 CUs as the problem has; the remaining rows
+    // go to the 128x128 kernel below
+    const bool wide = L.Cout % 256 == 0;
+    const int bm = wide ? 256 : 512, bn = wide ? 256 : 128;
+    const int nt2 = L.Cout / bn;
+    const int mt_all = p.M / bm;
+    const int mt_big = (mt_all * nt2 / 256) * 256 / nt2;
+    if (mt_big > 0) {
+      ConvParams pb = p;
+      pb.M = mt_big * bm;
+      const double frac = (double)pb.M / (double)p.M;
+      {
+        ProfScope ps(c.prof, c.s, (tg + (wide ? "/conv_pp32_kernel<256,256>" : "/conv_pp32_kernel<512,128>")).c_str(), flops * frac, bytes * frac);
+        if (wide) hipLaunchKernelGGL((conv_pp32_kernel<256, 256>), dim3(mt_big * nt2), dim3(512), 4 * (256 + 256) * 64, c.s, pb);
+        else hipLaunchKernelGGL((conv_pp32_kernel<512, 128>), dim3(mt_big * nt2), dim3(512), 4 * (512 + 128) * 64, c.s, pb);
+      }
+      flops *= (1.0 - frac); bytes *= (1.0 - frac);
+      p.m_begin = mt_big * bm;
+      if (p.m_begin >= p.M) return 0;
+      mtiles = (p.M - p.m_begin + 127) / 128;
+    }
+  }
   if ((g_conv_variant == 4 || g_conv_variant == 5 || g_conv_variant == 0) && L.Cout % 256 == 0 && p.ksplit == 1 && KT >= 2) {
     // 256x256 tiles for as many FULL rounds of the 256 CUs as the problem has, the remaining rows on 128x128 tiles
     const int nt2 = L.Cout / 256;

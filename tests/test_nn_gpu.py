@@ -80,7 +80,7 @@ def test_conv_igemm_matches_torch(shape):
     np.testing.assert_allclose(got, ref, rtol=2e-3, atol=2e-3)
 
 
-@pytest.mark.parametrize("variant", [2, 3, 4, 5])
+@pytest.mark.parametrize("variant", [2, 3, 4, 5, 6])
 def test_conv_alternative_schedules_match_torch(variant):
     """the 256-pixel 3-stage (2) and ping-pong (3) schedules of the same implicit GEMM (A/B hooks)"""
     L = _lib.lib()
@@ -88,7 +88,7 @@ def test_conv_alternative_schedules_match_torch(variant):
     try:
         L.fpt_set_conv_variant(variant)
         for (NB, H, Cin, Cout, k, stride, use_res) in [(9, 40, 128, 128, 3, 1, True), (5, 40, 256, 256, 3, 1, False),
-                                                       (70, 20, 512, 512, 3, 1, True), (90, 40, 256, 256, 3, 1, True), (3, 80, 64, 128, 3, 2, False),
+                                                       (70, 20, 512, 512, 3, 1, True), (90, 40, 256, 256, 3, 1, True), (170, 40, 128, 128, 3, 1, True), (3, 80, 64, 128, 3, 2, False),
                                                        (40, 400, 512, 1536, 1, 1, False), (5, 80, 32, 64, 4, 1, False)]:
             W_ = 1 if k == 1 else H
             x = rng.normal(size=(NB, H, W_, Cin)).astype(np.float32)
