@@ -76,23 +76,33 @@ struct ConvParams {
   unsigned long long *clk;  // optional clock probe: per block {cycles0, realtime0, cycles1, realtime1}
 };
 
-// Epilogue shared by every conv schedule.  acc[ni][mi] holds D^T tiles: lane owns channels n_base + ni*16 + 4*(lane>>4)
-// .. +3 of pixel m_base + mi*16 + (lane&15).  All bias and residual loads are issued BEFORE the first store: on CDNA4
-// stores also count in vmcnt, so a load issued behind a store cannot be waited for without draining the store, and the
-// naive per-tile load -> add -> store order serialises into one memory round trip per tile (32 per wave for the
-// 256 x 256 tile: 15-25 us of a 75 us workgroup).
+// Epilogue shared by every conv schedule.
+// Weight rows are PERMUTED on the host inside each block of 16*NI output channels (permute_rows): MFMA tile ni, row
+// i = 4g + j (g = lane>>4, j = accumulator register) computes channel
+//     NI == 4:  32*(j>>1) + 8*g + 4*(j&1) + ni        NI == 2:  8*g + 2*j + ni
+// so a lane's accumulators hold 8 CONSECUTIVE channels per 16-byte store and the four lane groups of a store
+// instruction cover 64 contiguous bytes of one pixel (the natural D^T layout gives 4 channels / 8 bytes per store and
+// twice the store instructions; the 256x256 kernel spent 13 us of a 70 us workgroup in its store burst).
+// All bias and residual loads are issued BEFORE the first store: on CDNA4 stores also count in vmcnt, so a load issued
+// behind a store cannot be waited for without draining the store.
 template <int MI, int NI>
 __device__ __forceinline__ void conv_epilogue(const ConvParams &p, f4 (&acc)[NI][MI], int m_base, int n_base, int lane) {
+  static_assert(NI == 4 || NI == 2, "wave covers 64 or 32 channels");
+  constexpr int NS = NI / 2;  // 16-byte stores per pixel per lane
   const int ohw = p.OH * p.OW;
   const int OHp = p.OH + 2 * p.opad, OWp = p.OW + 2 * p.opad;
   const int RHp = p.OH + 2 * p.rpad, RWp = p.OW + 2 * p.rpad;
-  const int nl = n_base + (lane >> 4) * 4;
-  float4 bv[NI];
+  const int g = lane >> 4;
+  const int nl = n_base + 8 * g;  // store k covers channels nl + 32*k .. +7
+  float bv[NS][8];
 #pragma unroll
-  for (int ni = 0; ni < NI; ni++) bv[ni] = *reinterpret_cast<const float4 *>(p.bias + nl + ni * 16);
+  for (int k = 0; k < NS; k++) {
+    float4 b0 = *reinterpret_cast<const float4 *>(p.bias + nl + 32 * k), b1 = *reinterpret_cast<const float4 *>(p.bias + nl + 32 * k + 4);
+    bv[k][0] = b0.x; bv[k][1] = b0.y; bv[k][2] = b0.z; bv[k][3] = b0.w; bv[k][4] = b1.x; bv[k][5] = b1.y; bv[k][6] = b1.z; bv[k][7] = b1.w;
+  }
   size_t oofs[MI];
   bool ok[MI];
-  h4 rv[NI][MI];
+  h8 rv[NS][MI];
 #pragma unroll
   for (int mi = 0; mi < MI; mi++) {
     int m = m_base + mi * 16 + (lane & 15);
@@ -107,20 +117,48 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams &p, f4 (&acc)[NI]
     if (p.res) {
       size_t rpix = ((size_t)img * RHp + oh + p.rpad) * RWp + ow + p.rpad;
 #pragma unroll
-      for (int ni = 0; ni < NI; ni++)
-        rv[ni][mi] = ok[mi] ? *reinterpret_cast<const h4 *>(p.res + rpix * p.res_ld + nl + ni * 16) : (h4){0, 0, 0, 0};
+      for (int k = 0; k < NS; k++)
+        rv[k][mi] = ok[mi] ? *reinterpret_cast<const h8 *>(p.res + rpix * p.res_ld + nl + 32 * k) : (h8){0, 0, 0, 0, 0, 0, 0, 0};
     }
   }
 #pragma unroll
   for (int mi = 0; mi < MI; mi++) {
     if (!ok[mi]) continue;
 #pragma unroll
-    for (int ni = 0; ni < NI; ni++) {
-      float v0 = acc[ni][mi][0] + bv[ni].x, v1 = acc[ni][mi][1] + bv[ni].y, v2 = acc[ni][mi][2] + bv[ni].z, v3 = acc[ni][mi][3] + bv[ni].w;
-      if (p.res) { v0 += (float)rv[ni][mi][0]; v1 += (float)rv[ni][mi][1]; v2 += (float)rv[ni][mi][2]; v3 += (float)rv[ni][mi][3]; }
-      if (p.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
-      h4 o = {(_Float16)v0, (_Float16)v1, (_Float16)v2, (_Float16)v3};
-      *reinterpret_cast<h4 *>(p.out + oofs[mi] + nl + ni * 16) = o;
+    for (int k = 0; k < NS; k++) {
+      h8 o;
+#pragma unroll
+      for (int e = 0; e < 8; e++) {
+        const int jj = (NI == 4) ? 2 * k + (e >> 2) : (e >> 1);
+        const int ni = (NI == 4) ? (e & 3) : (e & 1);
+        float v = acc[ni][mi][jj] + bv[k][e];
+        if (p.res) v += (float)rv[k][mi][e];
+        if (p.relu) v = fmaxf(v, 0.f);
+        o[e] = (_Float16)v;
+      }
+      *reinterpret_cast<h8 *>(p.out + oofs[mi] + nl + 32 * k) = o;
+    }
+  }
+}
+
+// split-K partial slab (true channel order): per accumulator register j a lane owns NI consecutive channels
+template <int MI, int NI>
+__device__ __forceinline__ void conv_store_partial(const ConvParams &p, f4 (&acc)[NI][MI], int split, int m_base, int n_base, int lane) {
+  const int g = lane >> 4;
+#pragma unroll
+  for (int mi = 0; mi < MI; mi++) {
+    int m = m_base + mi * 16 + (lane & 15);
+    if (m >= p.M) continue;
+    float *dst = p.partial + ((size_t)split * p.M + m) * p.Cout + n_base;
+#pragma unroll
+    for (int jj = 0; jj < 4; jj++) {
+      if (NI == 4) {
+        f4 v = {acc[0][mi][jj], acc[1][mi][jj], acc[2][mi][jj], acc[3][mi][jj]};
+        *reinterpret_cast<f4 *>(dst + 32 * (jj >> 1) + 8 * g + 4 * (jj & 1)) = v;
+      } else {
+        float2 v = make_float2(acc[0][mi][jj], acc[1][mi][jj]);
+        *reinterpret_cast<float2 *>(dst + 8 * g + 2 * jj) = v;
+      }
     }
   }
 }
@@ -277,16 +315,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
 
   if (p.clk && tid == 0) { p.clk[blockIdx.x * 4 + 2] = __builtin_readcyclecounter(); p.clk[blockIdx.x * 4 + 3] = wall_clock64(); }
   if (p.ksplit > 1) {  // split-K: raw fp32 partial slab, reduced (+ bias / residual / ReLU) by conv_splitk_reduce_kernel
-#pragma unroll
-    for (int mi = 0; mi < 4; mi++) {
-      int m = m0 + wm * 64 + mi * 16 + (lane & 15);
-      if (m >= p.M) continue;
-#pragma unroll
-      for (int ni = 0; ni < NREP; ni++) {
-        int n = n0 + wn * (BN / 2) + ni * 16 + (lane >> 4) * 4;
-        *reinterpret_cast<f4 *>(p.partial + ((size_t)split * p.M + m) * p.Cout + n) = acc[ni][mi];
-      }
-    }
+    conv_store_partial<4, NREP>(p, acc, split, m0 + wm * 64, n0 + wn * (BN / 2), lane);
     return;
   }
   // ---- epilogue: lane owns channels cb..cb+3 (cb = 4*(lane>>4)) of pixel (lane&15) in each 16x16 tile
@@ -830,6 +859,13 @@ __global__ __launch_bounds__(512, 2) void conv_big_pp_kernel(const ConvParams p)
 #undef FP_VM0
   if (p.clk && tid == 0) { p.clk[blockIdx.x * 4 + 2] = __builtin_readcyclecounter(); p.clk[blockIdx.x * 4 + 3] = wall_clock64(); }
 
+  if (ABL & 4) {  // ablation: no epilogue (keep the accumulators live)
+#pragma unroll
+    for (int a = 0; a < NI; a++)
+#pragma unroll
+      for (int b = 0; b < MI; b++) asm volatile("" ::"v"(acc[a][b]));
+    return;
+  }
   conv_epilogue<MI, NI>(p, acc, m0 + wm * 128, n0 + wn * 64, lane);
 }
 
@@ -1335,6 +1371,21 @@ static std::vector<__half> relayout_k(const std::vector<__half> &w, int Cout, in
   return o;
 }
 
+// Row permutation matching conv_epilogue: inside every block of 16*NI output channels (NI = 4, or 2 when Cout == 64)
+// kernel row ni*16 + 4g + j holds the weights of channel 32*(j>>1) + 8g + 4*(j&1) + ni (NI=4) / 8g + 2j + ni (NI=2).
+static std::vector<__half> permute_rows(const std::vector<__half> &w, int Cout, int K) {
+  const int NI = (Cout % 128 == 0) ? 4 : 2, blk = 16 * NI;
+  std::vector<__half> o(w.size());
+  for (int b0 = 0; b0 < Cout; b0 += blk)
+    for (int ni = 0; ni < NI; ni++)
+      for (int g = 0; g < 4; g++)
+        for (int j = 0; j < 4; j++) {
+          int ch = (NI == 4) ? 32 * (j >> 1) + 8 * g + 4 * (j & 1) + ni : 8 * g + 2 * j + ni;
+          std::memcpy(&o[(size_t)(b0 + ni * 16 + 4 * g + j) * K], &w[(size_t)(b0 + ch) * K], (size_t)K * sizeof(__half));
+        }
+  return o;
+}
+
 // PyTorch conv weight [Cout,Cin,KH,KW] -> [Cout][KH][KW][Cin] fp16 -> kernel K order
 static bool make_conv(Net *net, const std::map<std::string, HostTensor> &m, const std::string &prefix, int stride,
                       ConvLayer *L, std::string *err) {
@@ -1348,7 +1399,7 @@ static bool make_conv(Net *net, const std::map<std::string, HostTensor> &m, cons
       for (int kh = 0; kh < KH; kh++)
         for (int kw = 0; kw < KW; kw++)
           hw[(((size_t)co * KH + kh) * KW + kw) * Ci + ci] = __float2half(w->data[(((size_t)co * Ci + ci) * KH + kh) * KW + kw]);
-  L->w = upload(net, relayout_k(hw, Co, KH * KW, Ci));
+  L->w = upload(net, permute_rows(relayout_k(hw, Co, KH * KW, Ci), Co, KH * KW * Ci));
   L->bias = upload(net, b->data);
   L->Cin = Ci; L->Cout = Co; L->KH = KH; L->KW = KW; L->stride = stride; L->pad = (KH - 1) / 2;
   return L->w && L->bias;
@@ -1373,7 +1424,7 @@ static bool make_stem(Net *net, const std::map<std::string, HostTensor> &m, cons
               hw[(((size_t)co * 4 + a) * 4 + bb) * 32 + (dy * 2 + dx) * 8 + c] =
                   __float2half(w->data[(((size_t)co * 6 + c) * 7 + kh) * 7 + kw]);
           }
-  L->w = upload(net, hw);
+  L->w = upload(net, permute_rows(hw, 64, 16 * 32));
   L->bias = upload(net, b->data);
   L->Cin = 32; L->Cout = 64; L->KH = 4; L->KW = 4; L->stride = 1; L->pad = 2; L->algo_K = 7 * 7 * 6;
   return L->w && L->bias;
@@ -1387,7 +1438,7 @@ static bool make_linear_conv(Net *net, const std::map<std::string, HostTensor> &
   if (w->shape.size() != 2) { *err = wname + ": expected 2-d weight"; return false; }
   std::vector<__half> hw(w->data.size());
   for (size_t i = 0; i < hw.size(); i++) hw[i] = __float2half(w->data[i]);
-  L->w = upload(net, hw);
+  L->w = upload(net, permute_rows(hw, w->shape[0], w->shape[1]));
   L->bias = upload(net, b->data);
   L->Cout = w->shape[0]; L->Cin = w->shape[1]; L->KH = L->KW = 1; L->stride = 1; L->pad = 0;
   return L->w && L->bias;
@@ -1600,6 +1651,7 @@ static int run_conv(const Ctx &c, const char *tag, const ConvLayer &L, const __h
     FP_HIP_OK(hipFuncSetAttribute((const void *)conv_big_pp_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 * 128 + 256 * 128)));
     FP_HIP_OK(hipFuncSetAttribute((const void *)conv_big_pp_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 * 128 + 256 * 128)));
     FP_HIP_OK(hipFuncSetAttribute((const void *)conv_big_pp_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 * 128 + 256 * 128)));
+    FP_HIP_OK(hipFuncSetAttribute((const void *)conv_big_pp_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 * 128 + 256 * 128)));
     FP_HIP_OK(hipFuncSetAttribute((const void *)conv_pp_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS3_128));
     FP_HIP_OK(hipFuncSetAttribute((const void *)conv_pp_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS3_64));
     g_conv_attr_done = true;
@@ -1675,6 +1727,7 @@ static int run_conv(const Ctx &c, const char *tag, const ConvLayer &L, const __h
         else if (g_conv_ablate == 1) hipLaunchKernelGGL(conv_big_pp_kernel<1>, dim3(mt_big * nt2), dim3(512), lds_big, c.s, pb);
         else if (g_conv_ablate == 2) hipLaunchKernelGGL(conv_big_pp_kernel<2>, dim3(mt_big * nt2), dim3(512), lds_big, c.s, pb);
         else if (g_conv_ablate == 3) hipLaunchKernelGGL(conv_big_pp_kernel<3>, dim3(mt_big * nt2), dim3(512), lds_big, c.s, pb);
+        else if (g_conv_ablate == 4) hipLaunchKernelGGL(conv_big_pp_kernel<4>, dim3(mt_big * nt2), dim3(512), lds_big, c.s, pb);
         else hipLaunchKernelGGL(conv_big_pp_kernel<0>, dim3(mt_big * nt2), dim3(512), lds_big, c.s, pb);
       }
       flops *= (1.0 - frac); bytes *= (1.0 - frac);
@@ -1959,7 +2012,7 @@ int fpt_conv(const float *x, const float *w, const float *bias, const float *res
       for (int xx = 0; xx < W; xx++)
         for (int c = 0; c < Cin; c++)
           hx[(((size_t)n * Hp + y + ip) * Wp + xx + ip) * Cin + c] = __float2half(x[(((size_t)n * H + y) * W + xx) * Cin + c]);
-  auto hw = relayout_k(to_half(w, nw), Cout, KH * KW, Cin);
+  auto hw = permute_rows(relayout_k(to_half(w, nw), Cout, KH * KW, Cin), Cout, KH * KW * Cin);
   FP_HIP_OK(hipMemcpy(dx.p, hx.data(), nx * 2, hipMemcpyHostToDevice));
   FP_HIP_OK(hipMemcpy(dw.p, hw.data(), nw * 2, hipMemcpyHostToDevice));
   FP_HIP_OK(hipMemcpy(db.p, bias, (size_t)Cout * 4, hipMemcpyHostToDevice));
