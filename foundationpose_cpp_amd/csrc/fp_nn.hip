@@ -1054,17 +1054,28 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvParam
 // attention: out[b,t,h*128+d] = softmax_k(q.k/sqrt(128)) v,  qkv = [B,T,1536] (q|k|v, heads contiguous inside each)
 // =================================================================================================
 
-__global__ __launch_bounds__(256) void attention_kernel(const __half *__restrict__ qkv, __half *__restrict__ out, int T) {
+// ATT_QROWS query rows per workgroup (64 = 4 waves, one per SIMD; 80-row / 5-wave tiles cover 400 tokens exactly but
+// measured 12 % slower: two waves of a workgroup share a SIMD).  The 1-D grid is remapped so the query
+// tiles of one (image, head) run on the SAME XCD and share its L2 copy of K/V (a (qt,h,b) grid spread them over all 8
+// XCDs: rocprofv3 FETCH_SIZE showed 1.16 GB fetched per launch for 0.31 GB of QKV).
+template <int ATT_QROWS, bool REMAP, bool PERM = true>
+__global__ __launch_bounds__(ATT_QROWS * 4) void attention_kernel(const __half *__restrict__ qkv, __half *__restrict__ out, int T, int nq) {
   constexpr int KS = 136;  // K tile row stride (halfs): 128 + 8 pad
   constexpr int VS = 40;   // V^T tile row stride (halfs): 32 keys + 8 pad
   __shared__ __attribute__((aligned(16))) _Float16 Ks[32 * KS];
   __shared__ __attribute__((aligned(16))) _Float16 Vt[HDIM * VS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  int logical;
+  {
+    const int nblk = gridDim.x, bi = blockIdx.x;
+    const int xcd = bi & 7, within = bi >> 3, q = nblk >> 3, r = nblk & 7;
+    logical = REMAP ? (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within : bi;
+  }
+  const int qt = logical % nq, h = (logical / nq) % HEADS, b = logical / (nq * HEADS);
   const int g = lane >> 4, li = lane & 15;
   const size_t rowstride = 3 * EMBED;
   const __half *base = qkv + (size_t)b * T * rowstride;
-  const int q_row = qt * 64 + wave * 16 + li;
+  const int q_row = qt * ATT_QROWS + wave * 16 + li;
   const int q_ld = min(q_row, T - 1);
   h8 qf[4];
 #pragma unroll
@@ -1081,8 +1092,10 @@ __global__ __launch_bounds__(256) void attention_kernel(const __half *__restrict
   // staging roles.  K: thread -> (key = idx>>4, 16-B chunk = idx&15): coalesced 256-B rows.  V: thread -> (key = idx&31,
   // chunk = idx>>5) so the 2-byte transposed LDS writes of one instruction cover 32 consecutive keys of one d row
   // (bank-conflict free; the previous key-major mapping was a 16-way conflict on every ds_write_b16).
+  // (the first 4 waves stage; wave 4 only computes)
   h8 kreg[2], vreg[2];
   auto load_tile = [&](int kb) {
+    if (ATT_QROWS > 64 && tid >= 256) return;
 #pragma unroll
     for (int j = 0; j < 2; j++) {
       int idx = tid + j * 256;
@@ -1094,13 +1107,17 @@ __global__ __launch_bounds__(256) void attention_kernel(const __half *__restrict
   };
   load_tile(0);
   for (int kb = 0; kb < nkb; kb++) {
+    if (ATT_QROWS <= 64 || tid < 256) {
 #pragma unroll
-    for (int j = 0; j < 2; j++) {
-      int idx = tid + j * 256;
-      *reinterpret_cast<h8 *>(&Ks[(idx >> 4) * KS + (idx & 15) * 8]) = kreg[j];
-      int key = idx & 31, chunk = idx >> 5;
+      for (int j = 0; j < 2; j++) {
+        int idx = tid + j * 256;
+        *reinterpret_cast<h8 *>(&Ks[(idx >> 4) * KS + (idx & 15) * 8]) = kreg[j];
+        int key = idx & 31, chunk = idx >> 5;
+        // V^T row e*16 + chunk holds d = chunk*8 + e, so MFMA column li of tile dt is d = li*8 + dt and a lane ends up
+        // owning 8 consecutive d (one 16-byte output store per query row)
 #pragma unroll
-      for (int e = 0; e < 8; e++) Vt[(chunk * 8 + e) * VS + key] = vreg[j][e];
+        for (int e = 0; e < 8; e++) Vt[(PERM ? e * 16 + chunk : chunk * 8 + e) * VS + key] = vreg[j][e];
+      }
     }
     __syncthreads();
     if (kb + 1 < nkb) load_tile(kb + 1);  // next tile's global loads fly under this tile's MFMAs
@@ -1151,7 +1168,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const __half *__restrict
     for (int dt = 0; dt < 8; dt++) {
 #pragma unroll
       for (int r = 0; r < 4; r++) o[dt][r] *= ar[r];
-      // V^T fragment: col d = dt*16 + li, k-slots 0..3 -> keys g*4.., 4..7 -> keys 16+g*4..
+      // V^T fragment: col li of tile dt is d = li*8 + dt; k-slots 0..3 -> keys g*4.., 4..7 -> keys 16+g*4..
       h4 v0 = *reinterpret_cast<const h4 *>(&Vt[(dt * 16 + li) * VS + g * 4]);
       h4 v1 = *reinterpret_cast<const h4 *>(&Vt[(dt * 16 + li) * VS + 16 + g * 4]);
       h8 vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
@@ -1164,11 +1181,18 @@ __global__ __launch_bounds__(256) void attention_kernel(const __half *__restrict
   for (int r = 0; r < 4; r++) lr[r] = 1.0f / __shfl(l_run, g * 4 + r);
 #pragma unroll
   for (int r = 0; r < 4; r++) {
-    int row = qt * 64 + wave * 16 + g * 4 + r;
+    int row = qt * ATT_QROWS + wave * 16 + g * 4 + r;
     if (row >= T) continue;
-    __half *dst = out + ((size_t)b * T + row) * EMBED + h * HDIM + li;
+    if (PERM) {
+      h8 ov;
 #pragma unroll
-    for (int dt = 0; dt < 8; dt++) dst[dt * 16] = __float2half(o[dt][r] * lr[r]);
+      for (int dt = 0; dt < 8; dt++) ov[dt] = (_Float16)(o[dt][r] * lr[r]);
+      *reinterpret_cast<h8 *>(out + ((size_t)b * T + row) * EMBED + h * HDIM + li * 8) = ov;
+    } else {
+      __half *dst = out + ((size_t)b * T + row) * EMBED + h * HDIM + li;
+#pragma unroll
+      for (int dt = 0; dt < 8; dt++) dst[dt * 16] = __float2half(o[dt][r] * lr[r]);
+    }
   }
 }
 
@@ -1786,10 +1810,18 @@ static int run_gemm(const Ctx &c, const char *tag, const ConvLayer &L, const __h
   return run_conv(c, tag, L, in, rows, 1, 1, 0, out, 0, relu, res, 0, 0);
 }
 
+static int g_att_variant = 1;  // A/B hook (tools/ab_attention.py): 1 remap + 16-B stores, 3 no XCD remap, 5 remap + 2-B stores, 7 neither
 static int run_attention(const Ctx &c, const __half *qkv, __half *out, int B, int T) {
   double flops = 4.0 * (double)B * HEADS * (double)T * T * HDIM;
   ProfScope ps(c.prof, c.s, "attention", flops, (double)B * T * (1536 + 512) * 2.0);
-  hipLaunchKernelGGL(attention_kernel, dim3((T + 63) / 64, HEADS, B), dim3(256), 0, c.s, qkv, out, T);
+  const int nq = (T + 63) / 64;
+  dim3 grid((unsigned)(nq * HEADS * B)), blk(256);
+  switch (g_att_variant) {
+    case 1: hipLaunchKernelGGL((attention_kernel<64, true>), grid, blk, 0, c.s, qkv, out, T, nq); break;
+    case 3: hipLaunchKernelGGL((attention_kernel<64, false>), grid, blk, 0, c.s, qkv, out, T, nq); break;
+    case 5: hipLaunchKernelGGL((attention_kernel<64, true, false>), grid, blk, 0, c.s, qkv, out, T, nq); break;
+    default: hipLaunchKernelGGL((attention_kernel<64, false, false>), grid, blk, 0, c.s, qkv, out, T, nq); break;
+  }
   return 0;
 }
 
@@ -2064,6 +2096,35 @@ int fpt_attention(const float *qkv, int B, int T, float *out) {
   FP_HIP_OK(hipMemcpy(ho.data(), dout.p, no * 2, hipMemcpyDeviceToHost));
   for (size_t i = 0; i < no; i++) out[i] = __half2float(ho[i]);
   return 0;
+}
+
+void fpt_set_att_variant(int v) { fp::g_att_variant = v; }
+
+// timing hook: random QKV resident in HBM, `iters` launches, returns ms per launch (negative on failure)
+float fpt_attention_bench(int B, int T, int iters, int variant) {
+  using namespace fp;
+  size_t nq = (size_t)B * T * 1536, no = (size_t)B * T * 512;
+  DevBuf<__half> dq(nq), dout(no);
+  if (!dq.p || !dout.p) return -1.f;
+  std::vector<__half> hq(nq);
+  uint32_t st = 12345u;
+  for (size_t i = 0; i < nq; i++) { st = st * 1664525u + 1013904223u; hq[i] = __float2half(((st >> 8) & 0xffff) / 65536.0f - 0.5f); }
+  if (hipMemcpy(dq.p, hq.data(), nq * 2, hipMemcpyHostToDevice) != hipSuccess) return -1.f;
+  Ctx c{nullptr, nullptr, nullptr};
+  int saved = g_att_variant;
+  g_att_variant = variant;
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  for (int i = 0; i < 3; i++) run_attention(c, dq.p, dout.p, B, T);
+  hipEventRecord(e0, nullptr);
+  for (int i = 0; i < iters; i++) run_attention(c, dq.p, dout.p, B, T);
+  hipEventRecord(e1, nullptr);
+  hipEventSynchronize(e1);
+  float ms = 0.f;
+  hipEventElapsedTime(&ms, e0, e1);
+  hipEventDestroy(e0); hipEventDestroy(e1);
+  g_att_variant = saved;
+  return ms / iters;
 }
 
 }  // extern "C"

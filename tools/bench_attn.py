@@ -1,0 +1,13 @@
+#!/usr/bin/env python3
+"""A/B of the attention kernel variants (bit0 = 64-row query tiles, bit1 = no XCD remap) at Register's shape."""
+import ctypes, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from foundationpose_cpp_amd import _lib
+L = _lib.lib()
+L.fpt_attention_bench.restype = ctypes.c_float
+L.fpt_attention_bench.argtypes = [ctypes.c_int] * 4
+B, T = int(os.environ.get("B", 252)), int(os.environ.get("T", 400))
+for v in (1, 3, 5, 7):
+    ms = L.fpt_attention_bench(B, T, 20, v)
+    fl = 4.0 * B * 4 * T * T * 128
+    print(f"variant {v}: {ms*1e3:8.1f} us  {fl/ms/1e9:7.1f} TF/s")
