@@ -1,0 +1,114 @@
+"""Size-independent properties of the HIP path at BASELINE.json's full sizes (N = 252 / 1008, 640x480 and 1280x720),
+where running the CPU oracle + PyTorch-CPU networks would take minutes:
+
+  * a hypothesis' crops do not depend on which batch it is rendered in (bit-exact);
+  * the refiner is per-hypothesis: outputs for a hypothesis are the same inside N=252 as alone (fp16 tolerance);
+  * the scorer is permutation-equivariant over hypotheses (its only cross-hypothesis op is attention over N);
+  * Register == the composition of the stage operators the reference's orchestrator calls
+    (foundationpose.cpp:181-228), at N = 1008 and at 1280x720 with a textured and an untextured mesh.
+"""
+import numpy as np
+import pytest
+
+from foundationpose_cpp_amd import FoundationPose, synthetic as syn, weights as W
+
+pytestmark = pytest.mark.gpu
+
+
+def _pose_err(a, b):
+    dR = a[:3, :3] @ b[:3, :3].T
+    return np.degrees(np.arccos(np.clip((np.trace(dR) - 1) / 2, -1, 1))), np.linalg.norm(a[:3, 3] - b[:3, 3])
+
+
+@pytest.fixture(scope="module")
+def wpaths(tmp_path_factory):
+    d = tmp_path_factory.mktemp("pw")
+    rp, sp = str(d / "r.fpw"), str(d / "s.fpw")
+    W.pack_synthetic("refiner", rp)
+    W.pack_synthetic("scorer", sp)
+    return rp, sp
+
+
+@pytest.fixture(scope="module")
+def model(syn_mesh, wpaths):
+    m = FoundationPose(syn_mesh, syn.intrinsics(), *wpaths)
+    yield m
+    m.close()
+
+
+def _compose_register(m, name, scene, refine_itr=1):
+    """Register spelled with the stage operators; returns (pose, refined poses, scores)."""
+    m.upload_frame(scene.rgb, scene.depth)
+    poses = m.get_hyp_poses(scene.mask)
+    for _ in range(refine_itr):
+        a, b = m.render_and_transform(name, poses, 1.2)
+        t, r = m.refiner_infer(a, b)
+        poses = m.refine_post_process(name, poses, t, r)
+    a, b = m.render_and_transform(name, poses, 1.1)
+    sc = m.scorer_infer(a, b)
+    return poses[m.argmax(sc)], poses, sc
+
+
+def test_crops_do_not_depend_on_batch(model, syn_mesh, syn_scene):
+    model.upload_frame(syn_scene.rgb, syn_scene.depth)
+    poses = model.get_hyp_poses(syn_scene.mask)
+    a, b = model.render_and_transform(syn_mesh.name, poses, 1.2)
+    for i in (0, 63, 64, 129, 251):                       # both sides of the strip-height switch at N = 64
+        ai, bi = model.render_and_transform(syn_mesh.name, poses[i:i + 1], 1.2)
+        np.testing.assert_array_equal(ai[0], a[i])
+        np.testing.assert_array_equal(bi[0], b[i])
+    a63, _ = model.render_and_transform(syn_mesh.name, poses[:63], 1.2)
+    np.testing.assert_array_equal(a63, a[:63])
+
+
+def test_refiner_is_per_hypothesis_and_scorer_is_permutation_equivariant(model, syn_mesh, syn_scene):
+    model.upload_frame(syn_scene.rgb, syn_scene.depth)
+    poses = model.get_hyp_poses(syn_scene.mask)
+    a, b = model.render_and_transform(syn_mesh.name, poses, 1.2)
+    t, r = model.refiner_infer(a, b)
+    sel = [5, 77, 250]
+    ts, rs = model.refiner_infer(a[sel], b[sel])
+    # small batches take the split-K schedule (different fp32 summation order), hence a tolerance rather than equality
+    np.testing.assert_allclose(ts, t[sel], rtol=0, atol=1e-3)
+    np.testing.assert_allclose(rs, r[sel], rtol=0, atol=1e-3)
+    sc = model.scorer_infer(a, b)
+    perm = np.random.default_rng(3).permutation(len(poses))
+    scp = model.scorer_infer(np.ascontiguousarray(a[perm]), np.ascontiguousarray(b[perm]))
+    np.testing.assert_allclose(scp, sc[perm], rtol=0, atol=2e-3)
+
+
+def test_register_1008_equals_stage_composition(model, syn_mesh, syn_scene):
+    model.set_inplane_steps(24)
+    try:
+        assert model.num_hypotheses == 1008
+        ok, pose = model.Register(syn_scene.rgb, syn_scene.depth, syn_scene.mask, syn_mesh.name)
+        assert ok, model.last_error
+        best, refined, sc = _compose_register(model, syn_mesh.name, syn_scene)
+    finally:
+        model.set_inplane_steps(6)
+    assert refined.shape == (1008, 4, 4) and np.isfinite(sc).all()
+    # the stage operators exchange fp32 crops while Register keeps fp16 crops in HBM, so compare through the scores:
+    # the returned pose is one of the composed refined poses and its score is the maximum up to fp16 noise
+    errs = [_pose_err(pose, p) for p in refined]
+    idx = int(np.argmin([e[0] + 1e3 * e[1] for e in errs]))
+    assert errs[idx][0] < 0.1 and errs[idx][1] < 1e-4, errs[idx]
+    assert sc[idx] >= sc.max() - 5e-3, (idx, sc[idx], sc.max())
+
+
+@pytest.mark.parametrize("textured", [True, False])
+def test_register_720p_textured_and_untextured(wpaths, textured):
+    mesh = syn.make_mesh(textured=textured, name="m720")
+    scene = syn.make_scene(mesh, 1280, 720)
+    m = FoundationPose(mesh, syn.intrinsics(1280, 720), *wpaths, max_input_image_height=720, max_input_image_width=1280)
+    ok, pose = m.Register(scene.rgb, scene.depth, scene.mask, "m720")
+    assert ok, m.last_error
+    ok2, pose2 = m.Register(scene.rgb, scene.depth, scene.mask, "m720")
+    assert ok2 and np.array_equal(pose, pose2)            # deterministic
+    best, refined, sc = _compose_register(m, "m720", scene)
+    errs = [_pose_err(pose, p) for p in refined]
+    idx = int(np.argmin([e[0] + 1e3 * e[1] for e in errs]))
+    assert errs[idx][0] < 0.1 and errs[idx][1] < 1e-4, errs[idx]
+    assert sc[idx] >= sc.max() - 5e-3
+    ok, tp = m.Track(scene.rgb, scene.depth, pose, "m720")
+    assert ok and np.isfinite(tp).all()
+    m.close()
