@@ -1,0 +1,406 @@
+"""ONNX initialiser reader -> packed FPW1 weights.
+
+The reference turns `refiner_hwc.onnx` / `scorer_hwc.onnx` into TensorRT engines with trtexec
+(tools/cvt_onnx2trt.bash:3-15) and never looks inside them.  This module does the equivalent step for the MI355X
+library: it reads the weights out of the ONNX file and writes the FPW1 container fp_create() loads.  It does NOT run
+the graph -- the network itself is the hand-written HIP in csrc/fp_nn.hip; only the initialisers are taken.
+
+No `onnx` / `protobuf` dependency: ONNX files are protobuf, and the handful of message types needed (ModelProto,
+GraphProto, NodeProto, AttributeProto, TensorProto; field numbers from onnx.proto3 [EXT]) are decoded from the wire
+format directly.
+
+Tensor -> layer assignment does not trust initialiser names (the TorchScript exporter folds BatchNorm into the
+preceding Conv and renames the results `onnx::Conv_123`, and stores Linear weights transposed as `onnx::MatMul_456`):
+  * Conv nodes in graph (= topological) order are the 15 convolutions of encodeA / encodeAB in definition order;
+    a BatchNormalization consuming a Conv output is folded here if the exporter did not;
+  * linear layers (Gemm, or MatMul with a constant operand followed by a constant Add) and LayerNormalization nodes are
+    assigned per graph output: the nodes that are ancestors of `trans` only are the translation head, of `rot` only the
+    rotation head (reference blob names, detection_6d_foundationpose/src/foundationpose.cpp:78-83);
+  * every assignment is checked against the shape the architecture requires and the reader fails
+    loudly on any mismatch, listing what it found.
+
+STATUS: the real ONNX files are not available offline (Google-Drive link, README.md:72), so this has been exercised
+only on graphs written by tests/onnx_writer.py in the TorchScript exporter's conventions -- mapping UNVERIFIED against
+the real files; `--list` prints everything the reader sees so a mismatch is diagnosable in one run.
+"""
+from __future__ import annotations
+
+import struct
+
+import numpy as np
+
+from . import weights as W
+
+# ---------------------------------------------------------------------------------------------------------------------
+# protobuf wire format
+
+
+def _varint(buf, pos):
+    res = shift = 0
+    while True:
+        b = buf[pos]
+        pos += 1
+        res |= (b & 0x7F) << shift
+        if not b & 0x80:
+            return res, pos
+        shift += 7
+
+
+def _fields(buf):
+    """yields (field_number, wire_type, value): value is int for varint/fixed, memoryview for length-delimited"""
+    pos, n = 0, len(buf)
+    while pos < n:
+        key, pos = _varint(buf, pos)
+        fn, wt = key >> 3, key & 7
+        if wt == 0:
+            v, pos = _varint(buf, pos)
+        elif wt == 1:
+            v = struct.unpack_from("<Q", buf, pos)[0]
+            pos += 8
+        elif wt == 2:
+            ln, pos = _varint(buf, pos)
+            v = buf[pos:pos + ln]
+            pos += ln
+        elif wt == 5:
+            v = struct.unpack_from("<I", buf, pos)[0]
+            pos += 4
+        else:
+            raise ValueError(f"unsupported protobuf wire type {wt}")
+        yield fn, wt, v
+
+
+def _packed_varints(v):
+    out, pos = [], 0
+    while pos < len(v):
+        x, pos = _varint(v, pos)
+        out.append(x)
+    return out
+
+
+def _s64(x):
+    return x - (1 << 64) if x >= (1 << 63) else x
+
+
+_DTYPES = {1: np.float32, 2: np.uint8, 3: np.int8, 5: np.int16, 6: np.int32, 7: np.int64, 9: np.bool_, 10: np.float16,
+           11: np.float64, 12: np.uint32, 13: np.uint64}
+
+
+def _tensor(buf):
+    dims, dtype, name, raw = [], 1, "", None
+    f32, i32, i64, f64 = [], [], [], []
+    external = False
+    for fn, wt, v in _fields(buf):
+        if fn == 1:
+            dims += [_s64(x) for x in _packed_varints(v)] if wt == 2 else [_s64(v)]
+        elif fn == 2:
+            dtype = v
+        elif fn == 4:
+            f32.append(np.frombuffer(v, "<f4") if wt == 2 else np.array([struct.unpack("<f", struct.pack("<I", v))[0]], "<f4"))
+        elif fn == 5:
+            i32 += _packed_varints(v) if wt == 2 else [v]
+        elif fn == 7:
+            i64 += [_s64(x) for x in _packed_varints(v)] if wt == 2 else [_s64(v)]
+        elif fn == 8:
+            name = bytes(v).decode()
+        elif fn == 9:
+            raw = bytes(v)
+        elif fn == 10:
+            f64.append(np.frombuffer(v, "<f8"))
+        elif fn in (13, 14):
+            external = external or fn == 13 or (fn == 14 and v == 1)
+    if external:
+        raise ValueError(f"tensor {name!r} uses external data; re-save the model with weights embedded")
+    if dtype == 16:                                        # bfloat16 -> fp32
+        u = np.frombuffer(raw, "<u2").astype(np.uint32) << 16 if raw is not None else (np.array(i32, np.uint32) << 16)
+        arr = u.view(np.float32)
+    elif raw is not None:
+        arr = np.frombuffer(raw, np.dtype(_DTYPES[dtype]).newbyteorder("<"))
+    elif f32:
+        arr = np.concatenate(f32)
+    elif f64:
+        arr = np.concatenate(f64)
+    elif i64:
+        arr = np.array(i64, np.int64)
+    elif i32:
+        arr = np.array(i32, np.int32)
+        if dtype == 10:                                    # fp16 stored as bit patterns in int32_data
+            arr = arr.astype(np.uint16).view(np.float16)
+    else:
+        arr = np.zeros(0, _DTYPES.get(dtype, np.float32))
+    return name, np.asarray(arr).reshape(dims if dims else ())
+
+
+class Node:
+    __slots__ = ("op", "name", "inputs", "outputs", "attrs", "index")
+
+    def __init__(self):
+        self.op, self.name, self.inputs, self.outputs, self.attrs, self.index = "", "", [], [], {}, -1
+
+    def __repr__(self):
+        return f"{self.index}:{self.op}({', '.join(self.inputs)}) -> {', '.join(self.outputs)}"
+
+
+def _attribute(buf):
+    name, val = "", None
+    for fn, wt, v in _fields(buf):
+        if fn == 1:
+            name = bytes(v).decode()
+        elif fn == 2:
+            val = struct.unpack("<f", struct.pack("<I", v))[0]
+        elif fn == 3:
+            val = _s64(v)
+        elif fn == 4:
+            val = bytes(v)
+        elif fn == 5:
+            val = _tensor(v)[1]
+        elif fn == 8:
+            val = (val or []) + ([_s64(x) for x in _packed_varints(v)] if wt == 2 else [_s64(v)])
+        elif fn == 7:
+            val = (val or []) + (list(np.frombuffer(v, "<f4")) if wt == 2 else [struct.unpack("<f", struct.pack("<I", v))[0]])
+    return name, val
+
+
+def _node(buf):
+    n = Node()
+    for fn, _wt, v in _fields(buf):
+        if fn == 1:
+            n.inputs.append(bytes(v).decode())
+        elif fn == 2:
+            n.outputs.append(bytes(v).decode())
+        elif fn == 3:
+            n.name = bytes(v).decode()
+        elif fn == 4:
+            n.op = bytes(v).decode()
+        elif fn == 5:
+            k, a = _attribute(v)
+            n.attrs[k] = a
+    return n
+
+
+def _value_name(buf):
+    for fn, _wt, v in _fields(buf):
+        if fn == 1:
+            return bytes(v).decode()
+    return ""
+
+
+class Graph:
+    def __init__(self):
+        self.nodes: list[Node] = []
+        self.init: dict[str, np.ndarray] = {}
+        self.inputs: list[str] = []
+        self.outputs: list[str] = []
+
+
+def read_graph(path: str) -> Graph:
+    """ModelProto.graph (field 7) -> nodes, initialisers (+ Constant nodes), graph input / output names."""
+    data = memoryview(open(path, "rb").read())
+    g = Graph()
+    gbuf = None
+    for fn, wt, v in _fields(data):
+        if fn == 7 and wt == 2:
+            gbuf = v
+    if gbuf is None:
+        raise ValueError(f"{path}: no GraphProto (field 7) -- not an ONNX model?")
+    for fn, wt, v in _fields(gbuf):
+        if fn == 1:
+            n = _node(v)
+            n.index = len(g.nodes)
+            g.nodes.append(n)
+        elif fn == 5:
+            name, arr = _tensor(v)
+            g.init[name] = arr
+        elif fn == 11:
+            g.inputs.append(_value_name(v))
+        elif fn == 12:
+            g.outputs.append(_value_name(v))
+    for n in g.nodes:                                       # Constant nodes behave like initialisers
+        if n.op == "Constant" and "value" in n.attrs and isinstance(n.attrs["value"], np.ndarray):
+            g.init[n.outputs[0]] = n.attrs["value"]
+    g.inputs = [i for i in g.inputs if i not in g.init]
+    return g
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# graph -> layers
+
+
+def _consumers(g: Graph):
+    c: dict[str, list[Node]] = {}
+    for n in g.nodes:
+        for i in n.inputs:
+            c.setdefault(i, []).append(n)
+    return c
+
+
+def _ancestors(g: Graph, out_name: str) -> set[int]:
+    prod = {o: n for n in g.nodes for o in n.outputs}
+    seen, stack = set(), [out_name]
+    while stack:
+        t = stack.pop()
+        n = prod.get(t)
+        if n is None or n.index in seen:
+            continue
+        seen.add(n.index)
+        stack.extend(n.inputs)
+    return seen
+
+
+def _f32(a):
+    return np.ascontiguousarray(np.asarray(a, np.float32))
+
+
+def _convs(g: Graph):
+    """[(weight OIHW, bias)] in graph order, BatchNormalization folded (eval-mode formula, weights.fold_batchnorm)."""
+    cons = _consumers(g)
+    out = []
+    for n in g.nodes:
+        if n.op != "Conv":
+            continue
+        if n.inputs[1] not in g.init:
+            raise ValueError(f"Conv {n!r}: weight is not a constant")
+        w = _f32(g.init[n.inputs[1]]).astype(np.float64)
+        b = _f32(g.init[n.inputs[2]]).astype(np.float64) if len(n.inputs) > 2 and n.inputs[2] in g.init else np.zeros(w.shape[0])
+        nxt = cons.get(n.outputs[0], [])
+        if len(nxt) == 1 and nxt[0].op == "BatchNormalization":
+            bn = nxt[0]
+            gam, beta, mu, var = (_f32(g.init[x]).astype(np.float64) for x in bn.inputs[1:5])
+            sc = gam / np.sqrt(var + float(bn.attrs.get("epsilon", 1e-5)))
+            w, b = w * sc[:, None, None, None], (b - mu) * sc + beta
+        out.append((n, w.astype(np.float32), b.astype(np.float32)))
+    return out
+
+
+def _linears(g: Graph):
+    """[(node, W[out,in], b[out])] in graph order: Gemm, or MatMul(x, const) [+ Add(const)]."""
+    cons = _consumers(g)
+    out = []
+    for n in g.nodes:
+        if n.op == "Gemm" and n.inputs[1] in g.init:
+            w = _f32(g.init[n.inputs[1]])
+            w = w if int(n.attrs.get("transB", 0)) else w.T
+            b = _f32(g.init[n.inputs[2]]) if len(n.inputs) > 2 and n.inputs[2] in g.init else np.zeros(w.shape[0], np.float32)
+            out.append((n, _f32(w * float(n.attrs.get("alpha", 1.0))), _f32(b * float(n.attrs.get("beta", 1.0)))))
+        elif n.op == "MatMul" and n.inputs[1] in g.init and g.init[n.inputs[1]].ndim == 2:
+            w = _f32(g.init[n.inputs[1]]).T
+            b = np.zeros(w.shape[0], np.float32)
+            nxt = cons.get(n.outputs[0], [])
+            if len(nxt) == 1 and nxt[0].op == "Add":
+                other = [i for i in nxt[0].inputs if i != n.outputs[0]]
+                if other and other[0] in g.init and g.init[other[0]].size == w.shape[0]:
+                    b = _f32(g.init[other[0]]).reshape(-1)
+            out.append((n, _f32(w), b))
+    return out
+
+
+def _layernorms(g: Graph):
+    out = [(n, _f32(g.init[n.inputs[1]]), _f32(g.init[n.inputs[2]])) for n in g.nodes
+           if n.op == "LayerNormalization" and n.inputs[1] in g.init and len(n.inputs) > 2 and n.inputs[2] in g.init]
+    if out:
+        return out
+    # opset < 17: LayerNorm is decomposed; its affine parameters keep their module names (…norm1.weight / .bias)
+    names = sorted(k[:-len(".weight")] for k in g.init if k.endswith((".norm1.weight", ".norm2.weight")))
+    cons = _consumers(g)
+    res = []
+    for base in names:
+        users = cons.get(base + ".weight", [])
+        if users and base + ".bias" in g.init:
+            res.append((users[0], _f32(g.init[base + ".weight"]), _f32(g.init[base + ".bias"])))
+    return sorted(res, key=lambda t: t[0].index)
+
+
+_CONV_NAMES = (["encodeA.0", "encodeA.1", "encodeA.2.conv1", "encodeA.2.conv2", "encodeA.3.conv1", "encodeA.3.conv2"] +
+               ["encodeAB.0.conv1", "encodeAB.0.conv2", "encodeAB.1.conv1", "encodeAB.1.conv2", "encodeAB.2",
+                "encodeAB.3.conv1", "encodeAB.3.conv2", "encodeAB.4.conv1", "encodeAB.4.conv2"])
+_CONV_SHAPES = ([(64, 6, 7, 7), (128, 64, 3, 3)] + [(128, 128, 3, 3)] * 4 + [(256, 256, 3, 3)] * 4 + [(512, 256, 3, 3)] +
+                [(512, 512, 3, 3)] * 4)
+
+
+def _take_linears(seq, specs, what):
+    """consume `seq` against [(name_w, name_b, out, in)]; a packed 1536x512 projection may arrive as three 512x512"""
+    out, i = {}, 0
+    for nw, nb, o, k in specs:
+        if i < len(seq) and seq[i][1].shape == (o, k):
+            out[nw], out[nb] = seq[i][1], seq[i][2]
+            i += 1
+        elif o == 3 * W.EMBED and i + 2 < len(seq) and all(s[1].shape == (W.EMBED, k) for s in seq[i:i + 3]):
+            out[nw] = np.concatenate([s[1] for s in seq[i:i + 3]], 0)
+            out[nb] = np.concatenate([s[2] for s in seq[i:i + 3]], 0)
+            i += 3
+        else:
+            found = [tuple(s[1].shape) for s in seq]
+            raise ValueError(f"{what}: expected a {o}x{k} linear layer for {nw}; linear layers found in order: {found}")
+    if i != len(seq):
+        raise ValueError(f"{what}: {len(seq) - i} unexpected extra linear layer(s): {[tuple(s[1].shape) for s in seq[i:]]}")
+    return out
+
+
+def _mha_specs(prefix):
+    E = W.EMBED
+    return [(f"{prefix}.in_proj_weight", f"{prefix}.in_proj_bias", 3 * E, E), (f"{prefix}.out_proj.weight", f"{prefix}.out_proj.bias", E, E)]
+
+
+def extract(path: str, kind: str) -> dict:
+    """ONNX file -> {FPW tensor name: fp32 array} (BatchNorm folded, PyTorch layouts), the dict write_fpw() takes."""
+    assert kind in ("refiner", "scorer")
+    g = read_graph(path)
+    convs = _convs(g)
+    if [tuple(c[1].shape) for c in convs] != _CONV_SHAPES:
+        raise ValueError(f"{path}: expected the 15 convolutions {_CONV_SHAPES}, found {[tuple(c[1].shape) for c in convs]}")
+    st = {}
+    for name, (_n, w, b) in zip(_CONV_NAMES, convs):
+        st[name + ".weight"], st[name + ".bias"] = w, b
+    lin, lns = _linears(g), _layernorms(g)
+    E = W.EMBED
+    if kind == "refiner":
+        if len(g.outputs) != 2:
+            raise ValueError(f"{path}: a refiner has two outputs (trans, rot); found {g.outputs}")
+        names = {o.lower(): o for o in g.outputs}
+        o_trans = names.get("trans", g.outputs[0])
+        o_rot = names.get("rot", g.outputs[1] if o_trans == g.outputs[0] else g.outputs[0])
+        anc = {"trans_head": _ancestors(g, o_trans), "rot_head": _ancestors(g, o_rot)}
+        for head, other in (("trans_head", "rot_head"), ("rot_head", "trans_head")):
+            own = anc[head] - anc[other]
+            specs = _mha_specs(f"{head}.0.self_attn") + [
+                (f"{head}.0.linear1.weight", f"{head}.0.linear1.bias", E, E),
+                (f"{head}.0.linear2.weight", f"{head}.0.linear2.bias", E, E), (f"{head}.1.weight", f"{head}.1.bias", 3, E)]
+            st.update(_take_linears([l for l in lin if l[0].index in own], specs, f"{path} {head}"))
+            hl = [l for l in lns if l[0].index in own]
+            if len(hl) != 2:
+                raise ValueError(f"{path} {head}: expected 2 LayerNorms, found {len(hl)}")
+            for nm, (_n, w, b) in zip(("norm1", "norm2"), hl):
+                st[f"{head}.0.{nm}.weight"], st[f"{head}.0.{nm}.bias"] = w, b
+    else:
+        if len(g.outputs) != 1:
+            raise ValueError(f"{path}: a scorer has one output (scores); found {g.outputs}")
+        specs = _mha_specs("att") + _mha_specs("att_cross") + [("linear.weight", "linear.bias", 1, E)]
+        st.update(_take_linears(lin, specs, f"{path} scorer"))
+    # the sinusoidal table is recomputed by the library; if the file carries one it must be that table
+    for arr in g.init.values():
+        if arr.ndim >= 2 and arr.shape[-2:] == (400, E):
+            pos = np.arange(400, dtype=np.float32)[:, None]
+            div = np.exp(np.arange(0, E, 2, dtype=np.float32) * np.float32(-(np.log(10000.0) / E)))[None]
+            pe = np.zeros((400, E), np.float32)
+            pe[:, 0::2], pe[:, 1::2] = np.sin(pos * div), np.cos(pos * div)
+            if not np.allclose(np.asarray(arr, np.float32).reshape(400, E), pe, atol=1e-4):
+                raise ValueError(f"{path}: positional table differs from the sinusoidal embedding the library computes")
+    return st
+
+
+def describe(path: str) -> str:
+    g = read_graph(path)
+    ops: dict[str, int] = {}
+    for n in g.nodes:
+        ops[n.op] = ops.get(n.op, 0) + 1
+    lines = [f"inputs  {g.inputs}", f"outputs {g.outputs}", f"nodes   {len(g.nodes)}: " + ", ".join(f"{k} x{v}" for k, v in sorted(ops.items()))]
+    lines += [f"conv    {n!r}: W{tuple(w.shape)}" for n, w, _b in _convs(g)]
+    lines += [f"linear  {n!r}: W{tuple(w.shape)}" for n, w, _b in _linears(g)]
+    lines += [f"lnorm   {n!r}" for n, _w, _b in _layernorms(g)]
+    lines += [f"init    {k}: {v.dtype}{tuple(v.shape)}" for k, v in g.init.items()]
+    return "\n".join(lines)
+
+
+def convert(path: str, kind: str, out_path: str) -> dict:
+    st = extract(path, kind)
+    W.write_fpw(out_path, st)
+    return st

@@ -5,6 +5,8 @@ the Google-Drive ONNX files into TensorRT engines; neither file is available off
   He-normal convs / Xavier linears / non-trivial BatchNorm statistics.  Every report using them says "synthetic weights".
 * `fold_batchnorm(state)`              conv+BN -> conv weight/bias (what TensorRT does when it builds the engine).
 * `write_fpw / read_fpw`               the packed "FPW1" container the C library loads (fp32 tensors, PyTorch layouts).
+* `python -m foundationpose_cpp_amd.weights --onnx refiner refiner_hwc.onnx refiner.fpw`
+                                       real weights: onnx_reader.py pulls the initialisers out of the ONNX files.
 
 numpy only.
 """
@@ -152,7 +154,17 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser(description="pack refine-net / score-net weights into the FPW1 container")
     ap.add_argument("--synthetic", nargs=2, metavar=("KIND", "OUT"), help="KIND = refiner|scorer")
     ap.add_argument("--seed", type=int, default=7)
+    ap.add_argument("--onnx", nargs=3, metavar=("KIND", "ONNX", "OUT"),
+                    help="read the initialisers of refiner_hwc.onnx / scorer_hwc.onnx (reference tools/cvt_onnx2trt.bash step)")
+    ap.add_argument("--list", metavar="ONNX", help="print what the ONNX reader sees in a file")
     a = ap.parse_args()
     if a.synthetic:
         pack_synthetic(a.synthetic[0], a.synthetic[1], a.seed)
         print("wrote", a.synthetic[1])
+    if a.onnx:
+        from . import onnx_reader
+        st = onnx_reader.convert(a.onnx[1], a.onnx[0], a.onnx[2])
+        print("wrote", a.onnx[2], f"({len(st)} tensors)")
+    if a.list:
+        from . import onnx_reader
+        print(onnx_reader.describe(a.list))
