@@ -21,6 +21,8 @@ SYMBOLS = [
     "fp_refine_post_process", "fp_argmax", "fp_register_shard_begin", "fp_register_shard_finish",
     "fp_profile_enable", "fp_profile_reset", "fp_profile_report", "fp_stream", "fp_synchronize",
     "fp_mesh_load_obj", "fp_mesh_free", "fp_mesh_view", "fp_mesh_orient_bounds",
+    "fp_image_read_png", "fp_frame_size", "fp_read_rgb_depth_mask", "fp_read_cam_k", "fp_image_write_png_rgb",
+    "fp_draw_bbox3d",
 ]
 
 
@@ -67,6 +69,12 @@ def lib() -> C.CDLL:
     L.fp_mesh_load_obj.argtypes = [C.c_char_p, C.c_char_p]
     L.fp_mesh_free.restype = None
     L.fp_mesh_free.argtypes = [C.c_void_p]
+    L.fp_image_read_png.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+    L.fp_frame_size.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p]
+    L.fp_read_rgb_depth_mask.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.fp_read_cam_k.argtypes = [C.c_char_p, C.c_void_p]
+    L.fp_image_write_png_rgb.argtypes = [C.c_char_p, C.c_void_p, C.c_int, C.c_int]
+    L.fp_draw_bbox3d.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     L.fp_mesh_view.restype = C.POINTER(FpMesh)
     L.fp_mesh_view.argtypes = [C.c_void_p]
     vp, ci, cf, cs = C.c_void_p, C.c_int, C.c_float, C.c_char_p

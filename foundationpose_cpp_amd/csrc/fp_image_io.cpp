@@ -1,0 +1,276 @@
+// fp_image_io.cpp -- frame / dataset I/O of the acceptance harness without OpenCV.
+//
+// Replaces the helpers the reference's simple_tests use around Register / Track
+// (simple_tests/include/tests/help_func.hpp: ReadRgbDepthMask :10-36, ReadRgbDepth :38-53, ReadCamK :108-129,
+//  draw3DBoundingBox :55-106) for the dataset layout of test_data/download.md:6-15
+//      <dir>/cam_K.txt  rgb/<id>.png  depth/<id>.png (u16, millimetres)  masks/<id>.png  mesh/
+//   * rgb   : cv::imread + BGR2RGB                    -> u8 [H,W,3] RGB
+//   * depth : IMREAD_UNCHANGED, convertTo f32, / 1000 -> f32 [H,W] metres
+//   * mask  : IMREAD_UNCHANGED; 3-channel masks keep the first channel after BGR2RGB, i.e. the file's R channel
+//   * cam_K : nine whitespace-separated numbers, row-major
+// PNG: non-interlaced, bit depth 8 or 16, colour types 0/2/3/4/6 (zlib inflate); writer: 8-bit RGB.
+#include <zlib.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <string>
+#include <vector>
+
+#include "../../include/foundationpose_amd.h"
+#include "fp_internal.h"
+
+namespace fp {
+
+static uint32_t be32(const uint8_t *p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; }
+
+// Decoded samples, 16 bits each (8-bit files are widened without scaling), `ch` interleaved channels; palette expanded.
+bool decode_png(const std::string &path, std::vector<uint16_t> &px, int &H, int &W, int &ch, int &bits) {
+  std::ifstream f(path, std::ios::binary);
+  if (!f) return false;
+  std::vector<uint8_t> buf((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+  static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
+  if (buf.size() < 33 || std::memcmp(buf.data(), sig, 8) != 0) return false;
+  size_t pos = 8;
+  int ctype = 0, interlace = 0;
+  std::vector<uint8_t> idat, plte;
+  W = H = bits = 0;
+  while (pos + 12 <= buf.size()) {
+    uint32_t len = be32(&buf[pos]);
+    if (pos + 12 + (size_t)len > buf.size()) return false;
+    const uint8_t *d = &buf[pos + 8];
+    if (!std::memcmp(&buf[pos + 4], "IHDR", 4) && len >= 13) {
+      W = (int)be32(d); H = (int)be32(d + 4); bits = d[8]; ctype = d[9]; interlace = d[12];
+    } else if (!std::memcmp(&buf[pos + 4], "PLTE", 4)) {
+      plte.assign(d, d + len);
+    } else if (!std::memcmp(&buf[pos + 4], "IDAT", 4)) {
+      idat.insert(idat.end(), d, d + len);
+    } else if (!std::memcmp(&buf[pos + 4], "IEND", 4)) {
+      break;
+    }
+    pos += 12 + (size_t)len;
+  }
+  if (W <= 0 || H <= 0 || (bits != 8 && bits != 16) || interlace != 0) return false;
+  int fch = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
+  if (!fch || (ctype == 3 && bits != 8)) return false;
+  const int bpp = fch * bits / 8;  // filter distance in bytes
+  const size_t stride = (size_t)W * bpp;
+  std::vector<uint8_t> raw((stride + 1) * H);
+  {
+    z_stream zs;
+    std::memset(&zs, 0, sizeof(zs));
+    if (inflateInit(&zs) != Z_OK) return false;
+    zs.next_in = idat.data();
+    zs.avail_in = (uInt)idat.size();
+    zs.next_out = raw.data();
+    zs.avail_out = (uInt)raw.size();
+    int rc = inflate(&zs, Z_FINISH);
+    size_t got = zs.total_out;
+    inflateEnd(&zs);
+    if (!(rc == Z_STREAM_END || rc == Z_OK || rc == Z_BUF_ERROR) || got != raw.size()) return false;
+  }
+  std::vector<uint8_t> img(stride * H);
+  for (int y = 0; y < H; y++) {
+    const uint8_t *src = &raw[(stride + 1) * y];
+    const uint8_t ft = src[0];
+    uint8_t *dst = &img[stride * y];
+    const uint8_t *up = y ? &img[stride * (y - 1)] : nullptr;
+    for (size_t x = 0; x < stride; x++) {
+      int a = x >= (size_t)bpp ? dst[x - bpp] : 0, b = up ? up[x] : 0, c = (up && x >= (size_t)bpp) ? up[x - bpp] : 0;
+      int v = src[1 + x];
+      switch (ft) {
+        case 0: break;
+        case 1: v += a; break;
+        case 2: v += b; break;
+        case 3: v += (a + b) >> 1; break;
+        case 4: {
+          int p = a + b - c, pa = std::abs(p - a), pb = std::abs(p - b), pc = std::abs(p - c);
+          v += (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
+          break;
+        }
+        default: return false;
+      }
+      dst[x] = (uint8_t)v;
+    }
+  }
+  ch = ctype == 3 ? 3 : fch;
+  px.resize((size_t)W * H * ch);
+  const size_t n = (size_t)W * H;
+  if (ctype == 3) {
+    for (size_t i = 0; i < n; i++) {
+      size_t e = (size_t)img[i] * 3;
+      if (e + 2 >= plte.size()) return false;
+      px[i * 3] = plte[e]; px[i * 3 + 1] = plte[e + 1]; px[i * 3 + 2] = plte[e + 2];
+    }
+  } else if (bits == 8) {
+    for (size_t i = 0; i < n * fch; i++) px[i] = img[i];
+  } else {
+    for (size_t i = 0; i < n * fch; i++) px[i] = (uint16_t)((img[2 * i] << 8) | img[2 * i + 1]);  // big-endian samples
+  }
+  return true;
+}
+
+// 8-bit view as RGB (grey replicated, alpha dropped); used by the mesh loader for textures
+bool load_png_rgb(const std::string &path, std::vector<uint8_t> &rgb, int &H, int &W) {
+  std::vector<uint16_t> px;
+  int ch = 0, bits = 0;
+  if (!decode_png(path, px, H, W, ch, bits) || bits != 8) return false;
+  rgb.resize((size_t)W * H * 3);
+  for (size_t i = 0; i < (size_t)W * H; i++) {
+    const uint16_t *p = &px[i * ch];
+    const bool grey = ch <= 2;
+    rgb[i * 3] = (uint8_t)p[0];
+    rgb[i * 3 + 1] = (uint8_t)(grey ? p[0] : p[1]);
+    rgb[i * 3 + 2] = (uint8_t)(grey ? p[0] : p[2]);
+  }
+  return true;
+}
+
+static void put_be32(std::vector<uint8_t> &o, uint32_t v) {
+  o.push_back(v >> 24); o.push_back((v >> 16) & 255); o.push_back((v >> 8) & 255); o.push_back(v & 255);
+}
+
+static void png_chunk(std::vector<uint8_t> &o, const char *type, const std::vector<uint8_t> &d) {
+  put_be32(o, (uint32_t)d.size());
+  size_t s = o.size();
+  o.insert(o.end(), type, type + 4);
+  o.insert(o.end(), d.begin(), d.end());
+  put_be32(o, (uint32_t)crc32(0, &o[s], (uInt)(o.size() - s)));
+}
+
+}  // namespace fp
+
+extern "C" {
+
+int fp_image_read_png(const char *path, int *H, int *W, int *channels, int *bit_depth, uint16_t *out, size_t out_capacity) {
+  std::vector<uint16_t> px;
+  int h, w, ch, bits;
+  FP_CHECK(path && fp::decode_png(path, px, h, w, ch, bits), std::string("Failed reading png from path : ") + (path ? path : "(null)"));
+  if (H) *H = h;
+  if (W) *W = w;
+  if (channels) *channels = ch;
+  if (bit_depth) *bit_depth = bits;
+  if (out) {
+    FP_CHECK(out_capacity >= px.size(), "fp_image_read_png: output buffer too small");
+    std::memcpy(out, px.data(), px.size() * sizeof(uint16_t));
+  }
+  return 0;
+}
+
+static int read_frame_part(const char *path, const char *what, std::vector<uint16_t> &px, int &h, int &w, int &ch, int &bits) {
+  FP_CHECK(path && fp::decode_png(path, px, h, w, ch, bits), std::string("Failed reading ") + what + " from path : " + (path ? path : "(null)"));
+  return 0;
+}
+
+int fp_frame_size(const char *rgb_path, int *H, int *W) {
+  std::vector<uint16_t> px;
+  int h, w, ch, bits;
+  if (read_frame_part(rgb_path, "rgb", px, h, w, ch, bits)) return 1;
+  *H = h;
+  *W = w;
+  return 0;
+}
+
+int fp_read_rgb_depth_mask(const char *rgb_path, const char *depth_path, const char *mask_path, int H, int W,
+                           uint8_t *rgb, float *depth, uint8_t *mask) {
+  std::vector<uint16_t> px;
+  int h, w, ch, bits;
+  const size_t n = (size_t)H * W;
+  if (rgb) {
+    if (read_frame_part(rgb_path, "rgb", px, h, w, ch, bits)) return 1;
+    FP_CHECK(h == H && w == W && bits == 8, std::string("rgb image has an unexpected size or bit depth: ") + rgb_path);
+    for (size_t i = 0; i < n; i++)
+      for (int c = 0; c < 3; c++) rgb[i * 3 + c] = (uint8_t)px[i * ch + (ch >= 3 ? c : 0)];
+  }
+  if (depth) {
+    if (read_frame_part(depth_path, "depth", px, h, w, ch, bits)) return 1;
+    FP_CHECK(h == H && w == W, std::string("depth image has an unexpected size: ") + depth_path);
+    for (size_t i = 0; i < n; i++) depth[i] = (float)px[i * ch] / 1000.f;  // convertTo(CV_32FC1) then / 1000.f
+  }
+  if (mask) {
+    if (read_frame_part(mask_path, "mask", px, h, w, ch, bits)) return 1;
+    FP_CHECK(h == H && w == W, std::string("mask image has an unexpected size: ") + mask_path);
+    for (size_t i = 0; i < n; i++) {
+      uint16_t v = px[i * ch];  // single channel, or the file's R channel
+      mask[i] = (uint8_t)(bits == 16 ? (v > 255 ? 255 : v) : v);
+    }
+  }
+  return 0;
+}
+
+int fp_read_cam_k(const char *cam_K_path, float K[9]) {
+  std::ifstream f(cam_K_path ? cam_K_path : "");
+  FP_CHECK((bool)f, std::string("Failed open file : ") + (cam_K_path ? cam_K_path : "(null)"));
+  for (int i = 0; i < 9; i++) {
+    double v;
+    FP_CHECK((bool)(f >> v), std::string("cam_K file holds fewer than 9 numbers: ") + cam_K_path);
+    K[i] = (float)v;
+  }
+  return 0;
+}
+
+int fp_image_write_png_rgb(const char *path, const uint8_t *rgb, int H, int W) {
+  FP_CHECK(path && rgb && H > 0 && W > 0, "fp_image_write_png_rgb: bad arguments");
+  std::vector<uint8_t> raw((size_t)H * (W * 3 + 1));
+  for (int y = 0; y < H; y++) {
+    raw[(size_t)y * (W * 3 + 1)] = 0;
+    std::memcpy(&raw[(size_t)y * (W * 3 + 1) + 1], rgb + (size_t)y * W * 3, (size_t)W * 3);
+  }
+  uLongf clen = compressBound((uLong)raw.size());
+  std::vector<uint8_t> comp(clen);
+  FP_CHECK(compress2(comp.data(), &clen, raw.data(), (uLong)raw.size(), 6) == Z_OK, "png deflate failed");
+  comp.resize(clen);
+  std::vector<uint8_t> o = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
+  std::vector<uint8_t> ihdr;
+  fp::put_be32(ihdr, (uint32_t)W);
+  fp::put_be32(ihdr, (uint32_t)H);
+  ihdr.insert(ihdr.end(), {8, 2, 0, 0, 0});
+  fp::png_chunk(o, "IHDR", ihdr);
+  fp::png_chunk(o, "IDAT", comp);
+  fp::png_chunk(o, "IEND", {});
+  FILE *fo = std::fopen(path, "wb");
+  FP_CHECK(fo != nullptr, std::string("cannot write ") + path);
+  size_t wr = std::fwrite(o.data(), 1, o.size(), fo);
+  std::fclose(fo);
+  FP_CHECK(wr == o.size(), std::string("short write to ") + path);
+  return 0;
+}
+
+// draw3DBoundingBox (help_func.hpp:55-106): the 8 corners (+-dimension/2) through `pose` (column-major bbox->camera, i.e.
+// ConvertPoseMesh2BBox(pose, loader)), pinhole projection with fx, fy, cx, cy, 12 green edges of thickness 2.
+int fp_draw_bbox3d(uint8_t *rgb, int H, int W, const float K[9], const float pose[16], const float dimension[3]) {
+  FP_CHECK(rgb && K && pose && dimension, "fp_draw_bbox3d: null argument");
+  const float l = dimension[0] / 2, w = dimension[1] / 2, h = dimension[2] / 2;
+  const float pts[8][3] = {{-l, -w, h}, {l, -w, h}, {l, w, h}, {-l, w, h}, {-l, -w, -h}, {l, -w, -h}, {l, w, -h}, {-l, w, -h}};
+  float u[8], v[8];
+  for (int i = 0; i < 8; i++) {
+    float c[3];
+    for (int r = 0; r < 3; r++) c[r] = pose[r] * pts[i][0] + pose[4 + r] * pts[i][1] + pose[8 + r] * pts[i][2] + pose[12 + r];
+    u[i] = K[0] * (c[0] / c[2]) + K[2];
+    v[i] = K[4] * (c[1] / c[2]) + K[5];
+  }
+  static const int edges[12][2] = {{0, 1}, {1, 2}, {2, 3}, {3, 0}, {4, 5}, {5, 6}, {6, 7}, {7, 4}, {0, 4}, {1, 5}, {2, 6}, {3, 7}};
+  for (auto &e : edges) {
+    float x0 = u[e[0]], y0 = v[e[0]], x1 = u[e[1]], y1 = v[e[1]];
+    if (!std::isfinite(x0 + y0 + x1 + y1)) continue;
+    int steps = (int)std::ceil(std::max(std::fabs(x1 - x0), std::fabs(y1 - y0)));
+    steps = std::min(std::max(steps, 1), 4 * (H + W));
+    for (int s = 0; s <= steps; s++) {
+      float t = (float)s / steps;
+      int cx = (int)std::lround(x0 + t * (x1 - x0)), cy = (int)std::lround(y0 + t * (y1 - y0));
+      for (int dy = 0; dy < 2; dy++)
+        for (int dx = 0; dx < 2; dx++) {
+          int px = cx + dx, py = cy + dy;
+          if (px < 0 || py < 0 || px >= W || py >= H) continue;
+          uint8_t *p = rgb + ((size_t)py * W + px) * 3;
+          p[0] = 0; p[1] = 255; p[2] = 0;
+        }
+    }
+  }
+  return 0;
+}
+
+}  // extern "C"

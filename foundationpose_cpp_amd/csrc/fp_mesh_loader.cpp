@@ -10,8 +10,6 @@
 //   * UVs are mandatory (throws in the reference :182-185 -> error here); missing/unreadable texture -> 2x2
 //     (100,100,100) (:217-222); texture is returned RGB (imread BGR + cvtColor BGR2RGB, :216,223).
 //   * meshes without normals get area-weighted vertex normals (the reference would dereference a null mNormals).
-#include <zlib.h>
-
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -29,94 +27,7 @@
 
 namespace {
 
-// ---------------------------------------------------------------- PNG ------------------------------------------------
-bool inflate_all(const std::vector<uint8_t> &in, std::vector<uint8_t> &out, size_t expect) {
-  out.resize(expect);
-  z_stream zs;
-  std::memset(&zs, 0, sizeof(zs));
-  if (inflateInit(&zs) != Z_OK) return false;
-  zs.next_in = const_cast<Bytef *>(in.data());
-  zs.avail_in = (uInt)in.size();
-  zs.next_out = out.data();
-  zs.avail_out = (uInt)out.size();
-  int rc = inflate(&zs, Z_FINISH);
-  size_t got = zs.total_out;
-  inflateEnd(&zs);
-  return (rc == Z_STREAM_END || rc == Z_OK || rc == Z_BUF_ERROR) && got == expect;
-}
-
-uint32_t be32(const uint8_t *p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; }
-
-// 8-bit, non-interlaced PNG of colour type 0 (grey), 2 (RGB), 3 (palette), 4 (grey+alpha), 6 (RGBA) -> RGB u8
-bool load_png_rgb(const std::string &path, std::vector<uint8_t> &rgb, int &H, int &W) {
-  std::ifstream f(path, std::ios::binary);
-  if (!f) return false;
-  std::vector<uint8_t> buf((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
-  static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
-  if (buf.size() < 33 || std::memcmp(buf.data(), sig, 8) != 0) return false;
-  size_t pos = 8;
-  int depth = 0, ctype = 0, interlace = 0;
-  std::vector<uint8_t> idat, plte;
-  W = H = 0;
-  while (pos + 12 <= buf.size()) {
-    uint32_t len = be32(&buf[pos]);
-    std::string type((const char *)&buf[pos + 4], 4);
-    if (pos + 12 + len > buf.size()) return false;
-    const uint8_t *d = &buf[pos + 8];
-    if (type == "IHDR") {
-      W = (int)be32(d); H = (int)be32(d + 4); depth = d[8]; ctype = d[9]; interlace = d[12];
-    } else if (type == "PLTE") {
-      plte.assign(d, d + len);
-    } else if (type == "IDAT") {
-      idat.insert(idat.end(), d, d + len);
-    } else if (type == "IEND") {
-      break;
-    }
-    pos += 12 + len;
-  }
-  if (W <= 0 || H <= 0 || depth != 8 || interlace != 0) return false;
-  int ch = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
-  if (!ch) return false;
-  size_t stride = (size_t)W * ch;
-  std::vector<uint8_t> raw;
-  if (!inflate_all(idat, raw, (stride + 1) * H)) return false;
-  std::vector<uint8_t> img(stride * H);
-  for (int y = 0; y < H; y++) {
-    const uint8_t *src = &raw[(stride + 1) * y];
-    uint8_t ft = src[0];
-    uint8_t *dst = &img[stride * y];
-    const uint8_t *up = y ? &img[stride * (y - 1)] : nullptr;
-    for (size_t x = 0; x < stride; x++) {
-      int a = x >= (size_t)ch ? dst[x - ch] : 0, b = up ? up[x] : 0, c = (up && x >= (size_t)ch) ? up[x - ch] : 0;
-      int v = src[1 + x];
-      switch (ft) {
-        case 0: break;
-        case 1: v += a; break;
-        case 2: v += b; break;
-        case 3: v += (a + b) >> 1; break;
-        case 4: {
-          int p = a + b - c, pa = std::abs(p - a), pb = std::abs(p - b), pc = std::abs(p - c);
-          v += (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
-          break;
-        }
-        default: return false;
-      }
-      dst[x] = (uint8_t)v;
-    }
-  }
-  rgb.resize((size_t)W * H * 3);
-  for (size_t i = 0; i < (size_t)W * H; i++) {
-    const uint8_t *p = &img[i * ch];
-    uint8_t r, g, b;
-    if (ctype == 0 || ctype == 4) { r = g = b = p[0]; }
-    else if (ctype == 3) {
-      if ((size_t)p[0] * 3 + 2 >= plte.size()) return false;
-      r = plte[p[0] * 3]; g = plte[p[0] * 3 + 1]; b = plte[p[0] * 3 + 2];
-    } else { r = p[0]; g = p[1]; b = p[2]; }
-    rgb[i * 3] = r; rgb[i * 3 + 1] = g; rgb[i * 3 + 2] = b;
-  }
-  return true;
-}
+using fp::load_png_rgb;  // PNG decode lives in fp_image_io.cpp
 
 // ---------------------------------------------------------------- 3x3 symmetric eigen (Jacobi) ------------------------
 void eigen_sym3(const double A_in[9], double evals[3], double evecs[9] /* columns, row-major storage */) {

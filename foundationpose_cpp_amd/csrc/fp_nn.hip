@@ -885,7 +885,7 @@ __global__ __launch_bounds__(512, 2) void conv_pp32_kernel(const ConvParams p) {
   constexpr int WM = BM / 128, WN = BN / 64;
   static_assert(WM * WN == 8, "8 waves");
   constexpr int XP = BM / 16, WP = BN / 16, PER = (XP + WP) / 8;  // DMA pieces per stage / per wave
-  constexpr int XB = XP * 1024, STAGE = (XP + WP) * 1024, NST = 4;
+  constexpr int XB = XP * 1024, STAGE = (XP + WP) * 1024;
   constexpr int MI = 8, NI = 4;
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -2114,15 +2114,15 @@ float fpt_attention_bench(int B, int T, int iters, int variant) {
   int saved = g_att_variant;
   g_att_variant = variant;
   hipEvent_t e0, e1;
-  hipEventCreate(&e0); hipEventCreate(&e1);
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return -1.f;
   for (int i = 0; i < 3; i++) run_attention(c, dq.p, dout.p, B, T);
-  hipEventRecord(e0, nullptr);
+  (void)hipEventRecord(e0, nullptr);
   for (int i = 0; i < iters; i++) run_attention(c, dq.p, dout.p, B, T);
-  hipEventRecord(e1, nullptr);
-  hipEventSynchronize(e1);
-  float ms = 0.f;
-  hipEventElapsedTime(&ms, e0, e1);
-  hipEventDestroy(e0); hipEventDestroy(e1);
+  (void)hipEventRecord(e1, nullptr);
+  float ms = -1.f;
+  if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) ms = -(float)iters;
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
   g_att_variant = saved;
   return ms / iters;
 }

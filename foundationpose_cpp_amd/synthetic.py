@@ -145,10 +145,13 @@ class Scene:
 
 
 def make_scene(mesh: Mesh, W: int = 640, H: int = 480, t=(0.02, -0.01, 0.70), rot_seed: int = 1,
-               noise_seed: int = 2, drop_seed: int = 3, bg_seed: int = 4) -> Scene:
+               noise_seed: int = 2, drop_seed: int = 3, bg_seed: int = 4, pose=None) -> Scene:
+    """pose (4x4 centred-mesh -> camera) overrides t / rot_seed (used for synthetic sequences)"""
     K = intrinsics(W, H)
     R = random_rotation(rot_seed)
     t = np.array(t, dtype=np.float64)
+    if pose is not None:
+        R, t = np.asarray(pose, np.float64)[:3, :3], np.asarray(pose, np.float64)[:3, 3]
     ax = np.array(SEMI_AXES)
     # rays in camera frame -> object frame (object frame = centred ellipsoid)
     yy, xx = np.mgrid[0:H, 0:W].astype(np.float64)

@@ -22,6 +22,7 @@
 #ifndef FOUNDATIONPOSE_AMD_H
 #define FOUNDATIONPOSE_AMD_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -131,6 +132,24 @@ int fp_register_shard_begin(fp_model *m, const void *rgb, const void *depth, con
                             float **feat_dev, float **poses_dev);
 int fp_register_shard_finish(fp_model *m, const float *all_feat_dev, const float *all_poses_dev, int N_total,
                              float out_pose[16], int *best_index, float *scores_host /* may be NULL */);
+
+/* ---- frame / dataset I/O of the acceptance harness (simple_tests/include/tests/help_func.hpp) without OpenCV ----
+ * dataset layout test_data/download.md:6-15: <dir>/cam_K.txt, rgb/<id>.png, depth/<id>.png (u16 mm), masks/<id>.png, mesh/ */
+/* generic PNG decode (8/16-bit, grey/RGB/palette/alpha, non-interlaced): samples widened to u16, `channels` interleaved.
+ * out may be NULL to query the size. */
+int fp_image_read_png(const char *path, int *H, int *W, int *channels, int *bit_depth, uint16_t *out, size_t out_capacity);
+int fp_frame_size(const char *rgb_path, int *H, int *W);
+/* ReadRgbDepthMask / ReadRgbDepth (help_func.hpp:10-53): rgb u8 [H,W,3] RGB; depth f32 [H,W] = u16 / 1000; mask u8 [H,W]
+ * (first channel).  Any of the three outputs (with its path) may be NULL. */
+int fp_read_rgb_depth_mask(const char *rgb_path, const char *depth_path, const char *mask_path, int H, int W,
+                           uint8_t *rgb, float *depth, uint8_t *mask);
+/* ReadCamK (help_func.hpp:108-129): nine whitespace-separated numbers, row-major. */
+int fp_read_cam_k(const char *cam_K_path, float K[9]);
+/* cv::imwrite stand-in: 8-bit RGB PNG. */
+int fp_image_write_png_rgb(const char *path, const uint8_t *rgb, int H, int W);
+/* draw3DBoundingBox (help_func.hpp:55-106): green 12-edge box of `dimension` under the column-major bbox->camera `pose`
+ * (= ConvertPoseMesh2BBox(pose_in_mesh, loader), mesh_loader.hpp:75-81), drawn into rgb in place. */
+int fp_draw_bbox3d(uint8_t *rgb, int H, int W, const float K[9], const float pose[16], const float dimension[3]);
 
 /* ---- measurement hooks ---- */
 /* When enabled, every kernel launch is bracketed with HIP events on the model's stream and accumulated per kernel
