@@ -21,7 +21,7 @@ namespace fp {
 
 static thread_local std::string g_last_error;
 void set_error(const std::string &msg) { g_last_error = msg; }
-unsigned long g_alloc_epoch = 0;
+std::atomic<unsigned long> g_alloc_epoch{0};
 
 // ------------------------------------------------------------------------------------------------
 // Profiler

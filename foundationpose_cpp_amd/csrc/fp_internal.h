@@ -5,6 +5,7 @@
 #include <hip/hip_fp16.h>
 #include <stdint.h>
 
+#include <atomic>
 #include <string>
 #include <vector>
 
@@ -24,7 +25,7 @@ void set_error(const std::string &msg);
 // fp_image_io.cpp: 8-bit PNG (grey / RGB / palette / alpha variants) -> RGB u8
 bool load_png_rgb(const std::string &path, std::vector<uint8_t> &rgb, int &H, int &W);
 // bumped whenever a device buffer that kernels may have baked into a captured hipGraph is (re)allocated
-extern unsigned long g_alloc_epoch;
+extern std::atomic<unsigned long> g_alloc_epoch;
 #define FP_HIP_OK(expr)                                                                              \
   do {                                                                                               \
     hipError_t _e = (expr);                                                                          \

@@ -1554,7 +1554,12 @@ struct NNScratch {
   int head_cap = 0;
   __half *head_buf = nullptr;
   float *head_f32 = nullptr;
+  // fp32 partial slabs of split-K convolutions (small batches); per model so that models on different streams /
+  // threads never share it
+  float *splitk = nullptr;
+  size_t splitk_cap = 0;
   ~NNScratch() {
+    if (splitk) (void)hipFree(splitk);
     if (buf) (void)hipFree(buf);
     if (f32) (void)hipFree(f32);
     if (head_buf) (void)hipFree(head_buf);
@@ -1610,12 +1615,12 @@ struct Ctx {
   hipStream_t s;
   Profiler *prof;
   const Net *net;
+  NNScratch *ws = nullptr;  // owner of the split-K slab (null only in the single-threaded test hooks)
 };
 
 static bool g_conv_attr_done = false;
 static unsigned long long *g_clk_probe = nullptr;
-static float *g_splitk_ws = nullptr;  // fp32 partial slabs for split-K (grown on demand; process lifetime)
-static size_t g_splitk_cap = 0;
+static NNScratch g_hook_ws;  // split-K slab of the fpt_* test hooks
 static int g_conv_variant = 0;
 static int g_conv_ablate = 0;  // timing-only ablations of conv_big_pp_kernel: 1 no loads, 2 no MFMAs, 3 neither  // 0 auto, 1 force the 128-pixel 2-stage kernel, 2 force the 256-pixel 3-stage kernel (A/B hook)
 
@@ -1693,14 +1698,15 @@ static int run_conv(const Ctx &c, const char *tag, const ConvLayer &L, const __h
         p.kt_per = (KT + S - 1) / S;
         p.ksplit = (KT + p.kt_per - 1) / p.kt_per;
         size_t need = (size_t)p.ksplit * p.M * p.Cout;
-        if (need > g_splitk_cap) {
-          if (g_splitk_ws) (void)hipFree(g_splitk_ws);
-          g_splitk_ws = nullptr; g_splitk_cap = 0;
+        NNScratch *sk = c.ws ? c.ws : &g_hook_ws;
+        if (need > sk->splitk_cap) {
+          if (sk->splitk) (void)hipFree(sk->splitk);
+          sk->splitk = nullptr; sk->splitk_cap = 0;
           g_alloc_epoch++;
-          FP_HIP_OK(hipMalloc((void **)&g_splitk_ws, need * sizeof(float)));
-          g_splitk_cap = need;
+          FP_HIP_OK(hipMalloc((void **)&sk->splitk, need * sizeof(float)));
+          sk->splitk_cap = need;
         }
-        p.partial = g_splitk_ws;
+        p.partial = sk->splitk;
       }
     }
   }
@@ -1902,7 +1908,7 @@ int refiner_forward(hipStream_t s, Profiler *prof, const Net *net, NNScratch *ws
                     float *trans_dev, float *rot_dev, int shared_b) {
   FP_CHECK(net && !net->scorer, "refiner_forward: wrong network");
   if (ensure_scratch(ws, N, s)) return 1;
-  Ctx c{s, prof, net};
+  Ctx c{s, prof, net, ws};
   const Arena a = carve(ws);
   if (run_trunk(c, a, nn_in, N, shared_b ? 1 : N)) return 1;
   const __half *x = a.tokens;
@@ -1929,7 +1935,7 @@ int refiner_forward(hipStream_t s, Profiler *prof, const Net *net, NNScratch *ws
 int scorer_features(hipStream_t s, Profiler *prof, const Net *net, NNScratch *ws, const __half *nn_in, int N, float *feat_dev) {
   FP_CHECK(net && net->scorer, "scorer_features: wrong network");
   if (ensure_scratch(ws, N, s)) return 1;
-  Ctx c{s, prof, net};
+  Ctx c{s, prof, net, ws};
   const Arena a = carve(ws);
   if (run_trunk(c, a, nn_in, N, N)) return 1;
   const size_t rows = (size_t)N * 400;
@@ -1945,7 +1951,7 @@ int scorer_features(hipStream_t s, Profiler *prof, const Net *net, NNScratch *ws
 int scorer_head(hipStream_t s, Profiler *prof, const Net *net, NNScratch *ws, const float *feats_dev, int n_total, float *scores_dev) {
   FP_CHECK(net && net->scorer, "scorer_head: wrong network");
   if (ensure_head_scratch(ws, n_total)) return 1;
-  Ctx c{s, prof, net};
+  Ctx c{s, prof, net, ws};
   const int N = n_total;
   __half *p = ws->head_buf;
   __half *xf = p; p += (size_t)N * EMBED;

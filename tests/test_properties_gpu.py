@@ -112,3 +112,58 @@ def test_register_720p_textured_and_untextured(wpaths, textured):
     ok, tp = m.Track(scene.rgb, scene.depth, pose, "m720")
     assert ok and np.isfinite(tp).all()
     m.close()
+
+
+def test_several_meshes_per_model(wpaths, syn_scene):
+    """one model, several registered targets (foundationpose.cpp:142-149): each target behaves like its own model"""
+    ma = syn.make_mesh(name="a")
+    mb = syn.make_mesh(textured=False, name="b", subdiv=3)
+    both = FoundationPose([ma, mb], syn.intrinsics(), *wpaths)
+    for mesh in (ma, mb):
+        solo = FoundationPose(mesh, syn.intrinsics(), *wpaths)
+        ok1, p1 = both.Register(syn_scene.rgb, syn_scene.depth, syn_scene.mask, mesh.name)
+        ok2, p2 = solo.Register(syn_scene.rgb, syn_scene.depth, syn_scene.mask, mesh.name)
+        assert ok1 and ok2, (both.last_error, solo.last_error)
+        np.testing.assert_array_equal(p1, p2)
+        ok1, t1 = both.Track(syn_scene.rgb, syn_scene.depth, p1, mesh.name)
+        ok2, t2 = solo.Track(syn_scene.rgb, syn_scene.depth, p2, mesh.name)
+        assert ok1 and ok2
+        np.testing.assert_array_equal(t1, t2)
+        solo.close()
+    ok, _ = both.Register(syn_scene.rgb, syn_scene.depth, syn_scene.mask, "c")
+    assert not ok and "target_name" in both.last_error
+    both.close()
+
+
+def test_two_models_serve_concurrently_on_their_own_streams(wpaths, syn_mesh, syn_scene):
+    """one model per stream / thread (the not-re-entrant-per-model contract of the reference, foundationpose.cpp:103-105):
+    concurrent Track + Register calls give exactly the sequential results"""
+    import threading
+    scenes = [syn_scene, syn.make_scene(syn_mesh, t=(-0.03, 0.02, 0.62), rot_seed=9)]
+    models = [FoundationPose(syn_mesh, syn.intrinsics(), *wpaths) for _ in scenes]
+    hyps = [syn.perturb_pose(s.gt_pose) for s in scenes]
+    seq = []
+    for m, s, h in zip(models, scenes, hyps):
+        ok, p = m.Track(s.rgb, s.depth, h, syn_mesh.name)
+        ok2, r = m.Register(s.rgb, s.depth, s.mask, syn_mesh.name)
+        assert ok and ok2
+        seq.append((p, r))
+    results = [[], []]
+
+    def worker(i):
+        m, s, h = models[i], scenes[i], hyps[i]
+        for k in range(12):
+            ok, p = m.Track(s.rgb, s.depth, h, syn_mesh.name)
+            results[i].append(("t", ok, p))
+            if k % 4 == i:                       # Register calls of one model overlap Track calls of the other
+                ok, r = m.Register(s.rgb, s.depth, s.mask, syn_mesh.name)
+                results[i].append(("r", ok, r))
+    th = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    for i in range(2):
+        assert len(results[i]) >= 12
+        for kind, ok, p in results[i]:
+            assert ok
+            np.testing.assert_array_equal(p, seq[i][0] if kind == "t" else seq[i][1])
+    [m.close() for m in models]
