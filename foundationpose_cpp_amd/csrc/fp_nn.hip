@@ -85,7 +85,7 @@ struct ConvParams {
 // twice the store instructions; the 256x256 kernel spent 13 us of a 70 us workgroup in its store burst).
 // All bias and residual loads are issued BEFORE the first store: on CDNA4 stores also count in vmcnt, so a load issued
 // behind a store cannot be waited for without draining the store.
-template <int MI, int NI>
+template <int MI, int NI, int EABL = 0>  // EABL (timing ablations): 1 = no stores, 2 = no residual loads
 __device__ __forceinline__ void conv_epilogue(const ConvParams &p, f4 (&acc)[NI][MI], int m_base, int n_base, int lane) {
   static_assert(NI == 4 || NI == 2, "wave covers 64 or 32 channels");
   constexpr int NS = NI / 2;  // 16-byte stores per pixel per lane
@@ -114,7 +114,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams &p, f4 (&acc)[NI]
     int choff = 0, oimg = img;
     if (p.split_imgs > 0 && img >= p.split_imgs) { oimg = img - p.split_imgs; choff = p.Cout; }
     oofs[mi] = (((size_t)oimg * OHp + oh + p.opad) * OWp + ow + p.opad) * p.out_ld + choff;
-    if (p.res) {
+    if (p.res && !(EABL & 2)) {
       size_t rpix = ((size_t)img * RHp + oh + p.rpad) * RWp + ow + p.rpad;
 #pragma unroll
       for (int k = 0; k < NS; k++)
@@ -132,11 +132,12 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams &p, f4 (&acc)[NI]
         const int jj = (NI == 4) ? 2 * k + (e >> 2) : (e >> 1);
         const int ni = (NI == 4) ? (e & 3) : (e & 1);
         float v = acc[ni][mi][jj] + bv[k][e];
-        if (p.res) v += (float)rv[k][mi][e];
+        if (p.res && !(EABL & 2)) v += (float)rv[k][mi][e];
         if (p.relu) v = fmaxf(v, 0.f);
         o[e] = (_Float16)v;
       }
-      *reinterpret_cast<h8 *>(p.out + oofs[mi] + nl + 32 * k) = o;
+      if (EABL & 1) asm volatile("" ::"v"(o));
+      else *reinterpret_cast<h8 *>(p.out + oofs[mi] + nl + 32 * k) = o;
     }
   }
 }
@@ -866,7 +867,7 @@ __global__ __launch_bounds__(512, 2) void conv_big_pp_kernel(const ConvParams p)
       for (int b = 0; b < MI; b++) asm volatile("" ::"v"(acc[a][b]));
     return;
   }
-  conv_epilogue<MI, NI>(p, acc, m0 + wm * 128, n0 + wn * 64, lane);
+  conv_epilogue<MI, NI, (ABL >> 3) & 3>(p, acc, m0 + wm * 128, n0 + wn * 64, lane);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -1681,6 +1682,8 @@ static int run_conv(const Ctx &c, const char *tag, const ConvLayer &L, const __h
     FP_HIP_OK(hipFuncSetAttribute((const void *)conv_big_pp_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 * 128 + 256 * 128)));
     FP_HIP_OK(hipFuncSetAttribute((const void *)conv_big_pp_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 * 128 + 256 * 128)));
     FP_HIP_OK(hipFuncSetAttribute((const void *)conv_big_pp_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 * 128 + 256 * 128)));
+    FP_HIP_OK(hipFuncSetAttribute((const void *)conv_big_pp_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 * 128 + 256 * 128)));
+    FP_HIP_OK(hipFuncSetAttribute((const void *)conv_big_pp_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 * 128 + 256 * 128)));
     FP_HIP_OK(hipFuncSetAttribute((const void *)conv_pp_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS3_128));
     FP_HIP_OK(hipFuncSetAttribute((const void *)conv_pp_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS3_64));
     g_conv_attr_done = true;
@@ -1758,6 +1761,8 @@ static int run_conv(const Ctx &c, const char *tag, const ConvLayer &L, const __h
         else if (g_conv_ablate == 2) hipLaunchKernelGGL(conv_big_pp_kernel<2>, dim3(mt_big * nt2), dim3(512), lds_big, c.s, pb);
         else if (g_conv_ablate == 3) hipLaunchKernelGGL(conv_big_pp_kernel<3>, dim3(mt_big * nt2), dim3(512), lds_big, c.s, pb);
         else if (g_conv_ablate == 4) hipLaunchKernelGGL(conv_big_pp_kernel<4>, dim3(mt_big * nt2), dim3(512), lds_big, c.s, pb);
+        else if (g_conv_ablate == 8) hipLaunchKernelGGL(conv_big_pp_kernel<8>, dim3(mt_big * nt2), dim3(512), lds_big, c.s, pb);
+        else if (g_conv_ablate == 16) hipLaunchKernelGGL(conv_big_pp_kernel<16>, dim3(mt_big * nt2), dim3(512), lds_big, c.s, pb);
         else hipLaunchKernelGGL(conv_big_pp_kernel<0>, dim3(mt_big * nt2), dim3(512), lds_big, c.s, pb);
       }
       flops *= (1.0 - frac); bytes *= (1.0 - frac);

@@ -1,22 +1,29 @@
-"""A/B of attention kernel variants inside the real Register pipeline (QKV freshly written by the GEMM)."""
+"""A/B of a library test hook inside the real Register pipeline (N = 252), same process / same box.
+
+    python tools/ab_pipeline.py fpt_set_att_variant 7 1 7 1
+    python tools/ab_pipeline.py fpt_set_conv_ablate 0 16 0 16        # 16 = no streaming stores
+"""
 import os, sys, tempfile
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from foundationpose_cpp_amd import FoundationPose, synthetic as syn, weights as W, _lib
+hook, values = sys.argv[1], [int(v) for v in sys.argv[2:]]
 mesh = syn.make_mesh(); scene = syn.make_scene(mesh)
 d = tempfile.mkdtemp()
 rp, sp = os.path.join(d, "r.fpw"), os.path.join(d, "s.fpw")
 W.pack_synthetic("refiner", rp); W.pack_synthetic("scorer", sp)
 m = FoundationPose(mesh, scene.K, rp, sp)
 L = _lib.lib()
-for v in (7, 1, 5, 3, 7, 1, 5, 3):
-    L.fpt_set_att_variant(v)
+for v in values:
+    getattr(L, hook)(v)
     for _ in range(2):
         m.Register(scene.rgb, scene.depth, scene.mask, mesh.name)
     m.profile(True); m.profile_reset()
-    for _ in range(5):
+    for _ in range(6):
         m.Register(scene.rgb, scene.depth, scene.mask, mesh.name)
     r = m.profile_report()
     m.profile(False)
-    att = sum(x["ms"] for k, x in r.items() if k.startswith("attention")) / 5
-    tot = sum(x["ms"] for x in r.values()) / 5
-    print(f"variant {v}: attention {att:.3f} ms/step   all kernels {tot:.3f} ms/step")
+    st = {}
+    for k, x in r.items():
+        st[k.split("/")[0]] = st.get(k.split("/")[0], 0.0) + x["ms"] / 6
+    top = sorted(st.items(), key=lambda kv: -kv[1])[:8]
+    print(f"{hook}({v}): all kernels {sum(st.values()):.3f} ms/step  " + "  ".join(f"{k} {t:.3f}" for k, t in top))
