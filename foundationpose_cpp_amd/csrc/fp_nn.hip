@@ -85,11 +85,10 @@ struct ConvParams {
 // twice the store instructions; the 256x256 kernel spent 13 us of a 70 us workgroup in its store burst).
 // All bias and residual loads are issued BEFORE the first store: on CDNA4 stores also count in vmcnt, so a load issued
 // behind a store cannot be waited for without draining the store.
-template <int MI, int NI, int EABL = 0>  // EABL (timing ablations): 1 = no stores, 2 = no residual loads
-__device__ __forceinline__ void conv_epilogue(const ConvParams &p, f4 (&acc)[NI][MI], int m_base, int n_base, int lane) {
+template <int MI, int NI, int EABL = 0, class PixFn>  // EABL (timing ablations): 1 = no stores, 2 = no residual loads
+__device__ __forceinline__ void conv_epilogue_px(const ConvParams &p, f4 (&acc)[NI][MI], int n_base, int lane, PixFn pix) {
   static_assert(NI == 4 || NI == 2, "wave covers 64 or 32 channels");
   constexpr int NS = NI / 2;  // 16-byte stores per pixel per lane
-  const int ohw = p.OH * p.OW;
   const int OHp = p.OH + 2 * p.opad, OWp = p.OW + 2 * p.opad;
   const int RHp = p.OH + 2 * p.rpad, RWp = p.OW + 2 * p.rpad;
   const int g = lane >> 4;
@@ -100,30 +99,34 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams &p, f4 (&acc)[NI]
     float4 b0 = *reinterpret_cast<const float4 *>(p.bias + nl + 32 * k), b1 = *reinterpret_cast<const float4 *>(p.bias + nl + 32 * k + 4);
     bv[k][0] = b0.x; bv[k][1] = b0.y; bv[k][2] = b0.z; bv[k][3] = b0.w; bv[k][4] = b1.x; bv[k][5] = b1.y; bv[k][6] = b1.z; bv[k][7] = b1.w;
   }
-  size_t oofs[MI];
-  bool ok[MI];
-  h8 rv[NS][MI];
+  // pixels in groups of at most 8 fragments: a group's residual values (4 VGPRs per fragment and store) stay in registers
+  constexpr int GB = MI > 8 ? (MI + 1) / 2 : MI;
 #pragma unroll
-  for (int mi = 0; mi < MI; mi++) {
-    int m = m_base + mi * 16 + (lane & 15);
-    ok[mi] = m < p.M;
-    int mm = ok[mi] ? m : 0;
-    int img = mm / ohw;
-    int rem = mm - img * ohw;
-    int oh = rem / p.OW, ow = rem - oh * p.OW;
+  for (int g0 = 0; g0 < MI; g0 += GB) {
+  size_t oofs[GB];
+  bool ok[GB];
+  h8 rv[NS][GB];
+#pragma unroll
+  for (int gi = 0; gi < GB; gi++) {
+    const int mi = g0 + gi;
+    if (mi >= MI) break;
+    int img, oh, ow;
+    ok[gi] = pix(mi, img, oh, ow);  // (img, oh, ow) must be a valid address even when !ok
     int choff = 0, oimg = img;
     if (p.split_imgs > 0 && img >= p.split_imgs) { oimg = img - p.split_imgs; choff = p.Cout; }
-    oofs[mi] = (((size_t)oimg * OHp + oh + p.opad) * OWp + ow + p.opad) * p.out_ld + choff;
+    oofs[gi] = (((size_t)oimg * OHp + oh + p.opad) * OWp + ow + p.opad) * p.out_ld + choff;
     if (p.res && !(EABL & 2)) {
       size_t rpix = ((size_t)img * RHp + oh + p.rpad) * RWp + ow + p.rpad;
 #pragma unroll
       for (int k = 0; k < NS; k++)
-        rv[k][mi] = ok[mi] ? *reinterpret_cast<const h8 *>(p.res + rpix * p.res_ld + nl + 32 * k) : (h8){0, 0, 0, 0, 0, 0, 0, 0};
+        rv[k][gi] = ok[gi] ? *reinterpret_cast<const h8 *>(p.res + rpix * p.res_ld + nl + 32 * k) : (h8){0, 0, 0, 0, 0, 0, 0, 0};
     }
   }
 #pragma unroll
-  for (int mi = 0; mi < MI; mi++) {
-    if (!ok[mi]) continue;
+  for (int gi = 0; gi < GB; gi++) {
+    const int mi = g0 + gi;
+    if (mi >= MI) break;
+    if (!ok[gi]) continue;
 #pragma unroll
     for (int k = 0; k < NS; k++) {
       h8 o;
@@ -132,14 +135,31 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams &p, f4 (&acc)[NI]
         const int jj = (NI == 4) ? 2 * k + (e >> 2) : (e >> 1);
         const int ni = (NI == 4) ? (e & 3) : (e & 1);
         float v = acc[ni][mi][jj] + bv[k][e];
-        if (p.res && !(EABL & 2)) v += (float)rv[k][mi][e];
+        if (p.res && !(EABL & 2)) v += (float)rv[k][gi][e];
         if (p.relu) v = fmaxf(v, 0.f);
         o[e] = (_Float16)v;
       }
       if (EABL & 1) asm volatile("" ::"v"(o));
-      else *reinterpret_cast<h8 *>(p.out + oofs[mi] + nl + 32 * k) = o;
+      else *reinterpret_cast<h8 *>(p.out + oofs[gi] + nl + 32 * k) = o;
     }
   }
+  }
+}
+
+// the implicit-GEMM schedules: output row m = m_base + mi*16 + (lane&15) in (image, oh, ow) raster order
+template <int MI, int NI, int EABL = 0>
+__device__ __forceinline__ void conv_epilogue(const ConvParams &p, f4 (&acc)[NI][MI], int m_base, int n_base, int lane) {
+  const int ohw = p.OH * p.OW;
+  conv_epilogue_px<MI, NI, EABL>(p, acc, n_base, lane, [&](int mi, int &img, int &oh, int &ow) {
+    int m = m_base + mi * 16 + (lane & 15);
+    const bool ok = m < p.M;
+    int mm = ok ? m : 0;
+    img = mm / ohw;
+    int rem = mm - img * ohw;
+    oh = rem / p.OW;
+    ow = rem - oh * p.OW;
+    return ok;
+  });
 }
 
 // split-K partial slab (true channel order): per accumulator register j a lane owns NI consecutive channels
@@ -1022,6 +1042,161 @@ __global__ __launch_bounds__(512, 2) void conv_pp32_kernel(const ConvParams p) {
   conv_epilogue<MI, NI>(p, acc, m0 + wm * 128, n0 + wn * 64, lane);
 }
 
+// -------------------------------------------------------------------------------------------------
+// conv_halo_kernel<TW>: 3x3 / stride 1 convolution with the INPUT TILE + HALO resident in LDS.
+// The implicit-GEMM schedules above re-fetch every input pixel once per tap (9x) through the global -> LDS path, which
+// is what bounds them (~47 B/clk/CU).  Here a workgroup owns an 8-row x TW-column output tile of one image and stages
+// the (8+2) x (TW+2) halo tile of a 64-channel chunk ONCE (the padded image rows are contiguous in memory, so the halo
+// tile is one linear run of pixels); the 9 taps are just 9 shifted LDS windows.  Only the weights stream per K-step
+// (8 KB per 32-wide step, 3-stage ring).  Global -> LDS traffic per flop is ~2x below the 256x256 tile's, small enough
+// that TWO workgroups (4 waves, 160 accumulators each) share a CU: one's prologue / halo reload / epilogue store burst
+// overlaps the other's MFMAs, which the one-workgroup-per-CU 256x256 tile cannot do.
+//   M fragment = a 4x4 pixel block (lane&15 -> dy = >>2, dx = &3); wave (wm, wn) owns block-row wm (TW/4 blocks) x 64 ch.
+//   halo LDS layout: pixel-major 128-byte rows, 16-byte slot = chunk ^ g, g = ((x>>1)&1) | ((y&3)<<1): conflict-free for
+//   every tap shift (checked by enumeration); the swizzle is applied by the DMA on the SOURCE chunk.
+// -------------------------------------------------------------------------------------------------
+template <int TW, int ABL = 0>  // ABL (timing ablations, wrong results): 1 no per-step barrier, 2 no MFMAs, 4 X fragments read once
+__global__ __launch_bounds__(256, 2) void conv_halo_kernel(const ConvParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int TH = 8, HC = TW + 2, HPX = (TH + 2) * HC;
+  constexpr int HPIECES = (HPX + 7) / 8, HALO_B = HPIECES * 1024;
+  constexpr int HPER = (HPIECES + 3) / 4;  // halo DMA pieces per wave
+  constexpr int WST = 128 * 64, NWST = 3;  // weight ring: 128 rows x 64 B per 32-wide K-step
+  constexpr int MI = TW / 4, NI = 4;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int n_tiles = p.Cout / 128;
+  int logical;
+  {
+    const int nblk = gridDim.x, b = blockIdx.x;
+    const int xcd = b & 7, within = b >> 3, q = nblk >> 3, r = nblk & 7;
+    logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
+  }
+  const int mt = logical / n_tiles, nt = logical - mt * n_tiles;
+  const int tiles_per_img = p.H / TH;
+  const int img = mt / tiles_per_img, ty0 = (mt - img * tiles_per_img) * TH;
+  const int n0 = nt * 128;
+  const int IHp = p.H + 2;
+
+  const unsigned char *in_b = reinterpret_cast<const unsigned char *>(p.in) + ((size_t)(img * IHp + ty0) * HC) * p.Cin * 2;
+  const unsigned char *w_b = reinterpret_cast<const unsigned char *>(p.w);
+  const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
+  const unsigned w_lds = lds_base + HALO_B;
+
+  // halo DMA: piece = wave + 4*i covers halo pixels piece*8 .. +7; lane -> (pixel = lane>>3, slot = lane&7)
+  auto issue_halo = [&](int chunk) {
+    const unsigned char *src = in_b + chunk * 128;
+    int lane8;  // opaque copy of lane>>3: keeps the 14 per-lane offsets from being hoisted out of the chunk loop (VGPRs)
+    asm volatile("v_lshrrev_b32 %0, 3, %1" : "=v"(lane8) : "v"(lane));
+#pragma unroll
+    for (int i = 0; i < HPER; i++) {
+      const int piece = wave + 4 * i;
+      if (piece < HPIECES) {
+        int q = min(piece * 8 + lane8, HPX - 1);
+        int hy = q / HC, hx = q - hy * HC;
+        int g = ((hx >> 1) & 1) | ((hy & 3) << 1);
+        unsigned off = (unsigned)(q * p.Cin * 2 + (((lane & 7) ^ g) << 4));
+        glds16_asm(src + off, lds_base + piece * 1024);
+        __builtin_amdgcn_sched_barrier(0);  // one address at a time: 14 hoisted 64-bit addresses would spill accumulators
+      }
+    }
+  };
+  // weight DMA: piece = wave*2 + i (16 rows x 64 B); lane -> (row = lane>>2, slot = lane&3), source chunk = slot ^ G
+  const int prow = lane >> 2;
+  const int gch = (lane & 3) ^ ((0x78 >> (((prow >> 2) & 3) * 2)) & 3);
+  unsigned woff[2];
+#pragma unroll
+  for (int i = 0; i < 2; i++) woff[i] = (unsigned)((n0 + (wave * 2 + i) * 16 + prow) * p.Ktot + gch * 8) * 2u;
+  auto issue_w = [&](int st) {
+    const unsigned char *wb = w_b + (size_t)st * 64;
+    const unsigned dst = w_lds + (st % NWST) * WST;
+#pragma unroll
+    for (int i = 0; i < 2; i++) glds16_asm(wb + woff[i], dst + (wave * 2 + i) * 1024);
+  };
+
+  f4 acc[NI][MI];
+#pragma unroll
+  for (int a = 0; a < NI; a++)
+#pragma unroll
+    for (int b = 0; b < MI; b++) acc[a][b] = (f4){0.f, 0.f, 0.f, 0.f};
+
+  const int li = lane & 15, dy = li >> 2, dx = li & 3, kg = lane >> 4;
+  const int fslot = kg ^ ((0x78 >> ((li >> 2) * 2)) & 3);
+  const int wfo = HALO_B + (wn * 64 + li) * 64 + fslot * 16;
+
+  const int S = p.Ktot >> 5;   // 32-wide K-steps: 18 per 64-channel chunk (9 taps x 2)
+  const int nch = p.Cin >> 6;
+  issue_halo(0);
+  issue_w(0);
+  issue_w(1);
+  if (p.clk && tid == 0) { p.clk[blockIdx.x * 4] = __builtin_readcyclecounter(); p.clk[blockIdx.x * 4 + 1] = wall_clock64(); }
+  int s = 0;
+  for (int ch = 0; ch < nch; ch++) {
+    for (int tap = 0; tap < 9; tap++) {
+      const int ky = tap / 3, kx = tap - ky * 3;
+      const int ty = wm * 4 + dy + ky, tx = dx + kx;
+      const int g = ((tx >> 1) & 1) | ((ty & 3) << 1);
+      const int pix_off = (ty * HC + tx) * 128;
+#pragma unroll
+      for (int ks = 0; ks < 2; ks++, s++) {
+        // W(s) (and, on a chunk's first step, the halo tile) landed; everyone finished reading step s-1
+        if ((tap == 0 && ks == 0) || s == S - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        if (!(ABL & 1) || (tap == 0 && ks == 0)) __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + 2 < S) issue_w(s + 2);
+        const unsigned char *xs = smem + pix_off + (((ks * 4 + kg) ^ g) << 4);
+        const unsigned char *ws = smem + wfo + (s % NWST) * WST;
+        // X fragments in two halves of MI/2 (register budget: 160 accumulators + 20 + 16 fragment registers); the
+        // second half's LDS reads are issued behind the first half's MFMAs
+        constexpr int HM = MI / 2;
+        h8 xf[HM], wf[NI];
+#pragma unroll
+        for (int ni = 0; ni < NI; ni++) wf[ni] = *reinterpret_cast<const h8 *>(ws + ni * 16 * 64);
+#pragma unroll
+        for (int mi = 0; mi < HM; mi++) xf[mi] = *reinterpret_cast<const h8 *>(xs + mi * 512);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ni = 0; ni < NI; ni++)
+#pragma unroll
+          for (int mi = 0; mi < HM; mi++) {
+            if (ABL & 2) asm volatile("" ::"v"(wf[ni]), "v"(xf[mi]));
+            else acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ni], xf[mi], acc[ni][mi], 0, 0, 0);
+          }
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int mi = 0; mi < HM; mi++) xf[mi] = *reinterpret_cast<const h8 *>(xs + (HM + mi) * 512);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (tap == 8 && ks == 1 && ch + 1 < nch) {  // last read of this chunk's halo tile: refill it under the MFMAs
+          __builtin_amdgcn_s_barrier();
+          __builtin_amdgcn_sched_barrier(0);
+          issue_halo(ch + 1);
+        }
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ni = 0; ni < NI; ni++)
+#pragma unroll
+          for (int mi = 0; mi < HM; mi++) {
+            if (ABL & 2) asm volatile("" ::"v"(wf[ni]), "v"(xf[mi]));
+            else acc[ni][HM + mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ni], xf[mi], acc[ni][HM + mi], 0, 0, 0);
+          }
+        __builtin_amdgcn_s_setprio(0);
+      }
+    }
+  }
+  if (p.clk && tid == 0) { p.clk[blockIdx.x * 4 + 2] = __builtin_readcyclecounter(); p.clk[blockIdx.x * 4 + 3] = wall_clock64(); }
+  conv_epilogue_px<MI, NI>(p, acc, n0 + wn * 64, lane, [&](int mi, int &oimg, int &oh, int &ow) {
+    oimg = img;
+    oh = ty0 + wm * 4 + dy;
+    ow = mi * 4 + dx;
+    return true;
+  });
+}
+
 // split-K reduction + the conv epilogue: out = relu(sum_s partial[s] + bias + res); thread = (pixel, 4 channels)
 __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvParams p) {
   const int nq = p.Cout / 4;
@@ -1663,6 +1838,7 @@ static int run_conv(const Ctx &c, const char *tag, const ConvLayer &L, const __h
   double flops = 2.0 * (double)p.M * p.Cout * (L.algo_K > 0 ? L.algo_K : p.Ktot);
   double bytes = ((double)NB * H * W * L.Cin + (double)p.M * p.Cout * (res ? 2 : 1) + (double)p.Cout * p.Ktot) * 2.0;
   constexpr int LDS3_128 = 3 * (256 * 128 + 128 * 128), LDS3_64 = 3 * (256 * 128 + 64 * 128);
+  constexpr int LDS_HALO40 = ((10 * 42 + 7) / 8) * 1024 + 3 * 128 * 64;
   if (!g_conv_attr_done) {
     FP_HIP_OK(hipFuncSetAttribute((const void *)conv_igemm_kernel<128, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (128 * 128 + 128 * 128)));
     FP_HIP_OK(hipFuncSetAttribute((const void *)conv_igemm_kernel<128, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (128 * 128 + 128 * 128)));
@@ -1684,6 +1860,9 @@ static int run_conv(const Ctx &c, const char *tag, const ConvLayer &L, const __h
     FP_HIP_OK(hipFuncSetAttribute((const void *)conv_big_pp_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 * 128 + 256 * 128)));
     FP_HIP_OK(hipFuncSetAttribute((const void *)conv_big_pp_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 * 128 + 256 * 128)));
     FP_HIP_OK(hipFuncSetAttribute((const void *)conv_big_pp_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 * 128 + 256 * 128)));
+    FP_HIP_OK(hipFuncSetAttribute((const void *)conv_halo_kernel<40, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_HALO40));
+    FP_HIP_OK(hipFuncSetAttribute((const void *)conv_halo_kernel<40, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_HALO40));
+    FP_HIP_OK(hipFuncSetAttribute((const void *)conv_halo_kernel<40, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_HALO40));
     FP_HIP_OK(hipFuncSetAttribute((const void *)conv_pp_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS3_128));
     FP_HIP_OK(hipFuncSetAttribute((const void *)conv_pp_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS3_64));
     g_conv_attr_done = true;
@@ -1720,7 +1899,16 @@ static int run_conv(const Ctx &c, const char *tag, const ConvLayer &L, const __h
   // measured (tools/bench_conv.py, N=126): the 128-px 2-stage kernel beats the 256-px 3-stage one on every layer
   // (756-769 vs 703-709 TF/s weighted), so the latter is only reachable through the A/B hook
   p.m_begin = 0;
-  if (((g_conv_variant == 0 && L.Cout == 128) || (g_conv_variant == 6 && (L.Cout % 256 == 0 || L.Cout == 128))) && p.ksplit == 1 &&
+  if ((g_conv_variant == 7 || g_conv_variant == 0) && L.KH == 3 && L.KW == 3 && L.stride == 1 && L.pad == 1 && ipad == 1 && W == 40 && H % 8 == 0 &&
+      L.Cin % 64 == 0 && L.Cout % 128 == 0 && p.ksplit == 1) {
+    ProfScope ps(c.prof, c.s, (tg + "/conv_halo_kernel").c_str(), flops, bytes);
+    const dim3 grid(NB * (H / 8) * (L.Cout / 128));
+    if (g_conv_ablate == 1) hipLaunchKernelGGL((conv_halo_kernel<40, 1>), grid, dim3(256), LDS_HALO40, c.s, p);
+    else if (g_conv_ablate == 2) hipLaunchKernelGGL((conv_halo_kernel<40, 2>), grid, dim3(256), LDS_HALO40, c.s, p);
+    else hipLaunchKernelGGL((conv_halo_kernel<40, 0>), grid, dim3(256), LDS_HALO40, c.s, p);
+    return 0;
+  }
+  if ((((g_conv_variant == 0 || g_conv_variant == 8) && L.Cout == 128) || (g_conv_variant == 6 && (L.Cout % 256 == 0 || L.Cout == 128))) && p.ksplit == 1 &&
       KT >= 4 && KT <= 80) {
     // ping-pong tiles (conv_pp32_kernel) for as many FULL rounds of the 256 CUs as the problem has; the remaining rows
     // go to the 128x128 kernel below
@@ -1744,7 +1932,7 @@ static int run_conv(const Ctx &c, const char *tag, const ConvLayer &L, const __h
       mtiles = (p.M - p.m_begin + 127) / 128;
     }
   }
-  if ((g_conv_variant == 4 || g_conv_variant == 5 || g_conv_variant == 0) && L.Cout % 256 == 0 && p.ksplit == 1 && KT >= 2) {
+  if ((g_conv_variant == 4 || g_conv_variant == 5 || g_conv_variant == 0 || g_conv_variant == 8) && L.Cout % 256 == 0 && p.ksplit == 1 && KT >= 2) {
     // 256x256 tiles for as many FULL rounds of the 256 CUs as the problem has, the remaining rows on 128x128 tiles
     const int nt2 = L.Cout / 256;
     const int mt_all = p.M / 256;                         // whole 256-row m-tiles

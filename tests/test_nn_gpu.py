@@ -80,7 +80,7 @@ def test_conv_igemm_matches_torch(shape):
     np.testing.assert_allclose(got, ref, rtol=2e-3, atol=2e-3)
 
 
-@pytest.mark.parametrize("variant", [2, 3, 4, 5, 6])
+@pytest.mark.parametrize("variant", [2, 3, 4, 5, 6, 7])
 def test_conv_alternative_schedules_match_torch(variant):
     """the 256-pixel 3-stage (2) and ping-pong (3) schedules of the same implicit GEMM (A/B hooks)"""
     L = _lib.lib()
