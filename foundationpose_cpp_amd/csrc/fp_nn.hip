@@ -1158,7 +1158,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const ConvParams p) {
 #pragma unroll
         for (int mi = 0; mi < HM; mi++) xf[mi] = *reinterpret_cast<const h8 *>(xs + mi * 512);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_setprio(1);
+        if (!(ABL & 8)) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ni = 0; ni < NI; ni++)
 #pragma unroll
@@ -1166,7 +1166,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const ConvParams p) {
             if (ABL & 2) asm volatile("" ::"v"(wf[ni]), "v"(xf[mi]));
             else acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ni], xf[mi], acc[ni][mi], 0, 0, 0);
           }
-        __builtin_amdgcn_s_setprio(0);
+        if (!(ABL & 8)) __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int mi = 0; mi < HM; mi++) xf[mi] = *reinterpret_cast<const h8 *>(xs + (HM + mi) * 512);
@@ -1176,7 +1176,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const ConvParams p) {
           __builtin_amdgcn_sched_barrier(0);
           issue_halo(ch + 1);
         }
-        __builtin_amdgcn_s_setprio(1);
+        if (!(ABL & 8)) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ni = 0; ni < NI; ni++)
 #pragma unroll
@@ -1184,7 +1184,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const ConvParams p) {
             if (ABL & 2) asm volatile("" ::"v"(wf[ni]), "v"(xf[mi]));
             else acc[ni][HM + mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ni], xf[mi], acc[ni][HM + mi], 0, 0, 0);
           }
-        __builtin_amdgcn_s_setprio(0);
+        if (!(ABL & 8)) __builtin_amdgcn_s_setprio(0);
       }
     }
   }
@@ -1863,6 +1863,7 @@ static int run_conv(const Ctx &c, const char *tag, const ConvLayer &L, const __h
     FP_HIP_OK(hipFuncSetAttribute((const void *)conv_halo_kernel<40, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_HALO40));
     FP_HIP_OK(hipFuncSetAttribute((const void *)conv_halo_kernel<40, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_HALO40));
     FP_HIP_OK(hipFuncSetAttribute((const void *)conv_halo_kernel<40, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_HALO40));
+    FP_HIP_OK(hipFuncSetAttribute((const void *)conv_halo_kernel<40, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_HALO40));
     FP_HIP_OK(hipFuncSetAttribute((const void *)conv_pp_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS3_128));
     FP_HIP_OK(hipFuncSetAttribute((const void *)conv_pp_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS3_64));
     g_conv_attr_done = true;
@@ -1900,11 +1901,13 @@ static int run_conv(const Ctx &c, const char *tag, const ConvLayer &L, const __h
   // (756-769 vs 703-709 TF/s weighted), so the latter is only reachable through the A/B hook
   p.m_begin = 0;
   if ((g_conv_variant == 7 || g_conv_variant == 0) && L.KH == 3 && L.KW == 3 && L.stride == 1 && L.pad == 1 && ipad == 1 && W == 40 && H % 8 == 0 &&
-      L.Cin % 64 == 0 && L.Cout % 128 == 0 && p.ksplit == 1) {
+      L.Cin % 64 == 0 && L.Cout % 128 == 0 && p.ksplit == 1 &&
+      (g_conv_variant == 7 || NB * (H / 8) * (L.Cout / 128) >= 300)) {  // measured crossover vs the implicit-GEMM tiles: ~32 hypotheses
     ProfScope ps(c.prof, c.s, (tg + "/conv_halo_kernel").c_str(), flops, bytes);
     const dim3 grid(NB * (H / 8) * (L.Cout / 128));
     if (g_conv_ablate == 1) hipLaunchKernelGGL((conv_halo_kernel<40, 1>), grid, dim3(256), LDS_HALO40, c.s, p);
     else if (g_conv_ablate == 2) hipLaunchKernelGGL((conv_halo_kernel<40, 2>), grid, dim3(256), LDS_HALO40, c.s, p);
+    else if (g_conv_ablate == 8) hipLaunchKernelGGL((conv_halo_kernel<40, 8>), grid, dim3(256), LDS_HALO40, c.s, p);
     else hipLaunchKernelGGL((conv_halo_kernel<40, 0>), grid, dim3(256), LDS_HALO40, c.s, p);
     return 0;
   }
