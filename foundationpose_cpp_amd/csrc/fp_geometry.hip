@@ -345,8 +345,10 @@ __device__ __noinline__ void raster_clipped(float4 v0, float4 v1, float4 v2, uns
 #undef FP_BARY_PT
 }
 
-template <int MODE, int STRIP_ROWS>
-__global__ __launch_bounds__(256) void raster_shade_kernel(
+// NT threads per workgroup: 256 normally; 1024 for tiny batches (Track), where the kernel is bound by the latency of the
+// F/NT dependent triangle iterations of each strip rather than by throughput
+template <int MODE, int STRIP_ROWS, int NT = 256>
+__global__ __launch_bounds__(NT) void raster_shade_kernel(
     const int32_t *__restrict__ faces, int F, int V, const float *__restrict__ uvs, const uint8_t *__restrict__ tex,
     int TH, int TW, float downscale, const PoseRec *__restrict__ recs, const float4 *__restrict__ clip_all,
     const float4 *__restrict__ attr_all, void *__restrict__ out_all, int32_t *__restrict__ tri_id_dbg,
@@ -359,10 +361,10 @@ __global__ __launch_bounds__(256) void raster_shade_kernel(
   const float4 *attr = attr_all + (size_t)n * V;
 
   const unsigned long long clear_key = ((unsigned long long)CR_DEPTH_MAX << 32) | 0xFFFFFFFFull;
-  for (int i = tid; i < STRIP_ROWS * CROP; i += 256) zbuf[i] = clear_key;
+  for (int i = tid; i < STRIP_ROWS * CROP; i += NT) zbuf[i] = clear_key;
   __syncthreads();
 
-  for (int f = tid; f < F; f += 256) {
+  for (int f = tid; f < F; f += NT) {
     int i0 = faces[f * 3], i1 = faces[f * 3 + 1], i2 = faces[f * 3 + 2];
     if ((unsigned)i0 >= (unsigned)V || (unsigned)i1 >= (unsigned)V || (unsigned)i2 >= (unsigned)V) continue;
     float4 v0 = clip[i0], v1 = clip[i1], v2 = clip[i2];
@@ -393,7 +395,7 @@ __global__ __launch_bounds__(256) void raster_shade_kernel(
   const PoseRec &rec = recs[n];
   const float tpx = rec.pose[12], tpy = rec.pose[13], tpz = rec.pose[14];
   const float xs = 2.f / (float)CROP, xo = 1.f / (float)CROP - 1.f;
-  for (int i = tid; i < STRIP_ROWS * CROP; i += 256) {
+  for (int i = tid; i < STRIP_ROWS * CROP; i += NT) {
     int ly = i / CROP, px = i - ly * CROP, py = row0 + ly;
     unsigned color = ~(unsigned)(zbuf[i] & 0xFFFFFFFFull);
     int triIdx = (int)color - 1;
@@ -484,6 +486,11 @@ static void launch_raster_shade_t(hipStream_t s, const DeviceMesh &m, const Pose
   size_t lds = (size_t)STRIP_ROWS * CROP * sizeof(unsigned long long);
   dim3 grid(CROP / STRIP_ROWS, N), block(256);
   float downscale = m.diameter / 2;
+  if (STRIP_ROWS == 8 && N <= 4 && mode == OUT_F16X8 && !tri_id_dbg && !rast_dbg) {
+    hipLaunchKernelGGL((raster_shade_kernel<OUT_F16X8, STRIP_ROWS, 1024>), grid, dim3(1024), lds, s, m.faces, m.F, m.V, m.uvs,
+                       m.tex, m.TH, m.TW, downscale, recs, clip, attr, out, tri_id_dbg, rast_dbg);
+    return;
+  }
   if (mode == OUT_F32X6)
     hipLaunchKernelGGL((raster_shade_kernel<OUT_F32X6, STRIP_ROWS>), grid, block, lds, s, m.faces, m.F, m.V, m.uvs, m.tex,
                        m.TH, m.TW, downscale, recs, clip, attr, out, tri_id_dbg, rast_dbg);
