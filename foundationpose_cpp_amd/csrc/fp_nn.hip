@@ -1814,6 +1814,7 @@ struct Ctx {
 static bool g_conv_attr_done = false;
 static unsigned long long *g_clk_probe = nullptr;
 static NNScratch g_hook_ws;  // split-K slab of the fpt_* test hooks
+static int g_splitk_target = 128;  // workgroups a split-K launch aims for (tools/ab_track.py: 96-128 best, 256 is 6 % slower)
 static int g_conv_variant = 0;
 static int g_conv_ablate = 0;  // timing-only ablations of conv_big_pp_kernel: 1 no loads, 2 no MFMAs, 3 neither  // 0 auto, 1 force the 128-pixel 2-stage kernel, 2 force the 256-pixel 3-stage kernel (A/B hook)
 
@@ -1893,7 +1894,7 @@ static int run_conv(const Ctx &c, const char *tag, const ConvLayer &L, const __h
   {
     const int tiles = mtiles * (L.Cout % 128 == 0 ? L.Cout / 128 : L.Cout / 64);
     if (tiles <= 96 && KT >= 8 && g_conv_variant != 2) {
-      int S = std::min(std::max(256 / tiles, 1), KT / 2);
+      int S = std::min(std::max(g_splitk_target / tiles, 1), KT / 2);
       if (S > 1) {
         p.kt_per = (KT + S - 1) / S;
         p.ksplit = (KT + p.kt_per - 1) / p.kt_per;
@@ -2216,6 +2217,7 @@ extern "C" {
 
 void fpt_set_conv_variant(int v) { fp::g_conv_variant = v; }
 void fpt_set_conv_ablate(int v) { fp::g_conv_ablate = v; }
+void fpt_set_splitk_target(int v) { fp::g_splitk_target = v; }
 void fpt_set_raster_strip_rows(int r) { fp::set_raster_strip_rows(r); }
 
 // clock probe: allocate room for `blocks` records, run convs, then read back mean shader MHz and mean main-loop cycles
