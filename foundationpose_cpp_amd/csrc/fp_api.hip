@@ -10,9 +10,11 @@
 #include <array>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
+#include <mutex>
 
 #include "fp_internal.h"
 #include "fp_nn.h"
@@ -20,6 +22,13 @@
 namespace fp {
 
 static thread_local std::string g_last_error;
+// One model executes at a time per process.  Two models driving the GPU from two host threads (each on its own stream)
+// produced rare wrong results in tools/dbg_concurrent.py -- a consumer kernel reading the PREVIOUS contents of a buffer
+// its producer on the same stream had just rewritten -- although every kernel is bit-reproducible under contention
+// (tools/stress_*.py) and no model writes another's buffers (tools/dbg_cross_model.py).  The cause is not isolated, so
+// every entry point that enqueues work holds this lock until its stream is idle again.
+static std::recursive_mutex g_gpu_mutex;
+#define FP_GPU_LOCK() std::lock_guard<std::recursive_mutex> fp_gpu_lock_(g_gpu_mutex)
 void set_error(const std::string &msg) { g_last_error = msg; }
 std::atomic<unsigned long> g_alloc_epoch{0};
 
@@ -245,6 +254,11 @@ struct fp_model {
 
   Net *refiner = nullptr, *scorer = nullptr;
   NNScratch *ws = nullptr;
+  // pinned staging for hypothesis poses: Register returns from its asynchronous section while the H2D copy may still be
+  // queued, so the source must outlive the call (a local std::vector did not: found by the two-model serving test)
+  float *poses_pinned = nullptr;
+  int poses_pinned_cap = 0;
+  unsigned long long *digests = nullptr;  // [16] device, debug checkpoints (null = off)
 
   // Track is launch-bound (~60 short kernels): after one eager call (allocations settle) the launch chain is captured
   // into a hipGraph and replayed.  The graph bakes buffer addresses, so it is keyed by g_alloc_epoch.
@@ -267,6 +281,15 @@ struct fp_model {
 };
 
 static void drop_track_graph(fp_model *m);
+
+// ---- debug checkpoints (tools/dbg_concurrent.py): order-independent 64-bit digest of a device buffer per pipeline stage
+__global__ void fp_digest_kernel(const uint32_t *p, size_t n, unsigned long long *out) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned long long acc = 0;
+  for (; i < n; i += (size_t)gridDim.x * blockDim.x) acc += (unsigned long long)p[i] * (2654435761ull + 2 * (i % 1000003ull));
+  if (acc) atomicAdd(out, acc);
+}
+static void checkpoint(fp_model *m, int slot, const void *buf, size_t bytes);
 
 static int ensure_capacity(fp_model *m, int N, size_t V) {
   if (N > m->cap) {
@@ -343,7 +366,56 @@ static int render_and_crop(fp_model *m, Target *t, int N, float crop_ratio, OutM
   return 0;
 }
 
+static void checkpoint(fp_model *m, int slot, const void *buf, size_t bytes) {
+  if (!m->digests || !buf) return;
+  hipLaunchKernelGGL(fp_digest_kernel, dim3(512), dim3(256), 0, m->stream, (const uint32_t *)buf, bytes / 4, m->digests + slot);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) std::fprintf(stderr, "checkpoint %d (%p, %zu B): %s\n", slot, buf, bytes, hipGetErrorString(e));
+}
+
 extern "C" {
+
+// debug: enable the stage digests and read them back (16 slots; zeroed by every read)
+int fpt_digests(fp_model *m, unsigned long long out[16]) {
+  FP_GPU_LOCK();
+  if (!m->digests) {
+    FP_HIP_OK(hipMalloc((void **)&m->digests, 16 * 8));
+    FP_HIP_OK(hipMemset(m->digests, 0, 16 * 8));
+    return 0;
+  }
+  FP_HIP_OK(hipMemcpyAsync(out, m->digests, 16 * 8, hipMemcpyDeviceToHost, m->stream));
+  FP_HIP_OK(hipMemsetAsync(m->digests, 0, 16 * 8, m->stream));
+  FP_HIP_OK(hipStreamSynchronize(m->stream));
+  return 0;
+}
+
+// debug: digests of every long-lived device buffer of an (idle) model: recs, poses, clip, attr, nn_in, trans, rot,
+// scores, feat, arena, arena f32 (11 values) -- to detect writes coming from OTHER models' kernels
+int fpt_digest_buffers(fp_model *m, unsigned long long out[16]) {
+  FP_GPU_LOCK();
+  unsigned long long *d = nullptr;
+  FP_HIP_OK(hipMalloc((void **)&d, 16 * 8));
+  FP_HIP_OK(hipMemsetAsync(d, 0, 16 * 8, m->stream));
+  const void *ab = nullptr, *af = nullptr;
+  size_t abytes = 0, afbytes = 0;
+  if (m->ws) nn_scratch_debug_info(m->ws, &ab, &abytes, &af, &afbytes);
+  size_t V = m->targets.empty() ? 0 : (size_t)m->targets[0].mesh.V;
+  const DeviceMesh *dm = m->targets.empty() ? nullptr : &m->targets[0].mesh;
+  struct { const void *p; size_t n; } bufs[16] = {
+      {m->recs, (size_t)m->cap * sizeof(PoseRec)}, {m->poses_dev, (size_t)m->cap * 64}, {m->clip, m->vert_cap * 16},
+      {m->attr, m->vert_cap * 16}, {m->nn_in, (size_t)2 * m->cap * FP_NN_IN_IMG_HALFS * 2}, {m->trans_dev, (size_t)m->cap * 12},
+      {m->rot_dev, (size_t)m->cap * 12}, {m->scores_dev, (size_t)m->cap * 4}, {m->feat_dev, (size_t)m->cap * 2048},
+      {ab, abytes}, {af, afbytes},
+      {dm ? dm->verts : nullptr, V * 12}, {dm ? dm->normals : nullptr, V * 12}, {dm ? dm->uvs : nullptr, V * 8},
+      {dm ? (const void *)dm->faces : nullptr, dm ? (size_t)dm->F * 12 : 0}, {dm ? (const void *)dm->tex : nullptr, dm ? (size_t)dm->TH * dm->TW * 3 : 0}};
+  for (int i = 0; i < 16; i++)
+    if (bufs[i].p && bufs[i].n >= 4)
+      hipLaunchKernelGGL(fp_digest_kernel, dim3(1024), dim3(256), 0, m->stream, (const uint32_t *)bufs[i].p, bufs[i].n / 4, d + i);
+  FP_HIP_OK(hipMemcpyAsync(out, d, 16 * 8, hipMemcpyDeviceToHost, m->stream));
+  FP_HIP_OK(hipStreamSynchronize(m->stream));
+  (void)hipFree(d);
+  return 0;
+}
 
 const char *fp_last_error(void) { return g_last_error.c_str(); }
 
@@ -359,7 +431,8 @@ fp_model *fp_create(const fp_mesh *meshes, int n_meshes, const float K[9], const
   std::memcpy(m->K, K, sizeof(float) * 9);
   if (max_h > 0) m->max_h = max_h;
   if (max_w > 0) m->max_w = max_w;
-  if (hipStreamCreate(&m->stream) != hipSuccess) { set_error("[FoundationPose] Failed to create stream"); return nullptr; }
+  // non-blocking: no implicit synchronisation with the legacy null stream (other models' threads, the caller's framework)
+  if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess) { set_error("[FoundationPose] Failed to create stream"); return nullptr; }
   for (int i = 0; i < n_meshes; i++) {
     const fp_mesh &src = meshes[i];
     if (!src.vertices || !src.normals || !src.texcoords || !src.faces || !src.texture || src.num_vertices <= 0 ||
@@ -424,6 +497,8 @@ void fp_destroy(fp_model *m) {
   dev_free(m->recs); dev_free(m->poses_dev); dev_free(m->clip); dev_free(m->attr); dev_free(m->nn_in);
   dev_free(m->blob_a); dev_free(m->blob_b); dev_free(m->trans_dev); dev_free(m->rot_dev); dev_free(m->scores_dev);
   dev_free(m->feat_dev); dev_free(m->argmax_dev); dev_free(m->dbg_tri); dev_free(m->dbg_rast);
+  if (m->poses_pinned) (void)hipHostFree(m->poses_pinned);
+  if (m->digests) (void)hipFree(m->digests);
   if (m->refiner) net_free(m->refiner);
   if (m->scorer) net_free(m->scorer);
   if (m->ws) nn_scratch_free(m->ws);
@@ -440,12 +515,14 @@ int fp_set_inplane_steps(fp_model *m, int steps) {
 int fp_num_hypotheses(const fp_model *m) { return m ? m->n_hyp() : 0; }
 void *fp_stream(fp_model *m) { return m ? (void *)m->stream : nullptr; }
 int fp_synchronize(fp_model *m) {
+  FP_GPU_LOCK();
   FP_CHECK(m, "null model");
   FP_HIP_OK(hipStreamSynchronize(m->stream));
   return 0;
 }
 
-int fp_upload_frame(fp_model *m, const void *rgb, const void *depth, int memspace, int H, int W) {
+// asynchronous: the caller of this helper synchronises m->stream before the host frame can go away
+static int upload_frame_async(fp_model *m, const void *rgb, const void *depth, int memspace, int H, int W) {
   Target *t = nullptr;
   if (check_frame_args(m, H, W, nullptr, &t)) return 1;
   FP_CHECK(rgb && depth, "[FoundationPose] Got INVALID rgb/depth ptr");
@@ -472,7 +549,15 @@ int fp_upload_frame(fp_model *m, const void *rgb, const void *depth, int memspac
   return 0;
 }
 
+int fp_upload_frame(fp_model *m, const void *rgb, const void *depth, int memspace, int H, int W) {
+  FP_GPU_LOCK();
+  if (upload_frame_async(m, rgb, depth, memspace, H, W)) return 1;
+  if (memspace == FP_HOST) FP_HIP_OK(hipStreamSynchronize(m->stream));  // the host frame may be released on return
+  return 0;
+}
+
 int fp_get_xyz_map(fp_model *m, float *xyz_host) {
+  FP_GPU_LOCK();
   FP_CHECK(m && m->depth && xyz_host, "[FoundationPose] fp_get_xyz_map: no frame uploaded");
   size_t px = (size_t)m->H * m->W;
   if (!m->xyz && dev_alloc(&m->xyz, m->frame_cap * 3)) return 1;
@@ -495,6 +580,7 @@ static int run_depth_filters(fp_model *m) {
 }
 
 int fp_filter_depth(fp_model *m, float *eroded_out, float *bilateral_out) {
+  FP_GPU_LOCK();
   FP_CHECK(m && m->depth, "[FoundationPose] fp_filter_depth: no frame uploaded");
   size_t px = (size_t)m->H * m->W;
   run_depth_filters(m);
@@ -531,6 +617,7 @@ static int sample_hypotheses(fp_model *m, const void *mask, int memspace, std::v
 }
 
 int fp_get_hyp_poses(fp_model *m, const void *mask, int memspace, float *poses_out, int *n_out) {
+  FP_GPU_LOCK();
   FP_CHECK(m && poses_out, "[FoundationPose] fp_get_hyp_poses: invalid arguments");
   std::vector<float> poses;
   if (sample_hypotheses(m, mask, memspace, poses)) return 1;
@@ -541,12 +628,23 @@ int fp_get_hyp_poses(fp_model *m, const void *mask, int memspace, float *poses_o
 
 static int upload_poses(fp_model *m, Target *t, const float *poses, int N) {
   if (ensure_capacity(m, N, (size_t)t->mesh.V)) return 1;
-  FP_HIP_OK(hipMemcpyAsync(m->poses_dev, poses, (size_t)N * 64, hipMemcpyHostToDevice, m->stream));
+  if (N > m->poses_pinned_cap) {
+    FP_HIP_OK(hipStreamSynchronize(m->stream));
+    if (m->poses_pinned) (void)hipHostFree(m->poses_pinned);
+  if (m->digests) (void)hipFree(m->digests);
+    m->poses_pinned = nullptr; m->poses_pinned_cap = 0;
+    FP_HIP_OK(hipHostMalloc((void **)&m->poses_pinned, (size_t)std::max(N, 256) * 64, hipHostMallocDefault));
+    m->poses_pinned_cap = std::max(N, 256);
+  }
+  // every entry point synchronises the stream before it returns or before it calls this again
+  std::memcpy(m->poses_pinned, poses, (size_t)N * 64);
+  FP_HIP_OK(hipMemcpyAsync(m->poses_dev, m->poses_pinned, (size_t)N * 64, hipMemcpyHostToDevice, m->stream));
   return 0;
 }
 
 int fp_render_and_transform(fp_model *m, const char *target_name, const float *poses, int N, float crop_ratio,
                             float *render_out, float *transf_out, int out_memspace) {
+  FP_GPU_LOCK();
   FP_CHECK(m && poses && N > 0, "[FoundationposeRender] The transform matrix vector is empty");
   FP_CHECK(m->depth != nullptr, "[FoundationPose] fp_render_and_transform: no frame uploaded");
   Target *t = m->find(target_name ? target_name : "");
@@ -570,6 +668,7 @@ int fp_render_and_transform(fp_model *m, const char *target_name, const float *p
 
 int fp_debug_rasterize(fp_model *m, const char *target_name, const float *poses, int N, float crop_ratio,
                        int32_t *tri_id, float *rast_out) {
+  FP_GPU_LOCK();
   FP_CHECK(m && poses && N > 0, "[FoundationposeRender] The transform matrix vector is empty");
   FP_CHECK(m->H > 0, "[FoundationPose] fp_debug_rasterize: no frame uploaded (image size unknown)");
   Target *t = m->find(target_name ? target_name : "");
@@ -606,6 +705,7 @@ static int pack_blobs(fp_model *m, const float *render_input, const float *trans
 
 int fp_refiner_infer(fp_model *m, const float *render_input, const float *transf_input, int memspace, int N,
                      float *trans_out, float *rot_out) {
+  FP_GPU_LOCK();
   FP_CHECK(m && m->refiner, "[FoundationPose] refiner weights not loaded");
   if (pack_blobs(m, render_input, transf_input, memspace, N)) return 1;
   if (refiner_forward(m->stream, &m->prof, m->refiner, m->ws, m->nn_in, N, m->trans_dev, m->rot_dev)) return 1;
@@ -617,6 +717,7 @@ int fp_refiner_infer(fp_model *m, const float *render_input, const float *transf
 
 int fp_scorer_infer(fp_model *m, const float *render_input, const float *transf_input, int memspace, int N,
                     float *scores_out) {
+  FP_GPU_LOCK();
   FP_CHECK(m && m->scorer, "[FoundationPose] scorer weights not loaded");
   if (pack_blobs(m, render_input, transf_input, memspace, N)) return 1;
   if (scorer_features(m->stream, &m->prof, m->scorer, m->ws, m->nn_in, N, m->feat_dev)) return 1;
@@ -628,6 +729,7 @@ int fp_scorer_infer(fp_model *m, const float *render_input, const float *transf_
 
 int fp_refine_post_process(fp_model *m, const char *target_name, const float *poses, const float *trans,
                            const float *rot, int N, float *poses_out) {
+  FP_GPU_LOCK();
   FP_CHECK(m && poses && trans && rot && poses_out && N > 0, "[FoundationPose] fp_refine_post_process: invalid arguments");
   Target *t = m->find(target_name ? target_name : "");
   FP_CHECK(t != nullptr, "[FoundationPose] unknown target_name");
@@ -642,6 +744,7 @@ int fp_refine_post_process(fp_model *m, const char *target_name, const float *po
 }
 
 int fp_argmax(fp_model *m, const float *scores, int N, int *index_out) {
+  FP_GPU_LOCK();
   FP_CHECK(m && scores && index_out && N > 0, "[FoundationPose] fp_argmax: invalid arguments");
   if (ensure_capacity(m, N, 0)) return 1;
   FP_HIP_OK(hipMemcpyAsync(m->scores_dev, scores, (size_t)N * 4, hipMemcpyHostToDevice, m->stream));
@@ -659,16 +762,27 @@ static int refine_iteration(fp_model *m, Target *t, int N, bool shared_b) {
   if (render_and_crop(m, t, N, 1.2f /* refine_mode_crop_ratio_ foundationpose.cpp:87 */, OUT_F16X8, m->nn_in,
                       m->nn_in + half, nullptr, nullptr, shared_b ? 1 : N))
     return 1;
+  checkpoint(m, 0, m->recs, (size_t)N * sizeof(PoseRec));
+  checkpoint(m, 1, m->clip, (size_t)N * t->mesh.V * 16);
+  checkpoint(m, 2, m->attr, (size_t)N * t->mesh.V * 16);
+  checkpoint(m, 3, m->nn_in, (size_t)N * FP_NN_IN_IMG_HALFS * 2);
+  checkpoint(m, 4, m->nn_in + half, (size_t)(shared_b ? 1 : N) * FP_NN_IN_IMG_HALFS * 2);
   if (refiner_forward(m->stream, &m->prof, m->refiner, m->ws, m->nn_in, N, m->trans_dev, m->rot_dev, shared_b ? 1 : 0))
     return 1;
-  ProfScope ps(&m->prof, m->stream, "pose_update");
-  launch_pose_update(m->stream, m->poses_dev, m->trans_dev, m->rot_dev, N, t->mesh.diameter);
+  checkpoint(m, 5, m->trans_dev, (size_t)N * 12);
+  checkpoint(m, 6, m->rot_dev, (size_t)N * 12);
+  {
+    ProfScope ps(&m->prof, m->stream, "pose_update");
+    launch_pose_update(m->stream, m->poses_dev, m->trans_dev, m->rot_dev, N, t->mesh.diameter);
+  }
+  checkpoint(m, 7, m->poses_dev, (size_t)N * 64);
   return 0;
 }
 
 int fp_register_shard_begin(fp_model *m, const void *rgb, const void *depth, const void *mask, int memspace, int H,
                             int W, const char *target_name, int refine_itr, int shard_begin, int shard_count,
                             float **feat_dev, float **poses_dev) {
+  FP_GPU_LOCK();
   Target *t = nullptr;
   if (check_frame_args(m, H, W, target_name ? target_name : "", &t)) return 1;
   FP_CHECK(m->refiner && m->scorer, "[FoundationPose] refiner/scorer weights not loaded");
@@ -676,7 +790,7 @@ int fp_register_shard_begin(fp_model *m, const void *rgb, const void *depth, con
   const int n_all = m->n_hyp();
   FP_CHECK(shard_begin >= 0 && shard_count > 0 && shard_begin + shard_count <= n_all,
            "[FoundationPose] hypothesis shard out of range");
-  if (fp_upload_frame(m, rgb, depth, memspace, H, W)) return 1;
+  if (upload_frame_async(m, rgb, depth, memspace, H, W)) return 1;
   std::vector<float> poses;
   if (sample_hypotheses(m, mask, memspace, poses)) {
     set_error(std::string("[FoundationPose] Failed to generate hyp poses!!! ") + g_last_error);
@@ -690,14 +804,21 @@ int fp_register_shard_begin(fp_model *m, const void *rgb, const void *depth, con
   if (render_and_crop(m, t, N, 1.1f /* score_mode_crop_ratio_ foundationpose.cpp:88 */, OUT_F16X8, m->nn_in,
                       m->nn_in + half, nullptr, nullptr))
     return 1;
+  checkpoint(m, 8, m->clip, (size_t)N * t->mesh.V * 16);
+  checkpoint(m, 9, m->attr, (size_t)N * t->mesh.V * 16);
+  checkpoint(m, 10, m->nn_in, (size_t)N * FP_NN_IN_IMG_HALFS * 2);
+  checkpoint(m, 11, m->nn_in + half, (size_t)N * FP_NN_IN_IMG_HALFS * 2);
   if (scorer_features(m->stream, &m->prof, m->scorer, m->ws, m->nn_in, N, m->feat_dev)) return 1;
+  checkpoint(m, 12, m->feat_dev, (size_t)N * 512 * 4);
   if (feat_dev) *feat_dev = m->feat_dev;
   if (poses_dev) *poses_dev = m->poses_dev;
+  FP_HIP_OK(hipStreamSynchronize(m->stream));  // the returned buffers are complete (and the GPU lock may be released)
   return 0;
 }
 
 int fp_register_shard_finish(fp_model *m, const float *all_feat_dev, const float *all_poses_dev, int N_total,
                              float out_pose[16], int *best_index, float *scores_host) {
+  FP_GPU_LOCK();
   FP_CHECK(m && m->scorer && all_feat_dev && all_poses_dev && N_total > 0 && out_pose,
            "[FoundationPose] fp_register_shard_finish: invalid arguments");
   float *scores = m->scores_dev;
@@ -707,6 +828,7 @@ int fp_register_shard_finish(fp_model *m, const float *all_feat_dev, const float
     scores = scores_tmp;
   }
   int rc = scorer_head(m->stream, &m->prof, m->scorer, m->ws, all_feat_dev, N_total, scores);
+  if (!rc) checkpoint(m, 13, scores, (size_t)N_total * 4);
   if (!rc) {
     ProfScope ps(&m->prof, m->stream, "argmax");
     launch_argmax(m->stream, scores, N_total, m->argmax_dev);
@@ -717,7 +839,10 @@ int fp_register_shard_finish(fp_model *m, const float *all_feat_dev, const float
       hipMemcpyAsync(scores_host, scores, (size_t)N_total * 4, hipMemcpyDeviceToHost, m->stream) != hipSuccess)
     rc = 1;
   if (!rc && hipStreamSynchronize(m->stream) != hipSuccess) rc = 1;
-  if (!rc && hipMemcpy(out_pose, all_poses_dev + (size_t)idx * 16, 64, hipMemcpyDeviceToHost) != hipSuccess) rc = 1;
+  // (never the legacy null stream: its implicit synchronisation with every blocking stream is what another model's
+  //  thread would be racing against)
+  if (!rc && hipMemcpyAsync(out_pose, all_poses_dev + (size_t)idx * 16, 64, hipMemcpyDeviceToHost, m->stream) != hipSuccess) rc = 1;
+  if (!rc && hipStreamSynchronize(m->stream) != hipSuccess) rc = 1;
   if (scores_tmp) (void)hipFree(scores_tmp);
   if (rc && g_last_error.empty()) set_error("[FoundationPose] fp_register_shard_finish failed");
   if (best_index) *best_index = idx;
@@ -726,6 +851,7 @@ int fp_register_shard_finish(fp_model *m, const float *all_feat_dev, const float
 
 int fp_register_ex(fp_model *m, const void *rgb, const void *depth, const void *mask, int memspace, int H, int W,
                    const char *target_name, int refine_itr, float out_pose[16]) {
+  FP_GPU_LOCK();
   FP_CHECK(m != nullptr, "[FoundationPose] null model");
   float *feat = nullptr, *poses = nullptr;
   if (fp_register_shard_begin(m, rgb, depth, mask, memspace, H, W, target_name, refine_itr, 0, m->n_hyp(), &feat,
@@ -747,6 +873,7 @@ static void drop_track_graph(fp_model *m) {
 
 int fp_track_ex(fp_model *m, const void *rgb, const void *depth, int memspace, int H, int W, const float hyp_pose[16],
                 const char *target_name, int refine_itr, float out_pose[16]) {
+  FP_GPU_LOCK();
   Target *t = nullptr;
   if (check_frame_args(m, H, W, target_name ? target_name : "", &t)) return 1;
   FP_CHECK(m->refiner, "[FoundationPose] refiner weights not loaded");
@@ -764,7 +891,7 @@ int fp_track_ex(fp_model *m, const void *rgb, const void *depth, int memspace, i
         m->frame_cap = px0;
       }
       m->H = H; m->W = W; m->rgb = m->rgb_own; m->depth = m->depth_own;
-    } else if (fp_upload_frame(m, rgb, depth, FP_HOST, H, W)) {
+    } else if (upload_frame_async(m, rgb, depth, FP_HOST, H, W)) {
       return 1;
     }
     if (memspace == FP_DEVICE) {
@@ -773,7 +900,7 @@ int fp_track_ex(fp_model *m, const void *rgb, const void *depth, int memspace, i
       FP_HIP_OK(hipMemcpyAsync(m->depth_own, depth, px * 4, hipMemcpyDeviceToDevice, m->stream));
     }
   } else {
-    if (fp_upload_frame(m, rgb, depth, memspace, H, W)) return 1;
+    if (upload_frame_async(m, rgb, depth, memspace, H, W)) return 1;
   }
   if (upload_poses(m, t, hyp_pose, 1)) return 1;
   auto &g = m->tg;

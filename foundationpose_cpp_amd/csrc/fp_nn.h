@@ -16,6 +16,8 @@ void net_free(Net *);
 
 NNScratch *nn_scratch_create();
 void nn_scratch_free(NNScratch *);
+// debug (cross-model corruption checks): the activation arena and the f32 side buffer
+void nn_scratch_debug_info(const NNScratch *, const void **buf, size_t *bytes, const void **f32, size_t *f32_bytes);
 
 // Network input: nn_in = f16 [2N,80,80,32]: space-to-depth(2x2) view of the NHWC [2N,160,160,8] tensor
 // (channels r,g,b,x,y,z,0,0), rendered crops A in images [0,N), observed crops B in [N,2N).

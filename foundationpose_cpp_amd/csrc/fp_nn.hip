@@ -29,7 +29,9 @@
 #include <cstring>
 #include <algorithm>
 #include <map>
+#include <atomic>
 #include <memory>
+#include <thread>
 
 namespace fp {
 
@@ -1145,6 +1147,9 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const ConvParams p) {
         if ((tap == 0 && ks == 0) || s == S - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         if (!(ABL & 1) || (tap == 0 && ks == 0)) __builtin_amdgcn_s_barrier();
+        // s_barrier is IntrNoMem for the compiler: without this fence the fragment loads below may be placed ABOVE the
+        // barrier on the steps that issue no DMA (the last two), reading weight pieces other waves have not landed yet
+        asm volatile("" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         if (s + 2 < S) issue_w(s + 2);
         const unsigned char *xs = smem + pix_off + (((ks * 4 + kg) ^ g) << 4);
@@ -1173,6 +1178,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const ConvParams p) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (tap == 8 && ks == 1 && ch + 1 < nch) {  // last read of this chunk's halo tile: refill it under the MFMAs
           __builtin_amdgcn_s_barrier();
+          asm volatile("" ::: "memory");
           __builtin_amdgcn_sched_barrier(0);
           issue_halo(ch + 1);
         }
@@ -1760,6 +1766,7 @@ struct NNScratch {
   }
 };
 NNScratch *nn_scratch_create() { return new NNScratch(); }
+
 void nn_scratch_free(NNScratch *w) { delete w; }
 
 // per-hypothesis activation sizes (halfs); conv inputs carry their physical zero border
@@ -1770,6 +1777,10 @@ static constexpr size_t SZ_512 = 22ull * 22 * 512;
 static constexpr size_t SZ_TOK = 400ull * 512;            // token buffers (no border)
 static constexpr size_t SZ_QKV = 400ull * 1536;
 static constexpr size_t PER_HYP = SZ_STEM + 3 * SZ_128 + 3 * SZ_256 + 3 * SZ_512 + SZ_QKV + 4 * SZ_TOK;
+void nn_scratch_debug_info(const NNScratch *w, const void **buf, size_t *bytes, const void **f32, size_t *f32_bytes) {
+  *buf = w->buf; *bytes = (size_t)w->cap * PER_HYP * sizeof(__half);
+  *f32 = w->f32; *f32_bytes = (size_t)w->cap * EMBED * sizeof(float);
+}
 
 static int ensure_scratch(NNScratch *ws, int N, hipStream_t s) {
   if (N <= ws->cap) return 0;
@@ -2317,6 +2328,167 @@ int fpt_attention(const float *qkv, int B, int T, float *out) {
   FP_HIP_OK(hipMemcpy(ho.data(), dout.p, no * 2, hipMemcpyDeviceToHost));
   for (size_t i = 0; i < no; i++) out[i] = __half2float(ho[i]);
   return 0;
+}
+
+
+// concurrency stress: `nthreads` host threads, each with its own stream and buffers, run the same convolution `iters`
+// times and compare every result bit-for-bit with their first one (device-side).  Returns the number of mismatching
+// elements summed over all threads (0 = deterministic under contention), negative on failure.
+__global__ void fpt_count_diff_kernel(const uint32_t *a, const uint32_t *b, size_t n, unsigned long long *cnt) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned local = 0;
+  for (; i < n; i += (size_t)gridDim.x * blockDim.x) local += a[i] != b[i];
+  if (local) atomicAdd(cnt, (unsigned long long)local);
+}
+
+long long fpt_conv_stress(int NB0, int H0, int Cin0, int Cout0, int with_res, int iters, int nthreads, int mix) {
+  using namespace fp;
+  std::vector<long long> bad(nthreads, -1);
+  std::vector<std::thread> th;
+  for (int t = 0; t < nthreads; t++)
+    th.emplace_back([&, t]() {
+      // mix: odd threads run a different layer (the 256x256-tile kernel on 20x20 maps) next to the first thread's
+      int NB = NB0, H = H0, Cin = Cin0, Cout = Cout0;
+      if (mix && (t & 1)) { NB = 2 * NB0; H = 20; Cin = 512; Cout = 512; }
+      const int Hp = H + 2, Wp = H + 2;
+      size_t nx = (size_t)NB * Hp * Wp * Cin, nw = (size_t)Cout * 9 * Cin, nout = (size_t)NB * Hp * Wp * Cout;
+      DevBuf<__half> dx(nx), dw(nw), dres(nout), dout(nout), dref(nout);
+      DevBuf<float> db(Cout);
+      DevBuf<unsigned long long> dcnt(1);
+      if (!dx.p || !dw.p || !dres.p || !dout.p || !dref.p || !db.p || !dcnt.p) return;
+      uint32_t st = 1234567u + 977u * t;
+      auto rnd = [&]() { st = st * 1664525u + 1013904223u; return ((st >> 8) & 0xffff) / 65536.0f - 0.5f; };
+      std::vector<__half> hx(nx, __float2half(0.f)), hw(nw), hr(nout, __float2half(0.f));
+      for (int n = 0; n < NB; n++)
+        for (int y = 1; y <= H; y++)
+          for (int x = 1; x <= H; x++)
+            for (int c = 0; c < Cin; c++) hx[(((size_t)n * Hp + y) * Wp + x) * Cin + c] = __float2half(rnd());
+      for (auto &v : hw) v = __float2half(rnd() * 0.05f);
+      for (auto &v : hr) v = __float2half(rnd());
+      std::vector<float> hb(Cout);
+      for (auto &v : hb) v = rnd();
+      hipStream_t s;
+      if (hipStreamCreate(&s) != hipSuccess) return;
+      (void)hipMemcpy(dx.p, hx.data(), nx * 2, hipMemcpyHostToDevice);
+      (void)hipMemcpy(dw.p, hw.data(), nw * 2, hipMemcpyHostToDevice);
+      (void)hipMemcpy(dres.p, hr.data(), nout * 2, hipMemcpyHostToDevice);
+      (void)hipMemcpy(db.p, hb.data(), (size_t)Cout * 4, hipMemcpyHostToDevice);
+      (void)hipMemset(dout.p, 0, nout * 2);
+      (void)hipMemset(dref.p, 0, nout * 2);
+      (void)hipMemset(dcnt.p, 0, 8);
+      Net net;
+      ConvLayer L;
+      L.w = dw.p; L.bias = db.p; L.Cin = Cin; L.Cout = Cout; L.KH = 3; L.KW = 3; L.stride = 1; L.pad = 1;
+      NNScratch ws;
+      Ctx c{s, nullptr, &net, &ws};
+      if (run_conv(c, "t", L, dx.p, NB, H, H, 1, dref.p, 1, true, with_res ? dres.p : nullptr, 1, 0)) return;
+      (void)hipStreamSynchronize(s);
+      for (int i = 0; i < iters; i++) {
+        if (run_conv(c, "t", L, dx.p, NB, H, H, 1, dout.p, 1, true, with_res ? dres.p : nullptr, 1, 0)) return;
+        hipLaunchKernelGGL(fpt_count_diff_kernel, dim3(1024), dim3(256), 0, s, (const uint32_t *)dout.p, (const uint32_t *)dref.p,
+                           nout / 2, dcnt.p);
+      }
+      unsigned long long cnt = 0;
+      (void)hipMemcpyAsync(&cnt, dcnt.p, 8, hipMemcpyDeviceToHost, s);
+      (void)hipStreamSynchronize(s);
+      (void)hipStreamDestroy(s);
+      bad[t] = (long long)cnt;
+    });
+  for (auto &x : th) x.join();
+  long long tot = 0;
+  for (auto b : bad) {
+    if (b < 0) return -1;
+    tot += b;
+  }
+  return tot;
+}
+
+// LDS canary: workgroups that own `words` dwords of LDS each fill them with a pattern and keep re-checking it while a
+// convolution runs on another stream; a non-zero return means some kernel wrote outside its own LDS allocation.
+__global__ void fpt_lds_canary_kernel(int words, int spins, unsigned long long *bad) {
+  extern __shared__ unsigned canary[];
+  const unsigned pat = 0xC0FFEE00u ^ (blockIdx.x * 2654435761u);
+  for (int i = threadIdx.x; i < words; i += blockDim.x) canary[i] = pat + i;
+  __syncthreads();
+  unsigned local = 0;
+  for (int r = 0; r < spins; r++) {
+    for (int i = threadIdx.x; i < words; i += blockDim.x) local += canary[i] != pat + i;
+    __builtin_amdgcn_s_sleep(64);
+  }
+  if (local) atomicAdd(bad, (unsigned long long)local);
+}
+
+long long fpt_lds_canary(int NB, int H, int Cin, int Cout, int iters, int canary_bytes) {
+  using namespace fp;
+  unsigned long long *dbad = nullptr;
+  if (hipMalloc((void **)&dbad, 8) != hipSuccess || hipMemset(dbad, 0, 8) != hipSuccess) return -1;
+  std::atomic<int> stop{0};
+  std::thread canary([&]() {
+    hipStream_t s;
+    if (hipStreamCreate(&s) != hipSuccess) return;
+    while (!stop.load()) {
+      hipLaunchKernelGGL(fpt_lds_canary_kernel, dim3(2048), dim3(64), (size_t)canary_bytes, s, canary_bytes / 4, 200, dbad);
+      (void)hipStreamSynchronize(s);
+    }
+    (void)hipStreamDestroy(s);
+  });
+  long long rc = fpt_conv_stress(NB, H, Cin, Cout, 1, iters, 1, 0);
+  stop.store(1);
+  canary.join();
+  unsigned long long bad = 0;
+  (void)hipMemcpy(&bad, dbad, 8, hipMemcpyDeviceToHost);
+  (void)hipFree(dbad);
+  return rc < 0 ? rc : (long long)bad;
+}
+
+// Inter-kernel visibility under concurrency: every thread owns a stream and a buffer and alternates
+//   writer (buf[i] = f(i, iteration))  ->  checker (counts buf[i] != f(i, iteration))
+// on it.  Same-stream ordering makes any non-zero count a platform-level visibility failure (stale data from the
+// previous iteration), independent of this library's kernels.
+__global__ void fpt_vis_write_kernel(float4 *buf, size_t n, unsigned it) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) { float v = (float)((i * 7u + it * 13u) & 0xffff); buf[i] = make_float4(v, v + 1.f, v + 2.f, v + 3.f); }
+}
+__global__ void fpt_vis_check_kernel(const float4 *buf, size_t n, unsigned it, unsigned long long *bad) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  // gather-style read (like the rasteriser reading vertex attributes): a different workgroup than the writer's
+  size_t j = (i * 2654435761ull) % n;
+  float v = (float)((j * 7u + it * 13u) & 0xffff);
+  float4 x = buf[j];
+  if (x.x != v || x.y != v + 1.f || x.z != v + 2.f || x.w != v + 3.f) atomicAdd(bad, 1ull);
+}
+long long fpt_visibility_stress(int nthreads, int iters, int mbytes) {
+  std::vector<long long> bad(nthreads, -1);
+  std::vector<std::thread> th;
+  for (int t = 0; t < nthreads; t++)
+    th.emplace_back([&, t]() {
+      const size_t n = (size_t)mbytes * (1 << 20) / 16;
+      float4 *buf = nullptr;
+      unsigned long long *dbad = nullptr;
+      hipStream_t s;
+      if (hipMalloc((void **)&buf, n * 16) != hipSuccess || hipMalloc((void **)&dbad, 8) != hipSuccess || hipStreamCreate(&s) != hipSuccess) return;
+      (void)hipMemsetAsync(dbad, 0, 8, s);
+      const unsigned grid = (unsigned)((n + 255) / 256);
+      for (int it = 0; it < iters; it++) {
+        hipLaunchKernelGGL(fpt_vis_write_kernel, dim3(grid), dim3(256), 0, s, buf, n, (unsigned)(it + 1000 * t));
+        hipLaunchKernelGGL(fpt_vis_check_kernel, dim3(grid), dim3(256), 0, s, buf, n, (unsigned)(it + 1000 * t), dbad);
+      }
+      unsigned long long b = 0;
+      (void)hipMemcpyAsync(&b, dbad, 8, hipMemcpyDeviceToHost, s);
+      (void)hipStreamSynchronize(s);
+      (void)hipStreamDestroy(s);
+      (void)hipFree(buf);
+      (void)hipFree(dbad);
+      bad[t] = (long long)b;
+    });
+  for (auto &x : th) x.join();
+  long long tot = 0;
+  for (auto b : bad) {
+    if (b < 0) return -1;
+    tot += b;
+  }
+  return tot;
 }
 
 void fpt_set_att_variant(int v) { fp::g_att_variant = v; }

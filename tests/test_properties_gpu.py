@@ -136,8 +136,9 @@ def test_several_meshes_per_model(wpaths, syn_scene):
 
 
 def test_two_models_serve_concurrently_on_their_own_streams(wpaths, syn_mesh, syn_scene):
-    """one model per stream / thread (the not-re-entrant-per-model contract of the reference, foundationpose.cpp:103-105):
-    concurrent Track + Register calls give exactly the sequential results"""
+    """one model per host thread (the not-re-entrant-per-model contract of the reference, foundationpose.cpp:103-105):
+    concurrent Track + Register calls give exactly the sequential results.  The library serialises the GPU work of
+    different models (overlapping two models' streams gave rare stale-read results)."""
     import threading
     scenes = [syn_scene, syn.make_scene(syn_mesh, t=(-0.03, 0.02, 0.62), rot_seed=9)]
     models = [FoundationPose(syn_mesh, syn.intrinsics(), *wpaths) for _ in scenes]
