@@ -457,6 +457,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm3_kernel(const ConvParams p)
   for (int kt = 0; kt < KT - 2; kt++) {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");  // tile kt landed (this wave's pieces); tile kt+1 in flight
     __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");  // s_barrier is IntrNoMem: keep LDS accesses on their side of it
     stage(kt + 2, wb3);
     compute(rb);
     rb = (rb == 2) ? 0 : rb + 1;
@@ -464,10 +465,12 @@ __global__ __launch_bounds__(512, 2) void conv_igemm3_kernel(const ConvParams p)
   }
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");
   __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");  // s_barrier is IntrNoMem: keep LDS accesses on their side of it
   compute(rb);
   rb = (rb == 2) ? 0 : rb + 1;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");  // s_barrier is IntrNoMem: keep LDS accesses on their side of it
   compute(rb);
   if (p.clk && tid == 0) { p.clk[blockIdx.x * 4 + 2] = __builtin_readcyclecounter(); p.clk[blockIdx.x * 4 + 3] = wall_clock64(); }
 
@@ -582,6 +585,7 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvParams p) {
 #define FP_PP_BARRIER()                  \
   do {                                   \
     __builtin_amdgcn_s_barrier();        \
+    asm volatile("" ::: "memory");      \
     __builtin_amdgcn_sched_barrier(0);   \
   } while (0)
 
@@ -727,12 +731,14 @@ __global__ __launch_bounds__(512, 2) void conv_big_kernel(const ConvParams p) {
   stage(0, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");  // s_barrier is IntrNoMem: keep LDS accesses on their side of it
   int buf = 0;
   for (int kt = 0; kt < KT - 1; kt++) {
     stage(kt + 1, buf ^ 1);
     compute(buf);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");  // s_barrier is IntrNoMem: keep LDS accesses on their side of it
     buf ^= 1;
   }
   compute(buf);
@@ -838,6 +844,7 @@ __global__ __launch_bounds__(512, 2) void conv_big_pp_kernel(const ConvParams p)
 #define FP_BAR()                         \
   do {                                   \
     __builtin_amdgcn_s_barrier();        \
+    asm volatile("" ::: "memory");      \
     __builtin_amdgcn_sched_barrier(0);   \
   } while (0)
 #define FP_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
@@ -994,6 +1001,7 @@ __global__ __launch_bounds__(512, 2) void conv_pp32_kernel(const ConvParams p) {
 #define FP_BAR()                         \
   do {                                   \
     __builtin_amdgcn_s_barrier();        \
+    asm volatile("" ::: "memory");      \
     __builtin_amdgcn_sched_barrier(0);   \
   } while (0)
 #define FP_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
