@@ -249,6 +249,8 @@ struct fp_model {
   float *blob_a = nullptr, *blob_b = nullptr;  // [cap,160,160,6] f32 (blob-mode entry points only)
   float *trans_dev = nullptr, *rot_dev = nullptr, *scores_dev = nullptr, *feat_dev = nullptr;
   int *argmax_dev = nullptr;
+  float *scores_all = nullptr;  // scores of the gathered hypotheses of every rank (sharded Register)
+  int scores_all_cap = 0;
   int32_t *dbg_tri = nullptr;
   float *dbg_rast = nullptr;
 
@@ -496,7 +498,7 @@ void fp_destroy(fp_model *m) {
   dev_free(m->rgb_own); dev_free(m->depth_own); dev_free(m->erode); dev_free(m->bilat); dev_free(m->xyz);
   dev_free(m->recs); dev_free(m->poses_dev); dev_free(m->clip); dev_free(m->attr); dev_free(m->nn_in);
   dev_free(m->blob_a); dev_free(m->blob_b); dev_free(m->trans_dev); dev_free(m->rot_dev); dev_free(m->scores_dev);
-  dev_free(m->feat_dev); dev_free(m->argmax_dev); dev_free(m->dbg_tri); dev_free(m->dbg_rast);
+  dev_free(m->feat_dev); dev_free(m->argmax_dev); dev_free(m->scores_all); dev_free(m->dbg_tri); dev_free(m->dbg_rast);
   if (m->poses_pinned) (void)hipHostFree(m->poses_pinned);
   if (m->digests) (void)hipFree(m->digests);
   if (m->refiner) net_free(m->refiner);
@@ -822,10 +824,14 @@ int fp_register_shard_finish(fp_model *m, const float *all_feat_dev, const float
   FP_CHECK(m && m->scorer && all_feat_dev && all_poses_dev && N_total > 0 && out_pose,
            "[FoundationPose] fp_register_shard_finish: invalid arguments");
   float *scores = m->scores_dev;
-  float *scores_tmp = nullptr;
-  if (N_total > m->cap) {
-    if (dev_alloc(&scores_tmp, (size_t)N_total)) return 1;
-    scores = scores_tmp;
+  if (N_total > m->cap) {  // gathered hypotheses of all ranks: a persistent buffer, not a malloc/free per Register
+    if (N_total > m->scores_all_cap) {
+      dev_free(m->scores_all);
+      m->scores_all_cap = 0;
+      if (dev_alloc(&m->scores_all, (size_t)N_total)) return 1;
+      m->scores_all_cap = N_total;
+    }
+    scores = m->scores_all;
   }
   int rc = scorer_head(m->stream, &m->prof, m->scorer, m->ws, all_feat_dev, N_total, scores);
   if (!rc) checkpoint(m, 13, scores, (size_t)N_total * 4);
@@ -843,7 +849,6 @@ int fp_register_shard_finish(fp_model *m, const float *all_feat_dev, const float
   //  thread would be racing against)
   if (!rc && hipMemcpyAsync(out_pose, all_poses_dev + (size_t)idx * 16, 64, hipMemcpyDeviceToHost, m->stream) != hipSuccess) rc = 1;
   if (!rc && hipStreamSynchronize(m->stream) != hipSuccess) rc = 1;
-  if (scores_tmp) (void)hipFree(scores_tmp);
   if (rc && g_last_error.empty()) set_error("[FoundationPose] fp_register_shard_finish failed");
   if (best_index) *best_index = idx;
   return rc;
