@@ -74,7 +74,7 @@ struct ConvParams {
   unsigned koff32[160];  // same per 32-wide K-step (conv_pp32_kernel)
   int m_begin;            // first output row handled by this launch (hybrid 256^2 + 128^2 launches)
   int ksplit, kt_per;     // split-K (small problems): K-steps [split*kt_per, ...) per workgroup, fp32 partial slabs
-  float *partial;         // [ksplit][M][Cout]
+  float *partial;         // [ksplit][M - m_begin][Cout]
   unsigned long long *clk;  // optional clock probe: per block {cycles0, realtime0, cycles1, realtime1}
 };
 
@@ -172,7 +172,7 @@ __device__ __forceinline__ void conv_store_partial(const ConvParams &p, f4 (&acc
   for (int mi = 0; mi < MI; mi++) {
     int m = m_base + mi * 16 + (lane & 15);
     if (m >= p.M) continue;
-    float *dst = p.partial + ((size_t)split * p.M + m) * p.Cout + n_base;
+    float *dst = p.partial + ((size_t)split * (p.M - p.m_begin) + (m - p.m_begin)) * p.Cout + n_base;
 #pragma unroll
     for (int jj = 0; jj < 4; jj++) {
       if (NI == 4) {
@@ -1215,10 +1215,12 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const ConvParams p) {
 __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvParams p) {
   const int nq = p.Cout / 4;
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (size_t)p.M * nq) return;
-  const int m = (int)(i / nq), n = (int)(i - (size_t)m * nq) * 4;
-  f4 a = *reinterpret_cast<const f4 *>(p.partial + (size_t)m * p.Cout + n);
-  for (int sp = 1; sp < p.ksplit; sp++) a += *reinterpret_cast<const f4 *>(p.partial + ((size_t)sp * p.M + m) * p.Cout + n);
+  const int rows = p.M - p.m_begin;
+  if (i >= (size_t)rows * nq) return;
+  const int mr = (int)(i / nq), n = (int)(i - (size_t)mr * nq) * 4;
+  const int m = p.m_begin + mr;
+  f4 a = *reinterpret_cast<const f4 *>(p.partial + (size_t)mr * p.Cout + n);
+  for (int sp = 1; sp < p.ksplit; sp++) a += *reinterpret_cast<const f4 *>(p.partial + ((size_t)sp * rows + mr) * p.Cout + n);
   float4 bv = *reinterpret_cast<const float4 *>(p.bias + n);
   float v0 = a[0] + bv.x, v1 = a[1] + bv.y, v2 = a[2] + bv.z, v3 = a[3] + bv.w;
   const int ohw = p.OH * p.OW;
@@ -1833,6 +1835,9 @@ struct Ctx {
 static bool g_conv_attr_done = false;
 static unsigned long long *g_clk_probe = nullptr;
 static NNScratch g_hook_ws;  // split-K slab of the fpt_* test hooks
+static int g_rem_splitk = 0;     // A/B hook: split-K for the rows a 256x256 / 512x128 launch leaves over.  Measured -0.1 ms per
+                                 // Register, but OFF: a row's fp32 summation order would then depend on where it falls in the
+                                 // batch, and sharded and unsharded Register must pick the same near-tied winner
 static int g_splitk_target = 128;  // workgroups a split-K launch aims for (tools/ab_track.py: 96-128 best, 256 is 6 % slower)
 static int g_conv_variant = 0;
 static int g_conv_ablate = 0;  // timing-only ablations of conv_big_pp_kernel: 1 no loads, 2 no MFMAs, 3 neither  // 0 auto, 1 force the 128-pixel 2-stage kernel, 2 force the 256-pixel 3-stage kernel (A/B hook)
@@ -1910,33 +1915,35 @@ static int run_conv(const Ctx &c, const char *tag, const ConvLayer &L, const __h
   // split-K for small problems (Track, N <= ~8): a 128x128 tile count far below the 512 workgroup slots of the chip
   // would leave most CUs idle while a few walk up to 72 K-steps; give every CU a slice instead
   p.ksplit = 1; p.kt_per = KT; p.partial = nullptr;
-  {
-    const int tiles = mtiles * (L.Cout % 128 == 0 ? L.Cout / 128 : L.Cout / 64);
-    if (tiles <= 96 && KT >= 8 && g_conv_variant != 2) {
-      int S = std::min(std::max(g_splitk_target / tiles, 1), KT / 2);
-      if (S > 1) {
-        p.kt_per = (KT + S - 1) / S;
-        p.ksplit = (KT + p.kt_per - 1) / p.kt_per;
-        size_t need = (size_t)p.ksplit * p.M * p.Cout;
-        NNScratch *sk = c.ws ? c.ws : &g_hook_ws;
-        if (need > sk->splitk_cap) {
-          if (sk->splitk) (void)hipFree(sk->splitk);
-          sk->splitk = nullptr; sk->splitk_cap = 0;
-          g_alloc_epoch++;
-          FP_HIP_OK(hipMalloc((void **)&sk->splitk, need * sizeof(float)));
-          sk->splitk_cap = need;
-        }
-        p.partial = sk->splitk;
-      }
+  p.m_begin = 0;
+  // (also used for the rows a 256x256 / 512x128 launch leaves over: `target` workgroups on an otherwise idle chip)
+  auto plan_splitk = [&](int rows, int target) -> int {
+    const int mt = (rows + 127) / 128;
+    const int tiles = mt * (L.Cout % 128 == 0 ? L.Cout / 128 : L.Cout / 64);
+    if (tiles > 96 || KT < 8 || g_conv_variant == 2) return 0;
+    int S = std::min(std::max(target / tiles, 1), KT / 2);
+    if (S <= 1) return 0;
+    p.kt_per = (KT + S - 1) / S;
+    p.ksplit = (KT + p.kt_per - 1) / p.kt_per;
+    size_t need = (size_t)p.ksplit * rows * p.Cout;
+    NNScratch *sk = c.ws ? c.ws : &g_hook_ws;
+    if (need > sk->splitk_cap) {
+      if (sk->splitk) (void)hipFree(sk->splitk);
+      sk->splitk = nullptr; sk->splitk_cap = 0;
+      g_alloc_epoch++;
+      FP_HIP_OK(hipMalloc((void **)&sk->splitk, need * sizeof(float)));
+      sk->splitk_cap = need;
     }
-  }
+    p.partial = sk->splitk;
+    return 0;
+  };
+  if (plan_splitk(p.M, g_splitk_target)) return 1;
   const std::string tg(tag);
   // large problems: 256-pixel tiles, 3-stage LDS-DMA pipeline (needs >= 3 K-steps and enough tiles to fill 256 CUs)
   const int big_tiles = ((p.M + 255) / 256) * (L.Cout % 128 == 0 ? L.Cout / 128 : L.Cout / 64);
   (void)big_tiles;
   // measured (tools/bench_conv.py, N=126): the 128-px 2-stage kernel beats the 256-px 3-stage one on every layer
   // (756-769 vs 703-709 TF/s weighted), so the latter is only reachable through the A/B hook
-  p.m_begin = 0;
   if ((g_conv_variant == 7 || g_conv_variant == 0) && L.KH == 3 && L.KW == 3 && L.stride == 1 && L.pad == 1 && ipad == 1 && W == 40 && H % 8 == 0 &&
       L.Cin % 64 == 0 && L.Cout % 128 == 0 && p.ksplit == 1 &&
       (g_conv_variant == 7 || NB * (H / 8) * (L.Cout / 128) >= 300)) {  // measured crossover vs the implicit-GEMM tiles: ~32 hypotheses
@@ -1970,6 +1977,7 @@ static int run_conv(const Ctx &c, const char *tag, const ConvLayer &L, const __h
       p.m_begin = mt_big * bm;
       if (p.m_begin >= p.M) return 0;
       mtiles = (p.M - p.m_begin + 127) / 128;
+      if (g_rem_splitk && plan_splitk(p.M - p.m_begin, 384)) return 1;
     }
   }
   if ((g_conv_variant == 4 || g_conv_variant == 5 || g_conv_variant == 0 || g_conv_variant == 8) && L.Cout % 256 == 0 && p.ksplit == 1 && KT >= 2) {
@@ -1997,6 +2005,7 @@ static int run_conv(const Ctx &c, const char *tag, const ConvLayer &L, const __h
       p.m_begin = mt_big * 256;
       if (p.m_begin >= p.M) return 0;
       mtiles = (p.M - p.m_begin + 127) / 128;
+      if (g_rem_splitk && plan_splitk(p.M - p.m_begin, 384)) return 1;
     }
   }
   if (g_conv_variant == 3 && KT >= 3 && p.ksplit == 1) {
@@ -2037,7 +2046,7 @@ static int run_conv(const Ctx &c, const char *tag, const ConvLayer &L, const __h
   }
   if (p.ksplit > 1) {
     ProfScope ps(c.prof, c.s, (tg + "/conv_splitk_reduce_kernel").c_str(), 0, 0);
-    size_t quads = (size_t)p.M * (p.Cout / 4);
+    size_t quads = (size_t)(p.M - p.m_begin) * (p.Cout / 4);
     hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, c.s, p);
   }
   return 0;
@@ -2237,6 +2246,7 @@ extern "C" {
 void fpt_set_conv_variant(int v) { fp::g_conv_variant = v; }
 void fpt_set_conv_ablate(int v) { fp::g_conv_ablate = v; }
 void fpt_set_splitk_target(int v) { fp::g_splitk_target = v; }
+void fpt_set_rem_splitk(int v) { fp::g_rem_splitk = v; }
 void fpt_set_raster_strip_rows(int r) { fp::set_raster_strip_rows(r); }
 
 // clock probe: allocate room for `blocks` records, run convs, then read back mean shader MHz and mean main-loop cycles
