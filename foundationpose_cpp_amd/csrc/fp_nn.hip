@@ -1211,6 +1211,115 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const ConvParams p) {
   });
 }
 
+// -------------------------------------------------------------------------------------------------
+// conv_stem_halo_kernel: the space-to-depth stem (4x4 taps, stride 1, 32 -> 64 channels, 84x84 padded input -> 80x80)
+// with the same resident-halo scheme as conv_halo_kernel.  The implicit-GEMM stem re-fetched every 64-byte input pixel
+// once per tap (16x) for a 128x64 tile and ran at ~365 TFLOP/s of padded work, bound by the global -> LDS path.
+//   tile = 8 rows x 80 cols (640 px) x all 64 channels; 4 waves split the pixels (block-row x column half), 160
+//   accumulators each; halo tile = (8+3) padded rows x 84 px x 64 B = one linear run of 59 KB staged once; 16 K-steps
+//   (one tap each, 32 channels); weights 4 KB per step through a 3-stage ring; two workgroups per CU.
+//   64-byte pixel rows: 16-byte slot = chunk ^ (y & 3); conflict-free because the pitch (84) is a multiple of 4.
+// -------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void conv_stem_halo_kernel(const ConvParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int TW = 80, TH = 8, HC = 84, HPX = (TH + 3) * HC;
+  constexpr int HPIECES = (HPX + 15) / 16, HALO_B = HPIECES * 1024;
+  constexpr int HPER = (HPIECES + 3) / 4;
+  constexpr int WST = 64 * 64, NWST = 3;
+  constexpr int MI = TW / 8, NI = 4, HM = MI / 2;  // 10 fragments (4x4 pixel blocks) per wave, in two halves
+  constexpr int S = 16;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int brow = wave >> 1, chalf = wave & 1;
+  int logical;
+  {
+    const int nblk = gridDim.x, b = blockIdx.x;
+    const int xcd = b & 7, within = b >> 3, q = nblk >> 3, r = nblk & 7;
+    logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
+  }
+  const int tiles_per_img = p.H / TH;
+  const int img = logical / tiles_per_img, ty0 = (logical - img * tiles_per_img) * TH;
+
+  const unsigned char *in_b = reinterpret_cast<const unsigned char *>(p.in) + ((size_t)(img * HC + ty0) * HC) * 64;
+  const unsigned char *w_b = reinterpret_cast<const unsigned char *>(p.w);
+  const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
+  const unsigned w_lds = lds_base + HALO_B;
+
+  {  // halo DMA: piece = wave + 4*i covers 16 halo pixels; lane -> (pixel = lane>>2, slot = lane&3)
+#pragma unroll
+    for (int i = 0; i < HPER; i++) {
+      const int piece = wave + 4 * i;
+      if (piece < HPIECES) {
+        int q = min(piece * 16 + (lane >> 2), HPX - 1);
+        int hy = q / HC;
+        unsigned off = (unsigned)(q * 64 + (((lane & 3) ^ (hy & 3)) << 4));
+        glds16_asm(in_b + off, lds_base + piece * 1024);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+  const int prow = lane >> 2;
+  const int gch = (lane & 3) ^ ((0x78 >> (((prow >> 2) & 3) * 2)) & 3);
+  const unsigned woff = (unsigned)((wave * 16 + prow) * p.Ktot + gch * 8) * 2u;
+  auto issue_w = [&](int st) { glds16_asm(w_b + (size_t)st * 64 + woff, w_lds + (st % NWST) * WST + wave * 1024); };
+
+  f4 acc[NI][MI];
+#pragma unroll
+  for (int a = 0; a < NI; a++)
+#pragma unroll
+    for (int b = 0; b < MI; b++) acc[a][b] = (f4){0.f, 0.f, 0.f, 0.f};
+
+  const int li = lane & 15, dy = li >> 2, dx = li & 3, kg = lane >> 4;
+  const int fslot = kg ^ ((0x78 >> ((li >> 2) * 2)) & 3);
+  const int wfo = HALO_B + li * 64 + fslot * 16;
+
+  issue_w(0);
+  issue_w(1);
+#pragma unroll 1
+  for (int s = 0; s < S; s++) {
+    const int ky = s >> 2, kx = s & 3;
+    const int ty = brow * 4 + dy + ky, tx = chalf * (TW / 2) + dx + kx;
+    if (s == 0 || s == S - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    if (s + 2 < S) issue_w(s + 2);
+    const unsigned char *xs = smem + (ty * HC + tx) * 64 + ((kg ^ (ty & 3)) << 4);
+    const unsigned char *ws = smem + wfo + (s % NWST) * WST;
+    h8 xf[HM], wf[NI];
+#pragma unroll
+    for (int ni = 0; ni < NI; ni++) wf[ni] = *reinterpret_cast<const h8 *>(ws + ni * 16 * 64);
+#pragma unroll
+    for (int mi = 0; mi < HM; mi++) xf[mi] = *reinterpret_cast<const h8 *>(xs + mi * 256);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int ni = 0; ni < NI; ni++)
+#pragma unroll
+      for (int mi = 0; mi < HM; mi++)
+        acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ni], xf[mi], acc[ni][mi], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int mi = 0; mi < HM; mi++) xf[mi] = *reinterpret_cast<const h8 *>(xs + (HM + mi) * 256);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int ni = 0; ni < NI; ni++)
+#pragma unroll
+      for (int mi = 0; mi < HM; mi++)
+        acc[ni][HM + mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ni], xf[mi], acc[ni][HM + mi], 0, 0, 0);
+  }
+  // Cout = 64: weight rows are permuted in 32-channel blocks (NI = 2 form), so the epilogue runs once per block
+  auto pix = [&](int mi, int &oimg, int &oh, int &ow) {
+    oimg = img;
+    oh = ty0 + brow * 4 + dy;
+    ow = chalf * (TW / 2) + mi * 4 + dx;
+    return true;
+  };
+  conv_epilogue_px<MI, 2>(p, reinterpret_cast<f4(&)[2][MI]>(acc[0]), 0, lane, pix);
+  conv_epilogue_px<MI, 2>(p, reinterpret_cast<f4(&)[2][MI]>(acc[2]), 32, lane, pix);
+}
+
 // split-K reduction + the conv epilogue: out = relu(sum_s partial[s] + bias + res); thread = (pixel, 4 channels)
 __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvParams p) {
   const int nq = p.Cout / 4;
@@ -1881,6 +1990,7 @@ static int run_conv(const Ctx &c, const char *tag, const ConvLayer &L, const __h
   double bytes = ((double)NB * H * W * L.Cin + (double)p.M * p.Cout * (res ? 2 : 1) + (double)p.Cout * p.Ktot) * 2.0;
   constexpr int LDS3_128 = 3 * (256 * 128 + 128 * 128), LDS3_64 = 3 * (256 * 128 + 64 * 128);
   constexpr int LDS_HALO40 = ((10 * 42 + 7) / 8) * 1024 + 3 * 128 * 64;
+  constexpr int LDS_STEM_HALO = ((11 * 84 + 15) / 16) * 1024 + 3 * 64 * 64;
   if (!g_conv_attr_done) {
     FP_HIP_OK(hipFuncSetAttribute((const void *)conv_igemm_kernel<128, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (128 * 128 + 128 * 128)));
     FP_HIP_OK(hipFuncSetAttribute((const void *)conv_igemm_kernel<128, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (128 * 128 + 128 * 128)));
@@ -1902,6 +2012,7 @@ static int run_conv(const Ctx &c, const char *tag, const ConvLayer &L, const __h
     FP_HIP_OK(hipFuncSetAttribute((const void *)conv_big_pp_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 * 128 + 256 * 128)));
     FP_HIP_OK(hipFuncSetAttribute((const void *)conv_big_pp_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 * 128 + 256 * 128)));
     FP_HIP_OK(hipFuncSetAttribute((const void *)conv_big_pp_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 * 128 + 256 * 128)));
+    FP_HIP_OK(hipFuncSetAttribute((const void *)conv_stem_halo_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_STEM_HALO));
     FP_HIP_OK(hipFuncSetAttribute((const void *)conv_halo_kernel<40, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_HALO40));
     FP_HIP_OK(hipFuncSetAttribute((const void *)conv_halo_kernel<40, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_HALO40));
     FP_HIP_OK(hipFuncSetAttribute((const void *)conv_halo_kernel<40, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_HALO40));
@@ -1944,6 +2055,12 @@ static int run_conv(const Ctx &c, const char *tag, const ConvLayer &L, const __h
   (void)big_tiles;
   // measured (tools/bench_conv.py, N=126): the 128-px 2-stage kernel beats the 256-px 3-stage one on every layer
   // (756-769 vs 703-709 TF/s weighted), so the latter is only reachable through the A/B hook
+  if ((g_conv_variant == 7 || g_conv_variant == 0) && L.Cin == 32 && L.KH == 4 && L.KW == 4 && L.Cout == 64 && ipad == 2 && W == 80 &&
+      H == 80 && p.ksplit == 1 && res == nullptr && split_imgs == 0 && (g_conv_variant == 7 || NB * 10 >= 300)) {
+    ProfScope ps(c.prof, c.s, (tg + "/conv_stem_halo_kernel").c_str(), flops, bytes);
+    hipLaunchKernelGGL(conv_stem_halo_kernel, dim3(NB * 10), dim3(256), LDS_STEM_HALO, c.s, p);
+    return 0;
+  }
   if ((g_conv_variant == 7 || g_conv_variant == 0) && L.KH == 3 && L.KW == 3 && L.stride == 1 && L.pad == 1 && ipad == 1 && W == 40 && H % 8 == 0 &&
       L.Cin % 64 == 0 && L.Cout % 128 == 0 && p.ksplit == 1 &&
       (g_conv_variant == 7 || NB * (H / 8) * (L.Cout / 128) >= 300)) {  // measured crossover vs the implicit-GEMM tiles: ~32 hypotheses
