@@ -1355,6 +1355,7 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvParam
 // attention: out[b,t,h*128+d] = softmax_k(q.k/sqrt(128)) v,  qkv = [B,T,1536] (q|k|v, heads contiguous inside each)
 // =================================================================================================
 
+// (a 64-key-block variant of this kernel measured 6 % slower inside Register and was dropped)
 // ATT_QROWS query rows per workgroup (64 = 4 waves, one per SIMD; 80-row / 5-wave tiles cover 400 tokens exactly but
 // measured 12 % slower: two waves of a workgroup share a SIMD).  The 1-D grid is remapped so the query
 // tiles of one (image, head) run on the SAME XCD and share its L2 copy of K/V (a (qt,h,b) grid spread them over all 8
@@ -1461,14 +1462,21 @@ __global__ __launch_bounds__(ATT_QROWS * 4) void attention_kernel(const __half *
     psum += __shfl_xor(psum, 32);
     l_run = l_run * alpha + psum;
     m_run = m_new;
-    // rescale O rows (row q' = g*4 + r lives in lanes with li == q')
-    float ar[4];
+    // rescale O rows (row q' = g*4 + r lives in lanes with li == q') -- only when some row's running maximum moved:
+    // after the first key blocks alpha is exactly 1 for every row most of the time, and the 32 multiplies + 4 shuffles
+    // per block made this kernel VALU-bound (x * 1.0f is exact, so skipping it changes nothing)
+    const bool rescale = __any(alpha != 1.0f);
+    if (rescale) {
+      float ar[4];
 #pragma unroll
-    for (int r = 0; r < 4; r++) ar[r] = __shfl(alpha, g * 4 + r);
+      for (int r = 0; r < 4; r++) ar[r] = __shfl(alpha, g * 4 + r);
+#pragma unroll
+      for (int dt = 0; dt < 8; dt++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) o[dt][r] *= ar[r];
+    }
 #pragma unroll
     for (int dt = 0; dt < 8; dt++) {
-#pragma unroll
-      for (int r = 0; r < 4; r++) o[dt][r] *= ar[r];
       // V^T fragment: col li of tile dt is d = li*8 + dt; k-slots 0..3 -> keys g*4.., 4..7 -> keys 16+g*4..
       h4 v0 = *reinterpret_cast<const h4 *>(&Vt[(dt * 16 + li) * VS + g * 4]);
       h4 v1 = *reinterpret_cast<const h4 *>(&Vt[(dt * 16 + li) * VS + 16 + g * 4]);
