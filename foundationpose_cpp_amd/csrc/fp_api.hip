@@ -235,8 +235,10 @@ struct fp_model {
   const uint8_t *rgb = nullptr;   // device
   const float *depth = nullptr;   // device
   float *erode = nullptr, *bilat = nullptr, *xyz = nullptr;
-  std::vector<float> bilat_host;
-  std::vector<uint8_t> mask_host;
+  // pinned read-back buffers of the sampler (pageable destinations made the 1.2 MB D2H take up to 1.5 ms on early calls)
+  float *bilat_host = nullptr;
+  uint8_t *mask_host = nullptr;
+  size_t host_px_cap = 0;
   size_t frame_cap = 0;
 
   // per-hypothesis scratch
@@ -500,6 +502,8 @@ void fp_destroy(fp_model *m) {
   dev_free(m->blob_a); dev_free(m->blob_b); dev_free(m->trans_dev); dev_free(m->rot_dev); dev_free(m->scores_dev);
   dev_free(m->feat_dev); dev_free(m->argmax_dev); dev_free(m->scores_all); dev_free(m->dbg_tri); dev_free(m->dbg_rast);
   if (m->poses_pinned) (void)hipHostFree(m->poses_pinned);
+  if (m->bilat_host) (void)hipHostFree(m->bilat_host);
+  if (m->mask_host) (void)hipHostFree(m->mask_host);
   if (m->digests) (void)hipFree(m->digests);
   if (m->refiner) net_free(m->refiner);
   if (m->scorer) net_free(m->scorer);
@@ -597,20 +601,26 @@ static int sample_hypotheses(fp_model *m, const void *mask, int memspace, std::v
   FP_CHECK(m->depth != nullptr && mask != nullptr, "[FoudationPoseSampler] Got INVALID depth/mask ptr on device!!!");
   size_t px = (size_t)m->H * m->W;
   run_depth_filters(m);
-  m->bilat_host.resize(px);
+  if (px > m->host_px_cap) {
+    if (m->bilat_host) (void)hipHostFree(m->bilat_host);
+    if (m->mask_host) (void)hipHostFree(m->mask_host);
+    m->bilat_host = nullptr; m->mask_host = nullptr; m->host_px_cap = 0;
+    FP_HIP_OK(hipHostMalloc((void **)&m->bilat_host, px * sizeof(float), hipHostMallocDefault));
+    FP_HIP_OK(hipHostMalloc((void **)&m->mask_host, px, hipHostMallocDefault));
+    m->host_px_cap = px;
+  }
   {
     ProfScope ps(&m->prof, m->stream, "d2h_filtered_depth", 0, (double)px * 4);
-    FP_HIP_OK(hipMemcpyAsync(m->bilat_host.data(), m->bilat, px * 4, hipMemcpyDeviceToHost, m->stream));
+    FP_HIP_OK(hipMemcpyAsync(m->bilat_host, m->bilat, px * 4, hipMemcpyDeviceToHost, m->stream));
   }
   const uint8_t *mask_h = (const uint8_t *)mask;
   if (memspace == FP_DEVICE) {
-    m->mask_host.resize(px);
-    FP_HIP_OK(hipMemcpyAsync(m->mask_host.data(), mask, px, hipMemcpyDeviceToHost, m->stream));
-    mask_h = m->mask_host.data();
+    FP_HIP_OK(hipMemcpyAsync(m->mask_host, mask, px, hipMemcpyDeviceToHost, m->stream));
+    mask_h = m->mask_host;
   }
   FP_HIP_OK(hipStreamSynchronize(m->stream));
   float center[3];
-  if (guess_translation(m->bilat_host.data(), mask_h, m->H, m->W, m->K, FP_MIN_DEPTH, center)) return 1;
+  if (guess_translation(m->bilat_host, mask_h, m->H, m->W, m->K, FP_MIN_DEPTH, center)) return 1;
   poses = m->grid_host;
   for (size_t i = 0; i < poses.size() / 16; i++) {
     poses[i * 16 + 12] = center[0]; poses[i * 16 + 13] = center[1]; poses[i * 16 + 14] = center[2];
@@ -633,7 +643,6 @@ static int upload_poses(fp_model *m, Target *t, const float *poses, int N) {
   if (N > m->poses_pinned_cap) {
     FP_HIP_OK(hipStreamSynchronize(m->stream));
     if (m->poses_pinned) (void)hipHostFree(m->poses_pinned);
-  if (m->digests) (void)hipFree(m->digests);
     m->poses_pinned = nullptr; m->poses_pinned_cap = 0;
     FP_HIP_OK(hipHostMalloc((void **)&m->poses_pinned, (size_t)std::max(N, 256) * 64, hipHostMallocDefault));
     m->poses_pinned_cap = std::max(N, 256);
