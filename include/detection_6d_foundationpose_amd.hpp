@@ -13,6 +13,7 @@
 #if __has_include(<Eigen/Dense>) && __has_include(<opencv2/core.hpp>)
 
 #include <Eigen/Dense>
+#include <cstring>
 #include <memory>
 #include <opencv2/core.hpp>
 #include <stdexcept>
@@ -57,6 +58,65 @@ inline Eigen::Matrix4f ConvertPoseMesh2BBox(const Eigen::Matrix4f &pose_in_mesh,
   Eigen::Matrix4f tf_to_center = Eigen::Matrix4f::Identity();
   tf_to_center.block<3, 1>(0, 3) = -mesh_loader->GetMeshModelCenter();
   return pose_in_mesh * tf_to_center * mesh_loader->GetOrientBounds();
+}
+
+// CreateAssimpMeshLoader(name, path) (mesh_loader.hpp:92-93) without assimp: Wavefront OBJ + MTL + PNG through
+// fp_mesh_load_obj.  Throws std::runtime_error where the reference throws (empty path, unreadable file, no UVs).
+class ObjMeshLoader : public BaseMeshLoader {
+public:
+  ObjMeshLoader(const std::string &name, const std::string &mesh_file_path) : name_(name) {
+    fp_loaded_mesh *h = fp_mesh_load_obj(name.c_str(), mesh_file_path.c_str());
+    if (!h) throw std::runtime_error(fp_last_error());
+    const fp_mesh *m = fp_mesh_view(h);
+    for (int i = 0; i < m->num_vertices; i++) {
+      vertices_.emplace_back(m->vertices[3 * i], m->vertices[3 * i + 1], m->vertices[3 * i + 2]);
+      normals_.emplace_back(m->normals[3 * i], m->normals[3 * i + 1], m->normals[3 * i + 2]);
+      uvs_.emplace_back(m->texcoords[2 * i], m->texcoords[2 * i + 1], 0.f);  // aiVector3D-style (u, v, 0)
+    }
+    for (int i = 0; i < m->num_faces; i++) {
+      Vector3ui f;
+      f[0] = m->faces[3 * i]; f[1] = m->faces[3 * i + 1]; f[2] = m->faces[3 * i + 2];
+      faces_.push_back(f);
+    }
+    texture_ = cv::Mat(m->tex_height, m->tex_width, CV_8UC3);
+    std::memcpy(texture_.data, m->texture, (size_t)m->tex_height * m->tex_width * 3);
+    diameter_ = m->diameter;
+    center_ = Eigen::Vector3f(m->center[0], m->center[1], m->center[2]);
+    float ob[16], dim[3];
+    fp_mesh_orient_bounds(h, ob, dim);
+    for (int c = 0; c < 4; c++)
+      for (int r = 0; r < 4; r++) orient_bounds_(r, c) = ob[c * 4 + r];
+    dimension_ = Eigen::Vector3f(dim[0], dim[1], dim[2]);
+    fp_mesh_free(h);
+  }
+  std::string GetName() const noexcept override { return name_; }
+  float GetMeshDiameter() const noexcept override { return diameter_; }
+  size_t GetMeshNumVertices() const noexcept override { return vertices_.size(); }
+  size_t GetMeshNumFaces() const noexcept override { return faces_.size(); }
+  const std::vector<Eigen::Vector3f> &GetMeshVertices() const noexcept override { return vertices_; }
+  const std::vector<Eigen::Vector3f> &GetMeshVertexNormals() const noexcept override { return normals_; }
+  const std::vector<Eigen::Vector3f> &GetMeshTextureCoords() const noexcept override { return uvs_; }
+  const std::vector<Vector3ui> &GetMeshTriangleFaces() const noexcept override { return faces_; }
+  const Eigen::Vector3f &GetMeshModelCenter() const noexcept override { return center_; }
+  const Eigen::Matrix4f &GetOrientBounds() const noexcept override { return orient_bounds_; }
+  const Eigen::Vector3f &GetObjectDimension() const noexcept override { return dimension_; }
+  const cv::Mat &GetTextureMap() const noexcept override { return texture_; }
+
+private:
+  std::string name_;
+  float diameter_ = 0;
+  std::vector<Eigen::Vector3f> vertices_, normals_, uvs_;
+  std::vector<Vector3ui> faces_;
+  Eigen::Vector3f center_, dimension_;
+  Eigen::Matrix4f orient_bounds_;
+  cv::Mat texture_;
+};
+inline std::shared_ptr<BaseMeshLoader> CreateObjMeshLoader(const std::string &name, const std::string &mesh_file_path) {
+  return std::make_shared<ObjMeshLoader>(name, mesh_file_path);
+}
+// same name as the reference's factory, so simple_tests needs no edit for the mesh either
+inline std::shared_ptr<BaseMeshLoader> CreateAssimpMeshLoader(const std::string &name, const std::string &mesh_file_path) {
+  return CreateObjMeshLoader(name, mesh_file_path);
 }
 
 class Base6DofDetectionModel {  // foundationpose.hpp:16-77, unchanged
