@@ -75,6 +75,11 @@ struct ConvParams {
   int m_begin;            // first output row handled by this launch (hybrid 256^2 + 128^2 launches)
   int ksplit, kt_per;     // split-K (small problems): K-steps [split*kt_per, ...) per workgroup, fp32 partial slabs
   float *partial;         // [ksplit][M - m_begin][Cout]
+  // weight groups along M (the refiner's two heads in ONE launch at small N, conv_igemm_kernel only): rows
+  // [g*grp_rows, (g+1)*grp_rows) use weights w + g*grp_w_halfs and bias + g*Cout; grp_rows % 128 == 0, 0 = off.
+  // in_shared / res_shared: the input / residual tensor has only the first group's rows and is read by every group.
+  int grp_rows, in_shared, res_shared;
+  unsigned grp_w_halfs;
   unsigned long long *clk;  // optional clock probe: per block {cycles0, realtime0, cycles1, realtime1}
 };
 
@@ -88,7 +93,8 @@ struct ConvParams {
 // All bias and residual loads are issued BEFORE the first store: on CDNA4 stores also count in vmcnt, so a load issued
 // behind a store cannot be waited for without draining the store.
 template <int MI, int NI, int EABL = 0, class PixFn>  // EABL (timing ablations): 1 = no stores, 2 = no residual loads
-__device__ __forceinline__ void conv_epilogue_px(const ConvParams &p, f4 (&acc)[NI][MI], int n_base, int lane, PixFn pix) {
+__device__ __forceinline__ void conv_epilogue_px(const ConvParams &p, f4 (&acc)[NI][MI], int n_base, int lane, PixFn pix,
+                                                 int bias_off = 0, int res_img_off = 0) {
   static_assert(NI == 4 || NI == 2, "wave covers 64 or 32 channels");
   constexpr int NS = NI / 2;  // 16-byte stores per pixel per lane
   const int OHp = p.OH + 2 * p.opad, OWp = p.OW + 2 * p.opad;
@@ -98,7 +104,7 @@ __device__ __forceinline__ void conv_epilogue_px(const ConvParams &p, f4 (&acc)[
   float bv[NS][8];
 #pragma unroll
   for (int k = 0; k < NS; k++) {
-    float4 b0 = *reinterpret_cast<const float4 *>(p.bias + nl + 32 * k), b1 = *reinterpret_cast<const float4 *>(p.bias + nl + 32 * k + 4);
+    float4 b0 = *reinterpret_cast<const float4 *>(p.bias + bias_off + nl + 32 * k), b1 = *reinterpret_cast<const float4 *>(p.bias + bias_off + nl + 32 * k + 4);
     bv[k][0] = b0.x; bv[k][1] = b0.y; bv[k][2] = b0.z; bv[k][3] = b0.w; bv[k][4] = b1.x; bv[k][5] = b1.y; bv[k][6] = b1.z; bv[k][7] = b1.w;
   }
   // pixels in groups of at most 8 fragments: a group's residual values (4 VGPRs per fragment and store) stay in registers
@@ -118,7 +124,7 @@ __device__ __forceinline__ void conv_epilogue_px(const ConvParams &p, f4 (&acc)[
     if (p.split_imgs > 0 && img >= p.split_imgs) { oimg = img - p.split_imgs; choff = p.Cout; }
     oofs[gi] = (((size_t)oimg * OHp + oh + p.opad) * OWp + ow + p.opad) * p.out_ld + choff;
     if (p.res && !(EABL & 2)) {
-      size_t rpix = ((size_t)img * RHp + oh + p.rpad) * RWp + ow + p.rpad;
+      size_t rpix = ((size_t)(img - res_img_off) * RHp + oh + p.rpad) * RWp + ow + p.rpad;
 #pragma unroll
       for (int k = 0; k < NS; k++)
         rv[k][gi] = ok[gi] ? *reinterpret_cast<const h8 *>(p.res + rpix * p.res_ld + nl + 32 * k) : (h8){0, 0, 0, 0, 0, 0, 0, 0};
@@ -152,6 +158,7 @@ __device__ __forceinline__ void conv_epilogue_px(const ConvParams &p, f4 (&acc)[
 template <int MI, int NI, int EABL = 0>
 __device__ __forceinline__ void conv_epilogue(const ConvParams &p, f4 (&acc)[NI][MI], int m_base, int n_base, int lane) {
   const int ohw = p.OH * p.OW;
+  const int grp = p.grp_rows ? m_base / p.grp_rows : 0;  // tile-uniform (grp_rows is a multiple of the tile height)
   conv_epilogue_px<MI, NI, EABL>(p, acc, n_base, lane, [&](int mi, int &img, int &oh, int &ow) {
     int m = m_base + mi * 16 + (lane & 15);
     const bool ok = m < p.M;
@@ -161,7 +168,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams &p, f4 (&acc)[NI]
     oh = rem / p.OW;
     ow = rem - oh * p.OW;
     return ok;
-  });
+  }, grp * p.Cout, p.res_shared ? grp * p.grp_rows : 0);
 }
 
 // split-K partial slab (true channel order): per accumulator register j a lane owns NI consecutive channels
@@ -227,6 +234,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
 #pragma unroll
   for (int i = 0; i < 4; i++) {
     int m = min(m0 + (wave * 4 + i) * 8 + srow, p.M - 1);  // rows past M re-read the last pixel (never stored)
+    if (p.in_shared) m -= (m0 / p.grp_rows) * p.grp_rows;   // every weight group reads the first group's rows
     int img = m / ohw;
     int rem = m - img * ohw;
     int oh = rem / p.OW, ow = rem - oh * p.OW;
@@ -240,7 +248,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
     woffv[i] = (unsigned)((n0 + row) * p.Ktot + g * 8) * 2u;
   }
   const unsigned char *in_b = reinterpret_cast<const unsigned char *>(p.in);
-  const unsigned char *w_b = reinterpret_cast<const unsigned char *>(p.w);
+  const unsigned char *w_b = reinterpret_cast<const unsigned char *>(p.w) + (p.grp_rows ? (size_t)(m0 / p.grp_rows) * p.grp_w_halfs * 2 : 0);
 
   auto stage = [&](int kt, int buf) {
     unsigned char *xs = smem + buf * STAGE;
@@ -1330,7 +1338,8 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvParam
   const int m = p.m_begin + mr;
   f4 a = *reinterpret_cast<const f4 *>(p.partial + (size_t)mr * p.Cout + n);
   for (int sp = 1; sp < p.ksplit; sp++) a += *reinterpret_cast<const f4 *>(p.partial + ((size_t)sp * rows + mr) * p.Cout + n);
-  float4 bv = *reinterpret_cast<const float4 *>(p.bias + n);
+  const int grp = p.grp_rows ? m / p.grp_rows : 0;
+  float4 bv = *reinterpret_cast<const float4 *>(p.bias + grp * p.Cout + n);
   float v0 = a[0] + bv.x, v1 = a[1] + bv.y, v2 = a[2] + bv.z, v3 = a[3] + bv.w;
   const int ohw = p.OH * p.OW;
   int img = m / ohw;
@@ -1339,7 +1348,7 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvParam
   const int OHp = p.OH + 2 * p.opad, OWp = p.OW + 2 * p.opad;
   const int RHp = p.OH + 2 * p.rpad, RWp = p.OW + 2 * p.rpad;
   if (p.res) {
-    size_t rpix = ((size_t)img * RHp + oh + p.rpad) * RWp + ow + p.rpad;
+    size_t rpix = ((size_t)(img - (p.res_shared ? grp * p.grp_rows : 0)) * RHp + oh + p.rpad) * RWp + ow + p.rpad;
     h4 r = *reinterpret_cast<const h4 *>(p.res + rpix * p.res_ld + n);
     v0 += (float)r[0]; v1 += (float)r[1]; v2 += (float)r[2]; v3 += (float)r[3];
   }
@@ -1361,7 +1370,8 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvParam
 // tiles of one (image, head) run on the SAME XCD and share its L2 copy of K/V (a (qt,h,b) grid spread them over all 8
 // XCDs: rocprofv3 FETCH_SIZE showed 1.16 GB fetched per launch for 0.31 GB of QKV).
 template <int ATT_QROWS, bool REMAP, bool PERM = true>
-__global__ __launch_bounds__(ATT_QROWS * 4) void attention_kernel(const __half *__restrict__ qkv, __half *__restrict__ out, int T, int nq) {
+__global__ __launch_bounds__(ATT_QROWS * 4) void attention_kernel(const __half *__restrict__ qkv, __half *__restrict__ out, int T, int nq,
+                                                                 int tstride /* rows between the first tokens of consecutive sequences */) {
   constexpr int KS = 136;  // K tile row stride (halfs): 128 + 8 pad
   constexpr int VS = 40;   // V^T tile row stride (halfs): 32 keys + 8 pad
   __shared__ __attribute__((aligned(16))) _Float16 Ks[32 * KS];
@@ -1376,7 +1386,7 @@ __global__ __launch_bounds__(ATT_QROWS * 4) void attention_kernel(const __half *
   const int qt = logical % nq, h = (logical / nq) % HEADS, b = logical / (nq * HEADS);
   const int g = lane >> 4, li = lane & 15;
   const size_t rowstride = 3 * EMBED;
-  const __half *base = qkv + (size_t)b * T * rowstride;
+  const __half *base = qkv + (size_t)b * tstride * rowstride;
   const int q_row = qt * ATT_QROWS + wave * 16 + li;
   const int q_ld = min(q_row, T - 1);
   h8 qf[4];
@@ -1496,9 +1506,9 @@ __global__ __launch_bounds__(ATT_QROWS * 4) void attention_kernel(const __half *
       h8 ov;
 #pragma unroll
       for (int dt = 0; dt < 8; dt++) ov[dt] = (_Float16)(o[dt][r] * lr[r]);
-      *reinterpret_cast<h8 *>(out + ((size_t)b * T + row) * EMBED + h * HDIM + li * 8) = ov;
+      *reinterpret_cast<h8 *>(out + ((size_t)b * tstride + row) * EMBED + h * HDIM + li * 8) = ov;
     } else {
-      __half *dst = out + ((size_t)b * T + row) * EMBED + h * HDIM + li;
+      __half *dst = out + ((size_t)b * tstride + row) * EMBED + h * HDIM + li;
 #pragma unroll
       for (int dt = 0; dt < 8; dt++) dst[dt * 16] = __float2half(o[dt][r] * lr[r]);
     }
@@ -1522,11 +1532,15 @@ __global__ void add_pos_embed_kernel(__half *__restrict__ x, const __half *__res
 }
 
 // y = LayerNorm(x) over 512 channels, eps 1e-5; one wave per row
-__global__ __launch_bounds__(256) void layernorm_kernel(const __half *__restrict__ x, const float *__restrict__ gamma,
-                                                        const float *__restrict__ beta, __half *__restrict__ y, size_t rows) {
+// rows >= split_row use (gamma1, beta1): the refiner's two heads normalised in one launch
+__global__ __launch_bounds__(256) void layernorm_kernel(const __half *__restrict__ x, const float *__restrict__ gamma0,
+                                                        const float *__restrict__ beta0, __half *__restrict__ y, size_t rows,
+                                                        const float *__restrict__ gamma1, const float *__restrict__ beta1,
+                                                        size_t split_row) {
   size_t row = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   int lane = threadIdx.x & 63;
   if (row >= rows) return;
+  const float *gamma = row >= split_row ? gamma1 : gamma0, *beta = row >= split_row ? beta1 : beta0;
   h8 v = reinterpret_cast<const h8 *>(x + row * EMBED)[lane];
   float f[8], s = 0.f;
 #pragma unroll
@@ -1550,11 +1564,11 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const __half *__restrict
 // tokens per load and walks the sequence in strides of 32 tokens (13 dependent steps for T = 400 instead of 100: at
 // N = 1 this kernel was 30 us of a 570 us Track); the 8 token slots combine through shfl_xor, the 4 waves through LDS,
 // both in a fixed order.
-__global__ __launch_bounds__(256) void token_mean_kernel(const __half *__restrict__ x, float *__restrict__ out, int T) {
+__global__ __launch_bounds__(256) void token_mean_kernel(const __half *__restrict__ x, float *__restrict__ out, int T, int tstride) {
   __shared__ float part[4][64];
   const int b = blockIdx.x, cg = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int slot = lane >> 3, c8 = (lane & 7) * 8;
-  const __half *src = x + (size_t)b * T * EMBED + cg * 64 + c8;
+  const __half *src = x + (size_t)b * tstride * EMBED + cg * 64 + c8;
   float s[8];
 #pragma unroll
   for (int e = 0; e < 8; e++) s[e] = 0.f;
@@ -1684,6 +1698,8 @@ struct Net {
   ConvLayer a0, a1, ra[2][2];        // encodeA
   ConvLayer rb[2][2], b2, rc[2][2];  // encodeAB
   EncLayer trans, rot;               // refiner
+  // the two heads' Linear layers stored back to back ([2][Cout][K], [2][Cout]) for the one-launch small-batch path
+  ConvLayer g_in_proj, g_out_proj, g_lin1, g_lin2;
   MHA att, att_cross;                // scorer
   LinearF32 score_lin;
   __half *pe = nullptr;     // [400,512]
@@ -1700,6 +1716,25 @@ static T *upload(Net *net, const std::vector<T> &h) {
   net->allocs.push_back(d);
   if (hipMemcpy(d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
   return d;
+}
+
+// [a | b] device copy of two equally shaped Linear layers (weights already in kernel row order)
+static bool make_grouped(Net *net, const ConvLayer &a, const ConvLayer &b, ConvLayer *g) {
+  if (a.Cin != b.Cin || a.Cout != b.Cout) return false;
+  const size_t nw = (size_t)a.Cout * a.Cin, nb = (size_t)a.Cout;
+  __half *w = nullptr;
+  float *bias = nullptr;
+  if (hipMalloc((void **)&w, 2 * nw * sizeof(__half)) != hipSuccess) return false;
+  net->allocs.push_back(w);
+  if (hipMalloc((void **)&bias, 2 * nb * sizeof(float)) != hipSuccess) return false;
+  net->allocs.push_back(bias);
+  if (hipMemcpy(w, a.w, nw * 2, hipMemcpyDeviceToDevice) != hipSuccess || hipMemcpy(w + nw, b.w, nw * 2, hipMemcpyDeviceToDevice) != hipSuccess ||
+      hipMemcpy(bias, a.bias, nb * 4, hipMemcpyDeviceToDevice) != hipSuccess || hipMemcpy(bias + nb, b.bias, nb * 4, hipMemcpyDeviceToDevice) != hipSuccess)
+    return false;
+  *g = a;
+  g->w = w;
+  g->bias = bias;
+  return true;
 }
 
 static bool get(const std::map<std::string, HostTensor> &m, const std::string &name, const HostTensor **t, std::string *err) {
@@ -1845,6 +1880,13 @@ Net *net_load(const char *path, bool is_scorer, std::string *err) {
            make_ln(net.get(), m, p0 + ".norm1", &heads[i]->ln1, err) && make_ln(net.get(), m, p0 + ".norm2", &heads[i]->ln2, err) &&
            make_linear_f32(net.get(), m, p1 + ".weight", p1 + ".bias", &heads[i]->head, err);
     }
+    if (ok) {
+      ok = make_grouped(net.get(), net->trans.att.in_proj, net->rot.att.in_proj, &net->g_in_proj) &&
+           make_grouped(net.get(), net->trans.att.out_proj, net->rot.att.out_proj, &net->g_out_proj) &&
+           make_grouped(net.get(), net->trans.lin1, net->rot.lin1, &net->g_lin1) &&
+           make_grouped(net.get(), net->trans.lin2, net->rot.lin2, &net->g_lin2);
+      if (!ok) *err = "could not build the grouped head weights";
+    }
   } else if (ok) {
     ok = make_mha(net.get(), m, "att", &net->att, err) && make_mha(net.get(), m, "att_cross", &net->att_cross, err) &&
          make_linear_f32(net.get(), m, "linear.weight", "linear.bias", &net->score_lin, err);
@@ -1952,6 +1994,7 @@ struct Ctx {
 static bool g_conv_attr_done = false;
 static unsigned long long *g_clk_probe = nullptr;
 static NNScratch g_hook_ws;  // split-K slab of the fpt_* test hooks
+static int g_grouped_heads = 1;  // A/B hook: the refiner's two heads as one launch per layer when N == 1 (Track)
 static int g_rem_splitk = 0;     // A/B hook: split-K for the rows a 256x256 / 512x128 launch leaves over.  Measured -0.1 ms per
                                  // Register, but OFF: a row's fp32 summation order would then depend on where it falls in the
                                  // batch, and sharded and unsharded Register must pick the same near-tied winner
@@ -1960,10 +2003,20 @@ static int g_conv_variant = 0;
 static int g_conv_ablate = 0;  // timing-only ablations of conv_big_pp_kernel: 1 no loads, 2 no MFMAs, 3 neither  // 0 auto, 1 force the 128-pixel 2-stage kernel, 2 force the 256-pixel 3-stage kernel (A/B hook)
 
 // in: [NB, H+2*ipad, W+2*ipad, Cin]; out: [.., OH+2*opad, OW+2*opad, ..]; res: border rpad
+struct ConvGroup {  // two weight groups along M (see ConvParams::grp_rows); L holds [2][Cout][K] weights and [2][Cout] biases
+  int rows = 0;     // rows per group (multiple of 128); the launch covers 2 * rows
+  bool in_shared = false, res_shared = false;
+};
 static int run_conv(const Ctx &c, const char *tag, const ConvLayer &L, const __half *in, int NB, int H, int W, int ipad,
-                    __half *out, int opad, bool relu, const __half *res = nullptr, int rpad = 0, int split_imgs = 0) {
+                    __half *out, int opad, bool relu, const __half *res = nullptr, int rpad = 0, int split_imgs = 0,
+                    const ConvGroup *grp = nullptr) {
   ConvParams p;
   p.clk = g_clk_probe;
+  p.grp_rows = grp ? grp->rows : 0;
+  p.in_shared = grp && grp->in_shared;
+  p.res_shared = grp && grp->res_shared;
+  p.grp_w_halfs = grp ? (unsigned)((size_t)L.Cout * L.KH * L.KW * L.Cin) : 0;
+  FP_CHECK(!grp || (grp->rows % 128 == 0 && L.KH == 1 && L.KW == 1 && NB == 2 * grp->rows), "grouped launch: unsupported shape");
   p.in = in; p.w = L.w; p.bias = L.bias; p.res = res; p.out = out;
   p.NB = NB; p.H = H; p.W = W; p.Cin = L.Cin;
   p.KH = L.KH; p.KW = L.KW; p.stride = L.stride; p.pad = L.pad;
@@ -2063,13 +2116,13 @@ static int run_conv(const Ctx &c, const char *tag, const ConvLayer &L, const __h
   (void)big_tiles;
   // measured (tools/bench_conv.py, N=126): the 128-px 2-stage kernel beats the 256-px 3-stage one on every layer
   // (756-769 vs 703-709 TF/s weighted), so the latter is only reachable through the A/B hook
-  if ((g_conv_variant == 7 || g_conv_variant == 0) && L.Cin == 32 && L.KH == 4 && L.KW == 4 && L.Cout == 64 && ipad == 2 && W == 80 &&
+  if (!grp && (g_conv_variant == 7 || g_conv_variant == 0) && L.Cin == 32 && L.KH == 4 && L.KW == 4 && L.Cout == 64 && ipad == 2 && W == 80 &&
       H == 80 && p.ksplit == 1 && res == nullptr && split_imgs == 0 && (g_conv_variant == 7 || NB * 10 >= 300)) {
     ProfScope ps(c.prof, c.s, (tg + "/conv_stem_halo_kernel").c_str(), flops, bytes);
     hipLaunchKernelGGL(conv_stem_halo_kernel, dim3(NB * 10), dim3(256), LDS_STEM_HALO, c.s, p);
     return 0;
   }
-  if ((g_conv_variant == 7 || g_conv_variant == 0) && L.KH == 3 && L.KW == 3 && L.stride == 1 && L.pad == 1 && ipad == 1 && W == 40 && H % 8 == 0 &&
+  if (!grp && (g_conv_variant == 7 || g_conv_variant == 0) && L.KH == 3 && L.KW == 3 && L.stride == 1 && L.pad == 1 && ipad == 1 && W == 40 && H % 8 == 0 &&
       L.Cin % 64 == 0 && L.Cout % 128 == 0 && p.ksplit == 1 &&
       (g_conv_variant == 7 || NB * (H / 8) * (L.Cout / 128) >= 300)) {  // measured crossover vs the implicit-GEMM tiles: ~32 hypotheses
     ProfScope ps(c.prof, c.s, (tg + "/conv_halo_kernel").c_str(), flops, bytes);
@@ -2080,7 +2133,7 @@ static int run_conv(const Ctx &c, const char *tag, const ConvLayer &L, const __h
     else hipLaunchKernelGGL((conv_halo_kernel<40, 0>), grid, dim3(256), LDS_HALO40, c.s, p);
     return 0;
   }
-  if ((((g_conv_variant == 0 || g_conv_variant == 8) && L.Cout == 128) || (g_conv_variant == 6 && (L.Cout % 256 == 0 || L.Cout == 128))) && p.ksplit == 1 &&
+  if (!grp && (((g_conv_variant == 0 || g_conv_variant == 8) && L.Cout == 128) || (g_conv_variant == 6 && (L.Cout % 256 == 0 || L.Cout == 128))) && p.ksplit == 1 &&
       KT >= 4 && KT <= 80) {
     // ping-pong tiles (conv_pp32_kernel) for as many FULL rounds of the 256 CUs as the problem has; the remaining rows
     // go to the 128x128 kernel below
@@ -2105,7 +2158,7 @@ static int run_conv(const Ctx &c, const char *tag, const ConvLayer &L, const __h
       if (g_rem_splitk && plan_splitk(p.M - p.m_begin, 384)) return 1;
     }
   }
-  if ((g_conv_variant == 4 || g_conv_variant == 5 || g_conv_variant == 0 || g_conv_variant == 8) && L.Cout % 256 == 0 && p.ksplit == 1 && KT >= 2) {
+  if (!grp && (g_conv_variant == 4 || g_conv_variant == 5 || g_conv_variant == 0 || g_conv_variant == 8) && L.Cout % 256 == 0 && p.ksplit == 1 && KT >= 2) {
     // 256x256 tiles for as many FULL rounds of the 256 CUs as the problem has, the remaining rows on 128x128 tiles
     const int nt2 = L.Cout / 256;
     const int mt_all = p.M / 256;                         // whole 256-row m-tiles
@@ -2133,7 +2186,7 @@ static int run_conv(const Ctx &c, const char *tag, const ConvLayer &L, const __h
       if (g_rem_splitk && plan_splitk(p.M - p.m_begin, 384)) return 1;
     }
   }
-  if (g_conv_variant == 3 && KT >= 3 && p.ksplit == 1) {
+  if (!grp && g_conv_variant == 3 && KT >= 3 && p.ksplit == 1) {
     ProfScope ps(c.prof, c.s, (tg + "/conv_pp_kernel").c_str(), flops, bytes);
     int mt2 = (p.M + 255) / 256;
     if (L.Cout % 128 == 0)
@@ -2142,7 +2195,7 @@ static int run_conv(const Ctx &c, const char *tag, const ConvLayer &L, const __h
       hipLaunchKernelGGL(conv_pp_kernel<64>, dim3(mt2 * (L.Cout / 64)), dim3(512), LDS3_64, c.s, p);
     return 0;
   }
-  if (g_conv_variant == 2 && KT >= 3) {
+  if (!grp && g_conv_variant == 2 && KT >= 3) {
     ProfScope ps(c.prof, c.s, (tg + "/conv_igemm3_kernel").c_str(), flops, bytes);
     int mt2 = (p.M + 255) / 256;
     if (L.Cout % 128 == 0)
@@ -2179,28 +2232,31 @@ static int run_conv(const Ctx &c, const char *tag, const ConvLayer &L, const __h
 
 // plain GEMM rows x Cin -> rows x Cout (Linear layer) on unpadded buffers
 static int run_gemm(const Ctx &c, const char *tag, const ConvLayer &L, const __half *in, int rows, __half *out, bool relu,
-                    const __half *res = nullptr) {
-  return run_conv(c, tag, L, in, rows, 1, 1, 0, out, 0, relu, res, 0, 0);
+                    const __half *res = nullptr, const ConvGroup *grp = nullptr) {
+  return run_conv(c, tag, L, in, rows, 1, 1, 0, out, 0, relu, res, 0, 0, grp);
 }
 
 static int g_att_variant = 1;  // A/B hook (tools/ab_attention.py): 1 remap + 16-B stores, 3 no XCD remap, 5 remap + 2-B stores, 7 neither
-static int run_attention(const Ctx &c, const __half *qkv, __half *out, int B, int T) {
+static int run_attention(const Ctx &c, const __half *qkv, __half *out, int B, int T, int tstride = 0) {
+  if (tstride == 0) tstride = T;
   double flops = 4.0 * (double)B * HEADS * (double)T * T * HDIM;
   ProfScope ps(c.prof, c.s, "attention", flops, (double)B * T * (1536 + 512) * 2.0);
   const int nq = (T + 63) / 64;
   dim3 grid((unsigned)(nq * HEADS * B)), blk(256);
   switch (g_att_variant) {
-    case 1: hipLaunchKernelGGL((attention_kernel<64, true>), grid, blk, 0, c.s, qkv, out, T, nq); break;
-    case 3: hipLaunchKernelGGL((attention_kernel<64, false>), grid, blk, 0, c.s, qkv, out, T, nq); break;
-    case 5: hipLaunchKernelGGL((attention_kernel<64, true, false>), grid, blk, 0, c.s, qkv, out, T, nq); break;
-    default: hipLaunchKernelGGL((attention_kernel<64, false, false>), grid, blk, 0, c.s, qkv, out, T, nq); break;
+    case 1: hipLaunchKernelGGL((attention_kernel<64, true>), grid, blk, 0, c.s, qkv, out, T, nq, tstride); break;
+    case 3: hipLaunchKernelGGL((attention_kernel<64, false>), grid, blk, 0, c.s, qkv, out, T, nq, tstride); break;
+    case 5: hipLaunchKernelGGL((attention_kernel<64, true, false>), grid, blk, 0, c.s, qkv, out, T, nq, tstride); break;
+    default: hipLaunchKernelGGL((attention_kernel<64, false, false>), grid, blk, 0, c.s, qkv, out, T, nq, tstride); break;
   }
   return 0;
 }
 
-static void run_layernorm(const Ctx &c, const __half *x, const LNParams &ln, __half *y, size_t rows) {
+static void run_layernorm(const Ctx &c, const __half *x, const LNParams &ln, __half *y, size_t rows, const LNParams *ln1 = nullptr,
+                          size_t split_row = 0) {
   ProfScope ps(c.prof, c.s, "layernorm", 0, (double)rows * EMBED * 4.0);
-  hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, c.s, x, ln.g, ln.b, y, rows);
+  hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, c.s, x, ln.g, ln.b, y, rows,
+                     ln1 ? ln1->g : ln.g, ln1 ? ln1->b : ln.b, ln1 ? split_row : rows);
 }
 
 static void run_small_linear(const Ctx &c, const float *x, const LinearF32 &L, float *y, int B) {
@@ -2209,9 +2265,9 @@ static void run_small_linear(const Ctx &c, const float *x, const LinearF32 &L, f
   hipLaunchKernelGGL(small_linear_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, c.s, x, L.w, L.b, y, B, L.out, L.in);
 }
 
-static void run_token_mean(const Ctx &c, const __half *x, float *out, int B, int T) {
+static void run_token_mean(const Ctx &c, const __half *x, float *out, int B, int T, int tstride = 0) {
   ProfScope ps(c.prof, c.s, "token_mean", 0, (double)B * T * EMBED * 2.0);
-  hipLaunchKernelGGL(token_mean_kernel, dim3(B, EMBED / 64), dim3(256), 0, c.s, x, out, T);
+  hipLaunchKernelGGL(token_mean_kernel, dim3(B, EMBED / 64), dim3(256), 0, c.s, x, out, T, tstride ? tstride : T);
 }
 
 // arena carve (by capacity, see ensure_scratch)
@@ -2282,6 +2338,26 @@ int refiner_forward(hipStream_t s, Profiler *prof, const Net *net, NNScratch *ws
   const size_t rows = (size_t)N * 400;
   const EncLayer *heads[2] = {&net->trans, &net->rot};
   float *outs[2] = {trans_dev, rot_dev};
+  if (N == 1 && g_grouped_heads) {
+    // Track: both heads in ONE launch per layer (Track is bound by its ~65 dependent launches, not by work).  Rows
+    // [0,400) = translation head, [512,912) = rotation head (groups padded to the 128-row tile; the rows in between
+    // carry don't-care values that no valid row ever reads: every op here is row-wise, attention is per sequence).
+    const int G = 512;
+    ConvGroup g_x{G, true, true}, g_in{G, false, true}, g_own{G, false, false};
+    const EncLayer &T0 = net->trans, &R0 = net->rot;
+    if (run_gemm(c, "gemm_qkv", net->g_in_proj, x, 2 * G, a.qkv, false, nullptr, &g_x)) return 1;
+    if (run_attention(c, a.qkv, a.att, 2, 400, G)) return 1;
+    if (run_gemm(c, "gemm_512", net->g_out_proj, a.att, 2 * G, a.y1, false, x, &g_in)) return 1;   // + residual x (shared)
+    run_layernorm(c, a.y1, T0.ln1, a.y2, 2 * G, &R0.ln1, G);
+    if (run_gemm(c, "gemm_512", net->g_lin1, a.y2, 2 * G, a.y1, true, nullptr, &g_own)) return 1;
+    if (run_gemm(c, "gemm_512", net->g_lin2, a.y1, 2 * G, a.att, false, a.y2, &g_own)) return 1;   // + residual x1
+    run_layernorm(c, a.att, T0.ln2, a.y1, 2 * G, &R0.ln2, G);
+    run_token_mean(c, a.y1, ws->f32, 2, 400, G);
+    run_small_linear(c, ws->f32, T0.head, trans_dev, 1);
+    run_small_linear(c, ws->f32 + EMBED, R0.head, rot_dev, 1);
+    FP_HIP_OK(hipGetLastError());
+    return 0;
+  }
   for (int i = 0; i < 2; i++) {
     const EncLayer &L = *heads[i];
     // post-norm TransformerEncoderLayer: x1 = LN1(x + SA(x)); x2 = LN2(x1 + W2 relu(W1 x1))
@@ -2339,7 +2415,7 @@ int scorer_head(hipStream_t s, Profiler *prof, const Net *net, NNScratch *ws, co
     // Linear(512,1) on fp16 rows: widen to f32 first (tiny)
     ProfScope ps(c.prof, c.s, "score_linear", 2.0 * N * EMBED, 0);
     // token_mean with T = 1 is a plain fp16 -> f32 copy of each row
-    hipLaunchKernelGGL(token_mean_kernel, dim3(N, EMBED / 64), dim3(256), 0, c.s, xf, o32, 1);
+    hipLaunchKernelGGL(token_mean_kernel, dim3(N, EMBED / 64), dim3(256), 0, c.s, xf, o32, 1, 1);
   }
   run_small_linear(c, o32, net->score_lin, scores_dev, N);
   FP_HIP_OK(hipGetLastError());
@@ -2372,6 +2448,7 @@ void fpt_set_conv_variant(int v) { fp::g_conv_variant = v; }
 void fpt_set_conv_ablate(int v) { fp::g_conv_ablate = v; }
 void fpt_set_splitk_target(int v) { fp::g_splitk_target = v; }
 void fpt_set_rem_splitk(int v) { fp::g_rem_splitk = v; }
+void fpt_set_grouped_heads(int v) { fp::g_grouped_heads = v; }
 void fpt_set_raster_strip_rows(int r) { fp::set_raster_strip_rows(r); }
 
 // clock probe: allocate room for `blocks` records, run convs, then read back mean shader MHz and mean main-loop cycles
