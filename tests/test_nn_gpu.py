@@ -254,6 +254,36 @@ def test_register_end_to_end_252(model, nets, syn_mesh, syn_scene):
     assert not ok
 
 
+@pytest.mark.parametrize("steps", [1, 2])
+def test_register_mid_sized_batches_match_oracle(model, nets, syn_mesh, syn_scene, steps):
+    """42 / 84 hypotheses (in-plane steps 1 / 2): the batch sizes where the schedule choice changes layer by layer
+    (resident-halo kernels above ~32 hypotheses, implicit-GEMM tiles below, split-K off)."""
+    n = 42 * steps
+    model.set_inplane_steps(steps)
+    try:
+        assert model.num_hypotheses == n
+        ok, pose = model.Register(syn_scene.rgb, syn_scene.depth, syn_scene.mask, syn_mesh.name)
+    finally:
+        model.set_inplane_steps(6)
+    assert ok, model.last_error
+    om = fo.OracleMesh(syn_mesh)
+    poses = fo.get_hyp_poses(syn_scene.depth, syn_scene.mask, syn_scene.K, inplane_step=360 // steps)
+    assert len(poses) == n
+    a = fo.render(om, poses, syn_scene.K, syn_scene.depth.shape, 1.2)
+    b = fo.crop(syn_scene.rgb, syn_scene.depth, syn_scene.K, poses, 1.2, syn_mesh.diameter)
+    with torch.no_grad():
+        t, r = nets[2](torch.from_numpy(a), torch.from_numpy(b))
+    refined = fo.refine_post_process(poses, t.numpy(), r.numpy(), syn_mesh.diameter)
+    a = fo.render(om, refined, syn_scene.K, syn_scene.depth.shape, 1.1)
+    b = fo.crop(syn_scene.rgb, syn_scene.depth, syn_scene.K, refined, 1.1, syn_mesh.diameter)
+    with torch.no_grad():
+        scores = nets[3](torch.from_numpy(a), torch.from_numpy(b)).numpy()
+    errs = [_pose_err(pose, x) for x in syn.from_colmajor(refined)]
+    idx = int(np.argmin([e[0] + 1e3 * e[1] for e in errs]))
+    assert errs[idx][0] < 0.1 and errs[idx][1] < 1e-4, errs[idx]
+    assert scores[idx] >= scores.max() - 5e-3, (idx, scores[idx], scores.max())
+
+
 def test_register_two_refine_iterations_matches_oracle(model, nets, syn_mesh, syn_scene):
     """refine_itr = 2: iteration 0 uses the shared observed crop (one translation for all hypotheses), iteration 1 the
     per-hypothesis crops; both must agree with the oracle pipeline that always computes every crop."""
