@@ -266,14 +266,15 @@ struct fp_model {
 
   // Track is launch-bound (~60 short kernels): after one eager call (allocations settle) the launch chain is captured
   // into a hipGraph and replayed.  The graph bakes buffer addresses, so it is keyed by g_alloc_epoch.
-  struct TrackGraph {
+  // (Register's ~110 launches are replayed the same way: inter-kernel gaps are ~4 % of a 12 ms Register.)
+  struct GraphSlot {
     hipGraphExec_t exec = nullptr;
     hipGraph_t graph = nullptr;
     Target *target = nullptr;
-    int H = 0, W = 0, itr = 0;
+    int H = 0, W = 0, itr = 0, n = 0;
     unsigned long epoch = 0;
     int eager_calls = 0;
-  } tg;
+  } tg, rg;  // Track body / Register body
   bool use_graphs = true;
 
   Target *find(const char *name) {
@@ -284,7 +285,6 @@ struct fp_model {
   int n_hyp() const { return 42 * inplane_steps; }
 };
 
-static void drop_track_graph(fp_model *m);
 
 // ---- debug checkpoints (tools/dbg_concurrent.py): order-independent 64-bit digest of a device buffer per pipeline stage
 __global__ void fp_digest_kernel(const uint32_t *p, size_t n, unsigned long long *out) {
@@ -377,7 +377,73 @@ static void checkpoint(fp_model *m, int slot, const void *buf, size_t bytes) {
   if (e != hipSuccess) std::fprintf(stderr, "checkpoint %d (%p, %zu B): %s\n", slot, buf, bytes, hipGetErrorString(e));
 }
 
+static int upload_frame_async(fp_model *m, const void *rgb, const void *depth, int memspace, int H, int W);
+
+static void drop_graph(fp_model::GraphSlot &g) {
+  if (g.exec) (void)hipGraphExecDestroy(g.exec);
+  if (g.graph) (void)hipGraphDestroy(g.graph);
+  g.exec = nullptr; g.graph = nullptr; g.eager_calls = 0;
+}
+
+// Runs `body` (a chain of launches on m->stream reading / writing only model-owned buffers): eagerly the first time a
+// (target, H, W, itr, n) configuration is seen, captured into a hipGraph on the second call once allocations have
+// settled (the graph bakes buffer addresses, so it is keyed by g_alloc_epoch), replayed from then on.
+template <class Body>
+static int run_graphed(fp_model *m, fp_model::GraphSlot &g, Target *t, int H, int W, int itr, int n, bool graphable, Body body) {
+  const bool same = g.target == t && g.H == H && g.W == W && g.itr == itr && g.n == n && g.epoch == g_alloc_epoch;
+  if (graphable && same && g.exec) {
+    FP_HIP_OK(hipGraphLaunch(g.exec, m->stream));
+  } else if (graphable && same && g.eager_calls >= 1) {
+    drop_graph(g);
+    FP_HIP_OK(hipStreamBeginCapture(m->stream, hipStreamCaptureModeThreadLocal));
+    int rc = body();
+    hipError_t e = hipStreamEndCapture(m->stream, &g.graph);
+    if (rc || e != hipSuccess || hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0) != hipSuccess) {
+      drop_graph(g);
+      m->use_graphs = false;  // fall back to eager launches for good
+      if (body()) return 1;
+    } else {
+      g.eager_calls = 1;
+      FP_HIP_OK(hipGraphLaunch(g.exec, m->stream));
+    }
+  } else {
+    if (!same) { drop_graph(g); g.target = t; g.H = H; g.W = W; g.itr = itr; g.n = n; }
+    if (body()) return 1;
+    g.epoch = g_alloc_epoch;  // allocations made by this eager call are now settled
+    g.eager_calls = graphable ? g.eager_calls + 1 : 0;
+  }
+  return 0;
+}
+
+// frame into the model's own buffers (graphs bake addresses): H2D for host frames, D2D for a caller's device frame
+static int stage_frame_owned(fp_model *m, const void *rgb, const void *depth, int memspace, int H, int W) {
+  if (memspace != FP_DEVICE) return upload_frame_async(m, rgb, depth, FP_HOST, H, W);
+  const size_t px = (size_t)H * W;
+  if (px > m->frame_cap) {
+    g_alloc_epoch++;
+    dev_free(m->rgb_own); dev_free(m->depth_own); dev_free(m->erode); dev_free(m->bilat); dev_free(m->xyz);
+    if (dev_alloc(&m->rgb_own, px * 3) || dev_alloc(&m->depth_own, px) || dev_alloc(&m->erode, px) || dev_alloc(&m->bilat, px)) return 1;
+    m->frame_cap = px;
+  }
+  m->H = H; m->W = W; m->rgb = m->rgb_own; m->depth = m->depth_own;
+  FP_HIP_OK(hipMemcpyAsync(m->rgb_own, rgb, px * 3, hipMemcpyDeviceToDevice, m->stream));
+  FP_HIP_OK(hipMemcpyAsync(m->depth_own, depth, px * 4, hipMemcpyDeviceToDevice, m->stream));
+  return 0;
+}
+
 extern "C" {
+
+// A/B hook: hipGraph replay of the Track / Register bodies on or off for one model
+int fpt_model_use_graphs(fp_model *m, int on) {
+  FP_GPU_LOCK();
+  m->use_graphs = on != 0;
+  drop_graph(m->tg);
+  drop_graph(m->rg);
+  return 0;
+}
+
+// bit 0: graphs still enabled (a failed capture disables them), bit 1: Track graph instantiated, bit 2: Register graph
+int fpt_model_graph_state(fp_model *m) { return (m->use_graphs ? 1 : 0) | (m->tg.exec ? 2 : 0) | (m->rg.exec ? 4 : 0); }
 
 // debug: enable the stage digests and read them back (16 slots; zeroed by every read)
 int fpt_digests(fp_model *m, unsigned long long out[16]) {
@@ -492,7 +558,8 @@ fp_model *fp_create(const fp_mesh *meshes, int n_meshes, const float K[9], const
 void fp_destroy(fp_model *m) {
   if (!m) return;
   if (m->stream) (void)hipStreamSynchronize(m->stream);
-  drop_track_graph(m);
+  drop_graph(m->tg);
+  drop_graph(m->rg);
   m->prof.reset();
   for (auto &t : m->targets) {
     dev_free(t.mesh.verts); dev_free(t.mesh.normals); dev_free(t.mesh.uvs); dev_free(t.mesh.faces); dev_free(t.mesh.tex);
@@ -801,7 +868,8 @@ int fp_register_shard_begin(fp_model *m, const void *rgb, const void *depth, con
   const int n_all = m->n_hyp();
   FP_CHECK(shard_begin >= 0 && shard_count > 0 && shard_begin + shard_count <= n_all,
            "[FoundationPose] hypothesis shard out of range");
-  if (upload_frame_async(m, rgb, depth, memspace, H, W)) return 1;
+  const bool graphable = m->use_graphs && !m->prof.on && !m->digests && refine_itr >= 1;
+  if (graphable ? stage_frame_owned(m, rgb, depth, memspace, H, W) : upload_frame_async(m, rgb, depth, memspace, H, W)) return 1;
   std::vector<float> poses;
   if (sample_hypotheses(m, mask, memspace, poses)) {
     set_error(std::string("[FoundationPose] Failed to generate hyp poses!!! ") + g_last_error);
@@ -809,18 +877,22 @@ int fp_register_shard_begin(fp_model *m, const void *rgb, const void *depth, con
   }
   const int N = shard_count;
   if (upload_poses(m, t, poses.data() + (size_t)shard_begin * 16, N)) return 1;
-  for (int it = 0; it < refine_itr; it++)
-    if (refine_iteration(m, t, N, it == 0 && N > 1)) return 1;  // sampler output: one translation for all hypotheses
   const size_t half = (size_t)N * FP_NN_IN_IMG_HALFS;
-  if (render_and_crop(m, t, N, 1.1f /* score_mode_crop_ratio_ foundationpose.cpp:88 */, OUT_F16X8, m->nn_in,
-                      m->nn_in + half, nullptr, nullptr))
+  if (run_graphed(m, m->rg, t, H, W, refine_itr, N, graphable, [&]() {
+        for (int it = 0; it < refine_itr; it++)
+          if (refine_iteration(m, t, N, it == 0 && N > 1)) return 1;  // sampler output: one translation for all hypotheses
+        if (render_and_crop(m, t, N, 1.1f /* score_mode_crop_ratio_ foundationpose.cpp:88 */, OUT_F16X8, m->nn_in,
+                            m->nn_in + half, nullptr, nullptr))
+          return 1;
+        checkpoint(m, 8, m->clip, (size_t)N * t->mesh.V * 16);
+        checkpoint(m, 9, m->attr, (size_t)N * t->mesh.V * 16);
+        checkpoint(m, 10, m->nn_in, (size_t)N * FP_NN_IN_IMG_HALFS * 2);
+        checkpoint(m, 11, m->nn_in + half, (size_t)N * FP_NN_IN_IMG_HALFS * 2);
+        if (scorer_features(m->stream, &m->prof, m->scorer, m->ws, m->nn_in, N, m->feat_dev)) return 1;
+        checkpoint(m, 12, m->feat_dev, (size_t)N * 512 * 4);
+        return 0;
+      }))
     return 1;
-  checkpoint(m, 8, m->clip, (size_t)N * t->mesh.V * 16);
-  checkpoint(m, 9, m->attr, (size_t)N * t->mesh.V * 16);
-  checkpoint(m, 10, m->nn_in, (size_t)N * FP_NN_IN_IMG_HALFS * 2);
-  checkpoint(m, 11, m->nn_in + half, (size_t)N * FP_NN_IN_IMG_HALFS * 2);
-  if (scorer_features(m->stream, &m->prof, m->scorer, m->ws, m->nn_in, N, m->feat_dev)) return 1;
-  checkpoint(m, 12, m->feat_dev, (size_t)N * 512 * 4);
   if (feat_dev) *feat_dev = m->feat_dev;
   if (poses_dev) *poses_dev = m->poses_dev;
   FP_HIP_OK(hipStreamSynchronize(m->stream));  // the returned buffers are complete (and the GPU lock may be released)
@@ -879,12 +951,6 @@ int fp_register(fp_model *m, const uint8_t *rgb, const float *depth, const uint8
   return fp_register_ex(m, rgb, depth, mask, FP_HOST, H, W, target_name, refine_itr, out_pose);
 }
 
-static void drop_track_graph(fp_model *m) {
-  if (m->tg.exec) (void)hipGraphExecDestroy(m->tg.exec);
-  if (m->tg.graph) (void)hipGraphDestroy(m->tg.graph);
-  m->tg.exec = nullptr; m->tg.graph = nullptr; m->tg.eager_calls = 0;
-}
-
 int fp_track_ex(fp_model *m, const void *rgb, const void *depth, int memspace, int H, int W, const float hyp_pose[16],
                 const char *target_name, int refine_itr, float out_pose[16]) {
   FP_GPU_LOCK();
@@ -892,58 +958,15 @@ int fp_track_ex(fp_model *m, const void *rgb, const void *depth, int memspace, i
   if (check_frame_args(m, H, W, target_name ? target_name : "", &t)) return 1;
   FP_CHECK(m->refiner, "[FoundationPose] refiner weights not loaded");
   FP_CHECK(hyp_pose && out_pose, "[FoundationPose] Track: null pose");
-  const bool graphable = m->use_graphs && !m->prof.on && refine_itr >= 1;
-  if (graphable) {
-    // the graph reads the frame from the model's own buffers, so a caller's device frame is copied in (2 MB D2D)
-    if (memspace == FP_DEVICE) {
-      // size the owned buffers without copying, then D2D
-      size_t px0 = (size_t)H * W;
-      if (px0 > m->frame_cap) {
-        g_alloc_epoch++;
-        dev_free(m->rgb_own); dev_free(m->depth_own); dev_free(m->erode); dev_free(m->bilat); dev_free(m->xyz);
-        if (dev_alloc(&m->rgb_own, px0 * 3) || dev_alloc(&m->depth_own, px0) || dev_alloc(&m->erode, px0) || dev_alloc(&m->bilat, px0)) return 1;
-        m->frame_cap = px0;
-      }
-      m->H = H; m->W = W; m->rgb = m->rgb_own; m->depth = m->depth_own;
-    } else if (upload_frame_async(m, rgb, depth, FP_HOST, H, W)) {
-      return 1;
-    }
-    if (memspace == FP_DEVICE) {
-      const size_t px = (size_t)H * W;
-      FP_HIP_OK(hipMemcpyAsync(m->rgb_own, rgb, px * 3, hipMemcpyDeviceToDevice, m->stream));
-      FP_HIP_OK(hipMemcpyAsync(m->depth_own, depth, px * 4, hipMemcpyDeviceToDevice, m->stream));
-    }
-  } else {
-    if (upload_frame_async(m, rgb, depth, memspace, H, W)) return 1;
-  }
+  const bool graphable = m->use_graphs && !m->prof.on && !m->digests && refine_itr >= 1;
+  if (graphable ? stage_frame_owned(m, rgb, depth, memspace, H, W) : upload_frame_async(m, rgb, depth, memspace, H, W)) return 1;
   if (upload_poses(m, t, hyp_pose, 1)) return 1;
-  auto &g = m->tg;
-  const bool same = g.target == t && g.H == H && g.W == W && g.itr == refine_itr && g.epoch == g_alloc_epoch;
-  if (graphable && same && g.exec) {
-    FP_HIP_OK(hipGraphLaunch(g.exec, m->stream));
-  } else if (graphable && same && g.eager_calls >= 1) {
-    // second call with stable allocations: capture and run
-    drop_track_graph(m);
-    FP_HIP_OK(hipStreamBeginCapture(m->stream, hipStreamCaptureModeThreadLocal));
-    int rc = 0;
-    for (int it = 0; it < refine_itr && !rc; it++) rc = refine_iteration(m, t, 1, false);
-    hipError_t e = hipStreamEndCapture(m->stream, &g.graph);
-    if (rc || e != hipSuccess || hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0) != hipSuccess) {
-      drop_track_graph(m);
-      m->use_graphs = false;  // fall back to eager launches for good
-      for (int it = 0; it < refine_itr; it++)
-        if (refine_iteration(m, t, 1, false)) return 1;
-    } else {
-      g.eager_calls = 1;
-      FP_HIP_OK(hipGraphLaunch(g.exec, m->stream));
-    }
-  } else {
-    if (!same) { drop_track_graph(m); g.target = t; g.H = H; g.W = W; g.itr = refine_itr; }
-    for (int it = 0; it < refine_itr; it++)
-      if (refine_iteration(m, t, 1, false)) return 1;
-    g.epoch = g_alloc_epoch;  // allocations made by this eager call are now settled
-    g.eager_calls = graphable ? g.eager_calls + 1 : 0;
-  }
+  if (run_graphed(m, m->tg, t, H, W, refine_itr, 1, graphable, [&]() {
+        for (int it = 0; it < refine_itr; it++)
+          if (refine_iteration(m, t, 1, false)) return 1;
+        return 0;
+      }))
+    return 1;
   FP_HIP_OK(hipMemcpyAsync(out_pose, m->poses_dev, 64, hipMemcpyDeviceToHost, m->stream));
   FP_HIP_OK(hipStreamSynchronize(m->stream));
   return 0;
