@@ -158,47 +158,6 @@ std::vector<float> make_rotation_grid(int min_views, int inplane_steps) {
 }
 
 // GuessTranslation (D6F/src/foundationpose_sampling.cpp:250-298) on host buffers
-static int guess_translation(const float *depth, const uint8_t *mask, int H, int W, const float *K, float min_depth,
-                             float center[3]) {
-  int umin = W, umax = -1, vmin = H, vmax = -1;
-  std::vector<float> vals;
-  for (int i = 0; i < H; i++)
-    for (int j = 0; j < W; j++)
-      if (mask[(size_t)i * W + j] > 0) {
-        umin = std::min(umin, j); umax = std::max(umax, j);
-        vmin = std::min(vmin, i); vmax = std::max(vmax, i);
-        float d = depth[(size_t)i * W + j];
-        if (d >= min_depth) vals.push_back(d);
-      }
-  FP_CHECK(umax >= 0, "[FoundationposeSampling] Mask is all zero.");
-  FP_CHECK(!vals.empty(), "[FoundationposeSampling] No valid value in mask.");
-  float uc = (float)((umin + umax) / 2.0), vc = (float)((vmin + vmax) / 2.0);
-  size_t n = vals.size();
-  float zc;
-  std::nth_element(vals.begin(), vals.begin() + n / 2, vals.end());
-  float hi = vals[n / 2];
-  if (n % 2 == 0) {
-    float lo = *std::max_element(vals.begin(), vals.begin() + n / 2);
-    zc = (float)((lo + hi) / 2.0);
-  } else {
-    zc = hi;
-  }
-  // K.inverse() * (uc,vc,1) * zc : cofactor inverse in float
-  const float *m = K;
-  float c00 = m[4] * m[8] - m[5] * m[7], c01 = m[5] * m[6] - m[3] * m[8], c02 = m[3] * m[7] - m[4] * m[6];
-  float det = m[0] * c00 + m[1] * c01 + m[2] * c02, id = 1.0f / det;
-  float Ki[9] = {c00 * id, (m[2] * m[7] - m[1] * m[8]) * id, (m[1] * m[5] - m[2] * m[4]) * id,
-                 c01 * id, (m[0] * m[8] - m[2] * m[6]) * id, (m[2] * m[3] - m[0] * m[5]) * id,
-                 c02 * id, (m[1] * m[6] - m[0] * m[7]) * id, (m[0] * m[4] - m[1] * m[3]) * id};
-  for (int r = 0; r < 3; r++) {
-    float s = Ki[r * 3] * uc;
-    s = s + Ki[r * 3 + 1] * vc;
-    s = s + Ki[r * 3 + 2] * 1.0f;
-    center[r] = s * zc;
-  }
-  return 0;
-}
-
 template <typename T>
 static int dev_alloc(T **p, size_t count) {
   FP_HIP_OK(hipMalloc((void **)p, std::max<size_t>(count, 1) * sizeof(T)));
@@ -235,10 +194,12 @@ struct fp_model {
   const uint8_t *rgb = nullptr;   // device
   const float *depth = nullptr;   // device
   float *erode = nullptr, *bilat = nullptr, *xyz = nullptr;
-  // pinned read-back buffers of the sampler (pageable destinations made the 1.2 MB D2H take up to 1.5 ms on early calls)
-  float *bilat_host = nullptr;
-  uint8_t *mask_host = nullptr;
-  size_t host_px_cap = 0;
+  // device-side sampler (GuessTranslation): rotation grid, scan state (int[8]), compacted depth list, mask copy
+  float *grid_dev = nullptr;
+  int *samp_state = nullptr;
+  float *samp_vals = nullptr;
+  uint8_t *mask_dev = nullptr;
+  size_t samp_px_cap = 0;
   size_t frame_cap = 0;
 
   // per-hypothesis scratch
@@ -378,6 +339,7 @@ static void checkpoint(fp_model *m, int slot, const void *buf, size_t bytes) {
 }
 
 static int upload_frame_async(fp_model *m, const void *rgb, const void *depth, int memspace, int H, int W);
+static int set_rotation_grid(fp_model *m, int steps);
 
 static void drop_graph(fp_model::GraphSlot &g) {
   if (g.exec) (void)hipGraphExecDestroy(g.exec);
@@ -540,7 +502,7 @@ fp_model *fp_create(const fp_mesh *meshes, int n_meshes, const float K[9], const
       return nullptr;
     }
   }
-  m->grid_host = make_rotation_grid(40, m->inplane_steps);
+  if (set_rotation_grid(m.get(), m->inplane_steps)) { fp_destroy(m.release()); return nullptr; }
   m->ws = nn_scratch_create();
   std::string err;
   if (refiner_weights) {
@@ -569,8 +531,7 @@ void fp_destroy(fp_model *m) {
   dev_free(m->blob_a); dev_free(m->blob_b); dev_free(m->trans_dev); dev_free(m->rot_dev); dev_free(m->scores_dev);
   dev_free(m->feat_dev); dev_free(m->argmax_dev); dev_free(m->scores_all); dev_free(m->dbg_tri); dev_free(m->dbg_rast);
   if (m->poses_pinned) (void)hipHostFree(m->poses_pinned);
-  if (m->bilat_host) (void)hipHostFree(m->bilat_host);
-  if (m->mask_host) (void)hipHostFree(m->mask_host);
+  dev_free(m->grid_dev); dev_free(m->samp_state); dev_free(m->samp_vals); dev_free(m->mask_dev);
   if (m->digests) (void)hipFree(m->digests);
   if (m->refiner) net_free(m->refiner);
   if (m->scorer) net_free(m->scorer);
@@ -581,9 +542,9 @@ void fp_destroy(fp_model *m) {
 
 int fp_set_inplane_steps(fp_model *m, int steps) {
   FP_CHECK(m && steps >= 1 && steps <= 360, "[FoundationPose] fp_set_inplane_steps: invalid arguments");
-  m->inplane_steps = steps;
-  m->grid_host = make_rotation_grid(40, steps);
-  return 0;
+  FP_GPU_LOCK();
+  FP_HIP_OK(hipStreamSynchronize(m->stream));
+  return set_rotation_grid(m, steps);
 }
 int fp_num_hypotheses(const fp_model *m) { return m ? m->n_hyp() : 0; }
 void *fp_stream(fp_model *m) { return m ? (void *)m->stream : nullptr; }
@@ -663,45 +624,70 @@ int fp_filter_depth(fp_model *m, float *eroded_out, float *bilateral_out) {
   return 0;
 }
 
-// GetHypPoses (D6F/src/foundationpose_sampling.cpp:344-394) -> m->poses_dev[0..n) and optional host copy
-static int sample_hypotheses(fp_model *m, const void *mask, int memspace, std::vector<float> &poses) {
+// MakeRotationGrid result, host + device copies (device: the sampler kernel stamps the translation into it)
+static int set_rotation_grid(fp_model *m, int steps) {
+  m->inplane_steps = steps;
+  m->grid_host = make_rotation_grid(40, steps);
+  g_alloc_epoch++;
+  dev_free(m->grid_dev);
+  if (dev_alloc(&m->grid_dev, m->grid_host.size())) return 1;
+  FP_HIP_OK(hipMemcpy(m->grid_dev, m->grid_host.data(), m->grid_host.size() * 4, hipMemcpyHostToDevice));
+  return 0;
+}
+
+// GetHypPoses (D6F/src/foundationpose_sampling.cpp:344-394), entirely on the device: erode + bilateral, then
+// GuessTranslation (bounding box of the mask, exact median of the filtered depth under it) and the hypothesis poses
+// [first, first+N) of the rotation grid written to m->poses_dev.  No read-back, no synchronisation: the status word
+// (sampler_status) is fetched together with the results.
+static int sample_hypotheses_async(fp_model *m, Target *t, const void *mask, int memspace, int first, int N) {
   FP_CHECK(m->depth != nullptr && mask != nullptr, "[FoudationPoseSampler] Got INVALID depth/mask ptr on device!!!");
-  size_t px = (size_t)m->H * m->W;
+  const size_t px = (size_t)m->H * m->W;
+  if (ensure_capacity(m, N, t ? (size_t)t->mesh.V : 0)) return 1;
+  if (px > m->samp_px_cap) {
+    g_alloc_epoch++;
+    dev_free(m->samp_vals); dev_free(m->mask_dev);
+    m->samp_px_cap = 0;
+    if (dev_alloc(&m->samp_vals, px) || dev_alloc(&m->mask_dev, px)) return 1;
+    m->samp_px_cap = px;
+  }
+  if (!m->samp_state) {
+    if (dev_alloc(&m->samp_state, 8)) return 1;
+    const int init[8] = {0x7fffffff, -1, 0x7fffffff, -1, 0, 0, 3, 0};
+    FP_HIP_OK(hipMemcpy(m->samp_state, init, sizeof(init), hipMemcpyHostToDevice));
+    g_alloc_epoch++;
+  }
   run_depth_filters(m);
-  if (px > m->host_px_cap) {
-    if (m->bilat_host) (void)hipHostFree(m->bilat_host);
-    if (m->mask_host) (void)hipHostFree(m->mask_host);
-    m->bilat_host = nullptr; m->mask_host = nullptr; m->host_px_cap = 0;
-    FP_HIP_OK(hipHostMalloc((void **)&m->bilat_host, px * sizeof(float), hipHostMallocDefault));
-    FP_HIP_OK(hipHostMalloc((void **)&m->mask_host, px, hipHostMallocDefault));
-    m->host_px_cap = px;
+  const uint8_t *mask_d = (const uint8_t *)mask;
+  if (memspace != FP_DEVICE) {  // the caller's host mask stays valid until the entry point returns (it synchronises)
+    FP_HIP_OK(hipMemcpyAsync(m->mask_dev, mask, px, hipMemcpyHostToDevice, m->stream));
+    mask_d = m->mask_dev;
   }
-  {
-    ProfScope ps(&m->prof, m->stream, "d2h_filtered_depth", 0, (double)px * 4);
-    FP_HIP_OK(hipMemcpyAsync(m->bilat_host, m->bilat, px * 4, hipMemcpyDeviceToHost, m->stream));
-  }
-  const uint8_t *mask_h = (const uint8_t *)mask;
-  if (memspace == FP_DEVICE) {
-    FP_HIP_OK(hipMemcpyAsync(m->mask_host, mask, px, hipMemcpyDeviceToHost, m->stream));
-    mask_h = m->mask_host;
-  }
+  ProfScope ps(&m->prof, m->stream, "sampler", 0, (double)px * 5);
+  launch_sampler(m->stream, m->bilat, mask_d, m->H, m->W, FP_MIN_DEPTH, m->K, m->grid_dev, first, N, m->samp_state, m->samp_vals,
+                 m->poses_dev);
+  return 0;
+}
+
+// after a synchronisation: the reference's failure modes (foundationpose_sampling.cpp:269,278)
+static int sampler_status(fp_model *m) {
+  int st = 3;
+  FP_HIP_OK(hipMemcpyAsync(&st, m->samp_state + 6, 4, hipMemcpyDeviceToHost, m->stream));
   FP_HIP_OK(hipStreamSynchronize(m->stream));
-  float center[3];
-  if (guess_translation(m->bilat_host, mask_h, m->H, m->W, m->K, FP_MIN_DEPTH, center)) return 1;
-  poses = m->grid_host;
-  for (size_t i = 0; i < poses.size() / 16; i++) {
-    poses[i * 16 + 12] = center[0]; poses[i * 16 + 13] = center[1]; poses[i * 16 + 14] = center[2];
-  }
+  FP_CHECK(st != 1, "[FoundationposeSampling] Mask is all zero.");
+  FP_CHECK(st != 2, "[FoundationposeSampling] No valid value in mask.");
+  FP_CHECK(st == 0, "[FoundationposeSampling] sampler did not run");
   return 0;
 }
 
 int fp_get_hyp_poses(fp_model *m, const void *mask, int memspace, float *poses_out, int *n_out) {
   FP_GPU_LOCK();
   FP_CHECK(m && poses_out, "[FoundationPose] fp_get_hyp_poses: invalid arguments");
-  std::vector<float> poses;
-  if (sample_hypotheses(m, mask, memspace, poses)) return 1;
-  std::memcpy(poses_out, poses.data(), poses.size() * sizeof(float));
-  if (n_out) *n_out = (int)(poses.size() / 16);
+  const int n = m->n_hyp();
+  if (sample_hypotheses_async(m, m->targets.empty() ? nullptr : &m->targets[0], mask, memspace, 0, n)) return 1;
+  if (sampler_status(m)) return 1;
+  FP_HIP_OK(hipMemcpyAsync(poses_out, m->poses_dev, (size_t)n * 64, hipMemcpyDeviceToHost, m->stream));
+  FP_HIP_OK(hipStreamSynchronize(m->stream));
+  if (n_out) *n_out = n;
   return 0;
 }
 
@@ -870,13 +856,8 @@ int fp_register_shard_begin(fp_model *m, const void *rgb, const void *depth, con
            "[FoundationPose] hypothesis shard out of range");
   const bool graphable = m->use_graphs && !m->prof.on && !m->digests && refine_itr >= 1;
   if (graphable ? stage_frame_owned(m, rgb, depth, memspace, H, W) : upload_frame_async(m, rgb, depth, memspace, H, W)) return 1;
-  std::vector<float> poses;
-  if (sample_hypotheses(m, mask, memspace, poses)) {
-    set_error(std::string("[FoundationPose] Failed to generate hyp poses!!! ") + g_last_error);
-    return 1;
-  }
   const int N = shard_count;
-  if (upload_poses(m, t, poses.data() + (size_t)shard_begin * 16, N)) return 1;
+  if (sample_hypotheses_async(m, t, mask, memspace, shard_begin, N)) return 1;
   const size_t half = (size_t)N * FP_NN_IN_IMG_HALFS;
   if (run_graphed(m, m->rg, t, H, W, refine_itr, N, graphable, [&]() {
         for (int it = 0; it < refine_itr; it++)
@@ -895,7 +876,11 @@ int fp_register_shard_begin(fp_model *m, const void *rgb, const void *depth, con
     return 1;
   if (feat_dev) *feat_dev = m->feat_dev;
   if (poses_dev) *poses_dev = m->poses_dev;
-  FP_HIP_OK(hipStreamSynchronize(m->stream));  // the returned buffers are complete (and the GPU lock may be released)
+  // synchronises: the returned buffers are complete (and the GPU lock may be released); reports the sampler's verdict
+  if (sampler_status(m)) {
+    set_error(std::string("[FoundationPose] Failed to generate hyp poses!!! ") + g_last_error);
+    return 1;
+  }
   return 0;
 }
 

@@ -511,6 +511,134 @@ void launch_raster_shade(hipStream_t s, const DeviceMesh &m, const PoseRec *recs
 }
 
 // ---------------------------------------------------------------------------------------------
+// GuessTranslation on the device (foundationpose_sampling.cpp:250-298): no 1.2 MB read-back, no host median, no
+// synchronisation in the middle of Register.
+//   sampler_scan_kernel : bounding box of mask > 0 and a compacted list of the filtered depths with mask > 0 and
+//                         depth >= min_depth (order arbitrary: only order statistics are taken from it)
+//   sampler_pose_kernel : one workgroup; exact median by a 4-pass radix select on the float bit patterns (positive
+//                         floats order like their bits; even counts average the two middle values in double like the
+//                         reference), centre = K^-1 (uc, vc, 1) zc in the host code's float expression order, then
+//                         poses[i] = grid[first + i] with that translation.  state[6] = 0 ok / 1 empty mask / 2 no depth.
+// state layout (ints): 0 umin, 1 umax, 2 vmin, 3 vmax, 4 count, 5 (unused), 6 status
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sampler_scan_kernel(const float *__restrict__ depth, const uint8_t *__restrict__ mask,
+                                                           int H, int W, float min_depth, int *__restrict__ state,
+                                                           float *__restrict__ vals) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const bool in = i < H * W;
+  const bool m = in && mask[i] > 0;
+  const int v = in ? i / W : 0, u = in ? i - v * W : 0;
+  if (__any(m)) {
+    int umin = m ? u : 0x7fffffff, umax = m ? u : -1, vmin = m ? v : 0x7fffffff, vmax = m ? v : -1;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      umin = min(umin, __shfl_xor(umin, o)); umax = max(umax, __shfl_xor(umax, o));
+      vmin = min(vmin, __shfl_xor(vmin, o)); vmax = max(vmax, __shfl_xor(vmax, o));
+    }
+    if ((threadIdx.x & 63) == 0) {
+      atomicMin(&state[0], umin); atomicMax(&state[1], umax);
+      atomicMin(&state[2], vmin); atomicMax(&state[3], vmax);
+    }
+  }
+  const float d = m ? depth[i] : 0.f;
+  const bool valid = m && d >= min_depth;
+  const unsigned long long ball = __ballot(valid);
+  if (ball) {
+    const int lane = threadIdx.x & 63;
+    int base = 0;
+    if (lane == 0) base = atomicAdd(&state[4], __popcll(ball));
+    base = __shfl(base, 0);
+    if (valid) vals[base + __popcll(ball & ((1ull << lane) - 1ull))] = d;
+  }
+}
+
+// k-th smallest (0-based) of keys[0..n): 4 passes over 8-bit digits, most significant first
+__device__ unsigned radix_select(const unsigned *keys, int n, int k, unsigned *hist /* LDS [256] */, unsigned *sh /* LDS [2] */) {
+  unsigned prefix = 0, pmask = 0;
+  for (int pass = 3; pass >= 0; pass--) {
+    for (int b = threadIdx.x; b < 256; b += blockDim.x) hist[b] = 0;
+    __syncthreads();
+    const int shift = pass * 8;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+      unsigned key = keys[i];
+      if ((key & pmask) == prefix) atomicAdd(&hist[(key >> shift) & 255], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      unsigned acc = 0, b = 0;
+      for (; b < 256; b++) {
+        if (acc + hist[b] > (unsigned)k) break;
+        acc += hist[b];
+      }
+      sh[0] = b; sh[1] = acc;
+    }
+    __syncthreads();
+    prefix |= sh[0] << shift;
+    pmask |= 255u << shift;
+    k -= (int)sh[1];
+    __syncthreads();
+  }
+  return prefix;
+}
+
+__global__ __launch_bounds__(1024) void sampler_pose_kernel(int *__restrict__ state, const float *__restrict__ vals, K9 K,
+                                                            const float *__restrict__ grid, int first, int N,
+                                                            float *__restrict__ poses) {
+  __shared__ unsigned hist[256];
+  __shared__ unsigned sh[2];
+  __shared__ float center[3];
+  const int n = state[4];
+  const int umin = state[0], umax = state[1], vmin = state[2], vmax = state[3];
+  const bool bad = umax < 0 || n <= 0;  // uniform over the workgroup
+  const unsigned *keys = reinterpret_cast<const unsigned *>(vals);
+  unsigned hi_bits = 0, lo_bits = 0;
+  if (!bad) {
+    hi_bits = radix_select(keys, n, n / 2, hist, sh);
+    lo_bits = hi_bits;
+    if ((n & 1) == 0) lo_bits = radix_select(keys, n, n / 2 - 1, hist, sh);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    // leave the scan state ready for the next frame (the status word is read back by the host after this launch)
+    state[0] = 0x7fffffff; state[1] = -1; state[2] = 0x7fffffff; state[3] = -1; state[4] = 0;
+    state[6] = bad ? (umax < 0 ? 1 : 2) : 0;
+  }
+  if (bad) return;
+  if (threadIdx.x == 0) {
+    const float hi = __uint_as_float(hi_bits), lo = __uint_as_float(lo_bits);
+    const float zc = (n & 1) ? hi : (float)(((double)lo + (double)hi) / 2.0);
+    const float uc = (float)((umin + umax) / 2.0), vc = (float)((vmin + vmax) / 2.0);
+    const float *m = K.k;
+    float c00 = m[4] * m[8] - m[5] * m[7], c01 = m[5] * m[6] - m[3] * m[8], c02 = m[3] * m[7] - m[4] * m[6];
+    float det = m[0] * c00 + m[1] * c01 + m[2] * c02, id = 1.0f / det;
+    float Ki[9] = {c00 * id, (m[2] * m[7] - m[1] * m[8]) * id, (m[1] * m[5] - m[2] * m[4]) * id,
+                   c01 * id, (m[0] * m[8] - m[2] * m[6]) * id, (m[2] * m[3] - m[0] * m[5]) * id,
+                   c02 * id, (m[1] * m[6] - m[0] * m[7]) * id, (m[0] * m[4] - m[1] * m[3]) * id};
+    for (int r = 0; r < 3; r++) {
+      float sacc = Ki[r * 3] * uc;
+      sacc = sacc + Ki[r * 3 + 1] * vc;
+      sacc = sacc + Ki[r * 3 + 2] * 1.0f;
+      center[r] = sacc * zc;
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < N * 16; i += blockDim.x) {
+    const int e = i & 15;
+    poses[i] = (e >= 12 && e < 15) ? center[e - 12] : grid[(size_t)first * 16 + i];
+  }
+}
+
+void launch_sampler(hipStream_t s, const float *filtered_depth, const uint8_t *mask_dev, int H, int W, float min_depth,
+                    const float *K9_host, const float *grid_dev, int first, int N, int *state, float *vals, float *poses) {
+  // `state` was initialised when it was allocated and every sampler_pose_kernel launch resets it for the next frame
+  hipLaunchKernelGGL(sampler_scan_kernel, dim3((H * W + 255) / 256), dim3(256), 0, s, filtered_depth, mask_dev, H, W, min_depth,
+                     state, vals);
+  K9 K;
+  for (int i = 0; i < 9; i++) K.k[i] = K9_host[i];
+  hipLaunchKernelGGL(sampler_pose_kernel, dim3(1), dim3(1024), 0, s, state, vals, K, grid_dev, first, N, poses);
+}
+
+// ---------------------------------------------------------------------------------------------
 // crop / warp of the observed RGB-D frame
 // ---------------------------------------------------------------------------------------------
 

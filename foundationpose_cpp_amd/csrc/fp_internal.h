@@ -119,6 +119,9 @@ void launch_bilateral(hipStream_t s, const float *depth, float *out, int H, int 
 void launch_pose_update(hipStream_t s, float *poses, const float *trans, const float *rot, int N, float diameter);
 // first-max arg-max over scores[N] -> *index (foundationpose_decoder.cu:24-35)
 void launch_argmax(hipStream_t s, const float *scores, int N, int *index_dev);
+// GuessTranslation + hypothesis poses on the device; state = int[8] (status in state[6]: 0 ok, 1 empty mask, 2 no valid depth)
+void launch_sampler(hipStream_t s, const float *filtered_depth, const uint8_t *mask_dev, int H, int W, float min_depth,
+                    const float *K9_host, const float *grid_dev, int first, int N, int *state, float *vals, float *poses);
 // f32 [N,160,160,6] -> f16 [N,160,160,8] (blob-mode entry points feeding the f16 networks)
 void launch_pack_f32x6_to_f16x8(hipStream_t s, const float *in, __half *out, size_t pixels);
 

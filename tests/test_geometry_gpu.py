@@ -33,7 +33,8 @@ def hyp(model, syn_scene):
 def test_rotation_grid_and_translation_match_oracle(hyp, syn_scene):
     ref = syn.from_colmajor(fo.get_hyp_poses(syn_scene.depth, syn_scene.mask, syn_scene.K))
     np.testing.assert_allclose(hyp[:, :3, :3], ref[:, :3, :3], atol=1e-6)
-    np.testing.assert_allclose(hyp[:, :3, 3], ref[:, :3, 3], rtol=1e-5)
+    # GuessTranslation runs on the device (exact radix-select median, the host code's float expression order): bit-exact
+    np.testing.assert_array_equal(hyp[:, :3, 3], ref[:, :3, 3])
 
 
 def test_depth_filters_and_xyz(model, syn_scene):
@@ -157,3 +158,43 @@ def test_pose_update_and_argmax(model, syn_mesh):
     s[[17, 500, 900]] = s.max() + 1
     assert model.argmax(s) == 17 == fo.argmax(s)
     assert model.argmax(s[:1]) == 0
+
+
+def test_device_sampler_median_cases(syn_mesh):
+    """GuessTranslation on the device against the oracle for odd / even counts, duplicates, one pixel and a full-frame
+    mask (exact median: even counts average the two middle values; foundationpose_sampling.cpp:276-294)."""
+    m = FoundationPose(syn_mesh, syn.intrinsics())
+    rng = np.random.default_rng(12)
+    H, W = 480, 640
+    K = syn.intrinsics()
+    rgb = np.zeros((H, W, 3), np.uint8)
+    for case in range(6):
+        depth = np.full((H, W), 0.8, np.float32)
+        mask = np.zeros((H, W), np.uint8)
+        if case == 0:      # odd count, distinct values
+            mask[100:103, 200:211] = 1                     # 33 pixels
+            depth[100:103, 200:211] = rng.uniform(0.5, 0.9, (3, 11)).astype(np.float32)
+        elif case == 1:    # even count
+            mask[50:54, 300:310] = 255                     # 40 pixels
+            depth[50:54, 300:310] = rng.uniform(0.5, 0.9, (4, 10)).astype(np.float32)
+        elif case == 2:    # many duplicates (quantised depth)
+            mask[200:260, 100:180] = 1
+            depth[200:260, 100:180] = (rng.integers(600, 610, (60, 80)) / 1000.0).astype(np.float32)
+        elif case == 3:    # single pixel
+            mask[7, 9] = 1
+            depth[7, 9] = 0.731
+        elif case == 4:    # full-frame mask with holes in the depth
+            mask[:] = 1
+            depth = rng.uniform(0.3, 1.2, (H, W)).astype(np.float32)
+            depth[rng.uniform(size=(H, W)) < 0.3] = 0.0
+        else:              # two blobs: bounding box spans both
+            mask[10:20, 10:20] = 1
+            mask[400:410, 600:620] = 1
+            depth[:] = (0.5 + 0.0001 * np.arange(W, dtype=np.float32))[None, :]     # smooth ramp (noise would be eroded away)
+        m.upload_frame(rgb, depth)
+        got = m.get_hyp_poses(mask)
+        ref = fo.get_hyp_poses(depth, mask, K)
+        assert (got is None) == (ref is None), (case, m.last_error)
+        assert got is not None, (case, m.last_error)
+        np.testing.assert_array_equal(got[0, :3, 3], syn.from_colmajor(ref[:1])[0, :3, 3], err_msg=f"case {case}")
+    m.close()
