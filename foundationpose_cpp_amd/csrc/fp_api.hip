@@ -212,6 +212,10 @@ struct fp_model {
   float *blob_a = nullptr, *blob_b = nullptr;  // [cap,160,160,6] f32 (blob-mode entry points only)
   float *trans_dev = nullptr, *rot_dev = nullptr, *scores_dev = nullptr, *feat_dev = nullptr;
   int *argmax_dev = nullptr;
+  // one read-back per Register: device [pose16] + pinned host mirror {idx, sampler status, pose16}
+  float *best_pose_dev = nullptr;
+  int *result_pinned = nullptr;  // 18 words
+  bool defer_begin_sync = false;  // fp_register_ex: shard_begin leaves its synchronisation to shard_finish
   float *scores_all = nullptr;  // scores of the gathered hypotheses of every rank (sharded Register)
   int scores_all_cap = 0;
   int32_t *dbg_tri = nullptr;
@@ -529,7 +533,8 @@ void fp_destroy(fp_model *m) {
   dev_free(m->rgb_own); dev_free(m->depth_own); dev_free(m->erode); dev_free(m->bilat); dev_free(m->xyz);
   dev_free(m->recs); dev_free(m->poses_dev); dev_free(m->clip); dev_free(m->attr); dev_free(m->nn_in);
   dev_free(m->blob_a); dev_free(m->blob_b); dev_free(m->trans_dev); dev_free(m->rot_dev); dev_free(m->scores_dev);
-  dev_free(m->feat_dev); dev_free(m->argmax_dev); dev_free(m->scores_all); dev_free(m->dbg_tri); dev_free(m->dbg_rast);
+  dev_free(m->feat_dev); dev_free(m->argmax_dev); dev_free(m->scores_all); dev_free(m->best_pose_dev);
+  if (m->result_pinned) (void)hipHostFree(m->result_pinned); dev_free(m->dbg_tri); dev_free(m->dbg_rast);
   if (m->poses_pinned) (void)hipHostFree(m->poses_pinned);
   dev_free(m->grid_dev); dev_free(m->samp_state); dev_free(m->samp_vals); dev_free(m->mask_dev);
   if (m->digests) (void)hipFree(m->digests);
@@ -876,6 +881,7 @@ int fp_register_shard_begin(fp_model *m, const void *rgb, const void *depth, con
     return 1;
   if (feat_dev) *feat_dev = m->feat_dev;
   if (poses_dev) *poses_dev = m->poses_dev;
+  if (m->defer_begin_sync) return 0;  // fp_register_ex: one synchronisation at the very end
   // synchronises: the returned buffers are complete (and the GPU lock may be released); reports the sampler's verdict
   if (sampler_status(m)) {
     set_error(std::string("[FoundationPose] Failed to generate hyp poses!!! ") + g_last_error);
@@ -899,22 +905,32 @@ int fp_register_shard_finish(fp_model *m, const float *all_feat_dev, const float
     }
     scores = m->scores_all;
   }
+  if (!m->best_pose_dev && dev_alloc(&m->best_pose_dev, 16)) return 1;
+  if (!m->result_pinned) FP_HIP_OK(hipHostMalloc((void **)&m->result_pinned, 18 * sizeof(int), hipHostMallocDefault));
   int rc = scorer_head(m->stream, &m->prof, m->scorer, m->ws, all_feat_dev, N_total, scores);
   if (!rc) checkpoint(m, 13, scores, (size_t)N_total * 4);
   if (!rc) {
     ProfScope ps(&m->prof, m->stream, "argmax");
-    launch_argmax(m->stream, scores, N_total, m->argmax_dev);
+    launch_argmax(m->stream, scores, N_total, m->argmax_dev, all_poses_dev, m->best_pose_dev);
   }
-  int idx = 0;
-  if (!rc && hipMemcpyAsync(&idx, m->argmax_dev, 4, hipMemcpyDeviceToHost, m->stream) != hipSuccess) rc = 1;
+  // ONE synchronisation: winner index, the sampler's status word (when this call also ran the sampler) and the pose
+  int *res = m->result_pinned;
+  res[1] = 0;
+  if (!rc && hipMemcpyAsync(&res[0], m->argmax_dev, 4, hipMemcpyDeviceToHost, m->stream) != hipSuccess) rc = 1;
+  if (!rc && m->defer_begin_sync && hipMemcpyAsync(&res[1], m->samp_state + 6, 4, hipMemcpyDeviceToHost, m->stream) != hipSuccess) rc = 1;
+  if (!rc && hipMemcpyAsync(&res[2], m->best_pose_dev, 64, hipMemcpyDeviceToHost, m->stream) != hipSuccess) rc = 1;
   if (!rc && scores_host &&
       hipMemcpyAsync(scores_host, scores, (size_t)N_total * 4, hipMemcpyDeviceToHost, m->stream) != hipSuccess)
     rc = 1;
   if (!rc && hipStreamSynchronize(m->stream) != hipSuccess) rc = 1;
-  // (never the legacy null stream: its implicit synchronisation with every blocking stream is what another model's
-  //  thread would be racing against)
-  if (!rc && hipMemcpyAsync(out_pose, all_poses_dev + (size_t)idx * 16, 64, hipMemcpyDeviceToHost, m->stream) != hipSuccess) rc = 1;
-  if (!rc && hipStreamSynchronize(m->stream) != hipSuccess) rc = 1;
+  int idx = 0;
+  if (!rc) {
+    idx = res[0];
+    std::memcpy(out_pose, &res[2], 64);
+    if (res[1] == 1) { set_error("[FoundationPose] Failed to generate hyp poses!!! [FoundationposeSampling] Mask is all zero."); rc = 1; }
+    else if (res[1] == 2) { set_error("[FoundationPose] Failed to generate hyp poses!!! [FoundationposeSampling] No valid value in mask."); rc = 1; }
+    else if (res[1] != 0) { set_error("[FoundationPose] Failed to generate hyp poses!!! sampler did not run"); rc = 1; }
+  }
   if (rc && g_last_error.empty()) set_error("[FoundationPose] fp_register_shard_finish failed");
   if (best_index) *best_index = idx;
   return rc;
@@ -925,10 +941,12 @@ int fp_register_ex(fp_model *m, const void *rgb, const void *depth, const void *
   FP_GPU_LOCK();
   FP_CHECK(m != nullptr, "[FoundationPose] null model");
   float *feat = nullptr, *poses = nullptr;
-  if (fp_register_shard_begin(m, rgb, depth, mask, memspace, H, W, target_name, refine_itr, 0, m->n_hyp(), &feat,
-                              &poses))
-    return 1;
-  return fp_register_shard_finish(m, feat, poses, m->n_hyp(), out_pose, nullptr, nullptr);
+  m->defer_begin_sync = true;  // begin + finish back to back on one stream: a single synchronisation, at the end
+  int rc = fp_register_shard_begin(m, rgb, depth, mask, memspace, H, W, target_name, refine_itr, 0, m->n_hyp(), &feat, &poses);
+  if (!rc) rc = fp_register_shard_finish(m, feat, poses, m->n_hyp(), out_pose, nullptr, nullptr);
+  else (void)hipStreamSynchronize(m->stream);
+  m->defer_begin_sync = false;
+  return rc;
 }
 
 int fp_register(fp_model *m, const uint8_t *rgb, const float *depth, const uint8_t *mask, int H, int W,

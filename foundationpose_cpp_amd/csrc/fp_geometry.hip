@@ -829,7 +829,9 @@ void launch_pose_update(hipStream_t s, float *poses, const float *trans, const f
   hipLaunchKernelGGL(pose_update_kernel, dim3((N + 63) / 64), dim3(64), 0, s, poses, trans, rot, N, diameter);
 }
 
-__global__ void argmax_kernel(const float *__restrict__ scores, int N, int *__restrict__ index) {
+// index[0] = first maximum; when `poses` is given the winner's 4x4 is copied to best_pose so the host needs ONE read-back
+__global__ void argmax_kernel(const float *__restrict__ scores, int N, int *__restrict__ index, const float *__restrict__ poses,
+                              float *__restrict__ best_pose) {
   __shared__ float sv[256];
   __shared__ int si[256];
   int tid = threadIdx.x;
@@ -848,11 +850,13 @@ __global__ void argmax_kernel(const float *__restrict__ scores, int N, int *__re
     }
     __syncthreads();
   }
-  if (tid == 0) *index = si[0] == 0x7FFFFFFF ? 0 : si[0];
+  const int win = si[0] == 0x7FFFFFFF ? 0 : si[0];
+  if (tid == 0) *index = win;
+  if (poses && tid < 16) best_pose[tid] = poses[(size_t)win * 16 + tid];
 }
 
-void launch_argmax(hipStream_t s, const float *scores, int N, int *index_dev) {
-  hipLaunchKernelGGL(argmax_kernel, dim3(1), dim3(256), 0, s, scores, N, index_dev);
+void launch_argmax(hipStream_t s, const float *scores, int N, int *index_dev, const float *poses, float *best_pose_dev) {
+  hipLaunchKernelGGL(argmax_kernel, dim3(1), dim3(256), 0, s, scores, N, index_dev, poses, best_pose_dev);
 }
 
 __global__ void pack_f32x6_to_f16x8_kernel(const float *__restrict__ in, uint4 *__restrict__ out, size_t pixels) {

@@ -118,7 +118,8 @@ void launch_bilateral(hipStream_t s, const float *depth, float *out, int H, int 
 // device-side refine post process: poses updated in place from trans/rot [N,3] (foundationpose.cpp:360-406)
 void launch_pose_update(hipStream_t s, float *poses, const float *trans, const float *rot, int N, float diameter);
 // first-max arg-max over scores[N] -> *index (foundationpose_decoder.cu:24-35)
-void launch_argmax(hipStream_t s, const float *scores, int N, int *index_dev);
+void launch_argmax(hipStream_t s, const float *scores, int N, int *index_dev, const float *poses = nullptr,
+                   float *best_pose_dev = nullptr);
 // GuessTranslation + hypothesis poses on the device; state = int[8] (status in state[6]: 0 ok, 1 empty mask, 2 no valid depth)
 void launch_sampler(hipStream_t s, const float *filtered_depth, const uint8_t *mask_dev, int H, int W, float min_depth,
                     const float *K9_host, const float *grid_dev, int first, int N, int *state, float *vals, float *poses);
