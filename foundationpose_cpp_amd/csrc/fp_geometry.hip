@@ -502,9 +502,32 @@ static void launch_raster_shade_t(hipStream_t s, const DeviceMesh &m, const Pose
 static int g_strip_rows_override = 0;
 void set_raster_strip_rows(int r) { g_strip_rows_override = r; }
 
+// tall strips with 1024-thread workgroups: every strip walks ALL triangles (setup + cull), so 2 strips of 80 rows do a
+// quarter of the redundant setup of 8 strips of 20 (0.40 -> 0.21 ms per Register at N = 252); 102 KB of LDS = one
+// workgroup per CU, hence 16 waves per workgroup.  A/B codes for set_raster_strip_rows: 1080 / 1040 / 1020
+template <int STRIP_ROWS>
+static void launch_raster_tall(hipStream_t s, const DeviceMesh &m, const PoseRec *recs, int N, const float4 *clip,
+                               const float4 *attr, void *out) {
+  size_t lds = (size_t)STRIP_ROWS * CROP * sizeof(unsigned long long);
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void *)raster_shade_kernel<OUT_F16X8, STRIP_ROWS, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((raster_shade_kernel<OUT_F16X8, STRIP_ROWS, 1024>), dim3(CROP / STRIP_ROWS, N), dim3(1024), lds, s, m.faces, m.F,
+                     m.V, m.uvs, m.tex, m.TH, m.TW, m.diameter / 2, recs, clip, attr, out, nullptr, nullptr);
+}
+
 void launch_raster_shade(hipStream_t s, const DeviceMesh &m, const PoseRec *recs, int N, const float4 *clip,
                          const float4 *attr, OutMode mode, void *out, int32_t *tri_id_dbg, float *rast_dbg) {
-  int rows = g_strip_rows_override ? g_strip_rows_override : (N >= 64 ? 20 : 8);  // A/B: tools/ab_raster_strips.py
+  int rows = g_strip_rows_override ? g_strip_rows_override : (N >= 100 ? 1080 : (N >= 64 ? 20 : 8));  // A/B: tools/ab_raster_strips.py
+  if (rows > 1000 && mode == OUT_F16X8 && !tri_id_dbg && !rast_dbg) {
+    if (rows == 1080) launch_raster_tall<80>(s, m, recs, N, clip, attr, out);
+    else if (rows == 1040) launch_raster_tall<40>(s, m, recs, N, clip, attr, out);
+    else launch_raster_tall<20>(s, m, recs, N, clip, attr, out);
+    return;
+  }
+  if (rows > 1000) rows = 20;
   if (rows == 40) launch_raster_shade_t<40>(s, m, recs, N, clip, attr, mode, out, tri_id_dbg, rast_dbg);
   else if (rows == 20) launch_raster_shade_t<20>(s, m, recs, N, clip, attr, mode, out, tri_id_dbg, rast_dbg);
   else launch_raster_shade_t<8>(s, m, recs, N, clip, attr, mode, out, tri_id_dbg, rast_dbg);

@@ -26,4 +26,6 @@ for v in values:
     for k, x in r.items():
         st[k.split("/")[0]] = st.get(k.split("/")[0], 0.0) + x["ms"] / 6
     top = sorted(st.items(), key=lambda kv: -kv[1])[:8]
-    print(f"{hook}({v}): all kernels {sum(st.values()):.3f} ms/step  " + "  ".join(f"{k} {t:.3f}" for k, t in top))
+    watch = os.environ.get("FP_AB_WATCH")
+    extra = f"  [{watch} {st.get(watch, 0.0):.3f}]" if watch else ""
+    print(f"{hook}({v}): all kernels {sum(st.values()):.3f} ms/step{extra}  " + "  ".join(f"{k} {t:.3f}" for k, t in top))
