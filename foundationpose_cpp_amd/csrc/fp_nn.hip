@@ -5,19 +5,22 @@
 // simple_tests/src/test_foundationpose.cpp:24-35).  The architecture is the published NVlabs FoundationPose one
 // (SURVEY.md Appendix B [EXT]); the arithmetic oracle is oracle/nets_torch.py.
 //
-// Kernels
-//   conv_igemm_kernel<BN>  NHWC implicit-GEMM convolution == GEMM with K = KH*KW*Cin on v_mfma_f32_16x16x32_f16.
-//                          128 pixels x BN channels per workgroup, BK = 64.  Operand tiles are staged with
-//                          global_load_lds_dwordx4 (16 B/lane, no VGPR round trip): each wave-instruction moves an
-//                          8-row x 128-B piece; LDS stays lane-linear and the XOR swizzle (slot ^= row&7) is applied to
-//                          the per-lane SOURCE chunk and to the ds_read_b128 fragment address, so fragment reads are
-//                          bank-conflict free.  im2col never touches HBM: the per-lane source address is the tap's
-//                          input pixel, out-of-image taps read a zero page.  Double-buffered LDS, one barrier per K-step.
-//                          The MFMA is issued as D^T = W * X^T so a lane owns 4 consecutive output channels of one
-//                          pixel: bias + residual + ReLU fuse into the epilogue with 8-byte stores.
-//                          The 7x7 stride-2 stem runs through the same kernel as a 4x4 stride-1 conv over the
-//                          space-to-depth input the render/crop kernels emit (fp_geometry.hip s2d_index); Linear layers
-//                          are 1x1 convs; the a|b channel concat is an epilogue addressing mode.
+// Kernels (DESIGN.md section 4.2 has the why and the measurements)
+//   All convolution / Linear schedules are the same contraction D^T[channel][pixel] = W * X^T on
+//   v_mfma_f32_16x16x32_f16 over NHWC activations that carry a physical zero border: operand tiles are staged with
+//   global_load_lds_dwordx4 (16 B/lane LDS-DMA, no VGPR round trip), LDS stays lane-linear and the XOR swizzle is applied
+//   to the per-lane SOURCE chunk and to the ds_read_b128 fragment address (conflict-free); im2col never touches HBM.
+//   Weight rows are permuted on the host so a lane's accumulators are 8 consecutive channels: bias + residual + ReLU (+
+//   the a|b channel concat as an addressing mode) fuse into an epilogue of 16-byte stores (conv_epilogue_px).
+//     conv_halo_kernel<40>      3x3/s1 on 40x40 maps: the (8+2)x(40+2) input tile of a 64-channel chunk resident in LDS,
+//                               the 9 taps are shifted LDS windows, only weights stream; 2 workgroups per CU.
+//     conv_stem_halo_kernel     the 7x7/s2 stem as a 4x4/s1 conv over the space-to-depth input, same resident-halo scheme.
+//     conv_big_pp_kernel        256x256 implicit-GEMM tile, 8 waves in two ping-pong groups, hand-counted s_waitcnt /
+//                               raw s_barrier; conv_512, the stride-2 convs, Linear layers (full rounds of the 256 CUs).
+//     conv_pp32_kernel<512,128> 32-wide K-steps, 4-stage ring; the stride-2 conv with 128 output channels.
+//     conv_igemm_kernel<BN>     128 x BN tile, 2 workgroups per CU, optional split-K (+ conv_splitk_reduce_kernel) and
+//                               weight groups along M: left-over rows, small batches (Track).
+//     conv_igemm3 / conv_pp / conv_big kernels: earlier schedules kept behind fpt_set_conv_variant for A/B.
 //   attention_kernel       softmax(QK^T/sqrt(d))V for 4 heads x 128, any sequence length (400 tokens per hypothesis, or
 //                          the N hypotheses of the score-net's cross attention): S^T = K Q^T on MFMA so a softmax row is
 //                          lane-local, P feeds the PV MFMA straight from registers (k-slot permutation shared with V^T).
