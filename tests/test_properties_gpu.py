@@ -95,6 +95,23 @@ def test_register_1008_equals_stage_composition(model, syn_mesh, syn_scene):
     assert sc[idx] >= sc.max() - 5e-3, (idx, sc[idx], sc.max())
 
 
+@pytest.mark.parametrize("steps", [3, 5, 7])
+def test_register_equals_stage_composition_at_odd_batch_sizes(model, syn_mesh, syn_scene, steps):
+    """N = 126 / 210 / 294: row counts that leave differently sized left-overs after the 256-row tiles"""
+    model.set_inplane_steps(steps)
+    try:
+        ok, pose = model.Register(syn_scene.rgb, syn_scene.depth, syn_scene.mask, syn_mesh.name)
+        assert ok, model.last_error
+        best, refined, sc = _compose_register(model, syn_mesh.name, syn_scene)
+    finally:
+        model.set_inplane_steps(6)
+    assert len(refined) == 42 * steps and np.isfinite(sc).all()
+    errs = [_pose_err(pose, p) for p in refined]
+    idx = int(np.argmin([e[0] + 1e3 * e[1] for e in errs]))
+    assert errs[idx][0] < 0.1 and errs[idx][1] < 1e-4, errs[idx]
+    assert sc[idx] >= sc.max() - 5e-3, (idx, sc[idx], sc.max())
+
+
 @pytest.mark.parametrize("textured", [True, False])
 def test_register_720p_textured_and_untextured(wpaths, textured):
     mesh = syn.make_mesh(textured=textured, name="m720")
