@@ -171,7 +171,7 @@ def main():
             stages[k.split("/", 1)[0]] = stages.get(k.split("/", 1)[0], 0.0) + v["ms"]
         stages = {k: round(v, 3) for k, v in sorted(stages.items(), key=lambda kv: -kv[1])}
         traffic, traffic_src = None, None
-        pmc_path = os.path.join(ROOT, "profiles", "r01f_register_n252_pmc_hbm.json")
+        pmc_path = os.path.join(ROOT, "profiles", "r01g_register_n252_pmc_hbm.json")
         if os.path.exists(pmc_path) and not args.track and world == 1:
             pmc = json.load(open(pmc_path))
             for name, rec in pmc.items():
