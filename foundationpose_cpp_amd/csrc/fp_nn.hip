@@ -17,7 +17,9 @@
 //     conv_stem_halo_kernel     the 7x7/s2 stem as a 4x4/s1 conv over the space-to-depth input, same resident-halo scheme.
 //     conv_big_pp_kernel        256x256 implicit-GEMM tile, 8 waves in two ping-pong groups, hand-counted s_waitcnt /
 //                               raw s_barrier; conv_512, the stride-2 convs, Linear layers (full rounds of the 256 CUs).
-//     conv_pp32_kernel<512,128> 32-wide K-steps, 4-stage ring; the stride-2 conv with 128 output channels.
+//     conv_s2_halo_kernel       the 3x3/s2 conv 64->128 on the 80x80 stem output: the input tile staged one column-parity
+//                               plane at a time (a stride-2 tap is a stride-1 window of one plane).  HBM-bound layer.
+//     conv_pp32_kernel<512,128> 32-wide K-steps, 4-stage ring; the same stride-2 conv below ~30 hypotheses.
 //     conv_igemm_kernel<BN>     128 x BN tile, 2 workgroups per CU, optional split-K (+ conv_splitk_reduce_kernel) and
 //                               weight groups along M: left-over rows, small batches (Track).
 //     conv_igemm3 / conv_pp / conv_big kernels: earlier schedules kept behind fpt_set_conv_variant for A/B.
@@ -1331,6 +1333,132 @@ __global__ __launch_bounds__(256, 2) void conv_stem_halo_kernel(const ConvParams
   conv_epilogue_px<MI, 2>(p, reinterpret_cast<f4(&)[2][MI]>(acc[2]), 32, lane, pix);
 }
 
+// -------------------------------------------------------------------------------------------------
+// conv_s2_halo_kernel: the 3x3 / stride-2 convolution 64 -> 128 channels on the 80x80 stem output (encodeA.1), again
+// with the input tile resident in LDS.
+//   tile = 4 output rows x 40 cols (160 px) x 128 channels; 4 waves = 2 (column halves) x 2 (64 channels), 80
+//   accumulators each; 2 workgroups per CU.
+//   Stride 2: a tap (ky,kx) reads input columns 2*ox + kx, i.e. one column-PARITY plane at consecutive positions --
+//   exactly like a stride-1 tap.  The tile's 9 input rows are therefore staged one parity plane at a time (9 x 41 px x
+//   128 B = 47 KB; every fetched 128-byte line is used whole): plane 0 serves the six taps with kx in {0,2} (12
+//   32-channel K-steps), plane 1 the three taps with kx = 1 (6 K-steps).  Weights: 8 KB per step, 3-stage ring.
+//   16-byte slot of an LDS pixel = chunk ^ (((row>>1)&3) | (((x>>1)&1)<<2)): conflict-free fragment reads.
+// -------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void conv_s2_halo_kernel(const ConvParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int IC = 82, HR = 9, PW = 41, HPX = HR * PW;  // 4 output rows need 9 input rows; 41 columns per parity plane
+  constexpr int HPIECES = (HPX + 7) / 8, HALO_B = HPIECES * 1024;
+  constexpr int HPER = (HPIECES + 3) / 4;
+  constexpr int WST = 128 * 64, NWST = 3;
+  constexpr int MI = 5, NI = 4, S = 18, SA = 12;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int chalf = wave >> 1, wn = wave & 1;
+  int logical;
+  {
+    const int nblk = gridDim.x, b = blockIdx.x;
+    const int xcd = b & 7, within = b >> 3, q = nblk >> 3, r = nblk & 7;
+    logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
+  }
+  const int img = logical / 10, oy0 = (logical - img * 10) * 4;
+
+  // input image: [82][82][64] halfs (border 1); the tile's first input row is 2*oy0 (padded coordinates)
+  const unsigned char *in_b = reinterpret_cast<const unsigned char *>(p.in) + ((size_t)(img * IC + 2 * oy0) * IC) * 128;
+  const unsigned char *w_b = reinterpret_cast<const unsigned char *>(p.w);
+  const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
+  const unsigned w_lds = lds_base + HALO_B;
+
+  auto issue_halo = [&](int plane) {  // columns of one parity, all 64 channels
+    int lane8;
+    asm volatile("v_lshrrev_b32 %0, 3, %1" : "=v"(lane8) : "v"(lane));  // opaque: keeps the offsets out of long live ranges
+#pragma unroll
+    for (int i = 0; i < HPER; i++) {
+      const int piece = wave + 4 * i;
+      if (piece < HPIECES) {
+        int q = min(piece * 8 + lane8, HPX - 1);
+        int r = q / PW, xp = q - r * PW;
+        int c = min(2 * xp + plane, IC - 1);
+        int g = ((r >> 1) & 3) | (((xp >> 1) & 1) << 2);
+        unsigned off = (unsigned)((r * IC + c) * 128 + (((lane & 7) ^ g) << 4));
+        glds16_asm(in_b + off, __builtin_amdgcn_readfirstlane(lds_base + piece * 1024));
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  };
+  const int prow = lane >> 2;
+  const int gch = (lane & 3) ^ ((0x78 >> (((prow >> 2) & 3) * 2)) & 3);
+  unsigned woff[2];
+#pragma unroll
+  for (int i = 0; i < 2; i++) woff[i] = (unsigned)(((wave * 2 + i) * 16 + prow) * p.Ktot + gch * 8) * 2u;
+  // step -> (tap, 32-channel half): steps 0..11 walk the kx in {0,2} taps, 12..17 the kx = 1 taps
+  auto step_tap = [&](int st, int &ky, int &kx) {
+    if (st < SA) { const int t = st >> 1; ky = t >> 1; kx = (t & 1) * 2; }
+    else { ky = (st - SA) >> 1; kx = 1; }
+  };
+  auto issue_w = [&](int st) {
+    int ky, kx;
+    step_tap(st, ky, kx);
+    const unsigned char *wb = w_b + (size_t)((ky * 3 + kx) * 128 + (st & 1) * 64);
+    const unsigned dst = __builtin_amdgcn_readfirstlane(w_lds + (st % NWST) * WST);
+#pragma unroll
+    for (int i = 0; i < 2; i++) glds16_asm(wb + woff[i], dst + (wave * 2 + i) * 1024);
+  };
+
+  f4 acc[NI][MI];
+#pragma unroll
+  for (int a = 0; a < NI; a++)
+#pragma unroll
+    for (int b = 0; b < MI; b++) acc[a][b] = (f4){0.f, 0.f, 0.f, 0.f};
+
+  const int li = lane & 15, dy = li >> 2, dx = li & 3, kg = lane >> 4;
+  const int fslot = kg ^ ((0x78 >> ((li >> 2) * 2)) & 3);
+  const int wfo = HALO_B + (wn * 64 + li) * 64 + fslot * 16;
+
+  issue_halo(0);
+  issue_w(0);
+  issue_w(1);
+#pragma unroll 1
+  for (int s = 0; s < S; s++) {
+    int ky, kx;
+    step_tap(s, ky, kx);
+    if (s == 0 || s == SA || s == S - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    if (s + 2 < S) issue_w(s + 2);
+    const int r = 2 * dy + ky;                         // input row inside the tile
+    const int xp = chalf * 20 + dx + (kx >> 1);        // + mi*4 per fragment (keeps (xp>>1)&1 of the lane)
+    const int g = ((r >> 1) & 3) | (((xp >> 1) & 1) << 2);
+    const unsigned char *xs = smem + (r * PW + xp) * 128 + (((((s & 1) << 2) | kg) ^ g) << 4);
+    const unsigned char *ws = smem + wfo + (s % NWST) * WST;
+    h8 xf[MI], wf[NI];
+#pragma unroll
+    for (int ni = 0; ni < NI; ni++) wf[ni] = *reinterpret_cast<const h8 *>(ws + ni * 16 * 64);
+#pragma unroll
+    for (int mi = 0; mi < MI; mi++) xf[mi] = *reinterpret_cast<const h8 *>(xs + mi * 512);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (s == SA - 1) {  // last read of plane 0: stage plane 1 under this step's MFMAs
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      issue_halo(1);
+    }
+#pragma unroll
+    for (int ni = 0; ni < NI; ni++)
+#pragma unroll
+      for (int mi = 0; mi < MI; mi++)
+        acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ni], xf[mi], acc[ni][mi], 0, 0, 0);
+  }
+  conv_epilogue_px<MI, NI>(p, acc, wn * 64, lane, [&](int mi, int &oimg, int &oh, int &ow) {
+    oimg = img;
+    oh = oy0 + dy;
+    ow = chalf * 20 + mi * 4 + dx;
+    return true;
+  });
+}
+
 // split-K reduction + the conv epilogue: out = relu(sum_s partial[s] + bias + res); thread = (pixel, 4 channels)
 __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvParams p) {
   const int nq = p.Cout / 4;
@@ -2055,6 +2183,7 @@ static int run_conv(const Ctx &c, const char *tag, const ConvLayer &L, const __h
   constexpr int LDS3_128 = 3 * (256 * 128 + 128 * 128), LDS3_64 = 3 * (256 * 128 + 64 * 128);
   constexpr int LDS_HALO40 = ((10 * 42 + 7) / 8) * 1024 + 3 * 128 * 64;
   constexpr int LDS_STEM_HALO = ((11 * 84 + 15) / 16) * 1024 + 3 * 64 * 64;
+  constexpr int LDS_S2_HALO = ((9 * 41 + 7) / 8) * 1024 + 3 * 128 * 64;
   if (!g_conv_attr_done) {
     FP_HIP_OK(hipFuncSetAttribute((const void *)conv_igemm_kernel<128, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (128 * 128 + 128 * 128)));
     FP_HIP_OK(hipFuncSetAttribute((const void *)conv_igemm_kernel<128, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (128 * 128 + 128 * 128)));
@@ -2077,6 +2206,7 @@ static int run_conv(const Ctx &c, const char *tag, const ConvLayer &L, const __h
     FP_HIP_OK(hipFuncSetAttribute((const void *)conv_big_pp_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 * 128 + 256 * 128)));
     FP_HIP_OK(hipFuncSetAttribute((const void *)conv_big_pp_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 * 128 + 256 * 128)));
     FP_HIP_OK(hipFuncSetAttribute((const void *)conv_stem_halo_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_STEM_HALO));
+    FP_HIP_OK(hipFuncSetAttribute((const void *)conv_s2_halo_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_S2_HALO));
     FP_HIP_OK(hipFuncSetAttribute((const void *)conv_halo_kernel<40, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_HALO40));
     FP_HIP_OK(hipFuncSetAttribute((const void *)conv_halo_kernel<40, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_HALO40));
     FP_HIP_OK(hipFuncSetAttribute((const void *)conv_halo_kernel<40, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_HALO40));
@@ -2123,6 +2253,13 @@ static int run_conv(const Ctx &c, const char *tag, const ConvLayer &L, const __h
       H == 80 && p.ksplit == 1 && res == nullptr && split_imgs == 0 && (g_conv_variant == 7 || NB * 10 >= 300)) {
     ProfScope ps(c.prof, c.s, (tg + "/conv_stem_halo_kernel").c_str(), flops, bytes);
     hipLaunchKernelGGL(conv_stem_halo_kernel, dim3(NB * 10), dim3(256), LDS_STEM_HALO, c.s, p);
+    return 0;
+  }
+  if (!grp && (g_conv_variant == 7 || g_conv_variant == 0) && L.KH == 3 && L.KW == 3 && L.stride == 2 && L.pad == 1 && ipad == 1 &&
+      W == 80 && H == 80 && L.Cin == 64 && L.Cout == 128 && p.ksplit == 1 && res == nullptr && split_imgs == 0 &&
+      (g_conv_variant == 7 || NB * 10 >= 300)) {
+    ProfScope ps(c.prof, c.s, (tg + "/conv_s2_halo_kernel").c_str(), flops, bytes);
+    hipLaunchKernelGGL(conv_s2_halo_kernel, dim3(NB * 10), dim3(256), LDS_S2_HALO, c.s, p);
     return 0;
   }
   if (!grp && (g_conv_variant == 7 || g_conv_variant == 0) && L.KH == 3 && L.KW == 3 && L.stride == 1 && L.pad == 1 && ipad == 1 && W == 40 && H % 8 == 0 &&
