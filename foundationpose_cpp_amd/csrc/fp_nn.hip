@@ -390,7 +390,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm3_kernel(const ConvParams p)
     logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
   }
   const int mt = logical / n_tiles, nt = logical - mt * n_tiles;
-  const int m0 = mt * BM, n0 = nt * BN;
+  const int m0 = p.m_begin + mt * BM, n0 = nt * BN;
   const int ohw = p.OH * p.OW;
   const int IHp = p.H + 2 * p.ipad, IWp = p.W + 2 * p.ipad;
 
@@ -521,7 +521,7 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvParams p) {
     logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
   }
   const int mt = logical / n_tiles, nt = logical - mt * n_tiles;
-  const int m0 = mt * BM, n0 = nt * BN;
+  const int m0 = p.m_begin + mt * BM, n0 = nt * BN;
   const int ohw = p.OH * p.OW;
   const int IHp = p.H + 2 * p.ipad, IWp = p.W + 2 * p.ipad;
 
@@ -2125,6 +2125,7 @@ struct Ctx {
 static bool g_conv_attr_done = false;
 static unsigned long long *g_clk_probe = nullptr;
 static NNScratch g_hook_ws;  // split-K slab of the fpt_* test hooks
+static int g_rem_kernel = 1;  // A/B hook: kernel for the rows the full 256x256 rounds of a long-K layer leave over (0 = 128x128 2-stage, 1 = 256x128 ping-pong, 2 = 256x128 3-stage)
 static int g_grouped_heads = 1;  // A/B hook: the refiner's two heads as one launch per layer when N == 1 (Track)
 static int g_rem_splitk = 0;     // A/B hook: split-K for the rows a 256x256 / 512x128 launch leaves over.  Measured -0.1 ms per
                                  // Register, but OFF: a row's fp32 summation order would then depend on where it falls in the
@@ -2325,6 +2326,16 @@ static int run_conv(const Ctx &c, const char *tag, const ConvLayer &L, const __h
       mtiles = (p.M - p.m_begin + 127) / 128;
       if (g_rem_splitk && plan_splitk(p.M - p.m_begin, 384)) return 1;
     }
+  }
+  if (!grp && p.m_begin > 0 && g_rem_kernel && KT >= 16 && p.ksplit == 1 && L.Cout % 128 == 0) {
+    // left-over rows on an otherwise idle chip: a lone workgroup per CU walks all K-steps, so per-step latency is what
+    // counts -- the 8-wave 3-stage ping-pong schedule hides it a little better than the 2-stage 128x128 tile (conv_512
+    // left-overs 61 -> 55 us per launch; measured neutral-to-slower for the 8-step Linear layers, hence KT >= 16)
+    const int mt2 = (p.M - p.m_begin + 255) / 256;
+    ProfScope ps(c.prof, c.s, (tg + (g_rem_kernel == 1 ? "/conv_pp_kernel(rem)" : "/conv_igemm3_kernel(rem)")).c_str(), flops, bytes);
+    if (g_rem_kernel == 1) hipLaunchKernelGGL(conv_pp_kernel<128>, dim3(mt2 * (L.Cout / 128)), dim3(512), LDS3_128, c.s, p);
+    else hipLaunchKernelGGL(conv_igemm3_kernel<128>, dim3(mt2 * (L.Cout / 128)), dim3(512), LDS3_128, c.s, p);
+    return 0;
   }
   if (!grp && g_conv_variant == 3 && KT >= 3 && p.ksplit == 1) {
     ProfScope ps(c.prof, c.s, (tg + "/conv_pp_kernel").c_str(), flops, bytes);
@@ -2589,6 +2600,7 @@ void fpt_set_conv_ablate(int v) { fp::g_conv_ablate = v; }
 void fpt_set_splitk_target(int v) { fp::g_splitk_target = v; }
 void fpt_set_rem_splitk(int v) { fp::g_rem_splitk = v; }
 void fpt_set_grouped_heads(int v) { fp::g_grouped_heads = v; }
+void fpt_set_rem_kernel(int v) { fp::g_rem_kernel = v; }
 void fpt_set_raster_strip_rows(int r) { fp::set_raster_strip_rows(r); }
 
 // clock probe: allocate room for `blocks` records, run convs, then read back mean shader MHz and mean main-loop cycles
