@@ -1501,7 +1501,7 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvParam
 // tiles of one (image, head) run on the SAME XCD and share its L2 copy of K/V (a (qt,h,b) grid spread them over all 8
 // XCDs: rocprofv3 FETCH_SIZE showed 1.16 GB fetched per launch for 0.31 GB of QKV).
 template <int ATT_QROWS, bool REMAP, bool PERM = true>
-__global__ __launch_bounds__(ATT_QROWS * 4) void attention_kernel(const __half *__restrict__ qkv, __half *__restrict__ out, int T, int nq,
+__global__ __launch_bounds__(ATT_QROWS * 4, 2) void attention_kernel(const __half *__restrict__ qkv, __half *__restrict__ out, int T, int nq,
                                                                  int tstride /* rows between the first tokens of consecutive sequences */) {
   constexpr int KS = 136;  // K tile row stride (halfs): 128 + 8 pad
   constexpr int VS = 40;   // V^T tile row stride (halfs): 32 keys + 8 pad
@@ -2576,6 +2576,40 @@ int scorer_head(hipStream_t s, Profiler *prof, const Net *net, NNScratch *ws, co
 }  // namespace fp
 
 // =================================================================================================
+// MFMA micro-benchmark (measurement only): every wave issues `iters` x 8 independent v_mfma_f32_16x16x32_f16 from
+// registers -- the rate the matrix pipes sustain with all 256 CUs busy at whatever clock the power limit allows.
+__global__ __launch_bounds__(256) void mfma_peak_kernel(float *out, int iters, int zero_operands, unsigned long long *clk) {
+  using fp::f4;
+  using fp::h8;
+  const int lane = threadIdx.x & 63;
+  h8 a, b;
+  unsigned st = 2654435761u * (unsigned)(blockIdx.x * 256 + threadIdx.x + 1);
+#pragma unroll
+  for (int i = 0; i < 8; i++) {  // random operands in [-0.5, 0.5): data-dependent power draw like real activations
+    st = st * 1664525u + 1013904223u;
+    a[i] = (_Float16)(((st >> 8) & 0xffff) / 65536.0f - 0.5f);
+    st = st * 1664525u + 1013904223u;
+    b[i] = (_Float16)(((st >> 8) & 0xffff) / 65536.0f - 0.5f);
+    if (zero_operands) { a[i] = 0; b[i] = 0; }
+  }
+  unsigned long long c0 = 0, w0 = 0;
+  if (clk && blockIdx.x == 0 && threadIdx.x == 0) { c0 = __builtin_readcyclecounter(); w0 = wall_clock64(); }
+  f4 acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; j++) acc[j] = (f4){0.f, 0.f, 0.f, 0.f};
+  for (int i = 0; i < iters; i++) {
+#pragma unroll
+    for (int j = 0; j < 8; j++)  // inline asm: the builtin made hipcc shuffle the accumulators through AGPRs every iteration
+      asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[j]) : "v"(a), "v"(b));
+  }
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // drain the MFMA pipe before the accumulators are read
+  float sum = 0.f;
+#pragma unroll
+  for (int j = 0; j < 8; j++) sum += acc[j][0] + acc[j][1] + acc[j][2] + acc[j][3];
+  if (sum == 12345.678f) out[lane] = sum;  // keeps the accumulators live; never true in practice
+  if (clk && blockIdx.x == 0 && threadIdx.x == 0) { clk[0] = __builtin_readcyclecounter() - c0; clk[1] = wall_clock64() - w0; }
+}
+
 // kernel-level test / micro-benchmark hooks (not part of the public C ABI; used by tests/test_nn_gpu.py and
 // tools/bench_conv.py).  Host f32 in / out, fp16 on the device exactly like the production path.
 // =================================================================================================
@@ -2890,6 +2924,38 @@ float fpt_attention_bench(int B, int T, int iters, int variant) {
   (void)hipEventDestroy(e1);
   g_att_variant = saved;
   return ms / iters;
+}
+
+// sustained dense fp16 MFMA rate in TFLOP/s (whole chip, `waves_per_simd` waves on every SIMD); negative on failure
+float fpt_mfma_peak(int iters, int waves_per_simd, int zero_operands, double *mhz) {
+  hipStream_t s;
+  if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return -1.f;
+  hipDeviceProp_t prop;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return -1.f;
+  const int wgs = prop.multiProcessorCount * waves_per_simd;  // 256 threads = one wave per SIMD of a CU
+  DevBuf<float> out(64);
+  DevBuf<unsigned long long> clk(2);
+  hipEvent_t e0, e1;
+  if (!out.p || !clk.p || hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return -1.f;
+  hipLaunchKernelGGL(mfma_peak_kernel, dim3(wgs), dim3(256), 0, s, out.p, iters / 4, zero_operands, (unsigned long long *)nullptr);  // warm-up / clock ramp
+  (void)hipEventRecord(e0, s);
+  hipLaunchKernelGGL(mfma_peak_kernel, dim3(wgs), dim3(256), 0, s, out.p, iters, zero_operands, clk.p);
+  (void)hipEventRecord(e1, s);
+  float ms = -1.f;
+  const bool ok = hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(&ms, e0, e1) == hipSuccess;
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  (void)hipStreamDestroy(s);
+  if (!ok || ms <= 0.f) return -1.f;
+  if (mhz) {  // shader clock during the run: cycle counter against the 100 MHz wall clock
+    unsigned long long h[2] = {0, 0};
+    if (hipMemcpy(h, clk.p, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) return -1.f;
+    *mhz = h[1] ? (double)h[0] / (double)h[1] * 100.0 : 0.0;
+  }
+  const double flops = (double)wgs * 4.0 * (double)iters * 8.0 * 16384.0;
+  return (float)(flops / (ms * 1e-3) / 1e12);
 }
 
 }  // extern "C"
