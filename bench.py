@@ -14,7 +14,8 @@ with the frame (rgb, depth, mask) already resident in HBM when the timed region 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
   roofline     -- dominant kernel (the conv/linear implicit-GEMM kernel with the largest share of the step, MFMA-bound):
                   algorithmic FLOPs of its launches in one step / their HIP-event durations on the library's stream
-                  (fp_profile_*), vs the 2.5 PFLOP/s dense fp16 MFMA peak; `traffic` = fabric bytes per launch from the
+                  (fp_profile_*), vs the 2.5 PFLOP/s dense fp16 MFMA peak (and vs the rate a register-resident MFMA
+                  micro-benchmark sustains on the same box, `peak_measured`); `traffic` = fabric bytes per launch from the
                   committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (profiles/, corrected as the guide prescribes).
   cpu_baseline -- the oracle (C/OpenMP geometry + PyTorch-CPU fp32 networks), N = 8 Register, on the host cores.
 """
@@ -177,6 +178,18 @@ def main():
             for name, rec in pmc.items():
                 if dom.split("<")[0] in name:
                     traffic, traffic_src = round(rec["traffic_bytes_per_launch"]), os.path.relpath(pmc_path, ROOT)
+        # what the matrix pipes sustain on THIS box with every SIMD busy (register-resident MFMAs, random operands): the
+        # datasheet 2.5 PFLOP/s assumes 2.4 GHz, under MFMA load the power limit holds the clock near 2.0 GHz
+        measured_peak, measured_mhz = None, None
+        if world == 1:
+            from foundationpose_cpp_amd import _lib
+            L = _lib.lib()
+            L.fpt_mfma_peak.restype = C.c_float
+            L.fpt_mfma_peak.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
+            mhz = C.c_double(0)
+            v = max(L.fpt_mfma_peak(200000, 8, 0, C.byref(mhz)) for _ in range(2))
+            if v > 0:
+                measured_peak, measured_mhz = round(float(v), 1), round(mhz.value)
         res = {
             "metric": "Track fps (N=1)" if args.track else "pose-hypotheses/sec (Register N=252, 640x480)",
             "value": round(units * args.steps / dt, 2),
@@ -198,6 +211,8 @@ def main():
                 "bound": "mfma", "kernel": dom,
                 "achieved": round(achieved, 1), "peak": PEAK_FP16_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / PEAK_FP16_TFLOPS, 4),
+                "peak_measured": measured_peak, "peak_measured_clock_mhz": measured_mhz,
+                "frac_of_measured": round(achieved / measured_peak, 4) if measured_peak else None,
                 "launches_per_step": dv["calls"], "algorithmic_gflop_per_launch": round(dv["flops"] / max(dv["calls"], 1) / 1e9, 1),
                 "avg_launch_ms": round(dv["ms"] / max(dv["calls"], 1), 4),
                 "algorithmic_bytes_per_launch": round(dv["bytes"] / max(dv["calls"], 1)),
