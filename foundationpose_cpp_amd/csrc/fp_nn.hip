@@ -1459,6 +1459,107 @@ __global__ __launch_bounds__(256, 2) void conv_s2_halo_kernel(const ConvParams p
   });
 }
 
+// -------------------------------------------------------------------------------------------------
+// gemm_k32_kernel: the Linear layers (QKV, out_proj, FFN; K = 512, 100 800 rows at N = 252).  With only 8 64-wide
+// K-steps a 256x256 tile that owns its CU spends as long in its prologue (two stages of loads with nothing to overlap)
+// and in its 128 KB store burst as in the K loop (~720 TFLOP/s).  Here: 128 rows x 256 channels, 4 waves = 2 (64 rows)
+// x 2 (128 channels), 128 accumulators, 32-wide K-steps of 24 KB through a 3-stage LDS-DMA ring (72 KB), TWO
+// workgroups per CU so one's prologue / epilogue runs under the other's MFMAs.  LDS rows are 64 bytes; the 16-byte
+// slot of (row, chunk) is chunk ^ f((row>>2)&3), f = {0,2,3,1} (conflict-free ds_read_b128 fragments).
+// -------------------------------------------------------------------------------------------------
+template <int ABL = 0>  // timing ablations: 1 = no MFMAs, 2 = no loads after the first stage, 4 = no stores
+__global__ __launch_bounds__(256, 2) void gemm_k32_kernel(const ConvParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int BM = 128, BN = 256;
+  constexpr int XST = BM * 64, WST = BN * 64, STAGE = XST + WST, NST = 3;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave & 1, wn = wave >> 1;
+  const int n_tiles = p.Cout / BN;
+  int logical;
+  {
+    const int nblk = gridDim.x, b = blockIdx.x;
+    const int xcd = b & 7, within = b >> 3, q = nblk >> 3, r = nblk & 7;
+    logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
+  }
+  const int mt = logical / n_tiles, nt = logical - mt * n_tiles;
+  const int m0 = p.m_begin + mt * BM, n0 = nt * BN;
+  const int S = p.Ktot >> 5;
+
+  const unsigned char *in_b = reinterpret_cast<const unsigned char *>(p.in);
+  const unsigned char *w_b = reinterpret_cast<const unsigned char *>(p.w);
+  const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
+
+  // staging: a wave-instruction moves 16 rows x 64 B; lane -> (row = lane>>2, slot = lane&3), source chunk swizzled
+  const int prow = lane >> 2;
+  const int gch = (lane & 3) ^ ((0x78 >> (((prow >> 2) & 3) * 2)) & 3);
+  unsigned xoff[2], woff[4];
+#pragma unroll
+  for (int i = 0; i < 2; i++) {
+    const int m = min(m0 + (wave * 2 + i) * 16 + prow, p.M - 1);  // rows past M re-read the last row (never stored)
+    xoff[i] = (unsigned)(m * p.Ktot + gch * 8) * 2u;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; i++) woff[i] = (unsigned)((n0 + (wave * 4 + i) * 16 + prow) * p.Ktot + gch * 8) * 2u;
+  auto issue = [&](int st) {
+    const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + (st % NST) * STAGE);
+    const unsigned char *xb = in_b + (size_t)st * 64, *wb = w_b + (size_t)st * 64;
+#pragma unroll
+    for (int i = 0; i < 2; i++) glds16_asm(xb + xoff[i], dst + (wave * 2 + i) * 1024);
+#pragma unroll
+    for (int i = 0; i < 4; i++) glds16_asm(wb + woff[i], dst + XST + (wave * 4 + i) * 1024);
+  };
+
+  f4 acc[2][4][4];  // [64-channel block][16-channel tile][16-row tile]
+#pragma unroll
+  for (int h = 0; h < 2; h++)
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+      for (int b = 0; b < 4; b++) acc[h][a][b] = (f4){0.f, 0.f, 0.f, 0.f};
+
+  const int li = lane & 15, kg = lane >> 4;
+  const int fslot = kg ^ ((0x78 >> ((li >> 2) * 2)) & 3);
+  const int xfo = (wm * 64 + li) * 64 + fslot * 16;
+  const int wfo = XST + (wn * 128 + li) * 64 + fslot * 16;
+
+  issue(0);
+  if (S > 1 && !(ABL & 2)) issue(1);
+#pragma unroll 1
+  for (int s = 0; s < S; s++) {
+    if (s == S - 1 || (ABL & 2)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    if (s + 2 < S && !(ABL & 2)) issue(s + 2);
+    const unsigned char *sb = smem + ((ABL & 2) ? 0 : (s % NST)) * STAGE;
+    h8 xf[4], wf[8];
+#pragma unroll
+    for (int mi = 0; mi < 4; mi++) xf[mi] = *reinterpret_cast<const h8 *>(sb + xfo + mi * 1024);
+#pragma unroll
+    for (int ni = 0; ni < 8; ni++) wf[ni] = *reinterpret_cast<const h8 *>(sb + wfo + ni * 1024);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (ABL & 1) {
+#pragma unroll
+      for (int ni = 0; ni < 8; ni++) asm volatile("" ::"v"(wf[ni]));
+#pragma unroll
+      for (int mi = 0; mi < 4; mi++) asm volatile("" ::"v"(xf[mi]));
+      continue;
+    }
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ni = 0; ni < 8; ni++)
+#pragma unroll
+      for (int mi = 0; mi < 4; mi++)
+        acc[ni >> 2][ni & 3][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ni], xf[mi], acc[ni >> 2][ni & 3][mi], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+  }
+  conv_epilogue<4, 4, (ABL >> 2) & 1>(p, acc[0], m0 + wm * 64, n0 + wn * 128, lane);
+  conv_epilogue<4, 4, (ABL >> 2) & 1>(p, acc[1], m0 + wm * 64, n0 + wn * 128 + 64, lane);
+}
+
 // split-K reduction + the conv epilogue: out = relu(sum_s partial[s] + bias + res); thread = (pixel, 4 channels)
 __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvParams p) {
   const int nq = p.Cout / 4;
@@ -1529,7 +1630,7 @@ __global__ __launch_bounds__(ATT_QROWS * 4, 2) void attention_kernel(const __hal
 #pragma unroll
   for (int dt = 0; dt < 8; dt++) o[dt] = (f4){0.f, 0.f, 0.f, 0.f};
   float m_run = -INFINITY, l_run = 0.f;
-  const float scale = 0.08838834764831845f;  // 1/sqrt(128)
+  const float sl2e = 0.08838834764831845f * 1.4426950408889634f;  // 1/sqrt(128) * log2(e)
 
   const int nkb = (T + 31) / 32;
   // staging roles.  K: thread -> (key = idx>>4, 16-B chunk = idx&15): coalesced 256-B rows.  V: thread -> (key = idx&31,
@@ -1575,27 +1676,29 @@ __global__ __launch_bounds__(ATT_QROWS * 4, 2) void attention_kernel(const __hal
         st[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[ds], st[kt], 0, 0, 0);
       }
     }
-    float mx = -INFINITY;
+    // softmax in base 2 on the RAW scores: p = exp2(s*c - m*c), c = scale*log2(e) -- one fma + one v_exp per score; the
+    // running maximum m is kept unscaled.  Keys past T exist only in the last block (wave-uniform branch).
+    if (kb == nkb - 1 && (T & 31)) {
 #pragma unroll
-    for (int kt = 0; kt < 2; kt++)
+      for (int kt = 0; kt < 2; kt++)
 #pragma unroll
-      for (int r = 0; r < 4; r++) {
-        int key = kb * 32 + kt * 16 + g * 4 + r;
-        float s = (key < T) ? st[kt][r] * scale : -INFINITY;
-        st[kt][r] = s;
-        mx = fmaxf(mx, s);
-      }
+        for (int r = 0; r < 4; r++)
+          if (kb * 32 + kt * 16 + g * 4 + r >= T) st[kt][r] = -INFINITY;
+    }
+    float mx = fmaxf(fmaxf(fmaxf(st[0][0], st[0][1]), fmaxf(st[0][2], st[0][3])),
+                     fmaxf(fmaxf(st[1][0], st[1][1]), fmaxf(st[1][2], st[1][3])));
     mx = fmaxf(mx, __shfl_xor(mx, 16));
     mx = fmaxf(mx, __shfl_xor(mx, 32));
-    float m_new = fmaxf(m_run, mx);
-    float alpha = __expf(m_run - m_new);  // m_run = -inf on the first block -> 0
+    const float m_new = fmaxf(m_run, mx);
+    const float mc = m_new * sl2e;
+    const float alpha = __builtin_amdgcn_exp2f(m_run * sl2e - mc);  // m_run = -inf on the first block -> 0
     float psum = 0.f;
     h8 pf;
 #pragma unroll
     for (int kt = 0; kt < 2; kt++)
 #pragma unroll
       for (int r = 0; r < 4; r++) {
-        float pv = __expf(st[kt][r] - m_new);
+        float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(st[kt][r], sl2e, -mc));
         psum += pv;
         pf[kt * 4 + r] = (_Float16)pv;
       }
@@ -2126,6 +2229,7 @@ static bool g_conv_attr_done = false;
 static unsigned long long *g_clk_probe = nullptr;
 static NNScratch g_hook_ws;  // split-K slab of the fpt_* test hooks
 static int g_rem_kernel = 1;  // A/B hook: kernel for the rows the full 256x256 rounds of a long-K layer leave over (0 = 128x128 2-stage, 1 = 256x128 ping-pong, 2 = 256x128 3-stage)
+static int g_gemm_kernel = 1;  // A/B hook: Linear layers on gemm_k32_kernel (0 = the 256x256 ping-pong tile + left-overs)
 static int g_grouped_heads = 1;  // A/B hook: the refiner's two heads as one launch per layer when N == 1 (Track)
 static int g_rem_splitk = 0;     // A/B hook: split-K for the rows a 256x256 / 512x128 launch leaves over.  Measured -0.1 ms per
                                  // Register, but OFF: a row's fp32 summation order would then depend on where it falls in the
@@ -2184,6 +2288,7 @@ static int run_conv(const Ctx &c, const char *tag, const ConvLayer &L, const __h
   constexpr int LDS3_128 = 3 * (256 * 128 + 128 * 128), LDS3_64 = 3 * (256 * 128 + 64 * 128);
   constexpr int LDS_HALO40 = ((10 * 42 + 7) / 8) * 1024 + 3 * 128 * 64;
   constexpr int LDS_STEM_HALO = ((11 * 84 + 15) / 16) * 1024 + 3 * 64 * 64;
+  constexpr int LDS_GEMM_K32 = 3 * (128 + 256) * 64;
   constexpr int LDS_S2_HALO = ((9 * 41 + 7) / 8) * 1024 + 3 * 128 * 64;
   if (!g_conv_attr_done) {
     FP_HIP_OK(hipFuncSetAttribute((const void *)conv_igemm_kernel<128, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (128 * 128 + 128 * 128)));
@@ -2208,6 +2313,10 @@ static int run_conv(const Ctx &c, const char *tag, const ConvLayer &L, const __h
     FP_HIP_OK(hipFuncSetAttribute((const void *)conv_big_pp_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 * 128 + 256 * 128)));
     FP_HIP_OK(hipFuncSetAttribute((const void *)conv_stem_halo_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_STEM_HALO));
     FP_HIP_OK(hipFuncSetAttribute((const void *)conv_s2_halo_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_S2_HALO));
+    FP_HIP_OK(hipFuncSetAttribute((const void *)gemm_k32_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_GEMM_K32));
+    FP_HIP_OK(hipFuncSetAttribute((const void *)gemm_k32_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_GEMM_K32));
+    FP_HIP_OK(hipFuncSetAttribute((const void *)gemm_k32_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_GEMM_K32));
+    FP_HIP_OK(hipFuncSetAttribute((const void *)gemm_k32_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_GEMM_K32));
     FP_HIP_OK(hipFuncSetAttribute((const void *)conv_halo_kernel<40, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_HALO40));
     FP_HIP_OK(hipFuncSetAttribute((const void *)conv_halo_kernel<40, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_HALO40));
     FP_HIP_OK(hipFuncSetAttribute((const void *)conv_halo_kernel<40, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_HALO40));
@@ -2254,6 +2363,18 @@ static int run_conv(const Ctx &c, const char *tag, const ConvLayer &L, const __h
       H == 80 && p.ksplit == 1 && res == nullptr && split_imgs == 0 && (g_conv_variant == 7 || NB * 10 >= 300)) {
     ProfScope ps(c.prof, c.s, (tg + "/conv_stem_halo_kernel").c_str(), flops, bytes);
     hipLaunchKernelGGL(conv_stem_halo_kernel, dim3(NB * 10), dim3(256), LDS_STEM_HALO, c.s, p);
+    return 0;
+  }
+  if (!grp && g_gemm_kernel && g_conv_variant == 0 && L.KH == 1 && L.KW == 1 && H == 1 && W == 1 && ipad == 0 && opad == 0 && L.Cout % 256 == 0 &&
+      p.Ktot % 32 == 0 && p.ksplit == 1 && split_imgs == 0 && ((p.M + 127) / 128) * (L.Cout / 256) >= 512) {
+    ProfScope ps(c.prof, c.s, (tg + "/gemm_k32_kernel").c_str(), flops, bytes);
+    const dim3 grid(((p.M + 127) / 128) * (L.Cout / 256));
+    switch (g_gemm_kernel) {  // 1 = product; 11 / 12 / 14: timing ablations (wrong results)
+      case 11: hipLaunchKernelGGL(gemm_k32_kernel<1>, grid, dim3(256), LDS_GEMM_K32, c.s, p); break;
+      case 12: hipLaunchKernelGGL(gemm_k32_kernel<2>, grid, dim3(256), LDS_GEMM_K32, c.s, p); break;
+      case 14: hipLaunchKernelGGL(gemm_k32_kernel<4>, grid, dim3(256), LDS_GEMM_K32, c.s, p); break;
+      default: hipLaunchKernelGGL(gemm_k32_kernel<0>, grid, dim3(256), LDS_GEMM_K32, c.s, p); break;
+    }
     return 0;
   }
   if (!grp && (g_conv_variant == 7 || g_conv_variant == 0) && L.KH == 3 && L.KW == 3 && L.stride == 2 && L.pad == 1 && ipad == 1 &&
@@ -2634,6 +2755,7 @@ void fpt_set_conv_ablate(int v) { fp::g_conv_ablate = v; }
 void fpt_set_splitk_target(int v) { fp::g_splitk_target = v; }
 void fpt_set_rem_splitk(int v) { fp::g_rem_splitk = v; }
 void fpt_set_grouped_heads(int v) { fp::g_grouped_heads = v; }
+void fpt_set_gemm_kernel(int v) { fp::g_gemm_kernel = v; }
 void fpt_set_rem_kernel(int v) { fp::g_rem_kernel = v; }
 void fpt_set_raster_strip_rows(int r) { fp::set_raster_strip_rows(r); }
 
