@@ -2365,7 +2365,7 @@ static int run_conv(const Ctx &c, const char *tag, const ConvLayer &L, const __h
     hipLaunchKernelGGL(conv_stem_halo_kernel, dim3(NB * 10), dim3(256), LDS_STEM_HALO, c.s, p);
     return 0;
   }
-  if (!grp && g_gemm_kernel && g_conv_variant == 0 && L.KH == 1 && L.KW == 1 && H == 1 && W == 1 && ipad == 0 && opad == 0 && L.Cout % 256 == 0 &&
+  if (!grp && g_gemm_kernel && g_conv_variant == 0 && L.KH == 1 && L.KW == 1 && L.stride == 1 && L.pad == 0 && ipad == 0 && L.Cout % 256 == 0 &&
       p.Ktot % 32 == 0 && p.ksplit == 1 && split_imgs == 0 && ((p.M + 127) / 128) * (L.Cout / 256) >= 512) {
     ProfScope ps(c.prof, c.s, (tg + "/gemm_k32_kernel").c_str(), flops, bytes);
     const dim3 grid(((p.M + 127) / 128) * (L.Cout / 256));

@@ -109,6 +109,31 @@ def test_conv_alternative_schedules_match_torch(variant):
         L.fpt_set_conv_variant(0)
 
 
+@pytest.mark.parametrize("rows,Cout,relu,use_res", [(66001, 512, True, True), (11111, 1536, False, False)])
+def test_linear_layers_two_workgroups_per_cu_kernel(rows, Cout, relu, use_res):
+    """gemm_k32_kernel (Linear layers with >= 512 tiles): ragged last tile, residual + ReLU epilogue, both n-tile counts"""
+    rng = np.random.default_rng(11)
+    x = rng.normal(size=(rows, 1, 1, 512)).astype(np.float32)
+    w = (rng.normal(size=(Cout, 512, 1, 1)) / np.sqrt(512)).astype(np.float32)
+    b = rng.normal(size=Cout).astype(np.float32)
+    res = rng.normal(size=(rows, 1, 1, Cout)).astype(np.float32) if use_res else None
+    got = _conv_hip(x, w, b, 1, 0, relu, res)
+    ref = _h(x).reshape(rows, 512) @ _h(w).reshape(Cout, 512).T + b
+    if use_res:
+        ref = ref + _h(res).reshape(rows, Cout)
+    if relu:
+        ref = np.maximum(ref, 0)
+    np.testing.assert_allclose(got.reshape(rows, Cout), ref, rtol=2e-3, atol=2e-3)
+    # asymmetric operands: a transposed fragment or a wrong channel permutation cannot pass
+    x2 = np.zeros((rows, 1, 1, 512), np.float32)
+    x2[:, 0, 0, :] = (np.arange(rows)[:, None] % 97) / 97.0 + np.arange(512)[None, :] / 512.0
+    w2 = np.zeros((Cout, 512, 1, 1), np.float32)
+    w2[np.arange(Cout), (np.arange(Cout) * 5) % 512, 0, 0] = 1.0 + np.arange(Cout) / Cout
+    got2 = _conv_hip(x2, w2, np.zeros(Cout, np.float32), 1, 0, False, None)
+    ref2 = _h(x2).reshape(rows, 512) @ _h(w2).reshape(Cout, 512).T
+    np.testing.assert_allclose(got2.reshape(rows, Cout), ref2, rtol=2e-3, atol=2e-3)
+
+
 def test_conv_transpose_detecting_and_split_store():
     # asymmetric weights/inputs (a transposed fragment layout cannot pass) + the a|b channel-concat epilogue
     NB, H, Cin, Cout = 4, 8, 128, 128
