@@ -73,6 +73,7 @@ def main():
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-mfma-peak", action="store_true", help="skip the MFMA micro-benchmark (profiling runs)")
     ap.add_argument("--track", action="store_true", help="measure Track fps (N=1 hypothesis) instead of Register")
     args = ap.parse_args()
 
@@ -172,7 +173,7 @@ def main():
             stages[k.split("/", 1)[0]] = stages.get(k.split("/", 1)[0], 0.0) + v["ms"]
         stages = {k: round(v, 3) for k, v in sorted(stages.items(), key=lambda kv: -kv[1])}
         traffic, traffic_src = None, None
-        pmc_path = os.path.join(ROOT, "profiles", "r01g_register_n252_pmc_hbm.json")
+        pmc_path = os.path.join(ROOT, "profiles", "r01h_register_n252_pmc_hbm.json")
         if os.path.exists(pmc_path) and not args.track and world == 1:
             pmc = json.load(open(pmc_path))
             for name, rec in pmc.items():
@@ -181,7 +182,7 @@ def main():
         # what the matrix pipes sustain on THIS box with every SIMD busy (register-resident MFMAs, random operands): the
         # datasheet 2.5 PFLOP/s assumes 2.4 GHz, under MFMA load the power limit holds the clock near 2.0 GHz
         measured_peak, measured_mhz = None, None
-        if world == 1:
+        if world == 1 and not args.no_mfma_peak:
             from foundationpose_cpp_amd import _lib
             L = _lib.lib()
             L.fpt_mfma_peak.restype = C.c_float

@@ -7,7 +7,7 @@ ROOT=$(pwd)
 export TMPDIR=/tmp
 OUT=$ROOT/gpurun_out/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT
-CMD="python $ROOT/bench.py --steps 4 --warmup 2 --no-cpu-baseline"
+CMD="python $ROOT/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-mfma-peak"
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o p -- $CMD > $OUT/stats.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o p -- $CMD > $OUT/fetch.log 2>&1
