@@ -226,7 +226,7 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(mesh, scene, states)
-        print(json.dumps(res))
+        print(json.dumps(res), flush=True)
     model.close()
     if world > 1 or force_shard:
         dist.destroy_process_group()
