@@ -1560,6 +1560,139 @@ __global__ __launch_bounds__(256, 2) void gemm_k32_kernel(const ConvParams p) {
   conv_epilogue<4, 4, (ABL >> 2) & 1>(p, acc[1], m0 + wm * 64, n0 + wn * 128 + 64, lane);
 }
 
+// -------------------------------------------------------------------------------------------------
+// conv_deep_kernel: the rows the full 256x256 rounds of a long-K layer leave over (2.5 % of conv_512 at N = 252) run on
+// an otherwise idle chip, one workgroup per CU walking all 72 K-steps: that chain is latency-bound, not bandwidth- or
+// MFMA-bound.  So: small tiles (BM x 128, more CUs in use), the whole LDS as a deep LDS-DMA ring (6 x 24 KB stages at
+// BM = 64: five K-steps in flight, counted vmcnt, one barrier per step) and the next step's fragments read under the
+// current step's MFMAs (two register sets).  Same K order / accumulation order as every
+// other schedule, so a row's value does not depend on which kernel computed it.
+// -------------------------------------------------------------------------------------------------
+template <int BM>
+__global__ __launch_bounds__(256, 2) void conv_deep_kernel(const ConvParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int BN = 128;
+  constexpr int XB = BM * 128, WB = BN * 128, STAGE = XB + WB;
+  constexpr int NST = BM == 64 ? 6 : 4, D = NST - 1;  // D stages in flight
+  constexpr int XP = BM / 32, WP = 4, LPS = XP + WP;  // 1-KB pieces (8 rows x 128 B) per wave per stage
+  constexpr int MI = BM / 32;                         // wave tile = BM/2 rows x 64 channels
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave & 1, wn = wave >> 1;
+  const int n_tiles = p.Cout / BN;
+  int logical;
+  {
+    const int nblk = gridDim.x, b = blockIdx.x;
+    const int xcd = b & 7, within = b >> 3, q = nblk >> 3, r = nblk & 7;
+    logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
+  }
+  const int mt = logical / n_tiles, nt = logical - mt * n_tiles;
+  const int m0 = p.m_begin + mt * BM, n0 = nt * BN;
+  const int ohw = p.OH * p.OW;
+  const int IHp = p.H + 2 * p.ipad, IWp = p.W + 2 * p.ipad;
+  const int KT = p.Ktot >> 6;
+
+  const int srow = lane >> 3;
+  const int g = (lane & 7) ^ srow;
+  unsigned xoff[XP], woff[WP];
+#pragma unroll
+  for (int i = 0; i < XP; i++) {
+    int m = min(m0 + (wave * XP + i) * 8 + srow, p.M - 1);  // rows past M re-read the last pixel (never stored)
+    int img = m / ohw;
+    int rem = m - img * ohw;
+    int oh = rem / p.OW, ow = rem - oh * p.OW;
+    int ih0 = oh * p.stride - p.pad + p.ipad, iw0 = ow * p.stride - p.pad + p.ipad;
+    xoff[i] = (unsigned)(((img * IHp + ih0) * IWp + iw0) * p.Cin + g * 8) * 2u;
+  }
+#pragma unroll
+  for (int i = 0; i < WP; i++) woff[i] = (unsigned)((n0 + (wave * WP + i) * 8 + srow) * p.Ktot + g * 8) * 2u;
+  const unsigned char *in_b = reinterpret_cast<const unsigned char *>(p.in);
+  const unsigned char *w_b = reinterpret_cast<const unsigned char *>(p.w);
+  const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
+  auto issue = [&](int kt) {
+    const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + (kt % NST) * STAGE);
+    const unsigned char *xb = in_b + p.koff[kt];
+    const unsigned char *wb = w_b + (size_t)kt * 128;
+#pragma unroll
+    for (int i = 0; i < XP; i++) glds16_asm(xb + xoff[i], dst + (wave * XP + i) * 1024);
+#pragma unroll
+    for (int i = 0; i < WP; i++) glds16_asm(wb + woff[i], dst + XB + (wave * WP + i) * 1024);
+  };
+
+  f4 acc[4][MI];
+#pragma unroll
+  for (int a = 0; a < 4; a++)
+#pragma unroll
+    for (int b = 0; b < MI; b++) acc[a][b] = (f4){0.f, 0.f, 0.f, 0.f};
+  const int frow = lane & 15, fk = lane >> 4;
+  int xfo[2], wfo[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ks++) {
+    int slot = (ks * 4 + fk) ^ (lane & 7);
+    xfo[ks] = (wm * (BM / 2) + frow) * 128 + slot * 16;
+    wfo[ks] = XB + (wn * 64 + frow) * 128 + slot * 16;
+  }
+
+  // wait until stage `st` has landed: at most min(max_younger, KT-1-st) younger stages may still be in flight
+  auto wait_stage = [&](int st, int max_younger) {
+    const int younger = min(max_younger, KT - 1 - st);
+    if (younger >= 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * LPS) : "memory");
+    else if (younger == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * LPS) : "memory");
+    else if (younger == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPS) : "memory");
+    else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(1 * LPS) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  };
+  struct Frags { h8 x[2][MI], w[2][4]; };
+  auto read_frags = [&](int kt, Frags &f) {
+    const unsigned char *sb = smem + (kt % NST) * STAGE;
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++) {
+#pragma unroll
+      for (int mi = 0; mi < MI; mi++) f.x[ks][mi] = *reinterpret_cast<const h8 *>(sb + xfo[ks] + mi * 16 * 128);
+#pragma unroll
+      for (int ni = 0; ni < 4; ni++) f.w[ks][ni] = *reinterpret_cast<const h8 *>(sb + wfo[ks] + ni * 16 * 128);
+    }
+  };
+  // one K-step: the fragments of stage kt are already in `cur`; stage kt+1's are read into `nxt` under this step's MFMAs
+  auto step = [&](int kt, const Frags &cur, Frags &nxt) {
+    if (kt + 1 < KT) {
+      wait_stage(kt + 1, D - 2);
+      __builtin_amdgcn_s_barrier();  // every wave has finished reading stages <= kt (read one step ahead)
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      if (kt + D < KT) issue(kt + D);  // reuses the buffer of stage kt-1
+      read_frags(kt + 1, nxt);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+      for (int ni = 0; ni < 4; ni++)
+#pragma unroll
+        for (int mi = 0; mi < MI; mi++)
+          acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(cur.w[ks][ni], cur.x[ks][mi], acc[ni][mi], 0, 0, 0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  };
+
+#pragma unroll
+  for (int s = 0; s < D; s++)
+    if (s < KT) issue(s);
+  Frags fa, fb;
+  wait_stage(0, D - 1);
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  read_frags(0, fa);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  int kt = 0;
+#pragma unroll 1
+  for (; kt + 1 < KT; kt += 2) {
+    step(kt, fa, fb);
+    step(kt + 1, fb, fa);
+  }
+  if (kt < KT) step(kt, fa, fb);
+  conv_epilogue<MI, 4>(p, acc, m0 + wm * (BM / 2), n0 + wn * 64, lane);
+}
+
 // split-K reduction + the conv epilogue: out = relu(sum_s partial[s] + bias + res); thread = (pixel, 4 channels)
 __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvParams p) {
   const int nq = p.Cout / 4;
@@ -2228,7 +2361,7 @@ struct Ctx {
 static bool g_conv_attr_done = false;
 static unsigned long long *g_clk_probe = nullptr;
 static NNScratch g_hook_ws;  // split-K slab of the fpt_* test hooks
-static int g_rem_kernel = 1;  // A/B hook: kernel for the rows the full 256x256 rounds of a long-K layer leave over (0 = 128x128 2-stage, 1 = 256x128 ping-pong, 2 = 256x128 3-stage)
+static int g_rem_kernel = 3;  // A/B hook: kernel for the rows the full 256x256 rounds of a long-K layer leave over (3 = conv_deep_kernel<64>, 4 = <128>, 1 = 256x128 ping-pong, 2 = 256x128 3-stage, 0 = 128x128 2-stage)
 static int g_gemm_kernel = 1;  // A/B hook: Linear layers on gemm_k32_kernel (0 = the 256x256 ping-pong tile + left-overs)
 static int g_grouped_heads = 1;  // A/B hook: the refiner's two heads as one launch per layer when N == 1 (Track)
 static int g_rem_splitk = 0;     // A/B hook: split-K for the rows a 256x256 / 512x128 launch leaves over.  Measured -0.1 ms per
@@ -2288,6 +2421,7 @@ static int run_conv(const Ctx &c, const char *tag, const ConvLayer &L, const __h
   constexpr int LDS3_128 = 3 * (256 * 128 + 128 * 128), LDS3_64 = 3 * (256 * 128 + 64 * 128);
   constexpr int LDS_HALO40 = ((10 * 42 + 7) / 8) * 1024 + 3 * 128 * 64;
   constexpr int LDS_STEM_HALO = ((11 * 84 + 15) / 16) * 1024 + 3 * 64 * 64;
+  constexpr int LDS_DEEP64 = 6 * (64 + 128) * 128, LDS_DEEP128 = 4 * (128 + 128) * 128;
   constexpr int LDS_GEMM_K32 = 3 * (128 + 256) * 64;
   constexpr int LDS_S2_HALO = ((9 * 41 + 7) / 8) * 1024 + 3 * 128 * 64;
   if (!g_conv_attr_done) {
@@ -2313,6 +2447,8 @@ static int run_conv(const Ctx &c, const char *tag, const ConvLayer &L, const __h
     FP_HIP_OK(hipFuncSetAttribute((const void *)conv_big_pp_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 * 128 + 256 * 128)));
     FP_HIP_OK(hipFuncSetAttribute((const void *)conv_stem_halo_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_STEM_HALO));
     FP_HIP_OK(hipFuncSetAttribute((const void *)conv_s2_halo_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_S2_HALO));
+    FP_HIP_OK(hipFuncSetAttribute((const void *)conv_deep_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DEEP64));
+    FP_HIP_OK(hipFuncSetAttribute((const void *)conv_deep_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DEEP128));
     FP_HIP_OK(hipFuncSetAttribute((const void *)gemm_k32_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_GEMM_K32));
     FP_HIP_OK(hipFuncSetAttribute((const void *)gemm_k32_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_GEMM_K32));
     FP_HIP_OK(hipFuncSetAttribute((const void *)gemm_k32_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_GEMM_K32));
@@ -2450,8 +2586,16 @@ static int run_conv(const Ctx &c, const char *tag, const ConvLayer &L, const __h
   }
   if (!grp && p.m_begin > 0 && g_rem_kernel && KT >= 16 && p.ksplit == 1 && L.Cout % 128 == 0) {
     // left-over rows on an otherwise idle chip: a lone workgroup per CU walks all K-steps, so per-step latency is what
-    // counts -- the 8-wave 3-stage ping-pong schedule hides it a little better than the 2-stage 128x128 tile (conv_512
-    // left-overs 61 -> 55 us per launch; measured neutral-to-slower for the 8-step Linear layers, hence KT >= 16)
+    // counts: conv_512 left-overs 61 us per launch on the 2-stage 128x128 tile, 55 us on the 256x128 ping-pong, 39 us on
+    // conv_deep_kernel<64> (neutral-to-slower for the 8-step Linear layers, hence KT >= 16)
+    if (g_rem_kernel == 3 || g_rem_kernel == 4) {
+      const int bm = g_rem_kernel == 3 ? 64 : 128;
+      const dim3 grid(((p.M - p.m_begin + bm - 1) / bm) * (L.Cout / 128));
+      ProfScope ps(c.prof, c.s, (tg + "/conv_deep_kernel").c_str(), flops, bytes);
+      if (bm == 64) hipLaunchKernelGGL(conv_deep_kernel<64>, grid, dim3(256), LDS_DEEP64, c.s, p);
+      else hipLaunchKernelGGL(conv_deep_kernel<128>, grid, dim3(256), LDS_DEEP128, c.s, p);
+      return 0;
+    }
     const int mt2 = (p.M - p.m_begin + 255) / 256;
     ProfScope ps(c.prof, c.s, (tg + (g_rem_kernel == 1 ? "/conv_pp_kernel(rem)" : "/conv_igemm3_kernel(rem)")).c_str(), flops, bytes);
     if (g_rem_kernel == 1) hipLaunchKernelGGL(conv_pp_kernel<128>, dim3(mt2 * (L.Cout / 128)), dim3(512), LDS3_128, c.s, p);
