@@ -2588,12 +2588,36 @@ static int run_conv(const Ctx &c, const char *tag, const ConvLayer &L, const __h
     // left-over rows on an otherwise idle chip: a lone workgroup per CU walks all K-steps, so per-step latency is what
     // counts: conv_512 left-overs 61 us per launch on the 2-stage 128x128 tile, 55 us on the 256x128 ping-pong, 39 us on
     // conv_deep_kernel<64> (neutral-to-slower for the 8-step Linear layers, hence KT >= 16)
-    if (g_rem_kernel == 3 || g_rem_kernel == 4) {
-      const int bm = g_rem_kernel == 3 ? 64 : 128;
-      const dim3 grid(((p.M - p.m_begin + bm - 1) / bm) * (L.Cout / 128));
+    const int n128 = L.Cout / 128;
+    if (g_rem_kernel == 4) {
+      const dim3 grid(((p.M - p.m_begin + 127) / 128) * n128);
       ProfScope ps(c.prof, c.s, (tg + "/conv_deep_kernel").c_str(), flops, bytes);
-      if (bm == 64) hipLaunchKernelGGL(conv_deep_kernel<64>, grid, dim3(256), LDS_DEEP64, c.s, p);
-      else hipLaunchKernelGGL(conv_deep_kernel<128>, grid, dim3(256), LDS_DEEP128, c.s, p);
+      hipLaunchKernelGGL(conv_deep_kernel<128>, grid, dim3(256), LDS_DEEP128, c.s, p);
+      return 0;
+    }
+    if (g_rem_kernel == 3) {
+      // conv_deep_kernel owns its CU, so it only pays while its grid is a single round (<= 256 workgroups).  A larger
+      // left-over (mid-sized batches) first takes full rounds of the 256x128 ping-pong kernel, then the deep kernel.
+      int rows = p.M - p.m_begin;
+      if (((rows + 63) / 64) * n128 > 256) {
+        const int mt_pp = (((rows + 255) / 256) * n128 / 256) * 256 / n128;  // 256-row m-tiles in full rounds
+        const int rows_pp = std::min(mt_pp * 256, rows);
+        const int rest = rows - rows_pp;
+        const bool cascade = mt_pp > 0 && ((rest + 63) / 64) * n128 <= 256;
+        ConvParams pb = p;
+        if (cascade) pb.M = p.m_begin + rows_pp;
+        const double frac = cascade ? (double)rows_pp / rows : 1.0;
+        {
+          ProfScope ps(c.prof, c.s, (tg + "/conv_pp_kernel(rem)").c_str(), flops * frac, bytes * frac);
+          hipLaunchKernelGGL(conv_pp_kernel<128>, dim3(((pb.M - pb.m_begin + 255) / 256) * n128), dim3(512), LDS3_128, c.s, pb);
+        }
+        if (!cascade || rest == 0) return 0;
+        flops *= (1.0 - frac); bytes *= (1.0 - frac);
+        p.m_begin += rows_pp;
+        rows = rest;
+      }
+      ProfScope ps(c.prof, c.s, (tg + "/conv_deep_kernel").c_str(), flops, bytes);
+      hipLaunchKernelGGL(conv_deep_kernel<64>, dim3(((rows + 63) / 64) * n128), dim3(256), LDS_DEEP64, c.s, p);
       return 0;
     }
     const int mt2 = (p.M - p.m_begin + 255) / 256;
