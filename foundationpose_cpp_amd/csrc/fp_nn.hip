@@ -2362,6 +2362,7 @@ static bool g_conv_attr_done = false;
 static unsigned long long *g_clk_probe = nullptr;
 static NNScratch g_hook_ws;  // split-K slab of the fpt_* test hooks
 static int g_rem_kernel = 3;  // A/B hook: kernel for the rows the full 256x256 rounds of a long-K layer leave over (3 = conv_deep_kernel<64>, 4 = <128>, 1 = 256x128 ping-pong, 2 = 256x128 3-stage, 0 = 128x128 2-stage)
+static int g_rem_small = 1;   // A/B hook (0 = off): long-K layers too small for one full 256x256 round take the left-over path as a whole
 static int g_gemm_kernel = 1;  // A/B hook: Linear layers on gemm_k32_kernel (0 = the 256x256 ping-pong tile + left-overs)
 static int g_grouped_heads = 1;  // A/B hook: the refiner's two heads as one launch per layer when N == 1 (Track)
 static int g_rem_splitk = 0;     // A/B hook: split-K for the rows a 256x256 / 512x128 launch leaves over.  Measured -0.1 ms per
@@ -2584,7 +2585,7 @@ static int run_conv(const Ctx &c, const char *tag, const ConvLayer &L, const __h
       if (g_rem_splitk && plan_splitk(p.M - p.m_begin, 384)) return 1;
     }
   }
-  if (!grp && p.m_begin > 0 && g_rem_kernel && KT >= 16 && p.ksplit == 1 && L.Cout % 128 == 0) {
+  if (!grp && (p.m_begin > 0 || (g_rem_small && p.M >= 8192)) && g_rem_kernel && KT >= 16 && p.ksplit == 1 && L.Cout % 128 == 0) {
     // left-over rows on an otherwise idle chip: a lone workgroup per CU walks all K-steps, so per-step latency is what
     // counts: conv_512 left-overs 61 us per launch on the 2-stage 128x128 tile, 55 us on the 256x128 ping-pong, 39 us on
     // conv_deep_kernel<64> (neutral-to-slower for the 8-step Linear layers, hence KT >= 16)
@@ -2925,6 +2926,7 @@ void fpt_set_rem_splitk(int v) { fp::g_rem_splitk = v; }
 void fpt_set_grouped_heads(int v) { fp::g_grouped_heads = v; }
 void fpt_set_gemm_kernel(int v) { fp::g_gemm_kernel = v; }
 void fpt_set_rem_kernel(int v) { fp::g_rem_kernel = v; }
+void fpt_set_rem_small(int v) { fp::g_rem_small = v; }
 void fpt_set_raster_strip_rows(int r) { fp::set_raster_strip_rows(r); }
 
 // clock probe: allocate room for `blocks` records, run convs, then read back mean shader MHz and mean main-loop cycles
