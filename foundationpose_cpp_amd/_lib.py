@@ -9,7 +9,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfoundationpose_amd.so")
+LIB_PATH = os.environ.get("FP_LIB_PATH") or os.path.join(_HERE, "libfoundationpose_amd.so")  # FP_LIB_PATH: experimental builds (tools/)
 CSRC = os.path.join(_HERE, "csrc")
 
 # every symbol include/foundationpose_amd.h declares

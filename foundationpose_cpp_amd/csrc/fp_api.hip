@@ -28,7 +28,12 @@ static thread_local std::string g_last_error;
 // (tools/stress_*.py) and no model writes another's buffers (tools/dbg_cross_model.py).  The cause is not isolated, so
 // every entry point that enqueues work holds this lock until its stream is idle again.
 static std::recursive_mutex g_gpu_mutex;
-#define FP_GPU_LOCK() std::lock_guard<std::recursive_mutex> fp_gpu_lock_(g_gpu_mutex)
+static const bool g_gpu_lock_off = std::getenv("FP_DISABLE_GPU_LOCK") != nullptr;  // debugging: tools/dbg_concurrent.py
+struct GpuLock {
+  GpuLock() { if (!g_gpu_lock_off) g_gpu_mutex.lock(); }
+  ~GpuLock() { if (!g_gpu_lock_off) g_gpu_mutex.unlock(); }
+};
+#define FP_GPU_LOCK() GpuLock fp_gpu_lock_
 void set_error(const std::string &msg) { g_last_error = msg; }
 std::atomic<unsigned long> g_alloc_epoch{0};
 
@@ -451,6 +456,29 @@ int fpt_digest_buffers(fp_model *m, unsigned long long out[16]) {
   FP_HIP_OK(hipStreamSynchronize(m->stream));
   (void)hipFree(d);
   return 0;
+}
+
+// debug: allocate the vertex-stage intermediates buffer (launches with N == 64 fill it) / read it back
+long long fpt_vertex_dbg(fp_model *m, void *dst, long long bytes) {
+  if (!fp::g_vertex_dbg) {
+    float4 *p = nullptr;
+    if (hipMalloc((void **)&p, (size_t)bytes) != hipSuccess) return -1;
+    fp::g_vertex_dbg = p;
+    return 0;
+  }
+  if (hipMemcpyAsync(dst, fp::g_vertex_dbg, (size_t)bytes, hipMemcpyDeviceToHost, m->stream) != hipSuccess || hipStreamSynchronize(m->stream) != hipSuccess) return -1;
+  return bytes;
+}
+// debug: copy one of the model's device buffers to the host (0 recs, 1 clip, 2 attr, 3 nn_in, 4 poses); returns bytes copied
+long long fpt_read_buffer(fp_model *m, int which, void *dst, long long max_bytes) {
+  size_t V = m->targets.empty() ? 0 : (size_t)m->targets[0].mesh.V;
+  const void *src[5] = {m->recs, m->clip, m->attr, m->nn_in, m->poses_dev};
+  size_t n[5] = {(size_t)m->cap * sizeof(PoseRec), (size_t)m->cap * V * 16, (size_t)m->cap * V * 16,
+                 (size_t)2 * m->cap * FP_NN_IN_IMG_HALFS * 2, (size_t)m->cap * 64};
+  if (which < 0 || which > 4 || !src[which]) return -1;
+  size_t b = std::min<size_t>(n[which], (size_t)max_bytes);
+  if (hipMemcpyAsync(dst, src[which], b, hipMemcpyDeviceToHost, m->stream) != hipSuccess || hipStreamSynchronize(m->stream) != hipSuccess) return -1;
+  return (long long)b;
 }
 
 const char *fp_last_error(void) { return g_last_error.c_str(); }

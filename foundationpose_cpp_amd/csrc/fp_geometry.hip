@@ -22,6 +22,7 @@
 // reference's ~14 full-tensor passes.  Triangles are tiny (~5 px) so lanes map to triangles, not pixels.
 
 #include "fp_internal.h"
+#include <cstdlib>
 
 namespace fp {
 
@@ -145,27 +146,47 @@ void launch_pose_setup(hipStream_t s, const float *poses_dev, int N, const float
 // vertex stage: clip position, camera-space point, per-vertex Lambert term
 // ---------------------------------------------------------------------------------------------
 
+template <int VAR>  // race hunt: 0 = LDS-staged record (compiler picks ds_read_b96), 1 = LDS, b128 reads only, 2 = scalar loads, 3 = 0 + lgkmcnt(0)
 __global__ void vertex_kernel(const float *__restrict__ verts, const float *__restrict__ normals, int V,
-                              const PoseRec *__restrict__ recs, float4 *__restrict__ clip, float4 *__restrict__ attr) {
+                              const PoseRec *__restrict__ recs, float4 *__restrict__ clip, float4 *__restrict__ attr,
+                              float4 *__restrict__ dbg) {
   int v = blockIdx.x * blockDim.x + threadIdx.x;
   int n = blockIdx.y;
-  __shared__ PoseRec rec;
-  {
+  const unsigned long long t_begin = dbg ? wall_clock64() : 0ull;
+  __shared__ __attribute__((aligned(16))) float recf[56];
+  float M[16], pose[16], a00, a11, a30, a31;
+  if (VAR == 2) {
+    const PoseRec &rec = recs[n];
+    for (int i = 0; i < 16; i++) { M[i] = rec.M[i]; pose[i] = rec.pose[i]; }
+    a00 = rec.a00; a11 = rec.a11; a30 = rec.a30; a31 = rec.a31;
+  } else {
     const float *src = reinterpret_cast<const float *>(&recs[n]);
-    float *dst = reinterpret_cast<float *>(&rec);
-    for (int i = threadIdx.x; i < (int)(sizeof(PoseRec) / 4); i += blockDim.x) dst[i] = src[i];
+    for (int i = threadIdx.x; i < (int)(sizeof(PoseRec) / 4); i += blockDim.x) recf[i] = src[i];
+    __syncthreads();
+    if (VAR == 1) {
+      const float4 *r4 = reinterpret_cast<const float4 *>(recf);
+      for (int i = 0; i < 4; i++) {
+        float4 a = r4[i], b = r4[4 + i];
+        M[i * 4] = a.x; M[i * 4 + 1] = a.y; M[i * 4 + 2] = a.z; M[i * 4 + 3] = a.w;
+        pose[i * 4] = b.x; pose[i * 4 + 1] = b.y; pose[i * 4 + 2] = b.z; pose[i * 4 + 3] = b.w;
+      }
+      float4 c = r4[8];
+      a00 = c.x; a11 = c.y; a30 = c.z; a31 = c.w;
+    } else {
+      for (int i = 0; i < 16; i++) { M[i] = recf[i]; pose[i] = recf[16 + i]; }
+      a00 = recf[32]; a11 = recf[33]; a30 = recf[34]; a31 = recf[35];
+    }
+    if (VAR == 3) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   }
-  __syncthreads();
   if (v >= V) return;
-  const float *M = rec.M, *pose = rec.pose;
   float x = verts[v * 3], y = verts[v * 3 + 1], z = verts[v * 3 + 2];
   float tx = M[0] * x + M[4] * y + M[8] * z + M[12];
   float ty = M[1] * x + M[5] * y + M[9] * z + M[13];
   float tz = M[2] * x + M[6] * y + M[10] * z + M[14];
   float tw = M[3] * x + M[7] * y + M[11] * z + M[15];
   float4 c;
-  c.x = tx * rec.a00 + tw * rec.a30;
-  c.y = ty * rec.a11 + tw * rec.a31;
+  c.x = tx * a00 + tw * a30;
+  c.y = ty * a11 + tw * a31;
   c.z = tz;
   c.w = tw;
   float4 a;
@@ -181,11 +202,27 @@ __global__ void vertex_kernel(const float *__restrict__ verts, const float *__re
   a.w = clampf(val, 0, 1);
   clip[(size_t)n * V + v] = c;
   attr[(size_t)n * V + v] = a;
+  if (dbg) {
+    const unsigned long long t_end = wall_clock64();
+    unsigned hwid = 0;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    dbg[((size_t)n * V + v) * 3] = make_float4(nx, ny, nz, l2);
+    dbg[((size_t)n * V + v) * 3 + 1] = make_float4(ux, uy, uz, val);
+    dbg[((size_t)n * V + v) * 3 + 2] = make_float4((float)(t_end - t_begin), __uint_as_float(hwid), __uint_as_float((unsigned)(t_begin & 0xffffffffu)), 0.f);
+  }
 }
 
+float4 *g_vertex_dbg = nullptr;  // race hunt (tools/dbg_concurrent3.py): per-vertex intermediates, first caller only
 void launch_vertex(hipStream_t s, const DeviceMesh &m, const PoseRec *recs, int N, float4 *clip, float4 *attr) {
-  hipLaunchKernelGGL(vertex_kernel, dim3((m.V + 255) / 256, N), dim3(256), 0, s, m.verts, m.normals, m.V, recs, clip,
-                     attr);
+  static const int var = std::getenv("FP_VERTEX_VAR") ? std::atoi(std::getenv("FP_VERTEX_VAR")) : 0;
+  float4 *dbg = g_vertex_dbg && N == 64 ? g_vertex_dbg : nullptr;
+  const dim3 grid((m.V + 255) / 256, N);
+  switch (var) {
+    case 1: hipLaunchKernelGGL(vertex_kernel<1>, grid, dim3(256), 0, s, m.verts, m.normals, m.V, recs, clip, attr, dbg); break;
+    case 2: hipLaunchKernelGGL(vertex_kernel<2>, grid, dim3(256), 0, s, m.verts, m.normals, m.V, recs, clip, attr, dbg); break;
+    case 3: hipLaunchKernelGGL(vertex_kernel<3>, grid, dim3(256), 0, s, m.verts, m.normals, m.V, recs, clip, attr, dbg); break;
+    default: hipLaunchKernelGGL(vertex_kernel<0>, grid, dim3(256), 0, s, m.verts, m.normals, m.V, recs, clip, attr, dbg); break;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------

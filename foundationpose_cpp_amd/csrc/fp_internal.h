@@ -106,6 +106,7 @@ enum OutMode { OUT_F32X6 = 0, OUT_F16X8 = 1 };
 
 void launch_pose_setup(hipStream_t s, const float *poses_dev, int N, const float *K9_host, int img_h, int img_w,
                        float crop_ratio, float diameter, PoseRec *recs);
+extern float4 *g_vertex_dbg;  // race hunt: per-vertex intermediates (null = off)
 void launch_vertex(hipStream_t s, const DeviceMesh &m, const PoseRec *recs, int N, float4 *clip, float4 *attr);
 void launch_raster_shade(hipStream_t s, const DeviceMesh &m, const PoseRec *recs, int N, const float4 *clip,
                          const float4 *attr, OutMode mode, void *out, int32_t *tri_id_dbg, float *rast_dbg);

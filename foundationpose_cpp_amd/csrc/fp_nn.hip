@@ -1702,7 +1702,10 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvParam
   const int mr = (int)(i / nq), n = (int)(i - (size_t)mr * nq) * 4;
   const int m = p.m_begin + mr;
   f4 a = *reinterpret_cast<const f4 *>(p.partial + (size_t)mr * p.Cout + n);
-  for (int sp = 1; sp < p.ksplit; sp++) a += *reinterpret_cast<const f4 *>(p.partial + ((size_t)sp * rows + mr) * p.Cout + n);
+  for (int sp = 1; sp < p.ksplit; sp++) {  // component-wise: no packed-f32 VALU ops in this library ("packed f32")
+    const f4 b = *reinterpret_cast<const f4 *>(p.partial + ((size_t)sp * rows + mr) * p.Cout + n);
+    a[0] += b[0]; a[1] += b[1]; a[2] += b[2]; a[3] += b[3];
+  }
   const int grp = p.grp_rows ? m / p.grp_rows : 0;
   float4 bv = *reinterpret_cast<const float4 *>(p.bias + grp * p.Cout + n);
   float v0 = a[0] + bv.x, v1 = a[1] + bv.y, v2 = a[2] + bv.z, v3 = a[3] + bv.w;

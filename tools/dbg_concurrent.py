@@ -7,6 +7,7 @@ from foundationpose_cpp_amd import FoundationPose, synthetic as syn, weights as 
 L = _lib.lib()
 if len(sys.argv) > 1:
     L.fpt_set_conv_variant(int(sys.argv[1]))
+ITERS = int(sys.argv[2]) if len(sys.argv) > 2 else 12
 mesh = syn.make_mesh()
 d = tempfile.mkdtemp(); rp, sp = os.path.join(d, "r.fpw"), os.path.join(d, "s.fpw")
 W.pack_synthetic("refiner", rp); W.pack_synthetic("scorer", sp)
@@ -40,7 +41,7 @@ def bufdig(m):
 static0 = [bufdig(m) for m in models]
 res = [[], []]
 def worker(i):
-    for k in range(12):
+    for k in range(ITERS):
         res[i].append(reg(models[i], scenes[i]))
 th = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
 [t.start() for t in th]; [t.join() for t in th]
@@ -54,7 +55,7 @@ for i in range(2):
             bad += 1
             dif = np.abs(sc - seq[i][1])
             print(f"model {i} iter {k}: winner {b} (seq {seq[i][0]}), scores differ in {int((dif > 0).sum())} of 252, max |d| {dif.max():.3e} at {int(dif.argmax())}")
-print("bad", bad, "of 24")
+print("bad", bad, "of", 2 * ITERS)
 for i, m in enumerate(models):
     after = bufdig(m)
     ch = [BN[j] for j in range(11, 16) if after[j] != static0[i][j]]
