@@ -184,7 +184,7 @@ def main():
         measured_peak, measured_mhz = None, None
         if world == 1 and not args.no_mfma_peak:
             from foundationpose_cpp_amd import _lib
-            L = _lib.lib()
+            L = _lib.test_lib()   # the micro-benchmark kernel lives in the test build
             L.fpt_mfma_peak.restype = C.c_float
             L.fpt_mfma_peak.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
             mhz = C.c_double(0)

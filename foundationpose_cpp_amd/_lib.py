@@ -22,7 +22,7 @@ SYMBOLS = [
     "fp_profile_enable", "fp_profile_reset", "fp_profile_report", "fp_stream", "fp_synchronize",
     "fp_mesh_load_obj", "fp_mesh_free", "fp_mesh_view", "fp_mesh_orient_bounds",
     "fp_image_read_png", "fp_frame_size", "fp_read_rgb_depth_mask", "fp_read_cam_k", "fp_image_write_png_rgb",
-    "fp_draw_bbox3d",
+    "fp_draw_bbox3d", "fp_set_precision", "fp_get_precision", "fp_calibrate_fp8", "fp_get_calibration", "fp_set_calibration",
 ]
 
 
@@ -94,6 +94,8 @@ def lib() -> C.CDLL:
         "fp_register_shard_finish": [vp, vp, vp, ci, vp, vp, vp],
         "fp_profile_enable": [vp, ci], "fp_profile_reset": [vp], "fp_profile_report": [vp, vp, ci],
         "fp_synchronize": [vp], "fp_mesh_orient_bounds": [vp, vp, vp],
+        "fp_set_precision": [vp, ci], "fp_get_precision": [vp], "fp_calibrate_fp8": [vp, vp, vp, vp, ci, ci, ci, cs],
+        "fp_get_calibration": [vp, vp], "fp_set_calibration": [vp, vp],
     }
     for name, at in sigs.items():
         f = getattr(L, name)
@@ -101,6 +103,31 @@ def lib() -> C.CDLL:
         f.restype = C.c_int
     _LIB = L
     return L
+
+
+TEST_LIB_PATH = os.path.join(_HERE, "libfoundationpose_amd_test.so")
+_TEST_LIB = None
+
+
+def test_lib() -> C.CDLL:
+    """The same sources built with -DFP_TEST_HOOKS: the product plus the fpt_* kernel-level hooks (unit tests of single
+    kernels, A/B switches, ablations, stress and debug helpers).  Used by tests/ and tools/ only; nothing in the
+    product path loads it."""
+    global _TEST_LIB
+    if _TEST_LIB is None:
+        if not os.path.exists(TEST_LIB_PATH):
+            raise RuntimeError(f"{TEST_LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
+        _TEST_LIB = C.CDLL(TEST_LIB_PATH)
+        _TEST_LIB.fp_last_error.restype = C.c_char_p
+    return _TEST_LIB
+
+
+def use_test_lib() -> None:
+    """tools/ only: make lib() load the test build (a superset of the product) so that fpt_* switches act on the very
+    library instance that runs the pipeline.  Must be called before the first lib()."""
+    global LIB_PATH
+    assert _LIB is None, "use_test_lib() must come before the first lib()"
+    LIB_PATH = TEST_LIB_PATH
 
 
 def last_error() -> str:

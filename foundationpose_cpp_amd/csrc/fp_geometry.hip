@@ -44,6 +44,21 @@ __device__ __forceinline__ float clampf(float f, float a, float b) { return fmax
 // border of FP_NN_IN_BORDER s2d-pixels ([N,84,84,32]); in 16-byte units the pixel (n,y,x) lands at
 // ((n*84 + y/2 + 2)*84 + x/2 + 2)*4 + (y&1)*2 + (x&1).  This turns the 7x7 stride-2 stem convolution into a 4x4
 // stride-1 convolution with Cin = 32 that the generic MFMA implicit-GEMM kernel runs without bounds checks.
+// six channel values -> one 16-byte network-input pixel (r,g,b,x,y,z,0,0) in the 2-byte type of the output mode
+template <int MODE>
+__device__ __forceinline__ uint4 pack6(const float (&o)[6]) {
+  if constexpr (MODE == OUT_BF16X8) {
+    union { __bf16 h[8]; uint4 u4; } pk;
+    for (int c = 0; c < 6; c++) pk.h[c] = (__bf16)o[c];
+    pk.h[6] = (__bf16)0.f; pk.h[7] = (__bf16)0.f;
+    return pk.u4;
+  } else {
+    union { __half h[8]; uint4 u4; } pk;
+    for (int c = 0; c < 6; c++) pk.h[c] = __float2half(o[c]);
+    pk.h[6] = __float2half(0.f); pk.h[7] = __float2half(0.f);
+    return pk.u4;
+  }
+}
 __device__ __forceinline__ size_t s2d_index(size_t n, int y, int x) {
   constexpr int P = CROP / 2 + 2 * FP_NN_IN_BORDER;
   return ((n * P + (size_t)((y >> 1) + FP_NN_IN_BORDER)) * P + (size_t)((x >> 1) + FP_NN_IN_BORDER)) * 4 +
@@ -146,47 +161,26 @@ void launch_pose_setup(hipStream_t s, const float *poses_dev, int N, const float
 // vertex stage: clip position, camera-space point, per-vertex Lambert term
 // ---------------------------------------------------------------------------------------------
 
-template <int VAR>  // race hunt: 0 = LDS-staged record (compiler picks ds_read_b96), 1 = LDS, b128 reads only, 2 = scalar loads, 3 = 0 + lgkmcnt(0)
+// The per-hypothesis record is read through uniform (scalar) loads.
 __global__ void vertex_kernel(const float *__restrict__ verts, const float *__restrict__ normals, int V,
                               const PoseRec *__restrict__ recs, float4 *__restrict__ clip, float4 *__restrict__ attr,
                               float4 *__restrict__ dbg) {
-  int v = blockIdx.x * blockDim.x + threadIdx.x;
-  int n = blockIdx.y;
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n = blockIdx.y;
+#ifdef FP_TEST_HOOKS
   const unsigned long long t_begin = dbg ? wall_clock64() : 0ull;
-  __shared__ __attribute__((aligned(16))) float recf[56];
-  float M[16], pose[16], a00, a11, a30, a31;
-  if (VAR == 2) {
-    const PoseRec &rec = recs[n];
-    for (int i = 0; i < 16; i++) { M[i] = rec.M[i]; pose[i] = rec.pose[i]; }
-    a00 = rec.a00; a11 = rec.a11; a30 = rec.a30; a31 = rec.a31;
-  } else {
-    const float *src = reinterpret_cast<const float *>(&recs[n]);
-    for (int i = threadIdx.x; i < (int)(sizeof(PoseRec) / 4); i += blockDim.x) recf[i] = src[i];
-    __syncthreads();
-    if (VAR == 1) {
-      const float4 *r4 = reinterpret_cast<const float4 *>(recf);
-      for (int i = 0; i < 4; i++) {
-        float4 a = r4[i], b = r4[4 + i];
-        M[i * 4] = a.x; M[i * 4 + 1] = a.y; M[i * 4 + 2] = a.z; M[i * 4 + 3] = a.w;
-        pose[i * 4] = b.x; pose[i * 4 + 1] = b.y; pose[i * 4 + 2] = b.z; pose[i * 4 + 3] = b.w;
-      }
-      float4 c = r4[8];
-      a00 = c.x; a11 = c.y; a30 = c.z; a31 = c.w;
-    } else {
-      for (int i = 0; i < 16; i++) { M[i] = recf[i]; pose[i] = recf[16 + i]; }
-      a00 = recf[32]; a11 = recf[33]; a30 = recf[34]; a31 = recf[35];
-    }
-    if (VAR == 3) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  }
+#endif
   if (v >= V) return;
+  const PoseRec &rec = recs[n];
+  const float *M = rec.M, *pose = rec.pose;
   float x = verts[v * 3], y = verts[v * 3 + 1], z = verts[v * 3 + 2];
   float tx = M[0] * x + M[4] * y + M[8] * z + M[12];
   float ty = M[1] * x + M[5] * y + M[9] * z + M[13];
   float tz = M[2] * x + M[6] * y + M[10] * z + M[14];
   float tw = M[3] * x + M[7] * y + M[11] * z + M[15];
   float4 c;
-  c.x = tx * a00 + tw * a30;
-  c.y = ty * a11 + tw * a31;
+  c.x = tx * rec.a00 + tw * rec.a30;
+  c.y = ty * rec.a11 + tw * rec.a31;
   c.z = tz;
   c.w = tw;
   float4 a;
@@ -202,7 +196,8 @@ __global__ void vertex_kernel(const float *__restrict__ verts, const float *__re
   a.w = clampf(val, 0, 1);
   clip[(size_t)n * V + v] = c;
   attr[(size_t)n * V + v] = a;
-  if (dbg) {
+#ifdef FP_TEST_HOOKS
+  if (dbg) {  // tools/dbg_concurrent3.py: per-vertex intermediates, wave duration and placement
     const unsigned long long t_end = wall_clock64();
     unsigned hwid = 0;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
@@ -210,19 +205,18 @@ __global__ void vertex_kernel(const float *__restrict__ verts, const float *__re
     dbg[((size_t)n * V + v) * 3 + 1] = make_float4(ux, uy, uz, val);
     dbg[((size_t)n * V + v) * 3 + 2] = make_float4((float)(t_end - t_begin), __uint_as_float(hwid), __uint_as_float((unsigned)(t_begin & 0xffffffffu)), 0.f);
   }
+#endif
 }
 
-float4 *g_vertex_dbg = nullptr;  // race hunt (tools/dbg_concurrent3.py): per-vertex intermediates, first caller only
+#ifdef FP_TEST_HOOKS
+float4 *g_vertex_dbg = nullptr;  // race hunt (tools/dbg_concurrent3.py): launches with N == 64 fill it
+#endif
 void launch_vertex(hipStream_t s, const DeviceMesh &m, const PoseRec *recs, int N, float4 *clip, float4 *attr) {
-  static const int var = std::getenv("FP_VERTEX_VAR") ? std::atoi(std::getenv("FP_VERTEX_VAR")) : 0;
-  float4 *dbg = g_vertex_dbg && N == 64 ? g_vertex_dbg : nullptr;
-  const dim3 grid((m.V + 255) / 256, N);
-  switch (var) {
-    case 1: hipLaunchKernelGGL(vertex_kernel<1>, grid, dim3(256), 0, s, m.verts, m.normals, m.V, recs, clip, attr, dbg); break;
-    case 2: hipLaunchKernelGGL(vertex_kernel<2>, grid, dim3(256), 0, s, m.verts, m.normals, m.V, recs, clip, attr, dbg); break;
-    case 3: hipLaunchKernelGGL(vertex_kernel<3>, grid, dim3(256), 0, s, m.verts, m.normals, m.V, recs, clip, attr, dbg); break;
-    default: hipLaunchKernelGGL(vertex_kernel<0>, grid, dim3(256), 0, s, m.verts, m.normals, m.V, recs, clip, attr, dbg); break;
-  }
+  float4 *dbg = nullptr;
+#ifdef FP_TEST_HOOKS
+  if (g_vertex_dbg && N == 64) dbg = g_vertex_dbg;
+#endif
+  hipLaunchKernelGGL(vertex_kernel, dim3((m.V + 255) / 256, N), dim3(256), 0, s, m.verts, m.normals, m.V, recs, clip, attr, dbg);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -509,65 +503,73 @@ __global__ __launch_bounds__(NT) void raster_shade_kernel(
       float2 *d2 = reinterpret_cast<float2 *>(d);
       d2[0] = make_float2(o[0], o[1]); d2[1] = make_float2(o[2], o[3]); d2[2] = make_float2(o[4], o[5]);
     } else {
-      union { __half h[8]; uint4 u4; } pk;
-      for (int c = 0; c < 6; c++) pk.h[c] = __float2half(o[c]);
-      pk.h[6] = __float2half(0.f); pk.h[7] = __float2half(0.f);
-      reinterpret_cast<uint4 *>(out_all)[s2d_index((size_t)n, CROP - 1 - py, px)] = pk.u4;
+      reinterpret_cast<uint4 *>(out_all)[s2d_index((size_t)n, CROP - 1 - py, px)] = pack6<MODE>(o);
     }
   }
 }
 
-template <int STRIP_ROWS>
+template <int MODE, int STRIP_ROWS>
 static void launch_raster_shade_t(hipStream_t s, const DeviceMesh &m, const PoseRec *recs, int N, const float4 *clip,
-                                  const float4 *attr, OutMode mode, void *out, int32_t *tri_id_dbg, float *rast_dbg) {
+                                  const float4 *attr, void *out, int32_t *tri_id_dbg, float *rast_dbg) {
   size_t lds = (size_t)STRIP_ROWS * CROP * sizeof(unsigned long long);
   dim3 grid(CROP / STRIP_ROWS, N), block(256);
   float downscale = m.diameter / 2;
-  if (STRIP_ROWS == 8 && N <= 4 && mode == OUT_F16X8 && !tri_id_dbg && !rast_dbg) {
-    hipLaunchKernelGGL((raster_shade_kernel<OUT_F16X8, STRIP_ROWS, 1024>), grid, dim3(1024), lds, s, m.faces, m.F, m.V, m.uvs,
+  if (STRIP_ROWS == 8 && N <= 4 && MODE != OUT_F32X6 && !tri_id_dbg && !rast_dbg) {
+    hipLaunchKernelGGL((raster_shade_kernel<MODE, STRIP_ROWS, 1024>), grid, dim3(1024), lds, s, m.faces, m.F, m.V, m.uvs,
                        m.tex, m.TH, m.TW, downscale, recs, clip, attr, out, tri_id_dbg, rast_dbg);
     return;
   }
-  if (mode == OUT_F32X6)
-    hipLaunchKernelGGL((raster_shade_kernel<OUT_F32X6, STRIP_ROWS>), grid, block, lds, s, m.faces, m.F, m.V, m.uvs, m.tex,
-                       m.TH, m.TW, downscale, recs, clip, attr, out, tri_id_dbg, rast_dbg);
-  else
-    hipLaunchKernelGGL((raster_shade_kernel<OUT_F16X8, STRIP_ROWS>), grid, block, lds, s, m.faces, m.F, m.V, m.uvs, m.tex,
-                       m.TH, m.TW, downscale, recs, clip, attr, out, tri_id_dbg, rast_dbg);
+  hipLaunchKernelGGL((raster_shade_kernel<MODE, STRIP_ROWS>), grid, block, lds, s, m.faces, m.F, m.V, m.uvs, m.tex,
+                     m.TH, m.TW, downscale, recs, clip, attr, out, tri_id_dbg, rast_dbg);
 }
 
-static int g_strip_rows_override = 0;
+#ifdef FP_TEST_HOOKS
+static int g_strip_rows_override = 0;  // A/B: tools/ab_raster_strips.py (test build only)
 void set_raster_strip_rows(int r) { g_strip_rows_override = r; }
+#else
+static constexpr int g_strip_rows_override = 0;
+#endif
 
 // tall strips with 1024-thread workgroups: every strip walks ALL triangles (setup + cull), so 2 strips of 80 rows do a
 // quarter of the redundant setup of 8 strips of 20 (0.40 -> 0.21 ms per Register at N = 252); 102 KB of LDS = one
 // workgroup per CU, hence 16 waves per workgroup.  A/B codes for set_raster_strip_rows: 1080 / 1040 / 1020
-template <int STRIP_ROWS>
+template <int MODE, int STRIP_ROWS>
 static void launch_raster_tall(hipStream_t s, const DeviceMesh &m, const PoseRec *recs, int N, const float4 *clip,
                                const float4 *attr, void *out) {
   size_t lds = (size_t)STRIP_ROWS * CROP * sizeof(unsigned long long);
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute((const void *)raster_shade_kernel<OUT_F16X8, STRIP_ROWS, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_done = true;
-  }
-  hipLaunchKernelGGL((raster_shade_kernel<OUT_F16X8, STRIP_ROWS, 1024>), dim3(CROP / STRIP_ROWS, N), dim3(1024), lds, s, m.faces, m.F,
+  // once per instantiation, thread-safe (function-local static): opt in to > 64 KB of dynamic LDS
+  static const hipError_t attr_rc = hipFuncSetAttribute((const void *)raster_shade_kernel<MODE, STRIP_ROWS, 1024>,
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  (void)attr_rc;
+  hipLaunchKernelGGL((raster_shade_kernel<MODE, STRIP_ROWS, 1024>), dim3(CROP / STRIP_ROWS, N), dim3(1024), lds, s, m.faces, m.F,
                      m.V, m.uvs, m.tex, m.TH, m.TW, m.diameter / 2, recs, clip, attr, out, nullptr, nullptr);
+}
+
+template <int MODE>
+static void launch_raster_mode(hipStream_t s, const DeviceMesh &m, const PoseRec *recs, int N, const float4 *clip,
+                               const float4 *attr, void *out, int32_t *tri_id_dbg, float *rast_dbg) {
+  int rows = g_strip_rows_override ? g_strip_rows_override : (N >= 100 ? 1080 : (N >= 64 ? 20 : 8));
+  if (rows > 1000 && MODE != OUT_F32X6 && !tri_id_dbg && !rast_dbg) {
+    if (rows == 1080) { launch_raster_tall<MODE, 80>(s, m, recs, N, clip, attr, out); return; }
+#ifdef FP_TEST_HOOKS
+    if (rows == 1040) launch_raster_tall<MODE, 40>(s, m, recs, N, clip, attr, out);
+    else launch_raster_tall<MODE, 20>(s, m, recs, N, clip, attr, out);
+    return;
+#endif
+  }
+  if (rows > 1000) rows = 20;
+#ifdef FP_TEST_HOOKS
+  if (rows == 40) { launch_raster_shade_t<MODE, 40>(s, m, recs, N, clip, attr, out, tri_id_dbg, rast_dbg); return; }
+#endif
+  if (rows == 20) launch_raster_shade_t<MODE, 20>(s, m, recs, N, clip, attr, out, tri_id_dbg, rast_dbg);
+  else launch_raster_shade_t<MODE, 8>(s, m, recs, N, clip, attr, out, tri_id_dbg, rast_dbg);
 }
 
 void launch_raster_shade(hipStream_t s, const DeviceMesh &m, const PoseRec *recs, int N, const float4 *clip,
                          const float4 *attr, OutMode mode, void *out, int32_t *tri_id_dbg, float *rast_dbg) {
-  int rows = g_strip_rows_override ? g_strip_rows_override : (N >= 100 ? 1080 : (N >= 64 ? 20 : 8));  // A/B: tools/ab_raster_strips.py
-  if (rows > 1000 && mode == OUT_F16X8 && !tri_id_dbg && !rast_dbg) {
-    if (rows == 1080) launch_raster_tall<80>(s, m, recs, N, clip, attr, out);
-    else if (rows == 1040) launch_raster_tall<40>(s, m, recs, N, clip, attr, out);
-    else launch_raster_tall<20>(s, m, recs, N, clip, attr, out);
-    return;
-  }
-  if (rows > 1000) rows = 20;
-  if (rows == 40) launch_raster_shade_t<40>(s, m, recs, N, clip, attr, mode, out, tri_id_dbg, rast_dbg);
-  else if (rows == 20) launch_raster_shade_t<20>(s, m, recs, N, clip, attr, mode, out, tri_id_dbg, rast_dbg);
-  else launch_raster_shade_t<8>(s, m, recs, N, clip, attr, mode, out, tri_id_dbg, rast_dbg);
+  if (mode == OUT_F32X6) launch_raster_mode<OUT_F32X6>(s, m, recs, N, clip, attr, out, tri_id_dbg, rast_dbg);
+  else if (mode == OUT_BF16X8) launch_raster_mode<OUT_BF16X8>(s, m, recs, N, clip, attr, out, tri_id_dbg, rast_dbg);
+  else launch_raster_mode<OUT_F16X8>(s, m, recs, N, clip, attr, out, tri_id_dbg, rast_dbg);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -748,10 +750,7 @@ __global__ __launch_bounds__(256) void crop_kernel(const uint8_t *__restrict__ r
     float2 *d2 = reinterpret_cast<float2 *>(reinterpret_cast<float *>(out_all) + opix * 6);
     d2[0] = make_float2(o[0], o[1]); d2[1] = make_float2(o[2], o[3]); d2[2] = make_float2(o[4], o[5]);
   } else {
-    union { __half h[8]; uint4 u4; } pk;
-    for (int c = 0; c < 6; c++) pk.h[c] = __float2half(o[c]);
-    pk.h[6] = __float2half(0.f); pk.h[7] = __float2half(0.f);
-    reinterpret_cast<uint4 *>(out_all)[s2d_index((size_t)n, y, x)] = pk.u4;
+    reinterpret_cast<uint4 *>(out_all)[s2d_index((size_t)n, y, x)] = pack6<MODE>(o);
   }
 }
 
@@ -761,6 +760,9 @@ void launch_crop(hipStream_t s, const uint8_t *rgb, const float *depth, int H, i
   float downscale = diameter / 2;
   if (mode == OUT_F32X6)
     hipLaunchKernelGGL(crop_kernel<OUT_F32X6>, grid, block, 0, s, rgb, depth, H, W, K[0], K[4], K[2], K[5], recs,
+                       downscale, out);
+  else if (mode == OUT_BF16X8)
+    hipLaunchKernelGGL(crop_kernel<OUT_BF16X8>, grid, block, 0, s, rgb, depth, H, W, K[0], K[4], K[2], K[5], recs,
                        downscale, out);
   else
     hipLaunchKernelGGL(crop_kernel<OUT_F16X8>, grid, block, 0, s, rgb, depth, H, W, K[0], K[4], K[2], K[5], recs,
@@ -919,23 +921,22 @@ void launch_argmax(hipStream_t s, const float *scores, int N, int *index_dev, co
   hipLaunchKernelGGL(argmax_kernel, dim3(1), dim3(256), 0, s, scores, N, index_dev, poses, best_pose_dev);
 }
 
-__global__ void pack_f32x6_to_f16x8_kernel(const float *__restrict__ in, uint4 *__restrict__ out, size_t pixels) {
+template <int MODE>
+__global__ void pack_f32x6_kernel(const float *__restrict__ in, uint4 *__restrict__ out, size_t pixels) {
   size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= pixels) return;
   const float2 *s2 = reinterpret_cast<const float2 *>(in + p * 6);
   float2 a = s2[0], b = s2[1], c = s2[2];
-  union { __half h[8]; uint4 u4; } pk;
-  pk.h[0] = __float2half(a.x); pk.h[1] = __float2half(a.y); pk.h[2] = __float2half(b.x);
-  pk.h[3] = __float2half(b.y); pk.h[4] = __float2half(c.x); pk.h[5] = __float2half(c.y);
-  pk.h[6] = __float2half(0.f); pk.h[7] = __float2half(0.f);
+  const float o[6] = {a.x, a.y, b.x, b.y, c.x, c.y};
   size_t n = p / (CROP * CROP);
   int rem = (int)(p - n * (CROP * CROP));
-  out[s2d_index(n, rem / CROP, rem % CROP)] = pk.u4;
+  out[s2d_index(n, rem / CROP, rem % CROP)] = pack6<MODE>(o);
 }
 
-void launch_pack_f32x6_to_f16x8(hipStream_t s, const float *in, __half *out, size_t pixels) {
-  hipLaunchKernelGGL(pack_f32x6_to_f16x8_kernel, dim3((unsigned)((pixels + 255) / 256)), dim3(256), 0, s, in,
-                     reinterpret_cast<uint4 *>(out), pixels);
+void launch_pack_f32x6(hipStream_t s, const float *in, void *out, size_t pixels, OutMode mode) {
+  const dim3 grid((unsigned)((pixels + 255) / 256));
+  if (mode == OUT_BF16X8) hipLaunchKernelGGL(pack_f32x6_kernel<OUT_BF16X8>, grid, dim3(256), 0, s, in, reinterpret_cast<uint4 *>(out), pixels);
+  else hipLaunchKernelGGL(pack_f32x6_kernel<OUT_F16X8>, grid, dim3(256), 0, s, in, reinterpret_cast<uint4 *>(out), pixels);
 }
 
 }  // namespace fp

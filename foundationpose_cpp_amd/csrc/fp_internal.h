@@ -102,15 +102,19 @@ struct DeviceMesh {
   uint8_t *tex = nullptr;    // [TH,TW,3]
 };
 
-enum OutMode { OUT_F32X6 = 0, OUT_F16X8 = 1 };
+enum OutMode { OUT_F32X6 = 0, OUT_F16X8 = 1, OUT_BF16X8 = 2 };  // F32X6: the reference's blob; *X8: the networks' s2d input tensor
 
 void launch_pose_setup(hipStream_t s, const float *poses_dev, int N, const float *K9_host, int img_h, int img_w,
                        float crop_ratio, float diameter, PoseRec *recs);
+#ifdef FP_TEST_HOOKS
 extern float4 *g_vertex_dbg;  // race hunt: per-vertex intermediates (null = off)
+#endif
 void launch_vertex(hipStream_t s, const DeviceMesh &m, const PoseRec *recs, int N, float4 *clip, float4 *attr);
 void launch_raster_shade(hipStream_t s, const DeviceMesh &m, const PoseRec *recs, int N, const float4 *clip,
                          const float4 *attr, OutMode mode, void *out, int32_t *tri_id_dbg, float *rast_dbg);
+#ifdef FP_TEST_HOOKS
 void set_raster_strip_rows(int rows);  // 0 = automatic (A/B hook)
+#endif
 void launch_crop(hipStream_t s, const uint8_t *rgb, const float *depth, int H, int W, const float *K9_host,
                  const PoseRec *recs, int N, float diameter, OutMode mode, void *out);
 void launch_depth_to_xyz(hipStream_t s, const float *depth, int H, int W, const float *K9_host, float *xyz);
@@ -124,8 +128,8 @@ void launch_argmax(hipStream_t s, const float *scores, int N, int *index_dev, co
 // GuessTranslation + hypothesis poses on the device; state = int[8] (status in state[6]: 0 ok, 1 empty mask, 2 no valid depth)
 void launch_sampler(hipStream_t s, const float *filtered_depth, const uint8_t *mask_dev, int H, int W, float min_depth,
                     const float *K9_host, const float *grid_dev, int first, int N, int *state, float *vals, float *poses);
-// f32 [N,160,160,6] -> f16 [N,160,160,8] (blob-mode entry points feeding the f16 networks)
-void launch_pack_f32x6_to_f16x8(hipStream_t s, const float *in, __half *out, size_t pixels);
+// f32 [N,160,160,6] -> the networks' 2-byte s2d input tensor (blob-mode entry points); mode = OUT_F16X8 / OUT_BF16X8
+void launch_pack_f32x6(hipStream_t s, const float *in, void *out, size_t pixels, OutMode mode);
 
 // host helpers (fp_host.cpp part of fp_api.hip)
 std::vector<float> make_rotation_grid(int min_views, int inplane_steps);

@@ -42,10 +42,117 @@ namespace fp {
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef __bf16 b8 __attribute__((ext_vector_type(8)));
+typedef __bf16 b4 __attribute__((ext_vector_type(4)));
 typedef float f4 __attribute__((ext_vector_type(4)));
+typedef int i2 __attribute__((ext_vector_type(2)));
+typedef int i4 __attribute__((ext_vector_type(4)));  // 16 raw bytes: one ds_read_b128 / one LDS-DMA lane
+typedef int i8 __attribute__((ext_vector_type(8)));  // 32 raw bytes: one fp8 operand of v_mfma_f32_16x16x128_f8f6f4
 
 static constexpr int EMBED = 512, HEADS = 4, HDIM = 128;
+
+// ---- element types ------------------------------------------------------------------------------
+// DT_F16 / DT_BF16: 2-byte storage, v_mfma_f32_16x16x32_{f16,bf16}; a 128-byte LDS row holds 64 elements = two MFMA k-steps.
+// DT_FP8 (OCP e4m3, BASELINE configs[4]): 1-byte storage, v_mfma_f32_16x16x128_f8f6f4 (unscaled form: both block
+//   scales are the literal 0, which selects the instruction without the scale prefix); a 128-byte row holds 128 elements = ONE
+//   MFMA k-step whose 32-byte operand is the concatenation of the two 16-byte reads the 2-byte types feed to their two
+//   MFMAs (lane group kg owns chunks kg and 4+kg of the row: W and X use the same assignment, so the contraction is
+//   unchanged and the LDS swizzles / bank-conflict analysis carry over).  Quantisation: per-output-channel weight scale,
+//   per-tensor activation scale (static, from fp_calibrate_fp8), folded into the epilogue.
+template <int DT> struct ElemT { using t = _Float16; using v8 = h8; using v4 = h4; };
+template <> struct ElemT<DT_BF16> { using t = __bf16; using v8 = b8; using v4 = b4; };
+
+template <int DT>
+__device__ __forceinline__ f4 mfma32(i4 a, i4 b, f4 c) {  // one 16x16x32 step on 2-byte operands
+  static_assert(DT == DT_F16 || DT == DT_BF16, "32-wide MFMA steps exist for the 2-byte types only");
+  if constexpr (DT == DT_BF16) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(b8, a), __builtin_bit_cast(b8, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, a), __builtin_bit_cast(h8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ f4 mfma128_fp8(i8 a, i8 b, f4 c) {
+  return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 0 /*A: fp8 e4m3*/, 0 /*B: fp8 e4m3*/, 0, 0, 0, 0);
+}
+// all MFMAs of one 128-byte K-step: w[ks][ni] / x[ks][mi] are the two 16-byte fragment reads of each row
+template <int DT, int NI, int MI>
+__device__ __forceinline__ void mma_kstep(f4 (&acc)[NI][MI], const i4 (&w)[2][NI], const i4 (&x)[2][MI]) {
+  if constexpr (DT == DT_FP8) {
+#pragma unroll
+    for (int ni = 0; ni < NI; ni++) {
+      const i8 wv = __builtin_shufflevector(w[0][ni], w[1][ni], 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+      for (int mi = 0; mi < MI; mi++)
+        acc[ni][mi] = mfma128_fp8(wv, __builtin_shufflevector(x[0][mi], x[1][mi], 0, 1, 2, 3, 4, 5, 6, 7), acc[ni][mi]);
+    }
+  } else {
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+      for (int ni = 0; ni < NI; ni++)
+#pragma unroll
+        for (int mi = 0; mi < MI; mi++) acc[ni][mi] = mfma32<DT>(w[ks][ni], x[ks][mi], acc[ni][mi]);
+  }
+}
+
+// 8 consecutive channels <-> float; FP8 values are stored SCALED (real = stored * scale).  The raw form (16 bytes, or 8
+// for FP8) is what stays in registers between the load and its use.
+__device__ __forceinline__ i4 load8_raw(const unsigned char *ptr, int dt) {
+  if (dt == DT_FP8) {
+    const i2 v = *reinterpret_cast<const i2 *>(ptr);
+    return (i4){v[0], v[1], 0, 0};
+  }
+  return *reinterpret_cast<const i4 *>(ptr);
+}
+__device__ __forceinline__ void decode8(i4 raw, int dt, float (&f)[8]) {
+  if (dt == DT_FP8) {
+    f[0] = __builtin_amdgcn_cvt_f32_fp8(raw[0], 0); f[1] = __builtin_amdgcn_cvt_f32_fp8(raw[0], 1);
+    f[2] = __builtin_amdgcn_cvt_f32_fp8(raw[0], 2); f[3] = __builtin_amdgcn_cvt_f32_fp8(raw[0], 3);
+    f[4] = __builtin_amdgcn_cvt_f32_fp8(raw[1], 0); f[5] = __builtin_amdgcn_cvt_f32_fp8(raw[1], 1);
+    f[6] = __builtin_amdgcn_cvt_f32_fp8(raw[1], 2); f[7] = __builtin_amdgcn_cvt_f32_fp8(raw[1], 3);
+  } else if (dt == DT_BF16) {
+    const b8 v = __builtin_bit_cast(b8, raw);
+#pragma unroll
+    for (int e = 0; e < 8; e++) f[e] = (float)v[e];
+  } else {
+    const h8 v = __builtin_bit_cast(h8, raw);
+#pragma unroll
+    for (int e = 0; e < 8; e++) f[e] = (float)v[e];
+  }
+}
+// element e (0..7) of a raw 8-channel group, as float (e is a constant once the caller's loop is unrolled)
+template <int DT>
+__device__ __forceinline__ float raw_elem(const i4 &raw, int e) {
+  if constexpr (DT == DT_FP8) {
+    const int w = raw[e >> 2];
+    switch (e & 3) {
+      case 0: return __builtin_amdgcn_cvt_f32_fp8(w, 0);
+      case 1: return __builtin_amdgcn_cvt_f32_fp8(w, 1);
+      case 2: return __builtin_amdgcn_cvt_f32_fp8(w, 2);
+      default: return __builtin_amdgcn_cvt_f32_fp8(w, 3);
+    }
+  } else if constexpr (DT == DT_BF16) return (float)__builtin_bit_cast(b8, raw)[e];
+  else return (float)__builtin_bit_cast(h8, raw)[e];
+}
+__device__ __forceinline__ float sat_fp8(float v) { return __builtin_amdgcn_fmed3f(v, -448.f, 448.f); }  // e4m3 finite range
+__device__ __forceinline__ void store8(unsigned char *ptr, int dt, const float (&f)[8]) {
+  if (dt == DT_FP8) {
+    i2 v = {0, 0};
+    v[0] = __builtin_amdgcn_cvt_pk_fp8_f32(sat_fp8(f[0]), sat_fp8(f[1]), v[0], false);
+    v[0] = __builtin_amdgcn_cvt_pk_fp8_f32(sat_fp8(f[2]), sat_fp8(f[3]), v[0], true);
+    v[1] = __builtin_amdgcn_cvt_pk_fp8_f32(sat_fp8(f[4]), sat_fp8(f[5]), v[1], false);
+    v[1] = __builtin_amdgcn_cvt_pk_fp8_f32(sat_fp8(f[6]), sat_fp8(f[7]), v[1], true);
+    *reinterpret_cast<i2 *>(ptr) = v;
+  } else if (dt == DT_BF16) {
+    b8 v;
+#pragma unroll
+    for (int e = 0; e < 8; e++) v[e] = (__bf16)f[e];
+    *reinterpret_cast<b8 *>(ptr) = v;
+  } else {
+    h8 v;
+#pragma unroll
+    for (int e = 0; e < 8; e++) v[e] = (_Float16)f[e];
+    *reinterpret_cast<h8 *>(ptr) = v;
+  }
+}
+__host__ __device__ constexpr int elem_bytes(int dt) { return dt == DT_FP8 ? 1 : 2; }
 
 // =================================================================================================
 // implicit-GEMM convolution
@@ -53,7 +160,7 @@ static constexpr int EMBED = 512, HEADS = 4, HDIM = 128;
 
 // LDS-DMA issued from inline asm: hipcc neither counts these loads nor inserts its conservative `s_waitcnt vmcnt(0)`
 // in front of a new LDS-DMA while an older one is in flight (it cannot tell the LDS stages apart), so the counted
-// waits in conv_igemm3_kernel are authoritative.  M0 (LDS destination base) is saved and restored inside the statement
+// waits in the hand-scheduled kernels are authoritative.  M0 (LDS destination base) is saved and restored inside the statement
 // (cdna_hip_programming.md §5.7).  lds_addr must be wave-uniform; the 16 bytes land at lds_addr + lane*16.
 __device__ __forceinline__ void glds16_asm(const void *gsrc, unsigned lds_addr) {
   unsigned keep;
@@ -64,27 +171,32 @@ __device__ __forceinline__ void glds16_asm(const void *gsrc, unsigned lds_addr) 
 }
 
 struct ConvParams {
-  const __half *in;     // [NB, H+2*ipad, W+2*ipad, Cin]  (zero border of width ipad >= pad is physically present)
-  const __half *w;      // [Cout][K] in kernel K order (relayout_k)
-  const float *bias;    // [Cout]
-  const __half *res;    // optional residual [NB, OH+2*rpad, OW+2*rpad, res_ld]
-  __half *out;          // [NB', OH+2*opad, OW+2*opad, out_ld]
+  const unsigned char *in;   // [NB, H+2*ipad, W+2*ipad, Cin]  (zero border of width ipad >= pad is physically present)
+  const unsigned char *w;    // [Cout][K] in kernel K order (relayout_k), element type = the kernel's DT
+  const float *bias;         // [Cout]
+  const float *cscale;       // FP8 input: [Cout] activation scale * weight scale of the channel; null otherwise
+  const unsigned char *res;  // optional residual [NB, OH+2*rpad, OW+2*rpad, res_ld], element type res_dt
+  unsigned char *out;        // [NB', OH+2*opad, OW+2*opad, out_ld], element type out_dt
   int NB, H, W, Cin, OH, OW, Cout, KH, KW, stride, pad;
   int ipad, opad, rpad;
   int M, Ktot, relu, out_ld, res_ld, split_imgs;
-  int ntaps;  // KH*KW; for Cin >= 64 the K order is (64-channel chunk outer, tap inner) so the taps of a chunk
+  int cin_b;      // bytes per input pixel  (Cin  * element size)
+  int krow_b;     // bytes per weight row   (Ktot * element size); K-steps of 128 bytes: krow_b >> 7, of 64 bytes: krow_b >> 6
+  int out_dt, res_dt;          // DT_* of the output / residual tensors
+  float res_scale, out_inv;    // FP8 tensors: residual real value = stored * res_scale; stored output = real * out_inv
+  int ntaps;  // KH*KW; for Cin >= 64 the K order is (128-byte channel chunk outer, tap inner) so the taps of a chunk
               // are consecutive K-steps and their overlapping input pixels are re-read while still L2-resident
   // byte offset of K-step kt's X slab relative to a row's (tap 0, channel 0) address; host-filled, read with s_load
   unsigned koff[80];
-  unsigned koff32[160];  // same per 32-wide K-step (conv_pp32_kernel)
+  unsigned koff32[160];  // same per 64-byte K-step (conv_pp32_kernel)
   int m_begin;            // first output row handled by this launch (hybrid 256^2 + 128^2 launches)
   int ksplit, kt_per;     // split-K (small problems): K-steps [split*kt_per, ...) per workgroup, fp32 partial slabs
   float *partial;         // [ksplit][M - m_begin][Cout]
   // weight groups along M (the refiner's two heads in ONE launch at small N, conv_igemm_kernel only): rows
-  // [g*grp_rows, (g+1)*grp_rows) use weights w + g*grp_w_halfs and bias + g*Cout; grp_rows % 128 == 0, 0 = off.
+  // [g*grp_rows, (g+1)*grp_rows) use weights w + g*grp_w_bytes and bias + g*Cout; grp_rows % 128 == 0, 0 = off.
   // in_shared / res_shared: the input / residual tensor has only the first group's rows and is read by every group.
   int grp_rows, in_shared, res_shared;
-  unsigned grp_w_halfs;
+  unsigned grp_w_bytes;
   unsigned long long *clk;  // optional clock probe: per block {cycles0, realtime0, cycles1, realtime1}
 };
 
@@ -92,33 +204,53 @@ struct ConvParams {
 // Weight rows are PERMUTED on the host inside each block of 16*NI output channels (permute_rows): MFMA tile ni, row
 // i = 4g + j (g = lane>>4, j = accumulator register) computes channel
 //     NI == 4:  32*(j>>1) + 8*g + 4*(j&1) + ni        NI == 2:  8*g + 2*j + ni
-// so a lane's accumulators hold 8 CONSECUTIVE channels per 16-byte store and the four lane groups of a store
-// instruction cover 64 contiguous bytes of one pixel (the natural D^T layout gives 4 channels / 8 bytes per store and
+// so a lane's accumulators hold 8 CONSECUTIVE channels per store and the four lane groups of a store
+// instruction cover 64 contiguous channels of one pixel (the natural D^T layout gives 4 channels per store and
 // twice the store instructions; the 256x256 kernel spent 13 us of a 70 us workgroup in its store burst).
 // All bias and residual loads are issued BEFORE the first store: on CDNA4 stores also count in vmcnt, so a load issued
 // behind a store cannot be waited for without draining the store.
-template <int MI, int NI, int EABL = 0, class PixFn>  // EABL (timing ablations): 1 = no stores, 2 = no residual loads
-__device__ __forceinline__ void conv_epilogue_px(const ConvParams &p, f4 (&acc)[NI][MI], int n_base, int lane, PixFn pix,
+// DT = the kernel's operand type = the residual's element type: an FP8 kernel multiplies by the per-channel dequantisation
+// scale first.  ODT = the output element type (differs from DT only in the two layers at a precision boundary).
+// The epilogue covers channel tiles [NI0, NI0 + NI) of an accumulator array of NIT tiles (the stem: two 32-channel passes
+// over its 4 tiles; the array is passed whole so that it stays in registers).
+template <int MI, int NI, int DT, int ODT, int EABL = 0, int NIT = NI, int NI0 = 0, class PixFn>  // EABL (timing ablations): 1 = no stores, 2 = no residual loads
+__device__ __forceinline__ void conv_epilogue_px(const ConvParams &p, f4 (&acc)[NIT][MI], int n_base, int lane, PixFn pix,
                                                  int bias_off = 0, int res_img_off = 0) {
   static_assert(NI == 4 || NI == 2, "wave covers 64 or 32 channels");
-  constexpr int NS = NI / 2;  // 16-byte stores per pixel per lane
+  constexpr int NS = NI / 2;  // 8-channel stores per pixel per lane
   const int OHp = p.OH + 2 * p.opad, OWp = p.OW + 2 * p.opad;
   const int RHp = p.OH + 2 * p.rpad, RWp = p.OW + 2 * p.rpad;
   const int g = lane >> 4;
   const int nl = n_base + 8 * g;  // store k covers channels nl + 32*k .. +7
-  float bv[NS][8];
+  constexpr int oes = elem_bytes(ODT), res_es = elem_bytes(DT);
+  // pass 1, in place: acc = acc [* dequantisation scale] + bias (8 channels of bias / scale live at a time)
 #pragma unroll
   for (int k = 0; k < NS; k++) {
+    float bv[8], sc[8];
     float4 b0 = *reinterpret_cast<const float4 *>(p.bias + bias_off + nl + 32 * k), b1 = *reinterpret_cast<const float4 *>(p.bias + bias_off + nl + 32 * k + 4);
-    bv[k][0] = b0.x; bv[k][1] = b0.y; bv[k][2] = b0.z; bv[k][3] = b0.w; bv[k][4] = b1.x; bv[k][5] = b1.y; bv[k][6] = b1.z; bv[k][7] = b1.w;
+    bv[0] = b0.x; bv[1] = b0.y; bv[2] = b0.z; bv[3] = b0.w; bv[4] = b1.x; bv[5] = b1.y; bv[6] = b1.z; bv[7] = b1.w;
+    if constexpr (DT == DT_FP8) {
+      float4 s0 = *reinterpret_cast<const float4 *>(p.cscale + bias_off + nl + 32 * k), s1 = *reinterpret_cast<const float4 *>(p.cscale + bias_off + nl + 32 * k + 4);
+      sc[0] = s0.x; sc[1] = s0.y; sc[2] = s0.z; sc[3] = s0.w; sc[4] = s1.x; sc[5] = s1.y; sc[6] = s1.z; sc[7] = s1.w;
+    }
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+      const int jj = (NI == 4) ? 2 * k + (e >> 2) : (e >> 1);
+      const int ni = (NI == 4) ? (e & 3) : (e & 1);
+#pragma unroll
+      for (int mi = 0; mi < MI; mi++) {
+        if constexpr (DT == DT_FP8) acc[NI0 + ni][mi][jj] = __builtin_fmaf(acc[NI0 + ni][mi][jj], sc[e], bv[e]);
+        else acc[NI0 + ni][mi][jj] += bv[e];
+      }
+    }
   }
-  // pixels in groups of at most 8 fragments: a group's residual values (4 VGPRs per fragment and store) stay in registers
+  // pixels in groups of at most 8 fragments: a group's residual values stay in registers
   constexpr int GB = MI > 8 ? (MI + 1) / 2 : MI;
 #pragma unroll
   for (int g0 = 0; g0 < MI; g0 += GB) {
   size_t oofs[GB];
   bool ok[GB];
-  h8 rv[NS][GB];
+  i4 rv[NS][GB];
 #pragma unroll
   for (int gi = 0; gi < GB; gi++) {
     const int mi = g0 + gi;
@@ -132,7 +264,7 @@ __device__ __forceinline__ void conv_epilogue_px(const ConvParams &p, f4 (&acc)[
       size_t rpix = ((size_t)(img - res_img_off) * RHp + oh + p.rpad) * RWp + ow + p.rpad;
 #pragma unroll
       for (int k = 0; k < NS; k++)
-        rv[k][gi] = ok[gi] ? *reinterpret_cast<const h8 *>(p.res + rpix * p.res_ld + nl + 32 * k) : (h8){0, 0, 0, 0, 0, 0, 0, 0};
+        rv[k][gi] = ok[gi] ? load8_raw(p.res + (rpix * p.res_ld + nl + 32 * k) * res_es, DT) : (i4){0, 0, 0, 0};
     }
   }
 #pragma unroll
@@ -142,29 +274,51 @@ __device__ __forceinline__ void conv_epilogue_px(const ConvParams &p, f4 (&acc)[
     if (!ok[gi]) continue;
 #pragma unroll
     for (int k = 0; k < NS; k++) {
-      h8 o;
+      i4 ov = {0, 0, 0, 0};  // packed output: 8 two-byte values, or 8 FP8 bytes in ov[0..1]
 #pragma unroll
-      for (int e = 0; e < 8; e++) {
-        const int jj = (NI == 4) ? 2 * k + (e >> 2) : (e >> 1);
-        const int ni = (NI == 4) ? (e & 3) : (e & 1);
-        float v = acc[ni][mi][jj] + bv[k][e];
-        if (p.res && !(EABL & 2)) v += (float)rv[k][gi][e];
-        if (p.relu) v = fmaxf(v, 0.f);
-        o[e] = (_Float16)v;
+      for (int e2 = 0; e2 < 8; e2 += 2) {
+        float v2[2];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+          const int e = e2 + h;
+          const int jj = (NI == 4) ? 2 * k + (e >> 2) : (e >> 1);
+          const int ni = (NI == 4) ? (e & 3) : (e & 1);
+          float v = acc[NI0 + ni][mi][jj];
+          if (p.res && !(EABL & 2)) {
+            if constexpr (DT == DT_FP8) v = __builtin_fmaf(raw_elem<DT>(rv[k][gi], e), p.res_scale, v);
+            else v += raw_elem<DT>(rv[k][gi], e);
+          }
+          if (p.relu) v = fmaxf(v, 0.f);
+          if constexpr (ODT == DT_FP8) v = sat_fp8(v * p.out_inv);
+          v2[h] = v;
+        }
+        if constexpr (ODT == DT_FP8) {
+          if (e2 == 0) ov[0] = __builtin_amdgcn_cvt_pk_fp8_f32(v2[0], v2[1], ov[0], false);
+          else if (e2 == 2) ov[0] = __builtin_amdgcn_cvt_pk_fp8_f32(v2[0], v2[1], ov[0], true);
+          else if (e2 == 4) ov[1] = __builtin_amdgcn_cvt_pk_fp8_f32(v2[0], v2[1], ov[1], false);
+          else ov[1] = __builtin_amdgcn_cvt_pk_fp8_f32(v2[0], v2[1], ov[1], true);
+        } else {
+          typedef typename ElemT<ODT>::t OE;
+          typedef OE oe2 __attribute__((ext_vector_type(2)));
+          const oe2 pr = {(OE)v2[0], (OE)v2[1]};
+          ov[e2 >> 1] = __builtin_bit_cast(int, pr);
+        }
       }
-      if (EABL & 1) asm volatile("" ::"v"(o));
-      else *reinterpret_cast<h8 *>(p.out + oofs[gi] + nl + 32 * k) = o;
+      unsigned char *dst = p.out + (oofs[gi] + nl + 32 * k) * oes;
+      if (EABL & 1) asm volatile("" ::"v"(ov));
+      else if constexpr (ODT == DT_FP8) *reinterpret_cast<i2 *>(dst) = (i2){ov[0], ov[1]};
+      else *reinterpret_cast<i4 *>(dst) = ov;
     }
   }
   }
 }
 
 // the implicit-GEMM schedules: output row m = m_base + mi*16 + (lane&15) in (image, oh, ow) raster order
-template <int MI, int NI, int EABL = 0>
+template <int MI, int NI, int DT, int ODT, int EABL = 0>
 __device__ __forceinline__ void conv_epilogue(const ConvParams &p, f4 (&acc)[NI][MI], int m_base, int n_base, int lane) {
   const int ohw = p.OH * p.OW;
   const int grp = p.grp_rows ? m_base / p.grp_rows : 0;  // tile-uniform (grp_rows is a multiple of the tile height)
-  conv_epilogue_px<MI, NI, EABL>(p, acc, n_base, lane, [&](int mi, int &img, int &oh, int &ow) {
+  conv_epilogue_px<MI, NI, DT, ODT, EABL>(p, acc, n_base, lane, [&](int mi, int &img, int &oh, int &ow) {
     int m = m_base + mi * 16 + (lane & 15);
     const bool ok = m < p.M;
     int mm = ok ? m : 0;
@@ -201,7 +355,7 @@ __device__ __forceinline__ void conv_store_partial(const ConvParams &p, f4 (&acc
 // Activations carry a physical zero border, so the K loop has no bounds checks, no selects and no divergent
 // branches: a tap's operand address is (wave-uniform tap/chunk offset in SGPRs) + (per-lane row offset fixed for the
 // whole kernel), which is exactly the saddr + voffset form of global_load_lds.
-template <int BN, int VAR = 0>
+template <int BN, int VAR, int DT, int ODT = DT>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int BM = 128;
@@ -244,16 +398,16 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
     int rem = m - img * ohw;
     int oh = rem / p.OW, ow = rem - oh * p.OW;
     int ih0 = oh * p.stride - p.pad + p.ipad, iw0 = ow * p.stride - p.pad + p.ipad;
-    xoff[i] = (unsigned)(((img * IHp + ih0) * IWp + iw0) * p.Cin + g * 8) * 2u;
+    xoff[i] = (unsigned)(((img * IHp + ih0) * IWp + iw0) * p.cin_b + g * 16);
   }
   unsigned woffv[WPIECES];
 #pragma unroll
   for (int i = 0; i < WPIECES; i++) {
     int row = (wave * WPIECES + i) * 8 + srow;
-    woffv[i] = (unsigned)((n0 + row) * p.Ktot + g * 8) * 2u;
+    woffv[i] = (unsigned)((n0 + row) * p.krow_b + g * 16);
   }
-  const unsigned char *in_b = reinterpret_cast<const unsigned char *>(p.in);
-  const unsigned char *w_b = reinterpret_cast<const unsigned char *>(p.w) + (p.grp_rows ? (size_t)(m0 / p.grp_rows) * p.grp_w_halfs * 2 : 0);
+  const unsigned char *in_b = p.in;
+  const unsigned char *w_b = p.w + (p.grp_rows ? (size_t)(m0 / p.grp_rows) * p.grp_w_bytes : 0);
 
   auto stage = [&](int kt, int buf) {
     unsigned char *xs = smem + buf * STAGE;
@@ -290,13 +444,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
     const unsigned char *sb = smem + buf * STAGE;
     if (VAR & 2) {
       // all 16 fragment reads of the K-step are issued up front: only the first LDS round trip is exposed
-      h8 xf[2][4], wf[2][NREP];
+      i4 xf[2][4], wf[2][NREP];
 #pragma unroll
       for (int ks = 0; ks < 2; ks++) {
 #pragma unroll
-        for (int mi = 0; mi < 4; mi++) xf[ks][mi] = *reinterpret_cast<const h8 *>(sb + xfo[ks] + mi * 16 * 128);
+        for (int mi = 0; mi < 4; mi++) xf[ks][mi] = *reinterpret_cast<const i4 *>(sb + xfo[ks] + mi * 16 * 128);
 #pragma unroll
-        for (int ni = 0; ni < NREP; ni++) wf[ks][ni] = *reinterpret_cast<const h8 *>(sb + wfo[ks] + ni * 16 * 128);
+        for (int ni = 0; ni < NREP; ni++) wf[ks][ni] = *reinterpret_cast<const i4 *>(sb + wfo[ks] + ni * 16 * 128);
       }
       if (VAR & 8) {  // ablation: no MFMAs, fragments kept live
 #pragma unroll
@@ -309,34 +463,30 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
         return;
       }
       if (VAR & 1) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int ks = 0; ks < 2; ks++)
-#pragma unroll
-        for (int ni = 0; ni < NREP; ni++)
-#pragma unroll
-          for (int mi = 0; mi < 4; mi++)
-            acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ks][ni], xf[ks][mi], acc[ni][mi], 0, 0, 0);
+      mma_kstep<DT, NREP, 4>(acc, wf, xf);
       if (VAR & 1) __builtin_amdgcn_s_setprio(0);
       return;
     }
+    if constexpr (DT != DT_FP8) {
 #pragma unroll
     for (int ks = 0; ks < 2; ks++) {
-      h8 xf[4], wf[NREP];
+      i4 xf[4], wf[NREP];
 #pragma unroll
-      for (int mi = 0; mi < 4; mi++) xf[mi] = *reinterpret_cast<const h8 *>(sb + xfo[ks] + mi * 16 * 128);
+      for (int mi = 0; mi < 4; mi++) xf[mi] = *reinterpret_cast<const i4 *>(sb + xfo[ks] + mi * 16 * 128);
 #pragma unroll
-      for (int ni = 0; ni < NREP; ni++) wf[ni] = *reinterpret_cast<const h8 *>(sb + wfo[ks] + ni * 16 * 128);
+      for (int ni = 0; ni < NREP; ni++) wf[ni] = *reinterpret_cast<const i4 *>(sb + wfo[ks] + ni * 16 * 128);
       if (VAR & 1) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int ni = 0; ni < NREP; ni++)
 #pragma unroll
         for (int mi = 0; mi < 4; mi++)
-          acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ni], xf[mi], acc[ni][mi], 0, 0, 0);
+          acc[ni][mi] = mfma32<DT>(wf[ni], xf[mi], acc[ni][mi]);
       if (VAR & 1) __builtin_amdgcn_s_setprio(0);
+    }
     }
   };
 
-  const int k_begin = split * p.kt_per, k_end = min(p.Ktot >> 6, k_begin + p.kt_per);
+  const int k_begin = split * p.kt_per, k_end = min(p.krow_b >> 7, k_begin + p.kt_per);
   stage(k_begin, 0);
   __syncthreads();
   // steady state is branch-free (stage next tile, compute current tile, one barrier); the last tile is peeled
@@ -355,139 +505,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
     return;
   }
   // ---- epilogue: lane owns channels cb..cb+3 (cb = 4*(lane>>4)) of pixel (lane&15) in each 16x16 tile
-  conv_epilogue<4, NREP>(p, acc, m0 + wm * 64, n0 + wn * (BN / 2), lane);
-}
-
-// -------------------------------------------------------------------------------------------------
-// Large-problem variant: 256 pixels x BN channels per workgroup, 8 waves (4 along pixels x 2 along channels, the
-// same 64 x BN/2 wave tile as above), THREE LDS stages and a prefetch distance of two K-steps.  The LDS-DMA loads are
-// kept in flight across the barrier: per K-step each wave issues G = 4 + BN/64 global_load_lds, so
-// `s_waitcnt vmcnt(G)` before the (raw) barrier retires exactly the tile about to be consumed and leaves the next
-// tile's loads outstanding (cdna_hip_programming.md "Pipelining across barriers").  One barrier per K-step orders
-// both hazards: RAW (every wave waited for its own pieces of tile kt) and WAR (every wave finished reading tile
-// kt-1 before anyone overwrites its buffer with tile kt+2).
-// -------------------------------------------------------------------------------------------------
-template <int BN>
-__global__ __launch_bounds__(512, 2) void conv_igemm3_kernel(const ConvParams p) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr int BM = 256;
-  constexpr int XB = BM * 128;
-  constexpr int WB = BN * 128;
-  constexpr int STAGE = XB + WB;
-  constexpr int NREP = BN / 32;
-  constexpr int WPIECES = BN / 64;  // 8-row pieces of the W tile per wave (8 waves)
-  constexpr int G = 4 + WPIECES;    // LDS-DMA instructions per wave per K-step
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave & 3, wn = wave >> 2;
-  if (p.clk && tid == 0) { p.clk[blockIdx.x * 4] = __builtin_readcyclecounter(); p.clk[blockIdx.x * 4 + 1] = wall_clock64(); }
-  const int n_tiles = p.Cout / BN;
-  int logical;
-  {
-    const int nblk = gridDim.x, b = blockIdx.x;
-    const int xcd = b & 7, within = b >> 3, q = nblk >> 3, r = nblk & 7;
-    logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
-  }
-  const int mt = logical / n_tiles, nt = logical - mt * n_tiles;
-  const int m0 = p.m_begin + mt * BM, n0 = nt * BN;
-  const int ohw = p.OH * p.OW;
-  const int IHp = p.H + 2 * p.ipad, IWp = p.W + 2 * p.ipad;
-
-  const int srow = lane >> 3;
-  const int g = (lane & 7) ^ srow;
-  unsigned xoff[4];
-#pragma unroll
-  for (int i = 0; i < 4; i++) {
-    int m = min(m0 + (wave * 4 + i) * 8 + srow, p.M - 1);
-    int img = m / ohw;
-    int rem = m - img * ohw;
-    int oh = rem / p.OW, ow = rem - oh * p.OW;
-    int ih0 = oh * p.stride - p.pad + p.ipad, iw0 = ow * p.stride - p.pad + p.ipad;
-    xoff[i] = (unsigned)(((img * IHp + ih0) * IWp + iw0) * p.Cin + g * 8) * 2u;
-  }
-  unsigned woffv[WPIECES];
-#pragma unroll
-  for (int i = 0; i < WPIECES; i++) {
-    int row = (wave * WPIECES + i) * 8 + srow;
-    woffv[i] = (unsigned)((n0 + row) * p.Ktot + g * 8) * 2u;
-  }
-  const unsigned char *in_b = reinterpret_cast<const unsigned char *>(p.in);
-  const unsigned char *w_b = reinterpret_cast<const unsigned char *>(p.w);
-  const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
-
-  auto stage = [&](int kt, int buf) {
-    const unsigned xs = lds_base + buf * STAGE;
-    const unsigned ws = xs + XB;
-    const unsigned char *xb = in_b + p.koff[kt];
-    const unsigned char *wb = w_b + (size_t)kt * 128;
-#pragma unroll
-    for (int i = 0; i < 4; i++) glds16_asm(xb + xoff[i], xs + (wave * 4 + i) * 1024);
-#pragma unroll
-    for (int i = 0; i < WPIECES; i++) glds16_asm(wb + woffv[i], ws + (wave * WPIECES + i) * 1024);
-  };
-
-  f4 acc[NREP][4];
-#pragma unroll
-  for (int a = 0; a < NREP; a++)
-#pragma unroll
-    for (int b = 0; b < 4; b++) acc[a][b] = (f4){0.f, 0.f, 0.f, 0.f};
-
-  const int frow = lane & 15, fk = lane >> 4;
-  int xfo[2], wfo[2];
-#pragma unroll
-  for (int ks = 0; ks < 2; ks++) {
-    int slot = (ks * 4 + fk) ^ (lane & 7);
-    xfo[ks] = (wm * 64 + frow) * 128 + slot * 16;
-    wfo[ks] = XB + (wn * (BN / 2) + frow) * 128 + slot * 16;
-  }
-
-  auto compute = [&](int buf) {
-    const unsigned char *sb = smem + buf * STAGE;
-    h8 xf[2][4], wf[2][NREP];
-#pragma unroll
-    for (int ks = 0; ks < 2; ks++) {
-#pragma unroll
-      for (int mi = 0; mi < 4; mi++) xf[ks][mi] = *reinterpret_cast<const h8 *>(sb + xfo[ks] + mi * 16 * 128);
-#pragma unroll
-      for (int ni = 0; ni < NREP; ni++) wf[ks][ni] = *reinterpret_cast<const h8 *>(sb + wfo[ks] + ni * 16 * 128);
-    }
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int ks = 0; ks < 2; ks++)
-#pragma unroll
-      for (int ni = 0; ni < NREP; ni++)
-#pragma unroll
-        for (int mi = 0; mi < 4; mi++)
-          acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ks][ni], xf[ks][mi], acc[ni][mi], 0, 0, 0);
-    __builtin_amdgcn_s_setprio(0);
-  };
-
-  const int KT = p.Ktot >> 6;  // >= 8 for every layer of the networks
-  stage(0, 0);
-  stage(1, 1);
-  int rb = 0, wb3 = 2;  // stage being read / written
-  for (int kt = 0; kt < KT - 2; kt++) {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");  // tile kt landed (this wave's pieces); tile kt+1 in flight
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");  // s_barrier is IntrNoMem: keep LDS accesses on their side of it
-    stage(kt + 2, wb3);
-    compute(rb);
-    rb = (rb == 2) ? 0 : rb + 1;
-    wb3 = (wb3 == 2) ? 0 : wb3 + 1;
-  }
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");  // s_barrier is IntrNoMem: keep LDS accesses on their side of it
-  compute(rb);
-  rb = (rb == 2) ? 0 : rb + 1;
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");  // s_barrier is IntrNoMem: keep LDS accesses on their side of it
-  compute(rb);
-  if (p.clk && tid == 0) { p.clk[blockIdx.x * 4 + 2] = __builtin_readcyclecounter(); p.clk[blockIdx.x * 4 + 3] = wall_clock64(); }
-
-  conv_epilogue<4, NREP>(p, acc, m0 + wm * 64, n0 + wn * (BN / 2), lane);
+  conv_epilogue<4, NREP, DT, ODT>(p, acc, m0 + wm * 64, n0 + wn * (BN / 2), lane);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -498,7 +516,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm3_kernel(const ConvParams p)
 // wave of either group, so its matrix pipe always has a pure-MFMA wave to run.  Three LDS stages; loads stay in
 // flight across the barriers (counted vmcnt, raw s_barrier); two barriers per K-step.
 // -------------------------------------------------------------------------------------------------
-template <int BN>
+template <int BN, int DT, int ODT = DT>
 __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int BM = 256;
@@ -535,16 +553,16 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvParams p) {
     int rem = m - img * ohw;
     int oh = rem / p.OW, ow = rem - oh * p.OW;
     int ih0 = oh * p.stride - p.pad + p.ipad, iw0 = ow * p.stride - p.pad + p.ipad;
-    xoff[i] = (unsigned)(((img * IHp + ih0) * IWp + iw0) * p.Cin + g * 8) * 2u;
+    xoff[i] = (unsigned)(((img * IHp + ih0) * IWp + iw0) * p.cin_b + g * 16);
   }
   unsigned woffv[WPIECES];
 #pragma unroll
   for (int i = 0; i < WPIECES; i++) {
     int row = (wave * WPIECES + i) * 8 + srow;
-    woffv[i] = (unsigned)((n0 + row) * p.Ktot + g * 8) * 2u;
+    woffv[i] = (unsigned)((n0 + row) * p.krow_b + g * 16);
   }
-  const unsigned char *in_b = reinterpret_cast<const unsigned char *>(p.in);
-  const unsigned char *w_b = reinterpret_cast<const unsigned char *>(p.w);
+  const unsigned char *in_b = p.in;
+  const unsigned char *w_b = p.w;
   const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
 
   auto stage = [&](int kt, int buf) {
@@ -573,26 +591,20 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvParams p) {
     wfo[ks] = XB + (wn * (BN / 2) + frow) * 128 + slot * 16;
   }
 
-  h8 xf[2][4], wf[2][NREP];
+  i4 xf[2][4], wf[2][NREP];
   auto ldfrags = [&](int buf) {
     const unsigned char *sb = smem + buf * STAGE;
 #pragma unroll
     for (int ks = 0; ks < 2; ks++) {
 #pragma unroll
-      for (int mi = 0; mi < 4; mi++) xf[ks][mi] = *reinterpret_cast<const h8 *>(sb + xfo[ks] + mi * 16 * 128);
+      for (int mi = 0; mi < 4; mi++) xf[ks][mi] = *reinterpret_cast<const i4 *>(sb + xfo[ks] + mi * 16 * 128);
 #pragma unroll
-      for (int ni = 0; ni < NREP; ni++) wf[ks][ni] = *reinterpret_cast<const h8 *>(sb + wfo[ks] + ni * 16 * 128);
+      for (int ni = 0; ni < NREP; ni++) wf[ks][ni] = *reinterpret_cast<const i4 *>(sb + wfo[ks] + ni * 16 * 128);
     }
   };
   auto mfmas = [&]() {
     __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int ks = 0; ks < 2; ks++)
-#pragma unroll
-      for (int ni = 0; ni < NREP; ni++)
-#pragma unroll
-        for (int mi = 0; mi < 4; mi++)
-          acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ks][ni], xf[ks][mi], acc[ni][mi], 0, 0, 0);
+    mma_kstep<DT, NREP, 4>(acc, wf, xf);
     __builtin_amdgcn_s_setprio(0);
   };
 #define FP_PP_BARRIER()                  \
@@ -602,7 +614,7 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvParams p) {
     __builtin_amdgcn_sched_barrier(0);   \
   } while (0)
 
-  const int KT = p.Ktot >> 6;  // >= 8
+  const int KT = p.krow_b >> 7;  // >= 8
   stage(0, 0);
   stage(1, 1);
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");  // tile 0 landed (this wave's pieces)
@@ -645,7 +657,7 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvParams p) {
   }
 #undef FP_PP_BARRIER
 
-  conv_epilogue<4, NREP>(p, acc, m0 + grp * 128 + wm * 64, n0 + wn * (BN / 2), lane);
+  conv_epilogue<4, NREP, DT, ODT>(p, acc, m0 + grp * 128 + wm * 64, n0 + wn * (BN / 2), lane);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -656,111 +668,8 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvParams p) {
 // under the matrix pipe.  8 waves (2 along pixels x 4 along channels), wave tile 128 x 64 (32 accumulators), BK = 64,
 // two 64-KB LDS stages, one workgroup per CU.  Needs Cout % 256 == 0.
 // -------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(512, 2) void conv_big_kernel(const ConvParams p) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr int BM = 256, BN = 256;
-  constexpr int XB = BM * 128, WB = BN * 128, STAGE = XB + WB;
-  constexpr int MI = 8, NI = 4;
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave & 1, wn = wave >> 1;
-  const int n_tiles = p.Cout / BN;
-  int logical;
-  {
-    const int nblk = gridDim.x, b = blockIdx.x;
-    const int xcd = b & 7, within = b >> 3, q = nblk >> 3, r = nblk & 7;
-    logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
-  }
-  const int mt = logical / n_tiles, nt = logical - mt * n_tiles;
-  const int m0 = mt * BM, n0 = nt * BN;
-  const int ohw = p.OH * p.OW;
-  const int IHp = p.H + 2 * p.ipad, IWp = p.W + 2 * p.ipad;
-
-  const int srow = lane >> 3;
-  const int g = (lane & 7) ^ srow;
-  unsigned xoff[4], woffv[4];
-#pragma unroll
-  for (int i = 0; i < 4; i++) {
-    int m = min(m0 + (wave * 4 + i) * 8 + srow, p.M - 1);
-    int img = m / ohw;
-    int rem = m - img * ohw;
-    int oh = rem / p.OW, ow = rem - oh * p.OW;
-    int ih0 = oh * p.stride - p.pad + p.ipad, iw0 = ow * p.stride - p.pad + p.ipad;
-    xoff[i] = (unsigned)(((img * IHp + ih0) * IWp + iw0) * p.Cin + g * 8) * 2u;
-    int row = (wave * 4 + i) * 8 + srow;
-    woffv[i] = (unsigned)((n0 + row) * p.Ktot + g * 8) * 2u;
-  }
-  const unsigned char *in_b = reinterpret_cast<const unsigned char *>(p.in);
-  const unsigned char *w_b = reinterpret_cast<const unsigned char *>(p.w);
-  const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
-
-  auto stage = [&](int kt, int buf) {
-    const unsigned xs = lds_base + buf * STAGE;
-    const unsigned ws = xs + XB;
-    const unsigned char *xb = in_b + p.koff[kt];
-    const unsigned char *wb = w_b + (size_t)kt * 128;
-#pragma unroll
-    for (int i = 0; i < 4; i++) glds16_asm(xb + xoff[i], xs + (wave * 4 + i) * 1024);
-#pragma unroll
-    for (int i = 0; i < 4; i++) glds16_asm(wb + woffv[i], ws + (wave * 4 + i) * 1024);
-  };
-
-  f4 acc[NI][MI];
-#pragma unroll
-  for (int a = 0; a < NI; a++)
-#pragma unroll
-    for (int b = 0; b < MI; b++) acc[a][b] = (f4){0.f, 0.f, 0.f, 0.f};
-
-  const int frow = lane & 15, fk = lane >> 4;
-  int xfo[2], wfo[2];
-#pragma unroll
-  for (int ks = 0; ks < 2; ks++) {
-    int slot = (ks * 4 + fk) ^ (lane & 7);
-    xfo[ks] = (wm * 128 + frow) * 128 + slot * 16;
-    wfo[ks] = XB + (wn * 64 + frow) * 128 + slot * 16;
-  }
-
-  auto compute = [&](int buf) {
-    const unsigned char *sb = smem + buf * STAGE;
-#pragma unroll
-    for (int ks = 0; ks < 2; ks++) {
-      h8 xf[MI], wf[NI];
-#pragma unroll
-      for (int mi = 0; mi < MI; mi++) xf[mi] = *reinterpret_cast<const h8 *>(sb + xfo[ks] + mi * 16 * 128);
-#pragma unroll
-      for (int ni = 0; ni < NI; ni++) wf[ni] = *reinterpret_cast<const h8 *>(sb + wfo[ks] + ni * 16 * 128);
-      __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int ni = 0; ni < NI; ni++)
-#pragma unroll
-        for (int mi = 0; mi < MI; mi++)
-          acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ni], xf[mi], acc[ni][mi], 0, 0, 0);
-      __builtin_amdgcn_s_setprio(0);
-    }
-  };
-
-  const int KT = p.Ktot >> 6;
-  stage(0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");  // s_barrier is IntrNoMem: keep LDS accesses on their side of it
-  int buf = 0;
-  for (int kt = 0; kt < KT - 1; kt++) {
-    stage(kt + 1, buf ^ 1);
-    compute(buf);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");  // s_barrier is IntrNoMem: keep LDS accesses on their side of it
-    buf ^= 1;
-  }
-  compute(buf);
-
-  conv_epilogue<MI, NI>(p, acc, m0 + wm * 128, n0 + wn * 64, lane);
-}
-
 // Ping-pong schedule of the 256 x 256 tile (see the slot comment inside).
-template <int ABL>
+template <int ABL, int DT, int ODT = DT>
 __global__ __launch_bounds__(512, 2) void conv_big_pp_kernel(const ConvParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int BM = 256, BN = 256;
@@ -792,12 +701,12 @@ __global__ __launch_bounds__(512, 2) void conv_big_pp_kernel(const ConvParams p)
     int rem = m - img * ohw;
     int oh = rem / p.OW, ow = rem - oh * p.OW;
     int ih0 = oh * p.stride - p.pad + p.ipad, iw0 = ow * p.stride - p.pad + p.ipad;
-    xoff[i] = (unsigned)(((img * IHp + ih0) * IWp + iw0) * p.Cin + g * 8) * 2u;
+    xoff[i] = (unsigned)(((img * IHp + ih0) * IWp + iw0) * p.cin_b + g * 16);
     int row = (wave * 4 + i) * 8 + srow;
-    woffv[i] = (unsigned)((n0 + row) * p.Ktot + g * 8) * 2u;
+    woffv[i] = (unsigned)((n0 + row) * p.krow_b + g * 16);
   }
-  const unsigned char *in_b = reinterpret_cast<const unsigned char *>(p.in);
-  const unsigned char *w_b = reinterpret_cast<const unsigned char *>(p.w);
+  const unsigned char *in_b = p.in;
+  const unsigned char *w_b = p.w;
   const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
 
   // the 8 LDS-DMA instructions of a K-step are issued in two halves (X pieces in the wave's L0 slot, W pieces at the
@@ -830,30 +739,6 @@ __global__ __launch_bounds__(512, 2) void conv_big_pp_kernel(const ConvParams p)
     wfo[ks] = XB + (wn * 64 + frow) * 128 + slot * 16;
   }
 
-  h8 xf[MI], wf[NI];
-  auto ld = [&](int buf, int ks) {
-    const unsigned char *sb = smem + buf * STAGE;
-#pragma unroll
-    for (int mi = 0; mi < MI; mi++) xf[mi] = *reinterpret_cast<const h8 *>(sb + xfo[ks] + mi * 16 * 128);
-#pragma unroll
-    for (int ni = 0; ni < NI; ni++) wf[ni] = *reinterpret_cast<const h8 *>(sb + wfo[ks] + ni * 16 * 128);
-  };
-  auto mfmas = [&]() {
-    if (ABL & 2) {  // ablation: keep fragments live, no MFMAs
-#pragma unroll
-      for (int mi = 0; mi < MI; mi++) asm volatile("" ::"v"(xf[mi]));
-#pragma unroll
-      for (int ni = 0; ni < NI; ni++) asm volatile("" ::"v"(wf[ni]));
-      return;
-    }
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int ni = 0; ni < NI; ni++)
-#pragma unroll
-      for (int mi = 0; mi < MI; mi++)
-        acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ni], xf[mi], acc[ni][mi], 0, 0, 0);
-    __builtin_amdgcn_s_setprio(0);
-  };
 #define FP_BAR()                         \
   do {                                   \
     __builtin_amdgcn_s_barrier();        \
@@ -862,41 +747,116 @@ __global__ __launch_bounds__(512, 2) void conv_big_pp_kernel(const ConvParams p)
   } while (0)
 #define FP_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 #define FP_VM0() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+  // Slots of ~32 MFMAs (16 for FP8, each twice as long): group 0 runs L0 M0 L1 M1 per K-step, group 1 the same one slot later,
+  // so on every SIMD one wave issues MFMAs from registers while its partner refills fragments from LDS / issues the next
+  // tile's LDS-DMA.  The slot sequence is the same for every element type (FP_PP_LOOP); what a half-slot reads and
+  // multiplies differs:
+  //   2-byte types: half h = the 32-wide k-step h over all 8 pixel fragments (12 fragment reads, 32 MFMAs);
+  //   FP8: one 128-wide MFMA consumes the whole 128-byte row, so the halves split the PIXEL fragments instead: half 0 reads
+  //        the 4 weight operands (kept for both halves) + pixel fragments 0..3, half 1 pixel fragments 4..7.
+#define FP_PP_LOOP(LD0, LD1, MF0, MF1)                                   \
+  do {                                                                   \
+    const int KT = p.krow_b >> 7;                                        \
+    stage_x(0, 0);                                                       \
+    stage_w(0, 0);                                                       \
+    FP_VM0();                                                            \
+    FP_BAR();                                                            \
+    if (p.clk && tid == 0) { p.clk[blockIdx.x * 4] = __builtin_readcyclecounter(); p.clk[blockIdx.x * 4 + 1] = wall_clock64(); } \
+    int buf = 0;                                                         \
+    if (wm == 0) {                                                       \
+      for (int kt = 0; kt < KT; kt++) {                                  \
+        LD0(buf);                                                        \
+        if (kt + 1 < KT && !(ABL & 1)) stage_x(kt + 1, buf ^ 1);         \
+        FP_LGKM0(); FP_BAR();                                            \
+        if (kt + 1 < KT && !(ABL & 1)) stage_w(kt + 1, buf ^ 1);         \
+        MF0(); FP_BAR();                                                 \
+        LD1(buf); FP_LGKM0(); FP_BAR();                                  \
+        MF1(); FP_VM0(); FP_BAR();                                       \
+        buf ^= 1;                                                        \
+      }                                                                  \
+      FP_BAR();                                                          \
+    } else {                                                             \
+      FP_BAR();                                                          \
+      for (int kt = 0; kt < KT; kt++) {                                  \
+        LD0(buf);                                                        \
+        if (kt + 1 < KT && !(ABL & 1)) stage_x(kt + 1, buf ^ 1);         \
+        FP_LGKM0(); FP_BAR();                                            \
+        if (kt + 1 < KT && !(ABL & 1)) stage_w(kt + 1, buf ^ 1);         \
+        MF0(); FP_BAR();                                                 \
+        LD1(buf); FP_LGKM0(); FP_VM0(); FP_BAR();                        \
+        MF1(); FP_BAR();                                                 \
+        buf ^= 1;                                                        \
+      }                                                                  \
+    }                                                                    \
+  } while (0)
 
-  // Slots of ~32 MFMAs: group 0 runs L0 M0 L1 M1 per K-step, group 1 the same one slot later, so on every SIMD one
-  // wave issues MFMAs from registers while its partner refills fragments from LDS / issues the next tile's LDS-DMA.
-  const int KT = p.Ktot >> 6;
-  stage_x(0, 0);
-  stage_w(0, 0);
-  FP_VM0();
-  FP_BAR();
-  if (p.clk && tid == 0) { p.clk[blockIdx.x * 4] = __builtin_readcyclecounter(); p.clk[blockIdx.x * 4 + 1] = wall_clock64(); }
-  int buf = 0;
-  if (wm == 0) {
-    for (int kt = 0; kt < KT; kt++) {
-      ld(buf, 0);
-      if (kt + 1 < KT && !(ABL & 1)) stage_x(kt + 1, buf ^ 1);
-      FP_LGKM0(); FP_BAR();
-      if (kt + 1 < KT && !(ABL & 1)) stage_w(kt + 1, buf ^ 1);
-      mfmas(); FP_BAR();
-      ld(buf, 1); FP_LGKM0(); FP_BAR();
-      mfmas(); FP_VM0(); FP_BAR();
-      buf ^= 1;
-    }
-    FP_BAR();
+  if constexpr (DT == DT_FP8) {
+    i8 xv[MI / 2], wv[NI];
+    auto ld0 = [&](int buf) {
+      const unsigned char *sb = smem + buf * STAGE;
+#pragma unroll
+      for (int ni = 0; ni < NI; ni++)
+        wv[ni] = __builtin_shufflevector(*reinterpret_cast<const i4 *>(sb + wfo[0] + ni * 16 * 128),
+                                         *reinterpret_cast<const i4 *>(sb + wfo[1] + ni * 16 * 128), 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+      for (int j = 0; j < MI / 2; j++)
+        xv[j] = __builtin_shufflevector(*reinterpret_cast<const i4 *>(sb + xfo[0] + j * 16 * 128),
+                                        *reinterpret_cast<const i4 *>(sb + xfo[1] + j * 16 * 128), 0, 1, 2, 3, 4, 5, 6, 7);
+    };
+    auto ld1 = [&](int buf) {
+      const unsigned char *sb = smem + buf * STAGE;
+#pragma unroll
+      for (int j = 0; j < MI / 2; j++)
+        xv[j] = __builtin_shufflevector(*reinterpret_cast<const i4 *>(sb + xfo[0] + (MI / 2 + j) * 16 * 128),
+                                        *reinterpret_cast<const i4 *>(sb + xfo[1] + (MI / 2 + j) * 16 * 128), 0, 1, 2, 3, 4, 5, 6, 7);
+    };
+    auto mf0 = [&]() {
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int ni = 0; ni < NI; ni++)
+#pragma unroll
+        for (int j = 0; j < MI / 2; j++) acc[ni][j] = mfma128_fp8(wv[ni], xv[j], acc[ni][j]);
+      __builtin_amdgcn_s_setprio(0);
+    };
+    auto mf1 = [&]() {
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int ni = 0; ni < NI; ni++)
+#pragma unroll
+        for (int j = 0; j < MI / 2; j++) acc[ni][MI / 2 + j] = mfma128_fp8(wv[ni], xv[j], acc[ni][MI / 2 + j]);
+      __builtin_amdgcn_s_setprio(0);
+    };
+    FP_PP_LOOP(ld0, ld1, mf0, mf1);
   } else {
-    FP_BAR();
-    for (int kt = 0; kt < KT; kt++) {
-      ld(buf, 0);
-      if (kt + 1 < KT && !(ABL & 1)) stage_x(kt + 1, buf ^ 1);
-      FP_LGKM0(); FP_BAR();
-      if (kt + 1 < KT && !(ABL & 1)) stage_w(kt + 1, buf ^ 1);
-      mfmas(); FP_BAR();
-      ld(buf, 1); FP_LGKM0(); FP_VM0(); FP_BAR();
-      mfmas(); FP_BAR();
-      buf ^= 1;
-    }
+    i4 xf[MI], wf[NI];
+    auto ldk = [&](int buf, int ks) {
+      const unsigned char *sb = smem + buf * STAGE;
+#pragma unroll
+      for (int mi = 0; mi < MI; mi++) xf[mi] = *reinterpret_cast<const i4 *>(sb + xfo[ks] + mi * 16 * 128);
+#pragma unroll
+      for (int ni = 0; ni < NI; ni++) wf[ni] = *reinterpret_cast<const i4 *>(sb + wfo[ks] + ni * 16 * 128);
+    };
+    auto ld0 = [&](int buf) { ldk(buf, 0); };
+    auto ld1 = [&](int buf) { ldk(buf, 1); };
+    auto mf = [&]() {
+      if (ABL & 2) {  // ablation: keep fragments live, no MFMAs
+#pragma unroll
+        for (int mi = 0; mi < MI; mi++) asm volatile("" ::"v"(xf[mi]));
+#pragma unroll
+        for (int ni = 0; ni < NI; ni++) asm volatile("" ::"v"(wf[ni]));
+        return;
+      }
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int ni = 0; ni < NI; ni++)
+#pragma unroll
+        for (int mi = 0; mi < MI; mi++)
+          acc[ni][mi] = mfma32<DT>(wf[ni], xf[mi], acc[ni][mi]);
+      __builtin_amdgcn_s_setprio(0);
+    };
+    FP_PP_LOOP(ld0, ld1, mf, mf);
   }
+#undef FP_PP_LOOP
 #undef FP_BAR
 #undef FP_LGKM0
 #undef FP_VM0
@@ -909,7 +869,7 @@ __global__ __launch_bounds__(512, 2) void conv_big_pp_kernel(const ConvParams p)
       for (int b = 0; b < MI; b++) asm volatile("" ::"v"(acc[a][b]));
     return;
   }
-  conv_epilogue<MI, NI, (ABL >> 3) & 3>(p, acc, m0 + wm * 128, n0 + wn * 64, lane);
+  conv_epilogue<MI, NI, DT, ODT, (ABL >> 3) & 3>(p, acc, m0 + wm * 128, n0 + wn * 64, lane);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -922,7 +882,7 @@ __global__ __launch_bounds__(512, 2) void conv_big_pp_kernel(const ConvParams p)
 //   stage = [BM + BN rows][64 B]; a DMA piece is 16 rows x 64 B; slot = chunk ^ G[(row>>2)&3], G = {0,2,3,1}, is
 //   conflict-free for the four 16-lane groups of ds_read_b128 with 64-byte rows (checked by enumeration).
 // -------------------------------------------------------------------------------------------------
-template <int BM, int BN>
+template <int BM, int BN, int DT, int ODT = DT>
 __global__ __launch_bounds__(512, 2) void conv_pp32_kernel(const ConvParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int WM = BM / 128, WN = BN / 64;
@@ -961,14 +921,14 @@ __global__ __launch_bounds__(512, 2) void conv_pp32_kernel(const ConvParams p) {
       int rem = m - img * ohw;
       int oh = rem / p.OW, ow = rem - oh * p.OW;
       int ih0 = oh * p.stride - p.pad + p.ipad, iw0 = ow * p.stride - p.pad + p.ipad;
-      poff[i] = (unsigned)(((img * IHp + ih0) * IWp + iw0) * p.Cin + gch * 8) * 2u;
+      poff[i] = (unsigned)(((img * IHp + ih0) * IWp + iw0) * p.cin_b + gch * 16);
     } else {
       int row = (piece - XP) * 16 + prow;
-      poff[i] = (unsigned)((n0 + row) * p.Ktot + gch * 8) * 2u;
+      poff[i] = (unsigned)((n0 + row) * p.krow_b + gch * 16);
     }
   }
-  const unsigned char *in_b = reinterpret_cast<const unsigned char *>(p.in);
-  const unsigned char *w_b = reinterpret_cast<const unsigned char *>(p.w);
+  const unsigned char *in_b = p.in;
+  const unsigned char *w_b = p.w;
   const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
 
   auto stage = [&](int st, int buf) {
@@ -994,13 +954,13 @@ __global__ __launch_bounds__(512, 2) void conv_pp32_kernel(const ConvParams p) {
   const int xfo = (wm * 128 + (lane & 15)) * 64 + fslot * 16;
   const int wfo = XB + (wn * 64 + (lane & 15)) * 64 + fslot * 16;
 
-  h8 xf[MI], wf[NI];
+  i4 xf[MI], wf[NI];
   auto ld = [&](int buf) {
     const unsigned char *sb = smem + buf * STAGE;
 #pragma unroll
-    for (int mi = 0; mi < MI; mi++) xf[mi] = *reinterpret_cast<const h8 *>(sb + xfo + mi * 16 * 64);
+    for (int mi = 0; mi < MI; mi++) xf[mi] = *reinterpret_cast<const i4 *>(sb + xfo + mi * 16 * 64);
 #pragma unroll
-    for (int ni = 0; ni < NI; ni++) wf[ni] = *reinterpret_cast<const h8 *>(sb + wfo + ni * 16 * 64);
+    for (int ni = 0; ni < NI; ni++) wf[ni] = *reinterpret_cast<const i4 *>(sb + wfo + ni * 16 * 64);
   };
   auto mfmas = [&]() {
     __builtin_amdgcn_s_setprio(1);
@@ -1008,7 +968,7 @@ __global__ __launch_bounds__(512, 2) void conv_pp32_kernel(const ConvParams p) {
     for (int ni = 0; ni < NI; ni++)
 #pragma unroll
       for (int mi = 0; mi < MI; mi++)
-        acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ni], xf[mi], acc[ni][mi], 0, 0, 0);
+        acc[ni][mi] = mfma32<DT>(wf[ni], xf[mi], acc[ni][mi]);
     __builtin_amdgcn_s_setprio(0);
   };
 #define FP_BAR()                         \
@@ -1027,7 +987,7 @@ __global__ __launch_bounds__(512, 2) void conv_pp32_kernel(const ConvParams p) {
     else FP_VM(0);                                       \
   } while (0)
 
-  const int S = p.Ktot >> 5;  // 32-wide K-steps, >= 16 for every layer
+  const int S = p.krow_b >> 6;  // 32-wide K-steps, >= 16 for every layer
   stage(0, 0);
   stage(1, 1);
   stage(2, 2);
@@ -1062,7 +1022,7 @@ __global__ __launch_bounds__(512, 2) void conv_pp32_kernel(const ConvParams p) {
 #undef FP_LGKM0
 #undef FP_VM
 #undef FP_WAIT_NEXT
-  conv_epilogue<MI, NI>(p, acc, m0 + wm * 128, n0 + wn * 64, lane);
+  conv_epilogue<MI, NI, DT, ODT>(p, acc, m0 + wm * 128, n0 + wn * 64, lane);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -1078,8 +1038,9 @@ __global__ __launch_bounds__(512, 2) void conv_pp32_kernel(const ConvParams p) {
 //   halo LDS layout: pixel-major 128-byte rows, 16-byte slot = chunk ^ g, g = ((x>>1)&1) | ((y&3)<<1): conflict-free for
 //   every tap shift (checked by enumeration); the swizzle is applied by the DMA on the SOURCE chunk.
 // -------------------------------------------------------------------------------------------------
-template <int TW, int ABL = 0>  // ABL (timing ablations, wrong results): 1 no per-step barrier, 2 no MFMAs, 4 X fragments read once
+template <int TW, int ABL, int DT>  // ABL (timing ablations, wrong results): 1 no per-step barrier, 2 no MFMAs, 4 X fragments read once
 __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const ConvParams p) {
+  static_assert(DT != DT_FP8, "2-byte element types (64-channel chunks); the FP8 sibling is conv_halo8_kernel");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int TH = 8, HC = TW + 2, HPX = (TH + 2) * HC;
   constexpr int HPIECES = (HPX + 7) / 8, HALO_B = HPIECES * 1024;
@@ -1103,8 +1064,8 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const ConvParams p) {
   const int n0 = nt * 128;
   const int IHp = p.H + 2;
 
-  const unsigned char *in_b = reinterpret_cast<const unsigned char *>(p.in) + ((size_t)(img * IHp + ty0) * HC) * p.Cin * 2;
-  const unsigned char *w_b = reinterpret_cast<const unsigned char *>(p.w);
+  const unsigned char *in_b = p.in + ((size_t)(img * IHp + ty0) * HC) * p.cin_b;
+  const unsigned char *w_b = p.w;
   const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
   const unsigned w_lds = lds_base + HALO_B;
 
@@ -1120,7 +1081,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const ConvParams p) {
         int q = min(piece * 8 + lane8, HPX - 1);
         int hy = q / HC, hx = q - hy * HC;
         int g = ((hx >> 1) & 1) | ((hy & 3) << 1);
-        unsigned off = (unsigned)(q * p.Cin * 2 + (((lane & 7) ^ g) << 4));
+        unsigned off = (unsigned)(q * p.cin_b + (((lane & 7) ^ g) << 4));
         glds16_asm(src + off, lds_base + piece * 1024);
         __builtin_amdgcn_sched_barrier(0);  // one address at a time: 14 hoisted 64-bit addresses would spill accumulators
       }
@@ -1131,7 +1092,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const ConvParams p) {
   const int gch = (lane & 3) ^ ((0x78 >> (((prow >> 2) & 3) * 2)) & 3);
   unsigned woff[2];
 #pragma unroll
-  for (int i = 0; i < 2; i++) woff[i] = (unsigned)((n0 + (wave * 2 + i) * 16 + prow) * p.Ktot + gch * 8) * 2u;
+  for (int i = 0; i < 2; i++) woff[i] = (unsigned)((n0 + (wave * 2 + i) * 16 + prow) * p.krow_b + gch * 16);
   auto issue_w = [&](int st) {
     const unsigned char *wb = w_b + (size_t)st * 64;
     const unsigned dst = w_lds + (st % NWST) * WST;
@@ -1149,8 +1110,8 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const ConvParams p) {
   const int fslot = kg ^ ((0x78 >> ((li >> 2) * 2)) & 3);
   const int wfo = HALO_B + (wn * 64 + li) * 64 + fslot * 16;
 
-  const int S = p.Ktot >> 5;   // 32-wide K-steps: 18 per 64-channel chunk (9 taps x 2)
-  const int nch = p.Cin >> 6;
+  const int S = p.krow_b >> 6;   // 32-wide K-steps: 18 per 64-channel chunk (9 taps x 2)
+  const int nch = p.cin_b >> 7;
   issue_halo(0);
   issue_w(0);
   issue_w(1);
@@ -1178,11 +1139,11 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const ConvParams p) {
         // X fragments in two halves of MI/2 (register budget: 160 accumulators + 20 + 16 fragment registers); the
         // second half's LDS reads are issued behind the first half's MFMAs
         constexpr int HM = MI / 2;
-        h8 xf[HM], wf[NI];
+        i4 xf[HM], wf[NI];
 #pragma unroll
-        for (int ni = 0; ni < NI; ni++) wf[ni] = *reinterpret_cast<const h8 *>(ws + ni * 16 * 64);
+        for (int ni = 0; ni < NI; ni++) wf[ni] = *reinterpret_cast<const i4 *>(ws + ni * 16 * 64);
 #pragma unroll
-        for (int mi = 0; mi < HM; mi++) xf[mi] = *reinterpret_cast<const h8 *>(xs + mi * 512);
+        for (int mi = 0; mi < HM; mi++) xf[mi] = *reinterpret_cast<const i4 *>(xs + mi * 512);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (!(ABL & 8)) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -1190,12 +1151,12 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const ConvParams p) {
 #pragma unroll
           for (int mi = 0; mi < HM; mi++) {
             if (ABL & 2) asm volatile("" ::"v"(wf[ni]), "v"(xf[mi]));
-            else acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ni], xf[mi], acc[ni][mi], 0, 0, 0);
+            else acc[ni][mi] = mfma32<DT>(wf[ni], xf[mi], acc[ni][mi]);
           }
         if (!(ABL & 8)) __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int mi = 0; mi < HM; mi++) xf[mi] = *reinterpret_cast<const h8 *>(xs + (HM + mi) * 512);
+        for (int mi = 0; mi < HM; mi++) xf[mi] = *reinterpret_cast<const i4 *>(xs + (HM + mi) * 512);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (tap == 8 && ks == 1 && ch + 1 < nch) {  // last read of this chunk's halo tile: refill it under the MFMAs
           __builtin_amdgcn_s_barrier();
@@ -1209,14 +1170,156 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const ConvParams p) {
 #pragma unroll
           for (int mi = 0; mi < HM; mi++) {
             if (ABL & 2) asm volatile("" ::"v"(wf[ni]), "v"(xf[mi]));
-            else acc[ni][HM + mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ni], xf[mi], acc[ni][HM + mi], 0, 0, 0);
+            else acc[ni][HM + mi] = mfma32<DT>(wf[ni], xf[mi], acc[ni][HM + mi]);
           }
         if (!(ABL & 8)) __builtin_amdgcn_s_setprio(0);
       }
     }
   }
   if (p.clk && tid == 0) { p.clk[blockIdx.x * 4 + 2] = __builtin_readcyclecounter(); p.clk[blockIdx.x * 4 + 3] = wall_clock64(); }
-  conv_epilogue_px<MI, NI>(p, acc, n0 + wn * 64, lane, [&](int mi, int &oimg, int &oh, int &ow) {
+  conv_epilogue_px<MI, NI, DT, DT>(p, acc, n0 + wn * 64, lane, [&](int mi, int &oimg, int &oh, int &ow) {
+    oimg = img;
+    oh = ty0 + wm * 4 + dy;
+    ow = mi * 4 + dx;
+    return true;
+  });
+}
+
+// -------------------------------------------------------------------------------------------------
+// conv_halo8_kernel: the FP8 (e4m3) sibling of conv_halo_kernel<40>: 3x3 / stride 1 on 40x40 maps, input tile + halo of a
+// 128-CHANNEL chunk (again 128 bytes per pixel, so the halo layout, its DMA and its swizzle are byte-identical) resident
+// in LDS.  One K-step = one tap of the chunk = one v_mfma_f32_16x16x128_f8f6f4 per (pixel block, channel tile): 9
+// steps per chunk of 40 MFMAs x 32 cycles per wave -- the same matrix-pipe time per step PAIR as the 2-byte kernel for
+// twice the contraction length.
+//   Weights: 128 rows x 128 B = 16 KB per step.  Two such stages next to the 53 KB halo would not let two workgroups
+//   share a CU (2 x 85 KB > 160 KB), so the weight tile is single-buffered in LDS and double-buffered through
+//   REGISTERS: every wave pulls its four 32-byte weight operands first, a second barrier frees the stage, the DMA for
+//   the next tap is issued, and the 40 MFMAs (1280 cycles) run from registers while it lands.  LDS: 53 + 16 = 69 KB.
+//   X operands are read two pixel blocks at a time under the MFMAs (160 accumulators + 32 + 16 operand registers).
+//   Weight stage layout: 128-byte rows, 16-byte slot = chunk ^ (row & 7) (the implicit-GEMM kernels' swizzle).
+// -------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void conv_halo8_kernel(const ConvParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int TW = 40, TH = 8, HC = TW + 2, HPX = (TH + 2) * HC;
+  constexpr int HPIECES = (HPX + 7) / 8, HALO_B = HPIECES * 1024;
+  constexpr int HPER = (HPIECES + 3) / 4;  // halo DMA pieces per wave
+  constexpr int MI = TW / 4, NI = 4;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int n_tiles = p.Cout / 128;
+  int logical;
+  {
+    const int nblk = gridDim.x, b = blockIdx.x;
+    const int xcd = b & 7, within = b >> 3, q = nblk >> 3, r = nblk & 7;
+    logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
+  }
+  const int mt = logical / n_tiles, nt = logical - mt * n_tiles;
+  const int tiles_per_img = p.H / TH;
+  const int img = mt / tiles_per_img, ty0 = (mt - img * tiles_per_img) * TH;
+  const int n0 = nt * 128;
+  const int IHp = p.H + 2;
+
+  const unsigned char *in_b = p.in + ((size_t)(img * IHp + ty0) * HC) * p.cin_b;
+  const unsigned char *w_b = p.w;
+  const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
+  const unsigned w_lds = lds_base + HALO_B;
+
+  // halo DMA: piece = wave + 4*i covers halo pixels piece*8 .. +7; lane -> (pixel = lane>>3, slot = lane&7)
+  auto issue_halo = [&](int chunk) {
+    const unsigned char *src = in_b + chunk * 128;
+    int lane8;  // opaque copy of lane>>3: keeps the 14 per-lane offsets from being hoisted out of the chunk loop (VGPRs)
+    asm volatile("v_lshrrev_b32 %0, 3, %1" : "=v"(lane8) : "v"(lane));
+#pragma unroll
+    for (int i = 0; i < HPER; i++) {
+      const int piece = wave + 4 * i;
+      if (piece < HPIECES) {
+        int q = min(piece * 8 + lane8, HPX - 1);
+        int hy = q / HC, hx = q - hy * HC;
+        int g = ((hx >> 1) & 1) | ((hy & 3) << 1);
+        unsigned off = (unsigned)(q * p.cin_b + (((lane & 7) ^ g) << 4));
+        glds16_asm(src + off, lds_base + piece * 1024);
+        __builtin_amdgcn_sched_barrier(0);  // one address at a time: hoisted 64-bit addresses would spill accumulators
+      }
+    }
+  };
+  // weight DMA: piece = wave*4 + i (8 rows x 128 B); lane -> (row = lane>>3, slot = lane&7), source chunk = slot ^ row
+  const int srow = lane >> 3;
+  unsigned woff[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) woff[i] = (unsigned)((n0 + (wave * 4 + i) * 8 + srow) * p.krow_b + (((lane & 7) ^ srow) << 4));
+  auto issue_w = [&](int st) {
+    const unsigned char *wb = w_b + (size_t)st * 128;
+#pragma unroll
+    for (int i = 0; i < 4; i++) glds16_asm(wb + woff[i], w_lds + (wave * 4 + i) * 1024);
+  };
+
+  f4 acc[NI][MI];
+#pragma unroll
+  for (int a = 0; a < NI; a++)
+#pragma unroll
+    for (int b = 0; b < MI; b++) acc[a][b] = (f4){0.f, 0.f, 0.f, 0.f};
+
+  const int li = lane & 15, dy = li >> 2, dx = li & 3, kg = lane >> 4;
+  // weight operand of channel tile ni: row wn*64 + ni*16 + li, chunks kg and 4 + kg
+  const int wfo0 = HALO_B + (wn * 64 + li) * 128 + ((kg ^ (li & 7)) << 4);
+  const int wfo1 = HALO_B + (wn * 64 + li) * 128 + (((4 + kg) ^ (li & 7)) << 4);
+
+  const int S = p.krow_b >> 7;   // 9 taps per 128-channel chunk
+  const int nch = p.cin_b >> 7;
+  issue_halo(0);
+  issue_w(0);
+  if (p.clk && tid == 0) { p.clk[blockIdx.x * 4] = __builtin_readcyclecounter(); p.clk[blockIdx.x * 4 + 1] = wall_clock64(); }
+  int s = 0;
+  for (int ch = 0; ch < nch; ch++) {
+    for (int tap = 0; tap < 9; tap++, s++) {
+      const int ky = tap / 3, kx = tap - ky * 3;
+      const int ty = wm * 4 + dy + ky, tx = dx + kx;
+      const int g = ((tx >> 1) & 1) | ((ty & 3) << 1);
+      const unsigned char *xs0 = smem + (ty * HC + tx) * 128 + ((kg ^ g) << 4);
+      const unsigned char *xs1 = smem + (ty * HC + tx) * 128 + (((4 + kg) ^ g) << 4);
+      // W(s) (and, on a chunk's first tap, the halo tile) landed
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      i8 wv[NI];
+#pragma unroll
+      for (int ni = 0; ni < NI; ni++)
+        wv[ni] = __builtin_shufflevector(*reinterpret_cast<const i4 *>(smem + wfo0 + ni * 16 * 128),
+                                         *reinterpret_cast<const i4 *>(smem + wfo1 + ni * 16 * 128), 0, 1, 2, 3, 4, 5, 6, 7);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();  // every wave holds W(s) in registers: the stage is free
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      if (s + 1 < S) issue_w(s + 1);
+#pragma unroll
+      for (int m2 = 0; m2 < MI; m2 += 2) {
+        i8 xv[2];
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+          xv[j] = __builtin_shufflevector(*reinterpret_cast<const i4 *>(xs0 + (m2 + j) * 512),
+                                          *reinterpret_cast<const i4 *>(xs1 + (m2 + j) * 512), 0, 1, 2, 3, 4, 5, 6, 7);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (m2 == MI - 2 && tap == 8 && ch + 1 < nch) {  // last read of this chunk's halo tile: refill it under the MFMAs
+          __builtin_amdgcn_s_barrier();
+          asm volatile("" ::: "memory");
+          __builtin_amdgcn_sched_barrier(0);
+          issue_halo(ch + 1);
+        }
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ni = 0; ni < NI; ni++)
+#pragma unroll
+          for (int j = 0; j < 2; j++) acc[ni][m2 + j] = mfma128_fp8(wv[ni], xv[j], acc[ni][m2 + j]);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+  if (p.clk && tid == 0) { p.clk[blockIdx.x * 4 + 2] = __builtin_readcyclecounter(); p.clk[blockIdx.x * 4 + 3] = wall_clock64(); }
+  conv_epilogue_px<MI, NI, DT_FP8, DT_FP8>(p, acc, n0 + wn * 64, lane, [&](int mi, int &oimg, int &oh, int &ow) {
     oimg = img;
     oh = ty0 + wm * 4 + dy;
     ow = mi * 4 + dx;
@@ -1233,6 +1336,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const ConvParams p) {
 //   (one tap each, 32 channels); weights 4 KB per step through a 3-stage ring; two workgroups per CU.
 //   64-byte pixel rows: 16-byte slot = chunk ^ (y & 3); conflict-free because the pitch (84) is a multiple of 4.
 // -------------------------------------------------------------------------------------------------
+template <int DT>
 __global__ __launch_bounds__(256, 2) void conv_stem_halo_kernel(const ConvParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int TW = 80, TH = 8, HC = 84, HPX = (TH + 3) * HC;
@@ -1254,8 +1358,8 @@ __global__ __launch_bounds__(256, 2) void conv_stem_halo_kernel(const ConvParams
   const int tiles_per_img = p.H / TH;
   const int img = logical / tiles_per_img, ty0 = (logical - img * tiles_per_img) * TH;
 
-  const unsigned char *in_b = reinterpret_cast<const unsigned char *>(p.in) + ((size_t)(img * HC + ty0) * HC) * 64;
-  const unsigned char *w_b = reinterpret_cast<const unsigned char *>(p.w);
+  const unsigned char *in_b = p.in + ((size_t)(img * HC + ty0) * HC) * 64;
+  const unsigned char *w_b = p.w;
   const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
   const unsigned w_lds = lds_base + HALO_B;
 
@@ -1274,7 +1378,7 @@ __global__ __launch_bounds__(256, 2) void conv_stem_halo_kernel(const ConvParams
   }
   const int prow = lane >> 2;
   const int gch = (lane & 3) ^ ((0x78 >> (((prow >> 2) & 3) * 2)) & 3);
-  const unsigned woff = (unsigned)((wave * 16 + prow) * p.Ktot + gch * 8) * 2u;
+  const unsigned woff = (unsigned)((wave * 16 + prow) * p.krow_b + gch * 16);
   auto issue_w = [&](int st) { glds16_asm(w_b + (size_t)st * 64 + woff, w_lds + (st % NWST) * WST + wave * 1024); };
 
   f4 acc[NI][MI];
@@ -1301,26 +1405,26 @@ __global__ __launch_bounds__(256, 2) void conv_stem_halo_kernel(const ConvParams
     if (s + 2 < S) issue_w(s + 2);
     const unsigned char *xs = smem + (ty * HC + tx) * 64 + ((kg ^ (ty & 3)) << 4);
     const unsigned char *ws = smem + wfo + (s % NWST) * WST;
-    h8 xf[HM], wf[NI];
+    i4 xf[HM], wf[NI];
 #pragma unroll
-    for (int ni = 0; ni < NI; ni++) wf[ni] = *reinterpret_cast<const h8 *>(ws + ni * 16 * 64);
+    for (int ni = 0; ni < NI; ni++) wf[ni] = *reinterpret_cast<const i4 *>(ws + ni * 16 * 64);
 #pragma unroll
-    for (int mi = 0; mi < HM; mi++) xf[mi] = *reinterpret_cast<const h8 *>(xs + mi * 256);
+    for (int mi = 0; mi < HM; mi++) xf[mi] = *reinterpret_cast<const i4 *>(xs + mi * 256);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
     for (int ni = 0; ni < NI; ni++)
 #pragma unroll
       for (int mi = 0; mi < HM; mi++)
-        acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ni], xf[mi], acc[ni][mi], 0, 0, 0);
+        acc[ni][mi] = mfma32<DT>(wf[ni], xf[mi], acc[ni][mi]);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int mi = 0; mi < HM; mi++) xf[mi] = *reinterpret_cast<const h8 *>(xs + (HM + mi) * 256);
+    for (int mi = 0; mi < HM; mi++) xf[mi] = *reinterpret_cast<const i4 *>(xs + (HM + mi) * 256);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
     for (int ni = 0; ni < NI; ni++)
 #pragma unroll
       for (int mi = 0; mi < HM; mi++)
-        acc[ni][HM + mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ni], xf[mi], acc[ni][HM + mi], 0, 0, 0);
+        acc[ni][HM + mi] = mfma32<DT>(wf[ni], xf[mi], acc[ni][HM + mi]);
   }
   // Cout = 64: weight rows are permuted in 32-channel blocks (NI = 2 form), so the epilogue runs once per block
   auto pix = [&](int mi, int &oimg, int &oh, int &ow) {
@@ -1329,8 +1433,9 @@ __global__ __launch_bounds__(256, 2) void conv_stem_halo_kernel(const ConvParams
     ow = chalf * (TW / 2) + mi * 4 + dx;
     return true;
   };
-  conv_epilogue_px<MI, 2>(p, reinterpret_cast<f4(&)[2][MI]>(acc[0]), 0, lane, pix);
-  conv_epilogue_px<MI, 2>(p, reinterpret_cast<f4(&)[2][MI]>(acc[2]), 32, lane, pix);
+  // EABL = 2: this layer never has a residual (the dispatcher requires it), so the residual path is compiled out
+  conv_epilogue_px<MI, 2, DT, DT, 2, 4, 0>(p, acc, 0, lane, pix);
+  conv_epilogue_px<MI, 2, DT, DT, 2, 4, 2>(p, acc, 32, lane, pix);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -1344,6 +1449,7 @@ __global__ __launch_bounds__(256, 2) void conv_stem_halo_kernel(const ConvParams
 //   32-channel K-steps), plane 1 the three taps with kx = 1 (6 K-steps).  Weights: 8 KB per step, 3-stage ring.
 //   16-byte slot of an LDS pixel = chunk ^ (((row>>1)&3) | (((x>>1)&1)<<2)): conflict-free fragment reads.
 // -------------------------------------------------------------------------------------------------
+template <int DT, int ODT = DT>
 __global__ __launch_bounds__(256, 2) void conv_s2_halo_kernel(const ConvParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int IC = 82, HR = 9, PW = 41, HPX = HR * PW;  // 4 output rows need 9 input rows; 41 columns per parity plane
@@ -1364,8 +1470,8 @@ __global__ __launch_bounds__(256, 2) void conv_s2_halo_kernel(const ConvParams p
   const int img = logical / 10, oy0 = (logical - img * 10) * 4;
 
   // input image: [82][82][64] halfs (border 1); the tile's first input row is 2*oy0 (padded coordinates)
-  const unsigned char *in_b = reinterpret_cast<const unsigned char *>(p.in) + ((size_t)(img * IC + 2 * oy0) * IC) * 128;
-  const unsigned char *w_b = reinterpret_cast<const unsigned char *>(p.w);
+  const unsigned char *in_b = p.in + ((size_t)(img * IC + 2 * oy0) * IC) * 128;
+  const unsigned char *w_b = p.w;
   const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
   const unsigned w_lds = lds_base + HALO_B;
 
@@ -1390,7 +1496,7 @@ __global__ __launch_bounds__(256, 2) void conv_s2_halo_kernel(const ConvParams p
   const int gch = (lane & 3) ^ ((0x78 >> (((prow >> 2) & 3) * 2)) & 3);
   unsigned woff[2];
 #pragma unroll
-  for (int i = 0; i < 2; i++) woff[i] = (unsigned)(((wave * 2 + i) * 16 + prow) * p.Ktot + gch * 8) * 2u;
+  for (int i = 0; i < 2; i++) woff[i] = (unsigned)(((wave * 2 + i) * 16 + prow) * p.krow_b + gch * 16);
   // step -> (tap, 32-channel half): steps 0..11 walk the kx in {0,2} taps, 12..17 the kx = 1 taps
   auto step_tap = [&](int st, int &ky, int &kx) {
     if (st < SA) { const int t = st >> 1; ky = t >> 1; kx = (t & 1) * 2; }
@@ -1433,11 +1539,11 @@ __global__ __launch_bounds__(256, 2) void conv_s2_halo_kernel(const ConvParams p
     const int g = ((r >> 1) & 3) | (((xp >> 1) & 1) << 2);
     const unsigned char *xs = smem + (r * PW + xp) * 128 + (((((s & 1) << 2) | kg) ^ g) << 4);
     const unsigned char *ws = smem + wfo + (s % NWST) * WST;
-    h8 xf[MI], wf[NI];
+    i4 xf[MI], wf[NI];
 #pragma unroll
-    for (int ni = 0; ni < NI; ni++) wf[ni] = *reinterpret_cast<const h8 *>(ws + ni * 16 * 64);
+    for (int ni = 0; ni < NI; ni++) wf[ni] = *reinterpret_cast<const i4 *>(ws + ni * 16 * 64);
 #pragma unroll
-    for (int mi = 0; mi < MI; mi++) xf[mi] = *reinterpret_cast<const h8 *>(xs + mi * 512);
+    for (int mi = 0; mi < MI; mi++) xf[mi] = *reinterpret_cast<const i4 *>(xs + mi * 512);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (s == SA - 1) {  // last read of plane 0: stage plane 1 under this step's MFMAs
       __builtin_amdgcn_s_barrier();
@@ -1449,9 +1555,9 @@ __global__ __launch_bounds__(256, 2) void conv_s2_halo_kernel(const ConvParams p
     for (int ni = 0; ni < NI; ni++)
 #pragma unroll
       for (int mi = 0; mi < MI; mi++)
-        acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ni], xf[mi], acc[ni][mi], 0, 0, 0);
+        acc[ni][mi] = mfma32<DT>(wf[ni], xf[mi], acc[ni][mi]);
   }
-  conv_epilogue_px<MI, NI>(p, acc, wn * 64, lane, [&](int mi, int &oimg, int &oh, int &ow) {
+  conv_epilogue_px<MI, NI, DT, ODT, 2>(p, acc, wn * 64, lane, [&](int mi, int &oimg, int &oh, int &ow) {  // 2: no residual in this layer
     oimg = img;
     oh = oy0 + dy;
     ow = chalf * 20 + mi * 4 + dx;
@@ -1467,7 +1573,7 @@ __global__ __launch_bounds__(256, 2) void conv_s2_halo_kernel(const ConvParams p
 // workgroups per CU so one's prologue / epilogue runs under the other's MFMAs.  LDS rows are 64 bytes; the 16-byte
 // slot of (row, chunk) is chunk ^ f((row>>2)&3), f = {0,2,3,1} (conflict-free ds_read_b128 fragments).
 // -------------------------------------------------------------------------------------------------
-template <int ABL = 0>  // timing ablations: 1 = no MFMAs, 2 = no loads after the first stage, 4 = no stores
+template <int ABL, int DT>  // timing ablations: 1 = no MFMAs, 2 = no loads after the first stage, 4 = no stores
 __global__ __launch_bounds__(256, 2) void gemm_k32_kernel(const ConvParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int BM = 128, BN = 256;
@@ -1485,10 +1591,10 @@ __global__ __launch_bounds__(256, 2) void gemm_k32_kernel(const ConvParams p) {
   }
   const int mt = logical / n_tiles, nt = logical - mt * n_tiles;
   const int m0 = p.m_begin + mt * BM, n0 = nt * BN;
-  const int S = p.Ktot >> 5;
+  const int S = p.krow_b >> 6;
 
-  const unsigned char *in_b = reinterpret_cast<const unsigned char *>(p.in);
-  const unsigned char *w_b = reinterpret_cast<const unsigned char *>(p.w);
+  const unsigned char *in_b = p.in;
+  const unsigned char *w_b = p.w;
   const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
 
   // staging: a wave-instruction moves 16 rows x 64 B; lane -> (row = lane>>2, slot = lane&3), source chunk swizzled
@@ -1498,10 +1604,10 @@ __global__ __launch_bounds__(256, 2) void gemm_k32_kernel(const ConvParams p) {
 #pragma unroll
   for (int i = 0; i < 2; i++) {
     const int m = min(m0 + (wave * 2 + i) * 16 + prow, p.M - 1);  // rows past M re-read the last row (never stored)
-    xoff[i] = (unsigned)(m * p.Ktot + gch * 8) * 2u;
+    xoff[i] = (unsigned)(m * p.krow_b + gch * 16);
   }
 #pragma unroll
-  for (int i = 0; i < 4; i++) woff[i] = (unsigned)((n0 + (wave * 4 + i) * 16 + prow) * p.Ktot + gch * 8) * 2u;
+  for (int i = 0; i < 4; i++) woff[i] = (unsigned)((n0 + (wave * 4 + i) * 16 + prow) * p.krow_b + gch * 16);
   auto issue = [&](int st) {
     const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + (st % NST) * STAGE);
     const unsigned char *xb = in_b + (size_t)st * 64, *wb = w_b + (size_t)st * 64;
@@ -1535,11 +1641,11 @@ __global__ __launch_bounds__(256, 2) void gemm_k32_kernel(const ConvParams p) {
     __builtin_amdgcn_sched_barrier(0);
     if (s + 2 < S && !(ABL & 2)) issue(s + 2);
     const unsigned char *sb = smem + ((ABL & 2) ? 0 : (s % NST)) * STAGE;
-    h8 xf[4], wf[8];
+    i4 xf[4], wf[8];
 #pragma unroll
-    for (int mi = 0; mi < 4; mi++) xf[mi] = *reinterpret_cast<const h8 *>(sb + xfo + mi * 1024);
+    for (int mi = 0; mi < 4; mi++) xf[mi] = *reinterpret_cast<const i4 *>(sb + xfo + mi * 1024);
 #pragma unroll
-    for (int ni = 0; ni < 8; ni++) wf[ni] = *reinterpret_cast<const h8 *>(sb + wfo + ni * 1024);
+    for (int ni = 0; ni < 8; ni++) wf[ni] = *reinterpret_cast<const i4 *>(sb + wfo + ni * 1024);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (ABL & 1) {
 #pragma unroll
@@ -1553,11 +1659,11 @@ __global__ __launch_bounds__(256, 2) void gemm_k32_kernel(const ConvParams p) {
     for (int ni = 0; ni < 8; ni++)
 #pragma unroll
       for (int mi = 0; mi < 4; mi++)
-        acc[ni >> 2][ni & 3][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ni], xf[mi], acc[ni >> 2][ni & 3][mi], 0, 0, 0);
+        acc[ni >> 2][ni & 3][mi] = mfma32<DT>(wf[ni], xf[mi], acc[ni >> 2][ni & 3][mi]);
     __builtin_amdgcn_s_setprio(0);
   }
-  conv_epilogue<4, 4, (ABL >> 2) & 1>(p, acc[0], m0 + wm * 64, n0 + wn * 128, lane);
-  conv_epilogue<4, 4, (ABL >> 2) & 1>(p, acc[1], m0 + wm * 64, n0 + wn * 128 + 64, lane);
+  conv_epilogue<4, 4, DT, DT, (ABL >> 2) & 1>(p, acc[0], m0 + wm * 64, n0 + wn * 128, lane);
+  conv_epilogue<4, 4, DT, DT, (ABL >> 2) & 1>(p, acc[1], m0 + wm * 64, n0 + wn * 128 + 64, lane);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -1568,7 +1674,7 @@ __global__ __launch_bounds__(256, 2) void gemm_k32_kernel(const ConvParams p) {
 // current step's MFMAs (two register sets).  Same K order / accumulation order as every
 // other schedule, so a row's value does not depend on which kernel computed it.
 // -------------------------------------------------------------------------------------------------
-template <int BM>
+template <int BM, int DT, int ODT = DT>
 __global__ __launch_bounds__(256, 2) void conv_deep_kernel(const ConvParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int BN = 128;
@@ -1591,7 +1697,7 @@ __global__ __launch_bounds__(256, 2) void conv_deep_kernel(const ConvParams p) {
   const int m0 = p.m_begin + mt * BM, n0 = nt * BN;
   const int ohw = p.OH * p.OW;
   const int IHp = p.H + 2 * p.ipad, IWp = p.W + 2 * p.ipad;
-  const int KT = p.Ktot >> 6;
+  const int KT = p.krow_b >> 7;
 
   const int srow = lane >> 3;
   const int g = (lane & 7) ^ srow;
@@ -1603,12 +1709,12 @@ __global__ __launch_bounds__(256, 2) void conv_deep_kernel(const ConvParams p) {
     int rem = m - img * ohw;
     int oh = rem / p.OW, ow = rem - oh * p.OW;
     int ih0 = oh * p.stride - p.pad + p.ipad, iw0 = ow * p.stride - p.pad + p.ipad;
-    xoff[i] = (unsigned)(((img * IHp + ih0) * IWp + iw0) * p.Cin + g * 8) * 2u;
+    xoff[i] = (unsigned)(((img * IHp + ih0) * IWp + iw0) * p.cin_b + g * 16);
   }
 #pragma unroll
-  for (int i = 0; i < WP; i++) woff[i] = (unsigned)((n0 + (wave * WP + i) * 8 + srow) * p.Ktot + g * 8) * 2u;
-  const unsigned char *in_b = reinterpret_cast<const unsigned char *>(p.in);
-  const unsigned char *w_b = reinterpret_cast<const unsigned char *>(p.w);
+  for (int i = 0; i < WP; i++) woff[i] = (unsigned)((n0 + (wave * WP + i) * 8 + srow) * p.krow_b + g * 16);
+  const unsigned char *in_b = p.in;
+  const unsigned char *w_b = p.w;
   const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
   auto issue = [&](int kt) {
     const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + (kt % NST) * STAGE);
@@ -1643,15 +1749,15 @@ __global__ __launch_bounds__(256, 2) void conv_deep_kernel(const ConvParams p) {
     else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(1 * LPS) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   };
-  struct Frags { h8 x[2][MI], w[2][4]; };
+  struct Frags { i4 x[2][MI], w[2][4]; };
   auto read_frags = [&](int kt, Frags &f) {
     const unsigned char *sb = smem + (kt % NST) * STAGE;
 #pragma unroll
     for (int ks = 0; ks < 2; ks++) {
 #pragma unroll
-      for (int mi = 0; mi < MI; mi++) f.x[ks][mi] = *reinterpret_cast<const h8 *>(sb + xfo[ks] + mi * 16 * 128);
+      for (int mi = 0; mi < MI; mi++) f.x[ks][mi] = *reinterpret_cast<const i4 *>(sb + xfo[ks] + mi * 16 * 128);
 #pragma unroll
-      for (int ni = 0; ni < 4; ni++) f.w[ks][ni] = *reinterpret_cast<const h8 *>(sb + wfo[ks] + ni * 16 * 128);
+      for (int ni = 0; ni < 4; ni++) f.w[ks][ni] = *reinterpret_cast<const i4 *>(sb + wfo[ks] + ni * 16 * 128);
     }
   };
   // one K-step: the fragments of stage kt are already in `cur`; stage kt+1's are read into `nxt` under this step's MFMAs
@@ -1664,13 +1770,7 @@ __global__ __launch_bounds__(256, 2) void conv_deep_kernel(const ConvParams p) {
       if (kt + D < KT) issue(kt + D);  // reuses the buffer of stage kt-1
       read_frags(kt + 1, nxt);
     }
-#pragma unroll
-    for (int ks = 0; ks < 2; ks++)
-#pragma unroll
-      for (int ni = 0; ni < 4; ni++)
-#pragma unroll
-        for (int mi = 0; mi < MI; mi++)
-          acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(cur.w[ks][ni], cur.x[ks][mi], acc[ni][mi], 0, 0, 0);
+    mma_kstep<DT, 4, MI>(acc, cur.w, cur.x);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   };
 
@@ -1690,25 +1790,35 @@ __global__ __launch_bounds__(256, 2) void conv_deep_kernel(const ConvParams p) {
     step(kt + 1, fb, fa);
   }
   if (kt < KT) step(kt, fa, fb);
-  conv_epilogue<MI, 4>(p, acc, m0 + wm * (BM / 2), n0 + wn * 64, lane);
+  conv_epilogue<MI, 4, DT, ODT>(p, acc, m0 + wm * (BM / 2), n0 + wn * 64, lane);
 }
 
-// split-K reduction + the conv epilogue: out = relu(sum_s partial[s] + bias + res); thread = (pixel, 4 channels)
+// split-K reduction + the conv epilogue: out = relu(sum_s partial[s] * scale + bias + res); thread = (pixel, 8 channels)
 __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvParams p) {
-  const int nq = p.Cout / 4;
+  const int nq = p.Cout / 8;
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int rows = p.M - p.m_begin;
   if (i >= (size_t)rows * nq) return;
-  const int mr = (int)(i / nq), n = (int)(i - (size_t)mr * nq) * 4;
+  const int mr = (int)(i / nq), n = (int)(i - (size_t)mr * nq) * 8;
   const int m = p.m_begin + mr;
-  f4 a = *reinterpret_cast<const f4 *>(p.partial + (size_t)mr * p.Cout + n);
-  for (int sp = 1; sp < p.ksplit; sp++) {  // component-wise: no packed-f32 VALU ops in this library ("packed f32")
-    const f4 b = *reinterpret_cast<const f4 *>(p.partial + ((size_t)sp * rows + mr) * p.Cout + n);
-    a[0] += b[0]; a[1] += b[1]; a[2] += b[2]; a[3] += b[3];
+  float v[8];
+  {
+    const f4 a0 = *reinterpret_cast<const f4 *>(p.partial + (size_t)mr * p.Cout + n), a1 = *reinterpret_cast<const f4 *>(p.partial + (size_t)mr * p.Cout + n + 4);
+#pragma unroll
+    for (int e = 0; e < 4; e++) { v[e] = a0[e]; v[4 + e] = a1[e]; }
+  }
+  for (int sp = 1; sp < p.ksplit; sp++) {  // component-wise: no packed-f32 VALU ops in this library
+    const float *src = p.partial + ((size_t)sp * rows + mr) * p.Cout + n;
+    const f4 b0 = *reinterpret_cast<const f4 *>(src), b1 = *reinterpret_cast<const f4 *>(src + 4);
+#pragma unroll
+    for (int e = 0; e < 4; e++) { v[e] += b0[e]; v[4 + e] += b1[e]; }
   }
   const int grp = p.grp_rows ? m / p.grp_rows : 0;
-  float4 bv = *reinterpret_cast<const float4 *>(p.bias + grp * p.Cout + n);
-  float v0 = a[0] + bv.x, v1 = a[1] + bv.y, v2 = a[2] + bv.z, v3 = a[3] + bv.w;
+#pragma unroll
+  for (int e = 0; e < 8; e++) {
+    if (p.cscale) v[e] *= p.cscale[grp * p.Cout + n + e];
+    v[e] += p.bias[grp * p.Cout + n + e];
+  }
   const int ohw = p.OH * p.OW;
   int img = m / ohw;
   int rem = m - img * ohw;
@@ -1717,15 +1827,20 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvParam
   const int RHp = p.OH + 2 * p.rpad, RWp = p.OW + 2 * p.rpad;
   if (p.res) {
     size_t rpix = ((size_t)(img - (p.res_shared ? grp * p.grp_rows : 0)) * RHp + oh + p.rpad) * RWp + ow + p.rpad;
-    h4 r = *reinterpret_cast<const h4 *>(p.res + rpix * p.res_ld + n);
-    v0 += (float)r[0]; v1 += (float)r[1]; v2 += (float)r[2]; v3 += (float)r[3];
+    float r[8];
+    decode8(load8_raw(p.res + (rpix * p.res_ld + n) * elem_bytes(p.res_dt), p.res_dt), p.res_dt, r);
+#pragma unroll
+    for (int e = 0; e < 8; e++) v[e] += r[e] * p.res_scale;
   }
-  if (p.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+#pragma unroll
+  for (int e = 0; e < 8; e++) {
+    if (p.relu) v[e] = fmaxf(v[e], 0.f);
+    v[e] *= p.out_inv;
+  }
   int choff = 0, oimg = img;
   if (p.split_imgs > 0 && img >= p.split_imgs) { oimg = img - p.split_imgs; choff = p.Cout; }
   size_t opix = ((size_t)oimg * OHp + oh + p.opad) * OWp + ow + p.opad;
-  h4 o = {(_Float16)v0, (_Float16)v1, (_Float16)v2, (_Float16)v3};
-  *reinterpret_cast<h4 *>(p.out + opix * p.out_ld + choff + n) = o;
+  store8(p.out + (opix * p.out_ld + choff + n) * elem_bytes(p.out_dt), p.out_dt, v);
 }
 
 // =================================================================================================
@@ -1737,13 +1852,16 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvParam
 // measured 12 % slower: two waves of a workgroup share a SIMD).  The 1-D grid is remapped so the query
 // tiles of one (image, head) run on the SAME XCD and share its L2 copy of K/V (a (qt,h,b) grid spread them over all 8
 // XCDs: rocprofv3 FETCH_SIZE showed 1.16 GB fetched per launch for 0.31 GB of QKV).
-template <int ATT_QROWS, bool REMAP, bool PERM = true>
-__global__ __launch_bounds__(ATT_QROWS * 4, 2) void attention_kernel(const __half *__restrict__ qkv, __half *__restrict__ out, int T, int nq,
+template <int ATT_QROWS, bool REMAP, bool PERM, int DT>
+__global__ __launch_bounds__(ATT_QROWS * 4, 2) void attention_kernel(const typename ElemT<DT>::t *__restrict__ qkv, typename ElemT<DT>::t *__restrict__ out, int T, int nq,
                                                                  int tstride /* rows between the first tokens of consecutive sequences */) {
   constexpr int KS = 136;  // K tile row stride (halfs): 128 + 8 pad
   constexpr int VS = 40;   // V^T tile row stride (halfs): 32 keys + 8 pad
-  __shared__ __attribute__((aligned(16))) _Float16 Ks[32 * KS];
-  __shared__ __attribute__((aligned(16))) _Float16 Vt[HDIM * VS];
+  using E = typename ElemT<DT>::t;
+  using E8 = typename ElemT<DT>::v8;
+  using E4 = typename ElemT<DT>::v4;
+  __shared__ __attribute__((aligned(16))) E Ks[32 * KS];
+  __shared__ __attribute__((aligned(16))) E Vt[HDIM * VS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int logical;
   {
@@ -1754,13 +1872,13 @@ __global__ __launch_bounds__(ATT_QROWS * 4, 2) void attention_kernel(const __hal
   const int qt = logical % nq, h = (logical / nq) % HEADS, b = logical / (nq * HEADS);
   const int g = lane >> 4, li = lane & 15;
   const size_t rowstride = 3 * EMBED;
-  const __half *base = qkv + (size_t)b * tstride * rowstride;
+  const E *base = qkv + (size_t)b * tstride * rowstride;
   const int q_row = qt * ATT_QROWS + wave * 16 + li;
   const int q_ld = min(q_row, T - 1);
-  h8 qf[4];
+  E8 qf[4];
 #pragma unroll
   for (int ds = 0; ds < 4; ds++)
-    qf[ds] = *reinterpret_cast<const h8 *>(base + (size_t)q_ld * rowstride + h * HDIM + ds * 32 + g * 8);
+    qf[ds] = *reinterpret_cast<const E8 *>(base + (size_t)q_ld * rowstride + h * HDIM + ds * 32 + g * 8);
 
   f4 o[8];
 #pragma unroll
@@ -1773,16 +1891,16 @@ __global__ __launch_bounds__(ATT_QROWS * 4, 2) void attention_kernel(const __hal
   // chunk = idx>>5) so the 2-byte transposed LDS writes of one instruction cover 32 consecutive keys of one d row
   // (bank-conflict free; the previous key-major mapping was a 16-way conflict on every ds_write_b16).
   // (the first 4 waves stage; wave 4 only computes)
-  h8 kreg[2], vreg[2];
+  E8 kreg[2], vreg[2];
   auto load_tile = [&](int kb) {
     if (ATT_QROWS > 64 && tid >= 256) return;
 #pragma unroll
     for (int j = 0; j < 2; j++) {
       int idx = tid + j * 256;
       int krow = min(kb * 32 + (idx >> 4), T - 1);
-      kreg[j] = *reinterpret_cast<const h8 *>(base + (size_t)krow * rowstride + EMBED + h * HDIM + (idx & 15) * 8);
+      kreg[j] = *reinterpret_cast<const E8 *>(base + (size_t)krow * rowstride + EMBED + h * HDIM + (idx & 15) * 8);
       int vrow = min(kb * 32 + (idx & 31), T - 1);
-      vreg[j] = *reinterpret_cast<const h8 *>(base + (size_t)vrow * rowstride + 2 * EMBED + h * HDIM + (idx >> 5) * 8);
+      vreg[j] = *reinterpret_cast<const E8 *>(base + (size_t)vrow * rowstride + 2 * EMBED + h * HDIM + (idx >> 5) * 8);
     }
   };
   load_tile(0);
@@ -1791,7 +1909,7 @@ __global__ __launch_bounds__(ATT_QROWS * 4, 2) void attention_kernel(const __hal
 #pragma unroll
       for (int j = 0; j < 2; j++) {
         int idx = tid + j * 256;
-        *reinterpret_cast<h8 *>(&Ks[(idx >> 4) * KS + (idx & 15) * 8]) = kreg[j];
+        *reinterpret_cast<E8 *>(&Ks[(idx >> 4) * KS + (idx & 15) * 8]) = kreg[j];
         int key = idx & 31, chunk = idx >> 5;
         // V^T row e*16 + chunk holds d = chunk*8 + e, so MFMA column li of tile dt is d = li*8 + dt and a lane ends up
         // owning 8 consecutive d (one 16-byte output store per query row)
@@ -1808,8 +1926,8 @@ __global__ __launch_bounds__(ATT_QROWS * 4, 2) void attention_kernel(const __hal
       st[kt] = (f4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ds = 0; ds < 4; ds++) {
-        h8 kf = *reinterpret_cast<const h8 *>(&Ks[(kt * 16 + li) * KS + ds * 32 + g * 8]);
-        st[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[ds], st[kt], 0, 0, 0);
+        E8 kf = *reinterpret_cast<const E8 *>(&Ks[(kt * 16 + li) * KS + ds * 32 + g * 8]);
+        st[kt] = mfma32<DT>(__builtin_bit_cast(i4, kf), __builtin_bit_cast(i4, qf[ds]), st[kt]);
       }
     }
     // softmax in base 2 on the RAW scores: p = exp2(s*c - m*c), c = scale*log2(e) -- one fma + one v_exp per score; the
@@ -1829,14 +1947,14 @@ __global__ __launch_bounds__(ATT_QROWS * 4, 2) void attention_kernel(const __hal
     const float mc = m_new * sl2e;
     const float alpha = __builtin_amdgcn_exp2f(m_run * sl2e - mc);  // m_run = -inf on the first block -> 0
     float psum = 0.f;
-    h8 pf;
+    E8 pf;
 #pragma unroll
     for (int kt = 0; kt < 2; kt++)
 #pragma unroll
       for (int r = 0; r < 4; r++) {
         float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(st[kt][r], sl2e, -mc));
         psum += pv;
-        pf[kt * 4 + r] = (_Float16)pv;
+        pf[kt * 4 + r] = (E)pv;
       }
     psum += __shfl_xor(psum, 16);
     psum += __shfl_xor(psum, 32);
@@ -1858,10 +1976,10 @@ __global__ __launch_bounds__(ATT_QROWS * 4, 2) void attention_kernel(const __hal
 #pragma unroll
     for (int dt = 0; dt < 8; dt++) {
       // V^T fragment: col li of tile dt is d = li*8 + dt; k-slots 0..3 -> keys g*4.., 4..7 -> keys 16+g*4..
-      h4 v0 = *reinterpret_cast<const h4 *>(&Vt[(dt * 16 + li) * VS + g * 4]);
-      h4 v1 = *reinterpret_cast<const h4 *>(&Vt[(dt * 16 + li) * VS + 16 + g * 4]);
-      h8 vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-      o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pf, vf, o[dt], 0, 0, 0);
+      E4 v0 = *reinterpret_cast<const E4 *>(&Vt[(dt * 16 + li) * VS + g * 4]);
+      E4 v1 = *reinterpret_cast<const E4 *>(&Vt[(dt * 16 + li) * VS + 16 + g * 4]);
+      E8 vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+      o[dt] = mfma32<DT>(__builtin_bit_cast(i4, pf), __builtin_bit_cast(i4, vf), o[dt]);
     }
     __syncthreads();
   }
@@ -1873,14 +1991,14 @@ __global__ __launch_bounds__(ATT_QROWS * 4, 2) void attention_kernel(const __hal
     int row = qt * ATT_QROWS + wave * 16 + g * 4 + r;
     if (row >= T) continue;
     if (PERM) {
-      h8 ov;
+      E8 ov;
 #pragma unroll
-      for (int dt = 0; dt < 8; dt++) ov[dt] = (_Float16)(o[dt][r] * lr[r]);
-      *reinterpret_cast<h8 *>(out + ((size_t)b * tstride + row) * EMBED + h * HDIM + li * 8) = ov;
+      for (int dt = 0; dt < 8; dt++) ov[dt] = (E)(o[dt][r] * lr[r]);
+      *reinterpret_cast<E8 *>(out + ((size_t)b * tstride + row) * EMBED + h * HDIM + li * 8) = ov;
     } else {
-      __half *dst = out + ((size_t)b * tstride + row) * EMBED + h * HDIM + li;
+      E *dst = out + ((size_t)b * tstride + row) * EMBED + h * HDIM + li;
 #pragma unroll
-      for (int dt = 0; dt < 8; dt++) dst[dt * 16] = __float2half(o[dt][r] * lr[r]);
+      for (int dt = 0; dt < 8; dt++) dst[dt * 16] = (E)(o[dt][r] * lr[r]);
     }
   }
 }
@@ -1890,28 +2008,35 @@ __global__ __launch_bounds__(ATT_QROWS * 4, 2) void attention_kernel(const __hal
 // =================================================================================================
 
 // x[b,t,:] += pe[t,:]  (rows = B*T, 512 channels, 8 halfs per thread)
-__global__ void add_pos_embed_kernel(__half *__restrict__ x, const __half *__restrict__ pe, int T, size_t rows) {
+template <int DT>
+__global__ void add_pos_embed_kernel(typename ElemT<DT>::t *__restrict__ x, const typename ElemT<DT>::t *__restrict__ pe, int T, size_t rows) {
+  using E8 = typename ElemT<DT>::v8;
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // 16-B chunk index
   if (i >= rows * (EMBED / 8)) return;
   size_t row = i / (EMBED / 8);
   int c = (int)(i - row * (EMBED / 8));
   int t = (int)(row % T);
-  h8 a = reinterpret_cast<const h8 *>(x)[i];
-  h8 pv = reinterpret_cast<const h8 *>(pe)[(size_t)t * (EMBED / 8) + c];
-  reinterpret_cast<h8 *>(x)[i] = a + pv;
+  E8 a = reinterpret_cast<const E8 *>(x)[i];
+  E8 pv = reinterpret_cast<const E8 *>(pe)[(size_t)t * (EMBED / 8) + c];
+  E8 r;
+#pragma unroll
+  for (int e = 0; e < 8; e++) r[e] = (typename ElemT<DT>::t)((float)a[e] + (float)pv[e]);
+  reinterpret_cast<E8 *>(x)[i] = r;
 }
 
 // y = LayerNorm(x) over 512 channels, eps 1e-5; one wave per row
 // rows >= split_row use (gamma1, beta1): the refiner's two heads normalised in one launch
-__global__ __launch_bounds__(256) void layernorm_kernel(const __half *__restrict__ x, const float *__restrict__ gamma0,
-                                                        const float *__restrict__ beta0, __half *__restrict__ y, size_t rows,
+template <int DT>
+__global__ __launch_bounds__(256) void layernorm_kernel(const typename ElemT<DT>::t *__restrict__ x, const float *__restrict__ gamma0,
+                                                        const float *__restrict__ beta0, typename ElemT<DT>::t *__restrict__ y, size_t rows,
                                                         const float *__restrict__ gamma1, const float *__restrict__ beta1,
                                                         size_t split_row) {
   size_t row = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   int lane = threadIdx.x & 63;
   if (row >= rows) return;
   const float *gamma = row >= split_row ? gamma1 : gamma0, *beta = row >= split_row ? beta1 : beta0;
-  h8 v = reinterpret_cast<const h8 *>(x + row * EMBED)[lane];
+  using E8 = typename ElemT<DT>::v8;
+  E8 v = reinterpret_cast<const E8 *>(x + row * EMBED)[lane];
   float f[8], s = 0.f;
 #pragma unroll
   for (int e = 0; e < 8; e++) { f[e] = (float)v[e]; s += f[e]; }
@@ -1923,10 +2048,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const __half *__restrict
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
   float rstd = rsqrtf(q * (1.0f / EMBED) + 1e-5f);
-  h8 r;
+  E8 r;
 #pragma unroll
-  for (int e = 0; e < 8; e++) r[e] = (_Float16)(f[e] * rstd * gamma[lane * 8 + e] + beta[lane * 8 + e]);
-  reinterpret_cast<h8 *>(y + row * EMBED)[lane] = r;
+  for (int e = 0; e < 8; e++) r[e] = (typename ElemT<DT>::t)(f[e] * rstd * gamma[lane * 8 + e] + beta[lane * 8 + e]);
+  reinterpret_cast<E8 *>(y + row * EMBED)[lane] = r;
 }
 
 // out[b,c] = mean_t x[b,t,c]  (f32 out).  Deterministic (no atomics: the arg-max over near-tied scores must not depend
@@ -1934,16 +2059,18 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const __half *__restrict
 // tokens per load and walks the sequence in strides of 32 tokens (13 dependent steps for T = 400 instead of 100: at
 // N = 1 this kernel was 30 us of a 570 us Track); the 8 token slots combine through shfl_xor, the 4 waves through LDS,
 // both in a fixed order.
-__global__ __launch_bounds__(256) void token_mean_kernel(const __half *__restrict__ x, float *__restrict__ out, int T, int tstride) {
+template <int DT>
+__global__ __launch_bounds__(256) void token_mean_kernel(const typename ElemT<DT>::t *__restrict__ x, float *__restrict__ out, int T, int tstride) {
+  using E8 = typename ElemT<DT>::v8;
   __shared__ float part[4][64];
   const int b = blockIdx.x, cg = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int slot = lane >> 3, c8 = (lane & 7) * 8;
-  const __half *src = x + (size_t)b * tstride * EMBED + cg * 64 + c8;
+  const typename ElemT<DT>::t *src = x + (size_t)b * tstride * EMBED + cg * 64 + c8;
   float s[8];
 #pragma unroll
   for (int e = 0; e < 8; e++) s[e] = 0.f;
   for (int t = wave * 8 + slot; t < T; t += 32) {
-    h8 v = *reinterpret_cast<const h8 *>(src + (size_t)t * EMBED);
+    E8 v = *reinterpret_cast<const E8 *>(src + (size_t)t * EMBED);
 #pragma unroll
     for (int e = 0; e < 8; e++) s[e] += (float)v[e];
   }
@@ -1976,11 +2103,11 @@ __global__ __launch_bounds__(256) void small_linear_kernel(const float *__restri
   if (lane == 0) y[widx] = s + bias[o];
 }
 
-// cat[i][:, :, C:2C] = cat[0][:, :, C:2C] for i in 1..N-1 (bordered [N,HP,WP,2C] tensor, interior pixels only).
-// Used when every hypothesis shares one observed crop (Register's first refine iteration: the sampler gives all 252
-// poses the same translation, foundationpose_sampling.cpp:388-391, so transf_input is identical for all of them).
-__global__ void broadcast_b_kernel(__half *__restrict__ cat, int N, int HP, int WP, int H, int W, int pad, int C) {
-  const int chunks = C / 8;
+// cat[i][:, :, C:2C] = cat[0][:, :, C:2C] for i in 1..N-1 (bordered [N,HP,WP,2C] tensor, interior pixels only); CB = bytes
+// of C channels.  Used when every hypothesis shares one observed crop (Register's first refine iteration: the sampler
+// gives all 252 poses the same translation, foundationpose_sampling.cpp:388-391, so transf_input is identical for all of them).
+__global__ void broadcast_b_kernel(unsigned char *__restrict__ cat, int N, int HP, int WP, int H, int W, int pad, int CB) {
+  const int chunks = CB / 16;
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   size_t per_img = (size_t)H * W * chunks;
   if (i >= per_img * (size_t)(N - 1)) return;
@@ -1988,14 +2115,15 @@ __global__ void broadcast_b_kernel(__half *__restrict__ cat, int N, int HP, int 
   size_t r = i - (size_t)(img - 1) * per_img;
   int pix = (int)(r / chunks), ch = (int)(r - (size_t)pix * chunks);
   int y = pix / W, x = pix - y * W;
-  size_t off = (((size_t)(y + pad)) * WP + (x + pad)) * (2 * C) + C + ch * 8;
-  const size_t img_stride = (size_t)HP * WP * 2 * C;
-  *reinterpret_cast<h8 *>(cat + (size_t)img * img_stride + off) = *reinterpret_cast<const h8 *>(cat + off);
+  size_t off = (((size_t)(y + pad)) * WP + (x + pad)) * (2 * CB) + CB + ch * 16;
+  const size_t img_stride = (size_t)HP * WP * 2 * CB;
+  *reinterpret_cast<i4 *>(cat + (size_t)img * img_stride + off) = *reinterpret_cast<const i4 *>(cat + off);
 }
 
-__global__ void cast_f32_f16_kernel(const float *__restrict__ in, __half *__restrict__ out, size_t n) {
+template <int DT>
+__global__ void cast_f32_kernel(const float *__restrict__ in, typename ElemT<DT>::t *__restrict__ out, size_t n) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) out[i] = __float2half(in[i]);
+  if (i < n) out[i] = (typename ElemT<DT>::t)in[i];
 }
 
 // =================================================================================================
@@ -2012,19 +2140,20 @@ static bool read_fpw(const char *path, std::map<std::string, HostTensor> &out, s
   if (!f) { *err = std::string("cannot open ") + path; return false; }
   char magic[4];
   uint32_t n = 0;
-  bool ok = std::fread(magic, 1, 4, f) == 4 && std::memcmp(magic, "FPW1", 4) == 0 && std::fread(&n, 4, 1, f) == 1;
+  bool ok = std::fread(magic, 1, 4, f) == 4 && std::memcmp(magic, "FPW1", 4) == 0 && std::fread(&n, 4, 1, f) == 1 && n <= 4096;
   for (uint32_t i = 0; ok && i < n; i++) {
     uint32_t ln = 0, nd = 0;
     ok = std::fread(&ln, 4, 1, f) == 1 && ln < 4096;
-    std::string name(ln, '\0');
+    std::string name(ok ? ln : 0, '\0');
     ok = ok && std::fread(&name[0], 1, ln, f) == ln && std::fread(&nd, 4, 1, f) == 1 && nd <= 8;
     HostTensor t;
     size_t cnt = 1;
     for (uint32_t d = 0; ok && d < nd; d++) {
       uint32_t s = 0;
-      ok = std::fread(&s, 4, 1, f) == 1;
+      ok = std::fread(&s, 4, 1, f) == 1 && s <= (1u << 24);
       t.shape.push_back((int)s);
       cnt *= s;
+      ok = ok && cnt <= ((size_t)1 << 28);  // no tensor of these networks exceeds 2^28 elements: a corrupt header must not drive a huge allocation
     }
     uint64_t nbytes = 0;
     ok = ok && std::fread(&nbytes, 8, 1, f) == 1 && nbytes == cnt * 4;
@@ -2040,8 +2169,11 @@ static bool read_fpw(const char *path, std::map<std::string, HostTensor> &out, s
 }
 
 struct ConvLayer {
-  __half *w = nullptr;
+  unsigned char *w = nullptr;  // kernel layout, element type dt
   float *bias = nullptr;
+  float *wscale = nullptr;     // FP8: [Cout] per-output-channel weight scale (w_real = w_stored * wscale)
+  float *cscale = nullptr;     // FP8: [Cout] input activation scale * wscale (net_set_fp8_scales)
+  int dt = DT_F16;
   int Cin = 0, Cout = 0, KH = 0, KW = 0, stride = 1, pad = 0;
   int algo_K = 0;  // algorithmic reduction length for FLOP accounting (the s2d stem pads 7x7x6=294 to 512)
 };
@@ -2063,8 +2195,14 @@ struct EncLayer {  // transformer encoder layer (refiner heads)
   LinearF32 head;
 };
 
+// trunk activation ids (FP8 scales / calibration): 0 stem, 1 a1, 2..5 encodeA blocks, 6..9 encodeAB 256 blocks, 10 b2,
+// 11..14 encodeAB 512 blocks (14 = the token tensor, never quantised)
+static constexpr int N_TRUNK_ACT = 15;
+
 struct Net {
   bool scorer = false;
+  int prec = PREC_F16;
+  int act_dt = DT_F16;               // element type of nn_in, of the token path and (non-FP8) of the trunk activations
   ConvLayer a0, a1, ra[2][2];        // encodeA
   ConvLayer rb[2][2], b2, rc[2][2];  // encodeAB
   EncLayer trans, rot;               // refiner
@@ -2072,7 +2210,13 @@ struct Net {
   ConvLayer g_in_proj, g_out_proj, g_lin1, g_lin2;
   MHA att, att_cross;                // scorer
   LinearF32 score_lin;
-  __half *pe = nullptr;     // [400,512]
+  void *pe = nullptr;                // [400,512], act_dt
+  // FP8: per-tensor activation scales (real = stored * scale) of the trunk, set by net_set_fp8_scales
+  bool fp8_ready = false;
+  float act_scale[N_TRUNK_ACT];
+  // calibration (2-byte nets): per-activation |max| collected on the device while the trunk runs
+  float *calib_dev = nullptr;
+  bool calib_on = false;
   std::vector<void *> allocs;
   ~Net() {
     for (void *p : allocs) (void)hipFree(p);
@@ -2088,17 +2232,68 @@ static T *upload(Net *net, const std::vector<T> &h) {
   return d;
 }
 
+// ---- host-side element conversion (round to nearest even) ----
+static uint16_t f32_to_bf16_bits(float x) {
+  uint32_t u;
+  std::memcpy(&u, &x, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);  // NaN stays NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+// OCP FP8 e4m3fn: 1-4-3, bias 7, max 448, no infinities; saturating
+static uint8_t f32_to_e4m3_bits(float x) {
+  const uint8_t sign = std::signbit(x) ? 0x80 : 0;
+  const float a = std::fabs(x);
+  if (!(a == a)) return (uint8_t)(sign | 0x7f);
+  if (a >= 448.f) return (uint8_t)(sign | 0x7e);
+  if (a < 0x1p-10f) return sign;  // below half of the smallest subnormal (2^-9)
+  int e;
+  (void)std::frexp(a, &e);
+  int E = e - 1;  // a in [2^E, 2^(E+1))
+  if (E < -6) {   // subnormal: quantum 2^-9
+    const int r = (int)std::nearbyint(a * 512.f);
+    return (uint8_t)(sign | (r >= 8 ? 0x08 : r));
+  }
+  int r = (int)std::nearbyint(std::ldexp(a, 3 - E));  // 8..16
+  if (r == 16) { r = 8; E++; }
+  if (E > 8 || (E == 8 && r > 14)) return (uint8_t)(sign | 0x7e);
+  return (uint8_t)(sign | ((E + 7) << 3) | (r - 8));
+}
+// rows of `K` floats -> kernel element bytes; FP8 rows are divided by their own scale (amax / 448) first
+static std::vector<unsigned char> to_elems(const std::vector<float> &w, int rows, int K, int dt, std::vector<float> *row_scale) {
+  const int es = elem_bytes(dt);
+  std::vector<unsigned char> o((size_t)rows * K * es);
+  if (row_scale) row_scale->assign(rows, 1.f);
+  for (int r = 0; r < rows; r++) {
+    const float *src = &w[(size_t)r * K];
+    if (dt == DT_FP8) {
+      float amax = 0.f;
+      for (int k = 0; k < K; k++) amax = std::max(amax, std::fabs(src[k]));
+      const float sc = amax > 0.f ? amax / 448.f : 1.f;
+      if (row_scale) (*row_scale)[r] = sc;
+      for (int k = 0; k < K; k++) o[(size_t)r * K + k] = f32_to_e4m3_bits(src[k] / sc);
+    } else {
+      uint16_t *dst = reinterpret_cast<uint16_t *>(&o[(size_t)r * K * 2]);
+      for (int k = 0; k < K; k++) {
+        if (dt == DT_BF16) dst[k] = f32_to_bf16_bits(src[k]);
+        else { __half h = __float2half(src[k]); std::memcpy(&dst[k], &h, 2); }
+      }
+    }
+  }
+  return o;
+}
+
 // [a | b] device copy of two equally shaped Linear layers (weights already in kernel row order)
 static bool make_grouped(Net *net, const ConvLayer &a, const ConvLayer &b, ConvLayer *g) {
-  if (a.Cin != b.Cin || a.Cout != b.Cout) return false;
-  const size_t nw = (size_t)a.Cout * a.Cin, nb = (size_t)a.Cout;
-  __half *w = nullptr;
+  if (a.Cin != b.Cin || a.Cout != b.Cout || a.dt != b.dt) return false;
+  const size_t nw = (size_t)a.Cout * a.Cin * elem_bytes(a.dt), nb = (size_t)a.Cout;
+  unsigned char *w = nullptr;
   float *bias = nullptr;
-  if (hipMalloc((void **)&w, 2 * nw * sizeof(__half)) != hipSuccess) return false;
+  if (hipMalloc((void **)&w, 2 * nw) != hipSuccess) return false;
   net->allocs.push_back(w);
   if (hipMalloc((void **)&bias, 2 * nb * sizeof(float)) != hipSuccess) return false;
   net->allocs.push_back(bias);
-  if (hipMemcpy(w, a.w, nw * 2, hipMemcpyDeviceToDevice) != hipSuccess || hipMemcpy(w + nw, b.w, nw * 2, hipMemcpyDeviceToDevice) != hipSuccess ||
+  if (hipMemcpy(w, a.w, nw, hipMemcpyDeviceToDevice) != hipSuccess || hipMemcpy(w + nw, b.w, nw, hipMemcpyDeviceToDevice) != hipSuccess ||
       hipMemcpy(bias, a.bias, nb * 4, hipMemcpyDeviceToDevice) != hipSuccess || hipMemcpy(bias + nb, b.bias, nb * 4, hipMemcpyDeviceToDevice) != hipSuccess)
     return false;
   *g = a;
@@ -2113,61 +2308,79 @@ static bool get(const std::map<std::string, HostTensor> &m, const std::string &n
   *t = &it->second;
   return true;
 }
+static bool shape_is(const HostTensor *t, std::initializer_list<int> want) { return t->shape == std::vector<int>(want); }
 
-// [Cout][tap][Cin] -> kernel K order: for Cin >= 64 [Cout][Cin/64][tap][64], otherwise unchanged
-static std::vector<__half> relayout_k(const std::vector<__half> &w, int Cout, int ntaps, int Cin) {
+// [Cout][tap][Cin] -> kernel K order: for Cin >= 64 [Cout][Cin/CH][tap][CH] with CH = the channels of a 128-byte chunk (64
+// for the 2-byte types, 128 for FP8), otherwise unchanged.  `es` = element bytes.
+static std::vector<unsigned char> relayout_k(const std::vector<unsigned char> &w, int Cout, int ntaps, int Cin, int es) {
+  const int CH = 128 / es;
   if (Cin < 64 || ntaps == 1) return w;
-  std::vector<__half> o(w.size());
-  const int nch = Cin / 64;
+  std::vector<unsigned char> o(w.size());
+  const int nch = Cin / CH;
   for (int co = 0; co < Cout; co++)
     for (int t = 0; t < ntaps; t++)
-      for (int ci = 0; ci < Cin; ci++)
-        o[(((size_t)co * nch + ci / 64) * ntaps + t) * 64 + (ci % 64)] = w[((size_t)co * ntaps + t) * Cin + ci];
+      for (int c0 = 0; c0 < nch; c0++)
+        std::memcpy(&o[((((size_t)co * nch + c0) * ntaps + t) * CH) * es], &w[(((size_t)co * ntaps + t) * Cin + (size_t)c0 * CH) * es], (size_t)CH * es);
   return o;
 }
 
 // Row permutation matching conv_epilogue: inside every block of 16*NI output channels (NI = 4, or 2 when Cout == 64)
 // kernel row ni*16 + 4g + j holds the weights of channel 32*(j>>1) + 8g + 4*(j&1) + ni (NI=4) / 8g + 2j + ni (NI=2).
-static std::vector<__half> permute_rows(const std::vector<__half> &w, int Cout, int K) {
+static std::vector<unsigned char> permute_rows(const std::vector<unsigned char> &w, int Cout, size_t row_bytes) {
   const int NI = (Cout % 128 == 0) ? 4 : 2, blk = 16 * NI;
-  std::vector<__half> o(w.size());
+  std::vector<unsigned char> o(w.size());
   for (int b0 = 0; b0 < Cout; b0 += blk)
     for (int ni = 0; ni < NI; ni++)
       for (int g = 0; g < 4; g++)
         for (int j = 0; j < 4; j++) {
           int ch = (NI == 4) ? 32 * (j >> 1) + 8 * g + 4 * (j & 1) + ni : 8 * g + 2 * j + ni;
-          std::memcpy(&o[(size_t)(b0 + ni * 16 + 4 * g + j) * K], &w[(size_t)(b0 + ch) * K], (size_t)K * sizeof(__half));
+          std::memcpy(&o[(size_t)(b0 + ni * 16 + 4 * g + j) * row_bytes], &w[(size_t)(b0 + ch) * row_bytes], row_bytes);
         }
   return o;
 }
 
-// PyTorch conv weight [Cout,Cin,KH,KW] -> [Cout][KH][KW][Cin] fp16 -> kernel K order
-static bool make_conv(Net *net, const std::map<std::string, HostTensor> &m, const std::string &prefix, int stride,
-                      ConvLayer *L, std::string *err) {
+// [Cout][KH][KW][Cin] f32 rows -> device layer of element type dt
+static bool finish_layer(Net *net, const std::vector<float> &rows_f32, const std::vector<float> &bias, int Cout, int ntaps, int Cin,
+                         int dt, ConvLayer *L) {
+  const int K = ntaps * Cin, es = elem_bytes(dt);
+  std::vector<float> rs;
+  auto elems = to_elems(rows_f32, Cout, K, dt, &rs);
+  L->w = upload(net, permute_rows(relayout_k(elems, Cout, ntaps, Cin, es), Cout, (size_t)K * es));
+  L->bias = upload(net, bias);
+  L->dt = dt;
+  if (dt == DT_FP8) {
+    L->wscale = upload(net, rs);
+    L->cscale = upload(net, rs);  // activation scale 1 until net_set_fp8_scales
+    if (!L->wscale || !L->cscale) return false;
+  }
+  return L->w && L->bias;
+}
+
+// PyTorch conv weight [Cout,Cin,KH,KW] -> kernel layout; the layer must have exactly the expected shape (the kernels and
+// the arena carve hard-code the architecture: a foreign file is a load error, not an out-of-bounds launch)
+static bool make_conv(Net *net, const std::map<std::string, HostTensor> &m, const std::string &prefix, int stride, int Cout,
+                      int Cin, int k, int dt, ConvLayer *L, std::string *err) {
   const HostTensor *w, *b;
   if (!get(m, prefix + ".weight", &w, err) || !get(m, prefix + ".bias", &b, err)) return false;
-  if (w->shape.size() != 4) { *err = prefix + ": expected 4-d conv weight"; return false; }
-  int Co = w->shape[0], Ci = w->shape[1], KH = w->shape[2], KW = w->shape[3];
-  std::vector<__half> hw((size_t)Co * KH * KW * Ci);
-  for (int co = 0; co < Co; co++)
-    for (int ci = 0; ci < Ci; ci++)
-      for (int kh = 0; kh < KH; kh++)
-        for (int kw = 0; kw < KW; kw++)
-          hw[(((size_t)co * KH + kh) * KW + kw) * Ci + ci] = __float2half(w->data[(((size_t)co * Ci + ci) * KH + kh) * KW + kw]);
-  L->w = upload(net, permute_rows(relayout_k(hw, Co, KH * KW, Ci), Co, KH * KW * Ci));
-  L->bias = upload(net, b->data);
-  L->Cin = Ci; L->Cout = Co; L->KH = KH; L->KW = KW; L->stride = stride; L->pad = (KH - 1) / 2;
-  return L->w && L->bias;
+  if (!shape_is(w, {Cout, Cin, k, k}) || !shape_is(b, {Cout})) { *err = prefix + ": unexpected weight / bias shape"; return false; }
+  std::vector<float> hw((size_t)Cout * k * k * Cin);
+  for (int co = 0; co < Cout; co++)
+    for (int ci = 0; ci < Cin; ci++)
+      for (int kh = 0; kh < k; kh++)
+        for (int kw = 0; kw < k; kw++)
+          hw[(((size_t)co * k + kh) * k + kw) * Cin + ci] = w->data[(((size_t)co * Cin + ci) * k + kh) * k + kw];
+  L->Cin = Cin; L->Cout = Cout; L->KH = k; L->KW = k; L->stride = stride; L->pad = (k - 1) / 2;
+  return finish_layer(net, hw, b->data, Cout, k * k, Cin, dt, L);
 }
 
 // 7x7 stride-2 pad-3 stem on [.,160,160,6] == 4x4 stride-1 pad-2 conv on the space-to-depth input [.,80,80,32]:
 // w_s2d[co][a][b][(dy*2+dx)*8 + c] = w[co][c][2a+dy-1][2b+dx-1] (zero outside the 7x7 support / for c >= 6)
-static bool make_stem(Net *net, const std::map<std::string, HostTensor> &m, const std::string &prefix, ConvLayer *L,
+static bool make_stem(Net *net, const std::map<std::string, HostTensor> &m, const std::string &prefix, int dt, ConvLayer *L,
                       std::string *err) {
   const HostTensor *w, *b;
   if (!get(m, prefix + ".weight", &w, err) || !get(m, prefix + ".bias", &b, err)) return false;
-  if (w->shape != std::vector<int>({64, 6, 7, 7})) { *err = prefix + ": expected [64,6,7,7] stem weight"; return false; }
-  std::vector<__half> hw((size_t)64 * 16 * 32, __float2half(0.f));
+  if (!shape_is(w, {64, 6, 7, 7}) || !shape_is(b, {64})) { *err = prefix + ": expected [64,6,7,7] stem weight"; return false; }
+  std::vector<float> hw((size_t)64 * 16 * 32, 0.f);
   for (int co = 0; co < 64; co++)
     for (int a = 0; a < 4; a++)
       for (int bb = 0; bb < 4; bb++)
@@ -2176,36 +2389,30 @@ static bool make_stem(Net *net, const std::map<std::string, HostTensor> &m, cons
             int kh = 2 * a + dy - 1, kw = 2 * bb + dx - 1;
             if (kh < 0 || kw < 0) continue;
             for (int c = 0; c < 6; c++)
-              hw[(((size_t)co * 4 + a) * 4 + bb) * 32 + (dy * 2 + dx) * 8 + c] =
-                  __float2half(w->data[(((size_t)co * 6 + c) * 7 + kh) * 7 + kw]);
+              hw[(((size_t)co * 4 + a) * 4 + bb) * 32 + (dy * 2 + dx) * 8 + c] = w->data[(((size_t)co * 6 + c) * 7 + kh) * 7 + kw];
           }
-  L->w = upload(net, permute_rows(hw, 64, 16 * 32));
-  L->bias = upload(net, b->data);
   L->Cin = 32; L->Cout = 64; L->KH = 4; L->KW = 4; L->stride = 1; L->pad = 2; L->algo_K = 7 * 7 * 6;
-  return L->w && L->bias;
+  return finish_layer(net, hw, b->data, 64, 16, 32, dt, L);
 }
 
-// Linear [out,in] as a 1x1 conv; rows [r0, r0+rows) of the weight
+// Linear [out,in] as a 1x1 conv
 static bool make_linear_conv(Net *net, const std::map<std::string, HostTensor> &m, const std::string &wname,
-                             const std::string &bname, ConvLayer *L, std::string *err) {
+                             const std::string &bname, int out, int in, int dt, ConvLayer *L, std::string *err) {
   const HostTensor *w, *b;
   if (!get(m, wname, &w, err) || !get(m, bname, &b, err)) return false;
-  if (w->shape.size() != 2) { *err = wname + ": expected 2-d weight"; return false; }
-  std::vector<__half> hw(w->data.size());
-  for (size_t i = 0; i < hw.size(); i++) hw[i] = __float2half(w->data[i]);
-  L->w = upload(net, permute_rows(hw, w->shape[0], w->shape[1]));
-  L->bias = upload(net, b->data);
-  L->Cout = w->shape[0]; L->Cin = w->shape[1]; L->KH = L->KW = 1; L->stride = 1; L->pad = 0;
-  return L->w && L->bias;
+  if (!shape_is(w, {out, in}) || !shape_is(b, {out})) { *err = wname + ": unexpected Linear shape"; return false; }
+  L->Cout = out; L->Cin = in; L->KH = L->KW = 1; L->stride = 1; L->pad = 0;
+  return finish_layer(net, w->data, b->data, out, 1, in, dt, L);
 }
 
 static bool make_linear_f32(Net *net, const std::map<std::string, HostTensor> &m, const std::string &wname,
-                            const std::string &bname, LinearF32 *L, std::string *err) {
+                            const std::string &bname, int out, int in, LinearF32 *L, std::string *err) {
   const HostTensor *w, *b;
   if (!get(m, wname, &w, err) || !get(m, bname, &b, err)) return false;
+  if (!shape_is(w, {out, in}) || !shape_is(b, {out})) { *err = wname + ": unexpected Linear shape"; return false; }
   L->w = upload(net, w->data);
   L->b = upload(net, b->data);
-  L->out = w->shape[0]; L->in = w->shape[1];
+  L->out = out; L->in = in;
   return L->w && L->b;
 }
 
@@ -2213,42 +2420,50 @@ static bool make_ln(Net *net, const std::map<std::string, HostTensor> &m, const 
                     std::string *err) {
   const HostTensor *w, *b;
   if (!get(m, prefix + ".weight", &w, err) || !get(m, prefix + ".bias", &b, err)) return false;
+  if (!shape_is(w, {EMBED}) || !shape_is(b, {EMBED})) { *err = prefix + ": unexpected LayerNorm shape"; return false; }
   L->g = upload(net, w->data);
   L->b = upload(net, b->data);
   return L->g && L->b;
 }
 
-static bool make_mha(Net *net, const std::map<std::string, HostTensor> &m, const std::string &prefix, MHA *a,
+static bool make_mha(Net *net, const std::map<std::string, HostTensor> &m, const std::string &prefix, int dt, MHA *a,
                      std::string *err) {
-  return make_linear_conv(net, m, prefix + ".in_proj_weight", prefix + ".in_proj_bias", &a->in_proj, err) &&
-         make_linear_conv(net, m, prefix + ".out_proj.weight", prefix + ".out_proj.bias", &a->out_proj, err) &&
-         make_linear_f32(net, m, prefix + ".out_proj.weight", prefix + ".out_proj.bias", &a->out_proj_f32, err);
+  return make_linear_conv(net, m, prefix + ".in_proj_weight", prefix + ".in_proj_bias", 3 * EMBED, EMBED, dt, &a->in_proj, err) &&
+         make_linear_conv(net, m, prefix + ".out_proj.weight", prefix + ".out_proj.bias", EMBED, EMBED, dt, &a->out_proj, err) &&
+         make_linear_f32(net, m, prefix + ".out_proj.weight", prefix + ".out_proj.bias", EMBED, EMBED, &a->out_proj_f32, err);
 }
 
-Net *net_load(const char *path, bool is_scorer, std::string *err) {
+static Net *net_load_impl(const char *path, bool is_scorer, int prec, std::string *err) {
   std::map<std::string, HostTensor> m;
   if (!read_fpw(path, m, err)) return nullptr;
   std::unique_ptr<Net> net(new Net());
   net->scorer = is_scorer;
-  bool ok = make_stem(net.get(), m, "encodeA.0", &net->a0, err) && make_conv(net.get(), m, "encodeA.1", 2, &net->a1, err);
+  net->prec = prec;
+  // PREC_FP8: the 3x3 trunk convolutions from encodeA.2 on (91 % of the FLOPs) run on FP8 operands; the stem and encodeA.1
+  // (bandwidth-bound, K = 294 / 576) and the transformer part stay in f16
+  const int adt = prec == PREC_BF16 ? DT_BF16 : DT_F16;
+  const int tdt = prec == PREC_FP8 ? DT_FP8 : adt;
+  net->act_dt = adt;
+  for (int i = 0; i < N_TRUNK_ACT; i++) net->act_scale[i] = 1.f;
+  bool ok = make_stem(net.get(), m, "encodeA.0", adt, &net->a0, err) && make_conv(net.get(), m, "encodeA.1", 2, 128, 64, 3, adt, &net->a1, err);
   for (int i = 0; ok && i < 2; i++)
     for (int j = 0; ok && j < 2; j++) {
       std::string cj = ".conv" + std::to_string(j + 1);
-      ok = make_conv(net.get(), m, "encodeA." + std::to_string(2 + i) + cj, 1, &net->ra[i][j], err) &&
-           make_conv(net.get(), m, "encodeAB." + std::to_string(i) + cj, 1, &net->rb[i][j], err) &&
-           make_conv(net.get(), m, "encodeAB." + std::to_string(3 + i) + cj, 1, &net->rc[i][j], err);
+      ok = make_conv(net.get(), m, "encodeA." + std::to_string(2 + i) + cj, 1, 128, 128, 3, tdt, &net->ra[i][j], err) &&
+           make_conv(net.get(), m, "encodeAB." + std::to_string(i) + cj, 1, 256, 256, 3, tdt, &net->rb[i][j], err) &&
+           make_conv(net.get(), m, "encodeAB." + std::to_string(3 + i) + cj, 1, 512, 512, 3, tdt, &net->rc[i][j], err);
     }
-  ok = ok && make_conv(net.get(), m, "encodeAB.2", 2, &net->b2, err);
+  ok = ok && make_conv(net.get(), m, "encodeAB.2", 2, 512, 256, 3, tdt, &net->b2, err);
   if (ok && !is_scorer) {
     EncLayer *heads[2] = {&net->trans, &net->rot};
     const char *names[2] = {"trans_head", "rot_head"};
     for (int i = 0; ok && i < 2; i++) {
       std::string p0 = std::string(names[i]) + ".0", p1 = std::string(names[i]) + ".1";
-      ok = make_mha(net.get(), m, p0 + ".self_attn", &heads[i]->att, err) &&
-           make_linear_conv(net.get(), m, p0 + ".linear1.weight", p0 + ".linear1.bias", &heads[i]->lin1, err) &&
-           make_linear_conv(net.get(), m, p0 + ".linear2.weight", p0 + ".linear2.bias", &heads[i]->lin2, err) &&
+      ok = make_mha(net.get(), m, p0 + ".self_attn", adt, &heads[i]->att, err) &&
+           make_linear_conv(net.get(), m, p0 + ".linear1.weight", p0 + ".linear1.bias", EMBED, EMBED, adt, &heads[i]->lin1, err) &&
+           make_linear_conv(net.get(), m, p0 + ".linear2.weight", p0 + ".linear2.bias", EMBED, EMBED, adt, &heads[i]->lin2, err) &&
            make_ln(net.get(), m, p0 + ".norm1", &heads[i]->ln1, err) && make_ln(net.get(), m, p0 + ".norm2", &heads[i]->ln2, err) &&
-           make_linear_f32(net.get(), m, p1 + ".weight", p1 + ".bias", &heads[i]->head, err);
+           make_linear_f32(net.get(), m, p1 + ".weight", p1 + ".bias", 3, EMBED, &heads[i]->head, err);
     }
     if (ok) {
       ok = make_grouped(net.get(), net->trans.att.in_proj, net->rot.att.in_proj, &net->g_in_proj) &&
@@ -2258,27 +2473,81 @@ Net *net_load(const char *path, bool is_scorer, std::string *err) {
       if (!ok) *err = "could not build the grouped head weights";
     }
   } else if (ok) {
-    ok = make_mha(net.get(), m, "att", &net->att, err) && make_mha(net.get(), m, "att_cross", &net->att_cross, err) &&
-         make_linear_f32(net.get(), m, "linear.weight", "linear.bias", &net->score_lin, err);
+    ok = make_mha(net.get(), m, "att", adt, &net->att, err) && make_mha(net.get(), m, "att_cross", adt, &net->att_cross, err) &&
+         make_linear_f32(net.get(), m, "linear.weight", "linear.bias", 1, EMBED, &net->score_lin, err);
   }
   if (ok) {
     // PositionalEmbedding(d_model=512, max_len=400): pe[t,2i]=sin(t*w_i), pe[t,2i+1]=cos(t*w_i), w_i=exp(-2i*ln(1e4)/512)
-    std::vector<__half> pe((size_t)400 * EMBED);
+    std::vector<float> pe((size_t)400 * EMBED);
     for (int t = 0; t < 400; t++)
       for (int i = 0; i < EMBED / 2; i++) {
         float div = std::exp((float)(2 * i) * -(std::log(10000.0f) / (float)EMBED));
-        pe[(size_t)t * EMBED + 2 * i] = __float2half(std::sin((float)t * div));
-        pe[(size_t)t * EMBED + 2 * i + 1] = __float2half(std::cos((float)t * div));
+        pe[(size_t)t * EMBED + 2 * i] = std::sin((float)t * div);
+        pe[(size_t)t * EMBED + 2 * i + 1] = std::cos((float)t * div);
       }
-    net->pe = upload(net.get(), pe);
+    net->pe = upload(net.get(), to_elems(pe, 400, EMBED, adt, nullptr));
     ok = net->pe != nullptr;
+    if (!ok) *err = "device allocation failed";
+  }
+  if (ok) {
+    float *c = nullptr;
+    ok = hipMalloc((void **)&c, N_TRUNK_ACT * sizeof(float)) == hipSuccess && hipMemset(c, 0, N_TRUNK_ACT * sizeof(float)) == hipSuccess;
+    if (c) net->allocs.push_back(c);
+    net->calib_dev = c;
     if (!ok) *err = "device allocation failed";
   }
   if (!ok) return nullptr;
   return net.release();
 }
 
+Net *net_load(const char *path, bool is_scorer, int prec, std::string *err) {
+  try {  // a malformed file must not take the process down through the C ABI
+    return net_load_impl(path, is_scorer, prec, err);
+  } catch (const std::exception &e) {
+    *err = std::string("loading ") + path + ": " + e.what();
+    return nullptr;
+  }
+}
+
 void net_free(Net *n) { delete n; }
+int net_precision(const Net *n) { return n->prec; }
+int net_input_dt(const Net *n) { return n->act_dt; }
+bool net_fp8_ready(const Net *n) { return n->prec != PREC_FP8 || n->fp8_ready; }
+
+// ---- FP8 calibration --------------------------------------------------------------------------------
+void net_calib_begin(Net *net, hipStream_t s) {
+  (void)hipMemsetAsync(net->calib_dev, 0, N_TRUNK_ACT * sizeof(float), s);
+  net->calib_on = true;
+}
+int net_calib_end(Net *net, hipStream_t s, float amax_out[16]) {
+  net->calib_on = false;
+  for (int i = 0; i < 16; i++) amax_out[i] = 0.f;
+  FP_HIP_OK(hipMemcpyAsync(amax_out, net->calib_dev, N_TRUNK_ACT * sizeof(float), hipMemcpyDeviceToHost, s));
+  FP_HIP_OK(hipStreamSynchronize(s));
+  return 0;
+}
+// input activation of every FP8 layer: {layer, activation id}
+static void fp8_layers(Net *n, ConvLayer *(&L)[13], int (&in_act)[13]) {
+  ConvLayer *l[13] = {&n->ra[0][0], &n->ra[0][1], &n->ra[1][0], &n->ra[1][1], &n->rb[0][0], &n->rb[0][1], &n->rb[1][0],
+                      &n->rb[1][1], &n->b2, &n->rc[0][0], &n->rc[0][1], &n->rc[1][0], &n->rc[1][1]};
+  for (int i = 0; i < 13; i++) { L[i] = l[i]; in_act[i] = i + 1; }
+}
+int net_set_fp8_scales(Net *net, const float amax[16]) {
+  FP_CHECK(net->prec == PREC_FP8, "net_set_fp8_scales: not an FP8 network");
+  // amax of the calibration frame maps to 224 = half of the e4m3 range: one binade of headroom before saturation
+  for (int i = 0; i < N_TRUNK_ACT; i++) net->act_scale[i] = amax[i] > 0.f ? amax[i] / 224.f : 1.f;
+  ConvLayer *L[13];
+  int in_act[13];
+  fp8_layers(net, L, in_act);
+  for (int i = 0; i < 13; i++) {
+    std::vector<float> ws(L[i]->Cout), cs(L[i]->Cout);
+    FP_HIP_OK(hipMemcpy(ws.data(), L[i]->wscale, ws.size() * 4, hipMemcpyDeviceToHost));
+    for (size_t k = 0; k < ws.size(); k++) cs[k] = ws[k] * net->act_scale[in_act[i]];
+    FP_HIP_OK(hipMemcpy(L[i]->cscale, cs.data(), cs.size() * 4, hipMemcpyHostToDevice));
+  }
+  net->fp8_ready = true;
+  return 0;
+}
 
 // =================================================================================================
 // scratch
@@ -2286,11 +2555,11 @@ void net_free(Net *n) { delete n; }
 
 struct NNScratch {
   int cap = 0;
-  __half *buf = nullptr;
+  unsigned char *buf = nullptr;
   float *f32 = nullptr;
   // cross-attention head over all gathered hypotheses (sized by n_total, independent of the local shard)
   int head_cap = 0;
-  __half *head_buf = nullptr;
+  unsigned char *head_buf = nullptr;
   float *head_f32 = nullptr;
   // fp32 partial slabs of split-K convolutions (small batches); per model so that models on different streams /
   // threads never share it
@@ -2308,16 +2577,18 @@ NNScratch *nn_scratch_create() { return new NNScratch(); }
 
 void nn_scratch_free(NNScratch *w) { delete w; }
 
-// per-hypothesis activation sizes (halfs); conv inputs carry their physical zero border
-static constexpr size_t SZ_STEM = 2ull * 82 * 82 * 64;   // stem out, read by the 3x3/s2 conv (border 1)
-static constexpr size_t SZ_128 = 2ull * 42 * 42 * 128;
-static constexpr size_t SZ_256 = 42ull * 42 * 256;
-static constexpr size_t SZ_512 = 22ull * 22 * 512;
-static constexpr size_t SZ_TOK = 400ull * 512;            // token buffers (no border)
-static constexpr size_t SZ_QKV = 400ull * 1536;
+// per-hypothesis activation sizes (BYTES at 2 bytes per element: one arena layout for every precision; an FP8 tensor uses
+// the first half of its slot); conv inputs carry their physical zero border.  A scratch object serves ONE precision:
+// the border positions of a tensor depend on its element size.
+static constexpr size_t SZ_STEM = 2ull * 82 * 82 * 64 * 2;   // stem out, read by the 3x3/s2 conv (border 1)
+static constexpr size_t SZ_128 = 2ull * 42 * 42 * 128 * 2;
+static constexpr size_t SZ_256 = 42ull * 42 * 256 * 2;
+static constexpr size_t SZ_512 = 22ull * 22 * 512 * 2;
+static constexpr size_t SZ_TOK = 400ull * 512 * 2;            // token buffers (no border)
+static constexpr size_t SZ_QKV = 400ull * 1536 * 2;
 static constexpr size_t PER_HYP = SZ_STEM + 3 * SZ_128 + 3 * SZ_256 + 3 * SZ_512 + SZ_QKV + 4 * SZ_TOK;
 void nn_scratch_debug_info(const NNScratch *w, const void **buf, size_t *bytes, const void **f32, size_t *f32_bytes) {
-  *buf = w->buf; *bytes = (size_t)w->cap * PER_HYP * sizeof(__half);
+  *buf = w->buf; *bytes = (size_t)w->cap * PER_HYP;
   *f32 = w->f32; *f32_bytes = (size_t)w->cap * EMBED * sizeof(float);
 }
 
@@ -2328,11 +2599,11 @@ static int ensure_scratch(NNScratch *ws, int N, hipStream_t s) {
   ws->buf = nullptr; ws->f32 = nullptr; ws->cap = 0;
   int cap = std::max(N, 8);
   g_alloc_epoch++;
-  FP_HIP_OK(hipMalloc((void **)&ws->buf, (size_t)cap * PER_HYP * sizeof(__half)));
+  FP_HIP_OK(hipMalloc((void **)&ws->buf, (size_t)cap * PER_HYP));
   FP_HIP_OK(hipMalloc((void **)&ws->f32, (size_t)cap * EMBED * sizeof(float)));
   // the zero borders are written here once and never again: every producer stores interiors only, and the arena is
   // carved by CAPACITY (not by the current N), so an image slot's border never moves
-  FP_HIP_OK(hipMemsetAsync(ws->buf, 0, (size_t)cap * PER_HYP * sizeof(__half), s));
+  FP_HIP_OK(hipMemsetAsync(ws->buf, 0, (size_t)cap * PER_HYP, s));
   ws->cap = cap;
   return 0;
 }
@@ -2343,7 +2614,8 @@ static int ensure_head_scratch(NNScratch *ws, int n_total) {
   if (ws->head_f32) (void)hipFree(ws->head_f32);
   ws->head_buf = nullptr; ws->head_f32 = nullptr; ws->head_cap = 0;
   int cap = std::max(n_total, 256);
-  FP_HIP_OK(hipMalloc((void **)&ws->head_buf, (size_t)cap * 5 * EMBED * sizeof(__half)));
+  g_alloc_epoch++;
+  FP_HIP_OK(hipMalloc((void **)&ws->head_buf, (size_t)cap * 5 * EMBED * 2));
   FP_HIP_OK(hipMalloc((void **)&ws->head_f32, (size_t)cap * EMBED * sizeof(float)));
   ws->head_cap = cap;
   return 0;
@@ -2353,7 +2625,6 @@ static int ensure_head_scratch(NNScratch *ws, int n_total) {
 // launch helpers
 // =================================================================================================
 
-
 struct Ctx {
   hipStream_t s;
   Profiler *prof;
@@ -2361,127 +2632,89 @@ struct Ctx {
   NNScratch *ws = nullptr;  // owner of the split-K slab (null only in the single-threaded test hooks)
 };
 
-static bool g_conv_attr_done = false;
+// A/B and ablation switches exist only in the test build (libfoundationpose_amd_test.so, -DFP_TEST_HOOKS); in the product
+// they are compile-time constants, so the alternative branches and their kernel instantiations are not in the library
+// and nothing can flip a schedule under a running model.
+#ifdef FP_TEST_HOOKS
+#define FP_HOOK static int
 static unsigned long long *g_clk_probe = nullptr;
 static NNScratch g_hook_ws;  // split-K slab of the fpt_* test hooks
-static int g_rem_kernel = 3;  // A/B hook: kernel for the rows the full 256x256 rounds of a long-K layer leave over (3 = conv_deep_kernel<64>, 4 = <128>, 1 = 256x128 ping-pong, 2 = 256x128 3-stage, 0 = 128x128 2-stage)
-static int g_rem_small = 1;   // A/B hook (0 = off): long-K layers too small for one full 256x256 round take the left-over path as a whole
-static int g_gemm_kernel = 1;  // A/B hook: Linear layers on gemm_k32_kernel (0 = the 256x256 ping-pong tile + left-overs)
-static int g_grouped_heads = 1;  // A/B hook: the refiner's two heads as one launch per layer when N == 1 (Track)
-static int g_rem_splitk = 0;     // A/B hook: split-K for the rows a 256x256 / 512x128 launch leaves over.  Measured -0.1 ms per
-                                 // Register, but OFF: a row's fp32 summation order would then depend on where it falls in the
-                                 // batch, and sharded and unsharded Register must pick the same near-tied winner
-static int g_splitk_target = 128;  // workgroups a split-K launch aims for (tools/ab_track.py: 96-128 best, 256 is 6 % slower)
-static int g_conv_variant = 0;
-static int g_conv_ablate = 0;  // timing-only ablations of conv_big_pp_kernel: 1 no loads, 2 no MFMAs, 3 neither  // 0 auto, 1 force the 128-pixel 2-stage kernel, 2 force the 256-pixel 3-stage kernel (A/B hook)
+#else
+#define FP_HOOK static constexpr int
+static constexpr unsigned long long *g_clk_probe = nullptr;
+#endif
+FP_HOOK g_conv_variant = 0;    // 0 default; 7 force / 8 disable the resident-halo kernels; 3 = 256x128 ping-pong everywhere; 5 = 256x256 rounds without
+                               // the halo kernels; 10..25 = conv_igemm_kernel<128> fragment-read / ablation variants
+FP_HOOK g_conv_ablate = 0;     // timing-only ablations (wrong results) of conv_big_pp_kernel / conv_halo_kernel
+FP_HOOK g_rem_kernel = 3;      // rows the full 256x256 rounds of a long-K layer leave over: 3 = conv_deep_kernel<64>, 4 = <128>, 1 = 256x128 ping-pong, 0 = 128x128 2-stage
+FP_HOOK g_rem_small = 1;       // long-K layers too small for one full 256x256 round take the left-over path as a whole
+FP_HOOK g_gemm_kernel = 1;     // Linear layers on gemm_k32_kernel (0 = the 256x256 ping-pong tile + left-overs; 11 / 12 / 14 ablations)
+FP_HOOK g_grouped_heads = 1;   // the refiner's two heads as one launch per layer when N == 1 (Track)
+FP_HOOK g_rem_splitk = 0;      // split-K for left-over rows.  Measured -0.1 ms per Register, but OFF: a row's fp32 summation order would then
+                               // depend on where it falls in the batch, and sharded and unsharded Register must pick the same near-tied winner
+FP_HOOK g_splitk_target = 128; // workgroups a split-K launch aims for (tools/ab_track.py: 96-128 best, 256 is 6 % slower)
+FP_HOOK g_att_variant = 1;     // 1 remap + 16-B stores, 3 no XCD remap, 5 remap + 2-B stores, 7 neither
+
+// One launch = (once per launch site and element type, thread-safe through the function-local static) dynamic-LDS opt-in +
+// the launch itself.
+#define FP_LAUNCH(KERN, grid, block, lds_bytes, stream, ...)                                                                        \
+  do {                                                                                                                              \
+    static const hipError_t fp_attr_rc_ = hipFuncSetAttribute((const void *)(KERN), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+    (void)fp_attr_rc_;                                                                                                              \
+    hipLaunchKernelGGL((KERN), grid, block, lds_bytes, stream, __VA_ARGS__);                                                        \
+  } while (0)
+
+// a tensor as run_conv sees it: element type + (FP8) per-tensor scale, real = stored * scale
+struct Act {
+  void *p = nullptr;
+  int dt = DT_F16;
+  float scale = 1.f;
+};
 
 // in: [NB, H+2*ipad, W+2*ipad, Cin]; out: [.., OH+2*opad, OW+2*opad, ..]; res: border rpad
 struct ConvGroup {  // two weight groups along M (see ConvParams::grp_rows); L holds [2][Cout][K] weights and [2][Cout] biases
   int rows = 0;     // rows per group (multiple of 128); the launch covers 2 * rows
   bool in_shared = false, res_shared = false;
 };
-static int run_conv(const Ctx &c, const char *tag, const ConvLayer &L, const __half *in, int NB, int H, int W, int ipad,
-                    __half *out, int opad, bool relu, const __half *res = nullptr, int rpad = 0, int split_imgs = 0,
-                    const ConvGroup *grp = nullptr) {
-  ConvParams p;
-  p.clk = g_clk_probe;
-  p.grp_rows = grp ? grp->rows : 0;
-  p.in_shared = grp && grp->in_shared;
-  p.res_shared = grp && grp->res_shared;
-  p.grp_w_halfs = grp ? (unsigned)((size_t)L.Cout * L.KH * L.KW * L.Cin) : 0;
-  FP_CHECK(!grp || (grp->rows % 128 == 0 && L.KH == 1 && L.KW == 1 && NB == 2 * grp->rows), "grouped launch: unsupported shape");
-  p.in = in; p.w = L.w; p.bias = L.bias; p.res = res; p.out = out;
-  p.NB = NB; p.H = H; p.W = W; p.Cin = L.Cin;
-  p.KH = L.KH; p.KW = L.KW; p.stride = L.stride; p.pad = L.pad;
-  p.ipad = ipad; p.opad = opad; p.rpad = rpad;
-  p.OH = (H + 2 * L.pad - L.KH) / L.stride + 1;
-  p.OW = (W + 2 * L.pad - L.KW) / L.stride + 1;
-  if (L.KH == 4 && L.pad == 2 && L.stride == 1) { p.OH = H; p.OW = W; }  // s2d stem: asymmetric padding (2 before, 1 after)
-  p.Cout = L.Cout;
-  p.M = NB * p.OH * p.OW;
-  p.Ktot = L.KH * L.KW * L.Cin;
-  p.ntaps = L.KH * L.KW;
-  p.relu = relu ? 1 : 0;
-  p.split_imgs = split_imgs;
-  p.out_ld = split_imgs > 0 ? 2 * L.Cout : L.Cout;
-  p.res_ld = L.Cout;
-  FP_CHECK(ipad >= L.pad && (L.Cin == 32 || L.Cin % 64 == 0) && p.Ktot % 64 == 0 && (L.Cout % 64) == 0 &&
-               (L.Cin != 32 || L.KW % 2 == 0) && p.Ktot / 64 <= 80,
-           "conv shape not supported by the MFMA kernel");
-  {
-    // K order: Cin >= 64 -> (64-channel chunk outer, tap inner); Cin == 32 (s2d stem) -> two horizontally adjacent taps
-    // (128 contiguous bytes) per K-step.  koff = byte offset of the K-step's X slab from the row's (tap 0, ch 0) address.
-    const int IWp = W + 2 * ipad;
-    for (int kt = 0; kt < p.Ktot / 64; kt++) {
-      int kh, kw, ch;
-      if (L.Cin >= 64) { ch = kt / p.ntaps; int tap = kt % p.ntaps; kh = tap / L.KW; kw = tap % L.KW; }
-      else { ch = 0; int tap = 2 * kt; kh = tap / L.KW; kw = tap % L.KW; }
-      p.koff[kt] = (unsigned)(((kh * IWp + kw) * L.Cin + ch * 64) * 2);
-      if (2 * kt + 1 < 160) { p.koff32[2 * kt] = p.koff[kt]; p.koff32[2 * kt + 1] = p.koff[kt] + 64; }
-    }
-  }
+
+// DT = element type of the layer's operands; ODT = of its output.  ODT != DT only for the two layers at the FP8 boundary
+// (encodeA.1: f16 -> FP8, the last encodeAB conv: FP8 -> f16 tokens); those instantiate only the schedules they can reach.
+template <int DT, int ODT>
+static int run_conv_dt(const Ctx &c, const char *tag, const ConvLayer &L, ConvParams &p, int NB, int H, int W, int ipad,
+                       bool has_res, int split_imgs, const ConvGroup *grp) {
+  constexpr bool B2 = DT != DT_FP8;  // 2-byte element type: the 64-byte-row kernels exist
+  constexpr bool SAME = DT == ODT;   // kernels without an ODT parameter write their operand type
+  const int KT = p.krow_b / 128;
   double flops = 2.0 * (double)p.M * p.Cout * (L.algo_K > 0 ? L.algo_K : p.Ktot);
-  double bytes = ((double)NB * H * W * L.Cin + (double)p.M * p.Cout * (res ? 2 : 1) + (double)p.Cout * p.Ktot) * 2.0;
-  constexpr int LDS3_128 = 3 * (256 * 128 + 128 * 128), LDS3_64 = 3 * (256 * 128 + 64 * 128);
+  double bytes = ((double)NB * H * W * L.Cin + (double)p.M * p.Cout * (has_res ? 2 : 1) + (double)p.Cout * p.Ktot) * elem_bytes(DT);
+  constexpr int LDS_IG128 = 2 * (128 * 128 + 128 * 128), LDS_IG64 = 2 * (128 * 128 + 64 * 128);
+  constexpr int LDS3_128 = 3 * (256 * 128 + 128 * 128);
+  constexpr int LDS_BIG = 2 * (256 * 128 + 256 * 128);
   constexpr int LDS_HALO40 = ((10 * 42 + 7) / 8) * 1024 + 3 * 128 * 64;
+  constexpr int LDS_HALO8 = ((10 * 42 + 7) / 8) * 1024 + 128 * 128;
   constexpr int LDS_STEM_HALO = ((11 * 84 + 15) / 16) * 1024 + 3 * 64 * 64;
   constexpr int LDS_DEEP64 = 6 * (64 + 128) * 128, LDS_DEEP128 = 4 * (128 + 128) * 128;
   constexpr int LDS_GEMM_K32 = 3 * (128 + 256) * 64;
   constexpr int LDS_S2_HALO = ((9 * 41 + 7) / 8) * 1024 + 3 * 128 * 64;
-  if (!g_conv_attr_done) {
-    FP_HIP_OK(hipFuncSetAttribute((const void *)conv_igemm_kernel<128, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (128 * 128 + 128 * 128)));
-    FP_HIP_OK(hipFuncSetAttribute((const void *)conv_igemm_kernel<128, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (128 * 128 + 128 * 128)));
-    FP_HIP_OK(hipFuncSetAttribute((const void *)conv_igemm_kernel<128, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (128 * 128 + 128 * 128)));
-    FP_HIP_OK(hipFuncSetAttribute((const void *)conv_igemm_kernel<128, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (128 * 128 + 128 * 128)));
-    FP_HIP_OK(hipFuncSetAttribute((const void *)conv_igemm_kernel<128, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (128 * 128 + 128 * 128)));
-    FP_HIP_OK(hipFuncSetAttribute((const void *)conv_igemm_kernel<128, 11>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (128 * 128 + 128 * 128)));
-    FP_HIP_OK(hipFuncSetAttribute((const void *)conv_igemm_kernel<128, 15>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (128 * 128 + 128 * 128)));
-    FP_HIP_OK(hipFuncSetAttribute((const void *)conv_igemm_kernel<64, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (128 * 128 + 64 * 128)));
-    FP_HIP_OK(hipFuncSetAttribute((const void *)conv_igemm3_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS3_128));
-    FP_HIP_OK(hipFuncSetAttribute((const void *)conv_igemm3_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS3_64));
-    FP_HIP_OK(hipFuncSetAttribute((const void *)conv_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 * 128 + 256 * 128)));
-    FP_HIP_OK(hipFuncSetAttribute((const void *)conv_pp32_kernel<256, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * (256 + 256) * 64));
-    FP_HIP_OK(hipFuncSetAttribute((const void *)conv_pp32_kernel<512, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * (512 + 128) * 64));
-    FP_HIP_OK(hipFuncSetAttribute((const void *)conv_big_pp_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 * 128 + 256 * 128)));
-    FP_HIP_OK(hipFuncSetAttribute((const void *)conv_big_pp_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 * 128 + 256 * 128)));
-    FP_HIP_OK(hipFuncSetAttribute((const void *)conv_big_pp_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 * 128 + 256 * 128)));
-    FP_HIP_OK(hipFuncSetAttribute((const void *)conv_big_pp_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 * 128 + 256 * 128)));
-    FP_HIP_OK(hipFuncSetAttribute((const void *)conv_big_pp_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 * 128 + 256 * 128)));
-    FP_HIP_OK(hipFuncSetAttribute((const void *)conv_big_pp_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 * 128 + 256 * 128)));
-    FP_HIP_OK(hipFuncSetAttribute((const void *)conv_big_pp_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 * 128 + 256 * 128)));
-    FP_HIP_OK(hipFuncSetAttribute((const void *)conv_stem_halo_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_STEM_HALO));
-    FP_HIP_OK(hipFuncSetAttribute((const void *)conv_s2_halo_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_S2_HALO));
-    FP_HIP_OK(hipFuncSetAttribute((const void *)conv_deep_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DEEP64));
-    FP_HIP_OK(hipFuncSetAttribute((const void *)conv_deep_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DEEP128));
-    FP_HIP_OK(hipFuncSetAttribute((const void *)gemm_k32_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_GEMM_K32));
-    FP_HIP_OK(hipFuncSetAttribute((const void *)gemm_k32_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_GEMM_K32));
-    FP_HIP_OK(hipFuncSetAttribute((const void *)gemm_k32_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_GEMM_K32));
-    FP_HIP_OK(hipFuncSetAttribute((const void *)gemm_k32_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_GEMM_K32));
-    FP_HIP_OK(hipFuncSetAttribute((const void *)conv_halo_kernel<40, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_HALO40));
-    FP_HIP_OK(hipFuncSetAttribute((const void *)conv_halo_kernel<40, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_HALO40));
-    FP_HIP_OK(hipFuncSetAttribute((const void *)conv_halo_kernel<40, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_HALO40));
-    FP_HIP_OK(hipFuncSetAttribute((const void *)conv_halo_kernel<40, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_HALO40));
-    FP_HIP_OK(hipFuncSetAttribute((const void *)conv_pp_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS3_128));
-    FP_HIP_OK(hipFuncSetAttribute((const void *)conv_pp_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS3_64));
-    g_conv_attr_done = true;
-  }
+  constexpr int LDS_PP32 = 4 * (512 + 128) * 64;
   int mtiles = (p.M + 127) / 128;
-  const int KT = p.Ktot / 64;
   // split-K for small problems (Track, N <= ~8): a 128x128 tile count far below the 512 workgroup slots of the chip
   // would leave most CUs idle while a few walk up to 72 K-steps; give every CU a slice instead
-  p.ksplit = 1; p.kt_per = KT; p.partial = nullptr;
-  p.m_begin = 0;
   // (also used for the rows a 256x256 / 512x128 launch leaves over: `target` workgroups on an otherwise idle chip)
   auto plan_splitk = [&](int rows, int target) -> int {
     const int mt = (rows + 127) / 128;
     const int tiles = mt * (L.Cout % 128 == 0 ? L.Cout / 128 : L.Cout / 64);
-    if (tiles > 96 || KT < 8 || g_conv_variant == 2) return 0;
+    if (tiles > 96 || KT < 8) return 0;
     int S = std::min(std::max(target / tiles, 1), KT / 2);
     if (S <= 1) return 0;
     p.kt_per = (KT + S - 1) / S;
     p.ksplit = (KT + p.kt_per - 1) / p.kt_per;
     size_t need = (size_t)p.ksplit * rows * p.Cout;
+#ifdef FP_TEST_HOOKS
     NNScratch *sk = c.ws ? c.ws : &g_hook_ws;
+#else
+    NNScratch *sk = c.ws;
+#endif
     if (need > sk->splitk_cap) {
       if (sk->splitk) (void)hipFree(sk->splitk);
       sk->splitk = nullptr; sk->splitk_cap = 0;
@@ -2494,92 +2727,106 @@ static int run_conv(const Ctx &c, const char *tag, const ConvLayer &L, const __h
   };
   if (plan_splitk(p.M, g_splitk_target)) return 1;
   const std::string tg(tag);
-  // large problems: 256-pixel tiles, 3-stage LDS-DMA pipeline (needs >= 3 K-steps and enough tiles to fill 256 CUs)
-  const int big_tiles = ((p.M + 255) / 256) * (L.Cout % 128 == 0 ? L.Cout / 128 : L.Cout / 64);
-  (void)big_tiles;
-  // measured (tools/bench_conv.py, N=126): the 128-px 2-stage kernel beats the 256-px 3-stage one on every layer
-  // (756-769 vs 703-709 TF/s weighted), so the latter is only reachable through the A/B hook
-  if (!grp && (g_conv_variant == 7 || g_conv_variant == 0) && L.Cin == 32 && L.KH == 4 && L.KW == 4 && L.Cout == 64 && ipad == 2 && W == 80 &&
-      H == 80 && p.ksplit == 1 && res == nullptr && split_imgs == 0 && (g_conv_variant == 7 || NB * 10 >= 300)) {
-    ProfScope ps(c.prof, c.s, (tg + "/conv_stem_halo_kernel").c_str(), flops, bytes);
-    hipLaunchKernelGGL(conv_stem_halo_kernel, dim3(NB * 10), dim3(256), LDS_STEM_HALO, c.s, p);
-    return 0;
-  }
-  if (!grp && g_gemm_kernel && g_conv_variant == 0 && L.KH == 1 && L.KW == 1 && L.stride == 1 && L.pad == 0 && ipad == 0 && L.Cout % 256 == 0 &&
-      p.Ktot % 32 == 0 && p.ksplit == 1 && split_imgs == 0 && ((p.M + 127) / 128) * (L.Cout / 256) >= 512) {
-    ProfScope ps(c.prof, c.s, (tg + "/gemm_k32_kernel").c_str(), flops, bytes);
-    const dim3 grid(((p.M + 127) / 128) * (L.Cout / 256));
-    switch (g_gemm_kernel) {  // 1 = product; 11 / 12 / 14: timing ablations (wrong results)
-      case 11: hipLaunchKernelGGL(gemm_k32_kernel<1>, grid, dim3(256), LDS_GEMM_K32, c.s, p); break;
-      case 12: hipLaunchKernelGGL(gemm_k32_kernel<2>, grid, dim3(256), LDS_GEMM_K32, c.s, p); break;
-      case 14: hipLaunchKernelGGL(gemm_k32_kernel<4>, grid, dim3(256), LDS_GEMM_K32, c.s, p); break;
-      default: hipLaunchKernelGGL(gemm_k32_kernel<0>, grid, dim3(256), LDS_GEMM_K32, c.s, p); break;
+  const bool halo_ok = g_conv_variant == 0 || g_conv_variant == 7;
+  const bool force = g_conv_variant == 7;
+  if constexpr (B2 && SAME) {
+    if (!grp && halo_ok && L.Cin == 32 && L.KH == 4 && L.KW == 4 && L.Cout == 64 && ipad == 2 && W == 80 && H == 80 && p.ksplit == 1 &&
+        !has_res && split_imgs == 0 && (force || NB * 10 >= 300)) {
+      ProfScope ps(c.prof, c.s, (tg + "/conv_stem_halo_kernel").c_str(), flops, bytes);
+      FP_LAUNCH((conv_stem_halo_kernel<DT>), dim3(NB * 10), dim3(256), LDS_STEM_HALO, c.s, p);
+      return 0;
     }
-    return 0;
+    if (!grp && g_gemm_kernel && g_conv_variant == 0 && L.KH == 1 && L.KW == 1 && L.stride == 1 && L.pad == 0 && ipad == 0 && L.Cout % 256 == 0 &&
+        p.Ktot % 32 == 0 && p.ksplit == 1 && split_imgs == 0 && ((p.M + 127) / 128) * (L.Cout / 256) >= 512) {
+      ProfScope ps(c.prof, c.s, (tg + "/gemm_k32_kernel").c_str(), flops, bytes);
+      const dim3 grid(((p.M + 127) / 128) * (L.Cout / 256));
+#ifdef FP_TEST_HOOKS
+      if (DT == DT_F16 && g_gemm_kernel == 11) { FP_LAUNCH((gemm_k32_kernel<1, DT_F16>), grid, dim3(256), LDS_GEMM_K32, c.s, p); return 0; }
+      if (DT == DT_F16 && g_gemm_kernel == 12) { FP_LAUNCH((gemm_k32_kernel<2, DT_F16>), grid, dim3(256), LDS_GEMM_K32, c.s, p); return 0; }
+      if (DT == DT_F16 && g_gemm_kernel == 14) { FP_LAUNCH((gemm_k32_kernel<4, DT_F16>), grid, dim3(256), LDS_GEMM_K32, c.s, p); return 0; }
+#endif
+      FP_LAUNCH((gemm_k32_kernel<0, DT>), grid, dim3(256), LDS_GEMM_K32, c.s, p);
+      return 0;
+    }
   }
-  if (!grp && (g_conv_variant == 7 || g_conv_variant == 0) && L.KH == 3 && L.KW == 3 && L.stride == 2 && L.pad == 1 && ipad == 1 &&
-      W == 80 && H == 80 && L.Cin == 64 && L.Cout == 128 && p.ksplit == 1 && res == nullptr && split_imgs == 0 &&
-      (g_conv_variant == 7 || NB * 10 >= 300)) {
-    ProfScope ps(c.prof, c.s, (tg + "/conv_s2_halo_kernel").c_str(), flops, bytes);
-    hipLaunchKernelGGL(conv_s2_halo_kernel, dim3(NB * 10), dim3(256), LDS_S2_HALO, c.s, p);
-    return 0;
+  if constexpr (B2) {
+    if (!grp && halo_ok && L.KH == 3 && L.KW == 3 && L.stride == 2 && L.pad == 1 && ipad == 1 && W == 80 && H == 80 && L.Cin == 64 &&
+        L.Cout == 128 && p.ksplit == 1 && !has_res && split_imgs == 0 && (force || NB * 10 >= 300)) {
+      ProfScope ps(c.prof, c.s, (tg + "/conv_s2_halo_kernel").c_str(), flops, bytes);
+      FP_LAUNCH((conv_s2_halo_kernel<DT, ODT>), dim3(NB * 10), dim3(256), LDS_S2_HALO, c.s, p);
+      return 0;
+    }
   }
-  if (!grp && (g_conv_variant == 7 || g_conv_variant == 0) && L.KH == 3 && L.KW == 3 && L.stride == 1 && L.pad == 1 && ipad == 1 && W == 40 && H % 8 == 0 &&
-      L.Cin % 64 == 0 && L.Cout % 128 == 0 && p.ksplit == 1 &&
-      (g_conv_variant == 7 || NB * (H / 8) * (L.Cout / 128) >= 300)) {  // measured crossover vs the implicit-GEMM tiles: ~32 hypotheses
-    ProfScope ps(c.prof, c.s, (tg + "/conv_halo_kernel").c_str(), flops, bytes);
+  // 3x3 / stride 1 on 40x40 maps with the input tile resident in LDS; measured crossover vs the implicit-GEMM tiles: ~32 hypotheses
+  if (SAME && !grp && halo_ok && L.KH == 3 && L.KW == 3 && L.stride == 1 && L.pad == 1 && ipad == 1 && W == 40 && H % 8 == 0 &&
+      p.cin_b % 128 == 0 && L.Cout % 128 == 0 && p.ksplit == 1 && (force || NB * (H / 8) * (L.Cout / 128) >= 300)) {
     const dim3 grid(NB * (H / 8) * (L.Cout / 128));
-    if (g_conv_ablate == 1) hipLaunchKernelGGL((conv_halo_kernel<40, 1>), grid, dim3(256), LDS_HALO40, c.s, p);
-    else if (g_conv_ablate == 2) hipLaunchKernelGGL((conv_halo_kernel<40, 2>), grid, dim3(256), LDS_HALO40, c.s, p);
-    else if (g_conv_ablate == 8) hipLaunchKernelGGL((conv_halo_kernel<40, 8>), grid, dim3(256), LDS_HALO40, c.s, p);
-    else hipLaunchKernelGGL((conv_halo_kernel<40, 0>), grid, dim3(256), LDS_HALO40, c.s, p);
+    if constexpr (!SAME) {
+    } else if constexpr (B2) {
+      ProfScope ps(c.prof, c.s, (tg + "/conv_halo_kernel").c_str(), flops, bytes);
+#ifdef FP_TEST_HOOKS
+      if (DT == DT_F16 && g_conv_ablate == 1) { FP_LAUNCH((conv_halo_kernel<40, 1, DT_F16>), grid, dim3(256), LDS_HALO40, c.s, p); return 0; }
+      if (DT == DT_F16 && g_conv_ablate == 2) { FP_LAUNCH((conv_halo_kernel<40, 2, DT_F16>), grid, dim3(256), LDS_HALO40, c.s, p); return 0; }
+      if (DT == DT_F16 && g_conv_ablate == 8) { FP_LAUNCH((conv_halo_kernel<40, 8, DT_F16>), grid, dim3(256), LDS_HALO40, c.s, p); return 0; }
+#endif
+      FP_LAUNCH((conv_halo_kernel<40, 0, DT>), grid, dim3(256), LDS_HALO40, c.s, p);
+    } else {
+      ProfScope ps(c.prof, c.s, (tg + "/conv_halo8_kernel").c_str(), flops, bytes);
+      FP_LAUNCH((conv_halo8_kernel), grid, dim3(256), LDS_HALO8, c.s, p);
+    }
     return 0;
   }
-  if (!grp && (((g_conv_variant == 0 || g_conv_variant == 8) && L.Cout == 128) || (g_conv_variant == 6 && (L.Cout % 256 == 0 || L.Cout == 128))) && p.ksplit == 1 &&
-      KT >= 4 && KT <= 80) {
-    // ping-pong tiles (conv_pp32_kernel) for as many FULL rounds of the 256 CUs as the problem has; the remaining rows
-    // go to the 128x128 kernel below
-    const bool wide = L.Cout % 256 == 0;
-    const int bm = wide ? 256 : 512, bn = wide ? 256 : 128;
-    const int nt2 = L.Cout / bn;
-    const int mt_all = p.M / bm;
-    const int mt_big = (mt_all * nt2 / 256) * 256 / nt2;
-    if (mt_big > 0) {
-      ConvParams pb = p;
-      pb.M = mt_big * bm;
-      const double frac = (double)pb.M / (double)p.M;
-      {
-        ProfScope ps(c.prof, c.s, (tg + (wide ? "/conv_pp32_kernel<256,256>" : "/conv_pp32_kernel<512,128>")).c_str(), flops * frac, bytes * frac);
-        if (wide) hipLaunchKernelGGL((conv_pp32_kernel<256, 256>), dim3(mt_big * nt2), dim3(512), 4 * (256 + 256) * 64, c.s, pb);
-        else hipLaunchKernelGGL((conv_pp32_kernel<512, 128>), dim3(mt_big * nt2), dim3(512), 4 * (512 + 128) * 64, c.s, pb);
+  if constexpr (B2) {
+    if (!grp && (g_conv_variant == 0 || g_conv_variant == 8) && L.Cout == 128 && p.ksplit == 1 && KT >= 4 && KT <= 80) {
+      // 512x128 ping-pong tiles (conv_pp32_kernel) for as many FULL rounds of the 256 CUs as the problem has; the remaining
+      // rows go to the kernels below
+      const int mt_all = p.M / 512;
+      const int mt_big = (mt_all / 256) * 256;
+      if (mt_big > 0) {
+        ConvParams pb = p;
+        pb.M = mt_big * 512;
+        const double frac = (double)pb.M / (double)p.M;
+        {
+          ProfScope ps(c.prof, c.s, (tg + "/conv_pp32_kernel<512,128>").c_str(), flops * frac, bytes * frac);
+          FP_LAUNCH((conv_pp32_kernel<512, 128, DT, ODT>), dim3(mt_big), dim3(512), LDS_PP32, c.s, pb);
+        }
+        flops *= (1.0 - frac); bytes *= (1.0 - frac);
+        p.m_begin = mt_big * 512;
+        if (p.m_begin >= p.M) return 0;
+        mtiles = (p.M - p.m_begin + 127) / 128;
+        if (g_rem_splitk && plan_splitk(p.M - p.m_begin, 384)) return 1;
       }
-      flops *= (1.0 - frac); bytes *= (1.0 - frac);
-      p.m_begin = mt_big * bm;
-      if (p.m_begin >= p.M) return 0;
-      mtiles = (p.M - p.m_begin + 127) / 128;
-      if (g_rem_splitk && plan_splitk(p.M - p.m_begin, 384)) return 1;
     }
   }
-  if (!grp && (g_conv_variant == 4 || g_conv_variant == 5 || g_conv_variant == 0 || g_conv_variant == 8) && L.Cout % 256 == 0 && p.ksplit == 1 && KT >= 2) {
-    // 256x256 tiles for as many FULL rounds of the 256 CUs as the problem has, the remaining rows on 128x128 tiles
+  if constexpr (!(DT == DT_F16 && ODT == DT_FP8))  // (encodeA.1 has 128 output channels: no 256-wide instantiation of the f16 -> FP8 boundary)
+  if (!grp && (g_conv_variant == 5 || g_conv_variant == 0 || g_conv_variant == 8) && L.Cout % 256 == 0 && p.ksplit == 1 && KT >= 2) {
+    // 256x256 tiles for as many FULL rounds of the 256 CUs as the problem has, the remaining rows on smaller tiles
     const int nt2 = L.Cout / 256;
     const int mt_all = p.M / 256;                         // whole 256-row m-tiles
     const int mt_big = (mt_all * nt2 / 256) * 256 / nt2;  // m-tiles covered by full rounds
     if (mt_big > 0) {
-      const int lds_big = 2 * (256 * 128 + 256 * 128);
       ConvParams pb = p;
       pb.M = mt_big * 256;                                // rows [0, mt_big*256)
       const double frac = (double)pb.M / (double)p.M;
       {
-        ProfScope ps(c.prof, c.s, (tg + (g_conv_variant == 4 ? "/conv_big_kernel" : "/conv_big_pp_kernel")).c_str(), flops * frac, bytes * frac);
-        if (g_conv_variant == 4) hipLaunchKernelGGL(conv_big_kernel, dim3(mt_big * nt2), dim3(512), lds_big, c.s, pb);
-        else if (g_conv_ablate == 1) hipLaunchKernelGGL(conv_big_pp_kernel<1>, dim3(mt_big * nt2), dim3(512), lds_big, c.s, pb);
-        else if (g_conv_ablate == 2) hipLaunchKernelGGL(conv_big_pp_kernel<2>, dim3(mt_big * nt2), dim3(512), lds_big, c.s, pb);
-        else if (g_conv_ablate == 3) hipLaunchKernelGGL(conv_big_pp_kernel<3>, dim3(mt_big * nt2), dim3(512), lds_big, c.s, pb);
-        else if (g_conv_ablate == 4) hipLaunchKernelGGL(conv_big_pp_kernel<4>, dim3(mt_big * nt2), dim3(512), lds_big, c.s, pb);
-        else if (g_conv_ablate == 8) hipLaunchKernelGGL(conv_big_pp_kernel<8>, dim3(mt_big * nt2), dim3(512), lds_big, c.s, pb);
-        else if (g_conv_ablate == 16) hipLaunchKernelGGL(conv_big_pp_kernel<16>, dim3(mt_big * nt2), dim3(512), lds_big, c.s, pb);
-        else hipLaunchKernelGGL(conv_big_pp_kernel<0>, dim3(mt_big * nt2), dim3(512), lds_big, c.s, pb);
+        ProfScope ps(c.prof, c.s, (tg + "/conv_big_pp_kernel").c_str(), flops * frac, bytes * frac);
+        const dim3 grid(mt_big * nt2);
+        bool done = false;
+#ifdef FP_TEST_HOOKS
+        if (DT == DT_F16 && g_conv_ablate) {
+          done = true;
+          switch (g_conv_ablate) {
+            case 1: FP_LAUNCH((conv_big_pp_kernel<1, DT_F16>), grid, dim3(512), LDS_BIG, c.s, pb); break;
+            case 2: FP_LAUNCH((conv_big_pp_kernel<2, DT_F16>), grid, dim3(512), LDS_BIG, c.s, pb); break;
+            case 3: FP_LAUNCH((conv_big_pp_kernel<3, DT_F16>), grid, dim3(512), LDS_BIG, c.s, pb); break;
+            case 4: FP_LAUNCH((conv_big_pp_kernel<4, DT_F16>), grid, dim3(512), LDS_BIG, c.s, pb); break;
+            case 8: FP_LAUNCH((conv_big_pp_kernel<8, DT_F16>), grid, dim3(512), LDS_BIG, c.s, pb); break;
+            case 16: FP_LAUNCH((conv_big_pp_kernel<16, DT_F16>), grid, dim3(512), LDS_BIG, c.s, pb); break;
+            default: done = false;
+          }
+        }
+#endif
+        if (!done) FP_LAUNCH((conv_big_pp_kernel<0, DT, ODT>), grid, dim3(512), LDS_BIG, c.s, pb);
       }
       flops *= (1.0 - frac); bytes *= (1.0 - frac);
       p.m_begin = mt_big * 256;
@@ -2596,7 +2843,7 @@ static int run_conv(const Ctx &c, const char *tag, const ConvLayer &L, const __h
     if (g_rem_kernel == 4) {
       const dim3 grid(((p.M - p.m_begin + 127) / 128) * n128);
       ProfScope ps(c.prof, c.s, (tg + "/conv_deep_kernel").c_str(), flops, bytes);
-      hipLaunchKernelGGL(conv_deep_kernel<128>, grid, dim3(256), LDS_DEEP128, c.s, p);
+      FP_LAUNCH((conv_deep_kernel<128, DT, ODT>), grid, dim3(256), LDS_DEEP128, c.s, p);
       return 0;
     }
     if (g_rem_kernel == 3) {
@@ -2613,7 +2860,7 @@ static int run_conv(const Ctx &c, const char *tag, const ConvLayer &L, const __h
         const double frac = cascade ? (double)rows_pp / rows : 1.0;
         {
           ProfScope ps(c.prof, c.s, (tg + "/conv_pp_kernel(rem)").c_str(), flops * frac, bytes * frac);
-          hipLaunchKernelGGL(conv_pp_kernel<128>, dim3(((pb.M - pb.m_begin + 255) / 256) * n128), dim3(512), LDS3_128, c.s, pb);
+          FP_LAUNCH((conv_pp_kernel<128, DT, ODT>), dim3(((pb.M - pb.m_begin + 255) / 256) * n128), dim3(512), LDS3_128, c.s, pb);
         }
         if (!cascade || rest == 0) return 0;
         flops *= (1.0 - frac); bytes *= (1.0 - frac);
@@ -2621,86 +2868,151 @@ static int run_conv(const Ctx &c, const char *tag, const ConvLayer &L, const __h
         rows = rest;
       }
       ProfScope ps(c.prof, c.s, (tg + "/conv_deep_kernel").c_str(), flops, bytes);
-      hipLaunchKernelGGL(conv_deep_kernel<64>, dim3(((rows + 63) / 64) * n128), dim3(256), LDS_DEEP64, c.s, p);
+      FP_LAUNCH((conv_deep_kernel<64, DT, ODT>), dim3(((rows + 63) / 64) * n128), dim3(256), LDS_DEEP64, c.s, p);
       return 0;
     }
-    const int mt2 = (p.M - p.m_begin + 255) / 256;
-    ProfScope ps(c.prof, c.s, (tg + (g_rem_kernel == 1 ? "/conv_pp_kernel(rem)" : "/conv_igemm3_kernel(rem)")).c_str(), flops, bytes);
-    if (g_rem_kernel == 1) hipLaunchKernelGGL(conv_pp_kernel<128>, dim3(mt2 * (L.Cout / 128)), dim3(512), LDS3_128, c.s, p);
-    else hipLaunchKernelGGL(conv_igemm3_kernel<128>, dim3(mt2 * (L.Cout / 128)), dim3(512), LDS3_128, c.s, p);
-    return 0;
+    if (g_rem_kernel == 1) {
+      const int mt2 = (p.M - p.m_begin + 255) / 256;
+      ProfScope ps(c.prof, c.s, (tg + "/conv_pp_kernel(rem)").c_str(), flops, bytes);
+      FP_LAUNCH((conv_pp_kernel<128, DT, ODT>), dim3(mt2 * n128), dim3(512), LDS3_128, c.s, p);
+      return 0;
+    }
   }
-  if (!grp && g_conv_variant == 3 && KT >= 3 && p.ksplit == 1) {
+  if (!grp && g_conv_variant == 3 && KT >= 3 && p.ksplit == 1 && L.Cout % 128 == 0) {
     ProfScope ps(c.prof, c.s, (tg + "/conv_pp_kernel").c_str(), flops, bytes);
-    int mt2 = (p.M + 255) / 256;
-    if (L.Cout % 128 == 0)
-      hipLaunchKernelGGL(conv_pp_kernel<128>, dim3(mt2 * (L.Cout / 128)), dim3(512), LDS3_128, c.s, p);
-    else
-      hipLaunchKernelGGL(conv_pp_kernel<64>, dim3(mt2 * (L.Cout / 64)), dim3(512), LDS3_64, c.s, p);
-    return 0;
-  }
-  if (!grp && g_conv_variant == 2 && KT >= 3) {
-    ProfScope ps(c.prof, c.s, (tg + "/conv_igemm3_kernel").c_str(), flops, bytes);
-    int mt2 = (p.M + 255) / 256;
-    if (L.Cout % 128 == 0)
-      hipLaunchKernelGGL(conv_igemm3_kernel<128>, dim3(mt2 * (L.Cout / 128)), dim3(512), LDS3_128, c.s, p);
-    else
-      hipLaunchKernelGGL(conv_igemm3_kernel<64>, dim3(mt2 * (L.Cout / 64)), dim3(512), LDS3_64, c.s, p);
+    FP_LAUNCH((conv_pp_kernel<128, DT, ODT>), dim3(((p.M + 255) / 256) * (L.Cout / 128)), dim3(512), LDS3_128, c.s, p);
     return 0;
   }
   if (L.Cout % 128 == 0) {
     ProfScope ps(c.prof, c.s, (tg + "/conv_igemm_kernel<128>").c_str(), flops, bytes);
     const dim3 grid(mtiles * (L.Cout / 128) * p.ksplit);
-    const int lds = 2 * (128 * 128 + 128 * 128);
-    switch (g_conv_variant) {
-      case 11: hipLaunchKernelGGL((conv_igemm_kernel<128, 1>), grid, dim3(256), lds, c.s, p); break;
-      case 12: hipLaunchKernelGGL((conv_igemm_kernel<128, 2>), grid, dim3(256), lds, c.s, p); break;
-      case 13: hipLaunchKernelGGL((conv_igemm_kernel<128, 3>), grid, dim3(256), lds, c.s, p); break;
-      case 10: hipLaunchKernelGGL((conv_igemm_kernel<128, 0>), grid, dim3(256), lds, c.s, p); break;
-      case 17: hipLaunchKernelGGL((conv_igemm_kernel<128, 7>), grid, dim3(256), lds, c.s, p); break;   // no loads
-      case 21: hipLaunchKernelGGL((conv_igemm_kernel<128, 11>), grid, dim3(256), lds, c.s, p); break;  // no MFMAs
-      case 25: hipLaunchKernelGGL((conv_igemm_kernel<128, 15>), grid, dim3(256), lds, c.s, p); break;  // neither
-      default: hipLaunchKernelGGL((conv_igemm_kernel<128, 3>), grid, dim3(256), lds, c.s, p); break;
+    bool done = false;
+#ifdef FP_TEST_HOOKS
+    if (DT == DT_F16 && g_conv_variant >= 10) {
+      done = true;
+      switch (g_conv_variant) {
+        case 10: FP_LAUNCH((conv_igemm_kernel<128, 0, DT_F16>), grid, dim3(256), LDS_IG128, c.s, p); break;
+        case 11: FP_LAUNCH((conv_igemm_kernel<128, 1, DT_F16>), grid, dim3(256), LDS_IG128, c.s, p); break;
+        case 12: FP_LAUNCH((conv_igemm_kernel<128, 2, DT_F16>), grid, dim3(256), LDS_IG128, c.s, p); break;
+        case 17: FP_LAUNCH((conv_igemm_kernel<128, 7, DT_F16>), grid, dim3(256), LDS_IG128, c.s, p); break;   // no loads
+        case 21: FP_LAUNCH((conv_igemm_kernel<128, 11, DT_F16>), grid, dim3(256), LDS_IG128, c.s, p); break;  // no MFMAs
+        case 25: FP_LAUNCH((conv_igemm_kernel<128, 15, DT_F16>), grid, dim3(256), LDS_IG128, c.s, p); break;  // neither
+        default: done = false;
+      }
     }
+#endif
+    if (!done) FP_LAUNCH((conv_igemm_kernel<128, 3, DT, ODT>), grid, dim3(256), LDS_IG128, c.s, p);
   } else {
     ProfScope ps(c.prof, c.s, (tg + "/conv_igemm_kernel<64>").c_str(), flops, bytes);
-    hipLaunchKernelGGL((conv_igemm_kernel<64, 3>), dim3(mtiles * (L.Cout / 64) * p.ksplit), dim3(256), 2 * (128 * 128 + 64 * 128), c.s, p);
+    FP_LAUNCH((conv_igemm_kernel<64, 3, DT, ODT>), dim3(mtiles * (L.Cout / 64) * p.ksplit), dim3(256), LDS_IG64, c.s, p);
   }
   if (p.ksplit > 1) {
     ProfScope ps(c.prof, c.s, (tg + "/conv_splitk_reduce_kernel").c_str(), 0, 0);
-    size_t quads = (size_t)(p.M - p.m_begin) * (p.Cout / 4);
-    hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, c.s, p);
+    size_t octs = (size_t)(p.M - p.m_begin) * (p.Cout / 8);
+    hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3((unsigned)((octs + 255) / 256)), dim3(256), 0, c.s, p);
   }
   return 0;
 }
 
-// plain GEMM rows x Cin -> rows x Cout (Linear layer) on unpadded buffers
-static int run_gemm(const Ctx &c, const char *tag, const ConvLayer &L, const __half *in, int rows, __half *out, bool relu,
-                    const __half *res = nullptr, const ConvGroup *grp = nullptr) {
-  return run_conv(c, tag, L, in, rows, 1, 1, 0, out, 0, relu, res, 0, 0, grp);
+static int run_conv(const Ctx &c, const char *tag, const ConvLayer &L, const Act &in, int NB, int H, int W, int ipad,
+                    const Act &out, int opad, bool relu, const Act *res = nullptr, int rpad = 0, int split_imgs = 0,
+                    const ConvGroup *grp = nullptr) {
+  ConvParams p;
+  FP_CHECK(in.dt == L.dt, "run_conv: input element type does not match the layer's weights");
+  FP_CHECK(L.dt != DT_FP8 || L.cscale, "run_conv: FP8 layer without scales");
+  const int es = elem_bytes(L.dt);
+  p.clk = g_clk_probe;
+  p.grp_rows = grp ? grp->rows : 0;
+  p.in_shared = grp && grp->in_shared;
+  p.res_shared = grp && grp->res_shared;
+  p.grp_w_bytes = grp ? (unsigned)((size_t)L.Cout * L.KH * L.KW * L.Cin * es) : 0;
+  FP_CHECK(!grp || (grp->rows % 128 == 0 && L.KH == 1 && L.KW == 1 && NB == 2 * grp->rows && L.dt != DT_FP8), "grouped launch: unsupported shape");
+  p.in = (const unsigned char *)in.p; p.w = L.w; p.bias = L.bias; p.cscale = L.dt == DT_FP8 ? L.cscale : nullptr;
+  p.res = res ? (const unsigned char *)res->p : nullptr; p.out = (unsigned char *)out.p;
+  p.out_dt = out.dt; p.res_dt = res ? res->dt : out.dt;
+  p.res_scale = res ? res->scale : 1.f;
+  p.out_inv = out.dt == DT_FP8 ? 1.f / out.scale : 1.f;
+  p.NB = NB; p.H = H; p.W = W; p.Cin = L.Cin;
+  p.KH = L.KH; p.KW = L.KW; p.stride = L.stride; p.pad = L.pad;
+  p.ipad = ipad; p.opad = opad; p.rpad = rpad;
+  p.OH = (H + 2 * L.pad - L.KH) / L.stride + 1;
+  p.OW = (W + 2 * L.pad - L.KW) / L.stride + 1;
+  if (L.KH == 4 && L.pad == 2 && L.stride == 1) { p.OH = H; p.OW = W; }  // s2d stem: asymmetric padding (2 before, 1 after)
+  p.Cout = L.Cout;
+  p.M = NB * p.OH * p.OW;
+  p.Ktot = L.KH * L.KW * L.Cin;
+  p.cin_b = L.Cin * es;
+  p.krow_b = p.Ktot * es;
+  p.ntaps = L.KH * L.KW;
+  p.relu = relu ? 1 : 0;
+  p.split_imgs = split_imgs;
+  p.out_ld = split_imgs > 0 ? 2 * L.Cout : L.Cout;
+  p.res_ld = L.Cout;
+  p.ksplit = 1; p.kt_per = p.krow_b / 128; p.partial = nullptr;
+  p.m_begin = 0;
+  FP_CHECK(ipad >= L.pad && (p.cin_b == 64 || p.cin_b % 128 == 0) && p.krow_b % 128 == 0 && (L.Cout % 64) == 0 &&
+               (p.cin_b != 64 || L.KW % 2 == 0) && p.krow_b / 128 <= 80,
+           "conv shape not supported by the MFMA kernel");
+  {
+    // K order: 128-byte channel chunks -> (chunk outer, tap inner); 64-byte pixels (s2d stem) -> two horizontally adjacent
+    // taps (128 contiguous bytes) per K-step.  koff = byte offset of the K-step's X slab from the row's (tap 0, ch 0) address.
+    const int IWp = W + 2 * ipad;
+    for (int kt = 0; kt < p.krow_b / 128; kt++) {
+      int kh, kw, ch;
+      if (p.cin_b >= 128) { ch = kt / p.ntaps; int tap = kt % p.ntaps; kh = tap / L.KW; kw = tap % L.KW; }
+      else { ch = 0; int tap = 2 * kt; kh = tap / L.KW; kw = tap % L.KW; }
+      p.koff[kt] = (unsigned)((kh * IWp + kw) * p.cin_b + ch * 128);
+      if (2 * kt + 1 < 160) { p.koff32[2 * kt] = p.koff[kt]; p.koff32[2 * kt + 1] = p.koff[kt] + 64; }
+    }
+  }
+  const bool hr = res != nullptr;
+  FP_CHECK(!res || res->dt == L.dt, "run_conv: the residual must have the layer's operand type");
+  if (L.dt == DT_FP8 && out.dt == DT_FP8) return run_conv_dt<DT_FP8, DT_FP8>(c, tag, L, p, NB, H, W, ipad, hr, split_imgs, grp);
+  if (L.dt == DT_FP8 && out.dt == DT_F16) return run_conv_dt<DT_FP8, DT_F16>(c, tag, L, p, NB, H, W, ipad, hr, split_imgs, grp);
+  if (L.dt == DT_F16 && out.dt == DT_FP8) return run_conv_dt<DT_F16, DT_FP8>(c, tag, L, p, NB, H, W, ipad, hr, split_imgs, grp);
+  if (L.dt == DT_BF16 && out.dt == DT_BF16) return run_conv_dt<DT_BF16, DT_BF16>(c, tag, L, p, NB, H, W, ipad, hr, split_imgs, grp);
+  if (L.dt == DT_F16 && out.dt == DT_F16) return run_conv_dt<DT_F16, DT_F16>(c, tag, L, p, NB, H, W, ipad, hr, split_imgs, grp);
+  FP_CHECK(false, "run_conv: unsupported combination of operand / output element types");
 }
 
-static int g_att_variant = 1;  // A/B hook (tools/ab_attention.py): 1 remap + 16-B stores, 3 no XCD remap, 5 remap + 2-B stores, 7 neither
-static int run_attention(const Ctx &c, const __half *qkv, __half *out, int B, int T, int tstride = 0) {
+// plain GEMM rows x Cin -> rows x Cout (Linear layer) on unpadded buffers
+static int run_gemm(const Ctx &c, const char *tag, const ConvLayer &L, const void *in, int rows, void *out, bool relu,
+                    const void *res = nullptr, const ConvGroup *grp = nullptr) {
+  Act ai{const_cast<void *>(in), L.dt, 1.f}, ao{out, L.dt, 1.f}, ar{const_cast<void *>(res), L.dt, 1.f};
+  return run_conv(c, tag, L, ai, rows, 1, 1, 0, ao, 0, relu, res ? &ar : nullptr, 0, 0, grp);
+}
+
+template <int DT>
+static void launch_attention(const Ctx &c, const void *qkv, void *out, int B, int T, int nq, int tstride) {
+  using E = typename ElemT<DT>::t;
+  dim3 grid((unsigned)(nq * HEADS * B)), blk(256);
+  const E *q = (const E *)qkv;
+  E *o = (E *)out;
+#ifdef FP_TEST_HOOKS
+  if (g_att_variant == 3) { hipLaunchKernelGGL((attention_kernel<64, false, true, DT>), grid, blk, 0, c.s, q, o, T, nq, tstride); return; }
+  if (g_att_variant == 5) { hipLaunchKernelGGL((attention_kernel<64, true, false, DT>), grid, blk, 0, c.s, q, o, T, nq, tstride); return; }
+  if (g_att_variant == 7) { hipLaunchKernelGGL((attention_kernel<64, false, false, DT>), grid, blk, 0, c.s, q, o, T, nq, tstride); return; }
+#endif
+  hipLaunchKernelGGL((attention_kernel<64, true, true, DT>), grid, blk, 0, c.s, q, o, T, nq, tstride);
+}
+static int run_attention(const Ctx &c, int dt, const void *qkv, void *out, int B, int T, int tstride = 0) {
   if (tstride == 0) tstride = T;
   double flops = 4.0 * (double)B * HEADS * (double)T * T * HDIM;
   ProfScope ps(c.prof, c.s, "attention", flops, (double)B * T * (1536 + 512) * 2.0);
   const int nq = (T + 63) / 64;
-  dim3 grid((unsigned)(nq * HEADS * B)), blk(256);
-  switch (g_att_variant) {
-    case 1: hipLaunchKernelGGL((attention_kernel<64, true>), grid, blk, 0, c.s, qkv, out, T, nq, tstride); break;
-    case 3: hipLaunchKernelGGL((attention_kernel<64, false>), grid, blk, 0, c.s, qkv, out, T, nq, tstride); break;
-    case 5: hipLaunchKernelGGL((attention_kernel<64, true, false>), grid, blk, 0, c.s, qkv, out, T, nq, tstride); break;
-    default: hipLaunchKernelGGL((attention_kernel<64, false, false>), grid, blk, 0, c.s, qkv, out, T, nq, tstride); break;
-  }
+  if (dt == DT_BF16) launch_attention<DT_BF16>(c, qkv, out, B, T, nq, tstride);
+  else launch_attention<DT_F16>(c, qkv, out, B, T, nq, tstride);
   return 0;
 }
 
-static void run_layernorm(const Ctx &c, const __half *x, const LNParams &ln, __half *y, size_t rows, const LNParams *ln1 = nullptr,
+static void run_layernorm(const Ctx &c, int dt, const void *x, const LNParams &ln, void *y, size_t rows, const LNParams *ln1 = nullptr,
                           size_t split_row = 0) {
   ProfScope ps(c.prof, c.s, "layernorm", 0, (double)rows * EMBED * 4.0);
-  hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, c.s, x, ln.g, ln.b, y, rows,
-                     ln1 ? ln1->g : ln.g, ln1 ? ln1->b : ln.b, ln1 ? split_row : rows);
+  const dim3 grid((unsigned)((rows + 3) / 4));
+  const float *g1 = ln1 ? ln1->g : ln.g, *b1 = ln1 ? ln1->b : ln.b;
+  const size_t sr = ln1 ? split_row : rows;
+  if (dt == DT_BF16) hipLaunchKernelGGL(layernorm_kernel<DT_BF16>, grid, dim3(256), 0, c.s, (const __bf16 *)x, ln.g, ln.b, (__bf16 *)y, rows, g1, b1, sr);
+  else hipLaunchKernelGGL(layernorm_kernel<DT_F16>, grid, dim3(256), 0, c.s, (const _Float16 *)x, ln.g, ln.b, (_Float16 *)y, rows, g1, b1, sr);
 }
 
 static void run_small_linear(const Ctx &c, const float *x, const LinearF32 &L, float *y, int B) {
@@ -2709,19 +3021,40 @@ static void run_small_linear(const Ctx &c, const float *x, const LinearF32 &L, f
   hipLaunchKernelGGL(small_linear_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, c.s, x, L.w, L.b, y, B, L.out, L.in);
 }
 
-static void run_token_mean(const Ctx &c, const __half *x, float *out, int B, int T, int tstride = 0) {
+static void run_token_mean(const Ctx &c, int dt, const void *x, float *out, int B, int T, int tstride = 0) {
   ProfScope ps(c.prof, c.s, "token_mean", 0, (double)B * T * EMBED * 2.0);
-  hipLaunchKernelGGL(token_mean_kernel, dim3(B, EMBED / 64), dim3(256), 0, c.s, x, out, T, tstride ? tstride : T);
+  if (dt == DT_BF16) hipLaunchKernelGGL(token_mean_kernel<DT_BF16>, dim3(B, EMBED / 64), dim3(256), 0, c.s, (const __bf16 *)x, out, T, tstride ? tstride : T);
+  else hipLaunchKernelGGL(token_mean_kernel<DT_F16>, dim3(B, EMBED / 64), dim3(256), 0, c.s, (const _Float16 *)x, out, T, tstride ? tstride : T);
+}
+
+// calibration: |max| of a tensor (2-byte element type) folded into slot[0] (bits of a non-negative float order like ints)
+template <int DT>
+__global__ __launch_bounds__(256) void amax_kernel(const typename ElemT<DT>::v8 *__restrict__ x, size_t n8, float *__restrict__ slot) {
+  float m = 0.f;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
+    const typename ElemT<DT>::v8 v = x[i];
+#pragma unroll
+    for (int e = 0; e < 8; e++) m = fmaxf(m, fabsf((float)v[e]));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(reinterpret_cast<int *>(slot), __float_as_int(m));
+}
+static void calib_record(const Ctx &c, int act_id, const void *buf, size_t bytes) {
+  if (!c.net->calib_on) return;
+  const size_t n8 = bytes / 16;
+  if (c.net->act_dt == DT_BF16) hipLaunchKernelGGL(amax_kernel<DT_BF16>, dim3(1024), dim3(256), 0, c.s, (const b8 *)buf, n8, c.net->calib_dev + act_id);
+  else hipLaunchKernelGGL(amax_kernel<DT_F16>, dim3(1024), dim3(256), 0, c.s, (const h8 *)buf, n8, c.net->calib_dev + act_id);
 }
 
 // arena carve (by capacity, see ensure_scratch)
 struct Arena {
-  __half *stem, *x128[3], *x256[3], *x512[3], *tokens, *qkv, *att, *y1, *y2;
+  unsigned char *stem, *x128[3], *x256[3], *x512[3], *tokens, *qkv, *att, *y1, *y2;
 };
 static Arena carve(NNScratch *ws) {
   Arena a;
   const size_t cap = (size_t)ws->cap;
-  __half *p = ws->buf;
+  unsigned char *p = ws->buf;
   a.stem = p; p += cap * SZ_STEM;
   for (int i = 0; i < 3; i++) { a.x128[i] = p; p += cap * SZ_128; }
   for (int i = 0; i < 3; i++) { a.x256[i] = p; p += cap * SZ_256; }
@@ -2736,49 +3069,77 @@ static Arena carve(NNScratch *ws) {
 
 // shared CNN trunk: nn_in [2N,84,84,32] (s2d, border 2) -> tokens [N,400,512] + positional embedding
 // n_b = number of observed-crop (B) images following the N rendered (A) images: N, or 1 when all hypotheses share it
-static int run_trunk(const Ctx &c, const Arena &a, const __half *nn_in, int N, int n_b) {
+static int run_trunk(const Ctx &c, const Arena &a, const void *nn_in, int N, int n_b) {
   const Net *net = c.net;
   const int NB2 = N + n_b;
-  if (run_conv(c, "conv_stem", net->a0, nn_in, NB2, 80, 80, 2, a.stem, 1, true)) return 1;
-  if (run_conv(c, "conv_a1", net->a1, a.stem, NB2, 80, 80, 1, a.x128[0], 1, true)) return 1;
+  const int adt = net->act_dt;                                  // nn_in, stem output, tokens
+  const int tdt = net->prec == PREC_FP8 ? DT_FP8 : adt;         // trunk activations from encodeA.1's output on
+  const float *sc = net->act_scale;                             // all 1 unless FP8
+  auto T = [&](void *p, int id) { return Act{p, tdt, tdt == DT_FP8 ? sc[id] : 1.f}; };
+  const size_t tes = elem_bytes(tdt);
+  const Act in{const_cast<void *>(nn_in), adt, 1.f}, stem{a.stem, adt, 1.f};
+  if (run_conv(c, "conv_stem", net->a0, in, NB2, 80, 80, 2, stem, 1, true)) return 1;
+  calib_record(c, 0, a.stem, (size_t)NB2 * 82 * 82 * 64 * 2);
+  const Act x0 = T(a.x128[0], 1), x1 = T(a.x128[1], 2), x2 = T(a.x128[2], 3), x1b = T(a.x128[1], 4), cat = T(a.x256[0], 5);
+  if (run_conv(c, "conv_a1", net->a1, stem, NB2, 80, 80, 1, x0, 1, true)) return 1;
+  calib_record(c, 1, a.x128[0], (size_t)NB2 * 42 * 42 * 128 * 2);
   // encodeA residual blocks @40x40x128; the last conv writes the a|b channel concat directly
-  if (run_conv(c, "conv_128", net->ra[0][0], a.x128[0], NB2, 40, 40, 1, a.x128[1], 1, true)) return 1;
-  if (run_conv(c, "conv_128", net->ra[0][1], a.x128[1], NB2, 40, 40, 1, a.x128[2], 1, true, a.x128[0], 1)) return 1;
-  if (run_conv(c, "conv_128", net->ra[1][0], a.x128[2], NB2, 40, 40, 1, a.x128[1], 1, true)) return 1;
-  if (run_conv(c, "conv_128", net->ra[1][1], a.x128[1], NB2, 40, 40, 1, a.x256[0], 1, true, a.x128[2], 1, N)) return 1;
+  if (run_conv(c, "conv_128", net->ra[0][0], x0, NB2, 40, 40, 1, x1, 1, true)) return 1;
+  calib_record(c, 2, a.x128[1], (size_t)NB2 * 42 * 42 * 128 * 2);
+  if (run_conv(c, "conv_128", net->ra[0][1], x1, NB2, 40, 40, 1, x2, 1, true, &x0, 1)) return 1;
+  calib_record(c, 3, a.x128[2], (size_t)NB2 * 42 * 42 * 128 * 2);
+  if (run_conv(c, "conv_128", net->ra[1][0], x2, NB2, 40, 40, 1, x1b, 1, true)) return 1;
+  calib_record(c, 4, a.x128[1], (size_t)NB2 * 42 * 42 * 128 * 2);
+  if (run_conv(c, "conv_128", net->ra[1][1], x1b, NB2, 40, 40, 1, cat, 1, true, &x2, 1, N)) return 1;
   if (n_b == 1 && N > 1) {  // image N landed in cat[0][..,128:256]; replicate it for the other hypotheses
     ProfScope ps(c.prof, c.s, "broadcast_b", 0, (double)N * 1600 * 256);
-    size_t total = (size_t)(N - 1) * 1600 * 16;
-    hipLaunchKernelGGL(broadcast_b_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c.s, a.x256[0], N, 42, 42, 40, 40, 1, 128);
+    size_t total = (size_t)(N - 1) * 1600 * (128 * tes / 16);
+    hipLaunchKernelGGL(broadcast_b_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c.s, a.x256[0], N, 42, 42, 40, 40, 1, (int)(128 * tes));
   }
+  calib_record(c, 5, a.x256[0], (size_t)N * 42 * 42 * 256 * 2);
   // encodeAB
-  if (run_conv(c, "conv_256", net->rb[0][0], a.x256[0], N, 40, 40, 1, a.x256[1], 1, true)) return 1;
-  if (run_conv(c, "conv_256", net->rb[0][1], a.x256[1], N, 40, 40, 1, a.x256[2], 1, true, a.x256[0], 1)) return 1;
-  if (run_conv(c, "conv_256", net->rb[1][0], a.x256[2], N, 40, 40, 1, a.x256[1], 1, true)) return 1;
-  if (run_conv(c, "conv_256", net->rb[1][1], a.x256[1], N, 40, 40, 1, a.x256[0], 1, true, a.x256[2], 1)) return 1;
-  if (run_conv(c, "conv_b2", net->b2, a.x256[0], N, 40, 40, 1, a.x512[0], 1, true)) return 1;
-  if (run_conv(c, "conv_512", net->rc[0][0], a.x512[0], N, 20, 20, 1, a.x512[1], 1, true)) return 1;
-  if (run_conv(c, "conv_512", net->rc[0][1], a.x512[1], N, 20, 20, 1, a.x512[2], 1, true, a.x512[0], 1)) return 1;
-  if (run_conv(c, "conv_512", net->rc[1][0], a.x512[2], N, 20, 20, 1, a.x512[1], 1, true)) return 1;
-  // last conv writes the un-bordered token tensor [N,400,512]
-  if (run_conv(c, "conv_512", net->rc[1][1], a.x512[1], N, 20, 20, 1, a.tokens, 0, true, a.x512[2], 1)) return 1;
+  const Act y1 = T(a.x256[1], 6), y2 = T(a.x256[2], 7), y1b = T(a.x256[1], 8), y0 = T(a.x256[0], 9);
+  if (run_conv(c, "conv_256", net->rb[0][0], cat, N, 40, 40, 1, y1, 1, true)) return 1;
+  calib_record(c, 6, a.x256[1], (size_t)N * 42 * 42 * 256 * 2);
+  if (run_conv(c, "conv_256", net->rb[0][1], y1, N, 40, 40, 1, y2, 1, true, &cat, 1)) return 1;
+  calib_record(c, 7, a.x256[2], (size_t)N * 42 * 42 * 256 * 2);
+  if (run_conv(c, "conv_256", net->rb[1][0], y2, N, 40, 40, 1, y1b, 1, true)) return 1;
+  calib_record(c, 8, a.x256[1], (size_t)N * 42 * 42 * 256 * 2);
+  if (run_conv(c, "conv_256", net->rb[1][1], y1b, N, 40, 40, 1, y0, 1, true, &y2, 1)) return 1;
+  calib_record(c, 9, a.x256[0], (size_t)N * 42 * 42 * 256 * 2);
+  const Act z0 = T(a.x512[0], 10), z1 = T(a.x512[1], 11), z2 = T(a.x512[2], 12), z1b = T(a.x512[1], 13);
+  if (run_conv(c, "conv_b2", net->b2, y0, N, 40, 40, 1, z0, 1, true)) return 1;
+  calib_record(c, 10, a.x512[0], (size_t)N * 22 * 22 * 512 * 2);
+  if (run_conv(c, "conv_512", net->rc[0][0], z0, N, 20, 20, 1, z1, 1, true)) return 1;
+  calib_record(c, 11, a.x512[1], (size_t)N * 22 * 22 * 512 * 2);
+  if (run_conv(c, "conv_512", net->rc[0][1], z1, N, 20, 20, 1, z2, 1, true, &z0, 1)) return 1;
+  calib_record(c, 12, a.x512[2], (size_t)N * 22 * 22 * 512 * 2);
+  if (run_conv(c, "conv_512", net->rc[1][0], z2, N, 20, 20, 1, z1b, 1, true)) return 1;
+  calib_record(c, 13, a.x512[1], (size_t)N * 22 * 22 * 512 * 2);
+  // last conv writes the un-bordered token tensor [N,400,512] (2-byte type in every precision)
+  const Act tok{a.tokens, adt, 1.f};
+  if (run_conv(c, "conv_512", net->rc[1][1], z1b, N, 20, 20, 1, tok, 0, true, &z2, 1)) return 1;
   {
     size_t rows = (size_t)N * 400;
     ProfScope ps(c.prof, c.s, "add_pos_embed", 0, (double)rows * EMBED * 4.0);
     size_t chunks = rows * (EMBED / 8);
-    hipLaunchKernelGGL(add_pos_embed_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, c.s, a.tokens, net->pe, 400, rows);
+    const dim3 grid((unsigned)((chunks + 255) / 256));
+    if (adt == DT_BF16) hipLaunchKernelGGL(add_pos_embed_kernel<DT_BF16>, grid, dim3(256), 0, c.s, (__bf16 *)a.tokens, (const __bf16 *)net->pe, 400, rows);
+    else hipLaunchKernelGGL(add_pos_embed_kernel<DT_F16>, grid, dim3(256), 0, c.s, (_Float16 *)a.tokens, (const _Float16 *)net->pe, 400, rows);
   }
   return 0;
 }
 
-int refiner_forward(hipStream_t s, Profiler *prof, const Net *net, NNScratch *ws, const __half *nn_in, int N,
+int refiner_forward(hipStream_t s, Profiler *prof, const Net *net, NNScratch *ws, const void *nn_in, int N,
                     float *trans_dev, float *rot_dev, int shared_b) {
   FP_CHECK(net && !net->scorer, "refiner_forward: wrong network");
+  FP_CHECK(net_fp8_ready(net), "[FoundationPose] FP8 precision needs activation scales: call fp_calibrate_fp8 first");
   if (ensure_scratch(ws, N, s)) return 1;
   Ctx c{s, prof, net, ws};
   const Arena a = carve(ws);
   if (run_trunk(c, a, nn_in, N, shared_b ? 1 : N)) return 1;
-  const __half *x = a.tokens;
+  const int dt = net->act_dt;
+  const void *x = a.tokens;
   const size_t rows = (size_t)N * 400;
   const EncLayer *heads[2] = {&net->trans, &net->rot};
   float *outs[2] = {trans_dev, rot_dev};
@@ -2790,13 +3151,13 @@ int refiner_forward(hipStream_t s, Profiler *prof, const Net *net, NNScratch *ws
     ConvGroup g_x{G, true, true}, g_in{G, false, true}, g_own{G, false, false};
     const EncLayer &T0 = net->trans, &R0 = net->rot;
     if (run_gemm(c, "gemm_qkv", net->g_in_proj, x, 2 * G, a.qkv, false, nullptr, &g_x)) return 1;
-    if (run_attention(c, a.qkv, a.att, 2, 400, G)) return 1;
+    if (run_attention(c, dt, a.qkv, a.att, 2, 400, G)) return 1;
     if (run_gemm(c, "gemm_512", net->g_out_proj, a.att, 2 * G, a.y1, false, x, &g_in)) return 1;   // + residual x (shared)
-    run_layernorm(c, a.y1, T0.ln1, a.y2, 2 * G, &R0.ln1, G);
+    run_layernorm(c, dt, a.y1, T0.ln1, a.y2, 2 * G, &R0.ln1, G);
     if (run_gemm(c, "gemm_512", net->g_lin1, a.y2, 2 * G, a.y1, true, nullptr, &g_own)) return 1;
     if (run_gemm(c, "gemm_512", net->g_lin2, a.y1, 2 * G, a.att, false, a.y2, &g_own)) return 1;   // + residual x1
-    run_layernorm(c, a.att, T0.ln2, a.y1, 2 * G, &R0.ln2, G);
-    run_token_mean(c, a.y1, ws->f32, 2, 400, G);
+    run_layernorm(c, dt, a.att, T0.ln2, a.y1, 2 * G, &R0.ln2, G);
+    run_token_mean(c, dt, a.y1, ws->f32, 2, 400, G);
     run_small_linear(c, ws->f32, T0.head, trans_dev, 1);
     run_small_linear(c, ws->f32 + EMBED, R0.head, rot_dev, 1);
     FP_HIP_OK(hipGetLastError());
@@ -2806,30 +3167,31 @@ int refiner_forward(hipStream_t s, Profiler *prof, const Net *net, NNScratch *ws
     const EncLayer &L = *heads[i];
     // post-norm TransformerEncoderLayer: x1 = LN1(x + SA(x)); x2 = LN2(x1 + W2 relu(W1 x1))
     if (run_gemm(c, "gemm_qkv", L.att.in_proj, x, (int)rows, a.qkv, false)) return 1;
-    if (run_attention(c, a.qkv, a.att, N, 400)) return 1;
+    if (run_attention(c, dt, a.qkv, a.att, N, 400)) return 1;
     if (run_gemm(c, "gemm_512", L.att.out_proj, a.att, (int)rows, a.y1, false, x)) return 1;  // + residual x
-    run_layernorm(c, a.y1, L.ln1, a.y2, rows);                                               // x1 = y2
+    run_layernorm(c, dt, a.y1, L.ln1, a.y2, rows);                                           // x1 = y2
     if (run_gemm(c, "gemm_512", L.lin1, a.y2, (int)rows, a.y1, true)) return 1;
     if (run_gemm(c, "gemm_512", L.lin2, a.y1, (int)rows, a.att, false, a.y2)) return 1;       // + residual x1
-    run_layernorm(c, a.att, L.ln2, a.y1, rows);
-    run_token_mean(c, a.y1, ws->f32, N, 400);
+    run_layernorm(c, dt, a.att, L.ln2, a.y1, rows);
+    run_token_mean(c, dt, a.y1, ws->f32, N, 400);
     run_small_linear(c, ws->f32, L.head, outs[i], N);  // Linear(512,3) commutes with the token mean
   }
   FP_HIP_OK(hipGetLastError());
   return 0;
 }
 
-int scorer_features(hipStream_t s, Profiler *prof, const Net *net, NNScratch *ws, const __half *nn_in, int N, float *feat_dev) {
+int scorer_features(hipStream_t s, Profiler *prof, const Net *net, NNScratch *ws, const void *nn_in, int N, float *feat_dev) {
   FP_CHECK(net && net->scorer, "scorer_features: wrong network");
+  FP_CHECK(net_fp8_ready(net), "[FoundationPose] FP8 precision needs activation scales: call fp_calibrate_fp8 first");
   if (ensure_scratch(ws, N, s)) return 1;
   Ctx c{s, prof, net, ws};
   const Arena a = carve(ws);
   if (run_trunk(c, a, nn_in, N, N)) return 1;
   const size_t rows = (size_t)N * 400;
   if (run_gemm(c, "gemm_qkv", net->att.in_proj, a.tokens, (int)rows, a.qkv, false)) return 1;
-  if (run_attention(c, a.qkv, a.att, N, 400)) return 1;
+  if (run_attention(c, net->act_dt, a.qkv, a.att, N, 400)) return 1;
   // feature = mean_t(out_proj(att)) = out_proj(mean_t(att))  (out_proj is affine) -> 512x512 GEMV per hypothesis
-  run_token_mean(c, a.att, ws->f32, N, 400);
+  run_token_mean(c, net->act_dt, a.att, ws->f32, N, 400);
   run_small_linear(c, ws->f32, net->att.out_proj_f32, feat_dev, N);
   FP_HIP_OK(hipGetLastError());
   return 0;
@@ -2839,27 +3201,29 @@ int scorer_head(hipStream_t s, Profiler *prof, const Net *net, NNScratch *ws, co
   FP_CHECK(net && net->scorer, "scorer_head: wrong network");
   if (ensure_head_scratch(ws, n_total)) return 1;
   Ctx c{s, prof, net, ws};
-  const int N = n_total;
-  __half *p = ws->head_buf;
-  __half *xf = p; p += (size_t)N * EMBED;
-  __half *qkv = p; p += (size_t)N * 3 * EMBED;
-  __half *att = p; p += (size_t)N * EMBED;
+  const int N = n_total, dt = net->act_dt;
+  unsigned char *p = ws->head_buf;
+  unsigned char *xf = p; p += (size_t)N * EMBED * 2;
+  unsigned char *qkv = p; p += (size_t)N * 3 * EMBED * 2;
+  unsigned char *att = p; p += (size_t)N * EMBED * 2;
   float *o32 = ws->head_f32;                  // [N,512]
   {
     ProfScope ps(c.prof, c.s, "cast", 0, (double)N * EMBED * 6.0);
     size_t n = (size_t)N * EMBED;
-    hipLaunchKernelGGL(cast_f32_f16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c.s, feats_dev, xf, n);
+    const dim3 grid((unsigned)((n + 255) / 256));
+    if (dt == DT_BF16) hipLaunchKernelGGL(cast_f32_kernel<DT_BF16>, grid, dim3(256), 0, c.s, feats_dev, (__bf16 *)xf, n);
+    else hipLaunchKernelGGL(cast_f32_kernel<DT_F16>, grid, dim3(256), 0, c.s, feats_dev, (_Float16 *)xf, n);
   }
   // att_cross: sequence = the N hypotheses, batch 1
   if (run_gemm(c, "gemm_cross", net->att_cross.in_proj, xf, N, qkv, false)) return 1;
-  if (run_attention(c, qkv, att, 1, N)) return 1;
+  if (run_attention(c, dt, qkv, att, 1, N)) return 1;
   // out_proj through the same MFMA GEMM (M = N rows), then Linear(512,1) in f32
   if (run_gemm(c, "gemm_cross", net->att_cross.out_proj, att, N, xf, false)) return 1;
   {
-    // Linear(512,1) on fp16 rows: widen to f32 first (tiny)
+    // Linear(512,1) on 2-byte rows: widen to f32 first (token_mean with T = 1 is a plain copy of each row)
     ProfScope ps(c.prof, c.s, "score_linear", 2.0 * N * EMBED, 0);
-    // token_mean with T = 1 is a plain fp16 -> f32 copy of each row
-    hipLaunchKernelGGL(token_mean_kernel, dim3(N, EMBED / 64), dim3(256), 0, c.s, xf, o32, 1, 1);
+    if (dt == DT_BF16) hipLaunchKernelGGL(token_mean_kernel<DT_BF16>, dim3(N, EMBED / 64), dim3(256), 0, c.s, (const __bf16 *)xf, o32, 1, 1);
+    else hipLaunchKernelGGL(token_mean_kernel<DT_F16>, dim3(N, EMBED / 64), dim3(256), 0, c.s, (const _Float16 *)xf, o32, 1, 1);
   }
   run_small_linear(c, o32, net->score_lin, scores_dev, N);
   FP_HIP_OK(hipGetLastError());
@@ -2868,6 +3232,7 @@ int scorer_head(hipStream_t s, Profiler *prof, const Net *net, NNScratch *ws, co
 
 }  // namespace fp
 
+#ifdef FP_TEST_HOOKS
 // =================================================================================================
 // MFMA micro-benchmark (measurement only): every wave issues `iters` x 8 independent v_mfma_f32_16x16x32_f16 from
 // registers -- the rate the matrix pipes sustain with all 256 CUs busy at whatever clock the power limit allows.
@@ -2918,10 +3283,33 @@ std::vector<__half> to_half(const float *src, size_t n) {
   for (size_t i = 0; i < n; i++) h[i] = __float2half(src[i]);
   return h;
 }
+// float <-> element bytes of a tensor (FP8: stored = real / scale)
+std::vector<unsigned char> encode(const float *src, size_t n, int dt, float scale) {
+  std::vector<float> tmp(src, src + n);
+  if (dt == fp::DT_FP8) {
+    std::vector<unsigned char> o(n);
+    for (size_t i = 0; i < n; i++) o[i] = fp::f32_to_e4m3_bits(src[i] / scale);
+    return o;
+  }
+  return fp::to_elems(tmp, 1, (int)n, dt, nullptr);
+}
+float e4m3_to_f32(unsigned char b) {
+  const int e = (b >> 3) & 15, m = b & 7;
+  float v = e == 0 ? std::ldexp((float)m, -9) : std::ldexp(1.0f + m / 8.0f, e - 7);
+  return (b & 0x80) ? -v : v;
+}
+void decode(const unsigned char *src, size_t n, int dt, float scale, float *dst) {
+  for (size_t i = 0; i < n; i++) {
+    if (dt == fp::DT_FP8) dst[i] = e4m3_to_f32(src[i]) * scale;
+    else if (dt == fp::DT_BF16) { uint32_t u = (uint32_t)reinterpret_cast<const uint16_t *>(src)[i] << 16; std::memcpy(&dst[i], &u, 4); }
+    else dst[i] = __half2float(reinterpret_cast<const __half *>(src)[i]);
+  }
+}
 }  // namespace
 
 extern "C" {
 
+void fpt_set_att_variant(int v) { fp::g_att_variant = v; }
 void fpt_set_conv_variant(int v) { fp::g_conv_variant = v; }
 void fpt_set_conv_ablate(int v) { fp::g_conv_ablate = v; }
 void fpt_set_splitk_target(int v) { fp::g_splitk_target = v; }
@@ -2957,49 +3345,57 @@ int fpt_clk_probe(int blocks, double *mhz_out, double *loop_cycles_out) {
   return 0;
 }
 
-// x [NB,H,W,Cin] NHWC f32, w [Cout,KH,KW,Cin] f32 (already in kernel layout), bias [Cout], res (optional) [NB,OH,OW,Cout]
+// x [NB,H,W,Cin] NHWC f32, w [Cout,KH,KW,Cin] f32, bias [Cout], res (optional) [NB,OH,OW,Cout]
 // -> out f32 [NB,OH,OW,Cout] (or, with split_imgs > 0, [NB-split,OH,OW,2*Cout]).  iters > 1: returns mean ms in *ms_out.
-int fpt_conv(const float *x, const float *w, const float *bias, const float *res, int NB, int H, int W, int Cin, int Cout,
-             int KH, int KW, int stride, int pad, int OH, int OW, int relu, int split_imgs, float *out, int iters,
-             float *ms_out) {
+// dt = element type of x / w / res on the device (DT_*), out_dt = element type of the output.  FP8 tensors are stored as
+// real / scale (in_scale, res_scale, out_scale); FP8 weights are quantised per output channel exactly like net_load does.
+int fpt_conv_dt(const float *x, const float *w, const float *bias, const float *res, int NB, int H, int W, int Cin, int Cout,
+                int KH, int KW, int stride, int pad, int OH, int OW, int relu, int split_imgs, float *out, int iters,
+                float *ms_out, int dt, int out_dt, float in_scale, float res_scale, float out_scale) {
   using namespace fp;
   const int ip = pad;  // physical input border
   const int Hp = H + 2 * ip, Wp = W + 2 * ip;
+  const int es = elem_bytes(dt), oes = elem_bytes(out_dt);
   size_t nx = (size_t)NB * Hp * Wp * Cin, nw = (size_t)Cout * KH * KW * Cin;
   size_t M = (size_t)NB * OH * OW;
   size_t nout = M * Cout;
-  DevBuf<__half> dx(nx), dw(nw), dres(nout), dout(nout * 2);
-  DevBuf<float> db(Cout);
-  FP_CHECK(dx.p && dw.p && dres.p && dout.p && db.p, "fpt_conv: allocation failed");
-  std::vector<__half> hx(nx, __float2half(0.f));
+  DevBuf<unsigned char> dx(nx * es), dres(nout * es), dout(nout * 2 * oes);
+  FP_CHECK(dx.p && dres.p && dout.p, "fpt_conv: allocation failed");
+  std::vector<float> xp(nx, 0.f);
   for (int n = 0; n < NB; n++)
     for (int y = 0; y < H; y++)
       for (int xx = 0; xx < W; xx++)
         for (int c = 0; c < Cin; c++)
-          hx[(((size_t)n * Hp + y + ip) * Wp + xx + ip) * Cin + c] = __float2half(x[(((size_t)n * H + y) * W + xx) * Cin + c]);
-  auto hw = permute_rows(relayout_k(to_half(w, nw), Cout, KH * KW, Cin), Cout, KH * KW * Cin);
-  FP_HIP_OK(hipMemcpy(dx.p, hx.data(), nx * 2, hipMemcpyHostToDevice));
-  FP_HIP_OK(hipMemcpy(dw.p, hw.data(), nw * 2, hipMemcpyHostToDevice));
-  FP_HIP_OK(hipMemcpy(db.p, bias, (size_t)Cout * 4, hipMemcpyHostToDevice));
-  FP_HIP_OK(hipMemset(dout.p, 0, nout * 4));
+          xp[(((size_t)n * Hp + y + ip) * Wp + xx + ip) * Cin + c] = x[(((size_t)n * H + y) * W + xx) * Cin + c];
+  auto hx = encode(xp.data(), nx, dt, in_scale);
+  FP_HIP_OK(hipMemcpy(dx.p, hx.data(), hx.size(), hipMemcpyHostToDevice));
+  FP_HIP_OK(hipMemset(dout.p, 0, nout * 2 * oes));
   if (res) {
-    auto hr = to_half(res, nout);
-    FP_HIP_OK(hipMemcpy(dres.p, hr.data(), nout * 2, hipMemcpyHostToDevice));
+    auto hr = encode(res, nout, dt, res_scale);
+    FP_HIP_OK(hipMemcpy(dres.p, hr.data(), hr.size(), hipMemcpyHostToDevice));
   }
   Net net;
   ConvLayer L;
-  L.w = dw.p; L.bias = db.p; L.Cin = Cin; L.Cout = Cout; L.KH = KH; L.KW = KW; L.stride = stride; L.pad = pad;
+  L.Cin = Cin; L.Cout = Cout; L.KH = KH; L.KW = KW; L.stride = stride; L.pad = pad;
+  FP_CHECK(finish_layer(&net, std::vector<float>(w, w + nw), std::vector<float>(bias, bias + Cout), Cout, KH * KW, Cin, dt, &L), "fpt_conv: weight upload failed");
+  if (dt == DT_FP8) {
+    std::vector<float> cs(Cout);
+    FP_HIP_OK(hipMemcpy(cs.data(), L.wscale, (size_t)Cout * 4, hipMemcpyDeviceToHost));
+    for (auto &v : cs) v *= in_scale;
+    FP_HIP_OK(hipMemcpy(L.cscale, cs.data(), (size_t)Cout * 4, hipMemcpyHostToDevice));
+  }
   Ctx c{nullptr, nullptr, &net};
   (void)OH; (void)OW;
+  const Act ain{dx.p, dt, in_scale}, aout{dout.p, out_dt, out_scale}, ares{dres.p, dt, res_scale};
   hipEvent_t e0, e1;
   FP_HIP_OK(hipEventCreate(&e0));
   FP_HIP_OK(hipEventCreate(&e1));
-  if (run_conv(c, "t", L, dx.p, NB, H, W, ip, dout.p, 0, relu != 0, res ? dres.p : nullptr, 0, split_imgs)) return 1;
+  if (run_conv(c, "t", L, ain, NB, H, W, ip, aout, 0, relu != 0, res ? &ares : nullptr, 0, split_imgs)) return 1;
   FP_HIP_OK(hipDeviceSynchronize());
   if (iters > 1) {
     FP_HIP_OK(hipEventRecord(e0, nullptr));
     for (int i = 0; i < iters; i++)
-      if (run_conv(c, "t", L, dx.p, NB, H, W, ip, dout.p, 0, relu != 0, res ? dres.p : nullptr, 0, split_imgs)) return 1;
+      if (run_conv(c, "t", L, ain, NB, H, W, ip, aout, 0, relu != 0, res ? &ares : nullptr, 0, split_imgs)) return 1;
     FP_HIP_OK(hipEventRecord(e1, nullptr));
     FP_HIP_OK(hipEventSynchronize(e1));
     float ms = 0;
@@ -3008,28 +3404,35 @@ int fpt_conv(const float *x, const float *w, const float *bias, const float *res
   }
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
-  std::vector<__half> ho(nout);
-  FP_HIP_OK(hipMemcpy(ho.data(), dout.p, nout * 2, hipMemcpyDeviceToHost));
-  for (size_t i = 0; i < nout; i++) out[i] = __half2float(ho[i]);
+  std::vector<unsigned char> ho(nout * oes);
+  FP_HIP_OK(hipMemcpy(ho.data(), dout.p, ho.size(), hipMemcpyDeviceToHost));
+  decode(ho.data(), nout, out_dt, out_scale, out);
   return 0;
+}
+int fpt_conv(const float *x, const float *w, const float *bias, const float *res, int NB, int H, int W, int Cin, int Cout,
+             int KH, int KW, int stride, int pad, int OH, int OW, int relu, int split_imgs, float *out, int iters,
+             float *ms_out) {
+  return fpt_conv_dt(x, w, bias, res, NB, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW, relu, split_imgs, out, iters, ms_out,
+                     fp::DT_F16, fp::DT_F16, 1.f, 1.f, 1.f);
 }
 
-// qkv f32 [B,T,1536] -> out f32 [B,T,512]
-int fpt_attention(const float *qkv, int B, int T, float *out) {
+// qkv f32 [B,T,1536] -> out f32 [B,T,512]; dt = DT_F16 / DT_BF16
+int fpt_attention_dt(const float *qkv, int B, int T, float *out, int dt) {
   using namespace fp;
   size_t nq = (size_t)B * T * 1536, no = (size_t)B * T * 512;
-  DevBuf<__half> dq(nq), dout(no);
+  DevBuf<unsigned char> dq(nq * 2), dout(no * 2);
   FP_CHECK(dq.p && dout.p, "fpt_attention: allocation failed");
-  auto hq = to_half(qkv, nq);
+  auto hq = encode(qkv, nq, dt, 1.f);
   FP_HIP_OK(hipMemcpy(dq.p, hq.data(), nq * 2, hipMemcpyHostToDevice));
   Ctx c{nullptr, nullptr, nullptr};
-  if (run_attention(c, dq.p, dout.p, B, T)) return 1;
+  if (run_attention(c, dt, dq.p, dout.p, B, T)) return 1;
   FP_HIP_OK(hipDeviceSynchronize());
-  std::vector<__half> ho(no);
+  std::vector<unsigned char> ho(no * 2);
   FP_HIP_OK(hipMemcpy(ho.data(), dout.p, no * 2, hipMemcpyDeviceToHost));
-  for (size_t i = 0; i < no; i++) out[i] = __half2float(ho[i]);
+  decode(ho.data(), no, dt, 1.f, out);
   return 0;
 }
+int fpt_attention(const float *qkv, int B, int T, float *out) { return fpt_attention_dt(qkv, B, T, out, fp::DT_F16); }
 
 
 // concurrency stress: `nthreads` host threads, each with its own stream and buffers, run the same convolution `iters`
@@ -3079,13 +3482,14 @@ long long fpt_conv_stress(int NB0, int H0, int Cin0, int Cout0, int with_res, in
       (void)hipMemset(dcnt.p, 0, 8);
       Net net;
       ConvLayer L;
-      L.w = dw.p; L.bias = db.p; L.Cin = Cin; L.Cout = Cout; L.KH = 3; L.KW = 3; L.stride = 1; L.pad = 1;
+      L.w = (unsigned char *)dw.p; L.bias = db.p; L.Cin = Cin; L.Cout = Cout; L.KH = 3; L.KW = 3; L.stride = 1; L.pad = 1;
       NNScratch ws;
       Ctx c{s, nullptr, &net, &ws};
-      if (run_conv(c, "t", L, dx.p, NB, H, H, 1, dref.p, 1, true, with_res ? dres.p : nullptr, 1, 0)) return;
+      const Act ain{dx.p, DT_F16, 1.f}, aref{dref.p, DT_F16, 1.f}, aout{dout.p, DT_F16, 1.f}, ares{dres.p, DT_F16, 1.f};
+      if (run_conv(c, "t", L, ain, NB, H, H, 1, aref, 1, true, with_res ? &ares : nullptr, 1, 0)) return;
       (void)hipStreamSynchronize(s);
       for (int i = 0; i < iters; i++) {
-        if (run_conv(c, "t", L, dx.p, NB, H, H, 1, dout.p, 1, true, with_res ? dres.p : nullptr, 1, 0)) return;
+        if (run_conv(c, "t", L, ain, NB, H, H, 1, aout, 1, true, with_res ? &ares : nullptr, 1, 0)) return;
         hipLaunchKernelGGL(fpt_count_diff_kernel, dim3(1024), dim3(256), 0, s, (const uint32_t *)dout.p, (const uint32_t *)dref.p,
                            nout / 2, dcnt.p);
       }
@@ -3192,8 +3596,6 @@ long long fpt_visibility_stress(int nthreads, int iters, int mbytes) {
   return tot;
 }
 
-void fpt_set_att_variant(int v) { fp::g_att_variant = v; }
-
 // timing hook: random QKV resident in HBM, `iters` launches, returns ms per launch (negative on failure)
 float fpt_attention_bench(int B, int T, int iters, int variant) {
   using namespace fp;
@@ -3209,9 +3611,9 @@ float fpt_attention_bench(int B, int T, int iters, int variant) {
   g_att_variant = variant;
   hipEvent_t e0, e1;
   if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return -1.f;
-  for (int i = 0; i < 3; i++) run_attention(c, dq.p, dout.p, B, T);
+  for (int i = 0; i < 3; i++) run_attention(c, DT_F16, dq.p, dout.p, B, T);
   (void)hipEventRecord(e0, nullptr);
-  for (int i = 0; i < iters; i++) run_attention(c, dq.p, dout.p, B, T);
+  for (int i = 0; i < iters; i++) run_attention(c, DT_F16, dq.p, dout.p, B, T);
   (void)hipEventRecord(e1, nullptr);
   float ms = -1.f;
   if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) ms = -(float)iters;
@@ -3254,3 +3656,4 @@ float fpt_mfma_peak(int iters, int waves_per_simd, int zero_operands, double *mh
 }
 
 }  // extern "C"
+#endif  // FP_TEST_HOOKS

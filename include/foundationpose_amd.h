@@ -15,7 +15,8 @@
  *   - every function returning int returns 0 on success, non-zero on failure; fp_last_error() describes it
  *     (the reference returns bool + a glog line, D6F/src/foundationpose_utils.hpp:76-84).
  *   - not re-entrant per model (like the reference: one renderer / scratch set per target,
- *     D6F/src/foundationpose.cpp:103-105).
+ *     D6F/src/foundationpose.cpp:103-105); DIFFERENT models may be driven from different threads concurrently, each runs
+ *     on its own non-blocking stream and their kernels overlap on the GPU.
  *   - memspace arguments: FP_HOST pointers are ordinary host memory, FP_DEVICE pointers are HIP device memory on
  *     the model's device (lets callers keep frames resident in HBM).
  */
@@ -150,6 +151,26 @@ int fp_image_write_png_rgb(const char *path, const uint8_t *rgb, int H, int W);
 /* draw3DBoundingBox (help_func.hpp:55-106): green 12-edge box of `dimension` under the column-major bbox->camera `pose`
  * (= ConvertPoseMesh2BBox(pose_in_mesh, loader), mesh_loader.hpp:75-81), drawn into rgb in place. */
 int fp_draw_bbox3d(uint8_t *rgb, int H, int W, const float K[9], const float pose[16], const float dimension[3]);
+
+/* ---- network precision ----------------------------------------------------------------------------------------------
+ * The reference runs TensorRT engines built with --fp16 (tools/cvt_onnx2trt.bash:3-15): FP_PREC_F16 is the default and
+ * the parity baseline.  FP_PREC_BF16: every tensor and MFMA operand in bf16 (BASELINE configs[1]).  FP_PREC_FP8: the 3x3
+ * trunk convolutions from encodeA.2 on (91 % of the FLOPs) on OCP e4m3 operands (v_mfma_f32_16x16x128_f8f6f4) with
+ * per-output-channel weight scales and static per-tensor activation scales, everything else f16 (BASELINE configs[4]);
+ * needs fp_calibrate_fp8 / fp_set_calibration first.  Networks of a precision are built from the weight files given to
+ * fp_create the first time the precision is selected. */
+#define FP_PREC_F16 0
+#define FP_PREC_BF16 1
+#define FP_PREC_FP8 2
+int fp_set_precision(fp_model *m, int precision);
+int fp_get_precision(const fp_model *m);
+/* Post-training static quantisation: one Register of the frame in f16 with |max| collection on the 15 trunk activations
+ * of both networks.  The pose is discarded; the model's precision is unchanged. */
+int fp_calibrate_fp8(fp_model *m, const void *rgb, const void *depth, const void *mask, int memspace, int H, int W,
+                     const char *target_name);
+/* The collected |max| values ([refiner 16 | scorer 16], 15 used each) so that a deployment can calibrate once and reuse. */
+int fp_get_calibration(const fp_model *m, float amax_out[32]);
+int fp_set_calibration(fp_model *m, const float amax[32]);
 
 /* ---- measurement hooks ---- */
 /* When enabled, every kernel launch is bracketed with HIP events on the model's stream and accumulated per kernel

@@ -2,6 +2,7 @@
 import os, sys, tempfile, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from foundationpose_cpp_amd import FoundationPose, synthetic as syn, weights as W, _lib
+_lib.use_test_lib()
 L = _lib.lib()
 mesh = syn.make_mesh(); scene = syn.make_scene(mesh)
 d = tempfile.mkdtemp(); rp, sp = os.path.join(d, "r.fpw"), os.path.join(d, "s.fpw")

@@ -6,6 +6,7 @@ mesh = syn.make_mesh(); scene = syn.make_scene(mesh)
 m = FoundationPose(mesh, scene.K)
 m.upload_frame(scene.rgb, scene.depth)
 poses = m.get_hyp_poses(scene.mask)
+_lib.use_test_lib()
 L = _lib.lib()
 for rows in (40, 20, 8, 40, 20, 8):
     L.fpt_set_raster_strip_rows(rows)

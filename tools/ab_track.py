@@ -9,6 +9,7 @@ d = tempfile.mkdtemp()
 rp, sp = os.path.join(d, "r.fpw"), os.path.join(d, "s.fpw")
 W.pack_synthetic("refiner", rp); W.pack_synthetic("scorer", sp)
 hyp = syn.perturb_pose(scene.gt_pose)
+_lib.use_test_lib()
 L = _lib.lib()
 for v in values:
     getattr(L, hook)(v)

@@ -3,6 +3,7 @@
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from foundationpose_cpp_amd import _lib
+_lib.use_test_lib()
 L = _lib.lib()
 L.fpt_attention_bench.restype = ctypes.c_float
 L.fpt_attention_bench.argtypes = [ctypes.c_int] * 4

@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--clock", action="store_true")
     ap.add_argument("--variant", type=int, default=0, help="0 auto, 1 = 128-px 2-stage kernel, 2 = 256-px 3-stage kernel")
     a = ap.parse_args()
+    _lib.use_test_lib()
     L = _lib.lib()
     L.fpt_set_conv_variant(a.variant)
     L.fpt_set_conv_ablate(a.ablate)

@@ -4,6 +4,7 @@ import sys, os, threading, tempfile, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from foundationpose_cpp_amd import FoundationPose, synthetic as syn, weights as W, _lib
+_lib.use_test_lib()
 L = _lib.lib()
 if len(sys.argv) > 1:
     L.fpt_set_conv_variant(int(sys.argv[1]))

@@ -4,6 +4,7 @@ import sys, os, threading, tempfile, ctypes as C, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from foundationpose_cpp_amd import FoundationPose, synthetic as syn, weights as W, _lib
+_lib.use_test_lib()
 L = _lib.lib()
 L.fpt_read_buffer.restype = C.c_longlong
 L.fpt_read_buffer.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_longlong]

@@ -3,6 +3,7 @@ import sys, os, tempfile, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from foundationpose_cpp_amd import FoundationPose, synthetic as syn, weights as W, _lib
+_lib.use_test_lib()
 L = _lib.lib()
 mesh = syn.make_mesh()
 d = tempfile.mkdtemp(); rp, sp = os.path.join(d, "r.fpw"), os.path.join(d, "s.fpw")

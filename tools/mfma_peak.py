@@ -6,6 +6,7 @@ The number bench.py quotes beside the datasheet peak: what the matrix pipes deli
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from foundationpose_cpp_amd import _lib
+_lib.use_test_lib()
 L = _lib.lib()
 L.fpt_mfma_peak.restype = C.c_float
 L.fpt_mfma_peak.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]

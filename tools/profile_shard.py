@@ -4,6 +4,8 @@
 import os, sys, tempfile
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+from foundationpose_cpp_amd import _lib as _l0
+if len(sys.argv) > 3: _l0.use_test_lib()
 from foundationpose_cpp_amd import FoundationPose, synthetic as syn, weights as W
 from foundationpose_cpp_amd.distributed import HipShardBackend
 count = int(sys.argv[1]) if len(sys.argv) > 1 else 32
@@ -17,7 +19,7 @@ H, Wd = scene.depth.shape
 be = HipShardBackend(m, dev)
 if len(sys.argv) > 3:   # optional test hook: python tools/profile_shard.py 32 fpt_set_rem_small 1
     from foundationpose_cpp_amd import _lib
-    getattr(_lib.lib(), sys.argv[2])(int(sys.argv[3]))
+    getattr(_lib.lib(), sys.argv[2])(int(sys.argv[3]))  # needs _lib.use_test_lib() (done at import below)
 for _ in range(2): be.shard_begin(rgb, depth, mask, H, Wd, mesh.name, 1, 0, count)
 m.profile(True); m.profile_reset()
 for _ in range(5): be.shard_begin(rgb, depth, mask, H, Wd, mesh.name, 1, 0, count)

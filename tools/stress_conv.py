@@ -2,6 +2,7 @@
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from foundationpose_cpp_amd import _lib
+_lib.use_test_lib()
 L = _lib.lib()
 L.fpt_conv_stress.restype = ctypes.c_longlong
 variant = int(sys.argv[1]) if len(sys.argv) > 1 else 0

@@ -4,6 +4,7 @@ import ctypes as C, os, sys, threading
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from foundationpose_cpp_amd import FoundationPose, synthetic as syn, _lib
+_lib.use_test_lib()
 L = _lib.lib()
 L.fpt_conv_stress.restype = C.c_longlong
 mesh = syn.make_mesh(); scene = syn.make_scene(mesh)
