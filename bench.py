@@ -3,7 +3,8 @@
 
 A "step" is one Register over one batch of synthetic input (SURVEY.md §8d scene, 640x480, refine_itr = 1):
 sampler -> render+crop (ratio 1.2) -> refine-net -> pose update -> render+crop (ratio 1.1) -> score-net -> arg-max,
-with the frame (rgb, depth, mask) already resident in HBM when the timed region starts.
+with the frame (rgb, depth, mask) already resident in HBM when the timed region starts (`value`).  The same JSON line also
+carries `host_frame` (the reference's calling convention: host frames, H2D inside the call) and `track` (Track fps, N = 1).
 
   N = 1  : workload = BASELINE.json configs[2] "Register, N=252 hypotheses, 640x480, single MI355X, fp16".
   N > 1  : one process per GPU (torch.distributed.run), WEAK scaling: every rank refines+scores 252 hypotheses of a
@@ -33,6 +34,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP16_TFLOPS = 2500.0   # MI355X dense fp16/bf16 MFMA peak (MI355X_MICROARCH.md)
+PEAK_FP8_TFLOPS = 5000.0    # dense FP8 (v_mfma_f32_16x16x128_f8f6f4), same guide
+PMC_FILE = "r02_register_n252_pmc_hbm.json"   # committed FETCH_SIZE / WRITE_SIZE passes of this round
 BASELINE_HYP_S = 705.6      # reference README.md:37-41: Register 2.8 fps x 252 on RTX 4060 (TensorRT fp16)
 
 
@@ -72,14 +75,20 @@ def main():
     ap.add_argument("--hyps", type=int, default=0, help="total hypotheses (default 252 per GPU, weak scaling)")
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
+    ap.add_argument("--dtype", choices=["f16", "bf16", "fp8"], default="f16",
+                    help="network precision: f16 = the reference's TensorRT --fp16 engines (headline); bf16 = BASELINE configs[1]; "
+                         "fp8 = e4m3 trunk convolutions, BASELINE configs[4] (use with --width 1280 --height 720)")
+    ap.add_argument("--untextured", action="store_true", help="the reference's 2x2 grey fallback texture (configs[4])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-mfma-peak", action="store_true", help="skip the MFMA micro-benchmark (profiling runs)")
-    ap.add_argument("--track", action="store_true", help="measure Track fps (N=1 hypothesis) instead of Register")
+    ap.add_argument("--no-extras", action="store_true", help="skip the host-frame and Track legs (profiling runs)")
+    ap.add_argument("--track", action="store_true", help="measure Track fps (N=1 hypothesis) as the headline instead of Register")
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
     from foundationpose_cpp_amd import FoundationPose, synthetic as syn, weights as W
+    from foundationpose_cpp_amd.api import FP_PREC_BF16, FP_PREC_FP8
     from foundationpose_cpp_amd.distributed import HipShardBackend, sharded_register
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -96,13 +105,18 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    mesh = syn.make_mesh()
+    mesh = syn.make_mesh(textured=not args.untextured)
     scene = syn.make_scene(mesh, args.width, args.height)
     with tempfile.TemporaryDirectory() as d:
         rp, sp = os.path.join(d, f"r{rank}.fpw"), os.path.join(d, f"s{rank}.fpw")
         states = (W.pack_synthetic("refiner", rp), W.pack_synthetic("scorer", sp))
         model = FoundationPose(mesh, scene.K, rp, sp, max_input_image_height=max(1080, args.height),
                                max_input_image_width=max(1920, args.width))
+        if args.dtype == "fp8":      # post-training static quantisation on the bench frame itself
+            model.calibrate_fp8(scene.rgb, scene.depth, scene.mask, mesh.name)
+            model.set_precision(FP_PREC_FP8)
+        elif args.dtype == "bf16":
+            model.set_precision(FP_PREC_BF16)
 
     n_total = args.hyps if args.hyps > 0 else 252 * world
     assert n_total % 42 == 0, "--hyps must be a multiple of 42 (icosphere views)"
@@ -114,16 +128,23 @@ def main():
     backend = HipShardBackend(model, dev)
     out_pose = np.zeros(16, np.float32)
     hyp16 = syn.to_colmajor(syn.perturb_pose(scene.gt_pose))
+    hyp44 = syn.perturb_pose(scene.gt_pose)
+
+    def track_dev():
+        model._must(model._L.fp_track_ex(model.handle, C.c_void_p(rgb.data_ptr()), C.c_void_p(depth.data_ptr()), 1,
+                                         H, Wd, hyp16.ctypes.data_as(C.c_void_p), mesh.name.encode(), 1,
+                                         out_pose.ctypes.data_as(C.c_void_p)))
+
+    def register_dev():
+        model._must(model._L.fp_register_ex(model.handle, C.c_void_p(rgb.data_ptr()), C.c_void_p(depth.data_ptr()),
+                                            C.c_void_p(mask.data_ptr()), 1, H, Wd, mesh.name.encode(), 1,
+                                            out_pose.ctypes.data_as(C.c_void_p)))
 
     def step():
         if args.track:
-            model._must(model._L.fp_track_ex(model.handle, C.c_void_p(rgb.data_ptr()), C.c_void_p(depth.data_ptr()), 1,
-                                             H, Wd, hyp16.ctypes.data_as(C.c_void_p), mesh.name.encode(), 1,
-                                             out_pose.ctypes.data_as(C.c_void_p)))
+            track_dev()
         elif world == 1 and not force_shard:
-            model._must(model._L.fp_register_ex(model.handle, C.c_void_p(rgb.data_ptr()), C.c_void_p(depth.data_ptr()),
-                                                C.c_void_p(mask.data_ptr()), 1, H, Wd, mesh.name.encode(), 1,
-                                                out_pose.ctypes.data_as(C.c_void_p)))
+            register_dev()
         else:
             sharded_register(backend, dist, n_total, rgb, depth, mask, H, Wd, mesh.name, 1)
 
@@ -132,14 +153,17 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    dt = time.perf_counter() - t0
+    def timed(fn, steps, warmup):
+        for _ in range(warmup):
+            fn()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        barrier()
+        return time.perf_counter() - t0
+
+    dt = timed(step, args.steps, args.warmup)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -152,6 +176,42 @@ def main():
     prof = model.profile_report()
     model.profile(False)
 
+    # ---- extra legs on one GPU (outside the headline's timed region): the reference's calling convention (host frames,
+    # H2D inside the call: speed_register / speed_track, simple_tests/src/test_foundationpose.cpp:118-127,145-154) and Track
+    extras = {}
+    if world == 1 and not force_shard and not args.no_extras and rank == 0:
+        def register_host():
+            ok, _ = model.Register(scene.rgb, scene.depth, scene.mask, mesh.name)
+            assert ok, model.last_error
+
+        def track_host():
+            ok, _ = model.Track(scene.rgb, scene.depth, hyp44, mesh.name)
+            assert ok, model.last_error
+
+        if not args.track:
+            th = timed(register_host, args.steps, 2)
+            extras["host_frame"] = {
+                "value": round(n_total * args.steps / th, 2), "unit": "hypotheses/s", "ms_per_step": round(th / args.steps * 1e3, 3),
+                "what": "fp_register from pageable host frames: H2D of rgb + depth + mask inside the timed call (the reference's "
+                        "speed_register convention); `value` above is the same call with the frame resident in HBM"}
+        ksteps = max(args.steps * 10, 100)
+        td = timed(track_dev, ksteps, 10)
+        thh = timed(track_host, ksteps, 10)
+        model.profile(True)
+        model.profile_reset()
+        track_dev()
+        tprof = model.profile_report()
+        model.profile(False)
+        tconv = {k: v for k, v in tprof.items() if k.startswith("conv_") or k.startswith("gemm_")}
+        tflops = sum(v["flops"] for v in tconv.values()) + sum(v["flops"] for k, v in tprof.items() if k == "attention")
+        extras["track"] = {
+            "metric": "Track fps (N=1)", "value": round(ksteps / td, 1), "unit": "frames/s", "ms_per_frame": round(td / ksteps * 1e3, 4),
+            "host_frame_value": round(ksteps / thh, 1), "host_frame_ms": round(thh / ksteps * 1e3, 4), "steps": ksteps,
+            "roofline": {"bound": "launch latency (one hipGraph of ~50 dependent kernels), not MFMA", "algorithmic_gflop_per_frame": round(tflops / 1e9, 2),
+                         "achieved": round(tflops / (td / ksteps) / 1e12, 1), "peak": PEAK_FP16_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(tflops / (td / ksteps) / 1e12 / PEAK_FP16_TFLOPS, 4)},
+        }
+
     if rank == 0:
         units = 1 if args.track else n_total
         ms = dt / args.steps * 1e3
@@ -159,25 +219,33 @@ def main():
         conv = {k: v for k, v in prof.items() if k.startswith("conv_") or k.startswith("gemm_")}
         conv_flops = sum(v["flops"] for v in conv.values())
         conv_ms = sum(v["ms"] for v in conv.values())
+        # in FP8 precision the 3x3 trunk layers from encodeA.2 on run on e4m3 operands (5 PFLOP/s dense), the rest on f16
+        fp8_layers = {"conv_128", "conv_256", "conv_b2", "conv_512"} if args.dtype == "fp8" else set()
         by_sym = {}
         for k, v in conv.items():
+            layer = k.split("/", 1)[0]
             sym = k.split("/", 1)[1] if "/" in k else k
-            a = by_sym.setdefault(sym, dict(ms=0.0, flops=0.0, bytes=0.0, calls=0))
+            if layer in fp8_layers and "halo8" not in sym:
+                sym += "[fp8]"
+            a = by_sym.setdefault(sym, dict(ms=0.0, flops=0.0, bytes=0.0, calls=0, fp8=layer in fp8_layers))
             for f in ("ms", "flops", "bytes", "calls"):
                 a[f] += v[f]
-        dom, dv = max(by_sym.items(), key=lambda kv: kv[1]["ms"]) if by_sym else ("none", dict(ms=0, flops=0, bytes=0, calls=1))
+        dom, dv = max(by_sym.items(), key=lambda kv: kv[1]["ms"]) if by_sym else ("none", dict(ms=0, flops=0, bytes=0, calls=1, fp8=False))
+        peak = PEAK_FP8_TFLOPS if dv.get("fp8") else PEAK_FP16_TFLOPS
         achieved = dv["flops"] / (dv["ms"] * 1e-3) / 1e12 if dv["ms"] > 0 else 0.0
         family = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+        # the family's own ceiling: time at peak of every launch's FLOPs at its operand type
+        ideal_ms = sum(v["flops"] / ((PEAK_FP8_TFLOPS if v["fp8"] else PEAK_FP16_TFLOPS) * 1e12) * 1e3 for v in by_sym.values())
         stages = {}
         for k, v in prof.items():
             stages[k.split("/", 1)[0]] = stages.get(k.split("/", 1)[0], 0.0) + v["ms"]
         stages = {k: round(v, 3) for k, v in sorted(stages.items(), key=lambda kv: -kv[1])}
         traffic, traffic_src = None, None
-        pmc_path = os.path.join(ROOT, "profiles", "r01h_register_n252_pmc_hbm.json")
-        if os.path.exists(pmc_path) and not args.track and world == 1:
+        pmc_path = os.path.join(ROOT, "profiles", PMC_FILE)
+        if os.path.exists(pmc_path) and not args.track and world == 1 and args.dtype == "f16" and (Wd, H) == (640, 480):
             pmc = json.load(open(pmc_path))
             for name, rec in pmc.items():
-                if dom.split("<")[0] in name:
+                if dom.split("<")[0].split("[")[0] in name:
                     traffic, traffic_src = round(rec["traffic_bytes_per_launch"]), os.path.relpath(pmc_path, ROOT)
         # what the matrix pipes sustain on THIS box with every SIMD busy (register-resident MFMAs, random operands): the
         # datasheet 2.5 PFLOP/s assumes 2.4 GHz, under MFMA load the power limit holds the clock near 2.0 GHz
@@ -192,38 +260,46 @@ def main():
             if v > 0:
                 measured_peak, measured_mhz = round(float(v), 1), round(mhz.value)
         res = {
-            "metric": "Track fps (N=1)" if args.track else "pose-hypotheses/sec (Register N=252, 640x480)",
+            "metric": "Track fps (N=1)" if args.track else f"pose-hypotheses/sec (Register N={n_total}, {Wd}x{H})",
             "value": round(units * args.steps / dt, 2),
             "unit": "frames/s" if args.track else "hypotheses/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
             "higher_is_better": True,
             "scaling": "weak" if args.hyps == 0 else "strong",
             "vs_baseline": None if args.track else round(units * args.steps / dt / BASELINE_HYP_S, 3),
-            "dtype": "f16", "data": "synthetic",
+            "dtype": args.dtype, "data": "synthetic",
             "config": {
                 "workload": (f"Track N=1 {Wd}x{H}" if args.track else
-                             f"Register N={n_total} hypotheses ({n_total // world}/GPU) {Wd}x{H} refine_itr=1"),
-                "mesh": "synthetic ellipsoid V=2562 F=5120, 512x512 texture", "weights": "synthetic (seed 7)",
+                             f"Register N={n_total} hypotheses ({n_total // world}/GPU) {Wd}x{H} refine_itr=1, frame resident in HBM"),
+                "mesh": f"synthetic ellipsoid V=2562 F=5120, {'2x2 grey (untextured)' if args.untextured else '512x512 texture'}",
+                "weights": "synthetic (seed 7)",
+                "precision": {"f16": "f16 storage / f32 accumulate (the reference's TensorRT --fp16)",
+                              "bf16": "bf16 storage / f32 accumulate",
+                              "fp8": "e4m3 operands (per-channel weight scale, calibrated per-tensor activation scale) for the 3x3 trunk "
+                                     "convolutions from encodeA.2 on (91 % of the FLOPs), f16 elsewhere"}[args.dtype],
                 "parallelism": f"hyp-shard x{world}" if world > 1 else "single GPU",
                 "collective": "1 RCCL all-gather [n_local,528] f32 per Register" if world > 1 else "none",
                 "baseline": "reference README.md:37-41 Register 2.8 fps x 252 = 705.6 hyp/s on RTX 4060 (TensorRT fp16)",
             },
             "roofline": {
                 "bound": "mfma", "kernel": dom,
-                "achieved": round(achieved, 1), "peak": PEAK_FP16_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / PEAK_FP16_TFLOPS, 4),
+                "achieved": round(achieved, 1), "peak": peak, "unit": "TFLOP/s",
+                "frac": round(achieved / peak, 4),
                 "peak_measured": measured_peak, "peak_measured_clock_mhz": measured_mhz,
-                "frac_of_measured": round(achieved / measured_peak, 4) if measured_peak else None,
+                "peak_measured_what": "register-resident f16 MFMA micro-benchmark on this box (fp8 MFMAs: 2x)",
+                "frac_of_measured": round(achieved / (measured_peak * (2 if dv.get("fp8") else 1)), 4) if measured_peak else None,
                 "launches_per_step": dv["calls"], "algorithmic_gflop_per_launch": round(dv["flops"] / max(dv["calls"], 1) / 1e9, 1),
                 "avg_launch_ms": round(dv["ms"] / max(dv["calls"], 1), 4),
                 "algorithmic_bytes_per_launch": round(dv["bytes"] / max(dv["calls"], 1)),
                 "traffic": traffic, "traffic_source": traffic_src,
-                "conv_family": {"achieved": round(family, 1), "frac": round(family / PEAK_FP16_TFLOPS, 4),
-                                "gflop_per_step": round(conv_flops / 1e9, 1), "ms_per_step": round(conv_ms, 3),
+                "traffic_kind": "committed rocprofv3 PMC passes of the same command (profiles/), NOT measured by this run" if traffic else None,
+                "conv_family": {"achieved": round(family, 1), "gflop_per_step": round(conv_flops / 1e9, 1), "ms_per_step": round(conv_ms, 3),
+                                "ms_at_peak": round(ideal_ms, 3), "frac": round(ideal_ms / conv_ms, 4) if conv_ms > 0 else None,
                                 "kernels_ms": {k2: round(v2["ms"], 3) for k2, v2 in by_sym.items()}},
             },
             "stage_ms": stages,
         }
+        res.update(extras)
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(mesh, scene, states)
         print(json.dumps(res), flush=True)

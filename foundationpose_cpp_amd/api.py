@@ -17,6 +17,7 @@ from . import _lib
 from .synthetic import Mesh, from_colmajor, to_colmajor
 
 FP_HOST, FP_DEVICE = 0, 1
+FP_PREC_F16, FP_PREC_BF16, FP_PREC_FP8 = 0, 1, 2   # include/foundationpose_amd.h
 CROP = 160
 
 
@@ -229,6 +230,33 @@ class FoundationPose:
         idx = C.c_int(-1)
         self._must(self._L.fp_argmax(self._h, _p(s), len(s), C.byref(idx)))
         return idx.value
+
+    # ---- network precision (include/foundationpose_amd.h "network precision") ---------------------
+    def set_precision(self, precision: int):
+        """FP_PREC_F16 (the reference's TensorRT --fp16 engines, default) / FP_PREC_BF16 / FP_PREC_FP8 (after calibrate_fp8)."""
+        self._must(self._L.fp_set_precision(self._h, precision))
+
+    @property
+    def precision(self) -> int:
+        return self._L.fp_get_precision(self._h)
+
+    def calibrate_fp8(self, rgb, depth, mask, target_name: str):
+        """One f16 Register of the frame with |max| collection on the trunk activations -> FP8 activation scales."""
+        rgb, depth, mask = self._frame(rgb, depth, mask)
+        if rgb is None:
+            raise FoundationPoseError(self.last_error)
+        self._must(self._L.fp_calibrate_fp8(self._h, _p(rgb), _p(depth), _p(mask), FP_HOST, depth.shape[0], depth.shape[1],
+                                            target_name.encode()))
+
+    def get_calibration(self):
+        out = np.zeros(32, np.float32)
+        self._must(self._L.fp_get_calibration(self._h, _p(out)))
+        return out
+
+    def set_calibration(self, amax):
+        a = np.ascontiguousarray(amax, np.float32)
+        assert a.size == 32
+        self._must(self._L.fp_set_calibration(self._h, _p(a)))
 
     # ---- measurement -----------------------------------------------------------------------------
     def profile(self, on: bool):

@@ -1,0 +1,336 @@
+"""bf16 and FP8 (OCP e4m3) paths: BASELINE.json configs[1] (Track, bf16 refine-net) and configs[4] (1280x720, textured +
+untextured, N = 252, FP8 convolutions).
+
+Kernel level (test build, fpt_conv_dt): every schedule an FP8 / bf16 layer can reach against a torch fp32 reference evaluated on the
+SAME quantised operands -- products of e4m3 / bf16 values are exact in fp32, so what is left is summation order and the
+rounding of the output.  End to end: poses against the f16 path and the oracle pipeline, tolerances stated per test.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from foundationpose_cpp_amd import FoundationPose, _lib, synthetic as syn, weights as W
+from foundationpose_cpp_amd.api import FP_PREC_BF16, FP_PREC_F16, FP_PREC_FP8
+from oracle import fp_oracle as fo
+from oracle import nets_torch as NT
+
+pytestmark = pytest.mark.gpu
+
+DT_F16, DT_BF16, DT_FP8 = 0, 1, 2
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+# ---- e4m3 (OCP fn: bias 7, max 448, no inf), round to nearest even, saturating: the numpy twin of f32_to_e4m3_bits ----
+def q_e4m3(x):
+    x = np.asarray(x, np.float64)
+    a = np.minimum(np.abs(x), 448.0)
+    e = np.floor(np.log2(np.maximum(a, 2.0 ** -20)))
+    e = np.maximum(e, -6.0)                      # subnormals share the exponent of the smallest normal
+    quantum = 2.0 ** (e - 3)
+    q = np.rint(a / quantum) * quantum           # np.rint rounds half to even
+    return (np.sign(x) * np.minimum(q, 448.0)).astype(np.float32)
+
+
+def q_bf16(x):
+    return torch.from_numpy(np.asarray(x, np.float32)).to(torch.bfloat16).to(torch.float32).numpy()
+
+
+def q_f16(x):
+    return np.asarray(x, np.float32).astype(np.float16).astype(np.float32)
+
+
+def _conv_dt(x, w_oihw, bias, stride, pad, relu, res, dt, out_dt, in_scale=1.0, res_scale=1.0, out_scale=1.0):
+    L = _lib.test_lib()
+    L.fpt_conv_dt.argtypes = [C.c_void_p] * 4 + [C.c_int] * 13 + [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int,
+                                                                  C.c_float, C.c_float, C.c_float]
+    NB, H, Wd, Cin = x.shape
+    Cout, _, KH, KW = w_oihw.shape
+    OH = (H + 2 * pad - KH) // stride + 1
+    OW = (Wd + 2 * pad - KW) // stride + 1
+    wk = np.ascontiguousarray(w_oihw.transpose(0, 2, 3, 1), np.float32)
+    out = np.zeros((NB, OH, OW, Cout), np.float32)
+    x = np.ascontiguousarray(x, np.float32)
+    b = np.ascontiguousarray(bias, np.float32)
+    r = np.ascontiguousarray(res, np.float32) if res is not None else None
+    rc = L.fpt_conv_dt(_p(x), _p(wk), _p(b), _p(r), NB, H, Wd, Cin, Cout, KH, KW, stride, pad, OH, OW, int(relu), 0,
+                       _p(out), 1, None, dt, out_dt, in_scale, res_scale, out_scale)
+    assert rc == 0, L.fp_last_error()
+    return out
+
+
+def _ref(xq, wq, bias, stride, pad, relu, resq):
+    y = torch.nn.functional.conv2d(torch.from_numpy(xq).permute(0, 3, 1, 2).double(), torch.from_numpy(wq).double(),
+                                   torch.from_numpy(np.asarray(bias, np.float64)), stride, pad).permute(0, 2, 3, 1)
+    if resq is not None:
+        y = y + torch.from_numpy(resq).double()
+    if relu:
+        y = torch.relu(y)
+    return y.float().numpy()
+
+
+FP8_SHAPES = [
+    # NB, H, Cin, Cout, stride, use_res, what it reaches
+    (3, 40, 128, 128, 1, True),     # small batch: conv_igemm_kernel<128> FP8 (M not a multiple of 128)
+    (70, 40, 128, 128, 1, True),    # conv_halo8_kernel, one 128-channel chunk, residual
+    (40, 40, 256, 256, 1, True),    # conv_halo8_kernel, two chunks (halo refill), two channel tiles
+    (170, 20, 512, 512, 1, True),   # conv_big_pp_kernel FP8 rounds + conv_deep_kernel<64> left-over
+    (300, 20, 512, 512, 1, False),  # conv_big_pp rounds + 256x128 ping-pong cascade + deep kernel
+    (70, 40, 256, 512, 2, False),   # encodeAB.2: stride 2 on the 256x256 tile
+    (1, 20, 512, 512, 1, True),     # Track-sized: split-K + reduce kernel with FP8 scales
+]
+
+
+@pytest.mark.parametrize("shape", FP8_SHAPES)
+def test_fp8_conv_schedules(shape):
+    NB, H, Cin, Cout, stride, use_res = shape
+    rng = np.random.default_rng(3)
+    x = np.maximum(rng.normal(size=(NB, H, H, Cin)), 0).astype(np.float32)          # post-ReLU like the real activations
+    w = (rng.normal(size=(Cout, Cin, 3, 3)) / np.sqrt(Cin * 9)).astype(np.float32)
+    b = (0.1 * rng.normal(size=Cout)).astype(np.float32)
+    OH = (H + 2 - 3) // stride + 1
+    res = np.maximum(rng.normal(size=(NB, OH, OH, Cout)), 0).astype(np.float32) if use_res else None
+    s_in, s_res, s_out = float(x.max()) / 224, (float(res.max()) / 224 if use_res else 1.0), 6.0 / 224
+    # the reference sees exactly the operands the kernel sees
+    xq = q_e4m3(x / s_in) * s_in
+    ws = np.abs(w).reshape(Cout, -1).max(1) / 448.0
+    wq = q_e4m3(w / ws[:, None, None, None]) * ws[:, None, None, None]
+    rq = q_e4m3(res / s_res) * s_res if use_res else None
+    ref = _ref(xq, wq, b, stride, 1, True, rq)
+    # FP8 -> FP8 (a trunk layer): the stored value is the e4m3 rounding of ref / s_out
+    got = _conv_dt(x, w, b, stride, 1, True, res, DT_FP8, DT_FP8, s_in, s_res, s_out)
+    want = q_e4m3(ref / s_out) * s_out
+    exact = np.mean(got == want)
+    # summation order can move a value across a rounding boundary: >= 99.5 % identical, the rest one e4m3 step (2^-3 relative)
+    assert exact > 0.995, exact
+    np.testing.assert_allclose(got, want, rtol=0.13, atol=s_out * 2.0 ** -9 * 1.01)
+    # FP8 -> f16 (the last trunk layer writes the f16 token tensor)
+    got16 = _conv_dt(x, w, b, stride, 1, True, res, DT_FP8, DT_F16, s_in, s_res, 1.0)
+    np.testing.assert_allclose(got16, ref, rtol=2e-3, atol=2e-3)
+
+
+@pytest.mark.parametrize("NB", [3, 40])
+def test_f16_to_fp8_boundary_layer(NB):
+    """encodeA.1 in FP8 precision: f16 operands (3x3 / stride 2, 64 -> 128 on 80x80), FP8 output; NB = 40 reaches
+    conv_s2_halo_kernel, NB = 3 the small-batch path."""
+    rng = np.random.default_rng(4)
+    x = np.maximum(rng.normal(size=(NB, 80, 80, 64)), 0).astype(np.float32)
+    w = (rng.normal(size=(128, 64, 3, 3)) / np.sqrt(64 * 9)).astype(np.float32)
+    b = (0.1 * rng.normal(size=128)).astype(np.float32)
+    s_out = 5.0 / 224
+    ref = _ref(q_f16(x), q_f16(w), b, 2, 1, True, None)
+    got = _conv_dt(x, w, b, 2, 1, True, None, DT_F16, DT_FP8, 1.0, 1.0, s_out)
+    want = q_e4m3(ref / s_out) * s_out
+    assert np.mean(got == want) > 0.995
+    np.testing.assert_allclose(got, want, rtol=0.13, atol=s_out * 2.0 ** -9 * 1.01)
+
+
+BF16_SHAPES = [
+    # NB, H, W, Cin, Cout, k, stride, use_res
+    (3, 40, 40, 128, 128, 3, 1, True),     # igemm
+    (70, 40, 40, 128, 128, 3, 1, True),    # conv_halo_kernel<bf16>
+    (40, 80, 80, 64, 128, 3, 2, False),    # conv_s2_halo_kernel<bf16>
+    (40, 80, 80, 32, 64, 4, 1, False),     # conv_stem_halo_kernel<bf16> (s2d stem mode)
+    (170, 20, 20, 512, 512, 3, 1, True),   # 256x256 ping-pong + deep kernel
+    (700, 40, 40, 128, 128, 3, 1, False),  # conv_pp32_kernel<512,128> rounds + left-over
+    (1, 66001, 1, 512, 1536, 1, 1, False), # gemm_k32_kernel<bf16>
+    (1, 400, 1, 512, 512, 1, 1, True),     # Track-sized Linear layer: split-K
+]
+
+
+@pytest.mark.parametrize("shape", BF16_SHAPES)
+def test_bf16_conv_schedules(shape):
+    NB, H, Wd, Cin, Cout, k, stride, use_res = shape
+    rng = np.random.default_rng(5)
+    x = rng.normal(size=(NB, H, Wd, Cin)).astype(np.float32)
+    w = (rng.normal(size=(Cout, Cin, k, k)) / np.sqrt(Cin * k * k)).astype(np.float32)
+    b = rng.normal(size=Cout).astype(np.float32)
+    pad = 2 if k == 4 else (k - 1) // 2
+    stem = k == 4
+    OH = H if stem else (H + 2 * pad - k) // stride + 1
+    OW = Wd if stem else (Wd + 2 * pad - k) // stride + 1
+    res = rng.normal(size=(NB, OH, OW, Cout)).astype(np.float32) if use_res else None
+    if stem:   # asymmetric padding (2 before, 1 after) of the space-to-depth stem
+        xt = torch.nn.functional.pad(torch.from_numpy(q_bf16(x)).permute(0, 3, 1, 2), (2, 1, 2, 1))
+        ref = torch.relu(torch.nn.functional.conv2d(xt, torch.from_numpy(q_bf16(w)), torch.from_numpy(b))).permute(0, 2, 3, 1).numpy()
+        L = _lib.test_lib()
+        L.fpt_conv_dt.argtypes = [C.c_void_p] * 4 + [C.c_int] * 13 + [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int,
+                                                                      C.c_float, C.c_float, C.c_float]
+        got = np.zeros((NB, OH, OW, Cout), np.float32)
+        wk = np.ascontiguousarray(w.transpose(0, 2, 3, 1), np.float32)
+        assert L.fpt_conv_dt(_p(x), _p(wk), _p(b), None, NB, H, Wd, Cin, Cout, k, k, 1, 2, OH, OW, 1, 0, _p(got), 1, None,
+                             DT_BF16, DT_BF16, 1.0, 1.0, 1.0) == 0, L.fp_last_error()
+    else:
+        ref = _ref(q_bf16(x), q_bf16(w), b, stride, pad, True, q_bf16(res) if use_res else None)
+        got = _conv_dt(x, w, b, stride, pad, True, res, DT_BF16, DT_BF16)
+    # output rounded to bf16: 2^-9 relative + summation order
+    np.testing.assert_allclose(got, ref, rtol=8e-3, atol=8e-3)
+
+
+@pytest.mark.parametrize("B,T", [(3, 400), (1, 252)])
+def test_bf16_attention(B, T):
+    L = _lib.test_lib()
+    rng = np.random.default_rng(6)
+    qkv = rng.normal(size=(B, T, 1536)).astype(np.float32)
+    out = np.zeros((B, T, 512), np.float32)
+    assert L.fpt_attention_dt(_p(qkv), B, T, _p(out), DT_BF16) == 0, L.fp_last_error()
+    q, k, v = [torch.from_numpy(q_bf16(qkv[..., i * 512:(i + 1) * 512])).view(B, T, 4, 128).transpose(1, 2) for i in range(3)]
+    ref = torch.nn.functional.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(B, T, 512).numpy()
+    np.testing.assert_allclose(out, ref, rtol=2e-2, atol=2e-2)   # P is rounded to bf16 (2^-9) before the PV product
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# end to end
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def nets(tmp_path_factory):
+    d = tmp_path_factory.mktemp("w")
+    rp, sp = str(d / "refiner.fpw"), str(d / "scorer.fpw")
+    rs = W.pack_synthetic("refiner", rp)
+    ss = W.pack_synthetic("scorer", sp)
+    return rp, sp, NT.build("refiner", rs), NT.build("scorer", ss)
+
+
+def _pose_err(a, b):
+    dR = a[:3, :3] @ b[:3, :3].T
+    ang = np.degrees(np.arccos(np.clip((np.trace(dR) - 1) / 2, -1, 1)))
+    return ang, np.linalg.norm(a[:3, 3] - b[:3, 3])
+
+
+def _oracle_track(nets, mesh, scene, hyp):
+    om = fo.OracleMesh(mesh)
+    p16 = syn.to_colmajor(hyp[None])
+    a = fo.render(om, p16, scene.K, scene.depth.shape, 1.2)
+    b = fo.crop(scene.rgb, scene.depth, scene.K, p16, 1.2, mesh.diameter)
+    with torch.no_grad():
+        t, r = nets[2](torch.from_numpy(a), torch.from_numpy(b))
+    return syn.from_colmajor(fo.refine_post_process(p16, t.numpy(), r.numpy(), mesh.diameter))[0]
+
+
+def test_track_bf16_refine_net(nets, syn_mesh, syn_scene):
+    """BASELINE configs[1]: Track, N = 1, bf16 refine-net.  bf16 keeps 8 significand bits (f16: 11), so the refiner's
+    outputs carry ~8x the f16 rounding noise; the pose must still sit well inside the north-star bar (1 deg / 1 mm):
+    asserted 0.3 deg / 0.3 mm against the fp32 oracle pipeline and against the f16 path."""
+    m = FoundationPose(syn_mesh, syn.intrinsics(), nets[0], nets[1])
+    try:
+        hyp = syn.perturb_pose(syn_scene.gt_pose)
+        ok, p16 = m.Track(syn_scene.rgb, syn_scene.depth, hyp, syn_mesh.name)
+        assert ok, m.last_error
+        m.set_precision(FP_PREC_BF16)
+        assert m.precision == FP_PREC_BF16
+        poses = []
+        for _ in range(3):      # eager, capture, replay
+            ok, pb = m.Track(syn_scene.rgb, syn_scene.depth, hyp, syn_mesh.name)
+            assert ok, m.last_error
+            poses.append(pb)
+        assert np.array_equal(poses[0], poses[1]) and np.array_equal(poses[1], poses[2])
+        ref = _oracle_track(nets, syn_mesh, syn_scene, hyp)
+        for other in (ref, p16):
+            ang, dist = _pose_err(poses[0], other)
+            assert ang < 0.3 and dist < 3e-4, (ang, dist)
+        # and a bf16 Register runs end to end and agrees with the f16 one on the winner's pose
+        ok, rb = m.Register(syn_scene.rgb, syn_scene.depth, syn_scene.mask, syn_mesh.name)
+        assert ok, m.last_error
+        m.set_precision(FP_PREC_F16)
+        ok, rh = m.Register(syn_scene.rgb, syn_scene.depth, syn_scene.mask, syn_mesh.name)
+        assert ok
+        print("bf16 vs f16 Register pose:", _pose_err(rb, rh))
+    finally:
+        m.close()
+
+
+def test_fp8_needs_calibration(nets, syn_mesh):
+    m = FoundationPose(syn_mesh, syn.intrinsics(), nets[0], nets[1])
+    try:
+        with pytest.raises(Exception) as e:
+            m.set_precision(FP_PREC_FP8)
+        assert "calibrat" in str(e.value)
+        assert m.precision == FP_PREC_F16
+    finally:
+        m.close()
+
+
+@pytest.mark.parametrize("textured", [True, False])
+def test_register_720p_fp8(nets, textured):
+    """BASELINE configs[4]: 1280x720, textured + untextured mesh, N = 252, FP8 convolutions.
+    The FP8 Register must (a) pick a hypothesis the oracle pipeline also ranks at the top and (b) return a pose within
+    1 deg / 1 mm of the f16 path's pose for THAT hypothesis (north-star tolerance; measured values are printed)."""
+    mesh = syn.make_mesh(textured=textured)
+    scene = syn.make_scene(mesh, W=1280, H=720)
+    m = FoundationPose(mesh, scene.K, nets[0], nets[1])
+    try:
+        ok, p_f16 = m.Register(scene.rgb, scene.depth, scene.mask, mesh.name)
+        assert ok, m.last_error
+        m.calibrate_fp8(scene.rgb, scene.depth, scene.mask, mesh.name)
+        cal = m.get_calibration()
+        assert np.all(cal[:14] > 0) and np.all(cal[16:30] > 0)
+        m.set_precision(FP_PREC_FP8)
+        ok, p_fp8 = m.Register(scene.rgb, scene.depth, scene.mask, mesh.name)
+        assert ok, m.last_error
+        ok, p_fp8b = m.Register(scene.rgb, scene.depth, scene.mask, mesh.name)
+        assert ok and np.array_equal(p_fp8, p_fp8b)          # deterministic (graph capture / replay included)
+        # oracle pipeline (fp32 networks) on the same frame
+        om = fo.OracleMesh(mesh)
+        poses = fo.get_hyp_poses(scene.depth, scene.mask, scene.K)
+        a = fo.render(om, poses, scene.K, scene.depth.shape, 1.2)
+        b = fo.crop(scene.rgb, scene.depth, scene.K, poses, 1.2, mesh.diameter)
+        with torch.no_grad():
+            t, r = nets[2](torch.from_numpy(a), torch.from_numpy(b))
+        refined = fo.refine_post_process(poses, t.numpy(), r.numpy(), mesh.diameter)
+        a = fo.render(om, refined, scene.K, scene.depth.shape, 1.1)
+        b = fo.crop(scene.rgb, scene.depth, scene.K, refined, 1.1, mesh.diameter)
+        with torch.no_grad():
+            s = nets[3](torch.from_numpy(a), torch.from_numpy(b)).numpy()
+        refined = syn.from_colmajor(refined)
+        errs = [_pose_err(p_fp8, rr) for rr in refined]
+        idx = int(np.argmin([e[0] + 1e3 * e[1] for e in errs]))
+        print(f"textured={textured}: FP8 winner = oracle hypothesis {idx}: {errs[idx][0]:.4f} deg / {errs[idx][1] * 1e3:.4f} mm from the "
+              f"oracle's refined pose; oracle score rank {int((s > s[idx]).sum())} of 252 (gap to best {s.max() - s[idx]:.2e}); "
+              f"vs f16 winner pose: {_pose_err(p_fp8, p_f16)}")
+        assert errs[idx][0] < 1.0 and errs[idx][1] < 1e-3, errs[idx]
+        assert s[idx] >= s.max() - 2e-2, (idx, s[idx], s.max())
+        # saved calibration is portable: a fresh model with the same numbers gives the same pose
+        m2 = FoundationPose(mesh, scene.K, nets[0], nets[1])
+        try:
+            m2.set_calibration(cal)
+            m2.set_precision(FP_PREC_FP8)
+            ok, p2 = m2.Register(scene.rgb, scene.depth, scene.mask, mesh.name)
+            assert ok and np.array_equal(p2, p_fp8)
+        finally:
+            m2.close()
+    finally:
+        m.close()
+
+
+def test_fp8_per_layer_error_vs_fp32(nets, syn_mesh, syn_scene):
+    """Per-stage error budget of the FP8 trunk: refiner and scorer outputs on 16 hypotheses against the torch fp32 networks.
+    f16 lands at ~1e-3 of the output scale; FP8 (3 significand bits per operand, 13 quantised layers) is asserted at 5e-2."""
+    m = FoundationPose(syn_mesh, syn.intrinsics(), nets[0], nets[1])
+    try:
+        m.upload_frame(syn_scene.rgb, syn_scene.depth)
+        poses = m.get_hyp_poses(syn_scene.mask)[:16]
+        a, b = m.render_and_transform(syn_mesh.name, poses, 1.2)
+        with torch.no_grad():
+            rt, rr = nets[2](torch.from_numpy(a), torch.from_numpy(b))
+            rs = nets[3](torch.from_numpy(a), torch.from_numpy(b)).numpy()
+        t16, r16 = m.refiner_infer(a, b)
+        s16 = m.scorer_infer(a, b)
+        m.calibrate_fp8(syn_scene.rgb, syn_scene.depth, syn_scene.mask, syn_mesh.name)
+        m.set_precision(FP_PREC_FP8)
+        t8, r8 = m.refiner_infer(a, b)
+        s8 = m.scorer_infer(a, b)
+        scale_t, scale_r, scale_s = np.abs(rt.numpy()).max(), np.abs(rr.numpy()).max(), np.abs(rs).max()
+        e = {
+            "trans f16": np.abs(t16 - rt.numpy()).max() / scale_t, "trans fp8": np.abs(t8 - rt.numpy()).max() / scale_t,
+            "rot f16": np.abs(r16 - rr.numpy()).max() / scale_r, "rot fp8": np.abs(r8 - rr.numpy()).max() / scale_r,
+            "score f16": np.abs(s16 - rs).max() / scale_s, "score fp8": np.abs(s8 - rs).max() / scale_s,
+        }
+        print("max |err| / max |output| vs torch fp32:", {k: float(f"{v:.3e}") for k, v in e.items()})
+        for k, v in e.items():
+            assert v < (5e-2 if "fp8" in k else 1e-2), (k, v)
+    finally:
+        m.close()
