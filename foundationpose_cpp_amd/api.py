@@ -231,6 +231,14 @@ class FoundationPose:
         self._must(self._L.fp_argmax(self._h, _p(s), len(s), C.byref(idx)))
         return idx.value
 
+    # ---- float model of the rendering stage (1 = contracted like nvcc -fmad=true, default; 0 = separate roundings) ----
+    def set_float_model(self, fmad: int):
+        self._must(self._L.fp_set_float_model(self._h, int(fmad)))
+
+    @property
+    def float_model(self) -> int:
+        return self._L.fp_get_float_model(self._h)
+
     # ---- network precision (include/foundationpose_amd.h "network precision") ---------------------
     def set_precision(self, precision: int):
         """FP_PREC_F16 (the reference's TensorRT --fp16 engines, default) / FP_PREC_BF16 / FP_PREC_FP8 (after calibrate_fp8)."""

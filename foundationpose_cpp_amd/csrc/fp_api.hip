@@ -224,6 +224,9 @@ struct fp_model {
   Net *refiner_p[3] = {nullptr, nullptr, nullptr}, *scorer_p[3] = {nullptr, nullptr, nullptr};
   NNScratch *ws_p[3] = {nullptr, nullptr, nullptr};
   int prec = PREC_F16;
+  // float model of the rendering stage: true = multiply-adds contracted like the reference's nvcc -fmad=true build
+  // (fp_geometry.hip "float model"), false = every operation separately rounded
+  bool fmad = true;
   Net *refiner = nullptr, *scorer = nullptr;  // = refiner_p[prec], scorer_p[prec]
   NNScratch *ws = nullptr;                    // = ws_p[prec]
   bool calibrating = false;
@@ -328,10 +331,10 @@ static int render_and_crop(fp_model *m, Target *t, int N, float crop_ratio, OutM
   if (out_a) {
     {
       ProfScope ps(&m->prof, s, "vertex", 0, (double)N * t->mesh.V * 32.0 + t->mesh.V * 24.0);
-      launch_vertex(s, t->mesh, m->recs, N, m->clip, m->attr);
+      launch_vertex(s, t->mesh, m->recs, N, m->clip, m->attr, m->fmad);
     }
     ProfScope ps(&m->prof, s, "raster_shade", 0, (double)N * (out_bytes + t->mesh.V * 32.0 + t->mesh.F * 12.0));
-    launch_raster_shade(s, t->mesh, m->recs, N, m->clip, m->attr, mode, out_a, dbg_tri, dbg_rast);
+    launch_raster_shade(s, t->mesh, m->recs, N, m->clip, m->attr, mode, out_a, dbg_tri, dbg_rast, m->fmad);
   }
   if (out_b) {
     ProfScope ps(&m->prof, s, "crop_warp", 0, (double)n_crop * out_bytes);
@@ -1031,6 +1034,16 @@ int fp_set_precision(fp_model *m, int precision) {
   return select_precision(m, precision);
 }
 int fp_get_precision(const fp_model *m) { return m ? m->prec : -1; }
+
+int fp_set_float_model(fp_model *m, int fmad) {
+  FP_CHECK(m != nullptr, "[FoundationPose] null model");
+  FP_HIP_OK(hipStreamSynchronize(m->stream));
+  m->fmad = fmad != 0;
+  drop_graph(m->tg);
+  drop_graph(m->rg);
+  return 0;
+}
+int fp_get_float_model(const fp_model *m) { return m ? (m->fmad ? 1 : 0) : -1; }
 
 // Post-training static quantisation for FP_PREC_FP8: one Register of the given frame in f16 with |max| collection on
 // every trunk activation of both networks; the per-tensor scales of the FP8 networks follow from it.

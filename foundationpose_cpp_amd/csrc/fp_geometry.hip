@@ -40,6 +40,22 @@ struct K9 { float k[9]; };
 
 __device__ __forceinline__ float clampf(float f, float a, float b) { return fmaxf(a, fminf(f, b)); }
 
+// ---- float model -----------------------------------------------------------------------------------------------
+// This file is compiled with -ffp-contract=off: the compiler never fuses a multiply with an add on its own.  The reference's
+// kernels are built by nvcc with its default -fmad=true (D6F/CMakeLists.txt:5 only sets -O3), i.e. its binary DOES contract.
+// FMAD = true restates that with explicit fmaf calls under one documented rule [EXT: ptxas' actual choices are not
+// published]: in a sum of products evaluated left to right, every `acc + a*b` whose product has no other use becomes
+// fmaf(a, b, acc); the FIRST product of a chain is a plain multiply; `x - a*b` is fmaf(-a, b, x); `a*b - c*d` is
+// fmaf(a, b, -(c*d)).  FMAD = false keeps every operation separately rounded (round 1's model).  the CPU oracle (oracle/, test infrastructure) carries
+// the same two models expression by expression, so integer results (triangle ids) are bit-exact in either.
+template <bool FMAD> __device__ __forceinline__ float mad(float a, float b, float c) { return FMAD ? fmaf(a, b, c) : a * b + c; }
+template <bool FMAD> __device__ __forceinline__ float dot3(float a0, float b0, float a1, float b1, float a2, float b2) {
+  return mad<FMAD>(a2, b2, mad<FMAD>(a1, b1, a0 * b0));
+}
+template <bool FMAD> __device__ __forceinline__ float diffprod(float a, float b, float c, float d) {  // a*b - c*d
+  return FMAD ? fmaf(a, b, -(c * d)) : a * b - c * d;
+}
+
 // fp16 network-input layout: space-to-depth(2x2) of NHWC [N,160,160,8] -> [N,80,80,32], stored with a physical zero
 // border of FP_NN_IN_BORDER s2d-pixels ([N,84,84,32]); in 16-byte units the pixel (n,y,x) lands at
 // ((n*84 + y/2 + 2)*84 + x/2 + 2)*4 + (y&1)*2 + (x&1).  This turns the 7x7 stride-2 stem convolution into a 4x4
@@ -162,6 +178,7 @@ void launch_pose_setup(hipStream_t s, const float *poses_dev, int N, const float
 // ---------------------------------------------------------------------------------------------
 
 // The per-hypothesis record is read through uniform (scalar) loads.
+template <bool FMAD>
 __global__ void vertex_kernel(const float *__restrict__ verts, const float *__restrict__ normals, int V,
                               const PoseRec *__restrict__ recs, float4 *__restrict__ clip, float4 *__restrict__ attr,
                               float4 *__restrict__ dbg) {
@@ -174,24 +191,24 @@ __global__ void vertex_kernel(const float *__restrict__ verts, const float *__re
   const PoseRec &rec = recs[n];
   const float *M = rec.M, *pose = rec.pose;
   float x = verts[v * 3], y = verts[v * 3 + 1], z = verts[v * 3 + 2];
-  float tx = M[0] * x + M[4] * y + M[8] * z + M[12];
-  float ty = M[1] * x + M[5] * y + M[9] * z + M[13];
-  float tz = M[2] * x + M[6] * y + M[10] * z + M[14];
-  float tw = M[3] * x + M[7] * y + M[11] * z + M[15];
+  float tx = dot3<FMAD>(M[0], x, M[4], y, M[8], z) + M[12];
+  float ty = dot3<FMAD>(M[1], x, M[5], y, M[9], z) + M[13];
+  float tz = dot3<FMAD>(M[2], x, M[6], y, M[10], z) + M[14];
+  float tw = dot3<FMAD>(M[3], x, M[7], y, M[11], z) + M[15];
   float4 c;
-  c.x = tx * rec.a00 + tw * rec.a30;
-  c.y = ty * rec.a11 + tw * rec.a31;
+  c.x = mad<FMAD>(tw, rec.a30, tx * rec.a00);
+  c.y = mad<FMAD>(tw, rec.a31, ty * rec.a11);
   c.z = tz;
   c.w = tw;
   float4 a;
-  a.x = pose[0] * x + pose[4] * y + pose[8] * z + pose[12];
-  a.y = pose[1] * x + pose[5] * y + pose[9] * z + pose[13];
-  a.z = pose[2] * x + pose[6] * y + pose[10] * z + pose[14];
+  a.x = dot3<FMAD>(pose[0], x, pose[4], y, pose[8], z) + pose[12];
+  a.y = dot3<FMAD>(pose[1], x, pose[5], y, pose[9], z) + pose[13];
+  a.z = dot3<FMAD>(pose[2], x, pose[6], y, pose[10], z) + pose[14];
   float nx = normals[v * 3], ny = normals[v * 3 + 1], nz = normals[v * 3 + 2];
-  float ux = pose[0] * nx + pose[4] * ny + pose[8] * nz;
-  float uy = pose[1] * nx + pose[5] * ny + pose[9] * nz;
-  float uz = pose[2] * nx + pose[6] * ny + pose[10] * nz;
-  float l2 = sqrtf(ux * ux + uy * uy + uz * uz);
+  float ux = dot3<FMAD>(pose[0], nx, pose[4], ny, pose[8], nz);
+  float uy = dot3<FMAD>(pose[1], nx, pose[5], ny, pose[9], nz);
+  float uz = dot3<FMAD>(pose[2], nx, pose[6], ny, pose[10], nz);
+  float l2 = sqrtf(dot3<FMAD>(ux, ux, uy, uy, uz, uz));
   float val = l2 == 0 ? 0 : -uz / l2;
   a.w = clampf(val, 0, 1);
   clip[(size_t)n * V + v] = c;
@@ -211,12 +228,13 @@ __global__ void vertex_kernel(const float *__restrict__ verts, const float *__re
 #ifdef FP_TEST_HOOKS
 float4 *g_vertex_dbg = nullptr;  // race hunt (tools/dbg_concurrent3.py): launches with N == 64 fill it
 #endif
-void launch_vertex(hipStream_t s, const DeviceMesh &m, const PoseRec *recs, int N, float4 *clip, float4 *attr) {
+void launch_vertex(hipStream_t s, const DeviceMesh &m, const PoseRec *recs, int N, float4 *clip, float4 *attr, bool fmad) {
   float4 *dbg = nullptr;
 #ifdef FP_TEST_HOOKS
   if (g_vertex_dbg && N == 64) dbg = g_vertex_dbg;
 #endif
-  hipLaunchKernelGGL(vertex_kernel, dim3((m.V + 255) / 256, N), dim3(256), 0, s, m.verts, m.normals, m.V, recs, clip, attr, dbg);
+  if (fmad) hipLaunchKernelGGL(vertex_kernel<true>, dim3((m.V + 255) / 256, N), dim3(256), 0, s, m.verts, m.normals, m.V, recs, clip, attr, dbg);
+  else hipLaunchKernelGGL(vertex_kernel<false>, dim3((m.V + 255) / 256, N), dim3(256), 0, s, m.verts, m.normals, m.V, recs, clip, attr, dbg);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -247,6 +265,39 @@ __device__ __forceinline__ bool edge_covers(int ox, int oy, int dx, int dy) {
   return e >= 0;
 }
 
+// 32-bit fixed-point depth plane of a triangle, depth(px, py) = gx*px + gy*py + g0 (mod 2^32), with CudaRaster's
+// arithmetic (setupPleq, CR/impl/Util.inl:184-210: the results must agree bit for bit, so the integer operations and
+// their order are the reference's; the decomposition into steps is this file's):
+//   1. the three depths share one block exponent: `drop` low bits are shifted out so that the largest keeps 23 bits;
+//   2. gradients = (depth differences x edge vectors) / area, the division carried out as a multiplication by the 24-bit
+//      mantissa of 1/area and one final shift;
+//   3. the constant term is anchored at the centre of the triangle's bounding box to keep the products small.
+struct DepthPlane { unsigned gx, gy, g0; };
+__device__ __forceinline__ DepthPlane make_depth_plane(float zA, float zB, float zC, I2 A /* vertex A, window sub-pixels minus half a pixel */,
+                                                       I2 e1, I2 e2, int area) {
+  const float inv_area = 1.0f / (float)area;
+  const float zmax = fmaxf(fmaxf(zA, zB), zC);
+  const int drop = min(max((__float_as_int(zmax) >> 23) - (127 + 22), 0), 8);
+  const int qA = (int)(f32_to_u32_trunc(zA) >> drop);
+  const int dB = (int)((f32_to_u32_trunc(zB) >> drop) - (unsigned)qA);
+  const int dC = (int)((f32_to_u32_trunc(zC) >> drop) - (unsigned)qA);
+  const unsigned mant = ((unsigned)__float_as_int(inv_area) & 0x007FFFFFu) | 0x00800000u;
+  const int expo = (23 + 127) - (__float_as_int(inv_area) >> 23);
+  const long long nx = ((long long)dB * e2.y - (long long)dC * e1.y) * (long long)mant;
+  const long long ny = ((long long)dC * e1.x - (long long)dB * e2.x) * (long long)mant;
+  DepthPlane pl;
+  pl.gx = (unsigned)(nx >> (expo - (drop + CR_SUBPIXEL_LOG2)));
+  pl.gy = (unsigned)(ny >> (expo - (drop + CR_SUBPIXEL_LOG2)));
+  const int cx = (A.x * 2 + imin3(e1.x, e2.x, 0) + imax3(e1.x, e2.x, 0)) >> (CR_SUBPIXEL_LOG2 + 1);
+  const int cy = (A.y * 2 + imin3(e1.y, e2.y, 0) + imax3(e1.y, e2.y, 0)) >> (CR_SUBPIXEL_LOG2 + 1);
+  const int ox = A.x - (int)((unsigned)cx << CR_SUBPIXEL_LOG2);
+  const int oy = A.y - (int)((unsigned)cy << CR_SUBPIXEL_LOG2);
+  pl.g0 = (unsigned)qA << drop;
+  pl.g0 -= (unsigned)(((nx >> 13) * ox + (ny >> 13) * oy) >> (expo - (drop + 13)));
+  pl.g0 -= pl.gx * (unsigned)cx + pl.gy * (unsigned)cy;
+  return pl;
+}
+
 // snap + setup + rasterise one (sub)triangle into the strip's LDS z-buffer
 template <int STRIP_ROWS>
 __device__ __forceinline__ void raster_one(float4 v0, float4 v1, float4 v2, unsigned color, int row0,
@@ -272,35 +323,13 @@ __device__ __forceinline__ void raster_one(float4 v0, float4 v1, float4 v2, unsi
   int px0 = max((minx + bx + 15) >> 4, 0), px1 = min((maxx + bx) >> 4, CROP - 1);
   int py0 = max((miny + bx + 15) >> 4, row0), py1 = min((maxy + bx) >> 4, row0 + STRIP_ROWS - 1);
   if (px0 > px1 || py0 > py1) return;
-  // fixed-point depth plane (setupTriangle + setupPleq)
+  // window-space depths in the 32-bit fixed-point range (the one fused multiply-add the reference's source spells out)
   const float zcoef = (float)(CR_DEPTH_MAX - CR_DEPTH_MIN) * 0.5f;
   const float zbias = (float)(unsigned)(CR_DEPTH_MAX + CR_DEPTH_MIN) * 0.5f;
-  float zv0 = fmaf(z0 * zcoef, rw0, zbias), zv1 = fmaf(z1 * zcoef, rw1, zbias), zv2 = fmaf(z2 * zcoef, rw2, zbias);
-  unsigned plx, ply, plz;
-  {
-    I2 q0 = {p0.x + (CROP << (CR_SUBPIXEL_LOG2 - 1)) - (1 << (CR_SUBPIXEL_LOG2 - 1)),
-             p0.y + (CROP << (CR_SUBPIXEL_LOG2 - 1)) - (1 << (CR_SUBPIXEL_LOG2 - 1))};
-    float areaRcp = 1.0f / (float)area;
-    float mxz = fmaxf(fmaxf(zv0, zv1), zv2);
-    int sh = (__float_as_int(mxz) >> 23) - (127 + 22);
-    sh = min(max(sh, 0), 8);
-    int t0 = (int)(f32_to_u32_trunc(zv0) >> sh);
-    int t1 = (int)((f32_to_u32_trunc(zv1) >> sh) - (unsigned)t0);
-    int t2 = (int)((f32_to_u32_trunc(zv2) >> sh) - (unsigned)t0);
-    unsigned rcpMant = ((unsigned)__float_as_int(areaRcp) & 0x007FFFFFu) | 0x00800000u;
-    int rcpShift = (23 + 127) - (__float_as_int(areaRcp) >> 23);
-    long long xc = ((long long)t1 * d2.y - (long long)t2 * d1.y) * (long long)rcpMant;
-    long long yc = ((long long)t2 * d1.x - (long long)t1 * d2.x) * (long long)rcpMant;
-    plx = (unsigned)(xc >> (rcpShift - (sh + CR_SUBPIXEL_LOG2)));
-    ply = (unsigned)(yc >> (rcpShift - (sh + CR_SUBPIXEL_LOG2)));
-    int centerX = (q0.x * 2 + imin3(d1.x, d2.x, 0) + imax3(d1.x, d2.x, 0)) >> (CR_SUBPIXEL_LOG2 + 1);
-    int centerY = (q0.y * 2 + imin3(d1.y, d2.y, 0) + imax3(d1.y, d2.y, 0)) >> (CR_SUBPIXEL_LOG2 + 1);
-    int vcx = q0.x - (int)((unsigned)centerX << CR_SUBPIXEL_LOG2);
-    int vcy = q0.y - (int)((unsigned)centerY << CR_SUBPIXEL_LOG2);
-    plz = (unsigned)t0 << sh;
-    plz -= (unsigned)(((xc >> 13) * vcx + (yc >> 13) * vcy) >> (rcpShift - (sh + 13)));
-    plz -= plx * (unsigned)centerX + ply * (unsigned)centerY;
-  }
+  const float zv0 = fmaf(z0 * zcoef, rw0, zbias), zv1 = fmaf(z1 * zcoef, rw1, zbias), zv2 = fmaf(z2 * zcoef, rw2, zbias);
+  const I2 anchor = {p0.x + (CROP << (CR_SUBPIXEL_LOG2 - 1)) - (1 << (CR_SUBPIXEL_LOG2 - 1)),
+                     p0.y + (CROP << (CR_SUBPIXEL_LOG2 - 1)) - (1 << (CR_SUBPIXEL_LOG2 - 1))};
+  const DepthPlane pl = make_depth_plane(zv0, zv1, zv2, anchor, d1, d2, area);
   int d01x = p1.x - p0.x, d01y = p1.y - p0.y;
   int d12x = p2.x - p1.x, d12y = p2.y - p1.y;
   int d20x = p0.x - p2.x, d20y = p0.y - p2.y;
@@ -314,71 +343,77 @@ __device__ __forceinline__ void raster_one(float4 v0, float4 v1, float4 v2, unsi
       if (!edge_covers(o0x, o0y, d01x, d01y)) continue;
       if (!edge_covers(o0x + d01x, o0y + d01y, d12x, d12y)) continue;
       if (!edge_covers(o0x, o0y, d20x, d20y)) continue;
-      unsigned depth = plx * (unsigned)px + ply * (unsigned)py + plz;
+      unsigned depth = pl.gx * (unsigned)px + pl.gy * (unsigned)py + pl.g0;
       unsigned long long key = ((unsigned long long)depth << 32) | lowkey;
       atomicMin(&zbuf[(py - row0) * CROP + px], key);
     }
   }
 }
 
-__device__ __forceinline__ int clip_poly_plane(float *out, const float *in, int numIn, float v0, float v1, float v2) {
-  int numOut = 0;
-  if (numIn >= 3) {
-    int ai = (numIn - 1) * 2;
-    float av = v0 + v1 * in[ai + 0] + v2 * in[ai + 1];
-    for (int bi = 0; bi < numIn * 2; bi += 2) {
-      float bv = v0 + v1 * in[bi + 0] + v2 * in[bi + 1];
-      if (av * bv < 0.0f) {
-        float bc = av / (av - bv), ac = 1.0f - bc;
-        out[numOut + 0] = in[ai + 0] * ac + in[bi + 0] * bc;
-        out[numOut + 1] = in[ai + 1] * ac + in[bi + 1] * bc;
-        numOut += 2;
-      }
-      if (bv >= 0.0f) { out[numOut + 0] = in[bi + 0]; out[numOut + 1] = in[bi + 1]; numOut += 2; }
-      ai = bi; av = bv;
+// One Sutherland-Hodgman pass.  The polygon lives in the triangle's barycentric plane (points (u, v)); the half-space
+// kept is f(u, v) = c0 + c1*u + c2*v >= 0 -- for a frustum plane w +- x_axis >= 0 that is (w0 +- a0) + (dw1 +- da1)*u +
+// (dw2 +- da2)*v.  An edge whose end points have values of opposite sign contributes its intersection, interpolated with
+// the weights fp / (fp - fc) like the reference's clipper (CR/impl/Util.inl:101-132), so that the fan fed to the
+// rasteriser is identical; FMAD applies the float model above to the two sums.
+template <bool FMAD>
+__device__ __forceinline__ int sh_clip_pass(const float (*src)[2], int n, float (*dst)[2], float c0, float c1, float c2) {
+  if (n < 3) return 0;
+  int m = 0;
+  float pu = src[n - 1][0], pv = src[n - 1][1];
+  float pf = FMAD ? fmaf(c2, pv, fmaf(c1, pu, c0)) : c0 + c1 * pu + c2 * pv;
+  for (int i = 0; i < n; i++) {
+    const float cu = src[i][0], cv = src[i][1];
+    const float cf = FMAD ? fmaf(c2, cv, fmaf(c1, cu, c0)) : c0 + c1 * cu + c2 * cv;
+    if (pf * cf < 0.0f) {  // the edge previous -> current crosses the plane
+      const float wc = pf / (pf - cf), wp = 1.0f - wc;
+      dst[m][0] = mad<FMAD>(cu, wc, pu * wp);
+      dst[m][1] = mad<FMAD>(cv, wc, pv * wp);
+      m++;
     }
+    if (cf >= 0.0f) { dst[m][0] = cu; dst[m][1] = cv; m++; }
+    pu = cu; pv = cv; pf = cf;
   }
-  return numOut >> 1;
+  return m;
 }
 
 // rare path: triangle crosses the depth range or leaves the S16 snap range -> clip against the frustum and fan
-template <int STRIP_ROWS>
+template <int STRIP_ROWS, bool FMAD>
 __device__ __noinline__ void raster_clipped(float4 v0, float4 v1, float4 v2, unsigned color, int row0,
                                             unsigned long long *zbuf) {
-  float bary[18], temp[18];
-  int num = 3;
-  bary[0] = 0.0f; bary[1] = 0.0f; bary[2] = 1.0f; bary[3] = 0.0f; bary[4] = 0.0f; bary[5] = 1.0f;
+  float poly[2][9][2];  // ping-pong polygon buffers: at most 3 + 6 vertices
+  int cur = 0, num = 3;
+  poly[0][0][0] = 0.0f; poly[0][0][1] = 0.0f; poly[0][1][0] = 1.0f; poly[0][1][1] = 0.0f; poly[0][2][0] = 0.0f; poly[0][2][1] = 1.0f;
   const float a0[4] = {v0.x, v0.y, v0.z, v0.w}, a1[4] = {v1.x, v1.y, v1.z, v1.w}, a2[4] = {v2.x, v2.y, v2.z, v2.w};
-  const float d1[4] = {v1.x - v0.x, v1.y - v0.y, v1.z - v0.z, v1.w - v0.w};
-  const float d2[4] = {v2.x - v0.x, v2.y - v0.y, v2.z - v0.z, v2.w - v0.w};
+  const float e1[4] = {v1.x - v0.x, v1.y - v0.y, v1.z - v0.z, v1.w - v0.w};
+  const float e2[4] = {v2.x - v0.x, v2.y - v0.y, v2.z - v0.z, v2.w - v0.w};
   for (int ax = 0; ax < 3; ax++) {
-    if ((a0[3] < fabsf(a0[ax])) | (a1[3] < fabsf(a1[ax])) | (a2[3] < fabsf(a2[ax]))) {
-      num = clip_poly_plane(temp, bary, num, a0[3] + a0[ax], d1[3] + d1[ax], d2[3] + d2[ax]);
-      num = clip_poly_plane(bary, temp, num, a0[3] - a0[ax], d1[3] - d1[ax], d2[3] - d2[ax]);
-    }
+    const bool outside = (a0[3] < fabsf(a0[ax])) | (a1[3] < fabsf(a1[ax])) | (a2[3] < fabsf(a2[ax]));
+    if (!outside) continue;
+    num = sh_clip_pass<FMAD>(poly[cur], num, poly[cur ^ 1], a0[3] + a0[ax], e1[3] + e1[ax], e2[3] + e2[ax]);  // w + axis >= 0
+    num = sh_clip_pass<FMAD>(poly[cur ^ 1], num, poly[cur], a0[3] - a0[ax], e1[3] - e1[ax], e2[3] - e2[ax]);  // w - axis >= 0
   }
   if (num < 3) return;
-  float4 c0, c1, c2;
-#define FP_BARY_PT(dst, i)                                             \
-  do {                                                                 \
-    (dst).x = a0[0] + d1[0] * bary[(i)*2] + d2[0] * bary[(i)*2 + 1];   \
-    (dst).y = a0[1] + d1[1] * bary[(i)*2] + d2[1] * bary[(i)*2 + 1];   \
-    (dst).z = a0[2] + d1[2] * bary[(i)*2] + d2[2] * bary[(i)*2 + 1];   \
-    (dst).w = a0[3] + d1[3] * bary[(i)*2] + d2[3] * bary[(i)*2 + 1];   \
-  } while (0)
-  FP_BARY_PT(c0, 0);
-  FP_BARY_PT(c1, 1);
-  for (int i = 2; i < num; i++) {
-    FP_BARY_PT(c2, i);
-    raster_one<STRIP_ROWS>(c0, c1, c2, color, row0, zbuf);
-    c1 = c2;
+  auto point = [&](int i) {
+    const float u = poly[cur][i][0], v = poly[cur][i][1];
+    float4 q;
+    q.x = mad<FMAD>(e2[0], v, mad<FMAD>(e1[0], u, a0[0]));
+    q.y = mad<FMAD>(e2[1], v, mad<FMAD>(e1[1], u, a0[1]));
+    q.z = mad<FMAD>(e2[2], v, mad<FMAD>(e1[2], u, a0[2]));
+    q.w = mad<FMAD>(e2[3], v, mad<FMAD>(e1[3], u, a0[3]));
+    return q;
+  };
+  const float4 hub = point(0);
+  float4 prev = point(1);
+  for (int i = 2; i < num; i++) {  // triangle fan around the first vertex
+    const float4 next = point(i);
+    raster_one<STRIP_ROWS>(hub, prev, next, color, row0, zbuf);
+    prev = next;
   }
-#undef FP_BARY_PT
 }
 
 // NT threads per workgroup: 256 normally; 1024 for tiny batches (Track), where the kernel is bound by the latency of the
 // F/NT dependent triangle iterations of each strip rather than by throughput
-template <int MODE, int STRIP_ROWS, int NT = 256>
+template <int MODE, int STRIP_ROWS, int NT, bool FMAD>
 __global__ __launch_bounds__(NT) void raster_shade_kernel(
     const int32_t *__restrict__ faces, int F, int V, const float *__restrict__ uvs, const uint8_t *__restrict__ tex,
     int TH, int TW, float downscale, const PoseRec *__restrict__ recs, const float4 *__restrict__ clip_all,
@@ -418,7 +453,7 @@ __global__ __launch_bounds__(NT) void raster_shade_kernel(
       fast = (loxy >= -32768 && hixy <= 32767 && hixy - loxy <= aabbLimit);
     }
     if (fast) raster_one<STRIP_ROWS>(v0, v1, v2, (unsigned)(f + 1), row0, zbuf);
-    else raster_clipped<STRIP_ROWS>(v0, v1, v2, (unsigned)(f + 1), row0, zbuf);
+    else raster_clipped<STRIP_ROWS, FMAD>(v0, v1, v2, (unsigned)(f + 1), row0, zbuf);
   }
   __syncthreads();
 
@@ -435,14 +470,14 @@ __global__ __launch_bounds__(NT) void raster_shade_kernel(
     if (triIdx >= 0 && triIdx < F) {
       int vi0 = faces[triIdx * 3], vi1 = faces[triIdx * 3 + 1], vi2 = faces[triIdx * 3 + 2];
       float4 p0 = clip[vi0], p1 = clip[vi1], p2 = clip[vi2];
-      float fx = xs * (float)px + xo, fy = xs * (float)py + xo;
-      float p0x = p0.x - fx * p0.w, p0y = p0.y - fy * p0.w;
-      float p1x = p1.x - fx * p1.w, p1y = p1.y - fy * p1.w;
-      float p2x = p2.x - fx * p2.w, p2y = p2.y - fy * p2.w;
-      float a0 = p1x * p2y - p1y * p2x, a1 = p2x * p0y - p2y * p0x, a2 = p0x * p1y - p0y * p1x;
+      float fx = mad<FMAD>(xs, (float)px, xo), fy = mad<FMAD>(xs, (float)py, xo);
+      float p0x = mad<FMAD>(-fx, p0.w, p0.x), p0y = mad<FMAD>(-fy, p0.w, p0.y);
+      float p1x = mad<FMAD>(-fx, p1.w, p1.x), p1y = mad<FMAD>(-fy, p1.w, p1.y);
+      float p2x = mad<FMAD>(-fx, p2.w, p2.x), p2y = mad<FMAD>(-fy, p2.w, p2.y);
+      float a0 = diffprod<FMAD>(p1x, p2y, p1y, p2x), a1 = diffprod<FMAD>(p2x, p0y, p2y, p0x), a2 = diffprod<FMAD>(p0x, p1y, p0y, p1x);
       float iw = 1.f / (a0 + a1 + a2);
       b0 = a0 * iw; b1 = a1 * iw;
-      float z = p0.z * a0 + p1.z * a1 + p2.z * a2, w = p0.w * a0 + p1.w * a1 + p2.w * a2;
+      float z = dot3<FMAD>(p0.z, a0, p1.z, a1, p2.z, a2), w = dot3<FMAD>(p0.w, a0, p1.w, a1, p2.w, a2);
       zw = z / w;
       b0 = clampf(b0, 0.f, 1.f); b1 = clampf(b1, 0.f, 1.f);
       if (b0 != b0) b0 = 0.f;
@@ -451,12 +486,12 @@ __global__ __launch_bounds__(NT) void raster_shade_kernel(
       idf = (float)(triIdx + 1);
       float b2 = 1.f - b0 - b1;
       float4 q0 = attr[vi0], q1 = attr[vi1], q2 = attr[vi2];
-      xyz0 = b0 * q0.x + b1 * q1.x + b2 * q2.x;
-      xyz1 = b0 * q0.y + b1 * q1.y + b2 * q2.y;
-      xyz2 = b0 * q0.z + b1 * q1.z + b2 * q2.z;
-      dif = b0 * q0.w + b1 * q1.w + b2 * q2.w;
-      uu = b0 * uvs[vi0 * 2] + b1 * uvs[vi1 * 2] + b2 * uvs[vi2 * 2];
-      vv = b0 * uvs[vi0 * 2 + 1] + b1 * uvs[vi1 * 2 + 1] + b2 * uvs[vi2 * 2 + 1];
+      xyz0 = dot3<FMAD>(b0, q0.x, b1, q1.x, b2, q2.x);
+      xyz1 = dot3<FMAD>(b0, q0.y, b1, q1.y, b2, q2.y);
+      xyz2 = dot3<FMAD>(b0, q0.z, b1, q1.z, b2, q2.z);
+      dif = dot3<FMAD>(b0, q0.w, b1, q1.w, b2, q2.w);
+      uu = dot3<FMAD>(b0, uvs[vi0 * 2], b1, uvs[vi1 * 2], b2, uvs[vi2 * 2]);
+      vv = dot3<FMAD>(b0, uvs[vi0 * 2 + 1], b1, uvs[vi1 * 2 + 1], b2, uvs[vi2 * 2 + 1]);
     }
     if (tri_id_dbg) tri_id_dbg[((size_t)n * CROP + py) * CROP + px] = (int)color;
     if (rast_dbg) {
@@ -468,7 +503,7 @@ __global__ __launch_bounds__(NT) void raster_shade_kernel(
     if (fg > 0.0f) {
       // bilinear texture fetch, wrap addressing, texel centre u*w - 0.5, texture value = u8 * (1/255)
       float u = uu - floorf(uu), v = vv - floorf(vv);
-      u = u * (float)TW - 0.5f; v = v * (float)TH - 0.5f;
+      u = mad<FMAD>(u, (float)TW, -0.5f); v = mad<FMAD>(v, (float)TH, -0.5f);
       int iu0 = (int)floorf(u), iv0 = (int)floorf(v);
       int iu1 = iu0 + 1, iv1 = iv0 + 1;
       u -= (float)iu0; v -= (float)iv0;
@@ -479,11 +514,11 @@ __global__ __launch_bounds__(NT) void raster_shade_kernel(
       const float sc = 1.0f / 255.0f;
       const uint8_t *t00 = tex + (iu0 + TW * iv0) * 3, *t10 = tex + (iu1 + TW * iv0) * 3;
       const uint8_t *t01 = tex + (iu0 + TW * iv1) * 3, *t11 = tex + (iu1 + TW * iv1) * 3;
-      float shade = 0.8f + dif * 0.5f;
+      float shade = mad<FMAD>(dif, 0.5f, 0.8f);
       for (int c = 0; c < 3; c++) {
         float a00 = (float)t00[c] * sc, a10 = (float)t10[c] * sc, a01 = (float)t01[c] * sc, a11 = (float)t11[c] * sc;
-        float top = a00 + u * (a10 - a00), bot = a01 + u * (a11 - a01);
-        float rgb = top + v * (bot - top);
+        float top = mad<FMAD>(u, a10 - a00, a00), bot = mad<FMAD>(u, a11 - a01, a01);
+        float rgb = mad<FMAD>(v, bot - top, top);
         float q = rgb * shade * fg;
         o[c] = clampf(clampf(q, 0, 1), 0.0f, 1.0f);
       }
@@ -508,18 +543,18 @@ __global__ __launch_bounds__(NT) void raster_shade_kernel(
   }
 }
 
-template <int MODE, int STRIP_ROWS>
+template <int MODE, int STRIP_ROWS, bool FMAD>
 static void launch_raster_shade_t(hipStream_t s, const DeviceMesh &m, const PoseRec *recs, int N, const float4 *clip,
                                   const float4 *attr, void *out, int32_t *tri_id_dbg, float *rast_dbg) {
   size_t lds = (size_t)STRIP_ROWS * CROP * sizeof(unsigned long long);
   dim3 grid(CROP / STRIP_ROWS, N), block(256);
   float downscale = m.diameter / 2;
   if (STRIP_ROWS == 8 && N <= 4 && MODE != OUT_F32X6 && !tri_id_dbg && !rast_dbg) {
-    hipLaunchKernelGGL((raster_shade_kernel<MODE, STRIP_ROWS, 1024>), grid, dim3(1024), lds, s, m.faces, m.F, m.V, m.uvs,
+    hipLaunchKernelGGL((raster_shade_kernel<MODE, STRIP_ROWS, 1024, FMAD>), grid, dim3(1024), lds, s, m.faces, m.F, m.V, m.uvs,
                        m.tex, m.TH, m.TW, downscale, recs, clip, attr, out, tri_id_dbg, rast_dbg);
     return;
   }
-  hipLaunchKernelGGL((raster_shade_kernel<MODE, STRIP_ROWS>), grid, block, lds, s, m.faces, m.F, m.V, m.uvs, m.tex,
+  hipLaunchKernelGGL((raster_shade_kernel<MODE, STRIP_ROWS, 256, FMAD>), grid, block, lds, s, m.faces, m.F, m.V, m.uvs, m.tex,
                      m.TH, m.TW, downscale, recs, clip, attr, out, tri_id_dbg, rast_dbg);
 }
 
@@ -533,43 +568,49 @@ static constexpr int g_strip_rows_override = 0;
 // tall strips with 1024-thread workgroups: every strip walks ALL triangles (setup + cull), so 2 strips of 80 rows do a
 // quarter of the redundant setup of 8 strips of 20 (0.40 -> 0.21 ms per Register at N = 252); 102 KB of LDS = one
 // workgroup per CU, hence 16 waves per workgroup.  A/B codes for set_raster_strip_rows: 1080 / 1040 / 1020
-template <int MODE, int STRIP_ROWS>
+template <int MODE, int STRIP_ROWS, bool FMAD>
 static void launch_raster_tall(hipStream_t s, const DeviceMesh &m, const PoseRec *recs, int N, const float4 *clip,
                                const float4 *attr, void *out) {
   size_t lds = (size_t)STRIP_ROWS * CROP * sizeof(unsigned long long);
   // once per instantiation, thread-safe (function-local static): opt in to > 64 KB of dynamic LDS
-  static const hipError_t attr_rc = hipFuncSetAttribute((const void *)raster_shade_kernel<MODE, STRIP_ROWS, 1024>,
+  static const hipError_t attr_rc = hipFuncSetAttribute((const void *)raster_shade_kernel<MODE, STRIP_ROWS, 1024, FMAD>,
                                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   (void)attr_rc;
-  hipLaunchKernelGGL((raster_shade_kernel<MODE, STRIP_ROWS, 1024>), dim3(CROP / STRIP_ROWS, N), dim3(1024), lds, s, m.faces, m.F,
+  hipLaunchKernelGGL((raster_shade_kernel<MODE, STRIP_ROWS, 1024, FMAD>), dim3(CROP / STRIP_ROWS, N), dim3(1024), lds, s, m.faces, m.F,
                      m.V, m.uvs, m.tex, m.TH, m.TW, m.diameter / 2, recs, clip, attr, out, nullptr, nullptr);
 }
 
-template <int MODE>
+template <int MODE, bool FMAD>
 static void launch_raster_mode(hipStream_t s, const DeviceMesh &m, const PoseRec *recs, int N, const float4 *clip,
                                const float4 *attr, void *out, int32_t *tri_id_dbg, float *rast_dbg) {
   int rows = g_strip_rows_override ? g_strip_rows_override : (N >= 100 ? 1080 : (N >= 64 ? 20 : 8));
   if (rows > 1000 && MODE != OUT_F32X6 && !tri_id_dbg && !rast_dbg) {
-    if (rows == 1080) { launch_raster_tall<MODE, 80>(s, m, recs, N, clip, attr, out); return; }
+    if (rows == 1080) { launch_raster_tall<MODE, 80, FMAD>(s, m, recs, N, clip, attr, out); return; }
 #ifdef FP_TEST_HOOKS
-    if (rows == 1040) launch_raster_tall<MODE, 40>(s, m, recs, N, clip, attr, out);
-    else launch_raster_tall<MODE, 20>(s, m, recs, N, clip, attr, out);
+    if (rows == 1040) launch_raster_tall<MODE, 40, FMAD>(s, m, recs, N, clip, attr, out);
+    else launch_raster_tall<MODE, 20, FMAD>(s, m, recs, N, clip, attr, out);
     return;
 #endif
   }
   if (rows > 1000) rows = 20;
 #ifdef FP_TEST_HOOKS
-  if (rows == 40) { launch_raster_shade_t<MODE, 40>(s, m, recs, N, clip, attr, out, tri_id_dbg, rast_dbg); return; }
+  if (rows == 40) { launch_raster_shade_t<MODE, 40, FMAD>(s, m, recs, N, clip, attr, out, tri_id_dbg, rast_dbg); return; }
 #endif
-  if (rows == 20) launch_raster_shade_t<MODE, 20>(s, m, recs, N, clip, attr, out, tri_id_dbg, rast_dbg);
-  else launch_raster_shade_t<MODE, 8>(s, m, recs, N, clip, attr, out, tri_id_dbg, rast_dbg);
+  if (rows == 20) launch_raster_shade_t<MODE, 20, FMAD>(s, m, recs, N, clip, attr, out, tri_id_dbg, rast_dbg);
+  else launch_raster_shade_t<MODE, 8, FMAD>(s, m, recs, N, clip, attr, out, tri_id_dbg, rast_dbg);
 }
 
 void launch_raster_shade(hipStream_t s, const DeviceMesh &m, const PoseRec *recs, int N, const float4 *clip,
-                         const float4 *attr, OutMode mode, void *out, int32_t *tri_id_dbg, float *rast_dbg) {
-  if (mode == OUT_F32X6) launch_raster_mode<OUT_F32X6>(s, m, recs, N, clip, attr, out, tri_id_dbg, rast_dbg);
-  else if (mode == OUT_BF16X8) launch_raster_mode<OUT_BF16X8>(s, m, recs, N, clip, attr, out, tri_id_dbg, rast_dbg);
-  else launch_raster_mode<OUT_F16X8>(s, m, recs, N, clip, attr, out, tri_id_dbg, rast_dbg);
+                         const float4 *attr, OutMode mode, void *out, int32_t *tri_id_dbg, float *rast_dbg, bool fmad) {
+#define FP_RASTER_MODE(MODE)                                                                                      \
+  do {                                                                                                            \
+    if (fmad) launch_raster_mode<MODE, true>(s, m, recs, N, clip, attr, out, tri_id_dbg, rast_dbg);               \
+    else launch_raster_mode<MODE, false>(s, m, recs, N, clip, attr, out, tri_id_dbg, rast_dbg);                   \
+  } while (0)
+  if (mode == OUT_F32X6) FP_RASTER_MODE(OUT_F32X6);
+  else if (mode == OUT_BF16X8) FP_RASTER_MODE(OUT_BF16X8);
+  else FP_RASTER_MODE(OUT_F16X8);
+#undef FP_RASTER_MODE
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -109,9 +109,10 @@ void launch_pose_setup(hipStream_t s, const float *poses_dev, int N, const float
 #ifdef FP_TEST_HOOKS
 extern float4 *g_vertex_dbg;  // race hunt: per-vertex intermediates (null = off)
 #endif
-void launch_vertex(hipStream_t s, const DeviceMesh &m, const PoseRec *recs, int N, float4 *clip, float4 *attr);
+// fmad: float model of the vertex stage / shader / interpolator / texture unit (fp_geometry.hip "float model")
+void launch_vertex(hipStream_t s, const DeviceMesh &m, const PoseRec *recs, int N, float4 *clip, float4 *attr, bool fmad);
 void launch_raster_shade(hipStream_t s, const DeviceMesh &m, const PoseRec *recs, int N, const float4 *clip,
-                         const float4 *attr, OutMode mode, void *out, int32_t *tri_id_dbg, float *rast_dbg);
+                         const float4 *attr, OutMode mode, void *out, int32_t *tri_id_dbg, float *rast_dbg, bool fmad);
 #ifdef FP_TEST_HOOKS
 void set_raster_strip_rows(int rows);  // 0 = automatic (A/B hook)
 #endif

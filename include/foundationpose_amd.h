@@ -172,6 +172,16 @@ int fp_calibrate_fp8(fp_model *m, const void *rgb, const void *depth, const void
 int fp_get_calibration(const fp_model *m, float amax_out[32]);
 int fp_set_calibration(fp_model *m, const float amax[32]);
 
+/* ---- float model of the rendering stage --------------------------------------------------------------------------
+ * The reference's CUDA kernels are compiled by nvcc with its default -fmad=true (D6F/CMakeLists.txt:5 sets only -O3), so
+ * the vertex transforms (foundationpose_render.cu:321-443), the nvdiffrast shader / interpolator / texture unit and
+ * CudaRaster's clipper run with multiply-adds contracted.  1 (default): the same contraction, spelled with explicit fmaf
+ * under one documented rule; 0: every operation separately rounded.  The CPU oracle implements both. */
+#define FP_FLOAT_SEPARATE 0
+#define FP_FLOAT_FMAD 1
+int fp_set_float_model(fp_model *m, int float_model);
+int fp_get_float_model(const fp_model *m);
+
 /* ---- measurement hooks ---- */
 /* When enabled, every kernel launch is bracketed with HIP events on the model's stream and accumulated per kernel
  * family; fp_profile_report writes "name calls total_ms flops bytes" lines. */

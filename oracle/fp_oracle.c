@@ -24,6 +24,21 @@
 static inline int32_t f2i_bits(float f) { int32_t i; memcpy(&i, &f, 4); return i; }
 static inline float clampf(float f, float a, float b) { return fmaxf(a, fminf(f, b)); } /* foundationpose_render.cu:25-28 */
 
+/* ---- float model of the rendering stage ---------------------------------------------------------------------------
+ * The reference's kernels are built by nvcc with its default -fmad=true (D6F/CMakeLists.txt:5 sets only -O3): its binary
+ * contracts multiply-adds.  This file is compiled with -ffp-contract=off; g_fmad = 1 restates the contraction with
+ * explicit fmaf under one documented rule [EXT: ptxas' actual choices are not published]: in a sum of products evaluated
+ * left to right every `acc + a*b` becomes fmaf(a, b, acc), the first product of a chain stays a plain multiply,
+ * `x - a*b` is fmaf(-a, b, x), `a*b - c*d` is fmaf(a, b, -(c*d)).  g_fmad = 0: every operation separately rounded
+ * (round 1's model).  Applies to K4 / K5 / K13 (foundationpose_render.cu:321-443), the nvdiffrast shader, interpolator
+ * and texture unit, and CudaRaster's clipper -- exactly the expressions fp_geometry.hip marks with mad<> / dot3<>. */
+static int g_fmad = 0;
+void fpo_set_fmad(int on) { g_fmad = on != 0; }
+int fpo_get_fmad(void) { return g_fmad; }
+static inline float MAD(float a, float b, float c) { return g_fmad ? fmaf(a, b, c) : a * b + c; }
+static inline float DOT3(float a0, float b0, float a1, float b1, float a2, float b2) { return MAD(a2, b2, MAD(a1, b1, a0 * b0)); }
+static inline float DIFFPROD(float a, float b, float c, float d) { return g_fmad ? fmaf(a, b, -(c * d)) : a * b - c * d; }
+
 /* cvt.rni.sat.s32.f32 (CR/Util.inl:37): round-to-nearest-even, saturating, NaN -> 0 */
 static inline int32_t f32_to_s32_sat(float a) {
   if (a != a) return 0;
@@ -401,13 +416,13 @@ static int clip_polygon_with_plane(float *out, const float *in, int numIn, float
   int numOut = 0;
   if (numIn >= 3) {
     int ai = (numIn - 1) * 2;
-    float av = v0 + v1 * in[ai + 0] + v2 * in[ai + 1];
+    float av = MAD(v2, in[ai + 1], MAD(v1, in[ai + 0], v0));
     for (int bi = 0; bi < numIn * 2; bi += 2) {
-      float bv = v0 + v1 * in[bi + 0] + v2 * in[bi + 1];
+      float bv = MAD(v2, in[bi + 1], MAD(v1, in[bi + 0], v0));
       if (av * bv < 0.0f) {
         float bc = av / (av - bv), ac = 1.0f - bc;
-        out[numOut + 0] = in[ai + 0] * ac + in[bi + 0] * bc;
-        out[numOut + 1] = in[ai + 1] * ac + in[bi + 1] * bc;
+        out[numOut + 0] = MAD(in[bi + 0], bc, in[ai + 0] * ac);
+        out[numOut + 1] = MAD(in[bi + 1], bc, in[ai + 1] * ac);
         numOut += 2;
       }
       if (bv >= 0.0f) { out[numOut + 0] = in[bi + 0]; out[numOut + 1] = in[bi + 1]; numOut += 2; }
@@ -567,10 +582,10 @@ static void cr_draw_triangle(int vw, int vh, f4 v0, f4 v1, f4 v2, uint32_t color
   f4 c0, c1, c2;
 #define BARY_PT(dst, i)                                       \
   do {                                                        \
-    (dst).x = ov0[0] + od1[0] * bary[(i)*2] + od2[0] * bary[(i)*2 + 1]; \
-    (dst).y = ov0[1] + od1[1] * bary[(i)*2] + od2[1] * bary[(i)*2 + 1]; \
-    (dst).z = ov0[2] + od1[2] * bary[(i)*2] + od2[2] * bary[(i)*2 + 1]; \
-    (dst).w = ov0[3] + od1[3] * bary[(i)*2] + od2[3] * bary[(i)*2 + 1]; \
+    (dst).x = MAD(od2[0], bary[(i)*2 + 1], MAD(od1[0], bary[(i)*2], ov0[0])); \
+    (dst).y = MAD(od2[1], bary[(i)*2 + 1], MAD(od1[1], bary[(i)*2], ov0[1])); \
+    (dst).z = MAD(od2[2], bary[(i)*2 + 1], MAD(od1[2], bary[(i)*2], ov0[2])); \
+    (dst).w = MAD(od2[3], bary[(i)*2 + 1], MAD(od1[3], bary[(i)*2], ov0[3])); \
   } while (0)
   BARY_PT(c0, 0); BARY_PT(c1, 1);
   for (int i = 2; i < numVerts; i++) {
@@ -586,7 +601,7 @@ static void cr_draw_triangle(int vw, int vh, f4 v0, f4 v1, f4 v2, uint32_t color
 /* a13-a16: render branch                                                                            */
 /* ------------------------------------------------------------------------------------------------ */
 
-static inline float lerpf(float a, float b, float c) { return a + c * (b - a); } /* NVDR/texture.cu:14 */
+static inline float lerpf(float a, float b, float c) { return MAD(c, b - a, a); } /* a + c * (b - a), NVDR/texture.cu:14 */
 
 void fpo_render(const fpo_mesh *m, const float *poses, int N, const float K[9], int img_h, int img_w,
                 int out_h, int out_w, float crop_ratio, float min_depth, float max_depth,
@@ -614,21 +629,21 @@ void fpo_render(const fpo_mesh *m, const float *poses, int N, const float K[9], 
     float a00 = img_w / (r - l), a11 = img_h / (t - b), a30 = (img_w - r - l) / (r - l), a31 = (img_h - t - b) / (t - b);
     for (int v = 0; v < V; v++) {
       float x = m->verts[v * 3], y = m->verts[v * 3 + 1], z = m->verts[v * 3 + 2];
-      float tx = M[0] * x + M[4] * y + M[8] * z + M[12];
-      float ty = M[1] * x + M[5] * y + M[9] * z + M[13];
-      float tz = M[2] * x + M[6] * y + M[10] * z + M[14];
-      float tw = M[3] * x + M[7] * y + M[11] * z + M[15];
-      clip[v].x = tx * a00 + tw * a30; clip[v].y = ty * a11 + tw * a31; clip[v].z = tz; clip[v].w = tw;
+      float tx = DOT3(M[0], x, M[4], y, M[8], z) + M[12];   /* M[0]*x + M[4]*y + M[8]*z + M[12] */
+      float ty = DOT3(M[1], x, M[5], y, M[9], z) + M[13];
+      float tz = DOT3(M[2], x, M[6], y, M[10], z) + M[14];
+      float tw = DOT3(M[3], x, M[7], y, M[11], z) + M[15];
+      clip[v].x = MAD(tw, a30, tx * a00); clip[v].y = MAD(tw, a31, ty * a11); clip[v].z = tz; clip[v].w = tw;
       /* transform_points_kernel :321-341 */
-      pts_cam[v * 3 + 0] = pose[0] * x + pose[4] * y + pose[8] * z + pose[12];
-      pts_cam[v * 3 + 1] = pose[1] * x + pose[5] * y + pose[9] * z + pose[13];
-      pts_cam[v * 3 + 2] = pose[2] * x + pose[6] * y + pose[10] * z + pose[14];
+      pts_cam[v * 3 + 0] = DOT3(pose[0], x, pose[4], y, pose[8], z) + pose[12];
+      pts_cam[v * 3 + 1] = DOT3(pose[1], x, pose[5], y, pose[9], z) + pose[13];
+      pts_cam[v * 3 + 2] = DOT3(pose[2], x, pose[6], y, pose[10], z) + pose[14];
       /* transform_normals_kernel :418-443 */
       float nx = m->normals[v * 3], ny = m->normals[v * 3 + 1], nz = m->normals[v * 3 + 2];
-      float ux = pose[0] * nx + pose[4] * ny + pose[8] * nz;
-      float uy = pose[1] * nx + pose[5] * ny + pose[9] * nz;
-      float uz = pose[2] * nx + pose[6] * ny + pose[10] * nz;
-      float l2 = sqrtf(ux * ux + uy * uy + uz * uz);
+      float ux = DOT3(pose[0], nx, pose[4], ny, pose[8], nz);
+      float uy = DOT3(pose[1], nx, pose[5], ny, pose[9], nz);
+      float uz = DOT3(pose[2], nx, pose[6], ny, pose[10], nz);
+      float l2 = sqrtf(DOT3(ux, ux, uy, uy, uz, uz));
       float val = l2 == 0 ? 0 : -uz / l2;
       diffuse[v] = clampf(val, 0, 1);
     }
@@ -657,23 +672,23 @@ void fpo_render(const fpo_mesh *m, const float *poses, int N, const float K[9], 
         if (valid) {
           int vi0 = m->faces[triIdx * 3], vi1 = m->faces[triIdx * 3 + 1], vi2 = m->faces[triIdx * 3 + 2];
           f4 p0 = clip[vi0], p1 = clip[vi1], p2 = clip[vi2];
-          float fx = xs * (float)px + xo, fy = ys * (float)py + yo;
-          float p0x = p0.x - fx * p0.w, p0y = p0.y - fy * p0.w;
-          float p1x = p1.x - fx * p1.w, p1y = p1.y - fy * p1.w;
-          float p2x = p2.x - fx * p2.w, p2y = p2.y - fy * p2.w;
-          float a0 = p1x * p2y - p1y * p2x, a1 = p2x * p0y - p2y * p0x, a2 = p0x * p1y - p0y * p1x;
+          float fx = MAD(xs, (float)px, xo), fy = MAD(ys, (float)py, yo);
+          float p0x = MAD(-fx, p0.w, p0.x), p0y = MAD(-fy, p0.w, p0.y);   /* p0.x - fx * p0.w */
+          float p1x = MAD(-fx, p1.w, p1.x), p1y = MAD(-fy, p1.w, p1.y);
+          float p2x = MAD(-fx, p2.w, p2.x), p2y = MAD(-fy, p2.w, p2.y);
+          float a0 = DIFFPROD(p1x, p2y, p1y, p2x), a1 = DIFFPROD(p2x, p0y, p2y, p0x), a2 = DIFFPROD(p0x, p1y, p0y, p1x);
           float iw = 1.f / (a0 + a1 + a2);
           b0 = a0 * iw; b1 = a1 * iw;
-          float z = p0.z * a0 + p1.z * a1 + p2.z * a2, w = p0.w * a0 + p1.w * a1 + p2.w * a2;
+          float z = DOT3(p0.z, a0, p1.z, a1, p2.z, a2), w = DOT3(p0.w, a0, p1.w, a1, p2.w, a2);
           zw = z / w;
           b0 = clampf(b0, 0.f, 1.f); b1 = clampf(b1, 0.f, 1.f); /* __saturatef */
           if (b0 != b0) b0 = 0.f; if (b1 != b1) b1 = 0.f;       /* __saturatef(NaN) = +0 */
           zw = fmaxf(fminf(zw, 1.f), -1.f);
           idf = (float)(triIdx + 1);
           float b2 = 1.f - b0 - b1;
-          for (int i = 0; i < 3; i++) xyz[i] = b0 * pts_cam[vi0 * 3 + i] + b1 * pts_cam[vi1 * 3 + i] + b2 * pts_cam[vi2 * 3 + i];
-          for (int i = 0; i < 2; i++) uv[i] = b0 * m->uvs[vi0 * 2 + i] + b1 * m->uvs[vi1 * 2 + i] + b2 * m->uvs[vi2 * 2 + i];
-          dif = b0 * diffuse[vi0] + b1 * diffuse[vi1] + b2 * diffuse[vi2];
+          for (int i = 0; i < 3; i++) xyz[i] = DOT3(b0, pts_cam[vi0 * 3 + i], b1, pts_cam[vi1 * 3 + i], b2, pts_cam[vi2 * 3 + i]);
+          for (int i = 0; i < 2; i++) uv[i] = DOT3(b0, m->uvs[vi0 * 2 + i], b1, m->uvs[vi1 * 2 + i], b2, m->uvs[vi2 * 2 + i]);
+          dif = DOT3(b0, diffuse[vi0], b1, diffuse[vi1], b2, diffuse[vi2]);
         }
         if (rast_out) { float *ro = rast_out + ((size_t)n * HW + pidx) * 4; ro[0] = b0; ro[1] = b1; ro[2] = zw; ro[3] = idf; }
         /* texture: bilinear, wrap, texel centre u*w-0.5; texture = u8 * (1/255) (foundationpose_render.cpp:503-506) */
@@ -682,7 +697,7 @@ void fpo_render(const fpo_mesh *m, const float *poses, int N, const float K[9], 
           int w = m->TW, h = m->TH;
           float u = uv[0], v = uv[1];
           u = u - floorf(u); v = v - floorf(v);
-          u = u * (float)w - 0.5f; v = v * (float)h - 0.5f;
+          u = MAD(u, (float)w, -0.5f); v = MAD(v, (float)h, -0.5f);
           int iu0 = (int)floorf(u), iv0 = (int)floorf(v);
           int iu1 = iu0 + 1, iv1 = iv0 + 1;
           u -= (float)iu0; v -= (float)iv0;
@@ -696,7 +711,7 @@ void fpo_render(const fpo_mesh *m, const float *poses, int N, const float K[9], 
           }
         }
         float fg = clampf(idf, 0, 1);
-        float shade = 0.8f + dif * 0.5f;
+        float shade = MAD(dif, 0.5f, 0.8f);
         float o[6];
         for (int c = 0; c < 3; c++) { float q = rgb[c] * shade * fg; q = clampf(q, 0, 1); o[c] = clampf(q, 0.0f, 1.0f); }
         /* threshold_and_downscale on the rendered xyz */

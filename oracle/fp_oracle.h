@@ -34,6 +34,11 @@ typedef struct {
   float diameter;        /* max pairwise vertex distance (assimp_mesh_loader.cpp:47-60) */
 } fpo_mesh;
 
+/* float model of the rendering stage: 1 = multiply-adds contracted like the reference's nvcc -fmad=true build (one documented
+ * rule, see fp_oracle.c), 0 = every operation separately rounded.  Process-wide; default 0. */
+void fpo_set_fmad(int on);
+int fpo_get_fmad(void);
+
 /* foundationpose_sampling.cpp:56-121,178-237.  Returns number of poses written (42*360/step). */
 int fpo_rotation_grid(int min_views, int inplane_step_deg, float *out_poses, int max_out);
 int fpo_icosphere(int min_views, float *out_verts /*[n,3]*/, int max_out);

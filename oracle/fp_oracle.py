@@ -27,7 +27,17 @@ def lib() -> C.CDLL:
     if _LIB is None:
         _LIB = C.CDLL(build())
         _LIB.fpo_mesh_diameter.restype = C.c_float
+        _LIB.fpo_set_fmad(1)   # default float model = the product's default (contracted like nvcc -fmad=true)
     return _LIB
+
+
+def set_fmad(on: bool) -> None:
+    """Float model of the rendering stage (fp_oracle.c): True = contracted multiply-adds (default), False = separate roundings."""
+    lib().fpo_set_fmad(1 if on else 0)
+
+
+def get_fmad() -> bool:
+    return bool(lib().fpo_get_fmad())
 
 
 class _Mesh(C.Structure):

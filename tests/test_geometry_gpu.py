@@ -198,3 +198,35 @@ def test_device_sampler_median_cases(syn_mesh):
         assert got is not None, (case, m.last_error)
         np.testing.assert_array_equal(got[0, :3, 3], syn.from_colmajor(ref[:1])[0, :3, 3], err_msg=f"case {case}")
     m.close()
+
+
+def test_separately_rounded_float_model_parity(syn_mesh, syn_scene):
+    """The default float model of the rendering stage contracts multiply-adds like the reference's nvcc -fmad=true build (all
+    tests above); FP_FLOAT_SEPARATE keeps every operation separately rounded.  HIP and oracle implement both: triangle ids
+    bit-exact and tensors within F32_TOL in the second model too (252 hypotheses, edge / clip poses, the big-triangle clip case)."""
+    m = FoundationPose(syn_mesh, syn.intrinsics())
+    try:
+        assert m.float_model == 1
+        m.set_float_model(0)
+        fo.set_fmad(False)
+        m.upload_frame(syn_scene.rgb, syn_scene.depth)
+        om = fo.OracleMesh(syn_mesh)
+        poses = m.get_hyp_poses(syn_scene.mask)
+        R = syn.random_rotation(11)
+        edge = np.stack([syn.pose_matrix(R, t) for t in [(0.45, 0.3, 0.7), (0.0, 0.0, 0.12), (0.0, 0.0, 0.05), (-0.6, 0.0, 0.7)]])
+        allp = np.concatenate([poses, edge])
+        tri, _ = m.debug_rasterize(syn_mesh.name, allp, 1.2)
+        a, _ = m.render_and_transform(syn_mesh.name, allp, 1.2)
+        ra, rtri, _ = fo.render(om, syn.to_colmajor(allp), syn_scene.K, (480, 640), 1.2, debug=True)
+        np.testing.assert_array_equal(tri, rtri)
+        np.testing.assert_allclose(a, ra, **F32_TOL)
+        # and the models differ from each other on the device exactly where they differ in the oracle
+        m.set_float_model(1)
+        fo.set_fmad(True)
+        a1, _ = m.render_and_transform(syn_mesh.name, allp[:8], 1.2)
+        r1 = fo.render(om, syn.to_colmajor(allp[:8]), syn_scene.K, (480, 640), 1.2)
+        np.testing.assert_allclose(a1, r1, **F32_TOL)
+        assert np.abs(a1 - a[:8]).max() > 0
+    finally:
+        fo.set_fmad(True)
+        m.close()

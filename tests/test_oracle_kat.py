@@ -22,6 +22,16 @@ def _quad_mesh(half=0.05, z=0.0, diameter=0.2, tex_val=200):
 K = syn.intrinsics()
 
 
+@pytest.fixture
+def float_model(request):
+    """runs a KAT under the float model named by its `fmad` parameter (fp_oracle.c: contracted like nvcc -fmad=true /
+    separately rounded) and restores the default afterwards.  The KAT inputs are small integers / powers of two, so
+    every product and sum is exact and BOTH models must reproduce the hand-derived answer."""
+    fo.set_fmad(request.getfixturevalue("fmad"))
+    yield
+    fo.set_fmad(True)
+
+
 def test_rotation_grid_counts_and_structure():
     # foundationpose_sampling.cpp:100 subdivides once (12 -> 42 >= 40); 42 views x 6 in-plane = 252 (:219)
     ico = fo.icosphere()
@@ -136,7 +146,8 @@ def test_argmax_first_max():
     assert fo.argmax(np.array([-5.0], np.float32)) == 0
 
 
-def test_render_quad_geometry_and_fill_rule():
+@pytest.mark.parametrize("fmad", [False, True])
+def test_render_quad_geometry_and_fill_rule(fmad, float_model):
     """A 0.1 m fronto-parallel square at z=1 m spans image u in [304,336], v in [224,256] (GL projection:
     ndc = 2u/W-1, i.e. u is a continuous coordinate with pixel i covering [i,i+1]).
     generate_pose_clip maps u in [bbox.l, bbox.r] = [282, 282+159/s] (s=160/76; ConstructBBox2D uses W-1=159,
@@ -174,7 +185,8 @@ def test_render_quad_geometry_and_fill_rule():
     assert (rast[0][cov][:, :2] >= 0).all() and (rast[0][cov][:, :2] <= 1).all()
 
 
-def test_render_depth_test_nearest_wins_and_tie_rule():
+@pytest.mark.parametrize("fmad", [False, True])
+def test_render_depth_test_nearest_wins_and_tie_rule(fmad, float_model):
     # two coincident quads (4 triangles): equal depth everywhere -> the later triangles win (FineRaster ROP rule)
     q = _quad_mesh()
     v = np.concatenate([q.vertices, q.vertices])
@@ -194,7 +206,8 @@ def test_render_depth_test_nearest_wins_and_tie_rule():
     assert set(np.unique(inner)) <= {1, 2}
 
 
-def test_render_frustum_clip_path():
+@pytest.mark.parametrize("fmad", [False, True])
+def test_render_frustum_clip_path(fmad, float_model):
     # a huge triangle crossing the near plane exercises clipTriangleWithFrustum; coverage must stay bounded and sane
     v = np.array([[-5, -5, 2.0], [5, -5, 2.0], [0, 5, -3.0]], np.float32)   # third vertex behind the camera
     mesh = syn.Mesh("big", v, np.tile(np.array([[0, 0, -1]], np.float32), (3, 1)), np.zeros((3, 2), np.float32),
@@ -240,3 +253,20 @@ def test_mesh_stats(syn_mesh):
     assert syn_mesh.vertices.shape == (2562, 3) and syn_mesh.faces.shape == (5120, 3)
     np.testing.assert_allclose(fo.mesh_diameter(syn_mesh.vertices), 0.19, rtol=1e-5)
     np.testing.assert_allclose(fo.mesh_center(syn_mesh.vertices + 0.5), [0.5, 0.5, 0.5], atol=1e-6)
+
+
+def test_float_models_differ_only_in_rounding(syn_mesh, syn_scene):
+    """contracted vs separately rounded rendering of three hypotheses of the synthetic scene: identical triangle ids (the
+    integer part of the pipeline sees the same snapped vertices), tensors equal up to a texel-boundary flip"""
+    om = fo.OracleMesh(syn_mesh)
+    poses = fo.get_hyp_poses(syn_scene.depth, syn_scene.mask, syn_scene.K)[[0, 100, 251]]
+    out = {}
+    try:
+        for fm in (False, True):
+            fo.set_fmad(fm)
+            out[fm] = fo.render(om, poses, syn_scene.K, syn_scene.depth.shape, 1.2, debug=True)
+    finally:
+        fo.set_fmad(True)
+    np.testing.assert_array_equal(out[False][1], out[True][1])
+    d = np.abs(out[False][0] - out[True][0])
+    assert 0 < d.max() < 2e-2 and d.mean() < 1e-6, (d.max(), d.mean())     # the models are really different, and only slightly
