@@ -18,7 +18,7 @@ SYMBOLS = [
     "fp_register", "fp_track", "fp_register_ex", "fp_track_ex",
     "fp_upload_frame", "fp_get_xyz_map", "fp_get_hyp_poses", "fp_filter_depth",
     "fp_render_and_transform", "fp_debug_rasterize", "fp_refiner_infer", "fp_scorer_infer",
-    "fp_refine_post_process", "fp_argmax", "fp_register_shard_begin", "fp_register_shard_finish",
+    "fp_refine_post_process", "fp_argmax", "fp_register_shard_begin", "fp_register_shard_finish", "fp_register_shard_begin_packed", "fp_register_shard_finish_packed",
     "fp_profile_enable", "fp_profile_reset", "fp_profile_report", "fp_stream", "fp_synchronize",
     "fp_mesh_load_obj", "fp_mesh_free", "fp_mesh_view", "fp_mesh_orient_bounds",
     "fp_image_read_png", "fp_frame_size", "fp_read_rgb_depth_mask", "fp_read_cam_k", "fp_image_write_png_rgb",
@@ -92,6 +92,8 @@ def lib() -> C.CDLL:
         "fp_refine_post_process": [vp, cs, vp, vp, vp, ci, vp], "fp_argmax": [vp, vp, ci, vp],
         "fp_register_shard_begin": [vp, vp, vp, vp, ci, ci, ci, cs, ci, ci, ci, vp, vp],
         "fp_register_shard_finish": [vp, vp, vp, ci, vp, vp, vp],
+        "fp_register_shard_begin_packed": [vp, vp, vp, vp, ci, ci, ci, cs, ci, ci, ci, vp, ci],
+        "fp_register_shard_finish_packed": [vp, vp, ci, vp, vp],
         "fp_profile_enable": [vp, ci], "fp_profile_reset": [vp], "fp_profile_report": [vp, vp, ci],
         "fp_synchronize": [vp], "fp_mesh_orient_bounds": [vp, vp, vp],
         "fp_set_precision": [vp, ci], "fp_get_precision": [vp], "fp_calibrate_fp8": [vp, vp, vp, vp, ci, ci, ci, cs],

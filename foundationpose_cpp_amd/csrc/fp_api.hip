@@ -213,8 +213,11 @@ struct fp_model {
   float *best_pose_dev = nullptr;
   int *result_pinned = nullptr;  // 18 words
   bool defer_begin_sync = false;  // fp_register_ex: shard_begin leaves its synchronisation to shard_finish
+  bool shard_sampler_pending = false;  // packed shard protocol: begin ran the sampler, finish reports its verdict
   float *scores_all = nullptr;  // scores of the gathered hypotheses of every rank (sharded Register)
   int scores_all_cap = 0;
+  float *gath_feat = nullptr, *gath_poses = nullptr;  // [n_total,512] / [n_total,16] unpacked from the all-gathered rows
+  int gath_cap = 0;
   int32_t *dbg_tri = nullptr;
   float *dbg_rast = nullptr;
 
@@ -410,6 +413,24 @@ static int stage_frame_owned(fp_model *m, const void *rgb, const void *depth, in
   return 0;
 }
 
+// ---- packed exchange buffers of a sharded Register: row = [pooled score feature 512 | refined pose 16]
+__global__ void pack_shard_kernel(const float *__restrict__ feat, const float *__restrict__ poses, int count, int per,
+                                  float *__restrict__ packed) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= per * 528) return;
+  const int r = i / 528, c = i - r * 528;
+  packed[i] = r >= count ? 0.f : (c < 512 ? feat[(size_t)r * 512 + c] : poses[(size_t)r * 16 + (c - 512)]);
+}
+// gathered rows are already in global hypothesis order (contiguous shards of `per` rows, padding only behind row n_total)
+__global__ void unpack_shards_kernel(const float *__restrict__ gathered, int n_total, float *__restrict__ feat,
+                                     float *__restrict__ poses) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_total * 528) return;
+  const int r = i / 528, c = i - r * 528;
+  if (c < 512) feat[(size_t)r * 512 + c] = gathered[i];
+  else poses[(size_t)r * 16 + (c - 512)] = gathered[i];
+}
+
 extern "C" {
 
 #ifdef FP_TEST_HOOKS
@@ -592,6 +613,7 @@ void fp_destroy(fp_model *m) {
   dev_free(m->recs); dev_free(m->poses_dev); dev_free(m->clip); dev_free(m->attr); dev_free(m->nn_in);
   dev_free(m->blob_a); dev_free(m->blob_b); dev_free(m->trans_dev); dev_free(m->rot_dev); dev_free(m->scores_dev);
   dev_free(m->feat_dev); dev_free(m->argmax_dev); dev_free(m->scores_all); dev_free(m->best_pose_dev);
+  dev_free(m->gath_feat); dev_free(m->gath_poses);
   if (m->result_pinned) (void)hipHostFree(m->result_pinned); dev_free(m->dbg_tri); dev_free(m->dbg_rast);
   if (m->poses_pinned) (void)hipHostFree(m->poses_pinned);
   dev_free(m->grid_dev); dev_free(m->samp_state); dev_free(m->samp_vals); dev_free(m->mask_dev);
@@ -981,6 +1003,44 @@ int fp_register_shard_finish(fp_model *m, const float *all_feat_dev, const float
     if (best_index) *best_index = res[0];
   }
   if (rc && g_last_error.empty()) set_error("[FoundationPose] fp_register_shard_finish failed");
+  return rc;
+}
+
+// Sharded Register without host stalls: everything is enqueued on the model's stream, nothing is allocated or synchronised.
+int fp_register_shard_begin_packed(fp_model *m, const void *rgb, const void *depth, const void *mask, int memspace, int H,
+                                   int W, const char *target_name, int refine_itr, int shard_begin, int shard_count,
+                                   float *packed_dev, int rows_per_rank) {
+  FP_CHECK(m && packed_dev && rows_per_rank >= shard_count && shard_count >= 0, "[FoundationPose] fp_register_shard_begin_packed: invalid arguments");
+  float *feat = nullptr, *poses = nullptr;
+  if (shard_count > 0) {
+    m->defer_begin_sync = true;
+    int rc = fp_register_shard_begin(m, rgb, depth, mask, memspace, H, W, target_name, refine_itr, shard_begin, shard_count, &feat, &poses);
+    m->defer_begin_sync = false;
+    if (rc) { (void)hipStreamSynchronize(m->stream); return 1; }
+    m->shard_sampler_pending = true;
+  }
+  const int n = rows_per_rank * 528;
+  hipLaunchKernelGGL(pack_shard_kernel, dim3((n + 255) / 256), dim3(256), 0, m->stream, feat, poses, shard_count, rows_per_rank, packed_dev);
+  FP_HIP_OK(hipGetLastError());
+  return 0;
+}
+
+int fp_register_shard_finish_packed(fp_model *m, const float *gathered_dev, int n_total, float out_pose[16], int *best_index) {
+  FP_CHECK(m && gathered_dev && n_total > 0 && out_pose, "[FoundationPose] fp_register_shard_finish_packed: invalid arguments");
+  if (n_total > m->gath_cap) {
+    FP_HIP_OK(hipStreamSynchronize(m->stream));
+    dev_free(m->gath_feat); dev_free(m->gath_poses);
+    m->gath_cap = 0;
+    if (dev_alloc(&m->gath_feat, (size_t)n_total * 512) || dev_alloc(&m->gath_poses, (size_t)n_total * 16)) return 1;
+    m->gath_cap = n_total;
+  }
+  const int n = n_total * 528;
+  hipLaunchKernelGGL(unpack_shards_kernel, dim3((n + 255) / 256), dim3(256), 0, m->stream, gathered_dev, n_total, m->gath_feat, m->gath_poses);
+  // the sampler's verdict of this rank's begin (if it had a shard) is fetched together with the result
+  m->defer_begin_sync = m->shard_sampler_pending;
+  m->shard_sampler_pending = false;
+  int rc = fp_register_shard_finish(m, m->gath_feat, m->gath_poses, n_total, out_pose, best_index, nullptr);
+  m->defer_begin_sync = false;
   return rc;
 }
 

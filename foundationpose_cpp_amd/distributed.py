@@ -3,15 +3,22 @@
 
 Every rank owns the same frame, mesh and weights and a contiguous slice of the hypothesis grid.  Render, crop,
 refine-net, pose update and the score-net trunk + per-hypothesis self-attention are independent per hypothesis; the
-only exchange is ONE all-gather of the pooled score features [n_local,512] (+ the refined poses [n_local,16] riding
-along), after which every rank evaluates the cross-hypothesis attention + Linear + arg-max redundantly and therefore
-agrees on the winner without a second collective.
+only exchange is ONE all-gather of one row per hypothesis, [pooled score feature 512 | refined pose 16] f32, after which
+every rank evaluates the cross-hypothesis attention + Linear + arg-max redundantly and therefore agrees on the winner
+without a second collective.
+
+No host stalls on the way (round 2): `shard_begin_packed` only enqueues on the library's stream and writes the rows
+straight into a persistent send buffer; the collective is ordered behind it with an event (no synchronize, no copies, no
+per-call allocations), and the library's stream waits for the collective the same way before the redundant finish, which
+ends in the Register's single synchronisation.
 """
 from __future__ import annotations
 
 import ctypes as C
 
 import numpy as np
+
+ROW = 528  # floats per exchanged row: 512 feature + 16 pose
 
 
 def shard_range(n_total: int, world: int, rank: int):
@@ -22,63 +29,59 @@ def shard_range(n_total: int, world: int, rank: int):
 
 
 class HipShardBackend:
-    """shard_begin / shard_finish over the C ABI with torch CUDA tensors as the exchange buffers."""
+    """The packed shard protocol over the C ABI with torch CUDA tensors as the (persistent) exchange buffers."""
 
     def __init__(self, model, device):
         import torch
         self.m, self.dev, self.torch = model, device, torch
-        self._hip = C.CDLL("libamdhip64.so")
+        self._bufs = {}
+        self._lib_stream = torch.cuda.ExternalStream(model.stream, device=device)   # the library's non-blocking stream
 
-    def _d2d(self, dst_ptr, src_ptr, nbytes):
-        rc = self._hip.hipMemcpy(C.c_void_p(dst_ptr), C.c_void_p(src_ptr), C.c_size_t(nbytes), 3)
-        assert rc == 0, f"hipMemcpy D2D failed ({rc})"
+    def buffers(self, per: int, world: int):
+        key = (per, world)
+        if key not in self._bufs:
+            t = self.torch
+            self._bufs[key] = (t.zeros((per, ROW), dtype=t.float32, device=self.dev),
+                               t.zeros((world * per, ROW), dtype=t.float32, device=self.dev))
+        return self._bufs[key]
 
-    def shard_begin(self, rgb_dev, depth_dev, mask_dev, H, W, name, refine_itr, begin, count):
-        torch = self.torch
-        feat = torch.zeros((count, 512), dtype=torch.float32, device=self.dev)
-        poses = torch.zeros((count, 16), dtype=torch.float32, device=self.dev)
-        if count > 0:
-            fp_, pp_ = C.c_void_p(), C.c_void_p()
-            self.m._must(self.m._L.fp_register_shard_begin(
-                self.m.handle, C.c_void_p(rgb_dev.data_ptr()), C.c_void_p(depth_dev.data_ptr()),
-                C.c_void_p(mask_dev.data_ptr()), 1, H, W, name.encode(), refine_itr, begin, count,
-                C.byref(fp_), C.byref(pp_)))
-            self.m.synchronize()
-            self._d2d(feat.data_ptr(), fp_.value, count * 512 * 4)
-            self._d2d(poses.data_ptr(), pp_.value, count * 16 * 4)
-        return feat, poses
+    def shard_begin_packed(self, rgb_dev, depth_dev, mask_dev, H, W, name, refine_itr, begin, count, packed, per):
+        self.m._must(self.m._L.fp_register_shard_begin_packed(
+            self.m.handle, C.c_void_p(rgb_dev.data_ptr()), C.c_void_p(depth_dev.data_ptr()),
+            C.c_void_p(mask_dev.data_ptr()), 1, H, W, name.encode(), refine_itr, begin, count,
+            C.c_void_p(packed.data_ptr()), per))
 
-    def shard_finish(self, all_feat, all_poses):
-        self.torch.cuda.synchronize(self.dev)
-        n = all_feat.shape[0]
+    def before_collective(self):
+        # the collective (on torch's current stream) starts when the library's stream has produced the rows
+        self.torch.cuda.current_stream(self.dev).wait_event(self._lib_stream.record_event())
+
+    def after_collective(self):
+        self._lib_stream.wait_event(self.torch.cuda.current_stream(self.dev).record_event())
+
+    def shard_finish_packed(self, gathered, n_total):
         out = np.zeros(16, np.float32)
         idx = C.c_int(-1)
-        self.m._must(self.m._L.fp_register_shard_finish(
-            self.m.handle, C.c_void_p(all_feat.data_ptr()), C.c_void_p(all_poses.data_ptr()), n,
-            out.ctypes.data_as(C.c_void_p), C.byref(idx), None))
+        self.m._must(self.m._L.fp_register_shard_finish_packed(
+            self.m.handle, C.c_void_p(gathered.data_ptr()), n_total, out.ctypes.data_as(C.c_void_p), C.byref(idx)))
         return out, idx.value
 
 
 def sharded_register(backend, dist, n_total, rgb, depth, mask, H, W, name, refine_itr=1):
     """One Register over `n_total` hypotheses sharded across dist.get_world_size() ranks.
-    Returns (pose16 column-major, winning global hypothesis index); identical on every rank."""
-    import torch
+    Returns (pose16 column-major, winning global hypothesis index); identical on every rank.
+
+    `backend` provides buffers / shard_begin_packed / before_collective / after_collective / shard_finish_packed
+    (HipShardBackend on MI355X; tests/test_distributed_cpu.py has a numpy stand-in for the gloo runs)."""
     world, rank = dist.get_world_size(), dist.get_rank()
     per = -(-n_total // world)
     begin, count = shard_range(n_total, world, rank)
-    feat, poses = backend.shard_begin(rgb, depth, mask, H, W, name, refine_itr, begin, count)
-    # fixed-size slots so a single all_gather_into_tensor works for ragged last shards
-    slot_f = torch.zeros((per, 512), dtype=feat.dtype, device=feat.device)
-    slot_p = torch.zeros((per, 16), dtype=poses.dtype, device=poses.device)
-    slot_f[:count] = feat
-    slot_p[:count] = poses
-    packed = torch.cat([slot_f, slot_p], dim=1).contiguous()          # ONE collective: [per, 528]
-    gathered = torch.empty((world * per, 528), dtype=packed.dtype, device=packed.device)
+    packed, gathered = backend.buffers(per, world)          # fixed-size slots: one collective also for a ragged last shard
+    backend.shard_begin_packed(rgb, depth, mask, H, W, name, refine_itr, begin, count, packed, per)
+    backend.before_collective()
     if world > 1:
-        dist.all_gather_into_tensor(gathered, packed)
+        dist.all_gather_into_tensor(gathered, packed)       # THE collective: [per, 528] f32 per rank
     else:
         gathered.copy_(packed)
-    rows = torch.cat([gathered[r * per: r * per + shard_range(n_total, world, r)[1]] for r in range(world)], dim=0)
-    all_feat = rows[:, :512].contiguous()
-    all_poses = rows[:, 512:].contiguous()
-    return backend.shard_finish(all_feat, all_poses)
+    backend.after_collective()
+    # contiguous shards of `per` rows: the gathered rows are already in global hypothesis order, padding only at the end
+    return backend.shard_finish_packed(gathered, n_total)

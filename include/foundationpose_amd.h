@@ -133,6 +133,19 @@ int fp_register_shard_begin(fp_model *m, const void *rgb, const void *depth, con
                             float **feat_dev, float **poses_dev);
 int fp_register_shard_finish(fp_model *m, const float *all_feat_dev, const float *all_poses_dev, int N_total,
                              float out_pose[16], int *best_index, float *scores_host /* may be NULL */);
+/* The same exchange without host stalls (what foundationpose_cpp_amd/distributed.py and bench.py --gpus N use):
+ *   fp_register_shard_begin_packed : as above, but only ENQUEUES on the model's stream (fp_stream) and leaves one row
+ *                                    [feature 512 | pose 16] per hypothesis in the CALLER's device buffer packed_dev
+ *                                    [rows_per_rank, 528] f32 (rows >= shard_count zeroed; shard_count may be 0).  No
+ *                                    synchronisation, no allocation: order the collective after it with an event on fp_stream.
+ *   (caller: ONE all_gather of packed_dev into gathered [world * rows_per_rank, 528]; with contiguous shards of
+ *    rows_per_rank hypotheses the gathered rows are already in global hypothesis order)
+ *   fp_register_shard_finish_packed: make fp_stream wait for the collective, then call; the cross-hypothesis head and the
+ *                                    arg-max run over rows [0, n_total); one synchronisation at the end. */
+int fp_register_shard_begin_packed(fp_model *m, const void *rgb, const void *depth, const void *mask, int memspace, int H,
+                                   int W, const char *target_name, int refine_itr, int shard_begin, int shard_count,
+                                   float *packed_dev, int rows_per_rank);
+int fp_register_shard_finish_packed(fp_model *m, const float *gathered_dev, int n_total, float out_pose[16], int *best_index);
 
 /* ---- frame / dataset I/O of the acceptance harness (simple_tests/include/tests/help_func.hpp) without OpenCV ----
  * dataset layout test_data/download.md:6-15: <dir>/cam_K.txt, rgb/<id>.png, depth/<id>.png (u16 mm), masks/<id>.png, mesh/ */

@@ -16,24 +16,48 @@ from foundationpose_cpp_amd.distributed import shard_range, sharded_register
 
 
 class FakeBackend:
-    """features / poses are a fixed function of the GLOBAL hypothesis index; finish = arg-max of a cross-row score."""
+    """features / poses are a fixed function of the GLOBAL hypothesis index; finish = arg-max of a cross-row score.
+    Implements the packed shard protocol of foundationpose_cpp_amd.distributed (rows [feature 512 | pose 16])."""
 
     def __init__(self, n_total):
         rng = np.random.default_rng(0)
         self.feat = rng.normal(size=(n_total, 512)).astype(np.float32)
         self.poses = rng.normal(size=(n_total, 16)).astype(np.float32)
         self.calls = []
+        self.order = []
+        self._bufs = {}
 
-    def shard_begin(self, rgb, depth, mask, H, W, name, itr, begin, count):
+    def buffers(self, per, world):
+        if (per, world) not in self._bufs:
+            self._bufs[(per, world)] = (torch.full((per, 528), 7.0), torch.full((world * per, 528), 9.0))   # stale garbage on purpose
+        return self._bufs[(per, world)]
+
+    def shard_begin_packed(self, rgb, depth, mask, H, W, name, itr, begin, count, packed, per):
         self.calls.append((begin, count))
-        return torch.from_numpy(self.feat[begin:begin + count].copy()), torch.from_numpy(self.poses[begin:begin + count].copy())
+        self.order.append("begin")
+        packed.zero_()
+        packed[:count, :512] = torch.from_numpy(self.feat[begin:begin + count])
+        packed[:count, 512:] = torch.from_numpy(self.poses[begin:begin + count])
 
-    def shard_finish(self, all_feat, all_poses):
-        f = all_feat.numpy()
+    def before_collective(self):
+        self.order.append("before")
+
+    def after_collective(self):
+        self.order.append("after")
+
+    def shard_finish_packed(self, gathered, n_total):
+        self.order.append("finish")
+        rows = gathered.numpy()[:n_total]
+        f = rows[:, :512]
         # cross-hypothesis dependence (like att_cross): score depends on the mean over ALL rows
         s = f @ f.mean(0)
         idx = int(np.argmax(s))
-        return all_poses.numpy()[idx].copy(), idx
+        return rows[idx, 512:].copy(), idx
+
+    def reference(self):
+        s = self.feat @ self.feat.mean(0)
+        idx = int(np.argmax(s))
+        return self.poses[idx].copy(), idx
 
 
 def test_shard_range_partitions():
@@ -54,11 +78,14 @@ def _worker(rank, world, port, n_total, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     be = FakeBackend(n_total)
     pose, idx = sharded_register(be, dist, n_total, None, None, None, 480, 640, "obj", 1)
-    q.put((rank, idx, pose.tolist(), be.calls))
+    pose2, idx2 = sharded_register(be, dist, n_total, None, None, None, 480, 640, "obj", 1)   # persistent buffers are reused
+    assert idx2 == idx and np.array_equal(pose2, pose) and len(be._bufs) == 1
+    assert be.order[:4] == ["begin", "before", "after", "finish"]
+    q.put((rank, idx, pose.tolist(), be.calls[:1]))
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_total", [252, 45])
+@pytest.mark.parametrize("n_total", [252, 45, 1])
 def test_two_rank_gloo_agrees_with_single_process(n_total):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -73,7 +100,7 @@ def test_two_rank_gloo_agrees_with_single_process(n_total):
         p.join(timeout=60)
         assert p.exitcode == 0
     be = FakeBackend(n_total)
-    ref_pose, ref_idx = be.shard_finish(torch.from_numpy(be.feat), torch.from_numpy(be.poses))
+    ref_pose, ref_idx = be.reference()
     for rank, idx, pose, calls in res:
         assert idx == ref_idx
         np.testing.assert_array_equal(np.asarray(pose, np.float32), ref_pose)
@@ -89,6 +116,6 @@ def test_single_process_world1():
     try:
         be = FakeBackend(100)
         pose, idx = sharded_register(be, dist, 100, None, None, None, 480, 640, "obj", 1)
-        assert idx == be.shard_finish(torch.from_numpy(be.feat), torch.from_numpy(be.poses))[1]
+        assert idx == be.reference()[1]
     finally:
         dist.destroy_process_group()

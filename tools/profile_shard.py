@@ -20,9 +20,13 @@ be = HipShardBackend(m, dev)
 if len(sys.argv) > 3:   # optional test hook: python tools/profile_shard.py 32 fpt_set_rem_small 1
     from foundationpose_cpp_amd import _lib
     getattr(_lib.lib(), sys.argv[2])(int(sys.argv[3]))  # needs _lib.use_test_lib() (done at import below)
-for _ in range(2): be.shard_begin(rgb, depth, mask, H, Wd, mesh.name, 1, 0, count)
+packed, _ = be.buffers(count, 1)
+def one():
+    be.shard_begin_packed(rgb, depth, mask, H, Wd, mesh.name, 1, 0, count, packed, count)
+    m.synchronize()
+for _ in range(2): one()
 m.profile(True); m.profile_reset()
-for _ in range(5): be.shard_begin(rgb, depth, mask, H, Wd, mesh.name, 1, 0, count)
+for _ in range(5): one()
 r = m.profile_report()
 tot = sum(v["ms"] for v in r.values()) / 5
 print(f"slice of {count}: {tot:.3f} ms of kernels per Register")

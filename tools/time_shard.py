@@ -1,9 +1,10 @@
-"""Per-rank latency of a sharded Register on ONE GPU: fp_register_shard_begin over `count` of 252 (or 1008) hypotheses +
-fp_register_shard_finish over all of them -- what each rank of a strong-scaled run executes besides the all-gather.
+"""Per-rank latency of a sharded Register on ONE GPU: the packed shard protocol (fp_register_shard_begin_packed over `count` of
+252 or 1008 hypotheses, event-ordered hand-off to torch's stream and back, fp_register_shard_finish_packed over all rows) --
+what each rank of a strong-scaled run executes besides the all-gather itself -- and the host time the calls themselves take.
 
     python tools/time_shard.py            # counts 32 (252/8), 63 (252/4), 126 (252/2 or 1008/8), 252
 """
-import ctypes as C, os, sys, tempfile, time
+import os, sys, tempfile, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from foundationpose_cpp_amd import FoundationPose, synthetic as syn, weights as W
@@ -19,15 +20,23 @@ H, Wd = scene.depth.shape
 be = HipShardBackend(m, dev)
 for n_total, counts in ((252, (32, 63, 126, 252)), (1008, (126,))):
     m.set_inplane_steps(n_total // 42)
-    feat_all = torch.zeros((n_total, 512), device=dev); pose_all = torch.zeros((n_total, 16), device=dev)
-    pose_all[:, 0] = pose_all[:, 5] = pose_all[:, 10] = pose_all[:, 15] = 1.0
     for count in counts:
-        for it in range(7):
+        world = -(-n_total // count)
+        packed, gathered = be.buffers(count, world)
+        gathered.zero_()
+        gathered[:, 512] = gathered[:, 517] = gathered[:, 522] = gathered[:, 527] = 1.0    # identity poses in the other ranks' rows
+        host = 0.0
+        for it in range(12):
             if it == 2:
-                torch.cuda.synchronize(); t0 = time.perf_counter()
-            f, p = be.shard_begin(rgb, depth, mask, H, Wd, mesh.name, 1, 0, count)
-            feat_all[:count] = f; pose_all[:count] = p
-            be.shard_finish(feat_all, pose_all)
+                torch.cuda.synchronize(); t0 = time.perf_counter(); host = 0.0
+            h0 = time.perf_counter()
+            be.shard_begin_packed(rgb, depth, mask, H, Wd, mesh.name, 1, 0, count, packed, count)
+            be.before_collective()
+            gathered[:count].copy_(packed)          # stands in for the all-gather on torch's stream
+            be.after_collective()
+            host += time.perf_counter() - h0        # everything before the finish's single synchronisation is asynchronous
+            be.shard_finish_packed(gathered, n_total)
         torch.cuda.synchronize()
-        ms = (time.perf_counter() - t0) / 5 * 1e3
-        print(f"N={n_total} shard of {count}: {ms:.3f} ms per Register per rank -> {n_total / ms * 1e3:.0f} hyp/s aggregate at {n_total // count if n_total % count == 0 else round(n_total / count)} ranks (excluding the all-gather)")
+        ms = (time.perf_counter() - t0) / 10 * 1e3
+        print(f"N={n_total} shard of {count}: {ms:.3f} ms per Register per rank ({host / 10 * 1e3:.3f} ms of it host time in the asynchronous calls = "
+              f"{host / 10 * 1e3 / ms * 100:.1f} %) -> {n_total / ms * 1e3:.0f} hyp/s aggregate at {world} ranks (excluding the all-gather)")
