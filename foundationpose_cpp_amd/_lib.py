@@ -22,7 +22,7 @@ SYMBOLS = [
     "fp_profile_enable", "fp_profile_reset", "fp_profile_report", "fp_stream", "fp_synchronize",
     "fp_mesh_load_obj", "fp_mesh_free", "fp_mesh_view", "fp_mesh_orient_bounds",
     "fp_image_read_png", "fp_frame_size", "fp_read_rgb_depth_mask", "fp_read_cam_k", "fp_image_write_png_rgb",
-    "fp_draw_bbox3d", "fp_set_precision", "fp_get_precision", "fp_calibrate_fp8", "fp_get_calibration", "fp_set_calibration", "fp_set_float_model", "fp_get_float_model",
+    "fp_draw_bbox3d", "fp_set_precision", "fp_get_precision", "fp_calibrate_fp8", "fp_get_calibration", "fp_set_calibration", "fp_set_float_model", "fp_get_float_model", "fp_net_create", "fp_net_destroy", "fp_net_max_batch", "fp_net_blob", "fp_net_infer",
 ]
 
 
@@ -75,6 +75,14 @@ def lib() -> C.CDLL:
     L.fp_read_cam_k.argtypes = [C.c_char_p, C.c_void_p]
     L.fp_image_write_png_rgb.argtypes = [C.c_char_p, C.c_void_p, C.c_int, C.c_int]
     L.fp_draw_bbox3d.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.fp_net_create.restype = C.c_void_p
+    L.fp_net_create.argtypes = [C.c_char_p, C.c_int, C.c_int]
+    L.fp_net_destroy.restype = None
+    L.fp_net_destroy.argtypes = [C.c_void_p]
+    L.fp_net_blob.restype = C.c_void_p
+    L.fp_net_blob.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+    L.fp_net_infer.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
+    L.fp_net_max_batch.argtypes = [C.c_void_p]
     L.fp_mesh_view.restype = C.POINTER(FpMesh)
     L.fp_mesh_view.argtypes = [C.c_void_p]
     vp, ci, cf, cs = C.c_void_p, C.c_int, C.c_float, C.c_char_p

@@ -1146,6 +1146,119 @@ int fp_set_calibration(fp_model *m, const float amax[32]) {
   return 0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// A network on its own, with the blob interface the reference's orchestrator drives through deploy_core's BaseInferCore
+// (GetBuffer / GetTensor / SetBufferLocation / RawPtr / SetShape / SyncInfer, D6F/src/foundationpose.cpp:126-139,331-354,
+// 410-436); include/infer_core_amd.hpp puts those C++ names on top of these calls.
+// ------------------------------------------------------------------------------------------------
+struct fp_net {
+  hipStream_t stream = nullptr;
+  Net *net = nullptr;
+  NNScratch *ws = nullptr;
+  bool scorer = false;
+  int max_batch = 0;
+  float *in_dev[2] = {nullptr, nullptr};   // render_input, transf_input  [max_batch,160,160,6] f32
+  float *in_host[2] = {nullptr, nullptr};  // pinned, allocated on first use
+  float *out_dev[2] = {nullptr, nullptr};  // trans, rot [max_batch,3]  |  scores [max_batch] (+ unused)
+  float *out_host[2] = {nullptr, nullptr};
+  float *feat_dev = nullptr;               // scorer: pooled features
+  __half *nn_in = nullptr;                 // packed 2-byte network input
+};
+static size_t net_blob_elems(const fp_net *n, int idx, bool out) {
+  if (!out) return (size_t)n->max_batch * FP_CROP_HW * FP_CROP_HW * 6;
+  return (size_t)n->max_batch * (n->scorer ? 1 : 3) * (idx == 0 || !n->scorer ? 1 : 0);
+}
+static int net_blob_index(const fp_net *n, const char *name, bool *out) {
+  const std::string s(name ? name : "");
+  if (s == "render_input") { *out = false; return 0; }
+  if (s == "transf_input") { *out = false; return 1; }
+  if (!n->scorer && s == "trans") { *out = true; return 0; }
+  if (!n->scorer && s == "rot") { *out = true; return 1; }
+  if (n->scorer && s == "scores") { *out = true; return 0; }
+  return -1;
+}
+
+fp_net *fp_net_create(const char *weights_path, int is_scorer, int max_batch) {
+  if (!weights_path || max_batch <= 0) { set_error("[FoundationPose] fp_net_create: invalid arguments"); return nullptr; }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { set_error("[FoundationPose] no HIP device available (this library has no CPU path)"); return nullptr; }
+  std::unique_ptr<fp_net> n(new fp_net());
+  n->scorer = is_scorer != 0;
+  n->max_batch = max_batch;
+  std::string err;
+  n->net = net_load(weights_path, n->scorer, PREC_F16, &err);
+  if (!n->net) { set_error("[FoundationPose] Failed to load network weights: " + err); return nullptr; }
+  n->ws = nn_scratch_create();
+  const size_t in_elems = (size_t)max_batch * FP_CROP_HW * FP_CROP_HW * 6;
+  bool ok = hipStreamCreateWithFlags(&n->stream, hipStreamNonBlocking) == hipSuccess;
+  for (int i = 0; ok && i < 2; i++) ok = !dev_alloc(&n->in_dev[i], in_elems) && !dev_alloc(&n->out_dev[i], (size_t)max_batch * 3);
+  ok = ok && !dev_alloc(&n->feat_dev, (size_t)max_batch * 512) && !dev_alloc(&n->nn_in, (size_t)2 * max_batch * FP_NN_IN_IMG_HALFS);
+  ok = ok && hipMemsetAsync(n->nn_in, 0, (size_t)2 * max_batch * FP_NN_IN_IMG_HALFS * sizeof(__half), n->stream) == hipSuccess;
+  if (!ok) { set_error("[FoundationPose] fp_net_create: device allocation failed"); fp_net_destroy(n.release()); return nullptr; }
+  return n.release();
+}
+
+void fp_net_destroy(fp_net *n) {
+  if (!n) return;
+  if (n->stream) (void)hipStreamSynchronize(n->stream);
+  for (int i = 0; i < 2; i++) {
+    dev_free(n->in_dev[i]); dev_free(n->out_dev[i]);
+    if (n->in_host[i]) (void)hipHostFree(n->in_host[i]);
+    if (n->out_host[i]) (void)hipHostFree(n->out_host[i]);
+  }
+  dev_free(n->feat_dev); dev_free(n->nn_in);
+  if (n->net) net_free(n->net);
+  if (n->ws) nn_scratch_free(n->ws);
+  if (n->stream) (void)hipStreamDestroy(n->stream);
+  delete n;
+}
+
+// raw pointer of a blob in the given memory space (BlobsTensor::GetTensor(name)->RawPtr()); NULL + fp_last_error for an
+// unknown name (the reference's GetTensor throws)
+void *fp_net_blob(fp_net *n, const char *name, int memspace) {
+  bool out = false;
+  const int idx = n ? net_blob_index(n, name, &out) : -1;
+  if (idx < 0) { set_error(std::string("[FoundationPose] no blob named '") + (name ? name : "") + "'"); return nullptr; }
+  if (memspace == FP_DEVICE) return out ? (void *)n->out_dev[idx] : (void *)n->in_dev[idx];
+  float **h = out ? &n->out_host[idx] : &n->in_host[idx];
+  if (!*h) {
+    const size_t elems = out ? (size_t)n->max_batch * 3 : (size_t)n->max_batch * FP_CROP_HW * FP_CROP_HW * 6;
+    if (hipHostMalloc((void **)h, elems * sizeof(float), hipHostMallocDefault) != hipSuccess) { set_error("[FoundationPose] pinned allocation failed"); return nullptr; }
+  }
+  return *h;
+}
+int fp_net_max_batch(const fp_net *n) { return n ? n->max_batch : 0; }
+
+// SyncInfer: inputs are taken from the blobs' FP_HOST or FP_DEVICE copies (render_loc / transf_loc), outputs are left in
+// the device blobs and, with out_loc == FP_HOST, copied to the host blobs as well; returns when they are complete.
+int fp_net_infer(fp_net *n, int batch, int render_loc, int transf_loc, int out_loc) {
+  FP_CHECK(n && batch > 0 && batch <= n->max_batch, "[FoundationPose] fp_net_infer: batch out of range");
+  const size_t px = (size_t)batch * FP_CROP_HW * FP_CROP_HW;
+  const int locs[2] = {render_loc, transf_loc};
+  for (int i = 0; i < 2; i++)
+    if (locs[i] == FP_HOST) {
+      FP_CHECK(n->in_host[i] != nullptr, "[FoundationPose] fp_net_infer: host input blob was never requested");
+      FP_HIP_OK(hipMemcpyAsync(n->in_dev[i], n->in_host[i], px * 24, hipMemcpyHostToDevice, n->stream));
+    }
+  launch_pack_f32x6(n->stream, n->in_dev[0], n->nn_in, px, OUT_F16X8);
+  launch_pack_f32x6(n->stream, n->in_dev[1], n->nn_in + (size_t)batch * FP_NN_IN_IMG_HALFS, px, OUT_F16X8);
+  if (n->scorer) {
+    if (scorer_features(n->stream, nullptr, n->net, n->ws, n->nn_in, batch, n->feat_dev)) return 1;
+    if (scorer_head(n->stream, nullptr, n->net, n->ws, n->feat_dev, batch, n->out_dev[0])) return 1;
+  } else {
+    if (refiner_forward(n->stream, nullptr, n->net, n->ws, n->nn_in, batch, n->out_dev[0], n->out_dev[1])) return 1;
+  }
+  if (out_loc == FP_HOST) {
+    const int nout = n->scorer ? 1 : 2;
+    for (int i = 0; i < nout; i++) {
+      if (!fp_net_blob(n, n->scorer ? "scores" : (i == 0 ? "trans" : "rot"), FP_HOST)) return 1;
+      FP_HIP_OK(hipMemcpyAsync(n->out_host[i], n->out_dev[i], (size_t)batch * (n->scorer ? 1 : 3) * sizeof(float), hipMemcpyDeviceToHost, n->stream));
+    }
+  }
+  FP_HIP_OK(hipStreamSynchronize(n->stream));
+  return 0;
+}
+
 int fp_profile_enable(fp_model *m, int on) {
   FP_CHECK(m, "null model");
   m->prof.on = on != 0;

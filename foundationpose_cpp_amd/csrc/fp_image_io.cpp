@@ -53,11 +53,14 @@ bool decode_png(const std::string &path, std::vector<uint16_t> &px, int &H, int 
     }
     pos += 12 + (size_t)len;
   }
-  if (W <= 0 || H <= 0 || (bits != 8 && bits != 16) || interlace != 0) return false;
+  // IHDR is file-supplied: bound the image (16384^2 covers any camera frame or texture) before it sizes an allocation, and
+  // keep every byte count inside zlib's 32-bit fields
+  if (W <= 0 || H <= 0 || W > 16384 || H > 16384 || (bits != 8 && bits != 16) || interlace != 0) return false;
   int fch = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
   if (!fch || (ctype == 3 && bits != 8)) return false;
   const int bpp = fch * bits / 8;  // filter distance in bytes
   const size_t stride = (size_t)W * bpp;
+  if ((stride + 1) * (size_t)H > 0x7fffffffu || idat.size() > 0x7fffffffu) return false;
   std::vector<uint8_t> raw((stride + 1) * H);
   {
     z_stream zs;
@@ -145,7 +148,7 @@ static void png_chunk(std::vector<uint8_t> &o, const char *type, const std::vect
 
 extern "C" {
 
-int fp_image_read_png(const char *path, int *H, int *W, int *channels, int *bit_depth, uint16_t *out, size_t out_capacity) {
+static int fp_image_read_png_impl(const char *path, int *H, int *W, int *channels, int *bit_depth, uint16_t *out, size_t out_capacity) {
   std::vector<uint16_t> px;
   int h, w, ch, bits;
   FP_CHECK(path && fp::decode_png(path, px, h, w, ch, bits), std::string("Failed reading png from path : ") + (path ? path : "(null)"));
@@ -159,13 +162,22 @@ int fp_image_read_png(const char *path, int *H, int *W, int *channels, int *bit_
   }
   return 0;
 }
+int fp_image_read_png(const char *path, int *H, int *W, int *channels, int *bit_depth, uint16_t *out, size_t out_capacity) {
+  try {
+    return fp_image_read_png_impl(path, H, W, channels, bit_depth, out, out_capacity);
+  } catch (const std::exception &e) {  // nothing may unwind through the C ABI
+    fp::set_error(std::string("fp_image_read_png: ") + e.what());
+    return 1;
+  }
+}
+
 
 static int read_frame_part(const char *path, const char *what, std::vector<uint16_t> &px, int &h, int &w, int &ch, int &bits) {
   FP_CHECK(path && fp::decode_png(path, px, h, w, ch, bits), std::string("Failed reading ") + what + " from path : " + (path ? path : "(null)"));
   return 0;
 }
 
-int fp_frame_size(const char *rgb_path, int *H, int *W) {
+static int fp_frame_size_impl(const char *rgb_path, int *H, int *W) {
   std::vector<uint16_t> px;
   int h, w, ch, bits;
   if (read_frame_part(rgb_path, "rgb", px, h, w, ch, bits)) return 1;
@@ -173,8 +185,17 @@ int fp_frame_size(const char *rgb_path, int *H, int *W) {
   *W = w;
   return 0;
 }
+int fp_frame_size(const char *rgb_path, int *H, int *W) {
+  try {
+    return fp_frame_size_impl(rgb_path, H, W);
+  } catch (const std::exception &e) {  // nothing may unwind through the C ABI
+    fp::set_error(std::string("fp_frame_size: ") + e.what());
+    return 1;
+  }
+}
 
-int fp_read_rgb_depth_mask(const char *rgb_path, const char *depth_path, const char *mask_path, int H, int W,
+
+static int fp_read_rgb_depth_mask_impl(const char *rgb_path, const char *depth_path, const char *mask_path, int H, int W,
                            uint8_t *rgb, float *depth, uint8_t *mask) {
   std::vector<uint16_t> px;
   int h, w, ch, bits;
@@ -200,8 +221,18 @@ int fp_read_rgb_depth_mask(const char *rgb_path, const char *depth_path, const c
   }
   return 0;
 }
+int fp_read_rgb_depth_mask(const char *rgb_path, const char *depth_path, const char *mask_path, int H, int W,
+                           uint8_t *rgb, float *depth, uint8_t *mask) {
+  try {
+    return fp_read_rgb_depth_mask_impl(rgb_path, depth_path, mask_path, H, W, rgb, depth, mask);
+  } catch (const std::exception &e) {  // nothing may unwind through the C ABI
+    fp::set_error(std::string("fp_read_rgb_depth_mask: ") + e.what());
+    return 1;
+  }
+}
 
-int fp_read_cam_k(const char *cam_K_path, float K[9]) {
+
+static int fp_read_cam_k_impl(const char *cam_K_path, float K[9]) {
   std::ifstream f(cam_K_path ? cam_K_path : "");
   FP_CHECK((bool)f, std::string("Failed open file : ") + (cam_K_path ? cam_K_path : "(null)"));
   for (int i = 0; i < 9; i++) {
@@ -211,8 +242,17 @@ int fp_read_cam_k(const char *cam_K_path, float K[9]) {
   }
   return 0;
 }
+int fp_read_cam_k(const char *cam_K_path, float K[9]) {
+  try {
+    return fp_read_cam_k_impl(cam_K_path, K);
+  } catch (const std::exception &e) {  // nothing may unwind through the C ABI
+    fp::set_error(std::string("fp_read_cam_k: ") + e.what());
+    return 1;
+  }
+}
 
-int fp_image_write_png_rgb(const char *path, const uint8_t *rgb, int H, int W) {
+
+static int fp_image_write_png_rgb_impl(const char *path, const uint8_t *rgb, int H, int W) {
   FP_CHECK(path && rgb && H > 0 && W > 0, "fp_image_write_png_rgb: bad arguments");
   std::vector<uint8_t> raw((size_t)H * (W * 3 + 1));
   for (int y = 0; y < H; y++) {
@@ -238,6 +278,15 @@ int fp_image_write_png_rgb(const char *path, const uint8_t *rgb, int H, int W) {
   FP_CHECK(wr == o.size(), std::string("short write to ") + path);
   return 0;
 }
+int fp_image_write_png_rgb(const char *path, const uint8_t *rgb, int H, int W) {
+  try {
+    return fp_image_write_png_rgb_impl(path, rgb, H, W);
+  } catch (const std::exception &e) {  // nothing may unwind through the C ABI
+    fp::set_error(std::string("fp_image_write_png_rgb: ") + e.what());
+    return 1;
+  }
+}
+
 
 // draw3DBoundingBox (help_func.hpp:55-106): the 8 corners (+-dimension/2) through `pose` (column-major bbox->camera, i.e.
 // ConvertPoseMesh2BBox(pose, loader)), pinhole projection with fx, fy, cx, cy, 12 green edges of thickness 2.

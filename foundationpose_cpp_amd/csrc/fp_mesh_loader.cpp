@@ -88,7 +88,7 @@ struct fp_loaded_mesh {
 
 extern "C" {
 
-fp_loaded_mesh *fp_mesh_load_obj(const char *name, const char *mesh_file_path) {
+static fp_loaded_mesh *fp_mesh_load_obj_impl(const char *name, const char *mesh_file_path) {
   if (!mesh_file_path || !*mesh_file_path) { fp::set_error("[AssimpMeshLoader] Got empty mesh_file_path !"); return nullptr; }
   std::ifstream f(mesh_file_path);
   if (!f) { fp::set_error(std::string("[AssimpMeshLoader] Failed to read mesh file: ") + mesh_file_path); return nullptr; }
@@ -240,8 +240,18 @@ fp_loaded_mesh *fp_mesh_load_obj(const char *name, const char *mesh_file_path) {
       if (tex_path.empty()) tex_path = first_map;
       if (!tex_path.empty()) tex_path = dirname_of(mesh_file_path) + "/" + tex_path;
     }
-    if (tex_path.empty() || !load_png_rgb(tex_path, m->texture, m->th, m->tw)) {
-      m->th = m->tw = 2;  // default texture map (:217-222)
+    const bool named = !tex_path.empty();
+    const bool present = named && std::ifstream(tex_path, std::ios::binary).good();
+    if (present && !load_png_rgb(tex_path, m->texture, m->th, m->tw)) {
+      // The reference decodes whatever cv::imread knows (JPEG, BMP, interlaced PNG ...); this loader reads non-interlaced
+      // 8-bit PNG only.  A texture file that EXISTS but cannot be decoded here must not silently become the grey default:
+      // the rendered crops would get the wrong colours and refine / score accuracy would drop without a trace.
+      fp::set_error("[MeshLoader] texture '" + tex_path + "' named by map_Kd cannot be decoded (supported: non-interlaced 8-bit PNG)");
+      delete m;
+      return nullptr;
+    }
+    if (!present) {  // no map_Kd, or the file is missing: default texture map, like the reference (:217-222)
+      m->th = m->tw = 2;
       m->texture.assign(12, 100);
     }
   }
@@ -250,6 +260,15 @@ fp_loaded_mesh *fp_mesh_load_obj(const char *name, const char *mesh_file_path) {
                     {m->center[0], m->center[1], m->center[2]}};
   return m;
 }
+fp_loaded_mesh *fp_mesh_load_obj(const char *name, const char *mesh_file_path) {
+  try {
+    return fp_mesh_load_obj_impl(name, mesh_file_path);
+  } catch (const std::exception &e) {  // nothing may unwind through the C ABI
+    fp::set_error(std::string("fp_mesh_load_obj: ") + e.what());
+    return nullptr;
+  }
+}
+
 
 void fp_mesh_free(fp_loaded_mesh *m) { delete m; }
 

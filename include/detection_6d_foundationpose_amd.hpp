@@ -7,8 +7,10 @@
 // dependency-free equivalent is foundationpose_amd.hpp.
 //
 // The reference constructs the model from two `inference_core::BaseInferCore` handles wrapping TensorRT engines
-// (foundationpose.cpp:448-458).  Here the "infer core" is a weights file: `CreateAmdInferCore(path)` returns a handle that
-// only carries the path, so simple_tests changes exactly its two factory calls (test_foundationpose.cpp:24-35).
+// (foundationpose.cpp:448-458).  infer_core_amd.hpp provides that interface on the MI355X networks: `CreateAmdInferCore(path,
+// inputs, outputs)` has CreateTrtInferCore's call shape and is a full core (GetBuffer / GetTensor / SetShape / SyncInfer);
+// `CreateAmdInferCore(path)` only names the weights.  simple_tests changes exactly its two factory calls
+// (test_foundationpose.cpp:24-35).
 #pragma once
 #if __has_include(<Eigen/Dense>) && __has_include(<opencv2/core.hpp>)
 
@@ -21,17 +23,7 @@
 #include <vector>
 
 #include "foundationpose_amd.h"
-
-namespace inference_core {
-struct BaseInferCore {  // minimal stand-in for deploy_core's handle: the MI355X library owns inference
-  std::string weights_path;
-};
-inline std::shared_ptr<BaseInferCore> CreateAmdInferCore(const std::string &packed_weights_path) {
-  auto c = std::make_shared<BaseInferCore>();
-  c->weights_path = packed_weights_path;
-  return c;
-}
-}  // namespace inference_core
+#include "infer_core_amd.hpp"  // inference_core::BaseInferCore / ITensor / BlobsTensor / CreateAmdInferCore
 
 namespace detection_6d {
 
@@ -153,7 +145,7 @@ public:
                       {L.GetMeshModelCenter()[0], L.GetMeshModelCenter()[1], L.GetMeshModelCenter()[2]}};
     }
     Eigen::Matrix<float, 3, 3, Eigen::RowMajor> Kr = K;
-    h_ = fp_create(cm.data(), (int)cm.size(), Kr.data(), refiner->weights_path.c_str(), scorer->weights_path.c_str(), max_h, max_w);
+    h_ = fp_create(cm.data(), (int)cm.size(), Kr.data(), refiner->WeightsPath().c_str(), scorer->WeightsPath().c_str(), max_h, max_w);
     if (!h_) throw std::runtime_error(std::string("[FoundationPose] Failed to Construct FoundationPose, ex : ") + fp_last_error());
   }
   ~FoundationPoseAmd() override { fp_destroy(h_); }

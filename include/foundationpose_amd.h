@@ -165,6 +165,22 @@ int fp_image_write_png_rgb(const char *path, const uint8_t *rgb, int H, int W);
  * (= ConvertPoseMesh2BBox(pose_in_mesh, loader), mesh_loader.hpp:75-81), drawn into rgb in place. */
 int fp_draw_bbox3d(uint8_t *rgb, int H, int W, const float K[9], const float pose[16], const float dimension[3]);
 
+/* ---- a network on its own: the infer-core contract ----------------------------------------------------------------
+ * The reference hands two deploy_core `BaseInferCore`s to the model and drives them through blobs
+ * (GetBuffer / GetTensor(name) / SetBufferLocation / RawPtr / SetShape / SyncInfer: D6F/src/foundationpose.cpp:126-139,
+ * 331-354,410-436; factory call shape simple_tests/src/test_foundationpose.cpp:24-35).  fp_net is that contract in C;
+ * include/infer_core_amd.hpp puts the C++ names on top.  Blobs: "render_input", "transf_input" f32 [max_batch,160,160,6]
+ * (foundationpose.cpp:78-83); refiner outputs "trans", "rot" [max_batch,3]; scorer output "scores" [max_batch]. */
+typedef struct fp_net fp_net;
+fp_net *fp_net_create(const char *packed_weights_path, int is_scorer, int max_batch);
+void fp_net_destroy(fp_net *net);
+int fp_net_max_batch(const fp_net *net);
+/* pointer of a blob's FP_HOST (pinned) or FP_DEVICE copy; NULL + fp_last_error for an unknown name */
+void *fp_net_blob(fp_net *net, const char *name, int memspace);
+/* SyncInfer over the first `batch` entries; *_loc say which copy of each input holds the data and whether the outputs are
+ * also wanted on the host */
+int fp_net_infer(fp_net *net, int batch, int render_loc, int transf_loc, int out_loc);
+
 /* ---- network precision ----------------------------------------------------------------------------------------------
  * The reference runs TensorRT engines built with --fp16 (tools/cvt_onnx2trt.bash:3-15): FP_PREC_F16 is the default and
  * the parity baseline.  FP_PREC_BF16: every tensor and MFMA operand in bf16 (BASELINE configs[1]).  FP_PREC_FP8: the 3x3

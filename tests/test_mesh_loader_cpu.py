@@ -80,6 +80,18 @@ def test_png_variants_and_fallback_texture(tmp_path, small_mesh):
     for tex in ("nope.png", None):
         m = load_mesh("obj", _write_obj(str(tmp_path), small_mesh, texture=tex))
         assert m.texture.shape == (2, 2, 3) and (m.texture == 100).all()
+    # a texture file that exists but is not a PNG this loader decodes (the reference's cv::imread would read a JPEG): an error,
+    # not a silent grey texture
+    (tmp_path / "photo.jpg").write_bytes(b"\xff\xd8\xff\xe0" + bytes(200))
+    with pytest.raises(FoundationPoseError, match="cannot be decoded"):
+        load_mesh("obj", _write_obj(str(tmp_path), small_mesh, texture="photo.jpg"))
+    # a corrupt header must not drive a huge allocation or unwind through the C ABI
+    import struct, zlib
+    def chunk(t, d): return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d))
+    bad = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", 2 ** 31 - 1, 2 ** 31 - 1, 8, 2, 0, 0, 0)) + chunk(b"IDAT", zlib.compress(b"\0" * 16)) + chunk(b"IEND", b"")
+    (tmp_path / "huge.png").write_bytes(bad)
+    with pytest.raises(FoundationPoseError, match="cannot be decoded"):
+        load_mesh("obj", _write_obj(str(tmp_path), small_mesh, texture="huge.png"))
 
 
 def test_error_behaviour_and_edge_cases(tmp_path, small_mesh):
