@@ -2003,6 +2003,262 @@ __global__ __launch_bounds__(ATT_QROWS * 4, 2) void attention_kernel(const typen
   }
 }
 
+// -------------------------------------------------------------------------------------------------
+// attention32_kernel [r2]: the kernel above is LDS-bandwidth-bound -- a wave owns ONE 16-row query tile, so every 32-key
+// block costs it the whole K and V tile (16 KB of fragment reads) for 16 MFMAs, 2.4x what the LDS delivers at the MFMA
+// rate, plus sixteen 2-byte transposing LDS writes per thread.  Here:
+//   * a wave owns 32 query rows (two 16-row tiles): every K / V fragment feeds two MFMAs (LDS bytes per MFMA halved),
+//     a workgroup = 4 waves = 128 query rows (4 workgroups per 400-token sequence and head instead of 7: K/V staged 4x);
+//   * O is accumulated TRANSPOSED, O^T[d][q] = V^T P^T: a lane owns one query in S^T and in O^T alike, so the online-softmax
+//     rescale is a lane-local multiply (no shuffles) and P^T feeds the MFMA's B operand straight from the softmax registers;
+//   * V stays row-major in LDS (16-byte staging writes) and the V^T operand comes from ds_read_b64_tr_b16 (hardware
+//     transpose read): [32 keys][16 d] sub-tiles of 1 KB (+32 B so the staging writes of one instruction spread over all
+//     banks), a 16-lane group reads one [4 keys][16 d] block = 128 contiguous bytes;
+//   * K rows (256 B) are XOR-swizzled by 16-byte slot (slot ^= key & 15): conflict-free staging writes and fragment reads;
+//   * two LDS buffers, ONE barrier per key block: tile kb+1 is written (from registers loaded two iterations earlier) while
+//     tile kb is consumed, the global loads of tiles kb+2 / kb+3 are in flight (two register sets);
+//   * all K fragments of a block are requested at once, all V^T fragments right after the QK MFMAs so their latency runs under the
+//     softmax (asm reads + one explicit wait: hipcc otherwise sinks each read to its first use); the cross-row max / sum use
+//     v_permlane16/32_swap instead of four LDS round trips (ds_bpermute) per softmax;
+//   * O leaves through LDS as whole 256-byte rows.
+// -------------------------------------------------------------------------------------------------
+typedef short s4 __attribute__((ext_vector_type(4)));
+// reductions over the four 16-lane rows of a wave (lanes li, li+16, li+32, li+48) on the VALU: v_permlane16_swap exchanges rows
+// 0<->1 and 2<->3, v_permlane32_swap the two halves (ds_bpermute shuffles put four LDS round trips per softmax on the
+// critical path of every key block)
+__device__ __forceinline__ float vmax_f32(float a, float b) {  // (fmaxf would be preceded by two canonicalising v_max)
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ float rows_max(float x) {
+  auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  const float m = vmax_f32(__uint_as_float(a[0]), __uint_as_float(a[1]));
+  auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(m), __float_as_uint(m), false, false);
+  return vmax_f32(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+__device__ __forceinline__ float rows_sum(float x) {
+  auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  const float m = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+  auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(m), __float_as_uint(m), false, false);
+  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+template <bool REMAP, int DT, int ABL = 0, int NW = 4>  // NW waves = NW * 32 query rows per workgroup; ABL (timing ablations, wrong results): 1 no staging after the first tile, 2 no softmax, 4 no PV, 8 no QK
+__global__ __launch_bounds__(NW * 64, 2) void attention32_kernel(const typename ElemT<DT>::t *__restrict__ qkv, typename ElemT<DT>::t *__restrict__ out, int T, int nq,
+                                                             int tstride /* rows between the first tokens of consecutive sequences */,
+                                                             int qkv_ld /* elements between consecutive qkv rows (>= 1536) */) {
+  using E = typename ElemT<DT>::t;
+  using E8 = typename ElemT<DT>::v8;
+  constexpr int KB = 32 * 256;   // K tile: 32 keys x 128 d
+  constexpr int VSUB = 1056;     // V sub-tile [32 keys][16 d] + 32 B
+  constexpr int BUF = KB + 8 * VSUB;
+  constexpr int NJ = 512 / (NW * 64);  // 16-byte chunks of K (and of V) a thread stages per tile
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BUF > NW * 8192 ? 2 * BUF : NW * 8192];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int logical;
+  {
+    const int nblk = gridDim.x, bi = blockIdx.x;
+    const int xcd = bi & 7, within = bi >> 3, q = nblk >> 3, r = nblk & 7;
+    logical = REMAP ? (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within : bi;
+  }
+  const int qt = logical % nq, h = (logical / nq) % HEADS, b = logical / (nq * HEADS);
+  const int g = lane >> 4, li = lane & 15;
+  const size_t rowstride = (size_t)qkv_ld;
+  const E *base = qkv + (size_t)b * tstride * rowstride + h * HDIM;
+  const int q0 = qt * (NW * 32) + wave * 32;
+  const bool active = q0 < T;  // (wave-uniform) waves past the sequence only help staging
+
+  i4 qf[2][4];
+#pragma unroll
+  for (int qi = 0; qi < 2; qi++) {
+    const int q_ld = min(q0 + qi * 16 + li, T - 1);
+#pragma unroll
+    for (int ds = 0; ds < 4; ds++) qf[qi][ds] = *reinterpret_cast<const i4 *>(base + (size_t)q_ld * rowstride + ds * 32 + g * 8);
+  }
+  f4 o[8][2];
+#pragma unroll
+  for (int dt = 0; dt < 8; dt++)
+#pragma unroll
+    for (int qi = 0; qi < 2; qi++) o[dt][qi] = (f4){0.f, 0.f, 0.f, 0.f};
+  float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
+  const float sl2e = 0.08838834764831845f * 1.4426950408889634f;  // 1/sqrt(128) * log2(e)
+
+  // staging: thread -> (key = idx >> 4, 16-byte chunk = idx & 15), idx = tid + 256 j: coalesced 256-byte rows
+  const int nkb = (T + 31) / 32;
+  // two register sets: tile kb+1 (written to LDS during block kb) and tile kb+2 (in flight for a whole block longer)
+  i4 kreg[2][NJ], vreg[2][NJ];
+  auto load_tile = [&](int kb, i4 (&kr)[NJ], i4 (&vr)[NJ]) {
+#pragma unroll
+    for (int j = 0; j < NJ; j++) {
+      const int idx = tid + j * (NW * 64);
+      const int row = min(kb * 32 + (idx >> 4), T - 1);
+      const E *src = base + (size_t)row * rowstride + (idx & 15) * 8;
+      kr[j] = *reinterpret_cast<const i4 *>(src + EMBED);
+      vr[j] = *reinterpret_cast<const i4 *>(src + 2 * EMBED);
+    }
+  };
+  auto store_tile = [&](int buf, const i4 (&kr)[NJ], const i4 (&vr)[NJ]) {
+    unsigned char *sb = smem + buf * BUF;
+#pragma unroll
+    for (int j = 0; j < NJ; j++) {
+      const int idx = tid + j * (NW * 64);
+      const int key = idx >> 4, chunk = idx & 15;
+      *reinterpret_cast<i4 *>(sb + key * 256 + ((chunk ^ (key & 15)) << 4)) = kr[j];
+      *reinterpret_cast<i4 *>(sb + KB + (chunk >> 1) * VSUB + key * 32 + (chunk & 1) * 16) = vr[j];
+    }
+  };
+  load_tile(0, kreg[0], vreg[0]);
+  store_tile(0, kreg[0], vreg[0]);
+  if (nkb > 1) load_tile(1, kreg[1], vreg[1]);   // odd tiles travel in set 1, even tiles in set 0
+  if (nkb > 2) load_tile(2, kreg[0], vreg[0]);
+  __syncthreads();
+
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
+  unsigned koff[4];
+#pragma unroll
+  for (int ds = 0; ds < 4; ds++) koff[ds] = (unsigned)(li * 256 + (((ds * 4 + g) ^ li) << 4));
+  const unsigned voff = (unsigned)((g * 4 + (li >> 2)) * 32 + (li & 3) * 8);
+
+  auto block = [&](const int kb, i4 (&kr)[NJ], i4 (&vr)[NJ]) {   // kr / vr hold tile kb+1 on entry, tile kb+3 on exit
+    f4 st[2][2];  // [query tile][key tile]: st[qi][kt][r] = S[key = kt*16 + g*4 + r][q = qi*16 + li]
+    if (ABL & 8) {
+#pragma unroll
+      for (int qi = 0; qi < 2; qi++)
+#pragma unroll
+        for (int kt = 0; kt < 2; kt++) st[qi][kt] = __builtin_bit_cast(f4, qf[qi][kt]);
+    } else if (active) {
+#pragma unroll
+      for (int qi = 0; qi < 2; qi++)
+#pragma unroll
+        for (int kt = 0; kt < 2; kt++) st[qi][kt] = (f4){0.f, 0.f, 0.f, 0.f};
+      // all K fragments of the block in one go (one LDS latency, then 16 MFMAs back to back).  The reads are asm statements: hipcc
+      // otherwise sinks every read to its first use and waits after each small group
+      i4 kf[2][4];
+      const unsigned kbase = lds0 + (unsigned)((kb & 1) * BUF);
+#pragma unroll
+      for (int ds = 0; ds < 4; ds++) {
+        asm volatile("ds_read_b128 %0, %1" : "=v"(kf[0][ds]) : "v"(kbase + koff[ds]));
+        asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(kf[1][ds]) : "v"(kbase + koff[ds]));
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int kt = 0; kt < 2; kt++)
+#pragma unroll
+        for (int ds = 0; ds < 4; ds++)
+#pragma unroll
+          for (int qi = 0; qi < 2; qi++) st[qi][kt] = mfma32<DT>(kf[kt][ds], qf[qi][ds], st[qi][kt]);
+    }
+    // V^T fragments of this block: requested now, consumed after the softmax (their latency runs under it)
+    i2 vlo[8], vhi[8];
+    if (active && !(ABL & 4)) {
+      const unsigned vbase = lds0 + (unsigned)((kb & 1) * BUF + KB) + voff;
+#pragma unroll
+      for (int dt = 0; dt < 8; dt++) {
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(vlo[dt]) : "v"(vbase), "n"(dt * VSUB));
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(vhi[dt]) : "v"(vbase), "n"(dt * VSUB + 512));
+      }
+    }
+    // the next tile goes into the other buffer (its last readers passed the barrier that ended the previous iteration)
+    if (kb + 1 < nkb && !(ABL & 1)) {
+      if (ABL & 32) {
+#pragma unroll
+        for (int j = 0; j < NJ; j++) asm volatile("" ::"v"(kr[j]), "v"(vr[j]));
+      } else store_tile((kb + 1) & 1, kr, vr);
+      if (kb + 3 < nkb && !(ABL & 16)) load_tile(kb + 3, kr, vr);
+    }
+    if (active) {
+      i4 pf[2];
+      if (ABL & 2) {
+#pragma unroll
+        for (int qi = 0; qi < 2; qi++) pf[qi] = __builtin_bit_cast(i4, st[qi][0] + st[qi][1]);
+      } else
+#pragma unroll
+      for (int qi = 0; qi < 2; qi++) {
+        // softmax in base 2 on the RAW scores: p = exp2(s*c - m*c), c = scale*log2(e); keys past T exist only in the last block
+        if (kb == nkb - 1 && (T & 31)) {
+#pragma unroll
+          for (int kt = 0; kt < 2; kt++)
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+              if (kb * 32 + kt * 16 + g * 4 + r >= T) st[qi][kt][r] = -INFINITY;
+        }
+        float mx = vmax_f32(vmax_f32(vmax_f32(st[qi][0][0], st[qi][0][1]), vmax_f32(st[qi][0][2], st[qi][0][3])),
+                            vmax_f32(vmax_f32(st[qi][1][0], st[qi][1][1]), vmax_f32(st[qi][1][2], st[qi][1][3])));
+        mx = rows_max(mx);
+        const float m_new = vmax_f32(m_run[qi], mx);
+        const float mc = m_new * sl2e;
+        const float alpha = __builtin_amdgcn_exp2f(m_run[qi] * sl2e - mc);  // m_run = -inf on the first block -> 0
+        float psum = 0.f;
+        E8 pv8;
+#pragma unroll
+        for (int kt = 0; kt < 2; kt++)
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(st[qi][kt][r], sl2e, -mc));
+            psum += pv;
+            pv8[kt * 4 + r] = (E)pv;
+          }
+        pf[qi] = __builtin_bit_cast(i4, pv8);
+        psum = rows_sum(psum);
+        l_run[qi] = l_run[qi] * alpha + psum;
+        m_run[qi] = m_new;
+        // O^T columns of this lane all belong to query li: the rescale is lane-local; x * 1.0f is exact, so it is skipped
+        // when no row's running maximum moved (most blocks after the first few)
+        if (__any(alpha != 1.0f)) {
+#pragma unroll
+          for (int dt = 0; dt < 8; dt++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) o[dt][qi][r] *= alpha;
+        }
+      }
+      // O^T[d][q] += V^T[d][key] P^T[key][q]; k-slot j of lane group g is key (j>>2)*16 + g*4 + (j&3) in both operands
+      if (ABL & 4) {
+#pragma unroll
+        for (int qi = 0; qi < 2; qi++) o[0][qi] += __builtin_bit_cast(f4, pf[qi]);
+      } else {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+  #pragma unroll
+        for (int dt = 0; dt < 8; dt++) {
+          const i4 vf = (i4){vlo[dt][0], vlo[dt][1], vhi[dt][0], vhi[dt][1]};
+#pragma unroll
+          for (int qi = 0; qi < 2; qi++) o[dt][qi] = mfma32<DT>(vf, pf[qi], o[dt][qi]);
+        }
+        }
+    }
+    __syncthreads();
+  };
+  for (int kb = 0; kb < nkb; kb += 2) {
+    block(kb, kreg[1], vreg[1]);
+    if (kb + 1 < nkb) block(kb + 1, kreg[0], vreg[0]);
+  }
+  if (!active) return;
+  // O tile of the wave through LDS (both buffers are free now; 8 KB per wave) -> whole 256-byte rows
+  unsigned char *ob = smem + wave * 8192;
+#pragma unroll
+  for (int qi = 0; qi < 2; qi++) {
+    const float inv = 1.0f / l_run[qi];
+    const int row = qi * 16 + li;
+#pragma unroll
+    for (int dt = 0; dt < 8; dt++) {
+      typename ElemT<DT>::v4 ov;
+#pragma unroll
+      for (int r = 0; r < 4; r++) ov[r] = (E)(o[dt][qi][r] * inv);
+      // d = dt*16 + g*4 + r: 16-byte slot dt*2 + (g>>1), swizzled by the row
+      *reinterpret_cast<typename ElemT<DT>::v4 *>(ob + row * 256 + (((dt * 2 + (g >> 1)) ^ (row & 15)) << 4) + (g & 1) * 8) = ov;
+    }
+  }
+#pragma unroll
+  for (int it = 0; it < 8; it++) {
+    const int id = it * 64 + lane, rr = id >> 4, c = id & 15;
+    const int row = q0 + rr;
+    const i4 v = *reinterpret_cast<const i4 *>(ob + rr * 256 + ((c ^ (rr & 15)) << 4));
+    if (row < T) *reinterpret_cast<i4 *>(out + ((size_t)b * tstride + row) * EMBED + h * HDIM + c * 8) = v;
+  }
+}
+
 // =================================================================================================
 // small kernels
 // =================================================================================================
@@ -2653,7 +2909,7 @@ FP_HOOK g_grouped_heads = 1;   // the refiner's two heads as one launch per laye
 FP_HOOK g_rem_splitk = 0;      // split-K for left-over rows.  Measured -0.1 ms per Register, but OFF: a row's fp32 summation order would then
                                // depend on where it falls in the batch, and sharded and unsharded Register must pick the same near-tied winner
 FP_HOOK g_splitk_target = 128; // workgroups a split-K launch aims for (tools/ab_track.py: 96-128 best, 256 is 6 % slower)
-FP_HOOK g_att_variant = 1;     // 1 remap + 16-B stores, 3 no XCD remap, 5 remap + 2-B stores, 7 neither
+FP_HOOK g_att_variant = 1;     // 1 = attention32_kernel (8 = without the XCD remap); round-1 kernel: 2 remap + 16-B stores, 3 no XCD remap, 5 remap + 2-B stores, 7 neither
 
 // One launch = (once per launch site and element type, thread-safe through the function-local static) dynamic-LDS opt-in +
 // the launch itself.
@@ -2983,25 +3239,49 @@ static int run_gemm(const Ctx &c, const char *tag, const ConvLayer &L, const voi
 }
 
 template <int DT>
-static void launch_attention(const Ctx &c, const void *qkv, void *out, int B, int T, int nq, int tstride) {
+static void launch_attention(const Ctx &c, const void *qkv, void *out, int B, int T, int tstride, int ld) {
   using E = typename ElemT<DT>::t;
-  dim3 grid((unsigned)(nq * HEADS * B)), blk(256);
   const E *q = (const E *)qkv;
   E *o = (E *)out;
 #ifdef FP_TEST_HOOKS
-  if (g_att_variant == 3) { hipLaunchKernelGGL((attention_kernel<64, false, true, DT>), grid, blk, 0, c.s, q, o, T, nq, tstride); return; }
-  if (g_att_variant == 5) { hipLaunchKernelGGL((attention_kernel<64, true, false, DT>), grid, blk, 0, c.s, q, o, T, nq, tstride); return; }
-  if (g_att_variant == 7) { hipLaunchKernelGGL((attention_kernel<64, false, false, DT>), grid, blk, 0, c.s, q, o, T, nq, tstride); return; }
+  if (g_att_variant != 1) {  // the round-1 kernel (64 query rows per workgroup), kept in the test build for A/B
+    const int nq = (T + 63) / 64;
+    dim3 grid((unsigned)(nq * HEADS * B)), blk(256);
+    if (g_att_variant == 3) hipLaunchKernelGGL((attention_kernel<64, false, true, DT>), grid, blk, 0, c.s, q, o, T, nq, tstride);
+    else if (g_att_variant == 5) hipLaunchKernelGGL((attention_kernel<64, true, false, DT>), grid, blk, 0, c.s, q, o, T, nq, tstride);
+    else if (g_att_variant == 7) hipLaunchKernelGGL((attention_kernel<64, false, false, DT>), grid, blk, 0, c.s, q, o, T, nq, tstride);
+    else if (g_att_variant == 9)  // 8 waves = 256 query rows per workgroup (K/V staged half as often; 9 % slower: the two waves of a SIMD run in lockstep)
+      hipLaunchKernelGGL((attention32_kernel<true, DT, 0, 8>), dim3((unsigned)(((T + 255) / 256) * HEADS * B)), dim3(512), 0, c.s, q, o, T, (T + 255) / 256, tstride, ld);
+    else if (g_att_variant == 8) hipLaunchKernelGGL((attention32_kernel<false, DT>), dim3((unsigned)(((T + 127) / 128) * HEADS * B)), blk, 0, c.s, q, o, T, (T + 127) / 128, tstride, ld);
+    else if (g_att_variant >= 16 && g_att_variant < 32) {
+      const dim3 g32((unsigned)(((T + 127) / 128) * HEADS * B));
+      const int nq32 = (T + 127) / 128;
+      switch (g_att_variant - 16) {
+        case 1: hipLaunchKernelGGL((attention32_kernel<true, DT, 1>), g32, blk, 0, c.s, q, o, T, nq32, tstride, ld); break;
+        case 2: hipLaunchKernelGGL((attention32_kernel<true, DT, 2>), g32, blk, 0, c.s, q, o, T, nq32, tstride, ld); break;
+        case 4: hipLaunchKernelGGL((attention32_kernel<true, DT, 4>), g32, blk, 0, c.s, q, o, T, nq32, tstride, ld); break;
+        case 8: hipLaunchKernelGGL((attention32_kernel<true, DT, 8>), g32, blk, 0, c.s, q, o, T, nq32, tstride, ld); break;
+        case 6: hipLaunchKernelGGL((attention32_kernel<true, DT, 6>), g32, blk, 0, c.s, q, o, T, nq32, tstride, ld); break;
+        case 14: hipLaunchKernelGGL((attention32_kernel<true, DT, 14>), g32, blk, 0, c.s, q, o, T, nq32, tstride, ld); break;
+        case 15: hipLaunchKernelGGL((attention32_kernel<true, DT, 15>), g32, blk, 0, c.s, q, o, T, nq32, tstride, ld); break;
+        case 0: hipLaunchKernelGGL((attention32_kernel<true, DT, 16>), g32, blk, 0, c.s, q, o, T, nq32, tstride, ld); break;
+        case 3: hipLaunchKernelGGL((attention32_kernel<true, DT, 32>), g32, blk, 0, c.s, q, o, T, nq32, tstride, ld); break;
+        default: hipLaunchKernelGGL((attention32_kernel<true, DT, 0>), g32, blk, 0, c.s, q, o, T, nq32, tstride, ld); break;
+      }
+    }
+    else hipLaunchKernelGGL((attention_kernel<64, true, true, DT>), grid, blk, 0, c.s, q, o, T, nq, tstride);
+    return;
+  }
 #endif
-  hipLaunchKernelGGL((attention_kernel<64, true, true, DT>), grid, blk, 0, c.s, q, o, T, nq, tstride);
+  const int nq = (T + 127) / 128;
+  hipLaunchKernelGGL((attention32_kernel<true, DT>), dim3((unsigned)(nq * HEADS * B)), dim3(256), 0, c.s, q, o, T, nq, tstride, ld);
 }
-static int run_attention(const Ctx &c, int dt, const void *qkv, void *out, int B, int T, int tstride = 0) {
+static int run_attention(const Ctx &c, int dt, const void *qkv, void *out, int B, int T, int tstride = 0, int ld = 3 * EMBED) {
   if (tstride == 0) tstride = T;
   double flops = 4.0 * (double)B * HEADS * (double)T * T * HDIM;
   ProfScope ps(c.prof, c.s, "attention", flops, (double)B * T * (1536 + 512) * 2.0);
-  const int nq = (T + 63) / 64;
-  if (dt == DT_BF16) launch_attention<DT_BF16>(c, qkv, out, B, T, nq, tstride);
-  else launch_attention<DT_F16>(c, qkv, out, B, T, nq, tstride);
+  if (dt == DT_BF16) launch_attention<DT_BF16>(c, qkv, out, B, T, tstride, ld);
+  else launch_attention<DT_F16>(c, qkv, out, B, T, tstride, ld);
   return 0;
 }
 
@@ -3599,7 +3879,9 @@ long long fpt_visibility_stress(int nthreads, int iters, int mbytes) {
 // timing hook: random QKV resident in HBM, `iters` launches, returns ms per launch (negative on failure)
 float fpt_attention_bench(int B, int T, int iters, int variant) {
   using namespace fp;
-  size_t nq = (size_t)B * T * 1536, no = (size_t)B * T * 512;
+  const char *pe = getenv("FPT_QKV_LD");   // row pitch experiment (attention32_kernel only)
+  const int ld = pe ? atoi(pe) : 1536;
+  size_t nq = (size_t)B * T * ld, no = (size_t)B * T * 512;
   DevBuf<__half> dq(nq), dout(no);
   if (!dq.p || !dout.p) return -1.f;
   std::vector<__half> hq(nq);
@@ -3611,9 +3893,9 @@ float fpt_attention_bench(int B, int T, int iters, int variant) {
   g_att_variant = variant;
   hipEvent_t e0, e1;
   if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return -1.f;
-  for (int i = 0; i < 3; i++) run_attention(c, DT_F16, dq.p, dout.p, B, T);
+  for (int i = 0; i < 3; i++) run_attention(c, DT_F16, dq.p, dout.p, B, T, 0, ld);
   (void)hipEventRecord(e0, nullptr);
-  for (int i = 0; i < iters; i++) run_attention(c, DT_F16, dq.p, dout.p, B, T);
+  for (int i = 0; i < iters; i++) run_attention(c, DT_F16, dq.p, dout.p, B, T, 0, ld);
   (void)hipEventRecord(e1, nullptr);
   float ms = -1.f;
   if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) ms = -(float)iters;
