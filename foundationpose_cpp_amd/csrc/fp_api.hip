@@ -188,6 +188,9 @@ struct fp_model {
   int H = 0, W = 0;
   uint8_t *rgb_own = nullptr;
   float *depth_own = nullptr;
+  FrameRef *frame_dev = nullptr, *frame_pinned = nullptr;  // what kernels inside graphs read the frame through
+  FrameRef frame_pub = {nullptr, nullptr};                 // last published value
+  unsigned frame_pub_count = 0;
   const uint8_t *rgb = nullptr;   // device
   const float *depth = nullptr;   // device
   float *erode = nullptr, *bilat = nullptr, *xyz = nullptr;
@@ -341,7 +344,7 @@ static int render_and_crop(fp_model *m, Target *t, int N, float crop_ratio, OutM
   }
   if (out_b) {
     ProfScope ps(&m->prof, s, "crop_warp", 0, (double)n_crop * out_bytes);
-    launch_crop(s, m->rgb, m->depth, m->H, m->W, m->K, m->recs, n_crop, t->mesh.diameter, mode, out_b);
+    launch_crop(s, m->frame_dev, m->H, m->W, m->K, m->recs, n_crop, t->mesh.diameter, mode, out_b);
   }
   FP_HIP_OK(hipGetLastError());
   return 0;
@@ -394,22 +397,6 @@ static int run_graphed(fp_model *m, fp_model::GraphSlot &g, Target *t, int H, in
     g.epoch = g_alloc_epoch;  // allocations made by this eager call are now settled
     g.eager_calls = graphable ? g.eager_calls + 1 : 0;
   }
-  return 0;
-}
-
-// frame into the model's own buffers (graphs bake addresses): H2D for host frames, D2D for a caller's device frame
-static int stage_frame_owned(fp_model *m, const void *rgb, const void *depth, int memspace, int H, int W) {
-  if (memspace != FP_DEVICE) return upload_frame_async(m, rgb, depth, FP_HOST, H, W);
-  const size_t px = (size_t)H * W;
-  if (px > m->frame_cap) {
-    g_alloc_epoch++;
-    dev_free(m->rgb_own); dev_free(m->depth_own); dev_free(m->erode); dev_free(m->bilat); dev_free(m->xyz);
-    if (dev_alloc(&m->rgb_own, px * 3) || dev_alloc(&m->depth_own, px) || dev_alloc(&m->erode, px) || dev_alloc(&m->bilat, px)) return 1;
-    m->frame_cap = px;
-  }
-  m->H = H; m->W = W; m->rgb = m->rgb_own; m->depth = m->depth_own;
-  FP_HIP_OK(hipMemcpyAsync(m->rgb_own, rgb, px * 3, hipMemcpyDeviceToDevice, m->stream));
-  FP_HIP_OK(hipMemcpyAsync(m->depth_own, depth, px * 4, hipMemcpyDeviceToDevice, m->stream));
   return 0;
 }
 
@@ -555,6 +542,11 @@ fp_model *fp_create(const fp_mesh *meshes, int n_meshes, const float K[9], const
   if (max_w > 0) m->max_w = max_w;
   // non-blocking: no implicit synchronisation with the legacy null stream (other models' threads, the caller's framework)
   if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess) { set_error("[FoundationPose] Failed to create stream"); return nullptr; }
+  if (hipMalloc((void **)&m->frame_dev, sizeof(FrameRef)) != hipSuccess ||
+      hipHostMalloc((void **)&m->frame_pinned, 8 * sizeof(FrameRef), hipHostMallocDefault) != hipSuccess) {
+    set_error("[FoundationPose] Failed to allocate the frame record");
+    return nullptr;
+  }
   for (int i = 0; i < n_meshes; i++) {
     const fp_mesh &src = meshes[i];
     if (!src.vertices || !src.normals || !src.texcoords || !src.faces || !src.texture || src.num_vertices <= 0 ||
@@ -616,6 +608,8 @@ void fp_destroy(fp_model *m) {
   dev_free(m->gath_feat); dev_free(m->gath_poses);
   if (m->result_pinned) (void)hipHostFree(m->result_pinned); dev_free(m->dbg_tri); dev_free(m->dbg_rast);
   if (m->poses_pinned) (void)hipHostFree(m->poses_pinned);
+  if (m->frame_pinned) (void)hipHostFree(m->frame_pinned);
+  if (m->frame_dev) (void)hipFree(m->frame_dev);
   dev_free(m->grid_dev); dev_free(m->samp_state); dev_free(m->samp_vals); dev_free(m->mask_dev);
   if (m->digests) (void)hipFree(m->digests);
   for (int i = 0; i < 3; i++) {
@@ -664,6 +658,13 @@ static int upload_frame_async(fp_model *m, const void *rgb, const void *depth, i
     FP_HIP_OK(hipMemcpyAsync(m->depth_own, depth, px * 4, hipMemcpyHostToDevice, m->stream));
     m->rgb = m->rgb_own;
     m->depth = m->depth_own;
+  }
+  if (m->frame_pub.rgb != m->rgb || m->frame_pub.depth != m->depth) {
+    // (a ring of pinned records: the asynchronous shard entry points return before the copy has run)
+    FrameRef *slot = m->frame_pinned + (m->frame_pub_count++ & 7);
+    slot->rgb = m->rgb; slot->depth = m->depth;
+    FP_HIP_OK(hipMemcpyAsync(m->frame_dev, slot, sizeof(FrameRef), hipMemcpyHostToDevice, m->stream));
+    m->frame_pub = *slot;
   }
   return 0;
 }
@@ -929,7 +930,7 @@ int fp_register_shard_begin(fp_model *m, const void *rgb, const void *depth, con
   FP_CHECK(shard_begin >= 0 && shard_count > 0 && shard_begin + shard_count <= n_all,
            "[FoundationPose] hypothesis shard out of range");
   const bool graphable = m->use_graphs && !m->prof.on && !m->digests && !m->calibrating && refine_itr >= 1;
-  if (graphable ? stage_frame_owned(m, rgb, depth, memspace, H, W) : upload_frame_async(m, rgb, depth, memspace, H, W)) return 1;
+  if (upload_frame_async(m, rgb, depth, memspace, H, W)) return 1;
   const int N = shard_count;
   if (sample_hypotheses_async(m, t, mask, memspace, shard_begin, N)) return 1;
   const size_t half = (size_t)N * FP_NN_IN_IMG_HALFS;
@@ -1068,7 +1069,7 @@ int fp_track_ex(fp_model *m, const void *rgb, const void *depth, int memspace, i
   FP_CHECK(m->refiner, "[FoundationPose] refiner weights not loaded");
   FP_CHECK(hyp_pose && out_pose, "[FoundationPose] Track: null pose");
   const bool graphable = m->use_graphs && !m->prof.on && !m->digests && !m->calibrating && refine_itr >= 1;
-  if (graphable ? stage_frame_owned(m, rgb, depth, memspace, H, W) : upload_frame_async(m, rgb, depth, memspace, H, W)) return 1;
+  if (upload_frame_async(m, rgb, depth, memspace, H, W)) return 1;
   if (upload_poses(m, t, hyp_pose, 1)) return 1;
   if (run_graphed(m, m->tg, t, H, W, refine_itr, 1, graphable, [&]() {
         for (int it = 0; it < refine_itr; it++)

@@ -746,13 +746,15 @@ void launch_sampler(hipStream_t s, const float *filtered_depth, const uint8_t *m
 // ---------------------------------------------------------------------------------------------
 
 template <int MODE>
-__global__ __launch_bounds__(256) void crop_kernel(const uint8_t *__restrict__ rgb, const float *__restrict__ depth,
+__global__ __launch_bounds__(256) void crop_kernel(const FrameRef *__restrict__ frame,
                                                    int H, int W, float fx, float fy, float cx, float cy,
                                                    const PoseRec *__restrict__ recs, float downscale,
                                                    void *__restrict__ out_all) {
   const int n = blockIdx.y;
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= CROP * CROP) return;
+  const uint8_t *__restrict__ rgb = frame->rgb;
+  const float *__restrict__ depth = frame->depth;
   const int y = i / CROP, x = i - y * CROP;
   const PoseRec &rec = recs[n];
   float sxf = rec.m0 * (float)x + rec.m2, syf = rec.m4 * (float)y + rec.m5;
@@ -795,18 +797,18 @@ __global__ __launch_bounds__(256) void crop_kernel(const uint8_t *__restrict__ r
   }
 }
 
-void launch_crop(hipStream_t s, const uint8_t *rgb, const float *depth, int H, int W, const float *K, const PoseRec *recs,
+void launch_crop(hipStream_t s, const FrameRef *frame, int H, int W, const float *K, const PoseRec *recs,
                  int N, float diameter, OutMode mode, void *out) {
   dim3 grid((CROP * CROP + 255) / 256, N), block(256);
   float downscale = diameter / 2;
   if (mode == OUT_F32X6)
-    hipLaunchKernelGGL(crop_kernel<OUT_F32X6>, grid, block, 0, s, rgb, depth, H, W, K[0], K[4], K[2], K[5], recs,
+    hipLaunchKernelGGL(crop_kernel<OUT_F32X6>, grid, block, 0, s, frame, H, W, K[0], K[4], K[2], K[5], recs,
                        downscale, out);
   else if (mode == OUT_BF16X8)
-    hipLaunchKernelGGL(crop_kernel<OUT_BF16X8>, grid, block, 0, s, rgb, depth, H, W, K[0], K[4], K[2], K[5], recs,
+    hipLaunchKernelGGL(crop_kernel<OUT_BF16X8>, grid, block, 0, s, frame, H, W, K[0], K[4], K[2], K[5], recs,
                        downscale, out);
   else
-    hipLaunchKernelGGL(crop_kernel<OUT_F16X8>, grid, block, 0, s, rgb, depth, H, W, K[0], K[4], K[2], K[5], recs,
+    hipLaunchKernelGGL(crop_kernel<OUT_F16X8>, grid, block, 0, s, frame, H, W, K[0], K[4], K[2], K[5], recs,
                        downscale, out);
 }
 

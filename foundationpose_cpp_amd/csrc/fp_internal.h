@@ -116,7 +116,13 @@ void launch_raster_shade(hipStream_t s, const DeviceMesh &m, const PoseRec *recs
 #ifdef FP_TEST_HOOKS
 void set_raster_strip_rows(int rows);  // 0 = automatic (A/B hook)
 #endif
-void launch_crop(hipStream_t s, const uint8_t *rgb, const float *depth, int H, int W, const float *K9_host,
+// the frame a replayed hipGraph reads: kernels inside graphs take the frame through this device-resident record, so a caller's
+// device frame is used in place (no copy into model-owned buffers) and the graph stays valid when the pointers change
+struct FrameRef {
+  const uint8_t *rgb;
+  const float *depth;
+};
+void launch_crop(hipStream_t s, const FrameRef *frame_dev, int H, int W, const float *K9_host,
                  const PoseRec *recs, int N, float diameter, OutMode mode, void *out);
 void launch_depth_to_xyz(hipStream_t s, const float *depth, int H, int W, const float *K9_host, float *xyz);
 void launch_erode(hipStream_t s, const float *depth, float *out, int H, int W);

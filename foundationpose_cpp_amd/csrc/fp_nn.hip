@@ -198,6 +198,9 @@ struct ConvParams {
   int grp_rows, in_shared, res_shared;
   unsigned grp_w_bytes;
   unsigned long long *clk;  // optional clock probe: per block {cycles0, realtime0, cycles1, realtime1}
+  // positional table [OH*OW][Cout] (element type out_dt) added to the ROUNDED output (exactly what add_pos_embed_kernel
+  // computes on the stored tensor); only conv_splitk_reduce_kernel implements it (Track: one launch less)
+  const unsigned char *post;
 };
 
 // Epilogue shared by every conv schedule.
@@ -1693,11 +1696,13 @@ __global__ __launch_bounds__(256, 2) void conv_deep_kernel(const ConvParams p) {
     const int xcd = b & 7, within = b >> 3, q = nblk >> 3, r = nblk & 7;
     logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
   }
+  const int split = logical % p.ksplit;  // split-K (small problems): this workgroup walks K-steps [K0, KT) into an fp32 partial slab
+  logical /= p.ksplit;
   const int mt = logical / n_tiles, nt = logical - mt * n_tiles;
   const int m0 = p.m_begin + mt * BM, n0 = nt * BN;
   const int ohw = p.OH * p.OW;
   const int IHp = p.H + 2 * p.ipad, IWp = p.W + 2 * p.ipad;
-  const int KT = p.krow_b >> 7;
+  const int K0 = split * p.kt_per, KT = min(p.krow_b >> 7, K0 + p.kt_per);
 
   const int srow = lane >> 3;
   const int g = (lane & 7) ^ srow;
@@ -1776,20 +1781,24 @@ __global__ __launch_bounds__(256, 2) void conv_deep_kernel(const ConvParams p) {
 
 #pragma unroll
   for (int s = 0; s < D; s++)
-    if (s < KT) issue(s);
+    if (K0 + s < KT) issue(K0 + s);
   Frags fa, fb;
-  wait_stage(0, D - 1);
+  wait_stage(K0, D - 1);
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
-  read_frags(0, fa);
+  read_frags(K0, fa);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  int kt = 0;
+  int kt = K0;
 #pragma unroll 1
   for (; kt + 1 < KT; kt += 2) {
     step(kt, fa, fb);
     step(kt + 1, fb, fa);
   }
   if (kt < KT) step(kt, fa, fb);
+  if (p.ksplit > 1) {
+    conv_store_partial<MI, 4>(p, acc, split, m0 + wm * (BM / 2), n0 + wn * 64, lane);
+    return;
+  }
   conv_epilogue<MI, 4, DT, ODT>(p, acc, m0 + wm * (BM / 2), n0 + wn * 64, lane);
 }
 
@@ -1836,6 +1845,12 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvParam
   for (int e = 0; e < 8; e++) {
     if (p.relu) v[e] = fmaxf(v[e], 0.f);
     v[e] *= p.out_inv;
+  }
+  if (p.post) {  // (2-byte output types only)
+    float pe[8];
+    decode8(load8_raw(p.post + ((size_t)rem * p.Cout + n) * 2, p.out_dt), p.out_dt, pe);
+#pragma unroll
+    for (int e = 0; e < 8; e++) v[e] = (p.out_dt == DT_BF16 ? (float)(__bf16)v[e] : (float)(_Float16)v[e]) + pe[e];
   }
   int choff = 0, oimg = img;
   if (p.split_imgs > 0 && img >= p.split_imgs) { oimg = img - p.split_imgs; choff = p.Cout; }
@@ -2357,6 +2372,25 @@ __global__ __launch_bounds__(256) void small_linear_kernel(const float *__restri
 #pragma unroll
   for (int k = 32; k > 0; k >>= 1) s += __shfl_xor(s, k);
   if (lane == 0) y[widx] = s + bias[o];
+}
+
+// the same for two independent layers of equal shape in ONE launch (blockIdx.y picks the layer): the refiner's two heads at Track
+struct SmallLinear2 {
+  const float *x[2], *W[2], *bias[2];
+  float *y[2];
+};
+__global__ __launch_bounds__(256) void small_linear2_kernel(const SmallLinear2 a, int B, int O, int C) {
+  const int h = blockIdx.y;
+  size_t widx = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  int lane = threadIdx.x & 63;
+  if (widx >= (size_t)B * O) return;
+  int b = (int)(widx / O), o = (int)(widx - (size_t)b * O);
+  const float *x = a.x[h], *W = a.W[h];
+  float s = 0.f;
+  for (int c = lane; c < C; c += 64) s += x[(size_t)b * C + c] * W[(size_t)o * C + c];
+#pragma unroll
+  for (int k = 32; k > 0; k >>= 1) s += __shfl_xor(s, k);
+  if (lane == 0) a.y[h][widx] = s + a.bias[h][o];
 }
 
 // cat[i][:, :, C:2C] = cat[0][:, :, C:2C] for i in 1..N-1 (bordered [N,HP,WP,2C] tensor, interior pixels only); CB = bytes
@@ -2909,6 +2943,9 @@ FP_HOOK g_grouped_heads = 1;   // the refiner's two heads as one launch per laye
 FP_HOOK g_rem_splitk = 0;      // split-K for left-over rows.  Measured -0.1 ms per Register, but OFF: a row's fp32 summation order would then
                                // depend on where it falls in the batch, and sharded and unsharded Register must pick the same near-tied winner
 FP_HOOK g_splitk_target = 128; // workgroups a split-K launch aims for (tools/ab_track.py: 96-128 best, 256 is 6 % slower)
+FP_HOOK g_splitk_min_kt = 9;    // layers with fewer 128-byte K-steps never split
+FP_HOOK g_splitk_deep = 1;      // split-K slices of at least 4 K-steps on conv_deep_kernel<128> (0 = conv_igemm_kernel<128>)
+FP_HOOK g_small_deep = 18;     // small problems (Track): conv_deep_kernel<64> over ALL K-steps instead of split-K + reduce when K has at most this many 128-byte steps
 FP_HOOK g_att_variant = 1;     // 1 = attention32_kernel (8 = without the XCD remap); round-1 kernel: 2 remap + 16-B stores, 3 no XCD remap, 5 remap + 2-B stores, 7 neither
 
 // One launch = (once per launch site and element type, thread-safe through the function-local static) dynamic-LDS opt-in +
@@ -2960,7 +2997,7 @@ static int run_conv_dt(const Ctx &c, const char *tag, const ConvLayer &L, ConvPa
   auto plan_splitk = [&](int rows, int target) -> int {
     const int mt = (rows + 127) / 128;
     const int tiles = mt * (L.Cout % 128 == 0 ? L.Cout / 128 : L.Cout / 64);
-    if (tiles > 96 || KT < 8) return 0;
+    if (tiles > 96 || KT < g_splitk_min_kt) return 0;
     int S = std::min(std::max(target / tiles, 1), KT / 2);
     if (S <= 1) return 0;
     p.kt_per = (KT + S - 1) / S;
@@ -2981,7 +3018,9 @@ static int run_conv_dt(const Ctx &c, const char *tag, const ConvLayer &L, ConvPa
     p.partial = sk->splitk;
     return 0;
   };
-  if (plan_splitk(p.M, g_splitk_target)) return 1;
+  const bool small_deep = !grp && g_small_deep > 0 && KT >= 4 && KT <= g_small_deep && L.Cout % 128 == 0 && ((p.M + 63) / 64) * (L.Cout / 128) >= 40 &&
+                          ((p.M + 63) / 64) * (L.Cout / 128) <= 256;
+  if (!small_deep && plan_splitk(p.M, g_splitk_target)) return 1;
   const std::string tg(tag);
   const bool halo_ok = g_conv_variant == 0 || g_conv_variant == 7;
   const bool force = g_conv_variant == 7;
@@ -3091,7 +3130,7 @@ static int run_conv_dt(const Ctx &c, const char *tag, const ConvLayer &L, ConvPa
       if (g_rem_splitk && plan_splitk(p.M - p.m_begin, 384)) return 1;
     }
   }
-  if (!grp && (p.m_begin > 0 || (g_rem_small && p.M >= 8192)) && g_rem_kernel && KT >= 16 && p.ksplit == 1 && L.Cout % 128 == 0) {
+  if (!grp && (p.m_begin > 0 || (g_rem_small && p.M >= 8192) || small_deep) && g_rem_kernel && (KT >= 16 || small_deep) && p.ksplit == 1 && L.Cout % 128 == 0) {
     // left-over rows on an otherwise idle chip: a lone workgroup per CU walks all K-steps, so per-step latency is what
     // counts: conv_512 left-overs 61 us per launch on the 2-stage 128x128 tile, 55 us on the 256x128 ping-pong, 39 us on
     // conv_deep_kernel<64> (neutral-to-slower for the 8-step Linear layers, hence KT >= 16)
@@ -3139,7 +3178,11 @@ static int run_conv_dt(const Ctx &c, const char *tag, const ConvLayer &L, ConvPa
     FP_LAUNCH((conv_pp_kernel<128, DT, ODT>), dim3(((p.M + 255) / 256) * (L.Cout / 128)), dim3(512), LDS3_128, c.s, p);
     return 0;
   }
-  if (L.Cout % 128 == 0) {
+  if (L.Cout % 128 == 0 && !grp && p.ksplit > 1 && g_splitk_deep && p.kt_per >= 4) {
+    // split-K slices on the deep-ring kernel (three K-steps in flight instead of one: a slice is a latency chain)
+    ProfScope ps(c.prof, c.s, (tg + "/conv_deep_kernel(split-K)").c_str(), flops, bytes);
+    FP_LAUNCH((conv_deep_kernel<128, DT, ODT>), dim3(mtiles * (L.Cout / 128) * p.ksplit), dim3(256), LDS_DEEP128, c.s, p);
+  } else if (L.Cout % 128 == 0) {
     ProfScope ps(c.prof, c.s, (tg + "/conv_igemm_kernel<128>").c_str(), flops, bytes);
     const dim3 grid(mtiles * (L.Cout / 128) * p.ksplit);
     bool done = false;
@@ -3170,10 +3213,14 @@ static int run_conv_dt(const Ctx &c, const char *tag, const ConvLayer &L, ConvPa
   return 0;
 }
 
+// post / post_fused: a positional table the layer may add to its output (see ConvParams::post); *post_fused tells the
+// caller whether the schedule that ran did (otherwise the caller launches add_pos_embed_kernel)
 static int run_conv(const Ctx &c, const char *tag, const ConvLayer &L, const Act &in, int NB, int H, int W, int ipad,
                     const Act &out, int opad, bool relu, const Act *res = nullptr, int rpad = 0, int split_imgs = 0,
-                    const ConvGroup *grp = nullptr) {
+                    const ConvGroup *grp = nullptr, const void *post = nullptr, bool *post_fused = nullptr) {
   ConvParams p;
+  p.post = (const unsigned char *)post;
+  if (post_fused) *post_fused = false;
   FP_CHECK(in.dt == L.dt, "run_conv: input element type does not match the layer's weights");
   FP_CHECK(L.dt != DT_FP8 || L.cscale, "run_conv: FP8 layer without scales");
   const int es = elem_bytes(L.dt);
@@ -3223,6 +3270,11 @@ static int run_conv(const Ctx &c, const char *tag, const ConvLayer &L, const Act
   }
   const bool hr = res != nullptr;
   FP_CHECK(!res || res->dt == L.dt, "run_conv: the residual must have the layer's operand type");
+  FP_CHECK(!post || (opad == 0 && split_imgs == 0 && out.dt != DT_FP8 && post_fused), "run_conv: positional table on an unsupported layer");
+  struct PostReport {  // the split-K decision is taken inside run_conv_dt (p.ksplit)
+    ConvParams &p; bool *flag;
+    ~PostReport() { if (flag) *flag = p.post != nullptr && p.ksplit > 1; }
+  } post_report{p, post_fused};
   if (L.dt == DT_FP8 && out.dt == DT_FP8) return run_conv_dt<DT_FP8, DT_FP8>(c, tag, L, p, NB, H, W, ipad, hr, split_imgs, grp);
   if (L.dt == DT_FP8 && out.dt == DT_F16) return run_conv_dt<DT_FP8, DT_F16>(c, tag, L, p, NB, H, W, ipad, hr, split_imgs, grp);
   if (L.dt == DT_F16 && out.dt == DT_FP8) return run_conv_dt<DT_F16, DT_FP8>(c, tag, L, p, NB, H, W, ipad, hr, split_imgs, grp);
@@ -3398,8 +3450,9 @@ static int run_trunk(const Ctx &c, const Arena &a, const void *nn_in, int N, int
   calib_record(c, 13, a.x512[1], (size_t)N * 22 * 22 * 512 * 2);
   // last conv writes the un-bordered token tensor [N,400,512] (2-byte type in every precision)
   const Act tok{a.tokens, adt, 1.f};
-  if (run_conv(c, "conv_512", net->rc[1][1], z1b, N, 20, 20, 1, tok, 0, true, &z2, 1)) return 1;
-  {
+  bool pe_done = false;
+  if (run_conv(c, "conv_512", net->rc[1][1], z1b, N, 20, 20, 1, tok, 0, true, &z2, 1, 0, nullptr, net->pe, &pe_done)) return 1;
+  if (!pe_done) {
     size_t rows = (size_t)N * 400;
     ProfScope ps(c.prof, c.s, "add_pos_embed", 0, (double)rows * EMBED * 4.0);
     size_t chunks = rows * (EMBED / 8);
@@ -3438,8 +3491,11 @@ int refiner_forward(hipStream_t s, Profiler *prof, const Net *net, NNScratch *ws
     if (run_gemm(c, "gemm_512", net->g_lin2, a.y1, 2 * G, a.att, false, a.y2, &g_own)) return 1;   // + residual x1
     run_layernorm(c, dt, a.att, T0.ln2, a.y1, 2 * G, &R0.ln2, G);
     run_token_mean(c, dt, a.y1, ws->f32, 2, 400, G);
-    run_small_linear(c, ws->f32, T0.head, trans_dev, 1);
-    run_small_linear(c, ws->f32 + EMBED, R0.head, rot_dev, 1);
+    {
+      ProfScope ps(c.prof, c.s, "small_linear", 2.0 * 2 * T0.head.out * T0.head.in, 0);
+      SmallLinear2 a{{ws->f32, ws->f32 + EMBED}, {T0.head.w, R0.head.w}, {T0.head.b, R0.head.b}, {trans_dev, rot_dev}};
+      hipLaunchKernelGGL(small_linear2_kernel, dim3((unsigned)((T0.head.out + 3) / 4), 2), dim3(256), 0, c.s, a, 1, T0.head.out, T0.head.in);
+    }
     FP_HIP_OK(hipGetLastError());
     return 0;
   }
@@ -3598,6 +3654,9 @@ void fpt_set_grouped_heads(int v) { fp::g_grouped_heads = v; }
 void fpt_set_gemm_kernel(int v) { fp::g_gemm_kernel = v; }
 void fpt_set_rem_kernel(int v) { fp::g_rem_kernel = v; }
 void fpt_set_rem_small(int v) { fp::g_rem_small = v; }
+void fpt_set_small_deep(int v) { fp::g_small_deep = v; }
+void fpt_set_splitk_deep(int v) { fp::g_splitk_deep = v; }
+void fpt_set_splitk_min_kt(int v) { fp::g_splitk_min_kt = v; }
 void fpt_set_raster_strip_rows(int r) { fp::set_raster_strip_rows(r); }
 
 // clock probe: allocate room for `blocks` records, run convs, then read back mean shader MHz and mean main-loop cycles
