@@ -2359,6 +2359,60 @@ __global__ __launch_bounds__(256) void token_mean_kernel(const typename ElemT<DT
   if (wave == 0) out[(size_t)b * EMBED + cg * 64 + lane] = (((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane]) / (float)T;
 }
 
+// out[b,:] = mean_t LayerNorm(x[b,t,:]): the encoder's second LayerNorm feeds nothing but the token mean, so the normalised
+// tensor never goes to memory (two 103 MB passes per head at N = 252).  One workgroup per sequence, 16 waves, a wave per row
+// (the arithmetic of layernorm_kernel incl. the rounding to the element type), per-lane column sums, fixed-order reduction.
+// Sequences b >= split_b use (gamma1, beta1): the refiner's two heads in one launch (Track).
+template <int DT>
+__global__ __launch_bounds__(1024) void layernorm_mean_kernel(const typename ElemT<DT>::t *__restrict__ x, const float *__restrict__ gamma0,
+                                                              const float *__restrict__ beta0, const float *__restrict__ gamma1,
+                                                              const float *__restrict__ beta1, int split_b, float *__restrict__ out, int T,
+                                                              int tstride) {
+  using E = typename ElemT<DT>::t;
+  using E8 = typename ElemT<DT>::v8;
+  __shared__ float part[16][EMBED];
+  const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float *gamma = b >= split_b ? gamma1 : gamma0, *beta = b >= split_b ? beta1 : beta0;
+  float gm[8], bt[8], acc[8];
+#pragma unroll
+  for (int e = 0; e < 8; e++) { gm[e] = gamma[lane * 8 + e]; bt[e] = beta[lane * 8 + e]; acc[e] = 0.f; }
+  const E *src = x + (size_t)b * tstride * EMBED;
+  auto fold = [&](const E8 &v) {
+    float f[8], s = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; e++) { f[e] = (float)v[e]; s += f[e]; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    float mean = s * (1.0f / EMBED), q = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; e++) { f[e] -= mean; q += f[e] * f[e]; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    float rstd = rsqrtf(q * (1.0f / EMBED) + 1e-5f);
+#pragma unroll
+    for (int e = 0; e < 8; e++) acc[e] += (float)(E)(f[e] * rstd * gm[e] + bt[e]);
+  };
+  // four rows of a wave in flight (rows wave, wave+16, ...: ascending order inside a wave, so the sums do not depend on the unroll)
+  for (int t = wave; t < T; t += 64) {
+    E8 v[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+      if (t + 16 * j < T) v[j] = reinterpret_cast<const E8 *>(src + (size_t)(t + 16 * j) * EMBED)[lane];
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+      if (t + 16 * j < T) fold(v[j]);
+  }
+#pragma unroll
+  for (int e = 0; e < 8; e++) part[wave][lane * 8 + e] = acc[e];
+  __syncthreads();
+  if (threadIdx.x < EMBED) {
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; w++) s += part[w][threadIdx.x];
+    out[(size_t)b * EMBED + threadIdx.x] = s / (float)T;
+  }
+}
+
 // y[b,o] = bias[o] + sum_c x[b,c] W[o,c]   (f32; one wave per output)
 __global__ __launch_bounds__(256) void small_linear_kernel(const float *__restrict__ x, const float *__restrict__ W,
                                                            const float *__restrict__ bias, float *__restrict__ y, int B,
@@ -3347,6 +3401,16 @@ static void run_layernorm(const Ctx &c, int dt, const void *x, const LNParams &l
   else hipLaunchKernelGGL(layernorm_kernel<DT_F16>, grid, dim3(256), 0, c.s, (const _Float16 *)x, ln.g, ln.b, (_Float16 *)y, rows, g1, b1, sr);
 }
 
+static void run_layernorm_mean(const Ctx &c, int dt, const void *x, const LNParams &ln, float *out, int B, int T, int tstride = 0,
+                               const LNParams *ln1 = nullptr, int split_b = 0) {
+  ProfScope ps(c.prof, c.s, "layernorm_mean", 0, (double)B * T * EMBED * 2.0);
+  const float *g1 = ln1 ? ln1->g : ln.g, *b1 = ln1 ? ln1->b : ln.b;
+  const int sb = ln1 ? split_b : B;
+  if (tstride == 0) tstride = T;
+  if (dt == DT_BF16) hipLaunchKernelGGL(layernorm_mean_kernel<DT_BF16>, dim3(B), dim3(1024), 0, c.s, (const __bf16 *)x, ln.g, ln.b, g1, b1, sb, out, T, tstride);
+  else hipLaunchKernelGGL(layernorm_mean_kernel<DT_F16>, dim3(B), dim3(1024), 0, c.s, (const _Float16 *)x, ln.g, ln.b, g1, b1, sb, out, T, tstride);
+}
+
 static void run_small_linear(const Ctx &c, const float *x, const LinearF32 &L, float *y, int B) {
   ProfScope ps(c.prof, c.s, "small_linear", 2.0 * B * L.out * L.in, 0);
   size_t waves = (size_t)B * L.out;
@@ -3489,6 +3553,7 @@ int refiner_forward(hipStream_t s, Profiler *prof, const Net *net, NNScratch *ws
     run_layernorm(c, dt, a.y1, T0.ln1, a.y2, 2 * G, &R0.ln1, G);
     if (run_gemm(c, "gemm_512", net->g_lin1, a.y2, 2 * G, a.y1, true, nullptr, &g_own)) return 1;
     if (run_gemm(c, "gemm_512", net->g_lin2, a.y1, 2 * G, a.att, false, a.y2, &g_own)) return 1;   // + residual x1
+    // (two sequences only: LayerNorm over 800 workgroup-rows + a 16-workgroup mean beat the one-workgroup-per-sequence fused kernel, 11 vs 20 us)
     run_layernorm(c, dt, a.att, T0.ln2, a.y1, 2 * G, &R0.ln2, G);
     run_token_mean(c, dt, a.y1, ws->f32, 2, 400, G);
     {
@@ -3508,8 +3573,7 @@ int refiner_forward(hipStream_t s, Profiler *prof, const Net *net, NNScratch *ws
     run_layernorm(c, dt, a.y1, L.ln1, a.y2, rows);                                           // x1 = y2
     if (run_gemm(c, "gemm_512", L.lin1, a.y2, (int)rows, a.y1, true)) return 1;
     if (run_gemm(c, "gemm_512", L.lin2, a.y1, (int)rows, a.att, false, a.y2)) return 1;       // + residual x1
-    run_layernorm(c, dt, a.att, L.ln2, a.y1, rows);
-    run_token_mean(c, dt, a.y1, ws->f32, N, 400);
+    run_layernorm_mean(c, dt, a.att, L.ln2, ws->f32, N, 400);
     run_small_linear(c, ws->f32, L.head, outs[i], N);  // Linear(512,3) commutes with the token mean
   }
   FP_HIP_OK(hipGetLastError());
