@@ -19,9 +19,12 @@ preceding Conv and renames the results `onnx::Conv_123`, and stores Linear weigh
   * every assignment is checked against the shape the architecture requires and the reader fails
     loudly on any mismatch, listing what it found.
 
-STATUS: the real ONNX files are not available offline (Google-Drive link, README.md:72), so this has been exercised
-only on graphs written by tests/onnx_writer.py in the TorchScript exporter's conventions -- mapping UNVERIFIED against
-the real files; `--list` prints everything the reader sees so a mismatch is diagnosable in one run.
+STATUS: exercised on (a) graphs written by tests/onnx_writer.py in the exporter's conventions and (b) files written by the
+REAL PyTorch TorchScript exporter from the oracle's restatement of the architecture, opset 14 (LayerNorm decomposed) and 17
+(tests/test_onnx_exporter.py, tests/torch_onnx_export.py): every tensor is recovered and the HIP networks loaded from such a
+file match the exporting torch module.  The published refiner_hwc.onnx / scorer_hwc.onnx themselves are not available offline
+(Google-Drive link, README.md:72): that THEY have this architecture is the remaining unverified step -- `--list` prints
+everything the reader sees so a mismatch is diagnosable in one run.
 """
 from __future__ import annotations
 
