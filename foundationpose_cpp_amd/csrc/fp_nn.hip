@@ -1139,43 +1139,95 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const ConvParams p) {
         if (s + 2 < S) issue_w(s + 2);
         const unsigned char *xs = smem + pix_off + (((ks * 4 + kg) ^ g) << 4);
         const unsigned char *ws = smem + wfo + (s % NWST) * WST;
-        // X fragments in two halves of MI/2 (register budget: 160 accumulators + 20 + 16 fragment registers); the
-        // second half's LDS reads are issued behind the first half's MFMAs
-        constexpr int HM = MI / 2;
-        i4 xf[HM], wf[NI];
+        if constexpr (ABL == 0) {  // (any ablation flag, e.g. 32: the round-1 schedule -- two halves of 5 fragments)
+          // X fragments in four groups (3,2,3,2 of MI = 10) through two small register sets: the LDS reads of group q+1 are in
+          // flight while the MFMAs of group q issue, so only the first group of a K-step waits for the LDS with the matrix pipe idle
+          static_assert(MI == 10, "group split written for 10 pixel fragments");
+          i4 wf[NI], xa[3], xb[2];
 #pragma unroll
-        for (int ni = 0; ni < NI; ni++) wf[ni] = *reinterpret_cast<const i4 *>(ws + ni * 16 * 64);
+          for (int ni = 0; ni < NI; ni++) wf[ni] = *reinterpret_cast<const i4 *>(ws + ni * 16 * 64);
 #pragma unroll
-        for (int mi = 0; mi < HM; mi++) xf[mi] = *reinterpret_cast<const i4 *>(xs + mi * 512);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (!(ABL & 8)) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ni = 0; ni < NI; ni++)
-#pragma unroll
-          for (int mi = 0; mi < HM; mi++) {
-            if (ABL & 2) asm volatile("" ::"v"(wf[ni]), "v"(xf[mi]));
-            else acc[ni][mi] = mfma32<DT>(wf[ni], xf[mi], acc[ni][mi]);
-          }
-        if (!(ABL & 8)) __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int mi = 0; mi < HM; mi++) xf[mi] = *reinterpret_cast<const i4 *>(xs + (HM + mi) * 512);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (tap == 8 && ks == 1 && ch + 1 < nch) {  // last read of this chunk's halo tile: refill it under the MFMAs
-          __builtin_amdgcn_s_barrier();
-          asm volatile("" ::: "memory");
+          for (int i = 0; i < 3; i++) xa[i] = *reinterpret_cast<const i4 *>(xs + i * 512);
           __builtin_amdgcn_sched_barrier(0);
-          issue_halo(ch + 1);
-        }
-        if (!(ABL & 8)) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int ni = 0; ni < NI; ni++)
+          for (int i = 0; i < 2; i++) xb[i] = *reinterpret_cast<const i4 *>(xs + (3 + i) * 512);
+          __builtin_amdgcn_sched_barrier(0);
+          __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-          for (int mi = 0; mi < HM; mi++) {
-            if (ABL & 2) asm volatile("" ::"v"(wf[ni]), "v"(xf[mi]));
-            else acc[ni][HM + mi] = mfma32<DT>(wf[ni], xf[mi], acc[ni][HM + mi]);
+          for (int ni = 0; ni < NI; ni++)
+#pragma unroll
+            for (int i = 0; i < 3; i++) acc[ni][i] = mfma32<DT>(wf[ni], xa[i], acc[ni][i]);
+          __builtin_amdgcn_s_setprio(0);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int i = 0; i < 3; i++) xa[i] = *reinterpret_cast<const i4 *>(xs + (5 + i) * 512);
+          __builtin_amdgcn_sched_barrier(0);
+          __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+          for (int ni = 0; ni < NI; ni++)
+#pragma unroll
+            for (int i = 0; i < 2; i++) acc[ni][3 + i] = mfma32<DT>(wf[ni], xb[i], acc[ni][3 + i]);
+          __builtin_amdgcn_s_setprio(0);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int i = 0; i < 2; i++) xb[i] = *reinterpret_cast<const i4 *>(xs + (8 + i) * 512);
+          __builtin_amdgcn_sched_barrier(0);
+          if (tap == 8 && ks == 1 && ch + 1 < nch) {  // last reads of this chunk's halo tile are issued: refill it under the MFMAs
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            issue_halo(ch + 1);
           }
-        if (!(ABL & 8)) __builtin_amdgcn_s_setprio(0);
+          __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+          for (int ni = 0; ni < NI; ni++)
+#pragma unroll
+            for (int i = 0; i < 3; i++) acc[ni][5 + i] = mfma32<DT>(wf[ni], xa[i], acc[ni][5 + i]);
+#pragma unroll
+          for (int ni = 0; ni < NI; ni++)
+#pragma unroll
+            for (int i = 0; i < 2; i++) acc[ni][8 + i] = mfma32<DT>(wf[ni], xb[i], acc[ni][8 + i]);
+          __builtin_amdgcn_s_setprio(0);
+        } else {
+          // X fragments in two halves of MI/2 (register budget: 160 accumulators + 20 + 16 fragment registers); the
+          // second half's LDS reads are issued behind the first half's MFMAs
+          constexpr int HM = MI / 2;
+          i4 xf[HM], wf[NI];
+#pragma unroll
+          for (int ni = 0; ni < NI; ni++) wf[ni] = *reinterpret_cast<const i4 *>(ws + ni * 16 * 64);
+#pragma unroll
+          for (int mi = 0; mi < HM; mi++) xf[mi] = *reinterpret_cast<const i4 *>(xs + mi * 512);
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          if (!(ABL & 8)) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+          for (int ni = 0; ni < NI; ni++)
+#pragma unroll
+            for (int mi = 0; mi < HM; mi++) {
+              if (ABL & 2) asm volatile("" ::"v"(wf[ni]), "v"(xf[mi]));
+              else acc[ni][mi] = mfma32<DT>(wf[ni], xf[mi], acc[ni][mi]);
+            }
+          if (!(ABL & 8)) __builtin_amdgcn_s_setprio(0);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int mi = 0; mi < HM; mi++) xf[mi] = *reinterpret_cast<const i4 *>(xs + (HM + mi) * 512);
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          if (tap == 8 && ks == 1 && ch + 1 < nch) {  // last read of this chunk's halo tile: refill it under the MFMAs
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            issue_halo(ch + 1);
+          }
+          if (!(ABL & 8)) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+          for (int ni = 0; ni < NI; ni++)
+#pragma unroll
+            for (int mi = 0; mi < HM; mi++) {
+              if (ABL & 2) asm volatile("" ::"v"(wf[ni]), "v"(xf[mi]));
+              else acc[ni][HM + mi] = mfma32<DT>(wf[ni], xf[mi], acc[ni][HM + mi]);
+            }
+          if (!(ABL & 8)) __builtin_amdgcn_s_setprio(0);
+        }
       }
     }
   }
@@ -1297,15 +1349,21 @@ __global__ __launch_bounds__(256, 2) void conv_halo8_kernel(const ConvParams p) 
       asm volatile("" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
       if (s + 1 < S) issue_w(s + 1);
+      // pixel fragments one at a time through two register sets: the reads of fragment m+1 are in flight while the four MFMAs of
+      // fragment m issue (the round-1 schedule read two fragments, waited, issued eight MFMAs, five times per tap)
+      auto read_x = [&](int m) {
+        return __builtin_shufflevector(*reinterpret_cast<const i4 *>(xs0 + m * 512), *reinterpret_cast<const i4 *>(xs1 + m * 512), 0, 1, 2, 3, 4, 5, 6, 7);
+      };
+      i8 xv[2];
+      xv[0] = read_x(0);
 #pragma unroll
-      for (int m2 = 0; m2 < MI; m2 += 2) {
-        i8 xv[2];
-#pragma unroll
-        for (int j = 0; j < 2; j++)
-          xv[j] = __builtin_shufflevector(*reinterpret_cast<const i4 *>(xs0 + (m2 + j) * 512),
-                                          *reinterpret_cast<const i4 *>(xs1 + (m2 + j) * 512), 0, 1, 2, 3, 4, 5, 6, 7);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (m2 == MI - 2 && tap == 8 && ch + 1 < nch) {  // last read of this chunk's halo tile: refill it under the MFMAs
+      for (int m = 0; m < MI; m++) {
+        if (m + 1 < MI) {
+          xv[(m + 1) & 1] = read_x(m + 1);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (m == MI - 2 && tap == 8 && ch + 1 < nch) {  // the last read of this chunk's halo tile is issued: refill it under the MFMAs
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
           __builtin_amdgcn_s_barrier();
           asm volatile("" ::: "memory");
           __builtin_amdgcn_sched_barrier(0);
@@ -1313,9 +1371,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo8_kernel(const ConvParams p) 
         }
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int ni = 0; ni < NI; ni++)
-#pragma unroll
-          for (int j = 0; j < 2; j++) acc[ni][m2 + j] = mfma128_fp8(wv[ni], xv[j], acc[ni][m2 + j]);
+        for (int ni = 0; ni < NI; ni++) acc[ni][m] = mfma128_fp8(wv[ni], xv[m & 1], acc[ni][m]);
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -3117,6 +3173,7 @@ static int run_conv_dt(const Ctx &c, const char *tag, const ConvLayer &L, ConvPa
       if (DT == DT_F16 && g_conv_ablate == 1) { FP_LAUNCH((conv_halo_kernel<40, 1, DT_F16>), grid, dim3(256), LDS_HALO40, c.s, p); return 0; }
       if (DT == DT_F16 && g_conv_ablate == 2) { FP_LAUNCH((conv_halo_kernel<40, 2, DT_F16>), grid, dim3(256), LDS_HALO40, c.s, p); return 0; }
       if (DT == DT_F16 && g_conv_ablate == 8) { FP_LAUNCH((conv_halo_kernel<40, 8, DT_F16>), grid, dim3(256), LDS_HALO40, c.s, p); return 0; }
+      if (DT == DT_F16 && g_conv_ablate == 32) { FP_LAUNCH((conv_halo_kernel<40, 32, DT_F16>), grid, dim3(256), LDS_HALO40, c.s, p); return 0; }
 #endif
       FP_LAUNCH((conv_halo_kernel<40, 0, DT>), grid, dim3(256), LDS_HALO40, c.s, p);
     } else {

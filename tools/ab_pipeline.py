@@ -11,11 +11,11 @@ mesh = syn.make_mesh(); scene = syn.make_scene(mesh)
 d = tempfile.mkdtemp()
 rp, sp = os.path.join(d, "r.fpw"), os.path.join(d, "s.fpw")
 W.pack_synthetic("refiner", rp); W.pack_synthetic("scorer", sp)
+_lib.use_test_lib()
+L = _lib.lib()
 m = FoundationPose(mesh, scene.K, rp, sp)
 if os.environ.get("FP_AB_INPLANE"):   # hypotheses = 42 x in-plane steps (default 6 -> 252)
     m.set_inplane_steps(int(os.environ["FP_AB_INPLANE"]))
-_lib.use_test_lib()
-L = _lib.lib()
 for v in values:
     getattr(L, hook)(v)
     for _ in range(2):
