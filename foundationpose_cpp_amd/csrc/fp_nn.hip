@@ -216,7 +216,7 @@ struct ConvParams {
 // scale first.  ODT = the output element type (differs from DT only in the two layers at a precision boundary).
 // The epilogue covers channel tiles [NI0, NI0 + NI) of an accumulator array of NIT tiles (the stem: two 32-channel passes
 // over its 4 tiles; the array is passed whole so that it stays in registers).
-template <int MI, int NI, int DT, int ODT, int EABL = 0, int NIT = NI, int NI0 = 0, class PixFn>  // EABL (timing ablations): 1 = no stores, 2 = no residual loads
+template <int MI, int NI, int DT, int ODT, int EABL = 0, int NIT = NI, int NI0 = 0, class PixFn>  // EABL: 1 = no stores, 2 = no residual loads (timing ablations / layers without residual), 4 = add ConvParams::post
 __device__ __forceinline__ void conv_epilogue_px(const ConvParams &p, f4 (&acc)[NIT][MI], int n_base, int lane, PixFn pix,
                                                  int bias_off = 0, int res_img_off = 0) {
   static_assert(NI == 4 || NI == 2, "wave covers 64 or 32 channels");
@@ -247,19 +247,26 @@ __device__ __forceinline__ void conv_epilogue_px(const ConvParams &p, f4 (&acc)[
       }
     }
   }
-  // pixels in groups of at most 8 fragments: a group's residual values stay in registers
-  constexpr int GB = MI > 8 ? (MI + 1) / 2 : MI;
+  // pixels in groups of at most 8 fragments (4 with a positional table): a group's residual / table values stay in registers
+  constexpr bool POST = (EABL & 4) != 0;
+  static_assert(!POST || ODT != DT_FP8, "the positional table is added to 2-byte outputs");
+  constexpr int GB = POST ? (MI > 4 ? 4 : MI) : (MI > 8 ? (MI + 1) / 2 : MI);
 #pragma unroll
   for (int g0 = 0; g0 < MI; g0 += GB) {
   size_t oofs[GB];
   bool ok[GB];
-  i4 rv[NS][GB];
+  i4 rv[NS][GB], pv[NS][POST ? GB : 1];
 #pragma unroll
   for (int gi = 0; gi < GB; gi++) {
     const int mi = g0 + gi;
     if (mi >= MI) break;
     int img, oh, ow;
     ok[gi] = pix(mi, img, oh, ow);  // (img, oh, ow) must be a valid address even when !ok
+    if constexpr (POST) {
+      const size_t tok = (size_t)oh * p.OW + ow;
+#pragma unroll
+      for (int k = 0; k < NS; k++) pv[k][gi] = *reinterpret_cast<const i4 *>(p.post + (tok * p.Cout + nl + 32 * k) * 2);
+    }
     int choff = 0, oimg = img;
     if (p.split_imgs > 0 && img >= p.split_imgs) { oimg = img - p.split_imgs; choff = p.Cout; }
     oofs[gi] = (((size_t)oimg * OHp + oh + p.opad) * OWp + ow + p.opad) * p.out_ld + choff;
@@ -293,6 +300,7 @@ __device__ __forceinline__ void conv_epilogue_px(const ConvParams &p, f4 (&acc)[
           }
           if (p.relu) v = fmaxf(v, 0.f);
           if constexpr (ODT == DT_FP8) v = sat_fp8(v * p.out_inv);
+          if constexpr (POST) v = (float)(typename ElemT<ODT>::t)v + raw_elem<ODT>(pv[k][gi], e);  // = add_pos_embed_kernel on the stored value
           v2[h] = v;
         }
         if constexpr (ODT == DT_FP8) {
@@ -672,7 +680,7 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvParams p) {
 // two 64-KB LDS stages, one workgroup per CU.  Needs Cout % 256 == 0.
 // -------------------------------------------------------------------------------------------------
 // Ping-pong schedule of the 256 x 256 tile (see the slot comment inside).
-template <int ABL, int DT, int ODT = DT>
+template <int ABL, int DT, int ODT = DT, bool POST = false>
 __global__ __launch_bounds__(512, 2) void conv_big_pp_kernel(const ConvParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int BM = 256, BN = 256;
@@ -872,7 +880,7 @@ __global__ __launch_bounds__(512, 2) void conv_big_pp_kernel(const ConvParams p)
       for (int b = 0; b < MI; b++) asm volatile("" ::"v"(acc[a][b]));
     return;
   }
-  conv_epilogue<MI, NI, DT, ODT, (ABL >> 3) & 3>(p, acc, m0 + wm * 128, n0 + wn * 64, lane);
+  conv_epilogue<MI, NI, DT, ODT, ((ABL >> 3) & 3) | (POST ? 4 : 0)>(p, acc, m0 + wm * 128, n0 + wn * 64, lane);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -1733,7 +1741,7 @@ __global__ __launch_bounds__(256, 2) void gemm_k32_kernel(const ConvParams p) {
 // current step's MFMAs (two register sets).  Same K order / accumulation order as every
 // other schedule, so a row's value does not depend on which kernel computed it.
 // -------------------------------------------------------------------------------------------------
-template <int BM, int DT, int ODT = DT>
+template <int BM, int DT, int ODT = DT, bool POST = false>
 __global__ __launch_bounds__(256, 2) void conv_deep_kernel(const ConvParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int BN = 128;
@@ -1855,7 +1863,7 @@ __global__ __launch_bounds__(256, 2) void conv_deep_kernel(const ConvParams p) {
     conv_store_partial<MI, 4>(p, acc, split, m0 + wm * (BM / 2), n0 + wn * 64, lane);
     return;
   }
-  conv_epilogue<MI, 4, DT, ODT>(p, acc, m0 + wm * (BM / 2), n0 + wn * 64, lane);
+  conv_epilogue<MI, 4, DT, ODT, POST ? 4 : 0>(p, acc, m0 + wm * (BM / 2), n0 + wn * 64, lane);
 }
 
 // split-K reduction + the conv epilogue: out = relu(sum_s partial[s] * scale + bias + res); thread = (pixel, 8 channels)
@@ -2469,19 +2477,40 @@ __global__ __launch_bounds__(1024) void layernorm_mean_kernel(const typename Ele
   }
 }
 
-// y[b,o] = bias[o] + sum_c x[b,c] W[o,c]   (f32; one wave per output)
+// y[b,o] = bias[o] + sum_c x[b,c] W[o,c]   (f32).  One wave per (output o, block of 8 rows b): the weight row lives in registers
+// (C = 512: 8 floats per lane) and is reused for the 8 rows, so W is read B/8 times instead of B times (the 512x512 out_proj of
+// the score-net at N = 252: 130 MB -> 16 MB of L2 reads); the summation order of a (b, o) pair is the same as one wave per output.
 __global__ __launch_bounds__(256) void small_linear_kernel(const float *__restrict__ x, const float *__restrict__ W,
                                                            const float *__restrict__ bias, float *__restrict__ y, int B,
                                                            int O, int C) {
+  const int nbb = (B + 7) / 8;
   size_t widx = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   int lane = threadIdx.x & 63;
-  if (widx >= (size_t)B * O) return;
-  int b = (int)(widx / O), o = (int)(widx - (size_t)b * O);
-  float s = 0.f;
-  for (int c = lane; c < C; c += 64) s += x[(size_t)b * C + c] * W[(size_t)o * C + c];
+  if (widx >= (size_t)nbb * O) return;
+  const int bb = (int)(widx / O), o = (int)(widx - (size_t)bb * O);
+  const int b0 = bb * 8, nb = min(8, B - b0);
+  if (C == 512) {
+    float w[8];
 #pragma unroll
-  for (int k = 32; k > 0; k >>= 1) s += __shfl_xor(s, k);
-  if (lane == 0) y[widx] = s + bias[o];
+    for (int j = 0; j < 8; j++) w[j] = W[(size_t)o * C + lane + 64 * j];
+    for (int i = 0; i < nb; i++) {
+      const float *xr = x + (size_t)(b0 + i) * C;
+      float s = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; j++) s += xr[lane + 64 * j] * w[j];
+#pragma unroll
+      for (int k = 32; k > 0; k >>= 1) s += __shfl_xor(s, k);
+      if (lane == 0) y[(size_t)(b0 + i) * O + o] = s + bias[o];
+    }
+    return;
+  }
+  for (int i = 0; i < nb; i++) {
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += x[(size_t)(b0 + i) * C + c] * W[(size_t)o * C + c];
+#pragma unroll
+    for (int k = 32; k > 0; k >>= 1) s += __shfl_xor(s, k);
+    if (lane == 0) y[(size_t)(b0 + i) * O + o] = s + bias[o];
+  }
 }
 
 // the same for two independent layers of equal shape in ONE launch (blockIdx.y picks the layer): the refiner's two heads at Track
@@ -3088,6 +3117,7 @@ static int run_conv_dt(const Ctx &c, const char *tag, const ConvLayer &L, ConvPa
   constexpr bool B2 = DT != DT_FP8;  // 2-byte element type: the 64-byte-row kernels exist
   constexpr bool SAME = DT == ODT;   // kernels without an ODT parameter write their operand type
   const int KT = p.krow_b / 128;
+  bool post_main = false;  // ConvParams::post handled by the 256x256 rounds + deep-ring left-over (see below)
   double flops = 2.0 * (double)p.M * p.Cout * (L.algo_K > 0 ? L.algo_K : p.Ktot);
   double bytes = ((double)NB * H * W * L.Cin + (double)p.M * p.Cout * (has_res ? 2 : 1) + (double)p.Cout * p.Ktot) * elem_bytes(DT);
   constexpr int LDS_IG128 = 2 * (128 * 128 + 128 * 128), LDS_IG64 = 2 * (128 * 128 + 64 * 128);
@@ -3210,6 +3240,14 @@ static int run_conv_dt(const Ctx &c, const char *tag, const ConvLayer &L, ConvPa
     const int nt2 = L.Cout / 256;
     const int mt_all = p.M / 256;                         // whole 256-row m-tiles
     const int mt_big = (mt_all * nt2 / 256) * 256 / nt2;  // m-tiles covered by full rounds
+    if (p.post) {
+      // the positional table is fused only when every row takes a schedule that implements it: the 256x256 rounds + the deep-ring
+      // kernel for the left-over (N = 252); otherwise nobody adds it here and the caller launches add_pos_embed_kernel
+      const int rows_left = p.M - mt_big * 256;
+      post_main = mt_big > 0 && g_conv_variant == 0 && g_conv_ablate == 0 && g_rem_kernel == 3 && KT >= 16 &&
+                  (rows_left == 0 || ((rows_left + 63) / 64) * (L.Cout / 128) <= 256);
+      if (!post_main) p.post = nullptr;
+    }
     if (mt_big > 0) {
       ConvParams pb = p;
       pb.M = mt_big * 256;                                // rows [0, mt_big*256)
@@ -3232,6 +3270,9 @@ static int run_conv_dt(const Ctx &c, const char *tag, const ConvLayer &L, ConvPa
           }
         }
 #endif
+        if constexpr (ODT != DT_FP8) {
+          if (!done && post_main) { FP_LAUNCH((conv_big_pp_kernel<0, DT, ODT, true>), grid, dim3(512), LDS_BIG, c.s, pb); done = true; }
+        }
         if (!done) FP_LAUNCH((conv_big_pp_kernel<0, DT, ODT>), grid, dim3(512), LDS_BIG, c.s, pb);
       }
       flops *= (1.0 - frac); bytes *= (1.0 - frac);
@@ -3241,6 +3282,7 @@ static int run_conv_dt(const Ctx &c, const char *tag, const ConvLayer &L, ConvPa
       if (g_rem_splitk && plan_splitk(p.M - p.m_begin, 384)) return 1;
     }
   }
+  if (p.post && !post_main && p.ksplit == 1) p.post = nullptr;  // only the split-K reduce implements it on the remaining paths
   if (!grp && (p.m_begin > 0 || (g_rem_small && p.M >= 8192) || small_deep) && g_rem_kernel && (KT >= 16 || small_deep) && p.ksplit == 1 && L.Cout % 128 == 0) {
     // left-over rows on an otherwise idle chip: a lone workgroup per CU walks all K-steps, so per-step latency is what
     // counts: conv_512 left-overs 61 us per launch on the 2-stage 128x128 tile, 55 us on the 256x128 ping-pong, 39 us on
@@ -3274,6 +3316,12 @@ static int run_conv_dt(const Ctx &c, const char *tag, const ConvLayer &L, ConvPa
         rows = rest;
       }
       ProfScope ps(c.prof, c.s, (tg + "/conv_deep_kernel").c_str(), flops, bytes);
+      if constexpr (ODT != DT_FP8) {
+        if (post_main) {
+          FP_LAUNCH((conv_deep_kernel<64, DT, ODT, true>), dim3(((rows + 63) / 64) * n128), dim3(256), LDS_DEEP64, c.s, p);
+          return 0;
+        }
+      }
       FP_LAUNCH((conv_deep_kernel<64, DT, ODT>), dim3(((rows + 63) / 64) * n128), dim3(256), LDS_DEEP64, c.s, p);
       return 0;
     }
@@ -3384,7 +3432,7 @@ static int run_conv(const Ctx &c, const char *tag, const ConvLayer &L, const Act
   FP_CHECK(!post || (opad == 0 && split_imgs == 0 && out.dt != DT_FP8 && post_fused), "run_conv: positional table on an unsupported layer");
   struct PostReport {  // the split-K decision is taken inside run_conv_dt (p.ksplit)
     ConvParams &p; bool *flag;
-    ~PostReport() { if (flag) *flag = p.post != nullptr && p.ksplit > 1; }
+    ~PostReport() { if (flag) *flag = p.post != nullptr; }  // (run_conv_dt clears p.post when no schedule that ran implements it)
   } post_report{p, post_fused};
   if (L.dt == DT_FP8 && out.dt == DT_FP8) return run_conv_dt<DT_FP8, DT_FP8>(c, tag, L, p, NB, H, W, ipad, hr, split_imgs, grp);
   if (L.dt == DT_FP8 && out.dt == DT_F16) return run_conv_dt<DT_FP8, DT_F16>(c, tag, L, p, NB, H, W, ipad, hr, split_imgs, grp);
@@ -3470,7 +3518,7 @@ static void run_layernorm_mean(const Ctx &c, int dt, const void *x, const LNPara
 
 static void run_small_linear(const Ctx &c, const float *x, const LinearF32 &L, float *y, int B) {
   ProfScope ps(c.prof, c.s, "small_linear", 2.0 * B * L.out * L.in, 0);
-  size_t waves = (size_t)B * L.out;
+  size_t waves = (size_t)((B + 7) / 8) * L.out;
   hipLaunchKernelGGL(small_linear_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, c.s, x, L.w, L.b, y, B, L.out, L.in);
 }
 
