@@ -115,7 +115,7 @@ def lib() -> C.CDLL:
     return L
 
 
-TEST_LIB_PATH = os.path.join(_HERE, "libfoundationpose_amd_test.so")
+TEST_LIB_PATH = os.environ.get("FP_TEST_LIB_PATH") or os.path.join(_HERE, "libfoundationpose_amd_test.so")  # override: A/B of two builds (tools/)
 _TEST_LIB = None
 
 
