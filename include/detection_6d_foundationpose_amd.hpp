@@ -166,6 +166,10 @@ public:
                     target_name.c_str(), (int)refine_itr, out_pose_in_mesh.data()) == 0;
   }
 
+  // the C-ABI handle: options the reference does not have (fp_set_precision, fp_calibrate_fp8, fp_set_float_model, the hypothesis-
+  // shard entry points ...) are reached through it: `auto *amd = dynamic_cast<detection_6d::FoundationPoseAmd *>(model.get());`
+  fp_model *handle() { return h_; }
+
 private:
   fp_model *h_ = nullptr;
 };

@@ -96,6 +96,19 @@ public:
     return ok(fp_track(h_, rgb.data, depth.data, depth.rows, depth.cols, hyp_pose_in_mesh.data(), target_name.c_str(),
                        (int)refine_itr, out_pose_in_mesh.data()));
   }
+  // ---- options the reference does not have ----
+  // element type of both networks: FP_PREC_F16 (default, the reference's TensorRT --fp16), FP_PREC_BF16, FP_PREC_FP8 (after CalibrateFp8 / SetCalibration)
+  bool SetPrecision(int precision) { return ok(fp_set_precision(h_, precision)); }
+  int precision() const { return fp_get_precision(h_); }
+  // one f16 Register of a representative frame that records the per-activation maxima the static FP8 quantisation needs
+  bool CalibrateFp8(const ImageU8 &rgb, const ImageF32 &depth, const ImageU8 &mask, const std::string &target_name) {
+    return ok(fp_calibrate_fp8(h_, rgb.data, depth.data, mask.data, FP_HOST, depth.rows, depth.cols, target_name.c_str()));
+  }
+  bool GetCalibration(std::array<float, 32> &amax) const { return fp_get_calibration(h_, amax.data()) == 0; }
+  bool SetCalibration(const std::array<float, 32> &amax) { return ok(fp_set_calibration(h_, amax.data())); }
+  // float model of the rendering stage: FP_FLOAT_FMAD (default: contracted like the reference's nvcc build) or FP_FLOAT_SEPARATE
+  bool SetFloatModel(int model) { return ok(fp_set_float_model(h_, model)); }
+
   const std::string &last_error() const { return err_; }
   fp_model *handle() { return h_; }
 

@@ -29,6 +29,13 @@ int main() {
     fp_amd::Pose out;
     bool ok = fp.Register({rgb.data(),480,640,3}, {depth.data(),480,640}, {mask.data(),480,640,1}, "tri", out);
     std::printf("constructed; Register ok=%d err=%s\n", (int)ok, fp.last_error().c_str());
+    // the options the reference does not have (compile + call coverage; without weights they report errors, never crash)
+    std::array<float, 32> cal{};
+    bool p8 = fp.SetPrecision(FP_PREC_FP8);                       // uncalibrated: must be refused
+    bool gc = fp.GetCalibration(cal);
+    bool fm = fp.SetFloatModel(FP_FLOAT_SEPARATE) && fp.SetFloatModel(FP_FLOAT_FMAD);
+    std::printf("fp8 without calibration accepted=%d precision=%d get_calibration=%d float_model=%d\n", (int)p8, fp.precision(), (int)gc, (int)fm);
+    if (p8) return 3;
     return ok ? 2 : 0;   // no weights loaded -> Register must fail with a message
   } catch (const std::runtime_error &e) {
     std::printf("threw: %s\n", e.what());
