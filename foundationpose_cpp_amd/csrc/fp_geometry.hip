@@ -583,7 +583,7 @@ static void launch_raster_tall(hipStream_t s, const DeviceMesh &m, const PoseRec
 template <int MODE, bool FMAD>
 static void launch_raster_mode(hipStream_t s, const DeviceMesh &m, const PoseRec *recs, int N, const float4 *clip,
                                const float4 *attr, void *out, int32_t *tri_id_dbg, float *rast_dbg) {
-  int rows = g_strip_rows_override ? g_strip_rows_override : (N >= 100 ? 1080 : (N >= 64 ? 20 : 8));
+  int rows = g_strip_rows_override ? g_strip_rows_override : (N >= 100 ? 1080 : (N >= 48 ? 20 : 8));  // (tools/ab_raster_strips.py: 8-row strips win up to ~40 hypotheses)
   if (rows > 1000 && MODE != OUT_F32X6 && !tri_id_dbg && !rast_dbg) {
     if (rows == 1080) { launch_raster_tall<MODE, 80, FMAD>(s, m, recs, N, clip, attr, out); return; }
 #ifdef FP_TEST_HOOKS
