@@ -536,7 +536,7 @@ fp_model *fp_create(const fp_mesh *meshes, int n_meshes, const float K[9], const
     set_error("[FoundationPose] no HIP device available (this library has no CPU path)");
     return nullptr;
   }
-  std::unique_ptr<fp_model> m(new fp_model());
+  std::unique_ptr<fp_model, void (*)(fp_model *)> m(new fp_model(), fp_destroy);  // a failed construction releases what it had allocated
   std::memcpy(m->K, K, sizeof(float) * 9);
   if (max_h > 0) m->max_h = max_h;
   if (max_w > 0) m->max_w = max_w;
