@@ -302,8 +302,20 @@ def main():
         res.update(extras)
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(mesh, scene, states)
-        print(json.dumps(res), flush=True)
+    else:
+        res = None
     model.close()
+    # RCCL prints a version banner through C stdio (flushed only at exit when stdout is a pipe): every rank pushes its buffered
+    # output out, THEN rank 0 prints, so that the JSON line is the last line of the job's stdout
+    sys.stdout.flush()
+    try:
+        C.CDLL(None).fflush(None)
+    except OSError:
+        pass
+    if world > 1 or force_shard:
+        dist.barrier()
+    if res is not None:
+        print(json.dumps(res), flush=True)
     if world > 1 or force_shard:
         dist.destroy_process_group()
 
