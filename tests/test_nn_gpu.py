@@ -172,7 +172,7 @@ def test_stem_space_to_depth_equals_7x7_stride2():
     np.testing.assert_allclose(got, ref, rtol=2e-3, atol=2e-3)
 
 
-@pytest.mark.parametrize("B,T", [(2, 400), (1, 252), (1, 7), (3, 33), (1, 1)])
+@pytest.mark.parametrize("B,T", [(2, 400), (1, 252), (1, 7), (3, 33), (1, 1), (1, 2016), (2, 129)])
 def test_attention_matches_torch(B, T):
     rng = np.random.default_rng(3)
     qkv = (rng.normal(size=(B, T, 1536)) * 1.5).astype(np.float32)
