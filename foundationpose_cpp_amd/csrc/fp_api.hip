@@ -240,6 +240,7 @@ struct fp_model {
   bool calibrated = false;
   // pinned staging for hypothesis poses: Register returns from its asynchronous section while the H2D copy may still be
   // queued, so the source must outlive the call (a local std::vector did not: found by the two-model serving test)
+  float *track_io = nullptr, *track_io_dev = nullptr;  // host-pinned [hypothesis 16 | refined pose 16] of Track and its device address
   float *poses_pinned = nullptr;
   int poses_pinned_cap = 0;
   unsigned long long *digests = nullptr;  // [16] device, debug checkpoints (null = off)
@@ -326,13 +327,13 @@ static int check_frame_args(fp_model *m, int H, int W, const char *target_name, 
 // render + crop for N poses already in m->poses_dev; writes the fp16 network input (both halves) or fp32 blobs
 // n_crop: number of observed crops to produce (N, or 1 when every hypothesis shares the same translation)
 static int render_and_crop(fp_model *m, Target *t, int N, float crop_ratio, OutMode mode, void *out_a, void *out_b,
-                           int32_t *dbg_tri, float *dbg_rast, int n_crop = -1) {
+                           int32_t *dbg_tri, float *dbg_rast, int n_crop = -1, const float *poses_src = nullptr) {
   if (n_crop < 0) n_crop = N;
   hipStream_t s = m->stream;
   const size_t out_bytes = (mode == OUT_F32X6 ? 24.0 : 16.0) * FP_CROP_HW * FP_CROP_HW;  // both 2-byte modes: 16 B per pixel
   {
     ProfScope ps(&m->prof, s, "pose_setup");
-    launch_pose_setup(s, m->poses_dev, N, m->K, m->H, m->W, crop_ratio, t->mesh.diameter, m->recs);
+    launch_pose_setup(s, poses_src ? poses_src : m->poses_dev, N, m->K, m->H, m->W, crop_ratio, t->mesh.diameter, m->recs);
   }
   if (out_a) {
     {
@@ -608,6 +609,7 @@ void fp_destroy(fp_model *m) {
   dev_free(m->gath_feat); dev_free(m->gath_poses);
   if (m->result_pinned) (void)hipHostFree(m->result_pinned); dev_free(m->dbg_tri); dev_free(m->dbg_rast);
   if (m->poses_pinned) (void)hipHostFree(m->poses_pinned);
+  if (m->track_io) (void)hipHostFree(m->track_io);
   if (m->frame_pinned) (void)hipHostFree(m->frame_pinned);
   if (m->frame_dev) (void)hipFree(m->frame_dev);
   dev_free(m->grid_dev); dev_free(m->samp_state); dev_free(m->samp_vals); dev_free(m->mask_dev);
@@ -897,10 +899,11 @@ int fp_argmax(fp_model *m, const float *scores, int N, int *index_out) {
 // one refine iteration over m->poses_dev[0..N): RefinePreProcess + SyncInfer + RefinePostProcess, all on device
 // shared_b: all N poses have the same translation (fresh sampler output), so the observed crop -- which depends only on
 // the translation (foundationpose_render.cpp:59, foundationpose_render.cu:78-80) -- is computed and encoded once.
-static int refine_iteration(fp_model *m, Target *t, int N, bool shared_b) {
+// poses_in / result_out (Track): the poses are read from / the refined poses also written to host-pinned memory
+static int refine_iteration(fp_model *m, Target *t, int N, bool shared_b, const float *poses_in = nullptr, float *result_out = nullptr) {
   const size_t half = (size_t)N * FP_NN_IN_IMG_HALFS;
   if (render_and_crop(m, t, N, 1.2f /* refine_mode_crop_ratio_ foundationpose.cpp:87 */, nn_mode(m), m->nn_in,
-                      m->nn_in + half, nullptr, nullptr, shared_b ? 1 : N))
+                      m->nn_in + half, nullptr, nullptr, shared_b ? 1 : N, poses_in))
     return 1;
   checkpoint(m, 0, m->recs, (size_t)N * sizeof(PoseRec));
   checkpoint(m, 1, m->clip, (size_t)N * t->mesh.V * 16);
@@ -913,7 +916,7 @@ static int refine_iteration(fp_model *m, Target *t, int N, bool shared_b) {
   checkpoint(m, 6, m->rot_dev, (size_t)N * 12);
   {
     ProfScope ps(&m->prof, m->stream, "pose_update");
-    launch_pose_update(m->stream, m->poses_dev, m->trans_dev, m->rot_dev, N, t->mesh.diameter);
+    launch_pose_update(m->stream, m->poses_dev, m->trans_dev, m->rot_dev, N, t->mesh.diameter, poses_in, result_out);
   }
   checkpoint(m, 7, m->poses_dev, (size_t)N * 64);
   return 0;
@@ -1070,15 +1073,22 @@ int fp_track_ex(fp_model *m, const void *rgb, const void *depth, int memspace, i
   FP_CHECK(hyp_pose && out_pose, "[FoundationPose] Track: null pose");
   const bool graphable = m->use_graphs && !m->prof.on && !m->digests && !m->calibrating && refine_itr >= 1;
   if (upload_frame_async(m, rgb, depth, memspace, H, W)) return 1;
-  if (upload_poses(m, t, hyp_pose, 1)) return 1;
+  if (ensure_capacity(m, 1, (size_t)t->mesh.V)) return 1;
+  // the hypothesis goes in and the refined pose comes out through host-pinned memory the kernels address directly: no copy
+  // kernels around the graph (two of the ~50 launches of a Track)
+  if (!m->track_io) {
+    FP_HIP_OK(hipHostMalloc((void **)&m->track_io, 32 * sizeof(float), hipHostMallocDefault));
+    FP_HIP_OK(hipHostGetDevicePointer((void **)&m->track_io_dev, m->track_io, 0));
+  }
+  std::memcpy(m->track_io, hyp_pose, 64);
   if (run_graphed(m, m->tg, t, H, W, refine_itr, 1, graphable, [&]() {
         for (int it = 0; it < refine_itr; it++)
-          if (refine_iteration(m, t, 1, false)) return 1;
+          if (refine_iteration(m, t, 1, false, it == 0 ? m->track_io_dev : nullptr, it == refine_itr - 1 ? m->track_io_dev + 16 : nullptr)) return 1;
         return 0;
       }))
     return 1;
-  FP_HIP_OK(hipMemcpyAsync(out_pose, m->poses_dev, 64, hipMemcpyDeviceToHost, m->stream));
   FP_HIP_OK(hipStreamSynchronize(m->stream));
+  std::memcpy(out_pose, m->track_io + 16, 64);
   return 0;
 }
 

@@ -897,13 +897,13 @@ void launch_bilateral(hipStream_t s, const float *depth, float *out, int H, int 
 // pose update, arg-max, packing
 // ---------------------------------------------------------------------------------------------
 
-__global__ void pose_update_kernel(float *__restrict__ poses, const float *__restrict__ trans,
-                                   const float *__restrict__ rot, int N, float diameter) {
+__global__ void pose_update_kernel(float *poses, const float *__restrict__ trans, const float *__restrict__ rot, int N, float diameter,
+                                   const float *poses_in, float *extra_out) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
   const float NORM = 0.349065850398865f;
   float P[16];
-  for (int k = 0; k < 16; k++) P[k] = poses[(size_t)i * 16 + k];
+  for (int k = 0; k < 16; k++) P[k] = poses_in[(size_t)i * 16 + k];
   float td[3], v[3];
   for (int k = 0; k < 3; k++) { td[k] = trans[i * 3 + k] * (diameter / 2); v[k] = tanhf(rot[i * 3 + k]) * NORM; }
   float n2 = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
@@ -928,10 +928,14 @@ __global__ void pose_update_kernel(float *__restrict__ poses, const float *__res
       O[cc * 4 + r] = sacc;
     }
   for (int k = 0; k < 16; k++) poses[(size_t)i * 16 + k] = O[k];
+  if (extra_out)
+    for (int k = 0; k < 16; k++) extra_out[(size_t)i * 16 + k] = O[k];
 }
 
-void launch_pose_update(hipStream_t s, float *poses, const float *trans, const float *rot, int N, float diameter) {
-  hipLaunchKernelGGL(pose_update_kernel, dim3((N + 63) / 64), dim3(64), 0, s, poses, trans, rot, N, diameter);
+void launch_pose_update(hipStream_t s, float *poses, const float *trans, const float *rot, int N, float diameter, const float *poses_in,
+                        float *extra_out) {
+  hipLaunchKernelGGL(pose_update_kernel, dim3((N + 63) / 64), dim3(64), 0, s, poses, trans, rot, N, diameter, poses_in ? poses_in : poses,
+                     extra_out);
 }
 
 // index[0] = first maximum; when `poses` is given the winner's 4x4 is copied to best_pose so the host needs ONE read-back

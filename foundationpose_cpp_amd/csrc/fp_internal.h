@@ -128,7 +128,10 @@ void launch_depth_to_xyz(hipStream_t s, const float *depth, int H, int W, const 
 void launch_erode(hipStream_t s, const float *depth, float *out, int H, int W);
 void launch_bilateral(hipStream_t s, const float *depth, float *out, int H, int W);
 // device-side refine post process: poses updated in place from trans/rot [N,3] (foundationpose.cpp:360-406)
-void launch_pose_update(hipStream_t s, float *poses, const float *trans, const float *rot, int N, float diameter);
+// poses_in (optional): read the poses from there instead of `poses`; extra_out (optional): a second copy of the result (Track: both
+// are host-pinned, so no copy kernels run around the graph)
+void launch_pose_update(hipStream_t s, float *poses, const float *trans, const float *rot, int N, float diameter,
+                        const float *poses_in = nullptr, float *extra_out = nullptr);
 // first-max arg-max over scores[N] -> *index (foundationpose_decoder.cu:24-35)
 void launch_argmax(hipStream_t s, const float *scores, int N, int *index_dev, const float *poses = nullptr,
                    float *best_pose_dev = nullptr);
