@@ -1073,6 +1073,11 @@ int fp_track_ex(fp_model *m, const void *rgb, const void *depth, int memspace, i
   FP_CHECK(hyp_pose && out_pose, "[FoundationPose] Track: null pose");
   const bool graphable = m->use_graphs && !m->prof.on && !m->digests && !m->calibrating && refine_itr >= 1;
   if (upload_frame_async(m, rgb, depth, memspace, H, W)) return 1;
+  if (refine_itr <= 0) {  // no refinement requested: the hypothesis is the answer (the reference's loop runs zero times)
+    FP_HIP_OK(hipStreamSynchronize(m->stream));
+    std::memcpy(out_pose, hyp_pose, 64);
+    return 0;
+  }
   if (ensure_capacity(m, 1, (size_t)t->mesh.V)) return 1;
   // the hypothesis goes in and the refined pose comes out through host-pinned memory the kernels address directly: no copy
   // kernels around the graph (two of the ~50 launches of a Track)

@@ -263,6 +263,15 @@ def test_track_end_to_end(model, nets, syn_mesh, syn_scene):
     # reference error behaviour: unknown target -> False
     ok, _ = model.Track(syn_scene.rgb, syn_scene.depth, hyp, "nope")
     assert not ok and "target_name" in model.last_error
+    # zero refine iterations: the reference's loop does not run and the hypothesis comes back unchanged
+    ok, same = model.Track(syn_scene.rgb, syn_scene.depth, hyp, syn_mesh.name, refine_itr=0)
+    assert ok and np.array_equal(same, hyp.astype(np.float32))
+    # two iterations == two single-iteration calls chained (the pose travels through host-pinned memory in both directions)
+    ok, p1 = model.Track(syn_scene.rgb, syn_scene.depth, hyp, syn_mesh.name)
+    ok2, p2 = model.Track(syn_scene.rgb, syn_scene.depth, p1, syn_mesh.name)
+    ok3, p12 = model.Track(syn_scene.rgb, syn_scene.depth, hyp, syn_mesh.name, refine_itr=2)
+    assert ok and ok2 and ok3
+    np.testing.assert_allclose(p12, p2, atol=1e-6)
 
 
 def test_register_end_to_end_252(model, nets, syn_mesh, syn_scene):
