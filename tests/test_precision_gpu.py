@@ -243,6 +243,50 @@ def test_track_bf16_refine_net(nets, syn_mesh, syn_scene):
         m.close()
 
 
+def test_track_and_small_batches_fp8(nets, syn_mesh, syn_scene):
+    """The small-batch FP8 schedules (split-K slices on the deep-ring kernel, unsplit short-K layers, the FP8 -> f16 boundary layer
+    through the split-K reduce with the positional table) that Track and small Register slices take: Track in FP8 against the fp32
+    oracle pipeline and the f16 path; calibration survives a get / set round trip into a fresh model."""
+    m = FoundationPose(syn_mesh, syn.intrinsics(), nets[0], nets[1])
+    m2 = FoundationPose(syn_mesh, syn.intrinsics(), nets[0], nets[1])
+    try:
+        hyp = syn.perturb_pose(syn_scene.gt_pose)
+        ok, p16 = m.Track(syn_scene.rgb, syn_scene.depth, hyp, syn_mesh.name)
+        assert ok, m.last_error
+        m.calibrate_fp8(syn_scene.rgb, syn_scene.depth, syn_scene.mask, syn_mesh.name)
+        cal = m.get_calibration()
+        print("calibration:", np.round(cal, 3))
+        assert cal.shape == (32,) and np.all(cal[:14] > 0) and np.all(cal[16:30] > 0)
+        m.set_precision(FP_PREC_FP8)
+        poses = []
+        for _ in range(3):      # eager, capture, replay
+            ok, p8 = m.Track(syn_scene.rgb, syn_scene.depth, hyp, syn_mesh.name)
+            assert ok, m.last_error
+            poses.append(p8)
+        assert np.array_equal(poses[0], poses[1]) and np.array_equal(poses[1], poses[2])
+        ref = _oracle_track(nets, syn_mesh, syn_scene, hyp)
+        for other in (ref, p16):
+            ang, dist = _pose_err(poses[0], other)
+            assert ang < 1.0 and dist < 1e-3, (ang, dist)      # the north-star bar; FP8 noise measured far inside (printed)
+        print("FP8 Track vs oracle / f16:", _pose_err(poses[0], ref), _pose_err(poses[0], p16))
+        # a fresh model with the stored calibration reproduces the FP8 result bit for bit
+        m2.set_calibration(cal)
+        m2.set_precision(FP_PREC_FP8)
+        ok, q8 = m2.Track(syn_scene.rgb, syn_scene.depth, hyp, syn_mesh.name)
+        assert ok and np.array_equal(q8, poses[0])
+        # a 42-hypothesis Register (one in-plane step) in FP8: runs the mid-sized schedules end to end
+        m.set_inplane_steps(1)
+        ok, r8 = m.Register(syn_scene.rgb, syn_scene.depth, syn_scene.mask, syn_mesh.name)
+        assert ok, m.last_error
+        m.set_precision(FP_PREC_F16)
+        ok, r16 = m.Register(syn_scene.rgb, syn_scene.depth, syn_scene.mask, syn_mesh.name)
+        assert ok
+        print("FP8 vs f16 Register (42 hypotheses) pose:", _pose_err(r8, r16))
+    finally:
+        m.close()
+        m2.close()
+
+
 def test_fp8_needs_calibration(nets, syn_mesh):
     m = FoundationPose(syn_mesh, syn.intrinsics(), nets[0], nets[1])
     try:
