@@ -2338,6 +2338,206 @@ __global__ __launch_bounds__(NW * 64, 2) void attention32_kernel(const typename 
   }
 }
 
+// -------------------------------------------------------------------------------------------------
+// attention32_skv_kernel [r2]: the same arithmetic for SMALL grids (Track: 2 sequences; the score-net's cross attention: one),
+// where a workgroup of attention32_kernel is a latency chain of T/32 key blocks on a mostly idle chip.  One workgroup per 32
+// query rows; its four waves split the KEY blocks (wave w takes blocks w, w+4, ...) and run independently -- private LDS
+// double buffers filled by LDS-DMA (K rows swizzled on the source side, V in the transpose-read sub-tile layout), no workgroup
+// barrier in the loop -- then merge their partial (max, sum, O) through LDS: chain length T/128 blocks, 3.25x more workgroups.
+// -------------------------------------------------------------------------------------------------
+template <bool REMAP, int DT>
+__global__ __launch_bounds__(256, 2) void attention32_skv_kernel(const typename ElemT<DT>::t *__restrict__ qkv, typename ElemT<DT>::t *__restrict__ out, int T, int nq,
+                                                                 int tstride, int qkv_ld) {
+  using E = typename ElemT<DT>::t;
+  using E8 = typename ElemT<DT>::v8;
+  constexpr int KB = 32 * 256, VSUB = 1056, BUF = KB + 8 * VSUB, WREG = 2 * BUF;  // per wave: two tile buffers (33 280 B)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_dyn[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int logical;
+  {
+    const int nblk = gridDim.x, bi = blockIdx.x;
+    const int xcd = bi & 7, within = bi >> 3, q = nblk >> 3, r = nblk & 7;
+    logical = REMAP ? (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within : bi;
+  }
+  const int qt = logical % nq, h = (logical / nq) % HEADS, b = logical / (nq * HEADS);
+  const int g = lane >> 4, li = lane & 15;
+  const size_t rowstride = (size_t)qkv_ld;
+  const E *base = qkv + (size_t)b * tstride * rowstride + h * HDIM;
+  const int q0 = qt * 32;
+  unsigned char *wbuf = smem_dyn + wave * WREG;
+  const unsigned wlds = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)wbuf;
+
+  i4 qf[2][4];
+#pragma unroll
+  for (int qi = 0; qi < 2; qi++) {
+    const int q_ld = min(q0 + qi * 16 + li, T - 1);
+#pragma unroll
+    for (int ds = 0; ds < 4; ds++) qf[qi][ds] = *reinterpret_cast<const i4 *>(base + (size_t)q_ld * rowstride + ds * 32 + g * 8);
+  }
+  f4 o[8][2];
+#pragma unroll
+  for (int dt = 0; dt < 8; dt++)
+#pragma unroll
+    for (int qi = 0; qi < 2; qi++) o[dt][qi] = (f4){0.f, 0.f, 0.f, 0.f};
+  float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
+  const float sl2e = 0.08838834764831845f * 1.4426950408889634f;
+
+  const int nkb = (T + 31) / 32;
+  // one wave stages a whole tile: 8 LDS-DMA instructions for K (4 keys x 256 B each; the lane at LDS slot s of key k fetches
+  // chunk s ^ (k & 15)) and 8 for V (one [32 keys][16 d] sub-tile each: lane -> key lane>>1, 8-d half lane&1)
+  auto issue_tile = [&](int kb, int bufi) {
+    const unsigned dst = __builtin_amdgcn_readfirstlane(wlds + bufi * BUF);
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const int key = i * 4 + (lane >> 4);
+      const int row = min(kb * 32 + key, T - 1);
+      const E *src = base + (size_t)row * rowstride + EMBED + (((lane & 15) ^ (key & 15)) * 8);
+      glds16_asm(src, dst + i * 1024);
+    }
+#pragma unroll
+    for (int dt = 0; dt < 8; dt++) {
+      const int row = min(kb * 32 + (lane >> 1), T - 1);
+      const E *src = base + (size_t)row * rowstride + 2 * EMBED + dt * 16 + (lane & 1) * 8;
+      glds16_asm(src, dst + KB + dt * VSUB);
+    }
+  };
+  unsigned koff[4];
+#pragma unroll
+  for (int ds = 0; ds < 4; ds++) koff[ds] = (unsigned)(li * 256 + (((ds * 4 + g) ^ li) << 4));
+  const unsigned voff = (unsigned)((g * 4 + (li >> 2)) * 32 + (li & 3) * 8);
+
+  int bufi = 0;
+  if (wave < nkb) issue_tile(wave, 0);
+  for (int kb = wave; kb < nkb; kb += 4, bufi ^= 1) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's tile kb has landed (only this wave reads it)
+    if (kb + 4 < nkb) issue_tile(kb + 4, bufi ^ 1);    // (its last reads finished an iteration ago: lgkmcnt(0) below)
+    f4 st[2][2];
+#pragma unroll
+    for (int qi = 0; qi < 2; qi++)
+#pragma unroll
+      for (int kt = 0; kt < 2; kt++) st[qi][kt] = (f4){0.f, 0.f, 0.f, 0.f};
+    i4 kf[2][4];
+    const unsigned kbase = wlds + (unsigned)(bufi * BUF);
+#pragma unroll
+    for (int ds = 0; ds < 4; ds++) {
+      asm volatile("ds_read_b128 %0, %1" : "=v"(kf[0][ds]) : "v"(kbase + koff[ds]));
+      asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(kf[1][ds]) : "v"(kbase + koff[ds]));
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int kt = 0; kt < 2; kt++)
+#pragma unroll
+      for (int ds = 0; ds < 4; ds++)
+#pragma unroll
+        for (int qi = 0; qi < 2; qi++) st[qi][kt] = mfma32<DT>(kf[kt][ds], qf[qi][ds], st[qi][kt]);
+    i2 vlo[8], vhi[8];
+    {
+      const unsigned vbase = kbase + KB + voff;
+#pragma unroll
+      for (int dt = 0; dt < 8; dt++) {
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(vlo[dt]) : "v"(vbase), "n"(dt * VSUB));
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(vhi[dt]) : "v"(vbase), "n"(dt * VSUB + 512));
+      }
+    }
+    i4 pf[2];
+#pragma unroll
+    for (int qi = 0; qi < 2; qi++) {
+      if (kb == nkb - 1 && (T & 31)) {
+#pragma unroll
+        for (int kt = 0; kt < 2; kt++)
+#pragma unroll
+          for (int r = 0; r < 4; r++)
+            if (kb * 32 + kt * 16 + g * 4 + r >= T) st[qi][kt][r] = -INFINITY;
+      }
+      float mx = vmax_f32(vmax_f32(vmax_f32(st[qi][0][0], st[qi][0][1]), vmax_f32(st[qi][0][2], st[qi][0][3])),
+                          vmax_f32(vmax_f32(st[qi][1][0], st[qi][1][1]), vmax_f32(st[qi][1][2], st[qi][1][3])));
+      mx = rows_max(mx);
+      const float m_new = vmax_f32(m_run[qi], mx);
+      const float mc = m_new * sl2e;
+      const float alpha = __builtin_amdgcn_exp2f(m_run[qi] * sl2e - mc);
+      float psum = 0.f;
+      E8 pv8;
+#pragma unroll
+      for (int kt = 0; kt < 2; kt++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(st[qi][kt][r], sl2e, -mc));
+          psum += pv;
+          pv8[kt * 4 + r] = (E)pv;
+        }
+      pf[qi] = __builtin_bit_cast(i4, pv8);
+      psum = rows_sum(psum);
+      l_run[qi] = l_run[qi] * alpha + psum;
+      m_run[qi] = m_new;
+      if (__any(alpha != 1.0f)) {
+#pragma unroll
+        for (int dt = 0; dt < 8; dt++)
+#pragma unroll
+          for (int r = 0; r < 4; r++) o[dt][qi][r] *= alpha;
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int dt = 0; dt < 8; dt++) {
+      const i4 vf = (i4){vlo[dt][0], vlo[dt][1], vhi[dt][0], vhi[dt][1]};
+#pragma unroll
+      for (int qi = 0; qi < 2; qi++) o[dt][qi] = mfma32<DT>(vf, pf[qi], o[dt][qi]);
+    }
+  }
+  // ---- merge the four partial results: O = sum_v O_v 2^((m_v - M) c) / sum_v l_v 2^((m_v - M) c)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  float *po = reinterpret_cast<float *>(wbuf);                  // [32 q][128 d] f32, 16-byte slots XOR-swizzled by the row
+  float *pml = reinterpret_cast<float *>(wbuf + 32 * 512);      // [2][32]: m, l
+#pragma unroll
+  for (int qi = 0; qi < 2; qi++) {
+    const int q = qi * 16 + li;
+#pragma unroll
+    for (int dt = 0; dt < 8; dt++)
+      *reinterpret_cast<f4 *>(reinterpret_cast<unsigned char *>(po) + q * 512 + (((dt * 4 + g) ^ (q & 31)) << 4)) = o[dt][qi];
+    if (g == 0) { pml[q] = m_run[qi]; pml[32 + q] = l_run[qi]; }
+  }
+  __syncthreads();
+  {
+    const int r8 = lane >> 3, c = lane & 7;     // this wave merges query rows wave*8 .. wave*8+7; a lane: one row, 16 d
+    const int q = wave * 8 + r8;
+    float mv[4], lv[4], M = -INFINITY;
+#pragma unroll
+    for (int v = 0; v < 4; v++) {
+      const float *ml = reinterpret_cast<const float *>(smem_dyn + v * WREG + 32 * 512);
+      mv[v] = ml[q]; lv[v] = ml[32 + q];
+      M = fmaxf(M, mv[v]);
+    }
+    float L = 0.f, acc[16];
+#pragma unroll
+    for (int e = 0; e < 16; e++) acc[e] = 0.f;
+#pragma unroll
+    for (int v = 0; v < 4; v++) {
+      const float w = __builtin_amdgcn_exp2f((mv[v] - M) * sl2e);   // a wave without key blocks: m = -inf -> weight 0
+      L += lv[v] * w;
+      const unsigned char *pv = smem_dyn + v * WREG + q * 512;
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const f4 x = *reinterpret_cast<const f4 *>(pv + (((c * 4 + j) ^ (q & 31)) << 4));
+#pragma unroll
+        for (int e = 0; e < 4; e++) acc[j * 4 + e] += x[e] * w;
+      }
+    }
+    const float inv = 1.0f / L;
+    const int row = q0 + q;
+    if (row < T) {
+      E8 o0, o1;
+#pragma unroll
+      for (int e = 0; e < 8; e++) { o0[e] = (E)(acc[e] * inv); o1[e] = (E)(acc[8 + e] * inv); }
+      E *dst = out + ((size_t)b * tstride + row) * EMBED + h * HDIM + c * 16;
+      *reinterpret_cast<E8 *>(dst) = o0;
+      *reinterpret_cast<E8 *>(dst + 8) = o1;
+    }
+  }
+}
+
 // =================================================================================================
 // small kernels
 // =================================================================================================
@@ -3084,6 +3284,7 @@ FP_HOOK g_rem_splitk = 0;      // split-K for left-over rows.  Measured -0.1 ms 
 FP_HOOK g_splitk_target = 128; // workgroups a split-K launch aims for (tools/ab_track.py: 96-128 best, 256 is 6 % slower)
 FP_HOOK g_splitk_min_kt = 9;    // layers with fewer 128-byte K-steps never split
 FP_HOOK g_splitk_deep = 1;      // split-K slices of at least 4 K-steps on conv_deep_kernel<128> (0 = conv_igemm_kernel<128>)
+FP_HOOK g_att_skv = 1;          // small attention grids on attention32_skv_kernel (keys split over the waves of a workgroup)
 FP_HOOK g_small_deep = 18;     // small problems (Track): conv_deep_kernel<64> over ALL K-steps instead of split-K + reduce when K has at most this many 128-byte steps
 FP_HOOK g_att_variant = 1;     // 1 = attention32_kernel (8 = without the XCD remap); round-1 kernel: 2 remap + 16-B stores, 3 no XCD remap, 5 remap + 2-B stores, 7 neither
 
@@ -3485,6 +3686,11 @@ static void launch_attention(const Ctx &c, const void *qkv, void *out, int B, in
   }
 #endif
   const int nq = (T + 127) / 128;
+  if (g_att_skv && nq * HEADS * B <= 64 && T > 32) {  // a small grid of long latency chains: split the keys over the waves instead
+    const int nq32 = (T + 31) / 32;
+    FP_LAUNCH((attention32_skv_kernel<true, DT>), dim3((unsigned)(nq32 * HEADS * B)), dim3(256), 4 * 2 * (32 * 256 + 8 * 1056), c.s, q, o, T, nq32, tstride, ld);
+    return;
+  }
   hipLaunchKernelGGL((attention32_kernel<true, DT>), dim3((unsigned)(nq * HEADS * B)), dim3(256), 0, c.s, q, o, T, nq, tstride, ld);
 }
 static int run_attention(const Ctx &c, int dt, const void *qkv, void *out, int B, int T, int tstride = 0, int ld = 3 * EMBED) {
@@ -3828,6 +4034,7 @@ void fpt_set_gemm_kernel(int v) { fp::g_gemm_kernel = v; }
 void fpt_set_rem_kernel(int v) { fp::g_rem_kernel = v; }
 void fpt_set_rem_small(int v) { fp::g_rem_small = v; }
 void fpt_set_small_deep(int v) { fp::g_small_deep = v; }
+void fpt_set_att_skv(int v) { fp::g_att_skv = v; }
 void fpt_set_splitk_deep(int v) { fp::g_splitk_deep = v; }
 void fpt_set_splitk_min_kt(int v) { fp::g_splitk_min_kt = v; }
 void fpt_set_raster_strip_rows(int r) { fp::set_raster_strip_rows(r); }
