@@ -430,15 +430,15 @@ __global__ __launch_bounds__(NT) void raster_shade_kernel(
   for (int i = tid; i < STRIP_ROWS * CROP; i += NT) zbuf[i] = clear_key;
   __syncthreads();
 
-  for (int f = tid; f < F; f += NT) {
-    int i0 = faces[f * 3], i1 = faces[f * 3 + 1], i2 = faces[f * 3 + 2];
-    if ((unsigned)i0 >= (unsigned)V || (unsigned)i1 >= (unsigned)V || (unsigned)i2 >= (unsigned)V) continue;
-    float4 v0 = clip[i0], v1 = clip[i1], v2 = clip[i2];
+  // triangle loop, software-pipelined two deep: a thread's iteration is a chain index load -> three vertex gathers -> setup, and
+  // with F / NT = 5 iterations per thread at N = 1 (Track) those latencies added up; now the vertices of triangle k+1 and the
+  // indices of triangle k+2 are in flight while triangle k is set up and rasterised
+  auto process = [&](int f, const float4 &v0, const float4 &v1, const float4 &v2) {
     if ((v0.w < fabsf(v0.x)) | (v0.w < fabsf(v0.y)) | (v0.w < fabsf(v0.z))) {
       if (((v0.w < +v0.x) & (v1.w < +v1.x) & (v2.w < +v2.x)) | ((v0.w < -v0.x) & (v1.w < -v1.x) & (v2.w < -v2.x)) |
           ((v0.w < +v0.y) & (v1.w < +v1.y) & (v2.w < +v2.y)) | ((v0.w < -v0.y) & (v1.w < -v1.y) & (v2.w < -v2.y)) |
           ((v0.w < +v0.z) & (v1.w < +v1.z) & (v2.w < +v2.z)) | ((v0.w < -v0.z) & (v1.w < -v1.z) & (v2.w < -v2.z)))
-        continue;
+        return;
     }
     bool fast = false;
     if ((v0.w >= fabsf(v0.z)) & (v1.w >= fabsf(v1.z)) & (v2.w >= fabsf(v2.z))) {
@@ -454,6 +454,26 @@ __global__ __launch_bounds__(NT) void raster_shade_kernel(
     }
     if (fast) raster_one<STRIP_ROWS>(v0, v1, v2, (unsigned)(f + 1), row0, zbuf);
     else raster_clipped<STRIP_ROWS, FMAD>(v0, v1, v2, (unsigned)(f + 1), row0, zbuf);
+  };
+  struct Tri { int i0, i1, i2; };
+  auto load_idx = [&](int f) {
+    Tri t{-1, -1, -1};
+    if (f < F) { t.i0 = faces[f * 3]; t.i1 = faces[f * 3 + 1]; t.i2 = faces[f * 3 + 2]; }
+    return t;
+  };
+  auto valid = [&](const Tri &t) { return (unsigned)t.i0 < (unsigned)V && (unsigned)t.i1 < (unsigned)V && (unsigned)t.i2 < (unsigned)V; };
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  {
+    Tri cur = load_idx(tid), nxt = load_idx(tid + NT);
+    bool ok = valid(cur);
+    float4 v0 = ok ? clip[cur.i0] : zero4, v1 = ok ? clip[cur.i1] : zero4, v2 = ok ? clip[cur.i2] : zero4;
+    for (int f = tid; f < F; f += NT) {
+      const bool okn = valid(nxt);
+      const float4 w0 = okn ? clip[nxt.i0] : zero4, w1 = okn ? clip[nxt.i1] : zero4, w2 = okn ? clip[nxt.i2] : zero4;
+      const Tri nn = load_idx(f + 2 * NT);
+      if (ok) process(f, v0, v1, v2);
+      v0 = w0; v1 = w1; v2 = w2; ok = okn; nxt = nn;
+    }
   }
   __syncthreads();
 
