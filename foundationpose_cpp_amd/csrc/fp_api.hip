@@ -331,14 +331,15 @@ static int render_and_crop(fp_model *m, Target *t, int N, float crop_ratio, OutM
   if (n_crop < 0) n_crop = N;
   hipStream_t s = m->stream;
   const size_t out_bytes = (mode == OUT_F32X6 ? 24.0 : 16.0) * FP_CROP_HW * FP_CROP_HW;  // both 2-byte modes: 16 B per pixel
-  {
+  if (!out_a) {
     ProfScope ps(&m->prof, s, "pose_setup");
     launch_pose_setup(s, poses_src ? poses_src : m->poses_dev, N, m->K, m->H, m->W, crop_ratio, t->mesh.diameter, m->recs);
   }
   if (out_a) {
-    {
+    {   // pose set-up (crop window, bounding box, projection) is computed inside the vertex kernel: one launch less per render
       ProfScope ps(&m->prof, s, "vertex", 0, (double)N * t->mesh.V * 32.0 + t->mesh.V * 24.0);
-      launch_vertex(s, t->mesh, m->recs, N, m->clip, m->attr, m->fmad);
+      launch_setup_vertex(s, t->mesh, poses_src ? poses_src : m->poses_dev, N, m->K, m->H, m->W, crop_ratio, t->mesh.diameter, m->recs,
+                          m->clip, m->attr, m->fmad);
     }
     ProfScope ps(&m->prof, s, "raster_shade", 0, (double)N * (out_bytes + t->mesh.V * 32.0 + t->mesh.F * 12.0));
     launch_raster_shade(s, t->mesh, m->recs, N, m->clip, m->attr, mode, out_a, dbg_tri, dbg_rast, m->fmad);

@@ -96,11 +96,10 @@ __device__ __forceinline__ void mat4_mul(const float *A, const float *B, float *
     }
 }
 
-__global__ void pose_setup_kernel(const float *__restrict__ poses, int N, K9 K, int img_h, int img_w,
-                                  float crop_ratio, float diameter, PoseRec *__restrict__ recs) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= N) return;
-  PoseRec rec;
+// the per-hypothesis record (crop window, bounding box, projection): one function for the stand-alone kernel and for the vertex
+// kernel that computes it in place (one launch less per render)
+__device__ __forceinline__ void make_pose_rec(const float *__restrict__ poses, int i, const K9 &K, int img_h, int img_w, float crop_ratio,
+                                              float diameter, PoseRec &rec) {
   for (int k = 0; k < 16; k++) rec.pose[k] = poses[(size_t)i * 16 + k];
   // crop window
   float r = diameter * crop_ratio / 2;
@@ -162,6 +161,14 @@ __global__ void pose_setup_kernel(const float *__restrict__ poses, int N, K9 K, 
   float GP[16];
   mat4_mul(GL, rec.pose, GP);
   mat4_mul(P, GP, rec.M);
+}
+
+__global__ void pose_setup_kernel(const float *__restrict__ poses, int N, K9 K, int img_h, int img_w,
+                                  float crop_ratio, float diameter, PoseRec *__restrict__ recs) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  PoseRec rec;
+  make_pose_rec(poses, i, K, img_h, img_w, crop_ratio, diameter, rec);
   recs[i] = rec;
 }
 
@@ -177,18 +184,30 @@ void launch_pose_setup(hipStream_t s, const float *poses_dev, int N, const float
 // vertex stage: clip position, camera-space point, per-vertex Lambert term
 // ---------------------------------------------------------------------------------------------
 
-// The per-hypothesis record is read through uniform (scalar) loads.
-template <bool FMAD>
+// The per-hypothesis record is read through uniform (scalar) loads -- or, SETUP, computed here by every thread from the pose (the
+// same function as pose_setup_kernel: identical values) and written out once per hypothesis for the rasteriser and the crop kernel.
+struct PoseSetupArgs {
+  const float *poses;
+  K9 K;
+  int img_h, img_w;
+  float crop_ratio, diameter;
+};
+template <bool FMAD, bool SETUP>
 __global__ void vertex_kernel(const float *__restrict__ verts, const float *__restrict__ normals, int V,
-                              const PoseRec *__restrict__ recs, float4 *__restrict__ clip, float4 *__restrict__ attr,
-                              float4 *__restrict__ dbg) {
+                              PoseRec *__restrict__ recs, float4 *__restrict__ clip, float4 *__restrict__ attr,
+                              float4 *__restrict__ dbg, const PoseSetupArgs sa) {
   const int v = blockIdx.x * blockDim.x + threadIdx.x;
   const int n = blockIdx.y;
 #ifdef FP_TEST_HOOKS
   const unsigned long long t_begin = dbg ? wall_clock64() : 0ull;
 #endif
   if (v >= V) return;
-  const PoseRec &rec = recs[n];
+  PoseRec own;
+  if constexpr (SETUP) {
+    make_pose_rec(sa.poses, n, sa.K, sa.img_h, sa.img_w, sa.crop_ratio, sa.diameter, own);
+    if (v == 0) recs[n] = own;
+  }
+  const PoseRec &rec = SETUP ? own : recs[n];
   const float *M = rec.M, *pose = rec.pose;
   float x = verts[v * 3], y = verts[v * 3 + 1], z = verts[v * 3 + 2];
   float tx = dot3<FMAD>(M[0], x, M[4], y, M[8], z) + M[12];
@@ -233,8 +252,25 @@ void launch_vertex(hipStream_t s, const DeviceMesh &m, const PoseRec *recs, int 
 #ifdef FP_TEST_HOOKS
   if (g_vertex_dbg && N == 64) dbg = g_vertex_dbg;
 #endif
-  if (fmad) hipLaunchKernelGGL(vertex_kernel<true>, dim3((m.V + 255) / 256, N), dim3(256), 0, s, m.verts, m.normals, m.V, recs, clip, attr, dbg);
-  else hipLaunchKernelGGL(vertex_kernel<false>, dim3((m.V + 255) / 256, N), dim3(256), 0, s, m.verts, m.normals, m.V, recs, clip, attr, dbg);
+  const PoseSetupArgs none{};
+  PoseRec *r = const_cast<PoseRec *>(recs);
+  if (fmad) hipLaunchKernelGGL((vertex_kernel<true, false>), dim3((m.V + 255) / 256, N), dim3(256), 0, s, m.verts, m.normals, m.V, r, clip, attr, dbg, none);
+  else hipLaunchKernelGGL((vertex_kernel<false, false>), dim3((m.V + 255) / 256, N), dim3(256), 0, s, m.verts, m.normals, m.V, r, clip, attr, dbg, none);
+}
+
+// pose set-up + vertex stage in one launch: recs[0..N) are WRITTEN here (by the thread of vertex 0 of each hypothesis)
+void launch_setup_vertex(hipStream_t s, const DeviceMesh &m, const float *poses_dev, int N, const float *K9_host, int img_h, int img_w,
+                         float crop_ratio, float diameter, PoseRec *recs, float4 *clip, float4 *attr, bool fmad) {
+  PoseSetupArgs sa;
+  sa.poses = poses_dev;
+  for (int i = 0; i < 9; i++) sa.K.k[i] = K9_host[i];
+  sa.img_h = img_h; sa.img_w = img_w; sa.crop_ratio = crop_ratio; sa.diameter = diameter;
+  float4 *dbg = nullptr;
+#ifdef FP_TEST_HOOKS
+  if (g_vertex_dbg && N == 64) dbg = g_vertex_dbg;
+#endif
+  if (fmad) hipLaunchKernelGGL((vertex_kernel<true, true>), dim3((m.V + 255) / 256, N), dim3(256), 0, s, m.verts, m.normals, m.V, recs, clip, attr, dbg, sa);
+  else hipLaunchKernelGGL((vertex_kernel<false, true>), dim3((m.V + 255) / 256, N), dim3(256), 0, s, m.verts, m.normals, m.V, recs, clip, attr, dbg, sa);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -111,6 +111,9 @@ extern float4 *g_vertex_dbg;  // race hunt: per-vertex intermediates (null = off
 #endif
 // fmad: float model of the vertex stage / shader / interpolator / texture unit (fp_geometry.hip "float model")
 void launch_vertex(hipStream_t s, const DeviceMesh &m, const PoseRec *recs, int N, float4 *clip, float4 *attr, bool fmad);
+// the two above in ONE launch (recs is an output)
+void launch_setup_vertex(hipStream_t s, const DeviceMesh &m, const float *poses_dev, int N, const float *K9_host, int img_h, int img_w,
+                         float crop_ratio, float diameter, PoseRec *recs, float4 *clip, float4 *attr, bool fmad);
 void launch_raster_shade(hipStream_t s, const DeviceMesh &m, const PoseRec *recs, int N, const float4 *clip,
                          const float4 *attr, OutMode mode, void *out, int32_t *tri_id_dbg, float *rast_dbg, bool fmad);
 #ifdef FP_TEST_HOOKS
