@@ -191,6 +191,7 @@ struct fp_model {
   FrameRef *frame_dev = nullptr, *frame_pinned = nullptr;  // what kernels inside graphs read the frame through
   FrameRef frame_pub = {nullptr, nullptr};                 // last published value
   unsigned frame_pub_count = 0;
+  bool frame_partial = false;  // the model's copy of a host frame holds only the rows Track needed (stage operators refuse it)
   const uint8_t *rgb = nullptr;   // device
   const float *depth = nullptr;   // device
   float *erode = nullptr, *bilat = nullptr, *xyz = nullptr;
@@ -363,7 +364,7 @@ static void checkpoint(fp_model *m, int slot, const void *buf, size_t bytes) {
   if (e != hipSuccess) std::fprintf(stderr, "checkpoint %d (%p, %zu B): %s\n", slot, buf, bytes, hipGetErrorString(e));
 }
 
-static int upload_frame_async(fp_model *m, const void *rgb, const void *depth, int memspace, int H, int W);
+static int upload_frame_async(fp_model *m, const void *rgb, const void *depth, int memspace, int H, int W, int row0 = 0, int row1 = -1);
 static int set_rotation_grid(fp_model *m, int steps);
 
 static void drop_graph(fp_model::GraphSlot &g) {
@@ -638,7 +639,9 @@ int fp_synchronize(fp_model *m) {
 }
 
 // asynchronous: the caller of this helper synchronises m->stream before the host frame can go away
-static int upload_frame_async(fp_model *m, const void *rgb, const void *depth, int memspace, int H, int W) {
+// row0 / row1 (host frames): only rows [row0, row1) are needed by the caller (Track: the observed-crop window) -- the rest of the
+// model's copy keeps whatever an earlier frame left there
+static int upload_frame_async(fp_model *m, const void *rgb, const void *depth, int memspace, int H, int W, int row0, int row1) {
   Target *t = nullptr;
   if (check_frame_args(m, H, W, nullptr, &t)) return 1;
   FP_CHECK(rgb && depth, "[FoundationPose] Got INVALID rgb/depth ptr");
@@ -655,10 +658,17 @@ static int upload_frame_async(fp_model *m, const void *rgb, const void *depth, i
   if (memspace == FP_DEVICE) {
     m->rgb = (const uint8_t *)rgb;
     m->depth = (const float *)depth;
+    m->frame_partial = false;
   } else {
-    ProfScope ps(&m->prof, m->stream, "h2d_frame", 0, (double)px * 7);
-    FP_HIP_OK(hipMemcpyAsync(m->rgb_own, rgb, px * 3, hipMemcpyHostToDevice, m->stream));
-    FP_HIP_OK(hipMemcpyAsync(m->depth_own, depth, px * 4, hipMemcpyHostToDevice, m->stream));
+    if (row1 < 0 || row1 > H) row1 = H;
+    row0 = std::max(0, std::min(row0, row1));
+    m->frame_partial = row0 > 0 || row1 < H;
+    const size_t o = (size_t)row0 * W, n = (size_t)(row1 - row0) * W;
+    ProfScope ps(&m->prof, m->stream, "h2d_frame", 0, (double)n * 7);
+    if (n) {
+      FP_HIP_OK(hipMemcpyAsync(m->rgb_own + o * 3, (const uint8_t *)rgb + o * 3, n * 3, hipMemcpyHostToDevice, m->stream));
+      FP_HIP_OK(hipMemcpyAsync(m->depth_own + o, (const float *)depth + o, n * 4, hipMemcpyHostToDevice, m->stream));
+    }
     m->rgb = m->rgb_own;
     m->depth = m->depth_own;
   }
@@ -680,6 +690,7 @@ int fp_upload_frame(fp_model *m, const void *rgb, const void *depth, int memspac
 
 int fp_get_xyz_map(fp_model *m, float *xyz_host) {
   FP_CHECK(m && m->depth && xyz_host, "[FoundationPose] fp_get_xyz_map: no frame uploaded");
+  FP_CHECK(!m->frame_partial, "[FoundationPose] the last call (Track from a host frame) uploaded only its crop window: call fp_upload_frame first");
   size_t px = (size_t)m->H * m->W;
   if (!m->xyz && dev_alloc(&m->xyz, m->frame_cap * 3)) return 1;
   launch_depth_to_xyz(m->stream, m->depth, m->H, m->W, m->K, m->xyz);
@@ -702,6 +713,7 @@ static int run_depth_filters(fp_model *m) {
 
 int fp_filter_depth(fp_model *m, float *eroded_out, float *bilateral_out) {
   FP_CHECK(m && m->depth, "[FoundationPose] fp_filter_depth: no frame uploaded");
+  FP_CHECK(!m->frame_partial, "[FoundationPose] the last call (Track from a host frame) uploaded only its crop window: call fp_upload_frame first");
   size_t px = (size_t)m->H * m->W;
   run_depth_filters(m);
   if (eroded_out) FP_HIP_OK(hipMemcpyAsync(eroded_out, m->erode, px * 4, hipMemcpyDeviceToHost, m->stream));
@@ -727,6 +739,7 @@ static int set_rotation_grid(fp_model *m, int steps) {
 // (sampler_status) is fetched together with the results.
 static int sample_hypotheses_async(fp_model *m, Target *t, const void *mask, int memspace, int first, int N) {
   FP_CHECK(m->depth != nullptr && mask != nullptr, "[FoudationPoseSampler] Got INVALID depth/mask ptr on device!!!");
+  FP_CHECK(!m->frame_partial, "[FoundationPose] the last call (Track from a host frame) uploaded only its crop window: call fp_upload_frame first");
   const size_t px = (size_t)m->H * m->W;
   if (ensure_capacity(m, N, t ? (size_t)t->mesh.V : 0)) return 1;
   if (px > m->samp_px_cap) {
@@ -795,6 +808,7 @@ int fp_render_and_transform(fp_model *m, const char *target_name, const float *p
                             float *render_out, float *transf_out, int out_memspace) {
   FP_CHECK(m && poses && N > 0, "[FoundationposeRender] The transform matrix vector is empty");
   FP_CHECK(m->depth != nullptr, "[FoundationPose] fp_render_and_transform: no frame uploaded");
+  FP_CHECK(!m->frame_partial, "[FoundationPose] the last call (Track from a host frame) uploaded only its crop window: call fp_upload_frame first");
   Target *t = m->find(target_name ? target_name : "");
   FP_CHECK(t != nullptr, "[FoundationPose] unknown target_name");
   if (upload_poses(m, t, poses, N)) return 1;
@@ -1073,7 +1087,28 @@ int fp_track_ex(fp_model *m, const void *rgb, const void *depth, int memspace, i
   FP_CHECK(m->refiner, "[FoundationPose] refiner weights not loaded");
   FP_CHECK(hyp_pose && out_pose, "[FoundationPose] Track: null pose");
   const bool graphable = m->use_graphs && !m->prof.on && !m->digests && !m->calibrating && refine_itr >= 1;
-  if (upload_frame_async(m, rgb, depth, memspace, H, W)) return 1;
+  // a single refine iteration reads the frame only inside the observed-crop window of the hypothesis (ComputeCropWindowTF,
+  // foundationpose_render.cpp:25-70, restated on the host in double with a margin): host frames upload just those rows
+  int row0 = 0, row1 = -1;
+  if (memspace != FP_DEVICE && refine_itr == 1) {
+    const double r = (double)t->mesh.diameter * 1.2 / 2, tx = hyp_pose[12], ty = hyp_pose[13], tz = hyp_pose[14];
+    auto proj_v = [&](double x, double y, double z) {
+      const double q1 = m->K[3] * x + m->K[4] * y + m->K[5] * z, q2 = m->K[6] * x + m->K[7] * y + m->K[8] * z;
+      return q1 / q2;
+    };
+    if (tz > 1e-6) {
+      const double v0 = proj_v(tx, ty, tz);
+      double rad = 0;
+      const double offs[4][2] = {{r, 0}, {-r, 0}, {0, r}, {0, -r}};
+      for (auto &o : offs) rad = std::max(rad, std::fabs(proj_v(tx + o[0], ty + o[1], tz) - v0));
+      if (std::isfinite(v0) && std::isfinite(rad)) {
+        row0 = (int)std::floor(v0 - rad) - 4;
+        row1 = (int)std::ceil(v0 + rad) + 5;
+        if (row1 <= 0 || row0 >= H) { row0 = 0; row1 = 0; }   // window outside the frame: nothing is read
+      }
+    }
+  }
+  if (upload_frame_async(m, rgb, depth, memspace, H, W, row0, row1)) return 1;
   if (refine_itr <= 0) {  // no refinement requested: the hypothesis is the answer (the reference's loop runs zero times)
     FP_HIP_OK(hipStreamSynchronize(m->stream));
     std::memcpy(out_pose, hyp_pose, 64);

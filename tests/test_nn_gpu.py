@@ -263,6 +263,17 @@ def test_track_end_to_end(model, nets, syn_mesh, syn_scene):
     # reference error behaviour: unknown target -> False
     ok, _ = model.Track(syn_scene.rgb, syn_scene.depth, hyp, "nope")
     assert not ok and "target_name" in model.last_error
+    # Track from a host frame uploads only the rows of the observed-crop window: a model that has never seen the whole frame (its
+    # copy is otherwise uninitialised) must return the same pose, and the stage operators must refuse the partial frame
+    m2 = FoundationPose(syn_mesh, syn.intrinsics(), nets[0], nets[1])
+    try:
+        ok, pose2 = m2.Track(syn_scene.rgb, syn_scene.depth, hyp, syn_mesh.name)
+        assert ok and np.array_equal(pose2, pose)
+        assert m2.get_hyp_poses(syn_scene.mask) is None and "crop window" in m2.last_error
+        m2.upload_frame(syn_scene.rgb, syn_scene.depth)
+        assert len(m2.get_hyp_poses(syn_scene.mask)) == 252
+    finally:
+        m2.close()
     # zero refine iterations: the reference's loop does not run and the hypothesis comes back unchanged
     ok, same = model.Track(syn_scene.rgb, syn_scene.depth, hyp, syn_mesh.name, refine_itr=0)
     assert ok and np.array_equal(same, hyp.astype(np.float32))
