@@ -1774,6 +1774,7 @@ __global__ __launch_bounds__(256, 2) void conv_deep_kernel(const ConvParams p) {
 #pragma unroll
   for (int i = 0; i < XP; i++) {
     int m = min(m0 + (wave * XP + i) * 8 + srow, p.M - 1);  // rows past M re-read the last pixel (never stored)
+    if (p.in_shared) m -= (m0 / p.grp_rows) * p.grp_rows;   // weight groups along M: every group reads the first group's rows
     int img = m / ohw;
     int rem = m - img * ohw;
     int oh = rem / p.OW, ow = rem - oh * p.OW;
@@ -1783,7 +1784,7 @@ __global__ __launch_bounds__(256, 2) void conv_deep_kernel(const ConvParams p) {
 #pragma unroll
   for (int i = 0; i < WP; i++) woff[i] = (unsigned)((n0 + (wave * WP + i) * 8 + srow) * p.krow_b + g * 16);
   const unsigned char *in_b = p.in;
-  const unsigned char *w_b = p.w;
+  const unsigned char *w_b = p.w + (p.grp_rows ? (size_t)(m0 / p.grp_rows) * p.grp_w_bytes : 0);
   const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
   auto issue = [&](int kt) {
     const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + (kt % NST) * STAGE);
@@ -3285,6 +3286,7 @@ FP_HOOK g_splitk_target = 128; // workgroups a split-K launch aims for (tools/ab
 FP_HOOK g_splitk_min_kt = 9;    // layers with fewer 128-byte K-steps never split
 FP_HOOK g_splitk_deep = 1;      // split-K slices of at least 4 K-steps on conv_deep_kernel<128> (0 = conv_igemm_kernel<128>)
 FP_HOOK g_att_skv = 1;          // small attention grids on attention32_skv_kernel (keys split over the waves of a workgroup)
+FP_HOOK g_gemm_deep = 1;         // short-K layers of small problems on conv_deep_kernel<128> instead of the two-stage 128x128 tile
 FP_HOOK g_small_deep = 18;     // small problems (Track): conv_deep_kernel<64> over ALL K-steps instead of split-K + reduce when K has at most this many 128-byte steps
 FP_HOOK g_att_variant = 1;     // 1 = attention32_kernel (8 = without the XCD remap); round-1 kernel: 2 remap + 16-B stores, 3 no XCD remap, 5 remap + 2-B stores, 7 neither
 
@@ -3538,7 +3540,13 @@ static int run_conv_dt(const Ctx &c, const char *tag, const ConvLayer &L, ConvPa
     FP_LAUNCH((conv_pp_kernel<128, DT, ODT>), dim3(((p.M + 255) / 256) * (L.Cout / 128)), dim3(512), LDS3_128, c.s, p);
     return 0;
   }
-  if (L.Cout % 128 == 0 && !grp && p.ksplit > 1 && g_splitk_deep && p.kt_per >= 4) {
+  if (L.Cout % 128 == 0 && p.ksplit == 1 && g_gemm_deep && p.m_begin == 0 && KT >= 4 && KT <= 8 && mtiles * (L.Cout / 128) <= 128 &&
+      (!grp || grp->rows % 128 == 0)) {
+    // short-K layers of small problems (the Linear layers of Track): a workgroup is a chain of <= 8 K-steps whose load latency the
+    // two-stage tile below exposes every step; the deep ring keeps three steps in flight
+    ProfScope ps(c.prof, c.s, (tg + "/conv_deep_kernel(short-K)").c_str(), flops, bytes);
+    FP_LAUNCH((conv_deep_kernel<128, DT, ODT>), dim3(mtiles * (L.Cout / 128)), dim3(256), LDS_DEEP128, c.s, p);
+  } else if (L.Cout % 128 == 0 && !grp && p.ksplit > 1 && g_splitk_deep && p.kt_per >= 4) {
     // split-K slices on the deep-ring kernel (three K-steps in flight instead of one: a slice is a latency chain)
     ProfScope ps(c.prof, c.s, (tg + "/conv_deep_kernel(split-K)").c_str(), flops, bytes);
     FP_LAUNCH((conv_deep_kernel<128, DT, ODT>), dim3(mtiles * (L.Cout / 128) * p.ksplit), dim3(256), LDS_DEEP128, c.s, p);
@@ -4034,6 +4042,7 @@ void fpt_set_gemm_kernel(int v) { fp::g_gemm_kernel = v; }
 void fpt_set_rem_kernel(int v) { fp::g_rem_kernel = v; }
 void fpt_set_rem_small(int v) { fp::g_rem_small = v; }
 void fpt_set_small_deep(int v) { fp::g_small_deep = v; }
+void fpt_set_gemm_deep(int v) { fp::g_gemm_deep = v; }
 void fpt_set_att_skv(int v) { fp::g_att_skv = v; }
 void fpt_set_splitk_deep(int v) { fp::g_splitk_deep = v; }
 void fpt_set_splitk_min_kt(int v) { fp::g_splitk_min_kt = v; }
