@@ -652,8 +652,16 @@ static void launch_raster_mode(hipStream_t s, const DeviceMesh &m, const PoseRec
 #ifdef FP_TEST_HOOKS
   if (rows == 40) { launch_raster_shade_t<MODE, 40, FMAD>(s, m, recs, N, clip, attr, out, tri_id_dbg, rast_dbg); return; }
 #endif
-  if (rows == 20) launch_raster_shade_t<MODE, 20, FMAD>(s, m, recs, N, clip, attr, out, tri_id_dbg, rast_dbg);
-  else launch_raster_shade_t<MODE, 8, FMAD>(s, m, recs, N, clip, attr, out, tri_id_dbg, rast_dbg);
+  if (rows == 20) { launch_raster_shade_t<MODE, 20, FMAD>(s, m, recs, N, clip, attr, out, tri_id_dbg, rast_dbg); return; }
+  // one or two hypotheses (Track): 4-row strips with 1024 threads -- the shading pass covers the strip in ONE iteration
+  // (640 pixels; 8 rows = 1280 pixels took two, the second a quarter full) and a strip meets half as many triangles
+  if ((rows == 4 || (rows == 8 && N <= 2 && !g_strip_rows_override)) && MODE != OUT_F32X6 && !tri_id_dbg && !rast_dbg) {
+    const size_t lds = (size_t)4 * CROP * sizeof(unsigned long long);
+    hipLaunchKernelGGL((raster_shade_kernel<MODE, 4, 1024, FMAD>), dim3(CROP / 4, N), dim3(1024), lds, s, m.faces, m.F, m.V, m.uvs,
+                       m.tex, m.TH, m.TW, m.diameter / 2, recs, clip, attr, out, tri_id_dbg, rast_dbg);
+    return;
+  }
+  launch_raster_shade_t<MODE, 8, FMAD>(s, m, recs, N, clip, attr, out, tri_id_dbg, rast_dbg);
 }
 
 void launch_raster_shade(hipStream_t s, const DeviceMesh &m, const PoseRec *recs, int N, const float4 *clip,
