@@ -18,7 +18,7 @@ m = FoundationPose(mesh, scene.K, rp, sp)
 rgb, depth, mask = (torch.from_numpy(a).to(dev) for a in (scene.rgb, scene.depth, scene.mask))
 H, Wd = scene.depth.shape
 be = HipShardBackend(m, dev)
-for n_total, counts in ((252, (32, 63, 126, 252)), (1008, (126,))):
+for n_total, counts in ((252, (32, 63, 126, 252)), (1008, (126,)), (2016, (252,))):   # 2016 / 252 = what `bench.py --gpus 8` runs per rank (weak scaling)
     m.set_inplane_steps(n_total // 42)
     for count in counts:
         world = -(-n_total // count)
