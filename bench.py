@@ -107,8 +107,13 @@ def main():
 
     mesh = syn.make_mesh(textured=not args.untextured)
     scene = syn.make_scene(mesh, args.width, args.height)
-    with tempfile.TemporaryDirectory() as d:
-        rp, sp = os.path.join(d, f"r{rank}.fpw"), os.path.join(d, f"s{rank}.fpw")
+    wdir = tempfile.mkdtemp()     # (kept until exit: the pipelined-Track leg creates more models from the same files)
+    import atexit, shutil
+    atexit.register(shutil.rmtree, wdir, True)
+    rp_keep, sp_keep = os.path.join(wdir, f"r{rank}.fpw"), os.path.join(wdir, f"s{rank}.fpw")
+    if True:
+        d = wdir
+        rp, sp = rp_keep, sp_keep
         states = (W.pack_synthetic("refiner", rp), W.pack_synthetic("scorer", sp))
         model = FoundationPose(mesh, scene.K, rp, sp, max_input_image_height=max(1080, args.height),
                                max_input_image_width=max(1920, args.width))
@@ -204,9 +209,31 @@ def main():
         model.profile(False)
         tconv = {k: v for k, v in tprof.items() if k.startswith("conv_") or k.startswith("gemm_")}
         tflops = sum(v["flops"] for v in tconv.values()) + sum(v["flops"] for k, v in tprof.items() if k == "attention")
+        # pipelined serving: ONE host thread keeps K models (objects of one scene, frame resident in HBM) in flight with
+        # fp_track_submit / fp_track_wait -- Track is launch-latency-bound, so independent objects overlap on the chip
+        pipelined = None
+        if args.dtype == "f16":
+            K_OBJ = 8
+            others = [FoundationPose(mesh, scene.K, rp_keep, sp_keep, max_input_image_height=max(1080, args.height),
+                                     max_input_image_width=max(1920, args.width)) for _ in range(K_OBJ - 1)]
+            fleet = [model] + others
+            outs = np.zeros(16, np.float32)
+
+            def submit_all():
+                for mm in fleet:
+                    mm._must(mm._L.fp_track_submit(mm.handle, C.c_void_p(rgb.data_ptr()), C.c_void_p(depth.data_ptr()), 1, H, Wd,
+                                                   hyp16.ctypes.data_as(C.c_void_p), mesh.name.encode(), 1))
+                for mm in fleet:
+                    mm._must(mm._L.fp_track_wait(mm.handle, outs.ctypes.data_as(C.c_void_p)))
+            tp = timed(submit_all, max(ksteps // K_OBJ, 20), 5)
+            pipelined = {"objects_in_flight": K_OBJ, "value": round(K_OBJ * max(ksteps // K_OBJ, 20) / tp, 1), "unit": "tracks/s",
+                         "what": "one host thread, fp_track_submit for every object then fp_track_wait for every object"}
+            for mm in others:
+                mm.close()
         extras["track"] = {
             "metric": "Track fps (N=1)", "value": round(ksteps / td, 1), "unit": "frames/s", "ms_per_frame": round(td / ksteps * 1e3, 4),
             "host_frame_value": round(ksteps / thh, 1), "host_frame_ms": round(thh / ksteps * 1e3, 4), "steps": ksteps,
+            "pipelined": pipelined,
             "roofline": {"bound": "launch latency (one hipGraph of ~50 dependent kernels), not MFMA", "algorithmic_gflop_per_frame": round(tflops / 1e9, 2),
                          "achieved": round(tflops / (td / ksteps) / 1e12, 1), "peak": PEAK_FP16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(tflops / (td / ksteps) / 1e12 / PEAK_FP16_TFLOPS, 4)},

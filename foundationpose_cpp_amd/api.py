@@ -135,6 +135,24 @@ class FoundationPose:
                                        target_name.encode(), refine_itr, _p(out)))
         return ok, (from_colmajor(out) if ok else None)
 
+    def track_submit(self, rgb, depth, hyp_pose, target_name: str, refine_itr: int = 1) -> bool:
+        """Enqueue a Track (frame upload + refinement) on this model's stream and return; `track_wait` fetches the pose.
+        One host thread can keep several models (objects) in flight this way.  The frame arrays are kept alive until the wait."""
+        rgb, depth, _ = self._frame(rgb, depth, None)
+        if rgb is None:
+            return False
+        hyp = to_colmajor(np.asarray(hyp_pose, np.float32))
+        self._pending_frame = (rgb, depth)
+        return self._ok(self._L.fp_track_submit(self._h, _p(rgb), _p(depth), FP_HOST, depth.shape[0], depth.shape[1], _p(hyp),
+                                                target_name.encode(), refine_itr))
+
+    def track_wait(self):
+        """-> (ok, pose[4,4]) of the last `track_submit`."""
+        out = np.zeros(16, np.float32)
+        ok = self._ok(self._L.fp_track_wait(self._h, _p(out)))
+        self._pending_frame = None
+        return ok, (from_colmajor(out) if ok else None)
+
     def _frame(self, rgb, depth, mask):
         # CheckInputArguments (foundationpose.cpp:155-179): sizes must agree
         rgb = np.ascontiguousarray(rgb, np.uint8)

@@ -191,6 +191,7 @@ struct fp_model {
   FrameRef *frame_dev = nullptr, *frame_pinned = nullptr;  // what kernels inside graphs read the frame through
   FrameRef frame_pub = {nullptr, nullptr};                 // last published value
   unsigned frame_pub_count = 0;
+  bool track_pending = false;  // fp_track_submit without its fp_track_wait
   bool frame_partial = false;  // the model's copy of a host frame holds only the rows Track needed (stage operators refuse it)
   const uint8_t *rgb = nullptr;   // device
   const float *depth = nullptr;   // device
@@ -1080,12 +1081,15 @@ int fp_register(fp_model *m, const uint8_t *rgb, const float *depth, const uint8
   return fp_register_ex(m, rgb, depth, mask, FP_HOST, H, W, target_name, refine_itr, out_pose);
 }
 
-int fp_track_ex(fp_model *m, const void *rgb, const void *depth, int memspace, int H, int W, const float hyp_pose[16],
-                const char *target_name, int refine_itr, float out_pose[16]) {
+// Track in two halves: everything is ENQUEUED by fp_track_submit (frame upload, the replayed graph); fp_track_wait synchronises the
+// model's stream and hands the pose over.  One host thread can so keep several models (objects) in flight at once.
+int fp_track_submit(fp_model *m, const void *rgb, const void *depth, int memspace, int H, int W, const float hyp_pose[16],
+                    const char *target_name, int refine_itr) {
   Target *t = nullptr;
   if (check_frame_args(m, H, W, target_name ? target_name : "", &t)) return 1;
   FP_CHECK(m->refiner, "[FoundationPose] refiner weights not loaded");
-  FP_CHECK(hyp_pose && out_pose, "[FoundationPose] Track: null pose");
+  FP_CHECK(hyp_pose, "[FoundationPose] Track: null pose");
+  FP_CHECK(!m->track_pending, "[FoundationPose] fp_track_submit: the previous submission has not been waited for");
   const bool graphable = m->use_graphs && !m->prof.on && !m->digests && !m->calibrating && refine_itr >= 1;
   // a single refine iteration reads the frame only inside the observed-crop window of the hypothesis (ComputeCropWindowTF,
   // foundationpose_render.cpp:25-70, restated on the host in double with a margin): host frames upload just those rows
@@ -1109,18 +1113,18 @@ int fp_track_ex(fp_model *m, const void *rgb, const void *depth, int memspace, i
     }
   }
   if (upload_frame_async(m, rgb, depth, memspace, H, W, row0, row1)) return 1;
+  if (!m->track_io) {
+    FP_HIP_OK(hipHostMalloc((void **)&m->track_io, 32 * sizeof(float), hipHostMallocDefault));
+    FP_HIP_OK(hipHostGetDevicePointer((void **)&m->track_io_dev, m->track_io, 0));
+  }
   if (refine_itr <= 0) {  // no refinement requested: the hypothesis is the answer (the reference's loop runs zero times)
-    FP_HIP_OK(hipStreamSynchronize(m->stream));
-    std::memcpy(out_pose, hyp_pose, 64);
+    std::memcpy(m->track_io + 16, hyp_pose, 64);
+    m->track_pending = true;
     return 0;
   }
   if (ensure_capacity(m, 1, (size_t)t->mesh.V)) return 1;
   // the hypothesis goes in and the refined pose comes out through host-pinned memory the kernels address directly: no copy
   // kernels around the graph (two of the ~50 launches of a Track)
-  if (!m->track_io) {
-    FP_HIP_OK(hipHostMalloc((void **)&m->track_io, 32 * sizeof(float), hipHostMallocDefault));
-    FP_HIP_OK(hipHostGetDevicePointer((void **)&m->track_io_dev, m->track_io, 0));
-  }
   std::memcpy(m->track_io, hyp_pose, 64);
   if (run_graphed(m, m->tg, t, H, W, refine_itr, 1, graphable, [&]() {
         for (int it = 0; it < refine_itr; it++)
@@ -1128,9 +1132,28 @@ int fp_track_ex(fp_model *m, const void *rgb, const void *depth, int memspace, i
         return 0;
       }))
     return 1;
+  m->track_pending = true;
+  return 0;
+}
+
+int fp_track_wait(fp_model *m, float out_pose[16]) {
+  FP_CHECK(m && out_pose, "[FoundationPose] fp_track_wait: invalid arguments");
+  FP_CHECK(m->track_pending, "[FoundationPose] fp_track_wait: nothing was submitted");
+  m->track_pending = false;
   FP_HIP_OK(hipStreamSynchronize(m->stream));
   std::memcpy(out_pose, m->track_io + 16, 64);
   return 0;
+}
+
+int fp_track_ex(fp_model *m, const void *rgb, const void *depth, int memspace, int H, int W, const float hyp_pose[16],
+                const char *target_name, int refine_itr, float out_pose[16]) {
+  FP_CHECK(out_pose, "[FoundationPose] Track: null pose");
+  if (fp_track_submit(m, rgb, depth, memspace, H, W, hyp_pose, target_name, refine_itr)) {
+    if (m && m->stream) (void)hipStreamSynchronize(m->stream);
+    if (m) m->track_pending = false;
+    return 1;
+  }
+  return fp_track_wait(m, out_pose);
 }
 
 int fp_track(fp_model *m, const uint8_t *rgb, const float *depth, int H, int W, const float hyp_pose[16],

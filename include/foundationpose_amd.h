@@ -82,6 +82,13 @@ int fp_register(fp_model *m, const uint8_t *rgb, const float *depth, const uint8
  * rows are uploaded (the stage operators below refuse the resulting partial copy until the next fp_upload_frame / Register). */
 int fp_track(fp_model *m, const uint8_t *rgb, const float *depth, int H, int W, const float hyp_pose[16],
              const char *target_name, int refine_itr, float out_pose[16]);
+/* Track in two halves for pipelined serving (one host thread, several models / objects in flight; the reference's un-vendored
+ * async_pipeline plays this role, D6F/src/foundationpose_utils.hpp:33-37): fp_track_submit ENQUEUES the frame upload and the whole
+ * refinement on the model's stream and returns; fp_track_wait synchronises that stream and returns the pose.  A host frame must
+ * stay valid until the wait; one submission per model at a time. */
+int fp_track_submit(fp_model *m, const void *rgb, const void *depth, int memspace, int H, int W, const float hyp_pose[16],
+                    const char *target_name, int refine_itr);
+int fp_track_wait(fp_model *m, float out_pose[16]);
 /* same, frame already resident in HBM (memspace FP_DEVICE for rgb/depth/mask) */
 int fp_register_ex(fp_model *m, const void *rgb, const void *depth, const void *mask, int memspace, int H, int W,
                    const char *target_name, int refine_itr, float out_pose[16]);

@@ -96,6 +96,18 @@ public:
     return ok(fp_track(h_, rgb.data, depth.data, depth.rows, depth.cols, hyp_pose_in_mesh.data(), target_name.c_str(),
                        (int)refine_itr, out_pose_in_mesh.data()));
   }
+  // Track in two halves (pipelined serving: one thread, several objects in flight): the frame must stay valid until TrackWait
+  bool TrackSubmit(const ImageU8 &rgb, const ImageF32 &depth, const Pose &hyp_pose_in_mesh, const std::string &target_name,
+                   size_t refine_itr = 1) {
+    if (rgb.rows != depth.rows || rgb.cols != depth.cols) {
+      err_ = "[FoundationPose] Got rgb/depth/mask with different size!";
+      return false;
+    }
+    return ok(fp_track_submit(h_, rgb.data, depth.data, FP_HOST, depth.rows, depth.cols, hyp_pose_in_mesh.data(), target_name.c_str(),
+                              (int)refine_itr));
+  }
+  bool TrackWait(Pose &out_pose_in_mesh) { return ok(fp_track_wait(h_, out_pose_in_mesh.data())); }
+
   // ---- options the reference does not have ----
   // element type of both networks: FP_PREC_F16 (default, the reference's TensorRT --fp16), FP_PREC_BF16, FP_PREC_FP8 (after CalibrateFp8 / SetCalibration)
   bool SetPrecision(int precision) { return ok(fp_set_precision(h_, precision)); }

@@ -154,8 +154,8 @@ def test_several_meshes_per_model(wpaths, syn_scene):
 
 def test_two_models_serve_concurrently_on_their_own_streams(wpaths, syn_mesh, syn_scene):
     """one model per host thread (the not-re-entrant-per-model contract of the reference, foundationpose.cpp:103-105):
-    concurrent Track + Register calls give exactly the sequential results.  The library serialises the GPU work of
-    different models (overlapping two models' streams gave rare stale-read results)."""
+    concurrent Track + Register calls give exactly the sequential results; the models' kernels overlap on the GPU (no lock since
+    round 2)."""
     import threading
     scenes = [syn_scene, syn.make_scene(syn_mesh, t=(-0.03, 0.02, 0.62), rot_seed=9)]
     models = [FoundationPose(syn_mesh, syn.intrinsics(), *wpaths) for _ in scenes]
@@ -185,3 +185,34 @@ def test_two_models_serve_concurrently_on_their_own_streams(wpaths, syn_mesh, sy
             assert ok
             np.testing.assert_array_equal(p, seq[i][0] if kind == "t" else seq[i][1])
     [m.close() for m in models]
+
+
+def test_pipelined_tracking_of_several_objects_from_one_thread(wpaths, syn_mesh, syn_scene):
+    """fp_track_submit / fp_track_wait (the role of the reference's async_pipeline, foundationpose_utils.hpp:33-37): one host thread
+    keeps four models (objects) in flight; every pose equals the synchronous Track of the same model, and misuse is refused."""
+    scenes = [syn_scene] + [syn.make_scene(syn_mesh, t=(0.02 * k - 0.03, 0.01 * k, 0.6 + 0.02 * k), rot_seed=20 + k) for k in range(3)]
+    models = [FoundationPose(syn_mesh, syn.intrinsics(), *wpaths) for _ in scenes]
+    try:
+        hyps = [syn.perturb_pose(s.gt_pose) for s in scenes]
+        ref = []
+        for m, s, h in zip(models, scenes, hyps):
+            ok, p = m.Track(s.rgb, s.depth, h, syn_mesh.name)
+            assert ok, m.last_error
+            ref.append(p)
+        for rounds in range(3):          # eager, capture, replay of every model's graph -- all four in flight each round
+            for m, s, h in zip(models, scenes, hyps):
+                assert m.track_submit(s.rgb, s.depth, h, syn_mesh.name), m.last_error
+            for m, p in zip(models, ref):
+                ok, got = m.track_wait()
+                assert ok and np.array_equal(got, p)
+        # a second submission before the wait, and a wait without a submission, are errors (not hangs)
+        m0, s0, h0 = models[0], scenes[0], hyps[0]
+        assert m0.track_submit(s0.rgb, s0.depth, h0, syn_mesh.name)
+        assert not m0.track_submit(s0.rgb, s0.depth, h0, syn_mesh.name) and "not been waited" in m0.last_error
+        ok, got = m0.track_wait()
+        assert ok and np.array_equal(got, ref[0])
+        ok, _ = m0.track_wait()
+        assert not ok and "nothing was submitted" in m0.last_error
+    finally:
+        for m in models:
+            m.close()
