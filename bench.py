@@ -230,6 +230,19 @@ def main():
                          "what": "one host thread, fp_track_submit for every object then fp_track_wait for every object"}
             for mm in others:
                 mm.close()
+            # fp_track_multi: the same 8 objects as ONE batch of one model (geometry per object, one refine-net pass over all crops)
+            hyps8 = np.tile(hyp16, (K_OBJ, 1)).astype(np.float32)
+            outs8 = np.zeros((K_OBJ, 16), np.float32)
+            names8 = (C.c_char_p * K_OBJ)(*[mesh.name.encode()] * K_OBJ)
+
+            def multi():
+                model._must(model._L.fp_track_multi(model.handle, C.c_void_p(rgb.data_ptr()), C.c_void_p(depth.data_ptr()), 1, H, Wd, K_OBJ,
+                                                    hyps8.ctypes.data_as(C.c_void_p), C.cast(names8, C.c_void_p), 1,
+                                                    outs8.ctypes.data_as(C.c_void_p)))
+            tm = timed(multi, max(ksteps // 4, 50), 5)
+            pipelined["batched"] = {"objects": K_OBJ, "ms_per_call": round(tm / max(ksteps // 4, 50) * 1e3, 4),
+                                    "value": round(K_OBJ * max(ksteps // 4, 50) / tm, 1), "unit": "tracks/s",
+                                    "what": "fp_track_multi: 8 objects of one frame in one batch"}
         extras["track"] = {
             "metric": "Track fps (N=1)", "value": round(ksteps / td, 1), "unit": "frames/s", "ms_per_frame": round(td / ksteps * 1e3, 4),
             "host_frame_value": round(ksteps / thh, 1), "host_frame_ms": round(thh / ksteps * 1e3, 4), "steps": ksteps,

@@ -15,7 +15,7 @@ CSRC = os.path.join(_HERE, "csrc")
 # every symbol include/foundationpose_amd.h declares
 SYMBOLS = [
     "fp_create", "fp_destroy", "fp_last_error", "fp_set_inplane_steps", "fp_num_hypotheses",
-    "fp_register", "fp_track", "fp_register_ex", "fp_track_ex", "fp_track_submit", "fp_track_wait",
+    "fp_register", "fp_track", "fp_register_ex", "fp_track_ex", "fp_track_submit", "fp_track_wait", "fp_track_multi",
     "fp_upload_frame", "fp_get_xyz_map", "fp_get_hyp_poses", "fp_filter_depth",
     "fp_render_and_transform", "fp_debug_rasterize", "fp_refiner_infer", "fp_scorer_infer",
     "fp_refine_post_process", "fp_argmax", "fp_register_shard_begin", "fp_register_shard_finish", "fp_register_shard_begin_packed", "fp_register_shard_finish_packed",
@@ -94,6 +94,7 @@ def lib() -> C.CDLL:
         "fp_track_ex": [vp, vp, vp, ci, ci, ci, vp, cs, ci, vp],
         "fp_track_submit": [vp, vp, vp, ci, ci, ci, vp, cs, ci],
         "fp_track_wait": [vp, vp],
+        "fp_track_multi": [vp, vp, vp, ci, ci, ci, ci, vp, vp, ci, vp],
         "fp_upload_frame": [vp, vp, vp, ci, ci, ci], "fp_get_xyz_map": [vp, vp],
         "fp_get_hyp_poses": [vp, vp, ci, vp, vp], "fp_filter_depth": [vp, vp, vp],
         "fp_render_and_transform": [vp, cs, vp, ci, cf, vp, vp, ci],

@@ -153,6 +153,19 @@ class FoundationPose:
         self._pending_frame = None
         return ok, (from_colmajor(out) if ok else None)
 
+    def track_multi(self, rgb, depth, hyp_poses, target_names, refine_itr: int = 1):
+        """Track of K objects of one frame as one batch -> (ok, poses[K,4,4])."""
+        rgb, depth, _ = self._frame(rgb, depth, None)
+        if rgb is None:
+            return False, None
+        hyp = to_colmajor(np.asarray(hyp_poses, np.float32))
+        K = len(hyp)
+        names = (C.c_char_p * K)(*[n.encode() for n in target_names])
+        out = np.zeros((K, 16), np.float32)
+        ok = self._ok(self._L.fp_track_multi(self._h, _p(rgb), _p(depth), FP_HOST, depth.shape[0], depth.shape[1], K, _p(hyp),
+                                             C.cast(names, C.c_void_p), refine_itr, _p(out)))
+        return ok, (from_colmajor(out) if ok else None)
+
     def _frame(self, rgb, depth, mask):
         # CheckInputArguments (foundationpose.cpp:155-179): sizes must agree
         rgb = np.ascontiguousarray(rgb, np.uint8)

@@ -191,6 +191,9 @@ struct fp_model {
   FrameRef *frame_dev = nullptr, *frame_pinned = nullptr;  // what kernels inside graphs read the frame through
   FrameRef frame_pub = {nullptr, nullptr};                 // last published value
   unsigned frame_pub_count = 0;
+  float *multi_io = nullptr, *multi_io_dev = nullptr;  // host-pinned [K poses in | K poses out] of fp_track_multi
+  int multi_io_cap = 0;
+  std::vector<Target *> mg_sig;                        // the object sequence the multi-object graph was captured for
   bool track_pending = false;  // fp_track_submit without its fp_track_wait
   bool frame_partial = false;  // the model's copy of a host frame holds only the rows Track needed (stage operators refuse it)
   const uint8_t *rgb = nullptr;   // device
@@ -257,7 +260,7 @@ struct fp_model {
     int H = 0, W = 0, itr = 0, n = 0, prec = 0;
     unsigned long epoch = 0;
     int eager_calls = 0;
-  } tg, rg;  // Track body / Register body
+  } tg, rg, mg;  // Track body / Register body / multi-object Track body
   bool use_graphs = true;
 
   Target *find(const char *name) {
@@ -329,26 +332,27 @@ static int check_frame_args(fp_model *m, int H, int W, const char *target_name, 
 // render + crop for N poses already in m->poses_dev; writes the fp16 network input (both halves) or fp32 blobs
 // n_crop: number of observed crops to produce (N, or 1 when every hypothesis shares the same translation)
 static int render_and_crop(fp_model *m, Target *t, int N, float crop_ratio, OutMode mode, void *out_a, void *out_b,
-                           int32_t *dbg_tri, float *dbg_rast, int n_crop = -1, const float *poses_src = nullptr) {
+                           int32_t *dbg_tri, float *dbg_rast, int n_crop = -1, const float *poses_src = nullptr, PoseRec *recs = nullptr) {
   if (n_crop < 0) n_crop = N;
+  if (!recs) recs = m->recs;   // (fp_track_multi: the records of one object group inside the batch)
   hipStream_t s = m->stream;
   const size_t out_bytes = (mode == OUT_F32X6 ? 24.0 : 16.0) * FP_CROP_HW * FP_CROP_HW;  // both 2-byte modes: 16 B per pixel
   if (!out_a) {
     ProfScope ps(&m->prof, s, "pose_setup");
-    launch_pose_setup(s, poses_src ? poses_src : m->poses_dev, N, m->K, m->H, m->W, crop_ratio, t->mesh.diameter, m->recs);
+    launch_pose_setup(s, poses_src ? poses_src : m->poses_dev, N, m->K, m->H, m->W, crop_ratio, t->mesh.diameter, recs);
   }
   if (out_a) {
     {   // pose set-up (crop window, bounding box, projection) is computed inside the vertex kernel: one launch less per render
       ProfScope ps(&m->prof, s, "vertex", 0, (double)N * t->mesh.V * 32.0 + t->mesh.V * 24.0);
-      launch_setup_vertex(s, t->mesh, poses_src ? poses_src : m->poses_dev, N, m->K, m->H, m->W, crop_ratio, t->mesh.diameter, m->recs,
+      launch_setup_vertex(s, t->mesh, poses_src ? poses_src : m->poses_dev, N, m->K, m->H, m->W, crop_ratio, t->mesh.diameter, recs,
                           m->clip, m->attr, m->fmad);
     }
     ProfScope ps(&m->prof, s, "raster_shade", 0, (double)N * (out_bytes + t->mesh.V * 32.0 + t->mesh.F * 12.0));
-    launch_raster_shade(s, t->mesh, m->recs, N, m->clip, m->attr, mode, out_a, dbg_tri, dbg_rast, m->fmad);
+    launch_raster_shade(s, t->mesh, recs, N, m->clip, m->attr, mode, out_a, dbg_tri, dbg_rast, m->fmad);
   }
   if (out_b) {
     ProfScope ps(&m->prof, s, "crop_warp", 0, (double)n_crop * out_bytes);
-    launch_crop(s, m->frame_dev, m->H, m->W, m->K, m->recs, n_crop, t->mesh.diameter, mode, out_b);
+    launch_crop(s, m->frame_dev, m->H, m->W, m->K, recs, n_crop, t->mesh.diameter, mode, out_b);
   }
   FP_HIP_OK(hipGetLastError());
   return 0;
@@ -601,6 +605,8 @@ void fp_destroy(fp_model *m) {
   if (m->stream) (void)hipStreamSynchronize(m->stream);
   drop_graph(m->tg);
   drop_graph(m->rg);
+  drop_graph(m->mg);
+  if (m->multi_io) (void)hipHostFree(m->multi_io);
   m->prof.reset();
   for (auto &t : m->targets) {
     dev_free(t.mesh.verts); dev_free(t.mesh.normals); dev_free(t.mesh.uvs); dev_free(t.mesh.faces); dev_free(t.mesh.tex);
@@ -1142,6 +1148,71 @@ int fp_track_wait(fp_model *m, float out_pose[16]) {
   m->track_pending = false;
   FP_HIP_OK(hipStreamSynchronize(m->stream));
   std::memcpy(out_pose, m->track_io + 16, 64);
+  return 0;
+}
+
+// Track of K objects of one frame in ONE batch: the geometry runs per object (its mesh), the refine-net once over all K crops.
+// Track is launch-latency-bound at N = 1, so K objects cost little more than one (tools/bench_multi_track.py).
+int fp_track_multi(fp_model *m, const void *rgb, const void *depth, int memspace, int H, int W, int K, const float *hyp_poses,
+                   const char *const *target_names, int refine_itr, float *out_poses) {
+  FP_CHECK(m != nullptr, "[FoundationPose] null model");
+  FP_CHECK(K >= 1 && K <= 64 && hyp_poses && target_names && out_poses, "[FoundationPose] fp_track_multi: invalid arguments (1..64 objects)");
+  FP_CHECK(m->refiner, "[FoundationPose] refiner weights not loaded");
+  FP_CHECK(!m->track_pending, "[FoundationPose] fp_track_multi: a submitted Track has not been waited for");
+  std::vector<Target *> targets(K);
+  size_t maxV = 0;
+  for (int i = 0; i < K; i++) {
+    Target *t = nullptr;
+    if (check_frame_args(m, H, W, target_names[i] ? target_names[i] : "", &t)) return 1;
+    targets[i] = t;
+    maxV = std::max(maxV, (size_t)t->mesh.V);
+  }
+  if (upload_frame_async(m, rgb, depth, memspace, H, W)) return 1;
+  if (refine_itr <= 0) {
+    FP_HIP_OK(hipStreamSynchronize(m->stream));
+    std::memcpy(out_poses, hyp_poses, (size_t)K * 64);
+    return 0;
+  }
+  if (ensure_capacity(m, K, maxV)) return 1;
+  if (K > m->multi_io_cap) {
+    FP_HIP_OK(hipStreamSynchronize(m->stream));
+    if (m->multi_io) (void)hipHostFree(m->multi_io);
+    m->multi_io = nullptr; m->multi_io_cap = 0;
+    g_alloc_epoch++;   // graphs bake the pinned addresses
+    FP_HIP_OK(hipHostMalloc((void **)&m->multi_io, (size_t)2 * 64 * 16 * sizeof(float), hipHostMallocDefault));
+    FP_HIP_OK(hipHostGetDevicePointer((void **)&m->multi_io_dev, m->multi_io, 0));
+    m->multi_io_cap = 64;
+  }
+  std::memcpy(m->multi_io, hyp_poses, (size_t)K * 64);
+  const bool graphable = m->use_graphs && !m->prof.on && !m->digests && !m->calibrating;
+  if (m->mg_sig != targets) { drop_graph(m->mg); m->mg.target = nullptr; m->mg_sig = targets; }
+  float *pin_in = m->multi_io_dev, *pin_out = m->multi_io_dev + 64 * 16;
+  const size_t IMG = FP_NN_IN_IMG_HALFS;
+  if (run_graphed(m, m->mg, targets[0], H, W, refine_itr, K, graphable, [&]() {
+        for (int it = 0; it < refine_itr; it++) {
+          for (int o = 0; o < K;) {   // groups of consecutive objects with the same mesh
+            int n = 1;
+            while (o + n < K && targets[o + n] == targets[o]) n++;
+            if (render_and_crop(m, targets[o], n, 1.2f, nn_mode(m), m->nn_in + (size_t)o * IMG, m->nn_in + (size_t)(K + o) * IMG, nullptr, nullptr, n,
+                                (it == 0 ? pin_in : m->poses_dev) + (size_t)o * 16, m->recs + o))
+              return 1;
+            o += n;
+          }
+          if (refiner_forward(m->stream, &m->prof, m->refiner, m->ws, m->nn_in, K, m->trans_dev, m->rot_dev, 0)) return 1;
+          for (int o = 0; o < K;) {
+            int n = 1;
+            while (o + n < K && targets[o + n] == targets[o]) n++;
+            launch_pose_update(m->stream, m->poses_dev + (size_t)o * 16, m->trans_dev + (size_t)o * 3, m->rot_dev + (size_t)o * 3, n,
+                               targets[o]->mesh.diameter, it == 0 ? pin_in + (size_t)o * 16 : nullptr,
+                               it == refine_itr - 1 ? pin_out + (size_t)o * 16 : nullptr);
+            o += n;
+          }
+        }
+        return 0;
+      }))
+    return 1;
+  FP_HIP_OK(hipStreamSynchronize(m->stream));
+  std::memcpy(out_poses, m->multi_io + 64 * 16, (size_t)K * 64);
   return 0;
 }
 

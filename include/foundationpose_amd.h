@@ -89,6 +89,11 @@ int fp_track(fp_model *m, const uint8_t *rgb, const float *depth, int H, int W, 
 int fp_track_submit(fp_model *m, const void *rgb, const void *depth, int memspace, int H, int W, const float hyp_pose[16],
                     const char *target_name, int refine_itr);
 int fp_track_wait(fp_model *m, float out_pose[16]);
+/* Track of K (1..64) objects of one frame as ONE batch: hyp_poses / out_poses are K column-major 4x4 matrices, target_names K names
+ * (objects with the same mesh should be adjacent).  The rendering runs per object, the refine-net once over all K crops; at this
+ * size the step is launch-latency-bound, so K objects cost little more than one. */
+int fp_track_multi(fp_model *m, const void *rgb, const void *depth, int memspace, int H, int W, int K, const float *hyp_poses,
+                   const char *const *target_names, int refine_itr, float *out_poses);
 /* same, frame already resident in HBM (memspace FP_DEVICE for rgb/depth/mask) */
 int fp_register_ex(fp_model *m, const void *rgb, const void *depth, const void *mask, int memspace, int H, int W,
                    const char *target_name, int refine_itr, float out_pose[16]);

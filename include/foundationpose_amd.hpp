@@ -107,6 +107,19 @@ public:
                               (int)refine_itr));
   }
   bool TrackWait(Pose &out_pose_in_mesh) { return ok(fp_track_wait(h_, out_pose_in_mesh.data())); }
+  // K objects of one frame as one batch (geometry per object, one refine-net pass over all crops)
+  bool TrackMulti(const ImageU8 &rgb, const ImageF32 &depth, const std::vector<Pose> &hyp_poses, const std::vector<std::string> &target_names,
+                  std::vector<Pose> &out_poses, size_t refine_itr = 1) {
+    if (rgb.rows != depth.rows || rgb.cols != depth.cols || hyp_poses.size() != target_names.size() || hyp_poses.empty()) {
+      err_ = "[FoundationPose] TrackMulti: inconsistent arguments";
+      return false;
+    }
+    std::vector<const char *> names;
+    for (const auto &n : target_names) names.push_back(n.c_str());
+    out_poses.resize(hyp_poses.size());
+    return ok(fp_track_multi(h_, rgb.data, depth.data, FP_HOST, depth.rows, depth.cols, (int)hyp_poses.size(), hyp_poses[0].data(), names.data(),
+                             (int)refine_itr, out_poses[0].data()));
+  }
 
   // ---- options the reference does not have ----
   // element type of both networks: FP_PREC_F16 (default, the reference's TensorRT --fp16), FP_PREC_BF16, FP_PREC_FP8 (after CalibrateFp8 / SetCalibration)

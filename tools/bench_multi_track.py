@@ -40,4 +40,16 @@ for K in [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]:
         for m in models: submit(m)
         for m in models: wait(m)
     print(f"        frame resident in HBM, all {K} in flight: {K * 100 / (time.perf_counter() - t0):.0f} tracks/s")
+    # fp_track_multi: the K objects as ONE batch of one model (geometry per object, one refine-net pass)
+    m0 = models[0]
+    hyps = np.tile(h16, (K, 1)); outs = np.zeros((K, 16), np.float32)
+    names = (C.c_char_p * K)(*[mesh.name.encode()] * K)
+    def multi():
+        m0._must(m0._L.fp_track_multi(m0.handle, C.c_void_p(rgb_d.data_ptr()), C.c_void_p(depth_d.data_ptr()), 1, H, Wd, K,
+                                      hyps.ctypes.data_as(C.c_void_p), C.cast(names, C.c_void_p), 1, outs.ctypes.data_as(C.c_void_p)))
+    for _ in range(5): multi()
+    t0 = time.perf_counter()
+    for _ in range(200): multi()
+    dt = (time.perf_counter() - t0) / 200
+    print(f"        fp_track_multi, {K} objects in one batch: {dt * 1e3:.3f} ms per call = {K / dt:.0f} tracks/s")
     for m in models: m.close()
