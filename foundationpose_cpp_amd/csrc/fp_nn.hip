@@ -3287,6 +3287,7 @@ FP_HOOK g_splitk_min_kt = 9;    // layers with fewer 128-byte K-steps never spli
 FP_HOOK g_splitk_deep = 1;      // split-K slices of at least 4 K-steps on conv_deep_kernel<128> (0 = conv_igemm_kernel<128>)
 FP_HOOK g_att_skv = 1;          // small attention grids on attention32_skv_kernel (keys split over the waves of a workgroup)
 FP_HOOK g_gemm_deep = 1;         // short-K layers of small problems on conv_deep_kernel<128> instead of the two-stage 128x128 tile
+FP_HOOK g_splitk_mid = 1;        // two split-K slices for long-K layers with 97..128 tiles (batches of ~8 objects)
 FP_HOOK g_small_deep = 18;     // small problems (Track): conv_deep_kernel<64> over ALL K-steps instead of split-K + reduce when K has at most this many 128-byte steps
 FP_HOOK g_att_variant = 1;     // 1 = attention32_kernel (8 = without the XCD remap); round-1 kernel: 2 remap + 16-B stores, 3 no XCD remap, 5 remap + 2-B stores, 7 neither
 
@@ -3340,7 +3341,13 @@ static int run_conv_dt(const Ctx &c, const char *tag, const ConvLayer &L, ConvPa
   auto plan_splitk = [&](int rows, int target) -> int {
     const int mt = (rows + 127) / 128;
     const int tiles = mt * (L.Cout % 128 == 0 ? L.Cout / 128 : L.Cout / 64);
-    if (tiles > 96 || KT < g_splitk_min_kt) return 0;
+    if (KT < g_splitk_min_kt) return 0;
+    if (tiles > 96) {
+      // a little above the split-K range (a batch of ~8 objects): long-K layers still leave half the chip idle for 72 K-steps;
+      // two slices per tile while the grid fits one round of the 256 CUs
+      if (!(g_splitk_mid && tiles <= 128 && KT >= 36)) return 0;
+      target = 2 * tiles;
+    }
     int S = std::min(std::max(target / tiles, 1), KT / 2);
     if (S <= 1) return 0;
     p.kt_per = (KT + S - 1) / S;
@@ -4042,6 +4049,7 @@ void fpt_set_gemm_kernel(int v) { fp::g_gemm_kernel = v; }
 void fpt_set_rem_kernel(int v) { fp::g_rem_kernel = v; }
 void fpt_set_rem_small(int v) { fp::g_rem_small = v; }
 void fpt_set_small_deep(int v) { fp::g_small_deep = v; }
+void fpt_set_splitk_mid(int v) { fp::g_splitk_mid = v; }
 void fpt_set_gemm_deep(int v) { fp::g_gemm_deep = v; }
 void fpt_set_att_skv(int v) { fp::g_att_skv = v; }
 void fpt_set_splitk_deep(int v) { fp::g_splitk_deep = v; }
