@@ -143,5 +143,18 @@ def use_test_lib() -> None:
     LIB_PATH = TEST_LIB_PATH
 
 
+_HIP = None
+
+
+def hip_runtime() -> C.CDLL:
+    """libamdhip64 (already mapped by the product library) for the few host-side copies api.py does itself"""
+    global _HIP
+    if _HIP is None:
+        _HIP = C.CDLL("libamdhip64.so")
+        _HIP.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        _HIP.hipMemcpy.restype = C.c_int
+    return _HIP
+
+
 def last_error() -> str:
     return (lib().fp_last_error() or b"").decode("utf-8", "replace")

@@ -124,6 +124,33 @@ class FoundationPose:
                                           target_name.encode(), refine_itr, _p(out)))
         return ok, (from_colmajor(out) if ok else None)
 
+    def register_detailed(self, rgb, depth, mask, target_name: str, refine_itr: int = 1):
+        """Register through the two ABI halves (`fp_register_shard_begin` over the whole grid + `fp_register_shard_finish`):
+        the same kernels as `Register`, but also hands back what the reference keeps internal (foundationpose.cpp:206-228):
+        -> (ok, pose[4,4], winner index, scores[N], refined poses[N,4,4], pooled score features[N,512])."""
+        rgb, depth, mask = self._frame(rgb, depth, mask)
+        if rgb is None:
+            return False, None, -1, None, None, None
+        n = self.num_hypotheses
+        feat, poses = C.c_void_p(), C.c_void_p()
+        if not self._ok(self._L.fp_register_shard_begin(self._h, _p(rgb), _p(depth), _p(mask), FP_HOST, depth.shape[0],
+                                                        depth.shape[1], target_name.encode(), refine_itr, 0, n,
+                                                        C.byref(feat), C.byref(poses))):
+            return False, None, -1, None, None, None
+        out = np.zeros(16, np.float32)
+        idx = C.c_int(-1)
+        scores = np.zeros(n, np.float32)
+        if not self._ok(self._L.fp_register_shard_finish(self._h, feat, poses, n, _p(out), C.byref(idx), _p(scores))):
+            return False, None, -1, None, None, None
+        refined = np.zeros((n, 16), np.float32)
+        feats = np.zeros((n, 512), np.float32)
+        hip = _lib.hip_runtime()
+        for dst, src in ((refined, poses), (feats, feat)):
+            rc = hip.hipMemcpy(_p(dst), src, dst.nbytes, 2)      # hipMemcpyDeviceToHost
+            if rc != 0:
+                raise FoundationPoseError(f"hipMemcpy failed ({rc})")
+        return True, from_colmajor(out), idx.value, scores, from_colmajor(refined), feats
+
     def Track(self, rgb, depth, hyp_pose, target_name: str, refine_itr: int = 1):
         """-> (ok, pose[4,4]).  foundationpose.hpp:59-64."""
         rgb, depth, _ = self._frame(rgb, depth, None)

@@ -65,7 +65,10 @@ def _mha(rng, st, prefix):
     st[f"{prefix}.out_proj.weight"], st[f"{prefix}.out_proj.bias"] = _linear(rng, EMBED, EMBED)
 
 
-def make_synthetic_state(kind: str, seed: int = 7) -> dict:
+def make_synthetic_state(kind: str, seed: int = 7, calibration: dict | None = None) -> dict:
+    """Seeded stand-in weights.  `calibration` (see `apply_calibration`) turns the plain draws into the DISCRIMINATING set the
+    parity tests use: same draws, re-centred / re-scaled stage by stage so that differences between hypotheses reach the
+    outputs (tests/golden/disc_calib_seed9.npz, produced by oracle/disc_weights.py)."""
     assert kind in ("refiner", "scorer")
     rng = np.random.default_rng(seed + (0 if kind == "refiner" else 1000))
     st: dict = {}
@@ -86,7 +89,32 @@ def make_synthetic_state(kind: str, seed: int = 7) -> dict:
         _mha(rng, st, "att")
         _mha(rng, st, "att_cross")
         st["linear.weight"], st["linear.bias"] = _linear(rng, 1, EMBED)
+    if calibration is not None:
+        apply_calibration(st, kind, calibration)
     return st
+
+
+def apply_calibration(st: dict, kind: str, calibration: dict) -> dict:
+    """Apply a calibration record to a state dict in place.  Keys are prefixed with the network kind:
+      "<kind>/<tensor name>"          replaces that tensor (BatchNorm running statistics, attention biases, output layers),
+      "<kind>/gain:<mha prefix>"      multiplies the W_q / W_k rows (first 2*EMBED) of `<mha prefix>.in_proj_weight`."""
+    for key, val in calibration.items():
+        k, _, name = key.partition("/")
+        if k != kind:
+            continue
+        val = np.asarray(val, np.float32)
+        if name.startswith("gain:"):
+            w = st[name[5:] + ".in_proj_weight"]
+            w[:2 * EMBED] = w[:2 * EMBED] * np.float32(val)
+        else:
+            assert name in st and st[name].shape == val.shape, (name, val.shape)
+            st[name] = val.copy()
+    return st
+
+
+def load_calibration(path: str) -> dict:
+    with np.load(path) as z:
+        return {k: z[k] for k in z.files}
 
 
 def fold_batchnorm(state: dict) -> dict:
@@ -143,8 +171,8 @@ def read_fpw(path: str) -> dict:
     return out
 
 
-def pack_synthetic(kind: str, path: str, seed: int = 7) -> dict:
-    st = make_synthetic_state(kind, seed)
+def pack_synthetic(kind: str, path: str, seed: int = 7, calibration: dict | None = None) -> dict:
+    st = make_synthetic_state(kind, seed, calibration)
     write_fpw(path, fold_batchnorm(st))
     return st
 

@@ -22,3 +22,26 @@ def syn_mesh():
 def syn_scene(syn_mesh):
     from foundationpose_cpp_amd import synthetic as syn
     return syn.make_scene(syn_mesh)
+
+
+DISC_SEED = 9
+
+
+@pytest.fixture(scope="session")
+def disc_cal():
+    """calibration record of the DISCRIMINATING synthetic weight set (oracle/disc_weights.py wrote it; numpy only to apply)"""
+    from foundationpose_cpp_amd import weights as W
+    return W.load_calibration(os.path.join(ROOT, "tests", "golden", f"disc_calib_seed{DISC_SEED}.npz"))
+
+
+@pytest.fixture(scope="session")
+def disc_nets(tmp_path_factory, disc_cal):
+    """(refiner.fpw, scorer.fpw, torch refiner, torch scorer) built from ONE state dict each -- outputs differ between
+    hypotheses by >= 30 % of their magnitude / score spread >= 0.5 (tests/test_disc_weights_cpu.py holds the oracle to that)"""
+    from foundationpose_cpp_amd import weights as W
+    from oracle import nets_torch as NT
+    d = tmp_path_factory.mktemp("wdisc")
+    rp, sp = str(d / "refiner.fpw"), str(d / "scorer.fpw")
+    rs = W.pack_synthetic("refiner", rp, DISC_SEED, disc_cal)
+    ss = W.pack_synthetic("scorer", sp, DISC_SEED, disc_cal)
+    return rp, sp, NT.build("refiner", rs), NT.build("scorer", ss)

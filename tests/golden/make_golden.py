@@ -8,7 +8,7 @@ networks) on the seeded synthetic scene of SURVEY.md §8d.  They pin the oracle 
 fixed target that does not depend on the oracle being importable; when real assets arrive (ONNX weights + the mustard
 sequence + a TensorRT pose log) they slot into the same file format.
 
-    python tests/golden/make_golden.py          # rewrites fp_golden_v1.npz (deterministic)
+    python tests/golden/make_golden.py          # rewrites fp_golden_v1.npz and fp_golden_disc_v1.npz (deterministic)
 """
 import hashlib
 import os
@@ -106,6 +106,29 @@ def main():
     out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "fp_golden_v1.npz")
     np.savez_compressed(out, **g)
     print(out, os.path.getsize(out) // 1024, "KiB;", len(g), "arrays")
+
+    # second weight set: the DISCRIMINATING one (plain draws of seed 9 + tests/golden/disc_calib_seed9.npz, written by
+    # `python -m oracle.disc_weights`), under which outputs differ between hypotheses -- 42 hypotheses (every 6th)
+    here = os.path.dirname(os.path.abspath(__file__))
+    cal = W.load_calibration(os.path.join(here, "disc_calib_seed9.npz"))
+    refiner = NT.build("refiner", W.make_synthetic_state("refiner", 9, cal)).eval()
+    scorer = NT.build("scorer", W.make_synthetic_state("scorer", 9, cal)).eval()
+    d = {"seed": np.int32(9), "hyp_step": np.int32(6)}
+    with torch.no_grad():
+        sel = poses[::6]
+        a = fo.render(om, sel, K, hw, 1.2)
+        b = fo.crop(scene.rgb, scene.depth, K, sel, 1.2, diam)
+        t, r = refiner(torch.from_numpy(a), torch.from_numpy(b))
+        d["refiner_trans"], d["refiner_rot"] = t.numpy().astype(np.float32), r.numpy().astype(np.float32)
+        ref = fo.refine_post_process(sel, t.numpy(), r.numpy(), diam)
+        d["refined_poses"] = ref.astype(np.float32)
+        a = fo.render(om, ref, K, hw, 1.1)
+        b = fo.crop(scene.rgb, scene.depth, K, ref, 1.1, diam)
+        sc = scorer(torch.from_numpy(a), torch.from_numpy(b)).numpy().reshape(-1)
+        d["scores"], d["best"] = sc.astype(np.float32), np.int32(fo.argmax(sc))
+    out = os.path.join(here, "fp_golden_disc_v1.npz")
+    np.savez_compressed(out, **d)
+    print(out, os.path.getsize(out) // 1024, "KiB;", len(d), "arrays; score std %.3f, top gap %.3f" % (sc.std(), np.sort(sc)[-1] - np.sort(sc)[-2]))
 
 
 if __name__ == "__main__":

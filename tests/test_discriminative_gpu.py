@@ -1,0 +1,263 @@
+"""Network WIRING parity under the discriminating synthetic weights (tests/golden/disc_calib_seed9.npz, oracle/disc_weights.py).
+
+Under the plain draws both networks are near-constant functions of their input (score spread 3e-5 over the 252 hypotheses), so
+the end-to-end checks of tests/test_nn_gpu.py are common-mode checks.  Here the oracle's outputs differ between hypotheses by
+>= 30 % of their magnitude (refiner) / a score spread >= 0.5 with a unique maximum, and every comparison is made on DE-MEANED
+outputs against the SPREAD of the oracle's outputs -- a wrong softmax scale in `att_cross`, a hypothesis row mixed up inside the
+trunk or a mis-broadcast shared observed crop moves these by O(spread) (reference call sites
+detection_6d_foundationpose/src/foundationpose.cpp:206-220,432-446).
+
+Tolerances are written against what the arithmetic allows: the between-hypothesis signal of a random-feature network pooled
+over 400 tokens is ~2 % of the feature scale, i.e. f16 (2^-11 per element) resolves it to 2-3 % of the spread, bf16 (2^-8) to
+10-30 %, FP8 e4m3 (2^-4) not at all (its refined poses land 4 deg / 13 mm from the oracle's under these output layers, which
+amplify the pooled token ~40x; FP8 therefore keeps its per-layer tests and the plain-weight pose checks of
+tests/test_precision_gpu.py) -- measured by tools/disc_noise.py, DESIGN.md section 2.
+Rendering is discontinuous in the pose (edge pixels flip), so a pose perturbed by 0.1 mm already moves the scores by ~30 % of
+their spread: the end-to-end Register check is therefore TEACHER-FORCED -- the oracle scores the poses the HIP refiner produced.
+"""
+import numpy as np
+import pytest
+import torch
+
+from foundationpose_cpp_amd import FoundationPose, synthetic as syn
+from foundationpose_cpp_amd.api import FP_PREC_BF16, FP_PREC_F16
+from oracle import fp_oracle as fo
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def model(disc_nets, syn_mesh):
+    m = FoundationPose(syn_mesh, syn.intrinsics(), disc_nets[0], disc_nets[1])
+    yield m
+    m.close()
+
+
+def _dm(x):
+    return x - x.mean(0, keepdims=True)
+
+
+def _blobs(model, mesh, scene, step, ratio, jitter=False):
+    model.upload_frame(scene.rgb, scene.depth)
+    poses = model.get_hyp_poses(scene.mask)[::step]
+    if jitter:     # sampler poses share ONE translation (= one observed crop); give every hypothesis its own
+        poses = np.stack([syn.perturb_pose(p, deg=3.0, trans=0.006, seed=100 + i) for i, p in enumerate(poses)])
+    return (poses,) + model.render_and_transform(mesh.name, poses, ratio)
+
+
+def _torch(net, a, b):
+    with torch.no_grad():
+        out = net(torch.from_numpy(a), torch.from_numpy(b))
+    return [o.numpy() for o in out] if isinstance(out, tuple) else out.numpy()
+
+
+def _oracle_blobs(mesh, scene, poses16, ratio):
+    return (fo.render(fo.OracleMesh(mesh), poses16, scene.K, scene.depth.shape, ratio),
+            fo.crop(scene.rgb, scene.depth, scene.K, poses16, ratio, mesh.diameter))
+
+
+def _rot_err_deg(a, b):
+    """rotation angle between poses [N,4,4]; via |R_a - R_b|_F = 2*sqrt(2)*sin(angle/2) in float64 (arccos of a float32 trace
+    resolves only 0.03 deg)"""
+    d = np.linalg.norm((a[:, :3, :3].astype(np.float64) - b[:, :3, :3].astype(np.float64)).reshape(len(a), 9), axis=1)
+    return np.degrees(2 * np.arcsin(np.clip(d / (2 * np.sqrt(2)), 0, 1)))
+
+
+@pytest.mark.parametrize("jitter", [False, True])
+def test_refiner_rows_follow_torch(model, disc_nets, syn_mesh, syn_scene, jitter):
+    """jitter: every hypothesis has its own translation, i.e. its own observed crop (what refine iterations >= 1 and Track see)"""
+    _, a, b = _blobs(model, syn_mesh, syn_scene, 6, 1.2, jitter)
+    assert (np.abs(b[1:] - b[:1]).max() > 0.1) == jitter
+    trans, rot = model.refiner_infer(a, b)
+    rt, rr = _torch(disc_nets[2], a, b)
+    for got, ref in ((trans, rt), (rot, rr)):
+        spread = ref.std(0)
+        assert (spread >= 0.3 * np.sqrt((ref ** 2).mean(0))).all()          # the fixture discriminates
+        err = _dm(got) - _dm(ref)
+        # f16: rms <= 2 % of the between-hypothesis spread, no single row off by more than 5 %
+        assert (np.sqrt((err ** 2).mean(0)) <= 0.02 * spread).all(), (np.sqrt((err ** 2).mean(0)) / spread)
+        assert (np.abs(err).max(0) <= 0.05 * spread).all(), (np.abs(err).max(0) / spread)
+        # and the common mode itself (the output layer cancels a pooled token ~40x the spread against its bias): 10 % of the spread
+        assert (np.abs(got.mean(0) - ref.mean(0)) <= 0.10 * spread).all()
+
+
+def test_scorer_scores_follow_torch(model, disc_nets, syn_mesh, syn_scene):
+    _, a, b = _blobs(model, syn_mesh, syn_scene, 6, 1.1)
+    scores = model.scorer_infer(a, b)
+    ref = _torch(disc_nets[3], a, b)
+    o = np.sort(ref)[::-1]
+    assert ref.std() >= 0.5 and o[0] - o[1] >= 1e-2, (ref.std(), o[:3])
+    err = _dm(scores) - _dm(ref)
+    # f16, measured (tools/disc_noise.py): rms 2.3 %, worst row 6.5 % of the spread
+    assert np.sqrt((err ** 2).mean()) <= 0.03 * ref.std() and np.abs(err).max() <= 0.08 * ref.std(), np.abs(err).max() / ref.std()
+    assert int(scores.argmax()) == int(ref.argmax())
+    assert np.corrcoef(np.argsort(np.argsort(scores)), np.argsort(np.argsort(ref)))[0, 1] > 0.995
+
+
+def test_one_perturbed_crop_moves_exactly_what_it_must(model, disc_nets, syn_mesh, syn_scene):
+    """replace ONE hypothesis' rendered crop: only its refiner row may change (bit-exact elsewhere) and it changes as in torch;
+    through `att_cross` ALL scores move, as in torch"""
+    poses, a, b = _blobs(model, syn_mesh, syn_scene, 6, 1.2)
+    j = 17
+    other = syn.perturb_pose(poses[j], deg=25.0, trans=0.004, seed=3)
+    a2 = a.copy()
+    a2[j] = model.render_and_transform(syn_mesh.name, other[None], 1.2)[0][0]
+    assert np.abs(a2[j] - a[j]).mean() > 1e-2
+    t1, r1 = model.refiner_infer(a, b)
+    t2, r2 = model.refiner_infer(a2, b)
+    keep = np.arange(len(a)) != j
+    assert np.array_equal(t1[keep], t2[keep]) and np.array_equal(r1[keep], r2[keep])
+    rt1, rr1 = _torch(disc_nets[2], a[j:j + 1], b[j:j + 1])
+    rt2, rr2 = _torch(disc_nets[2], a2[j:j + 1], b[j:j + 1])
+    for d_hip, d_ref in ((t2[j] - t1[j], (rt2 - rt1)[0]), (r2[j] - r1[j], (rr2 - rr1)[0])):
+        assert np.abs(d_ref).max() > 1e-2                                   # a real change ...
+        assert np.abs(d_hip - d_ref).max() <= 0.05 * np.abs(d_ref).max(), (d_hip, d_ref)   # ... tracked to 5 %
+    # scorer (1.1 crops; same perturbation)
+    _, a, b = _blobs(model, syn_mesh, syn_scene, 6, 1.1)
+    a2 = a.copy()
+    a2[j] = model.render_and_transform(syn_mesh.name, other[None], 1.1)[0][0]
+    s1, s2 = model.scorer_infer(a, b), model.scorer_infer(a2, b)
+    o1, o2 = _torch(disc_nets[3], a, b), _torch(disc_nets[3], a2, b)
+    d_hip, d_ref = s2 - s1, o2 - o1
+    assert np.abs(d_ref[keep]).max() >= 1e-2 and (np.abs(d_ref[keep]) > 1e-4).mean() > 0.9, "cross attention must couple the rows"
+    assert np.abs(d_hip - d_ref).max() <= 0.08 * o1.std(), (np.abs(d_hip - d_ref).max(), o1.std())
+    assert np.abs(d_hip[keep] - d_ref[keep]).max() <= 0.15 * np.abs(d_ref[keep]).max() + 0.01 * o1.std()
+
+
+def _oracle_refine(disc_nets, mesh, scene, inplane_step=60, refine_itr=1):
+    """the oracle's first half of Register: sampler poses -> refined poses; also the (last) network outputs"""
+    p0 = fo.get_hyp_poses(scene.depth, scene.mask, scene.K, inplane_step=inplane_step)
+    p = p0
+    for _ in range(refine_itr):
+        t, r = _torch(disc_nets[2], *_oracle_blobs(mesh, scene, p, 1.2))
+        p = fo.refine_post_process(p, t, r, mesh.diameter)
+    return p0, t, r, p
+
+
+@pytest.fixture(scope="module")
+def oracle_refined(disc_nets, syn_mesh, syn_scene):
+    """Register(252), refine_itr = 1 (shared with the precision variants)"""
+    return _oracle_refine(disc_nets, syn_mesh, syn_scene)
+
+
+def _register_vs_oracle(model, disc_nets, mesh, scene, oracle_refined, refine_itr=1):
+    """-> (winner index, HIP scores, teacher-forced oracle scores, translation / rotation error of the refined poses as
+    fractions of the between-hypothesis spread of the refinement deltas, correlation of the deltas)"""
+    ok, pose, idx, scores, refined, feats = model.register_detailed(scene.rgb, scene.depth, scene.mask, mesh.name, refine_itr)
+    assert ok, model.last_error
+    np.testing.assert_array_equal(pose, refined[idx])                       # the returned pose IS the winner's refined pose
+    p0, ref = syn.from_colmajor(oracle_refined[0]), syn.from_colmajor(oracle_refined[3])
+    # first half: the 252 refined poses (first iteration = the shared-observed-crop path of fp_api.hip refine_iteration)
+    d_ref, d_hip = ref[:, :3, 3] - p0[:, :3, 3], refined[:, :3, 3] - p0[:, :3, 3]
+    spread_t = np.linalg.norm(d_ref.std(0))
+    spread_r = _rot_err_deg(ref, p0).std() * np.sqrt(3)                     # rotation deltas, degrees (per-axis std x sqrt 3)
+    assert spread_t > 2e-3 and spread_r > 0.5                               # the deltas differ between hypotheses (mm / degrees)
+    e_t = np.linalg.norm(refined[:, :3, 3] - ref[:, :3, 3], axis=1).max() / spread_t
+    e_r = _rot_err_deg(refined, ref).max() / spread_r
+    corr = min(np.corrcoef(d_hip[:, k], d_ref[:, k])[0, 1] for k in range(3))
+    # second half, teacher-forced: the oracle renders + scores the poses the HIP refiner produced
+    os_ = _torch(disc_nets[3], *_oracle_blobs(mesh, scene, syn.to_colmajor(refined), 1.1))
+    return idx, scores, os_, e_t, e_r, corr
+
+
+def _rank_corr(a, b):
+    return np.corrcoef(np.argsort(np.argsort(a)), np.argsort(np.argsort(b)))[0, 1]
+
+
+def test_register_252_winner_index_and_all_scores(model, disc_nets, syn_mesh, syn_scene, oracle_refined):
+    model.set_precision(FP_PREC_F16)
+    idx, scores, os_, e_t, e_r, corr = _register_vs_oracle(model, disc_nets, syn_mesh, syn_scene, oracle_refined)
+    # every refined pose within 8 % of the spread of the refinement deltas (f16 resolves the pooled signal to 2-3 % rms)
+    assert e_t <= 0.08 and e_r <= 0.08 and corr > 0.999, (e_t, e_r, corr)
+    o = np.sort(os_)[::-1]
+    assert os_.std() >= 0.5 and o[0] - o[1] >= 1e-2, (os_.std(), o[:3])
+    err = _dm(scores) - _dm(os_)
+    assert np.sqrt((err ** 2).mean()) <= 0.03 * os_.std() and np.abs(err).max() <= 0.10 * os_.std(), (np.abs(err).max() / os_.std())
+    assert idx == int(os_.argmax()) == fo.argmax(os_)
+    assert _rank_corr(scores, os_) > 0.999
+
+
+@pytest.mark.parametrize("steps", [1, 2])
+def test_register_mid_sized_batches_winner_index(model, disc_nets, syn_mesh, syn_scene, steps):
+    """42 / 84 hypotheses (in-plane steps 1 / 2): the batch sizes where the schedule choice changes layer by layer (resident-halo
+    kernels above ~32 hypotheses, implicit-GEMM tiles below, split-K off) -- same bar as the 252 case"""
+    model.set_precision(FP_PREC_F16)
+    model.set_inplane_steps(steps)
+    try:
+        assert model.num_hypotheses == 42 * steps
+        orc = _oracle_refine(disc_nets, syn_mesh, syn_scene, inplane_step=360 // steps)
+        idx, scores, os_, e_t, e_r, corr = _register_vs_oracle(model, disc_nets, syn_mesh, syn_scene, orc)
+    finally:
+        model.set_inplane_steps(6)
+    assert e_t <= 0.08 and e_r <= 0.08 and corr > 0.999, (e_t, e_r, corr)
+    err = _dm(scores) - _dm(os_)
+    assert np.sqrt((err ** 2).mean()) <= 0.03 * os_.std() and np.abs(err).max() <= 0.10 * os_.std(), (np.abs(err).max() / os_.std())
+    o = np.sort(os_)[::-1]
+    assert idx == int(os_.argmax()) or (o[0] - o[1] < 0.10 * os_.std() and idx in np.argsort(-os_)[:2])
+    assert _rank_corr(scores, os_) > 0.995
+
+
+def test_register_two_refine_iterations(model, disc_nets, syn_mesh, syn_scene):
+    """refine_itr = 2: iteration 0 takes the shared-observed-crop path, iteration 1 the per-hypothesis crops.  The second
+    iteration starts from poses that already differ from the oracle's by the f16 noise of the first, and rendering is
+    discontinuous in the pose (0.1 mm moves the refiner outputs by 13-25 % of their spread, tools/disc_noise.py): measured, the
+    worst of the 252 refined poses is a whole spread away and the deltas correlate at 0.98.  The bar here is therefore the
+    correlation (a mixed-up row or crop gives ~0); the per-hypothesis-crop path itself is held to the f16 bar by
+    test_refiner_rows_follow_torch (poses with different translations), and the scores are teacher-forced as everywhere"""
+    model.set_precision(FP_PREC_F16)
+    orc = _oracle_refine(disc_nets, syn_mesh, syn_scene, refine_itr=2)
+    idx, scores, os_, e_t, e_r, corr = _register_vs_oracle(model, disc_nets, syn_mesh, syn_scene, orc, refine_itr=2)
+    assert corr > 0.97 and e_t < 1.5 and e_r < 1.5, (e_t, e_r, corr)
+    err = _dm(scores) - _dm(os_)
+    assert np.sqrt((err ** 2).mean()) <= 0.03 * os_.std() and np.abs(err).max() <= 0.10 * os_.std(), (np.abs(err).max() / os_.std())
+    o = np.sort(os_)[::-1]
+    assert idx == int(os_.argmax()) or (o[0] - o[1] < 0.10 * os_.std() and idx in np.argsort(-os_)[:2])
+
+
+def test_register_252_bf16_winner_in_top3(model, disc_nets, syn_mesh, syn_scene, oracle_refined):
+    """bf16 (8-bit mantissa) resolves the pooled between-hypothesis signal to 10-30 % of the spread and its common-mode error is
+    amplified by the output layers like the signal: the deltas must still CORRELATE with the oracle's, and the winner must be
+    among the teacher-forced oracle's top 3"""
+    model.set_precision(FP_PREC_BF16)
+    try:
+        idx, scores, os_, e_t, e_r, corr = _register_vs_oracle(model, disc_nets, syn_mesh, syn_scene, oracle_refined)
+    finally:
+        model.set_precision(FP_PREC_F16)
+    assert corr > 0.9 and e_t < 1.5 and e_r < 1.5, (e_t, e_r, corr)
+    assert idx in np.argsort(-os_)[:3], (idx, np.argsort(-os_)[:5])
+    err = _dm(scores) - _dm(os_)
+    assert np.sqrt((err ** 2).mean()) <= 0.25 * os_.std(), np.sqrt((err ** 2).mean()) / os_.std()
+    assert _rank_corr(scores, os_) > 0.95
+
+
+def test_sharded_register_agrees_on_the_winner(model, disc_nets, syn_mesh, syn_scene):
+    """2- and 8-rank emulations of the packed shard protocol on one GPU (as tests/test_nn_gpu.py, but with scores that are not
+    tied): shards of 126 run the schedules of the full batch -> the same winner and pose as the unsharded Register; shards of 32
+    take other schedules (fp32 summation order differs) -> every element of every row's pooled feature within 20 % of the
+    between-hypothesis spread (rms 2 %) and the winner among the unsharded top 3"""
+    from foundationpose_cpp_amd.distributed import HipShardBackend, shard_range
+    model.set_precision(FP_PREC_F16)
+    ok, pose, idx, scores, refined, feats = model.register_detailed(syn_scene.rgb, syn_scene.depth, syn_scene.mask, syn_mesh.name)
+    assert ok
+    dev = torch.device("cuda", 0)
+    rgb, depth, mask = (torch.from_numpy(x).to(dev) for x in (syn_scene.rgb, syn_scene.depth, syn_scene.mask))
+    be = HipShardBackend(model, dev)
+    for world in (2, 8):
+        per = -(-252 // world)
+        packed, gathered = be.buffers(per, world)
+        for r in range(world):
+            b0, c = shard_range(252, world, r)
+            be.shard_begin_packed(rgb, depth, mask, 480, 640, syn_mesh.name, 1, b0, c, packed, per)
+            be.before_collective()
+            gathered[r * per:(r + 1) * per].copy_(packed)
+            be.after_collective()
+        p16, idx_w = be.shard_finish_packed(gathered, 252)
+        rows = gathered[:252].cpu().numpy()
+        if world == 2:
+            assert idx_w == idx
+            np.testing.assert_allclose(syn.from_colmajor(p16), pose, atol=1e-6)
+        else:
+            spread = _dm(feats).std()
+            d = rows[:, :512] - feats
+            assert np.abs(d).max() <= 0.2 * spread and np.sqrt((d ** 2).mean()) <= 0.02 * spread, (np.abs(d).max() / spread, np.sqrt((d ** 2).mean()) / spread)
+            assert idx_w in np.argsort(-scores)[:3], (idx_w, np.argsort(-scores)[:5])

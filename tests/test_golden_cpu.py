@@ -85,3 +85,21 @@ def test_network_and_pipeline_vectors(gold, syn_mesh, syn_scene, tmp_path):
                        torch.from_numpy(fo.crop(syn_scene.rgb, syn_scene.depth, K, hyp, 1.2, diam)))
         np.testing.assert_allclose(fo.refine_post_process(hyp, t.numpy(), r.numpy(), diam), gold["track_out"], rtol=0, atol=2e-6)
     np.testing.assert_array_equal(syn.to_colmajor(syn.perturb_pose(syn_scene.gt_pose)[None]), hyp)
+
+
+def test_discriminating_weight_set_vectors(disc_nets, syn_mesh, syn_scene):
+    """tests/golden/fp_golden_disc_v1.npz: 42 hypotheses under the discriminating weights (make_golden.py wrote it)"""
+    g = np.load(os.path.join(os.path.dirname(GOLD), "fp_golden_disc_v1.npz"))
+    om, K, hw, diam = fo.OracleMesh(syn_mesh), syn_scene.K, syn_scene.depth.shape, syn_mesh.diameter
+    sel = fo.get_hyp_poses(syn_scene.depth, syn_scene.mask, K)[::int(g["hyp_step"])]
+    with torch.no_grad():
+        t, r = disc_nets[2](torch.from_numpy(fo.render(om, sel, K, hw, 1.2)),
+                            torch.from_numpy(fo.crop(syn_scene.rgb, syn_scene.depth, K, sel, 1.2, diam)))
+        # fp32 torch on another host / thread count: 1e-3 of the between-hypothesis spread
+        for got, ref in ((t.numpy(), g["refiner_trans"]), (r.numpy(), g["refiner_rot"])):
+            assert np.abs(got - ref).max() <= 2e-3 * ref.std(0).min(), np.abs(got - ref).max() / ref.std(0).min()
+        ref = g["refined_poses"]
+        sc = disc_nets[3](torch.from_numpy(fo.render(om, ref, K, hw, 1.1)),
+                          torch.from_numpy(fo.crop(syn_scene.rgb, syn_scene.depth, K, ref, 1.1, diam))).numpy()
+    assert np.abs(sc - g["scores"]).max() <= 2e-3 * g["scores"].std()
+    assert g["scores"].std() >= 0.5 and fo.argmax(g["scores"]) == int(g["best"])
