@@ -14,6 +14,7 @@
 #include <cstring>
 #include <map>
 #include <memory>
+#include <mutex>
 
 #include "fp_internal.h"
 #include "fp_nn.h"
@@ -378,6 +379,14 @@ static void drop_graph(fp_model::GraphSlot &g) {
   g.exec = nullptr; g.graph = nullptr; g.eager_calls = 0;
 }
 
+// every captured body bakes the float model, the precision and (FP8) the per-tensor activation scales in as kernel arguments:
+// anything that changes one of them drops ALL three graphs
+static void invalidate_graphs(fp_model *m) {
+  drop_graph(m->tg);
+  drop_graph(m->rg);
+  drop_graph(m->mg);
+}
+
 // Runs `body` (a chain of launches on m->stream reading / writing only model-owned buffers): eagerly the first time a
 // (target, H, W, itr, n) configuration is seen, captured into a hipGraph on the second call once allocations have
 // settled (the graph bakes buffer addresses, so it is keyed by g_alloc_epoch), replayed from then on.
@@ -426,14 +435,42 @@ __global__ void unpack_shards_kernel(const float *__restrict__ gathered, int n_t
   else poses[(size_t)r * 16 + (c - 512)] = gathered[i];
 }
 
+// Escape hatch (off by default): FP_SERIALIZE_MODELS=1 in the environment makes the synchronous entry points of ALL models in the
+// process (Register, Track, fp_track_multi, FP8 calibration) take one process-wide lock for their whole duration, so that kernels
+// of two models are never co-resident.  This is the round-1 behaviour; it exists because the packed-f32 erratum behind the
+// removal of that lock was mitigated, not reproduced in isolation.  The pipelined fp_track_submit /
+// fp_track_wait pair is not covered (it exists to overlap models).
+struct SerialGuard {
+  std::unique_lock<std::recursive_mutex> lk;
+  SerialGuard() {
+    static const bool on = [] { const char *e = std::getenv("FP_SERIALIZE_MODELS"); return e && *e && *e != '0'; }();
+    static std::recursive_mutex mu;
+    if (on) lk = std::unique_lock<std::recursive_mutex>(mu);
+  }
+};
+
+// Exception barrier of the C ABI: every entry point below that can allocate on the host (std::vector / std::string / new) is a
+// function-try-block ending in one of these; nothing is thrown across the extern "C" boundary.
+static int caught_exception() noexcept {
+  try {
+    try { throw; }
+    catch (const std::bad_alloc &) { set_error("[FoundationPose] out of host memory"); }
+    catch (const std::exception &e) { set_error(std::string("[FoundationPose] internal error: ") + e.what()); }
+    catch (...) { set_error("[FoundationPose] internal error (unknown exception)"); }
+  } catch (...) {
+  }
+  return 1;
+}
+#define FP_CATCH_INT catch (...) { return caught_exception(); }
+#define FP_CATCH_PTR catch (...) { caught_exception(); return nullptr; }
+
 extern "C" {
 
 #ifdef FP_TEST_HOOKS
 // A/B hook: hipGraph replay of the Track / Register bodies on or off for one model
 int fpt_model_use_graphs(fp_model *m, int on) {
   m->use_graphs = on != 0;
-  drop_graph(m->tg);
-  drop_graph(m->rg);
+  invalidate_graphs(m);
   return 0;
 }
 
@@ -537,7 +574,7 @@ static OutMode nn_mode(const fp_model *m) {
 }
 
 fp_model *fp_create(const fp_mesh *meshes, int n_meshes, const float K[9], const char *refiner_weights,
-                    const char *scorer_weights, int max_h, int max_w) {
+                    const char *scorer_weights, int max_h, int max_w) try {
   if (!meshes || n_meshes <= 0 || !K) { set_error("[FoundationPose] fp_create: invalid arguments"); return nullptr; }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
@@ -598,14 +635,12 @@ fp_model *fp_create(const fp_mesh *meshes, int n_meshes, const float K[9], const
   if (select_precision(m.get(), PREC_F16)) { fp_destroy(m.release()); return nullptr; }
   if (hipMalloc((void **)&m->argmax_dev, sizeof(int)) != hipSuccess) { fp_destroy(m.release()); return nullptr; }
   return m.release();
-}
+} FP_CATCH_PTR
 
 void fp_destroy(fp_model *m) {
   if (!m) return;
   if (m->stream) (void)hipStreamSynchronize(m->stream);
-  drop_graph(m->tg);
-  drop_graph(m->rg);
-  drop_graph(m->mg);
+  invalidate_graphs(m);
   if (m->multi_io) (void)hipHostFree(m->multi_io);
   m->prof.reset();
   for (auto &t : m->targets) {
@@ -632,18 +667,18 @@ void fp_destroy(fp_model *m) {
   delete m;
 }
 
-int fp_set_inplane_steps(fp_model *m, int steps) {
+int fp_set_inplane_steps(fp_model *m, int steps) try {
   FP_CHECK(m && steps >= 1 && steps <= 360, "[FoundationPose] fp_set_inplane_steps: invalid arguments");
   FP_HIP_OK(hipStreamSynchronize(m->stream));
   return set_rotation_grid(m, steps);
-}
+} FP_CATCH_INT
 int fp_num_hypotheses(const fp_model *m) { return m ? m->n_hyp() : 0; }
 void *fp_stream(fp_model *m) { return m ? (void *)m->stream : nullptr; }
-int fp_synchronize(fp_model *m) {
+int fp_synchronize(fp_model *m) try {
   FP_CHECK(m, "null model");
   FP_HIP_OK(hipStreamSynchronize(m->stream));
   return 0;
-}
+} FP_CATCH_INT
 
 // asynchronous: the caller of this helper synchronises m->stream before the host frame can go away
 // row0 / row1 (host frames): only rows [row0, row1) are needed by the caller (Track: the observed-crop window) -- the rest of the
@@ -689,13 +724,13 @@ static int upload_frame_async(fp_model *m, const void *rgb, const void *depth, i
   return 0;
 }
 
-int fp_upload_frame(fp_model *m, const void *rgb, const void *depth, int memspace, int H, int W) {
+int fp_upload_frame(fp_model *m, const void *rgb, const void *depth, int memspace, int H, int W) try {
   if (upload_frame_async(m, rgb, depth, memspace, H, W)) return 1;
   if (memspace == FP_HOST) FP_HIP_OK(hipStreamSynchronize(m->stream));  // the host frame may be released on return
   return 0;
-}
+} FP_CATCH_INT
 
-int fp_get_xyz_map(fp_model *m, float *xyz_host) {
+int fp_get_xyz_map(fp_model *m, float *xyz_host) try {
   FP_CHECK(m && m->depth && xyz_host, "[FoundationPose] fp_get_xyz_map: no frame uploaded");
   FP_CHECK(!m->frame_partial, "[FoundationPose] the last call (Track from a host frame) uploaded only its crop window: call fp_upload_frame first");
   size_t px = (size_t)m->H * m->W;
@@ -704,7 +739,7 @@ int fp_get_xyz_map(fp_model *m, float *xyz_host) {
   FP_HIP_OK(hipMemcpyAsync(xyz_host, m->xyz, px * 12, hipMemcpyDeviceToHost, m->stream));
   FP_HIP_OK(hipStreamSynchronize(m->stream));
   return 0;
-}
+} FP_CATCH_INT
 
 static int run_depth_filters(fp_model *m) {
   {
@@ -718,7 +753,7 @@ static int run_depth_filters(fp_model *m) {
   return 0;
 }
 
-int fp_filter_depth(fp_model *m, float *eroded_out, float *bilateral_out) {
+int fp_filter_depth(fp_model *m, float *eroded_out, float *bilateral_out) try {
   FP_CHECK(m && m->depth, "[FoundationPose] fp_filter_depth: no frame uploaded");
   FP_CHECK(!m->frame_partial, "[FoundationPose] the last call (Track from a host frame) uploaded only its crop window: call fp_upload_frame first");
   size_t px = (size_t)m->H * m->W;
@@ -727,7 +762,7 @@ int fp_filter_depth(fp_model *m, float *eroded_out, float *bilateral_out) {
   if (bilateral_out) FP_HIP_OK(hipMemcpyAsync(bilateral_out, m->bilat, px * 4, hipMemcpyDeviceToHost, m->stream));
   FP_HIP_OK(hipStreamSynchronize(m->stream));
   return 0;
-}
+} FP_CATCH_INT
 
 // MakeRotationGrid result, host + device copies (device: the sampler kernel stamps the translation into it)
 static int set_rotation_grid(fp_model *m, int steps) {
@@ -785,7 +820,7 @@ static int sampler_status(fp_model *m) {
   return 0;
 }
 
-int fp_get_hyp_poses(fp_model *m, const void *mask, int memspace, float *poses_out, int *n_out) {
+int fp_get_hyp_poses(fp_model *m, const void *mask, int memspace, float *poses_out, int *n_out) try {
   FP_CHECK(m && poses_out, "[FoundationPose] fp_get_hyp_poses: invalid arguments");
   const int n = m->n_hyp();
   if (sample_hypotheses_async(m, m->targets.empty() ? nullptr : &m->targets[0], mask, memspace, 0, n)) return 1;
@@ -794,7 +829,7 @@ int fp_get_hyp_poses(fp_model *m, const void *mask, int memspace, float *poses_o
   FP_HIP_OK(hipStreamSynchronize(m->stream));
   if (n_out) *n_out = n;
   return 0;
-}
+} FP_CATCH_INT
 
 static int upload_poses(fp_model *m, Target *t, const float *poses, int N) {
   if (ensure_capacity(m, N, (size_t)t->mesh.V)) return 1;
@@ -812,7 +847,7 @@ static int upload_poses(fp_model *m, Target *t, const float *poses, int N) {
 }
 
 int fp_render_and_transform(fp_model *m, const char *target_name, const float *poses, int N, float crop_ratio,
-                            float *render_out, float *transf_out, int out_memspace) {
+                            float *render_out, float *transf_out, int out_memspace) try {
   FP_CHECK(m && poses && N > 0, "[FoundationposeRender] The transform matrix vector is empty");
   FP_CHECK(m->depth != nullptr, "[FoundationPose] fp_render_and_transform: no frame uploaded");
   FP_CHECK(!m->frame_partial, "[FoundationPose] the last call (Track from a host frame) uploaded only its crop window: call fp_upload_frame first");
@@ -833,10 +868,10 @@ int fp_render_and_transform(fp_model *m, const char *target_name, const float *p
   }
   FP_HIP_OK(hipStreamSynchronize(m->stream));
   return 0;
-}
+} FP_CATCH_INT
 
 int fp_debug_rasterize(fp_model *m, const char *target_name, const float *poses, int N, float crop_ratio,
-                       int32_t *tri_id, float *rast_out) {
+                       int32_t *tri_id, float *rast_out) try {
   FP_CHECK(m && poses && N > 0, "[FoundationposeRender] The transform matrix vector is empty");
   FP_CHECK(m->H > 0, "[FoundationPose] fp_debug_rasterize: no frame uploaded (image size unknown)");
   Target *t = m->find(target_name ? target_name : "");
@@ -852,7 +887,7 @@ int fp_debug_rasterize(fp_model *m, const char *target_name, const float *poses,
   if (rast_out) FP_HIP_OK(hipMemcpyAsync(rast_out, m->dbg_rast, n * 16, hipMemcpyDeviceToHost, m->stream));
   FP_HIP_OK(hipStreamSynchronize(m->stream));
   return 0;
-}
+} FP_CATCH_INT
 
 // blob-mode network entry points: f32 NHWC [N,160,160,6] -> packed fp16 input
 static int pack_blobs(fp_model *m, const float *render_input, const float *transf_input, int memspace, int N) {
@@ -872,7 +907,7 @@ static int pack_blobs(fp_model *m, const float *render_input, const float *trans
 }
 
 int fp_refiner_infer(fp_model *m, const float *render_input, const float *transf_input, int memspace, int N,
-                     float *trans_out, float *rot_out) {
+                     float *trans_out, float *rot_out) try {
   FP_CHECK(m && m->refiner, "[FoundationPose] refiner weights not loaded");
   if (pack_blobs(m, render_input, transf_input, memspace, N)) return 1;
   if (refiner_forward(m->stream, &m->prof, m->refiner, m->ws, m->nn_in, N, m->trans_dev, m->rot_dev)) return 1;
@@ -880,10 +915,10 @@ int fp_refiner_infer(fp_model *m, const float *render_input, const float *transf
   FP_HIP_OK(hipMemcpyAsync(rot_out, m->rot_dev, (size_t)N * 12, hipMemcpyDeviceToHost, m->stream));
   FP_HIP_OK(hipStreamSynchronize(m->stream));
   return 0;
-}
+} FP_CATCH_INT
 
 int fp_scorer_infer(fp_model *m, const float *render_input, const float *transf_input, int memspace, int N,
-                    float *scores_out) {
+                    float *scores_out) try {
   FP_CHECK(m && m->scorer, "[FoundationPose] scorer weights not loaded");
   if (pack_blobs(m, render_input, transf_input, memspace, N)) return 1;
   if (scorer_features(m->stream, &m->prof, m->scorer, m->ws, m->nn_in, N, m->feat_dev)) return 1;
@@ -891,10 +926,10 @@ int fp_scorer_infer(fp_model *m, const float *render_input, const float *transf_
   FP_HIP_OK(hipMemcpyAsync(scores_out, m->scores_dev, (size_t)N * 4, hipMemcpyDeviceToHost, m->stream));
   FP_HIP_OK(hipStreamSynchronize(m->stream));
   return 0;
-}
+} FP_CATCH_INT
 
 int fp_refine_post_process(fp_model *m, const char *target_name, const float *poses, const float *trans,
-                           const float *rot, int N, float *poses_out) {
+                           const float *rot, int N, float *poses_out) try {
   FP_CHECK(m && poses && trans && rot && poses_out && N > 0, "[FoundationPose] fp_refine_post_process: invalid arguments");
   Target *t = m->find(target_name ? target_name : "");
   FP_CHECK(t != nullptr, "[FoundationPose] unknown target_name");
@@ -906,9 +941,9 @@ int fp_refine_post_process(fp_model *m, const char *target_name, const float *po
   FP_HIP_OK(hipMemcpyAsync(poses_out, m->poses_dev, (size_t)N * 64, hipMemcpyDeviceToHost, m->stream));
   FP_HIP_OK(hipStreamSynchronize(m->stream));
   return 0;
-}
+} FP_CATCH_INT
 
-int fp_argmax(fp_model *m, const float *scores, int N, int *index_out) {
+int fp_argmax(fp_model *m, const float *scores, int N, int *index_out) try {
   FP_CHECK(m && scores && index_out && N > 0, "[FoundationPose] fp_argmax: invalid arguments");
   if (ensure_capacity(m, N, 0)) return 1;
   FP_HIP_OK(hipMemcpyAsync(m->scores_dev, scores, (size_t)N * 4, hipMemcpyHostToDevice, m->stream));
@@ -916,7 +951,7 @@ int fp_argmax(fp_model *m, const float *scores, int N, int *index_out) {
   FP_HIP_OK(hipMemcpyAsync(index_out, m->argmax_dev, 4, hipMemcpyDeviceToHost, m->stream));
   FP_HIP_OK(hipStreamSynchronize(m->stream));
   return 0;
-}
+} FP_CATCH_INT
 
 // one refine iteration over m->poses_dev[0..N): RefinePreProcess + SyncInfer + RefinePostProcess, all on device
 // shared_b: all N poses have the same translation (fresh sampler output), so the observed crop -- which depends only on
@@ -946,7 +981,7 @@ static int refine_iteration(fp_model *m, Target *t, int N, bool shared_b, const 
 
 int fp_register_shard_begin(fp_model *m, const void *rgb, const void *depth, const void *mask, int memspace, int H,
                             int W, const char *target_name, int refine_itr, int shard_begin, int shard_count,
-                            float **feat_dev, float **poses_dev) {
+                            float **feat_dev, float **poses_dev) try {
   Target *t = nullptr;
   if (check_frame_args(m, H, W, target_name ? target_name : "", &t)) return 1;
   FP_CHECK(m->refiner && m->scorer, "[FoundationPose] refiner/scorer weights not loaded");
@@ -983,10 +1018,10 @@ int fp_register_shard_begin(fp_model *m, const void *rgb, const void *depth, con
     return 1;
   }
   return 0;
-}
+} FP_CATCH_INT
 
 int fp_register_shard_finish(fp_model *m, const float *all_feat_dev, const float *all_poses_dev, int N_total,
-                             float out_pose[16], int *best_index, float *scores_host) {
+                             float out_pose[16], int *best_index, float *scores_host) try {
   FP_CHECK(m && m->scorer && all_feat_dev && all_poses_dev && N_total > 0 && out_pose,
            "[FoundationPose] fp_register_shard_finish: invalid arguments");
   float *scores = m->scores_dev;
@@ -1023,6 +1058,7 @@ int fp_register_shard_finish(fp_model *m, const float *all_feat_dev, const float
     if (res[1] == 1) { set_error("[FoundationPose] Failed to generate hyp poses!!! [FoundationposeSampling] Mask is all zero."); rc = 1; }
     else if (res[1] == 2) { set_error("[FoundationPose] Failed to generate hyp poses!!! [FoundationposeSampling] No valid value in mask."); rc = 1; }
     else if (res[1] != 0) { set_error("[FoundationPose] Failed to generate hyp poses!!! sampler did not run"); rc = 1; }
+    else if (res[0] == -2) { set_error("[FoundationPose] scores are not finite (a rank of a sharded Register reported a failed shard, or the weights are broken)"); rc = 1; }
   }
   if (!rc) {
     std::memcpy(out_pose, &res[2], 64);
@@ -1030,12 +1066,12 @@ int fp_register_shard_finish(fp_model *m, const float *all_feat_dev, const float
   }
   if (rc && g_last_error.empty()) set_error("[FoundationPose] fp_register_shard_finish failed");
   return rc;
-}
+} FP_CATCH_INT
 
 // Sharded Register without host stalls: everything is enqueued on the model's stream, nothing is allocated or synchronised.
 int fp_register_shard_begin_packed(fp_model *m, const void *rgb, const void *depth, const void *mask, int memspace, int H,
                                    int W, const char *target_name, int refine_itr, int shard_begin, int shard_count,
-                                   float *packed_dev, int rows_per_rank) {
+                                   float *packed_dev, int rows_per_rank) try {
   FP_CHECK(m && packed_dev && rows_per_rank >= shard_count && shard_count >= 0, "[FoundationPose] fp_register_shard_begin_packed: invalid arguments");
   float *feat = nullptr, *poses = nullptr;
   if (shard_count > 0) {
@@ -1044,14 +1080,24 @@ int fp_register_shard_begin_packed(fp_model *m, const void *rgb, const void *dep
     m->defer_begin_sync = false;
     if (rc) { (void)hipStreamSynchronize(m->stream); return 1; }
     m->shard_sampler_pending = true;
+  } else {
+    // an empty shard still runs the (cheap) sampler, so that a bad mask fails on EVERY rank alike
+    Target *t = nullptr;
+    if (check_frame_args(m, H, W, target_name ? target_name : "", &t)) return 1;
+    FP_CHECK(mask != nullptr, "[FoundationPose] Register needs a mask");
+    if (upload_frame_async(m, rgb, depth, memspace, H, W) || sample_hypotheses_async(m, t, mask, memspace, 0, 1)) {
+      (void)hipStreamSynchronize(m->stream);
+      return 1;
+    }
+    m->shard_sampler_pending = true;
   }
   const int n = rows_per_rank * 528;
   hipLaunchKernelGGL(pack_shard_kernel, dim3((n + 255) / 256), dim3(256), 0, m->stream, feat, poses, shard_count, rows_per_rank, packed_dev);
   FP_HIP_OK(hipGetLastError());
   return 0;
-}
+} FP_CATCH_INT
 
-int fp_register_shard_finish_packed(fp_model *m, const float *gathered_dev, int n_total, float out_pose[16], int *best_index) {
+int fp_register_shard_finish_packed(fp_model *m, const float *gathered_dev, int n_total, float out_pose[16], int *best_index) try {
   FP_CHECK(m && gathered_dev && n_total > 0 && out_pose, "[FoundationPose] fp_register_shard_finish_packed: invalid arguments");
   if (n_total > m->gath_cap) {
     FP_HIP_OK(hipStreamSynchronize(m->stream));
@@ -1068,10 +1114,11 @@ int fp_register_shard_finish_packed(fp_model *m, const float *gathered_dev, int 
   int rc = fp_register_shard_finish(m, m->gath_feat, m->gath_poses, n_total, out_pose, best_index, nullptr);
   m->defer_begin_sync = false;
   return rc;
-}
+} FP_CATCH_INT
 
 int fp_register_ex(fp_model *m, const void *rgb, const void *depth, const void *mask, int memspace, int H, int W,
-                   const char *target_name, int refine_itr, float out_pose[16]) {
+                   const char *target_name, int refine_itr, float out_pose[16]) try {
+  SerialGuard serial;
   FP_CHECK(m != nullptr, "[FoundationPose] null model");
   float *feat = nullptr, *poses = nullptr;
   m->defer_begin_sync = true;  // begin + finish back to back on one stream: a single synchronisation, at the end
@@ -1080,17 +1127,17 @@ int fp_register_ex(fp_model *m, const void *rgb, const void *depth, const void *
   else (void)hipStreamSynchronize(m->stream);
   m->defer_begin_sync = false;
   return rc;
-}
+} FP_CATCH_INT
 
 int fp_register(fp_model *m, const uint8_t *rgb, const float *depth, const uint8_t *mask, int H, int W,
-                const char *target_name, int refine_itr, float out_pose[16]) {
+                const char *target_name, int refine_itr, float out_pose[16]) try {
   return fp_register_ex(m, rgb, depth, mask, FP_HOST, H, W, target_name, refine_itr, out_pose);
-}
+} FP_CATCH_INT
 
 // Track in two halves: everything is ENQUEUED by fp_track_submit (frame upload, the replayed graph); fp_track_wait synchronises the
 // model's stream and hands the pose over.  One host thread can so keep several models (objects) in flight at once.
-int fp_track_submit(fp_model *m, const void *rgb, const void *depth, int memspace, int H, int W, const float hyp_pose[16],
-                    const char *target_name, int refine_itr) {
+static int track_submit_impl(fp_model *m, const void *rgb, const void *depth, int memspace, int H, int W, const float hyp_pose[16],
+                             const char *target_name, int refine_itr) {
   Target *t = nullptr;
   if (check_frame_args(m, H, W, target_name ? target_name : "", &t)) return 1;
   FP_CHECK(m->refiner, "[FoundationPose] refiner weights not loaded");
@@ -1111,10 +1158,14 @@ int fp_track_submit(fp_model *m, const void *rgb, const void *depth, int memspac
       double rad = 0;
       const double offs[4][2] = {{r, 0}, {-r, 0}, {0, r}, {0, -r}};
       for (auto &o : offs) rad = std::max(rad, std::fabs(proj_v(tx + o[0], ty + o[1], tz) - v0));
-      if (std::isfinite(v0) && std::isfinite(rad)) {
-        row0 = (int)std::floor(v0 - rad) - 4;
-        row1 = (int)std::ceil(v0 + rad) + 5;
-        if (row1 <= 0 || row0 >= H) { row0 = 0; row1 = 0; }   // window outside the frame: nothing is read
+      // far outside [-H, 2H] (tiny tz, huge translation) the casts below would overflow: such a window either misses the frame
+      // (decided in double) or the whole frame is uploaded
+      if (std::isfinite(v0) && std::isfinite(rad) && rad < 4.0 * H) {
+        if (v0 + rad + 5 <= 0 || v0 - rad - 4 >= H) { row0 = 0; row1 = 0; }   // window outside the frame: nothing is read
+        else if (v0 > -(double)H && v0 < 2.0 * H) {
+          row0 = (int)std::floor(v0 - rad) - 4;
+          row1 = (int)std::ceil(v0 + rad) + 5;
+        }
       }
     }
   }
@@ -1142,19 +1193,28 @@ int fp_track_submit(fp_model *m, const void *rgb, const void *depth, int memspac
   return 0;
 }
 
-int fp_track_wait(fp_model *m, float out_pose[16]) {
+int fp_track_submit(fp_model *m, const void *rgb, const void *depth, int memspace, int H, int W, const float hyp_pose[16],
+                    const char *target_name, int refine_itr) try {
+  const int rc = track_submit_impl(m, rgb, depth, memspace, H, W, hyp_pose, target_name, refine_itr);
+  // a failure after the upload was enqueued must not leave H2D copies of the caller's host frame in flight
+  if (rc && m && m->stream) (void)hipStreamSynchronize(m->stream);
+  return rc;
+} FP_CATCH_INT
+
+int fp_track_wait(fp_model *m, float out_pose[16]) try {
   FP_CHECK(m && out_pose, "[FoundationPose] fp_track_wait: invalid arguments");
   FP_CHECK(m->track_pending, "[FoundationPose] fp_track_wait: nothing was submitted");
   m->track_pending = false;
   FP_HIP_OK(hipStreamSynchronize(m->stream));
   std::memcpy(out_pose, m->track_io + 16, 64);
   return 0;
-}
+} FP_CATCH_INT
 
 // Track of K objects of one frame in ONE batch: the geometry runs per object (its mesh), the refine-net once over all K crops.
 // Track is launch-latency-bound at N = 1, so K objects cost little more than one (tools/bench_multi_track.py).
 int fp_track_multi(fp_model *m, const void *rgb, const void *depth, int memspace, int H, int W, int K, const float *hyp_poses,
-                   const char *const *target_names, int refine_itr, float *out_poses) {
+                   const char *const *target_names, int refine_itr, float *out_poses) try {
+  SerialGuard serial;
   FP_CHECK(m != nullptr, "[FoundationPose] null model");
   FP_CHECK(K >= 1 && K <= 64 && hyp_poses && target_names && out_poses, "[FoundationPose] fp_track_multi: invalid arguments (1..64 objects)");
   FP_CHECK(m->refiner, "[FoundationPose] refiner weights not loaded");
@@ -1214,47 +1274,49 @@ int fp_track_multi(fp_model *m, const void *rgb, const void *depth, int memspace
   FP_HIP_OK(hipStreamSynchronize(m->stream));
   std::memcpy(out_poses, m->multi_io + 64 * 16, (size_t)K * 64);
   return 0;
-}
+} FP_CATCH_INT
 
 int fp_track_ex(fp_model *m, const void *rgb, const void *depth, int memspace, int H, int W, const float hyp_pose[16],
-                const char *target_name, int refine_itr, float out_pose[16]) {
+                const char *target_name, int refine_itr, float out_pose[16]) try {
+  SerialGuard serial;
   FP_CHECK(out_pose, "[FoundationPose] Track: null pose");
+  // an earlier fp_track_submit that is still in flight is the caller's to wait for: refuse without touching it
+  FP_CHECK(!m || !m->track_pending, "[FoundationPose] Track: a submitted Track has not been waited for (fp_track_wait)");
   if (fp_track_submit(m, rgb, depth, memspace, H, W, hyp_pose, target_name, refine_itr)) {
-    if (m && m->stream) (void)hipStreamSynchronize(m->stream);
-    if (m) m->track_pending = false;
+    if (m) m->track_pending = false;   // this call's own submission failed (fp_track_submit synchronised)
     return 1;
   }
   return fp_track_wait(m, out_pose);
-}
+} FP_CATCH_INT
 
 int fp_track(fp_model *m, const uint8_t *rgb, const float *depth, int H, int W, const float hyp_pose[16],
-             const char *target_name, int refine_itr, float out_pose[16]) {
+             const char *target_name, int refine_itr, float out_pose[16]) try {
   return fp_track_ex(m, rgb, depth, FP_HOST, H, W, hyp_pose, target_name, refine_itr, out_pose);
-}
+} FP_CATCH_INT
 
-int fp_set_precision(fp_model *m, int precision) {
+int fp_set_precision(fp_model *m, int precision) try {
   FP_CHECK(m != nullptr, "[FoundationPose] null model");
   FP_HIP_OK(hipStreamSynchronize(m->stream));
   FP_CHECK(precision != PREC_FP8 || m->calibrated,
            "[FoundationPose] FP8 precision needs activation scales: call fp_calibrate_fp8 (or fp_load_calibration) first");
   return select_precision(m, precision);
-}
+} FP_CATCH_INT
 int fp_get_precision(const fp_model *m) { return m ? m->prec : -1; }
 
-int fp_set_float_model(fp_model *m, int fmad) {
+int fp_set_float_model(fp_model *m, int fmad) try {
   FP_CHECK(m != nullptr, "[FoundationPose] null model");
   FP_HIP_OK(hipStreamSynchronize(m->stream));
   m->fmad = fmad != 0;
-  drop_graph(m->tg);
-  drop_graph(m->rg);
+  invalidate_graphs(m);
   return 0;
-}
+} FP_CATCH_INT
 int fp_get_float_model(const fp_model *m) { return m ? (m->fmad ? 1 : 0) : -1; }
 
 // Post-training static quantisation for FP_PREC_FP8: one Register of the given frame in f16 with |max| collection on
 // every trunk activation of both networks; the per-tensor scales of the FP8 networks follow from it.
 int fp_calibrate_fp8(fp_model *m, const void *rgb, const void *depth, const void *mask, int memspace, int H, int W,
-                     const char *target_name) {
+                     const char *target_name) try {
+  SerialGuard serial;
   FP_CHECK(m != nullptr, "[FoundationPose] null model");
   FP_CHECK(!m->refiner_path.empty() && !m->scorer_path.empty(), "[FoundationPose] fp_calibrate_fp8 needs both networks");
   const int prev = m->prec;
@@ -1271,26 +1333,24 @@ int fp_calibrate_fp8(fp_model *m, const void *rgb, const void *depth, const void
   // scales of already loaded FP8 networks are refreshed; otherwise they are applied when FP8 is first selected
   if (m->refiner_p[PREC_FP8] && net_set_fp8_scales(m->refiner_p[PREC_FP8], m->calib_amax[0])) return 1;
   if (m->scorer_p[PREC_FP8] && net_set_fp8_scales(m->scorer_p[PREC_FP8], m->calib_amax[1])) return 1;
-  drop_graph(m->tg);
-  drop_graph(m->rg);
+  invalidate_graphs(m);
   return select_precision(m, prev);
-}
-int fp_get_calibration(const fp_model *m, float amax_out[32]) {
+} FP_CATCH_INT
+int fp_get_calibration(const fp_model *m, float amax_out[32]) try {
   FP_CHECK(m && m->calibrated && amax_out, "[FoundationPose] no calibration available");
   std::memcpy(amax_out, m->calib_amax, sizeof(m->calib_amax));
   return 0;
-}
-int fp_set_calibration(fp_model *m, const float amax[32]) {
+} FP_CATCH_INT
+int fp_set_calibration(fp_model *m, const float amax[32]) try {
   FP_CHECK(m && amax, "[FoundationPose] fp_set_calibration: invalid arguments");
   FP_HIP_OK(hipStreamSynchronize(m->stream));
   std::memcpy(m->calib_amax, amax, sizeof(m->calib_amax));
   m->calibrated = true;
   if (m->refiner_p[PREC_FP8] && net_set_fp8_scales(m->refiner_p[PREC_FP8], m->calib_amax[0])) return 1;
   if (m->scorer_p[PREC_FP8] && net_set_fp8_scales(m->scorer_p[PREC_FP8], m->calib_amax[1])) return 1;
-  drop_graph(m->tg);
-  drop_graph(m->rg);
+  invalidate_graphs(m);
   return 0;
-}
+} FP_CATCH_INT
 
 // ------------------------------------------------------------------------------------------------
 // A network on its own, with the blob interface the reference's orchestrator drives through deploy_core's BaseInferCore
@@ -1324,7 +1384,7 @@ static int net_blob_index(const fp_net *n, const char *name, bool *out) {
   return -1;
 }
 
-fp_net *fp_net_create(const char *weights_path, int is_scorer, int max_batch) {
+fp_net *fp_net_create(const char *weights_path, int is_scorer, int max_batch) try {
   if (!weights_path || max_batch <= 0) { set_error("[FoundationPose] fp_net_create: invalid arguments"); return nullptr; }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { set_error("[FoundationPose] no HIP device available (this library has no CPU path)"); return nullptr; }
@@ -1342,7 +1402,7 @@ fp_net *fp_net_create(const char *weights_path, int is_scorer, int max_batch) {
   ok = ok && hipMemsetAsync(n->nn_in, 0, (size_t)2 * max_batch * FP_NN_IN_IMG_HALFS * sizeof(__half), n->stream) == hipSuccess;
   if (!ok) { set_error("[FoundationPose] fp_net_create: device allocation failed"); fp_net_destroy(n.release()); return nullptr; }
   return n.release();
-}
+} FP_CATCH_PTR
 
 void fp_net_destroy(fp_net *n) {
   if (!n) return;
@@ -1361,7 +1421,7 @@ void fp_net_destroy(fp_net *n) {
 
 // raw pointer of a blob in the given memory space (BlobsTensor::GetTensor(name)->RawPtr()); NULL + fp_last_error for an
 // unknown name (the reference's GetTensor throws)
-void *fp_net_blob(fp_net *n, const char *name, int memspace) {
+void *fp_net_blob(fp_net *n, const char *name, int memspace) try {
   bool out = false;
   const int idx = n ? net_blob_index(n, name, &out) : -1;
   if (idx < 0) { set_error(std::string("[FoundationPose] no blob named '") + (name ? name : "") + "'"); return nullptr; }
@@ -1372,12 +1432,12 @@ void *fp_net_blob(fp_net *n, const char *name, int memspace) {
     if (hipHostMalloc((void **)h, elems * sizeof(float), hipHostMallocDefault) != hipSuccess) { set_error("[FoundationPose] pinned allocation failed"); return nullptr; }
   }
   return *h;
-}
+} FP_CATCH_PTR
 int fp_net_max_batch(const fp_net *n) { return n ? n->max_batch : 0; }
 
 // SyncInfer: inputs are taken from the blobs' FP_HOST or FP_DEVICE copies (render_loc / transf_loc), outputs are left in
 // the device blobs and, with out_loc == FP_HOST, copied to the host blobs as well; returns when they are complete.
-int fp_net_infer(fp_net *n, int batch, int render_loc, int transf_loc, int out_loc) {
+int fp_net_infer(fp_net *n, int batch, int render_loc, int transf_loc, int out_loc) try {
   FP_CHECK(n && batch > 0 && batch <= n->max_batch, "[FoundationPose] fp_net_infer: batch out of range");
   const size_t px = (size_t)batch * FP_CROP_HW * FP_CROP_HW;
   const int locs[2] = {render_loc, transf_loc};
@@ -1403,20 +1463,20 @@ int fp_net_infer(fp_net *n, int batch, int render_loc, int transf_loc, int out_l
   }
   FP_HIP_OK(hipStreamSynchronize(n->stream));
   return 0;
-}
+} FP_CATCH_INT
 
-int fp_profile_enable(fp_model *m, int on) {
+int fp_profile_enable(fp_model *m, int on) try {
   FP_CHECK(m, "null model");
   m->prof.on = on != 0;
   return 0;
-}
-int fp_profile_reset(fp_model *m) {
+} FP_CATCH_INT
+int fp_profile_reset(fp_model *m) try {
   FP_CHECK(m, "null model");
   (void)hipStreamSynchronize(m->stream);
   m->prof.reset();
   return 0;
-}
-int fp_profile_report(fp_model *m, char *buf, int buf_len) {
+} FP_CATCH_INT
+int fp_profile_report(fp_model *m, char *buf, int buf_len) try {
   FP_CHECK(m && buf && buf_len > 0, "fp_profile_report: invalid arguments");
   (void)hipStreamSynchronize(m->stream);
   m->prof.collect();
@@ -1428,6 +1488,6 @@ int fp_profile_report(fp_model *m, char *buf, int buf_len) {
   }
   std::snprintf(buf, (size_t)buf_len, "%s", out.c_str());
   return 0;
-}
+} FP_CATCH_INT
 
 }  // extern "C"

@@ -1008,12 +1008,18 @@ __global__ void argmax_kernel(const float *__restrict__ scores, int N, int *__re
   __shared__ float sv[256];
   __shared__ int si[256];
   int tid = threadIdx.x;
+  __shared__ int any_nan;
   float best = -INFINITY;
   int bi = 0x7FFFFFFF;
+  if (tid == 0) any_nan = 0;
+  __syncthreads();
+  bool bad = false;
   for (int i = tid; i < N; i += 256) {
     float v = scores[i];
+    bad |= v != v;
     if (v > best || bi == 0x7FFFFFFF) { best = v; bi = i; }
   }
+  if (bad) any_nan = 1;   // same value from every writer
   sv[tid] = best; si[tid] = bi;
   __syncthreads();
   for (int st = 128; st > 0; st >>= 1) {
@@ -1024,7 +1030,8 @@ __global__ void argmax_kernel(const float *__restrict__ scores, int N, int *__re
     __syncthreads();
   }
   const int win = si[0] == 0x7FFFFFFF ? 0 : si[0];
-  if (tid == 0) *index = win;
+  // NaN scores (a rank of a sharded Register poisoned its rows because its half failed): index -2, reported by the host
+  if (tid == 0) *index = any_nan ? -2 : win;
   if (poses && tid < 16) best_pose[tid] = poses[(size_t)win * 16 + tid];
 }
 

@@ -17,6 +17,7 @@
 #include <cstring>
 #include <fstream>
 #include <map>
+#include <memory>
 #include <sstream>
 #include <string>
 #include <tuple>
@@ -132,17 +133,18 @@ static fp_loaded_mesh *fp_mesh_load_obj_impl(const char *name, const char *mesh_
     }
   }
   if (tris.empty() || pos.empty()) { fp::set_error(std::string("[AssimpMeshLoader] Failed to read mesh file: ") + mesh_file_path); return nullptr; }
-  auto *m = new fp_loaded_mesh();
+  std::unique_ptr<fp_loaded_mesh> owner(new fp_loaded_mesh());   // freed on every early return and if anything below throws
+  fp_loaded_mesh *m = owner.get();
   m->name = name ? name : "";
   std::map<std::tuple<int, int, int>, uint32_t> seen;
   bool has_uv = true, has_n = true;
   for (auto &t : tris)
     for (auto &c : t) {
-      if (c.v < 0 || c.v >= (int)pos.size()) { delete m; fp::set_error("[AssimpMeshLoader] Failed to read mesh file: bad vertex index"); return nullptr; }
+      if (c.v < 0 || c.v >= (int)pos.size()) { fp::set_error("[AssimpMeshLoader] Failed to read mesh file: bad vertex index"); return nullptr; }
       if (c.t < 0 || c.t >= (int)uv.size()) has_uv = false;
       if (c.n < 0 || c.n >= (int)nrm.size()) has_n = false;
     }
-  if (!has_uv) { delete m; fp::set_error("[AssimpMeshLoader] Got invalid texturecoords!"); return nullptr; }
+  if (!has_uv) { fp::set_error("[AssimpMeshLoader] Got invalid texturecoords!"); return nullptr; }
   for (auto &t : tris)
     for (auto &c : t) {
       auto key = std::make_tuple(c.v, c.t, has_n ? c.n : -1);
@@ -247,7 +249,6 @@ static fp_loaded_mesh *fp_mesh_load_obj_impl(const char *name, const char *mesh_
       // 8-bit PNG only.  A texture file that EXISTS but cannot be decoded here must not silently become the grey default:
       // the rendered crops would get the wrong colours and refine / score accuracy would drop without a trace.
       fp::set_error("[MeshLoader] texture '" + tex_path + "' named by map_Kd cannot be decoded (supported: non-interlaced 8-bit PNG)");
-      delete m;
       return nullptr;
     }
     if (!present) {  // no map_Kd, or the file is missing: default texture map, like the reference (:217-222)
@@ -258,7 +259,7 @@ static fp_loaded_mesh *fp_mesh_load_obj_impl(const char *name, const char *mesh_
   m->view = fp_mesh{m->name.c_str(), (int)V, (int)(m->faces.size() / 3), m->vertices.data(), m->normals.data(),
                     m->texcoords.data(), m->faces.data(), m->texture.data(), m->th, m->tw, m->diameter,
                     {m->center[0], m->center[1], m->center[2]}};
-  return m;
+  return owner.release();
 }
 fp_loaded_mesh *fp_mesh_load_obj(const char *name, const char *mesh_file_path) {
   try {

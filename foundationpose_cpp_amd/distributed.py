@@ -68,7 +68,9 @@ class HipShardBackend:
 
 def sharded_register(backend, dist, n_total, rgb, depth, mask, H, W, name, refine_itr=1):
     """One Register over `n_total` hypotheses sharded across dist.get_world_size() ranks.
-    Returns (pose16 column-major, winning global hypothesis index); identical on every rank.
+    Returns (pose16 column-major, winning global hypothesis index); identical on every rank -- also in failure: a sampler
+    failure (bad mask) is found by every rank's own sampler run (ranks with an empty shard included), and a rank whose begin
+    raises still joins the collective with NaN rows, which every other rank's finish reports.
 
     `backend` provides buffers / shard_begin_packed / before_collective / after_collective / shard_finish_packed
     (HipShardBackend on MI355X; tests/test_distributed_cpu.py has a numpy stand-in for the gloo runs)."""
@@ -76,12 +78,20 @@ def sharded_register(backend, dist, n_total, rgb, depth, mask, H, W, name, refin
     per = -(-n_total // world)
     begin, count = shard_range(n_total, world, rank)
     packed, gathered = backend.buffers(per, world)          # fixed-size slots: one collective also for a ragged last shard
-    backend.shard_begin_packed(rgb, depth, mask, H, W, name, refine_itr, begin, count, packed, per)
+    failure = None
+    try:
+        backend.shard_begin_packed(rgb, depth, mask, H, W, name, refine_itr, begin, count, packed, per)
+    except Exception as e:      # bad arguments / allocation failure on THIS rank: the others are already heading for the
+        failure = e             # collective -- join it with poisoned (NaN) rows so that nobody hangs, raise afterwards
+        packed.fill_(float("nan"))
     backend.before_collective()
     if world > 1:
         dist.all_gather_into_tensor(gathered, packed)       # THE collective: [per, 528] f32 per rank
     else:
         gathered.copy_(packed)
     backend.after_collective()
-    # contiguous shards of `per` rows: the gathered rows are already in global hypothesis order, padding only at the end
+    if failure is not None:
+        raise failure
+    # contiguous shards of `per` rows: the gathered rows are already in global hypothesis order, padding only at the end.
+    # NaN rows of a failed rank make every other rank's finish fail too ("scores are not finite ...", fp_register_shard_finish)
     return backend.shard_finish_packed(gathered, n_total)

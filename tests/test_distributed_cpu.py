@@ -33,6 +33,8 @@ class FakeBackend:
         return self._bufs[(per, world)]
 
     def shard_begin_packed(self, rgb, depth, mask, H, W, name, itr, begin, count, packed, per):
+        if name == "fail-on-rank-1" and begin > 0:
+            raise RuntimeError("allocation failed on this rank")
         self.calls.append((begin, count))
         self.order.append("begin")
         packed.zero_()
@@ -49,6 +51,8 @@ class FakeBackend:
         self.order.append("finish")
         rows = gathered.numpy()[:n_total]
         f = rows[:, :512]
+        if not np.isfinite(f).all():      # what fp_register_shard_finish reports for poisoned rows
+            raise RuntimeError("scores are not finite (a rank of a sharded Register reported a failed shard)")
         # cross-hypothesis dependence (like att_cross): score depends on the mean over ALL rows
         s = f @ f.mean(0)
         idx = int(np.argmax(s))
@@ -105,6 +109,40 @@ def test_two_rank_gloo_agrees_with_single_process(n_total):
         assert idx == ref_idx
         np.testing.assert_array_equal(np.asarray(pose, np.float32), ref_pose)
         assert calls == [shard_range(n_total, 2, rank)]
+
+
+def _failing_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    be = FakeBackend(252)
+    try:
+        sharded_register(be, dist, 252, None, None, None, 480, 640, "fail-on-rank-1", 1)
+        q.put((rank, "returned"))
+    except RuntimeError as e:
+        q.put((rank, str(e)))
+    # the group is still usable: nobody was left behind in the collective
+    pose, idx = sharded_register(be, dist, 252, None, None, None, 480, 640, "obj", 1)
+    assert idx == be.reference()[1]
+    dist.destroy_process_group()
+
+
+def test_a_failing_rank_does_not_hang_the_others():
+    """rank 1's begin raises before the all-gather: it must still join the collective (NaN rows); rank 0's finish then
+    fails as well instead of returning a pose computed from garbage, and both raise"""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_failing_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert "allocation failed" in res[1] and "not finite" in res[0], res
 
 
 def test_single_process_world1():

@@ -1,7 +1,6 @@
 """Build-level guards (no GPU needed):
   * the product and the test library load (every kernel launch stub resolves) and the product exports no fpt_* hook;
-  * NO packed-f32 VALU instruction (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32 / v_pk_mov_b32) in any code object of the
-    product: those returned wrong values in lanes 48-63 whenever waves of another queue's kernel shared the SIMD
+  * NO packed-f32 VALU instruction (any v_pk_*_f32, v_pk_mov_b32) in any code object of the product: those returned wrong values in lanes 48-63 whenever waves of another queue's kernel shared the SIMD
     (the root cause of the round-1 'stale read' under two concurrently running models)."""
 import ctypes
 import os
@@ -45,12 +44,11 @@ def test_libraries_load_and_product_has_no_test_hooks():
 
 
 def test_no_packed_f32_instructions_in_the_product():
-    if not os.path.exists(OBJDUMP):
-        import pytest
-        pytest.skip("llvm-objdump not available")
+    # no skip: without the disassembler the guard would silently not run (the ROCm image always has it)
+    assert os.path.exists(OBJDUMP), f"{OBJDUMP} is missing: the packed-f32 guard cannot run"
     asm = _disassemble(_lib.LIB_PATH)
     kernels = len(re.findall(r"^[0-9a-f]+ <[^>]+>:$", asm, flags=re.M))
     assert kernels >= 60, kernels                      # the extraction really saw the code objects
     assert asm.count("v_mfma_f32_16x16x128_f8f6f4") > 100 and asm.count("v_mfma_f32_16x16x32_bf16") > 100
-    bad = re.findall(r"v_pk_(?:mul|add|fma)_f32|v_pk_mov_b32", asm)
+    bad = re.findall(r"v_pk_\w+_f32|v_pk_mov_b32", asm)
     assert not bad, (len(bad), sorted(set(bad)))
