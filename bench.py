@@ -7,10 +7,15 @@ with the frame (rgb, depth, mask) already resident in HBM when the timed region 
 carries `host_frame` (the reference's calling convention: host frames, H2D inside the call) and `track` (Track fps, N = 1).
 
   N = 1  : workload = BASELINE.json configs[2] "Register, N=252 hypotheses, 640x480, single MI355X, fp16".
-  N > 1  : one process per GPU (torch.distributed.run), WEAK scaling: every rank refines+scores 252 hypotheses of a
-           252*N grid (42 views x 6N in-plane steps), ONE RCCL all-gather of the pooled score features [252,512]
-           (+ poses), then every rank runs the cross-hypothesis attention + arg-max redundantly.
-           `--hyps 1008` selects BASELINE.json configs[3] (1008 hypotheses sharded over the ranks = strong scaling).
+  N > 1  : one process per GPU (torch.distributed.run), the SAME workload strong-scaled -- BASELINE.json's metric is "Register
+           N=252 ... at 1/2/4/8 GPUs": the 252 hypotheses are sharded in contiguous slices of ceil(252/N) per GPU, ONE RCCL
+           all-gather of one row per hypothesis [pooled score feature 512 | pose 16] f32, then every rank runs the
+           cross-hypothesis attention + arg-max redundantly.  The line also carries `n1008` = BASELINE configs[3] (1008
+           hypotheses sharded the same way).  `--weak` keeps 252 hypotheses PER GPU (252*N in total) instead; `--hyps M` picks
+           any total.
+  Extra legs of the default N = 1 run (outside the headline's timed region, a few steps each, every one with its own roofline):
+           `host_frame`, `track` (incl. pipelined / batched serving), `track_bf16` (configs[1]), `fp8_720p` and
+           `fp8_720p_untextured` (configs[4]: 1280x720, e4m3 trunk convolutions, activation scales calibrated on the bench frame).
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
   roofline     -- dominant kernel (the conv/linear implicit-GEMM kernel with the largest share of the step, MFMA-bound):
@@ -66,13 +71,64 @@ def cpu_baseline(mesh, scene, states, n_hyp=8, reps=8):
                 sample=f"{reps} x Register N={n_hyp} 640x480 refine_itr=1 (oracle C/OpenMP geometry + PyTorch-CPU fp32 "
                        f"networks, {dt:.1f} s); the reference has no CPU path for this (SURVEY.md §8d)")
 
+FP8_LAYERS = {"conv_128", "conv_256", "conv_b2", "conv_512"}   # 3x3 trunk convolutions from encodeA.2 on run on e4m3 in FP8 mode
+
+
+def analyse_profile(prof, dtype, n_hyp, stages_per_hyp):
+    """fp_profile_report of ONE step -> (roofline object of the dominant MFMA kernel, per-stage ms).
+    Profiler keys are "<layer>/<kernel symbol>" for the conv family, "<kernel family>" otherwise."""
+    conv = {k: v for k, v in prof.items() if k.startswith("conv_") or k.startswith("gemm_")}
+    conv_flops = sum(v["flops"] for v in conv.values())
+    conv_ms = sum(v["ms"] for v in conv.values())
+    fp8_layers = FP8_LAYERS if dtype == "fp8" else set()
+    by_sym = {}
+    for k, v in conv.items():
+        layer = k.split("/", 1)[0]
+        sym = k.split("/", 1)[1] if "/" in k else k
+        if layer in fp8_layers and "halo8" not in sym:
+            sym += "[fp8]"
+        a = by_sym.setdefault(sym, dict(ms=0.0, flops=0.0, bytes=0.0, calls=0, fp8=layer in fp8_layers))
+        for f in ("ms", "flops", "bytes", "calls"):
+            a[f] += v[f]
+    dom, dv = max(by_sym.items(), key=lambda kv: kv[1]["ms"]) if by_sym else ("none", dict(ms=0, flops=0, bytes=0, calls=1, fp8=False))
+    peak = PEAK_FP8_TFLOPS if dv.get("fp8") else PEAK_FP16_TFLOPS
+    achieved = dv["flops"] / (dv["ms"] * 1e-3) / 1e12 if dv["ms"] > 0 else 0.0
+    family = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+    # the family's own ceiling: time at peak of every launch's FLOPs at its operand type
+    ideal_ms = sum(v["flops"] / ((PEAK_FP8_TFLOPS if v["fp8"] else PEAK_FP16_TFLOPS) * 1e12) * 1e3 for v in by_sym.values())
+    stages = {}
+    for k, v in prof.items():
+        stages[k.split("/", 1)[0]] = stages.get(k.split("/", 1)[0], 0.0) + v["ms"]
+    # the HBM-bound sub-steps (SURVEY.md 8d): vertex + raster/shade + observed-crop warp of every hypothesis-stage against
+    # 0.9 MB per hypothesis-stage (fp16 network input written once + mesh + crop source window + texture taps)
+    rc_ms = sum(stages.get(k, 0.0) for k in ("vertex", "raster_shade", "crop_warp"))
+    n_stages = n_hyp * stages_per_hyp
+    rc_gbs = n_stages * 0.9e6 / (rc_ms * 1e-3) / 1e9 if rc_ms > 0 else 0.0
+    roof = {
+        "bound": "mfma", "kernel": dom,
+        "achieved": round(achieved, 1), "peak": peak, "unit": "TFLOP/s",
+        "frac": round(achieved / peak, 4),
+        "launches_per_step": dv["calls"], "algorithmic_gflop_per_launch": round(dv["flops"] / max(dv["calls"], 1) / 1e9, 1),
+        "avg_launch_ms": round(dv["ms"] / max(dv["calls"], 1), 4),
+        "algorithmic_bytes_per_launch": round(dv["bytes"] / max(dv["calls"], 1)),
+        "conv_family": {"achieved": round(family, 1), "gflop_per_step": round(conv_flops / 1e9, 1), "ms_per_step": round(conv_ms, 3),
+                        "ms_at_peak": round(ideal_ms, 3), "frac": round(ideal_ms / conv_ms, 4) if conv_ms > 0 else None,
+                        "kernels_ms": {k2: round(v2["ms"], 3) for k2, v2 in by_sym.items()}},
+        "render_crop": {"bound": "hbm", "achieved": round(rc_gbs, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(rc_gbs / 8000.0, 4),
+                        "ms_per_step": round(rc_ms, 4), "hypothesis_stages": n_stages,
+                        "what": "vertex + raster_shade + crop_warp kernels, 0.9 MB algorithmic bytes per hypothesis-stage (SURVEY.md 8d)"},
+    }
+    stages = {k: round(v, 3) for k, v in sorted(stages.items(), key=lambda kv: -kv[1])}
+    return roof, stages, dom, dv
+
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--hyps", type=int, default=0, help="total hypotheses (default 252 per GPU, weak scaling)")
+    ap.add_argument("--hyps", type=int, default=0, help="total hypotheses sharded over the GPUs (default 252 = the BASELINE metric, strong scaling)")
+    ap.add_argument("--weak", action="store_true", help="weak scaling: 252 hypotheses PER GPU (252*N in total)")
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--dtype", choices=["f16", "bf16", "fp8"], default="f16",
@@ -117,13 +173,13 @@ def main():
         states = (W.pack_synthetic("refiner", rp), W.pack_synthetic("scorer", sp))
         model = FoundationPose(mesh, scene.K, rp, sp, max_input_image_height=max(1080, args.height),
                                max_input_image_width=max(1920, args.width))
-        if args.dtype == "fp8":      # post-training static quantisation on the bench frame itself
+        if args.dtype == "fp8":      # post-training static quantisation on the bench frame itself (stated in config.calibration)
             model.calibrate_fp8(scene.rgb, scene.depth, scene.mask, mesh.name)
             model.set_precision(FP_PREC_FP8)
         elif args.dtype == "bf16":
             model.set_precision(FP_PREC_BF16)
 
-    n_total = args.hyps if args.hyps > 0 else 252 * world
+    n_total = args.hyps if args.hyps > 0 else (252 * world if args.weak else 252)
     assert n_total % 42 == 0, "--hyps must be a multiple of 42 (icosphere views)"
     model.set_inplane_steps(n_total // 42)
     rgb = torch.from_numpy(scene.rgb).to(dev)
@@ -252,34 +308,87 @@ def main():
                          "frac": round(tflops / (td / ksteps) / 1e12 / PEAK_FP16_TFLOPS, 4)},
         }
 
+    # ---- BASELINE configs[3]: 1008 hypotheses (42 views x 24 in-plane steps) sharded exactly like the headline; every rank takes part
+    n1008 = None
+    if not args.track and not args.no_extras and args.hyps == 0 and not args.weak:
+        model.set_inplane_steps(24)
+
+        def step1008():
+            if world == 1 and not force_shard:
+                register_dev()
+            else:
+                sharded_register(backend, dist, 1008, rgb, depth, mask, H, Wd, mesh.name, 1)
+        k8 = max(3, args.steps // 4)
+        t8 = timed(step1008, k8, 1)
+        if world > 1:
+            t = torch.tensor([t8], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            t8 = float(t.item())
+        model.set_inplane_steps(n_total // 42)
+        n1008 = {"metric": f"pose-hypotheses/sec (Register N=1008, {Wd}x{H})", "value": round(1008 * k8 / t8, 2), "unit": "hypotheses/s",
+                 "ms_per_step": round(t8 / k8 * 1e3, 3), "steps": k8, "n_gpus": world, "scaling": "strong",
+                 "workload": f"BASELINE configs[3]: Register N=1008 sharded, {-(-1008 // world)}/GPU, {Wd}x{H}, refine_itr=1, f16"}
+
+    # ---- the other BASELINE configs as short legs of the one default run (one GPU): configs[4] FP8 1280x720 textured + untextured,
+    # configs[1] bf16 Track -- each on its own model / precision, each with its own roofline
+    if world == 1 and not force_shard and not args.no_extras and rank == 0 and not args.track and args.dtype == "f16" and (Wd, H) == (640, 480):
+        def register_leg(textured, dtype, w, h, steps):
+            mesh_l = syn.make_mesh(textured=textured)
+            scene_l = syn.make_scene(mesh_l, w, h)
+            m = FoundationPose(mesh_l, scene_l.K, rp_keep, sp_keep, max_input_image_height=max(1080, h), max_input_image_width=max(1920, w))
+            try:
+                if dtype == "fp8":
+                    m.calibrate_fp8(scene_l.rgb, scene_l.depth, scene_l.mask, mesh_l.name)
+                    m.set_precision(FP_PREC_FP8)
+                r_, d_, k_ = (torch.from_numpy(x).to(dev) for x in (scene_l.rgb, scene_l.depth, scene_l.mask))
+                o_ = np.zeros(16, np.float32)
+
+                def fn():
+                    m._must(m._L.fp_register_ex(m.handle, C.c_void_p(r_.data_ptr()), C.c_void_p(d_.data_ptr()), C.c_void_p(k_.data_ptr()), 1,
+                                                h, w, mesh_l.name.encode(), 1, o_.ctypes.data_as(C.c_void_p)))
+                tl = timed(fn, steps, 2)
+                m.profile(True)
+                m.profile_reset()
+                fn()
+                pr = m.profile_report()
+                m.profile(False)
+                roof_l, stages_l, _, _ = analyse_profile(pr, dtype, 252, 2)
+                return {"metric": f"pose-hypotheses/sec (Register N=252, {w}x{h})", "value": round(252 * steps / tl, 2), "unit": "hypotheses/s",
+                        "ms_per_step": round(tl / steps * 1e3, 3), "steps": steps, "dtype": dtype,
+                        "config": {"workload": f"BASELINE configs[4]: Register N=252 {w}x{h} refine_itr=1, frame resident in HBM, "
+                                               f"{'512x512 texture' if textured else '2x2 grey (untextured)'} mesh",
+                                   "precision": "e4m3 operands for the 3x3 trunk convolutions from encodeA.2 on (91 % of the FLOPs), f16 elsewhere",
+                                   "calibration": "FP8 activation scales calibrated on the bench frame itself (one f16 Register, fp_calibrate_fp8)"},
+                        "roofline": roof_l, "stage_ms": dict(list(stages_l.items())[:8])}
+            finally:
+                m.close()
+        lsteps = max(5, args.steps // 2)
+        extras["fp8_720p"] = register_leg(True, "fp8", 1280, 720, lsteps)
+        extras["fp8_720p_untextured"] = register_leg(False, "fp8", 1280, 720, lsteps)
+        # configs[1]: Track, N = 1, bf16 refine-net
+        model.set_precision(FP_PREC_BF16)
+        kb = max(args.steps * 5, 50)
+        tb = timed(track_dev, kb, 10)
+        model.profile(True)
+        model.profile_reset()
+        track_dev()
+        bprof = model.profile_report()
+        model.profile(False)
+        model.set_precision(0)
+        bflops = sum(v["flops"] for k, v in bprof.items() if k.startswith("conv_") or k.startswith("gemm_") or k == "attention")
+        extras["track_bf16"] = {
+            "metric": "Track fps (N=1)", "value": round(kb / tb, 1), "unit": "frames/s", "ms_per_frame": round(tb / kb * 1e3, 4), "steps": kb,
+            "dtype": "bf16", "config": {"workload": f"BASELINE configs[1]: Track N=1 {Wd}x{H}, bf16 refine-net, frame resident in HBM"},
+            "roofline": {"bound": "launch latency (one hipGraph of dependent kernels), not MFMA", "algorithmic_gflop_per_frame": round(bflops / 1e9, 2),
+                         "achieved": round(bflops / (tb / kb) / 1e12, 1), "peak": PEAK_FP16_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(bflops / (tb / kb) / 1e12 / PEAK_FP16_TFLOPS, 4), "kernels_per_frame": sum(v["calls"] for v in bprof.values())}}
+    if n1008 is not None:
+        extras["n1008"] = n1008
+
     if rank == 0:
         units = 1 if args.track else n_total
         ms = dt / args.steps * 1e3
-        # profiler keys are "<layer>/<kernel symbol>" for the conv family, "<kernel family>" otherwise
-        conv = {k: v for k, v in prof.items() if k.startswith("conv_") or k.startswith("gemm_")}
-        conv_flops = sum(v["flops"] for v in conv.values())
-        conv_ms = sum(v["ms"] for v in conv.values())
-        # in FP8 precision the 3x3 trunk layers from encodeA.2 on run on e4m3 operands (5 PFLOP/s dense), the rest on f16
-        fp8_layers = {"conv_128", "conv_256", "conv_b2", "conv_512"} if args.dtype == "fp8" else set()
-        by_sym = {}
-        for k, v in conv.items():
-            layer = k.split("/", 1)[0]
-            sym = k.split("/", 1)[1] if "/" in k else k
-            if layer in fp8_layers and "halo8" not in sym:
-                sym += "[fp8]"
-            a = by_sym.setdefault(sym, dict(ms=0.0, flops=0.0, bytes=0.0, calls=0, fp8=layer in fp8_layers))
-            for f in ("ms", "flops", "bytes", "calls"):
-                a[f] += v[f]
-        dom, dv = max(by_sym.items(), key=lambda kv: kv[1]["ms"]) if by_sym else ("none", dict(ms=0, flops=0, bytes=0, calls=1, fp8=False))
-        peak = PEAK_FP8_TFLOPS if dv.get("fp8") else PEAK_FP16_TFLOPS
-        achieved = dv["flops"] / (dv["ms"] * 1e-3) / 1e12 if dv["ms"] > 0 else 0.0
-        family = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
-        # the family's own ceiling: time at peak of every launch's FLOPs at its operand type
-        ideal_ms = sum(v["flops"] / ((PEAK_FP8_TFLOPS if v["fp8"] else PEAK_FP16_TFLOPS) * 1e12) * 1e3 for v in by_sym.values())
-        stages = {}
-        for k, v in prof.items():
-            stages[k.split("/", 1)[0]] = stages.get(k.split("/", 1)[0], 0.0) + v["ms"]
-        stages = {k: round(v, 3) for k, v in sorted(stages.items(), key=lambda kv: -kv[1])}
+        roof, stages, dom, dv = analyse_profile(prof, args.dtype, n_total // world if world > 1 else n_total, 1 if args.track else 2)
         traffic, traffic_src = None, None
         pmc_path = os.path.join(ROOT, "profiles", PMC_FILE)
         if os.path.exists(pmc_path) and not args.track and world == 1 and args.dtype == "f16" and (Wd, H) == (640, 480):
@@ -305,38 +414,34 @@ def main():
             "unit": "frames/s" if args.track else "hypotheses/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
             "higher_is_better": True,
-            "scaling": "weak" if args.hyps == 0 else "strong",
-            "vs_baseline": None if args.track else round(units * args.steps / dt / BASELINE_HYP_S, 3),
+            "scaling": "weak" if args.weak and args.hyps == 0 else "strong",
+            # the reference's number is timed around the host-frame call (speed_register): compare like with like when that leg ran
+            "vs_baseline": None if args.track else round((extras["host_frame"]["value"] if "host_frame" in extras and n_total == 252
+                                                          else units * args.steps / dt) / BASELINE_HYP_S, 3),
             "dtype": args.dtype, "data": "synthetic",
             "config": {
                 "workload": (f"Track N=1 {Wd}x{H}" if args.track else
-                             f"Register N={n_total} hypotheses ({n_total // world}/GPU) {Wd}x{H} refine_itr=1, frame resident in HBM"),
+                             f"Register N={n_total} hypotheses" + (f" sharded, {-(-n_total // world)}/GPU," if world > 1 else ",") +
+                             f" {Wd}x{H} refine_itr=1, frame resident in HBM"),
                 "mesh": f"synthetic ellipsoid V=2562 F=5120, {'2x2 grey (untextured)' if args.untextured else '512x512 texture'}",
                 "weights": "synthetic (seed 7)",
                 "precision": {"f16": "f16 storage / f32 accumulate (the reference's TensorRT --fp16)",
                               "bf16": "bf16 storage / f32 accumulate",
                               "fp8": "e4m3 operands (per-channel weight scale, calibrated per-tensor activation scale) for the 3x3 trunk "
                                      "convolutions from encodeA.2 on (91 % of the FLOPs), f16 elsewhere"}[args.dtype],
+                "calibration": "FP8 activation scales calibrated on the bench frame itself (one f16 Register, fp_calibrate_fp8)" if args.dtype == "fp8" else None,
                 "parallelism": f"hyp-shard x{world}" if world > 1 else "single GPU",
                 "collective": "1 RCCL all-gather [n_local,528] f32 per Register" if world > 1 else "none",
-                "baseline": "reference README.md:37-41 Register 2.8 fps x 252 = 705.6 hyp/s on RTX 4060 (TensorRT fp16)",
+                "baseline": "reference README.md:37-41 Register 2.8 fps x 252 = 705.6 hyp/s on RTX 4060 (TensorRT fp16), timed around the host-frame "
+                            "call; vs_baseline = host_frame.value / 705.6 when that leg ran (N=1 default run), else value / 705.6",
             },
-            "roofline": {
-                "bound": "mfma", "kernel": dom,
-                "achieved": round(achieved, 1), "peak": peak, "unit": "TFLOP/s",
-                "frac": round(achieved / peak, 4),
+            "roofline": dict(roof, **{
                 "peak_measured": measured_peak, "peak_measured_clock_mhz": measured_mhz,
                 "peak_measured_what": "register-resident f16 MFMA micro-benchmark on this box (fp8 MFMAs: 2x)",
-                "frac_of_measured": round(achieved / (measured_peak * (2 if dv.get("fp8") else 1)), 4) if measured_peak else None,
-                "launches_per_step": dv["calls"], "algorithmic_gflop_per_launch": round(dv["flops"] / max(dv["calls"], 1) / 1e9, 1),
-                "avg_launch_ms": round(dv["ms"] / max(dv["calls"], 1), 4),
-                "algorithmic_bytes_per_launch": round(dv["bytes"] / max(dv["calls"], 1)),
+                "frac_of_measured": round(roof["achieved"] / (measured_peak * (2 if dv.get("fp8") else 1)), 4) if measured_peak else None,
                 "traffic": traffic, "traffic_source": traffic_src,
                 "traffic_kind": "committed rocprofv3 PMC passes of the same command (profiles/), NOT measured by this run" if traffic else None,
-                "conv_family": {"achieved": round(family, 1), "gflop_per_step": round(conv_flops / 1e9, 1), "ms_per_step": round(conv_ms, 3),
-                                "ms_at_peak": round(ideal_ms, 3), "frac": round(ideal_ms / conv_ms, 4) if conv_ms > 0 else None,
-                                "kernels_ms": {k2: round(v2["ms"], 3) for k2, v2 in by_sym.items()}},
-            },
+            }),
             "stage_ms": stages,
         }
         res.update(extras)
