@@ -193,6 +193,8 @@ class Graph:
         self.init: dict[str, np.ndarray] = {}
         self.inputs: list[str] = []
         self.outputs: list[str] = []
+        self.opset: int | None = None          # default-domain opset version (ModelProto.opset_import)
+        self.producer: str = ""
 
 
 def read_graph(path: str) -> Graph:
@@ -203,6 +205,17 @@ def read_graph(path: str) -> Graph:
     for fn, wt, v in _fields(data):
         if fn == 7 and wt == 2:
             gbuf = v
+        elif fn == 2 and wt == 2:
+            g.producer = bytes(v).decode("utf-8", "replace")
+        elif fn == 8 and wt == 2:              # OperatorSetIdProto {1: domain, 2: version}
+            dom, ver = "", None
+            for f2, _w2, v2 in _fields(v):
+                if f2 == 1:
+                    dom = bytes(v2).decode()
+                elif f2 == 2:
+                    ver = int(v2)
+            if dom in ("", "ai.onnx") and ver is not None:
+                g.opset = ver
     if gbuf is None:
         raise ValueError(f"{path}: no GraphProto (field 7) -- not an ONNX model?")
     for fn, wt, v in _fields(gbuf):
@@ -257,11 +270,15 @@ def _convs(g: Graph):
     """[(weight OIHW, bias)] in graph order, BatchNormalization folded (eval-mode formula, weights.fold_batchnorm)."""
     cons = _consumers(g)
     out = []
+    seen_w = set()
     for n in g.nodes:
         if n.op != "Conv":
             continue
         if n.inputs[1] not in g.init:
             raise ValueError(f"Conv {n!r}: weight is not a constant")
+        if n.inputs[1] in seen_w:              # the same weights applied twice (encodeA run on A and on B separately): one layer
+            continue
+        seen_w.add(n.inputs[1])
         w = _f32(g.init[n.inputs[1]]).astype(np.float64)
         b = _f32(g.init[n.inputs[2]]).astype(np.float64) if len(n.inputs) > 2 and n.inputs[2] in g.init else np.zeros(w.shape[0])
         nxt = cons.get(n.outputs[0], [])
@@ -390,6 +407,137 @@ def extract(path: str, kind: str) -> dict:
     return st
 
 
+
+def check(path: str, kind: str | None = None):
+    """Structural diff of an ONNX file against the architecture the library implements -- a REPORT, not an
+    assert: -> (convertible: bool, lines).  Lines starting with "ok" agree, "note" are deviations the reader absorbs (leading
+    NHWC->NCHW Transpose, unfused BatchNormalization, Constant-fed weights, decomposed LayerNorm, split q/k/v projections,
+    encodeA applied twice), "DIFF" are what `convert` would fail on.  `kind` defaults to what the outputs say."""
+    g = read_graph(path)
+    L: list[str] = []
+    bad = [False]
+
+    def ok(m): L.append("ok    " + m)
+    def note(m): L.append("note  " + m)
+    def diff(m):
+        L.append("DIFF  " + m)
+        bad[0] = True
+    ops: dict[str, int] = {}
+    for n in g.nodes:
+        ops[n.op] = ops.get(n.op, 0) + 1
+    L.append(f"file  {path}: producer {g.producer or '?'}, opset {g.opset}, {len(g.nodes)} nodes, {len(g.init)} constant tensors")
+    if kind is None:
+        kind = "refiner" if len(g.outputs) == 2 else "scorer"
+        L.append(f"kind  inferred from {len(g.outputs)} output(s): {kind}")
+    # ---- inputs / outputs (reference blob names, foundationpose.cpp:78-83)
+    if len(g.inputs) == 2:
+        (ok if [i.lower() for i in g.inputs] == ["render_input", "transf_input"] else note)(f"inputs {g.inputs} (reference blobs: render_input, transf_input)")
+    else:
+        diff(f"expected 2 graph inputs (render_input, transf_input), found {g.inputs}")
+    want_out = ["trans", "rot"] if kind == "refiner" else ["scores"]
+    if len(g.outputs) != len(want_out):
+        diff(f"a {kind} has {len(want_out)} output(s) {want_out}; found {g.outputs}")
+    else:
+        (ok if sorted(o.lower() for o in g.outputs) == sorted(want_out) else note)(f"outputs {g.outputs} (reference blobs: {want_out})")
+    # ---- layout: the *_hwc files take NHWC blobs and transpose inside the graph
+    cons = _consumers(g)
+    for i in g.inputs:
+        first = cons.get(i, [])
+        tr = [n for n in first if n.op == "Transpose"]
+        if tr:
+            perm = tr[0].attrs.get("perm")
+            note(f"input {i!r} feeds Transpose(perm={list(perm) if perm is not None else '?'}): NHWC blob -> NCHW inside the graph "
+                 "(the library takes the NHWC blob directly, no action needed)")
+        elif first:
+            note(f"input {i!r} feeds {first[0].op} directly (no leading Transpose: an NCHW export? the library's boundary is NHWC)")
+    # ---- convolutions
+    n_conv_nodes = ops.get("Conv", 0)
+    try:
+        convs = _convs(g)
+    except ValueError as e:
+        diff(str(e))
+        convs = []
+    shapes = [tuple(c[1].shape) for c in convs]
+    if n_conv_nodes != len(convs):
+        note(f"{n_conv_nodes} Conv nodes share {len(convs)} weight tensors (encodeA applied to the two inputs separately): de-duplicated")
+    if shapes == _CONV_SHAPES:
+        ok(f"15 convolutions with the shapes of encodeA / encodeAB in order")
+    else:
+        diff(f"convolutions: expected {len(_CONV_SHAPES)} with shapes {_CONV_SHAPES}")
+        for i in range(max(len(shapes), len(_CONV_SHAPES))):
+            a = shapes[i] if i < len(shapes) else None
+            b = _CONV_SHAPES[i] if i < len(_CONV_SHAPES) else None
+            if a != b:
+                L.append(f"        conv #{i} ({_CONV_NAMES[i] if i < len(_CONV_NAMES) else 'extra'}): found {a}, expected {b}")
+    want_stride = {0: 2, 1: 2, 10: 2}
+    for i, (n, w, _b) in enumerate(convs[:15]):
+        st_ = n.attrs.get("strides")
+        pd = n.attrs.get("pads")
+        k = w.shape[-1]
+        if st_ is not None and list(st_) != [want_stride.get(i, 1)] * 2:
+            diff(f"conv #{i} ({_CONV_NAMES[i]}): strides {list(st_)}, expected {[want_stride.get(i, 1)] * 2}")
+        if pd is not None and list(pd) != [(k - 1) // 2] * 4:
+            diff(f"conv #{i} ({_CONV_NAMES[i]}): pads {list(pd)}, expected {[(k - 1) // 2] * 4}")
+        if int(n.attrs.get("group", 1)) != 1 or (n.attrs.get("dilations") is not None and list(n.attrs["dilations"]) != [1, 1]):
+            diff(f"conv #{i} ({_CONV_NAMES[i]}): grouped / dilated convolution")
+    nbn = ops.get("BatchNormalization", 0)
+    if nbn:
+        note(f"{nbn} unfused BatchNormalization node(s): folded into the preceding Conv by the reader (eval-mode formula)")
+    else:
+        ok("BatchNorm already folded into the convolutions by the exporter")
+    nconst = sum(1 for n in g.nodes if n.op == "Constant")
+    if nconst:
+        note(f"{nconst} Constant node(s): treated like initialisers")
+    # ---- linear layers / LayerNorm
+    E = W.EMBED
+    lin, lns = _linears(g), _layernorms(g)
+
+    def try_take(seq, specs, what):
+        try:
+            _take_linears(seq, specs, what)
+            ok(f"{what}: linear layers {[f'{o}x{k}' for _a, _b, o, k in specs]}" +
+               ("" if len(seq) == len(specs) else f" (q/k/v arrive as separate 512x512 projections: re-packed)"))
+        except ValueError as e:
+            diff(str(e))
+    if kind == "refiner" and len(g.outputs) == 2:
+        names = {o.lower(): o for o in g.outputs}
+        o_trans = names.get("trans", g.outputs[0])
+        o_rot = names.get("rot", g.outputs[1] if o_trans == g.outputs[0] else g.outputs[0])
+        anc = {"trans_head": _ancestors(g, o_trans), "rot_head": _ancestors(g, o_rot)}
+        for head, other in (("trans_head", "rot_head"), ("rot_head", "trans_head")):
+            own = anc[head] - anc[other]
+            specs = _mha_specs(f"{head}.0.self_attn") + [(f"{head}.0.linear1.weight", f"{head}.0.linear1.bias", E, E),
+                                                         (f"{head}.0.linear2.weight", f"{head}.0.linear2.bias", E, E),
+                                                         (f"{head}.1.weight", f"{head}.1.bias", 3, E)]
+            try_take([l for l in lin if l[0].index in own], specs, head)
+            hl = [l for l in lns if l[0].index in own]
+            (ok if len(hl) == 2 else diff)(f"{head}: {len(hl)} LayerNorm(s) (expected 2: post-norm TransformerEncoderLayer)")
+    elif kind == "scorer":
+        try_take(lin, _mha_specs("att") + _mha_specs("att_cross") + [("linear.weight", "linear.bias", 1, E)], "scorer")
+        if lns:
+            diff(f"a scorer has no LayerNorm; found {len(lns)}")
+    if ops.get("LayerNormalization", 0) == 0 and lns:
+        note(f"LayerNorm is decomposed (opset {g.opset} < 17: ReduceMean / Sub / Pow / Sqrt / Div); affine parameters found by their module names")
+    elif kind == "refiner" and not lns:
+        diff("no LayerNorm found: neither LayerNormalization nodes nor *.norm1/.norm2 initialisers")
+    nsm = ops.get("Softmax", 0)
+    (ok if nsm == 2 else diff)(f"{nsm} Softmax node(s) (expected 2: " + ("one self-attention per head" if kind == "refiner" else "att + att_cross") + ")")
+    nrelu = ops.get("Relu", 0)
+    want_relu = (15 if n_conv_nodes == len(convs) else 15 + 6) + (2 if kind == "refiner" else 0)
+    (ok if nrelu == want_relu else note)(f"{nrelu} Relu node(s) (architecture: {want_relu})")
+    for op in ("Gelu", "Erf", "Tanh", "Sigmoid", "LeakyRelu", "InstanceNormalization", "GroupNormalization", "ConvTranspose", "Resize"):
+        if ops.get(op):
+            diff(f"{ops[op]} {op} node(s): not part of the architecture the library implements")
+    pe = [k for k, v in g.init.items() if v.ndim >= 2 and v.shape[-2:] == (400, E)]
+    (ok if pe else note)(f"positional table {pe if pe else 'not stored as a constant (computed in the graph?)'}: the library recomputes the sinusoidal table")
+    # ---- the real thing
+    try:
+        st = extract(path, kind)
+        ok(f"convert: {len(st)} tensors recovered")
+    except (ValueError, AssertionError, KeyError) as e:
+        diff(f"convert fails: {e}")
+    return (not bad[0]), L
+
 def describe(path: str) -> str:
     g = read_graph(path)
     ops: dict[str, int] = {}
@@ -407,3 +555,20 @@ def convert(path: str, kind: str, out_path: str) -> dict:
     st = extract(path, kind)
     W.write_fpw(out_path, st)
     return st
+
+
+if __name__ == "__main__":      # python -m foundationpose_cpp_amd.onnx_reader --check refiner_hwc.onnx [refiner|scorer]
+    import argparse
+    import sys
+    ap = argparse.ArgumentParser(description="inspect an ONNX file against the architecture the HIP library implements")
+    ap.add_argument("--check", metavar="ONNX", help="structural diff against SURVEY.md Appendix B (exit 1 if not convertible)")
+    ap.add_argument("--list", metavar="ONNX", help="print everything the reader sees")
+    ap.add_argument("kind", nargs="?", choices=["refiner", "scorer"])
+    a = ap.parse_args()
+    if a.list:
+        print(describe(a.list))
+    if a.check:
+        good, lines = check(a.check, a.kind)
+        print("\n".join(lines))
+        print("RESULT: " + ("convertible -- python -m foundationpose_cpp_amd.weights --onnx <kind> <file> <out.fpw>" if good else "NOT convertible as is (see DIFF lines)"))
+        sys.exit(0 if good else 1)

@@ -47,3 +47,36 @@ def test_reader_fails_loudly(tmp_path):
     write_model(p, "scorer", st2)
     with pytest.raises(ValueError, match="expected a 1x512"):
         R.extract(p, "scorer")
+
+
+def test_check_reports_a_structural_diff_instead_of_asserting(tmp_path):
+    """`python -m foundationpose_cpp_amd.onnx_reader --check`: variations the reader absorbs are NOTES (leading Transpose, unfused
+    BatchNorm, split q/k/v), what breaks the conversion is a DIFF that names the layer -- for the day the published files arrive"""
+    st = W.make_synthetic_state("refiner")
+    p = str(tmp_path / "r.onnx")
+    write_model(p, "refiner", st, "named")
+    good, lines = R.check(p)
+    text = "\n".join(lines)
+    assert good and "DIFF" not in text
+    assert "feeds Transpose" in text and "unfused BatchNormalization" in text and "separate 512x512 projections" in text
+    assert "opset 17" in text and "convert: 58 tensors" in text
+    # a different trunk: wrong channel count in one convolution -> the diff names the layer and both shapes
+    st2 = {k: v.copy() for k, v in st.items()}
+    st2["encodeAB.2.conv.weight"] = np.zeros((256, 256, 3, 3), np.float32)
+    for k in ("conv.bias", "bn.weight", "bn.bias", "bn.running_mean", "bn.running_var"):
+        st2["encodeAB.2." + k] = np.ones(256, np.float32)
+    write_model(p, "refiner", st2, "folded")
+    good, lines = R.check(p, "refiner")
+    text = "\n".join(lines)
+    assert not good and "conv #10 (encodeAB.2): found (256, 256, 3, 3), expected (512, 256, 3, 3)" in text
+    # a scorer handed in as a refiner, and the CLI's exit code
+    ss = W.make_synthetic_state("scorer")
+    write_model(p, "scorer", ss)
+    good, lines = R.check(p, "refiner")
+    assert not good and any(l.startswith("DIFF") and "output" in l for l in lines)
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "foundationpose_cpp_amd.onnx_reader", "--check", p], cwd=root, capture_output=True, text=True)
+    assert r.returncode == 0 and "RESULT: convertible" in r.stdout, r.stdout + r.stderr
+    r = subprocess.run([sys.executable, "-m", "foundationpose_cpp_amd.onnx_reader", "--check", p, "refiner"], cwd=root, capture_output=True, text=True)
+    assert r.returncode == 1 and "NOT convertible" in r.stdout
