@@ -18,7 +18,7 @@ SYMBOLS = [
     "fp_register", "fp_track", "fp_register_ex", "fp_track_ex", "fp_track_submit", "fp_track_wait", "fp_track_multi",
     "fp_upload_frame", "fp_get_xyz_map", "fp_get_hyp_poses", "fp_filter_depth",
     "fp_render_and_transform", "fp_debug_rasterize", "fp_refiner_infer", "fp_scorer_infer",
-    "fp_refine_post_process", "fp_argmax", "fp_register_shard_begin", "fp_register_shard_finish", "fp_register_shard_begin_packed", "fp_register_shard_finish_packed",
+    "fp_refine_post_process", "fp_argmax", "fp_register_shard_begin", "fp_register_shard_finish", "fp_register_shard_begin_packed", "fp_register_shard_finish_packed", "fp_download",
     "fp_profile_enable", "fp_profile_reset", "fp_profile_report", "fp_stream", "fp_synchronize",
     "fp_mesh_load_obj", "fp_mesh_free", "fp_mesh_view", "fp_mesh_orient_bounds",
     "fp_image_read_png", "fp_frame_size", "fp_read_rgb_depth_mask", "fp_read_cam_k", "fp_image_write_png_rgb",
@@ -105,6 +105,7 @@ def lib() -> C.CDLL:
         "fp_register_shard_finish": [vp, vp, vp, ci, vp, vp, vp],
         "fp_register_shard_begin_packed": [vp, vp, vp, vp, ci, ci, ci, cs, ci, ci, ci, vp, ci],
         "fp_register_shard_finish_packed": [vp, vp, ci, vp, vp],
+        "fp_download": [vp, vp, vp, C.c_size_t],
         "fp_profile_enable": [vp, ci], "fp_profile_reset": [vp], "fp_profile_report": [vp, vp, ci],
         "fp_synchronize": [vp], "fp_mesh_orient_bounds": [vp, vp, vp],
         "fp_set_precision": [vp, ci], "fp_get_precision": [vp], "fp_calibrate_fp8": [vp, vp, vp, vp, ci, ci, ci, cs],
@@ -141,19 +142,6 @@ def use_test_lib() -> None:
     global LIB_PATH
     assert _LIB is None, "use_test_lib() must come before the first lib()"
     LIB_PATH = TEST_LIB_PATH
-
-
-_HIP = None
-
-
-def hip_runtime() -> C.CDLL:
-    """libamdhip64 (already mapped by the product library) for the few host-side copies api.py does itself"""
-    global _HIP
-    if _HIP is None:
-        _HIP = C.CDLL("libamdhip64.so")
-        _HIP.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
-        _HIP.hipMemcpy.restype = C.c_int
-    return _HIP
 
 
 def last_error() -> str:

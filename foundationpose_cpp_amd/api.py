@@ -144,11 +144,10 @@ class FoundationPose:
             return False, None, -1, None, None, None
         refined = np.zeros((n, 16), np.float32)
         feats = np.zeros((n, 512), np.float32)
-        hip = _lib.hip_runtime()
-        for dst, src in ((refined, poses), (feats, feat)):
-            rc = hip.hipMemcpy(_p(dst), src, dst.nbytes, 2)      # hipMemcpyDeviceToHost
-            if rc != 0:
-                raise FoundationPoseError(f"hipMemcpy failed ({rc})")
+        # (fp_download: a copy ordered on the model's own stream -- loading a second HIP runtime through ctypes would not even
+        # share stream handles with the library's, and the legacy stream is off limits while any thread captures a hipGraph)
+        self._must(self._L.fp_download(self._h, _p(refined), poses, refined.nbytes))
+        self._must(self._L.fp_download(self._h, _p(feats), feat, feats.nbytes))
         return True, from_colmajor(out), idx.value, scores, from_colmajor(refined), feats
 
     def Track(self, rgb, depth, hyp_pose, target_name: str, refine_itr: int = 1):

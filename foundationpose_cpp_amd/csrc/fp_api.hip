@@ -28,6 +28,24 @@ static thread_local std::string g_last_error;
 // hide wrong results under exactly that overlap; the cause -- packed-f32 VALU instructions returning wrong values in lanes
 // 48-63 while waves of another queue's kernel share the SIMD -- and the fix are in DESIGN.md section 9.)
 void set_error(const std::string &msg) { g_last_error = msg; }
+
+static hipStream_t utility_stream() {
+  static thread_local hipStream_t s = nullptr;   // lives as long as the thread's HIP context; never destroyed explicitly
+  if (!s && hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) s = nullptr;
+  return s;
+}
+hipError_t memcpy_sync(void *dst, const void *src, size_t bytes, hipMemcpyKind kind) {
+  hipStream_t s = utility_stream();
+  if (!s) return hipErrorUnknown;
+  hipError_t e = hipMemcpyAsync(dst, src, bytes, kind, s);
+  return e != hipSuccess ? e : hipStreamSynchronize(s);
+}
+hipError_t memset_sync(void *dst, int value, size_t bytes) {
+  hipStream_t s = utility_stream();
+  if (!s) return hipErrorUnknown;
+  hipError_t e = hipMemsetAsync(dst, value, bytes, s);
+  return e != hipSuccess ? e : hipStreamSynchronize(s);
+}
 std::atomic<unsigned long> g_alloc_epoch{0};
 
 // ------------------------------------------------------------------------------------------------
@@ -481,7 +499,7 @@ int fpt_model_graph_state(fp_model *m) { return (m->use_graphs ? 1 : 0) | (m->tg
 int fpt_digests(fp_model *m, unsigned long long out[16]) {
   if (!m->digests) {
     FP_HIP_OK(hipMalloc((void **)&m->digests, 16 * 8));
-    FP_HIP_OK(hipMemset(m->digests, 0, 16 * 8));
+    FP_HIP_OK(fp::memset_sync(m->digests, 0, 16 * 8));
     return 0;
   }
   FP_HIP_OK(hipMemcpyAsync(out, m->digests, 16 * 8, hipMemcpyDeviceToHost, m->stream));
@@ -617,11 +635,11 @@ fp_model *fp_create(const fp_mesh *meshes, int n_meshes, const float K[9], const
     for (size_t k = 0; k < f.size(); k++) f[k] = (int32_t)src.faces[k];
     bool ok = !dev_alloc(&d.verts, v.size()) && !dev_alloc(&d.normals, v.size()) && !dev_alloc(&d.uvs, uv.size()) &&
               !dev_alloc(&d.faces, f.size()) && !dev_alloc(&d.tex, (size_t)d.TH * d.TW * 3);
-    ok = ok && hipMemcpy(d.verts, v.data(), v.size() * 4, hipMemcpyHostToDevice) == hipSuccess;
-    ok = ok && hipMemcpy(d.normals, src.normals, v.size() * 4, hipMemcpyHostToDevice) == hipSuccess;
-    ok = ok && hipMemcpy(d.uvs, uv.data(), uv.size() * 4, hipMemcpyHostToDevice) == hipSuccess;
-    ok = ok && hipMemcpy(d.faces, f.data(), f.size() * 4, hipMemcpyHostToDevice) == hipSuccess;
-    ok = ok && hipMemcpy(d.tex, src.texture, (size_t)d.TH * d.TW * 3, hipMemcpyHostToDevice) == hipSuccess;
+    ok = ok && fp::memcpy_sync(d.verts, v.data(), v.size() * 4, hipMemcpyHostToDevice) == hipSuccess;
+    ok = ok && fp::memcpy_sync(d.normals, src.normals, v.size() * 4, hipMemcpyHostToDevice) == hipSuccess;
+    ok = ok && fp::memcpy_sync(d.uvs, uv.data(), uv.size() * 4, hipMemcpyHostToDevice) == hipSuccess;
+    ok = ok && fp::memcpy_sync(d.faces, f.data(), f.size() * 4, hipMemcpyHostToDevice) == hipSuccess;
+    ok = ok && fp::memcpy_sync(d.tex, src.texture, (size_t)d.TH * d.TW * 3, hipMemcpyHostToDevice) == hipSuccess;
     m->targets.push_back(t);
     if (!ok) {
       set_error("[FoundationPose Renderer] Failed to prepare buffer!!!");
@@ -771,7 +789,7 @@ static int set_rotation_grid(fp_model *m, int steps) {
   g_alloc_epoch++;
   dev_free(m->grid_dev);
   if (dev_alloc(&m->grid_dev, m->grid_host.size())) return 1;
-  FP_HIP_OK(hipMemcpy(m->grid_dev, m->grid_host.data(), m->grid_host.size() * 4, hipMemcpyHostToDevice));
+  FP_HIP_OK(fp::memcpy_sync(m->grid_dev, m->grid_host.data(), m->grid_host.size() * 4, hipMemcpyHostToDevice));
   return 0;
 }
 
@@ -794,7 +812,7 @@ static int sample_hypotheses_async(fp_model *m, Target *t, const void *mask, int
   if (!m->samp_state) {
     if (dev_alloc(&m->samp_state, 8)) return 1;
     const int init[8] = {0x7fffffff, -1, 0x7fffffff, -1, 0, 0, 3, 0};
-    FP_HIP_OK(hipMemcpy(m->samp_state, init, sizeof(init), hipMemcpyHostToDevice));
+    FP_HIP_OK(fp::memcpy_sync(m->samp_state, init, sizeof(init), hipMemcpyHostToDevice));
     g_alloc_epoch++;
   }
   run_depth_filters(m);
@@ -1066,6 +1084,13 @@ int fp_register_shard_finish(fp_model *m, const float *all_feat_dev, const float
   }
   if (rc && g_last_error.empty()) set_error("[FoundationPose] fp_register_shard_finish failed");
   return rc;
+} FP_CATCH_INT
+
+int fp_download(fp_model *m, void *dst_host, const void *src_dev, size_t bytes) try {
+  FP_CHECK(m && dst_host && src_dev, "[FoundationPose] fp_download: invalid arguments");
+  if (bytes) FP_HIP_OK(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, m->stream));
+  FP_HIP_OK(hipStreamSynchronize(m->stream));
+  return 0;
 } FP_CATCH_INT
 
 // Sharded Register without host stalls: everything is enqueued on the model's stream, nothing is allocated or synchronised.

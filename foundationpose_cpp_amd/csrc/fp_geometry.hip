@@ -822,6 +822,11 @@ __global__ __launch_bounds__(256) void crop_kernel(const FrameRef *__restrict__ 
   const int y = i / CROP, x = i - y * CROP;
   const PoseRec &rec = recs[n];
   float sxf = rec.m0 * (float)x + rec.m2, syf = rec.m4 * (float)y + rec.m5;
+  // degenerate hypotheses (tz ~ 0: a crop window of 1e13 pixels) give source coordinates far outside any image, or NaN; clamp them
+  // to +-2^24 BEFORE the float->int conversions so that x0 + 1 / the pointer arithmetic below cannot overflow (values inside
+  // the image are untouched, NaN becomes -2^24 = outside).  A 1e-12 m hypothesis faulted the GPU here before (round 3).
+  sxf = fminf(fmaxf(sxf, -16777216.0f), 16777216.0f);
+  syf = fminf(fmaxf(syf, -16777216.0f), 16777216.0f);
   float o[6];
   {
     int x0 = (int)floorf(sxf), y0 = (int)floorf(syf);

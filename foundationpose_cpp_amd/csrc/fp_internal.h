@@ -24,6 +24,11 @@ namespace fp {
 void set_error(const std::string &msg);
 // fp_image_io.cpp: 8-bit PNG (grey / RGB / palette / alpha variants) -> RGB u8
 bool load_png_rgb(const std::string &path, std::vector<uint8_t> &rgb, int &H, int &W);
+// Synchronous copies / fills WITHOUT the legacy (null) stream: hipMemcpy / hipMemset fail with hipErrorStreamCaptureImplicit (906)
+// while ANY thread of the process captures a hipGraph (another model replaying its warm-up), so the library never touches the
+// legacy stream -- these go through a per-thread non-blocking utility stream and wait for it.
+hipError_t memcpy_sync(void *dst, const void *src, size_t bytes, hipMemcpyKind kind);
+hipError_t memset_sync(void *dst, int value, size_t bytes);
 // bumped whenever a device buffer that kernels may have baked into a captured hipGraph is (re)allocated
 extern std::atomic<unsigned long> g_alloc_epoch;
 #define FP_HIP_OK(expr)                                                                              \

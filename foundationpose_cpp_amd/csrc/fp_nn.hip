@@ -2858,7 +2858,7 @@ static T *upload(Net *net, const std::vector<T> &h) {
   T *d = nullptr;
   if (hipMalloc((void **)&d, std::max<size_t>(h.size(), 1) * sizeof(T)) != hipSuccess) return nullptr;
   net->allocs.push_back(d);
-  if (hipMemcpy(d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+  if (fp::memcpy_sync(d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
   return d;
 }
 
@@ -2923,8 +2923,8 @@ static bool make_grouped(Net *net, const ConvLayer &a, const ConvLayer &b, ConvL
   net->allocs.push_back(w);
   if (hipMalloc((void **)&bias, 2 * nb * sizeof(float)) != hipSuccess) return false;
   net->allocs.push_back(bias);
-  if (hipMemcpy(w, a.w, nw, hipMemcpyDeviceToDevice) != hipSuccess || hipMemcpy(w + nw, b.w, nw, hipMemcpyDeviceToDevice) != hipSuccess ||
-      hipMemcpy(bias, a.bias, nb * 4, hipMemcpyDeviceToDevice) != hipSuccess || hipMemcpy(bias + nb, b.bias, nb * 4, hipMemcpyDeviceToDevice) != hipSuccess)
+  if (fp::memcpy_sync(w, a.w, nw, hipMemcpyDeviceToDevice) != hipSuccess || fp::memcpy_sync(w + nw, b.w, nw, hipMemcpyDeviceToDevice) != hipSuccess ||
+      fp::memcpy_sync(bias, a.bias, nb * 4, hipMemcpyDeviceToDevice) != hipSuccess || fp::memcpy_sync(bias + nb, b.bias, nb * 4, hipMemcpyDeviceToDevice) != hipSuccess)
     return false;
   *g = a;
   g->w = w;
@@ -3121,7 +3121,7 @@ static Net *net_load_impl(const char *path, bool is_scorer, int prec, std::strin
   }
   if (ok) {
     float *c = nullptr;
-    ok = hipMalloc((void **)&c, N_TRUNK_ACT * sizeof(float)) == hipSuccess && hipMemset(c, 0, N_TRUNK_ACT * sizeof(float)) == hipSuccess;
+    ok = hipMalloc((void **)&c, N_TRUNK_ACT * sizeof(float)) == hipSuccess && fp::memset_sync(c, 0, N_TRUNK_ACT * sizeof(float)) == hipSuccess;
     if (c) net->allocs.push_back(c);
     net->calib_dev = c;
     if (!ok) *err = "device allocation failed";
@@ -3171,9 +3171,9 @@ int net_set_fp8_scales(Net *net, const float amax[16]) {
   fp8_layers(net, L, in_act);
   for (int i = 0; i < 13; i++) {
     std::vector<float> ws(L[i]->Cout), cs(L[i]->Cout);
-    FP_HIP_OK(hipMemcpy(ws.data(), L[i]->wscale, ws.size() * 4, hipMemcpyDeviceToHost));
+    FP_HIP_OK(fp::memcpy_sync(ws.data(), L[i]->wscale, ws.size() * 4, hipMemcpyDeviceToHost));
     for (size_t k = 0; k < ws.size(); k++) cs[k] = ws[k] * net->act_scale[in_act[i]];
-    FP_HIP_OK(hipMemcpy(L[i]->cscale, cs.data(), cs.size() * 4, hipMemcpyHostToDevice));
+    FP_HIP_OK(fp::memcpy_sync(L[i]->cscale, cs.data(), cs.size() * 4, hipMemcpyHostToDevice));
   }
   net->fp8_ready = true;
   return 0;
@@ -4062,14 +4062,14 @@ int fpt_clk_probe(int blocks, double *mhz_out, double *loop_cycles_out) {
   if (blocks > 0) {
     if (g_clk_probe) (void)hipFree(g_clk_probe);
     FP_HIP_OK(hipMalloc((void **)&g_clk_probe, (size_t)blocks * 32));
-    FP_HIP_OK(hipMemset(g_clk_probe, 0, (size_t)blocks * 32));
+    FP_HIP_OK(fp::memset_sync(g_clk_probe, 0, (size_t)blocks * 32));
     return 0;
   }
   FP_CHECK(g_clk_probe, "no probe");
   int n = -blocks;
   std::vector<unsigned long long> h((size_t)n * 4);
   FP_HIP_OK(hipDeviceSynchronize());
-  FP_HIP_OK(hipMemcpy(h.data(), g_clk_probe, h.size() * 8, hipMemcpyDeviceToHost));
+  FP_HIP_OK(fp::memcpy_sync(h.data(), g_clk_probe, h.size() * 8, hipMemcpyDeviceToHost));
   double sc = 0, sr = 0; int cnt = 0;
   for (int i = 0; i < n; i++) {
     if (h[i * 4 + 3] > h[i * 4 + 1]) { sc += (double)(h[i * 4 + 2] - h[i * 4]); sr += (double)(h[i * 4 + 3] - h[i * 4 + 1]); cnt++; }
@@ -4104,11 +4104,11 @@ int fpt_conv_dt(const float *x, const float *w, const float *bias, const float *
         for (int c = 0; c < Cin; c++)
           xp[(((size_t)n * Hp + y + ip) * Wp + xx + ip) * Cin + c] = x[(((size_t)n * H + y) * W + xx) * Cin + c];
   auto hx = encode(xp.data(), nx, dt, in_scale);
-  FP_HIP_OK(hipMemcpy(dx.p, hx.data(), hx.size(), hipMemcpyHostToDevice));
-  FP_HIP_OK(hipMemset(dout.p, 0, nout * 2 * oes));
+  FP_HIP_OK(fp::memcpy_sync(dx.p, hx.data(), hx.size(), hipMemcpyHostToDevice));
+  FP_HIP_OK(fp::memset_sync(dout.p, 0, nout * 2 * oes));
   if (res) {
     auto hr = encode(res, nout, dt, res_scale);
-    FP_HIP_OK(hipMemcpy(dres.p, hr.data(), hr.size(), hipMemcpyHostToDevice));
+    FP_HIP_OK(fp::memcpy_sync(dres.p, hr.data(), hr.size(), hipMemcpyHostToDevice));
   }
   Net net;
   ConvLayer L;
@@ -4116,9 +4116,9 @@ int fpt_conv_dt(const float *x, const float *w, const float *bias, const float *
   FP_CHECK(finish_layer(&net, std::vector<float>(w, w + nw), std::vector<float>(bias, bias + Cout), Cout, KH * KW, Cin, dt, &L), "fpt_conv: weight upload failed");
   if (dt == DT_FP8) {
     std::vector<float> cs(Cout);
-    FP_HIP_OK(hipMemcpy(cs.data(), L.wscale, (size_t)Cout * 4, hipMemcpyDeviceToHost));
+    FP_HIP_OK(fp::memcpy_sync(cs.data(), L.wscale, (size_t)Cout * 4, hipMemcpyDeviceToHost));
     for (auto &v : cs) v *= in_scale;
-    FP_HIP_OK(hipMemcpy(L.cscale, cs.data(), (size_t)Cout * 4, hipMemcpyHostToDevice));
+    FP_HIP_OK(fp::memcpy_sync(L.cscale, cs.data(), (size_t)Cout * 4, hipMemcpyHostToDevice));
   }
   Ctx c{nullptr, nullptr, &net};
   (void)OH; (void)OW;
@@ -4141,7 +4141,7 @@ int fpt_conv_dt(const float *x, const float *w, const float *bias, const float *
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
   std::vector<unsigned char> ho(nout * oes);
-  FP_HIP_OK(hipMemcpy(ho.data(), dout.p, ho.size(), hipMemcpyDeviceToHost));
+  FP_HIP_OK(fp::memcpy_sync(ho.data(), dout.p, ho.size(), hipMemcpyDeviceToHost));
   decode(ho.data(), nout, out_dt, out_scale, out);
   return 0;
 }
@@ -4159,12 +4159,12 @@ int fpt_attention_dt(const float *qkv, int B, int T, float *out, int dt) {
   DevBuf<unsigned char> dq(nq * 2), dout(no * 2);
   FP_CHECK(dq.p && dout.p, "fpt_attention: allocation failed");
   auto hq = encode(qkv, nq, dt, 1.f);
-  FP_HIP_OK(hipMemcpy(dq.p, hq.data(), nq * 2, hipMemcpyHostToDevice));
+  FP_HIP_OK(fp::memcpy_sync(dq.p, hq.data(), nq * 2, hipMemcpyHostToDevice));
   Ctx c{nullptr, nullptr, nullptr};
   if (run_attention(c, dt, dq.p, dout.p, B, T)) return 1;
   FP_HIP_OK(hipDeviceSynchronize());
   std::vector<unsigned char> ho(no * 2);
-  FP_HIP_OK(hipMemcpy(ho.data(), dout.p, no * 2, hipMemcpyDeviceToHost));
+  FP_HIP_OK(fp::memcpy_sync(ho.data(), dout.p, no * 2, hipMemcpyDeviceToHost));
   decode(ho.data(), no, dt, 1.f, out);
   return 0;
 }
@@ -4209,13 +4209,13 @@ long long fpt_conv_stress(int NB0, int H0, int Cin0, int Cout0, int with_res, in
       for (auto &v : hb) v = rnd();
       hipStream_t s;
       if (hipStreamCreate(&s) != hipSuccess) return;
-      (void)hipMemcpy(dx.p, hx.data(), nx * 2, hipMemcpyHostToDevice);
-      (void)hipMemcpy(dw.p, hw.data(), nw * 2, hipMemcpyHostToDevice);
-      (void)hipMemcpy(dres.p, hr.data(), nout * 2, hipMemcpyHostToDevice);
-      (void)hipMemcpy(db.p, hb.data(), (size_t)Cout * 4, hipMemcpyHostToDevice);
-      (void)hipMemset(dout.p, 0, nout * 2);
-      (void)hipMemset(dref.p, 0, nout * 2);
-      (void)hipMemset(dcnt.p, 0, 8);
+      (void)fp::memcpy_sync(dx.p, hx.data(), nx * 2, hipMemcpyHostToDevice);
+      (void)fp::memcpy_sync(dw.p, hw.data(), nw * 2, hipMemcpyHostToDevice);
+      (void)fp::memcpy_sync(dres.p, hr.data(), nout * 2, hipMemcpyHostToDevice);
+      (void)fp::memcpy_sync(db.p, hb.data(), (size_t)Cout * 4, hipMemcpyHostToDevice);
+      (void)fp::memset_sync(dout.p, 0, nout * 2);
+      (void)fp::memset_sync(dref.p, 0, nout * 2);
+      (void)fp::memset_sync(dcnt.p, 0, 8);
       Net net;
       ConvLayer L;
       L.w = (unsigned char *)dw.p; L.bias = db.p; L.Cin = Cin; L.Cout = Cout; L.KH = 3; L.KW = 3; L.stride = 1; L.pad = 1;
@@ -4262,7 +4262,7 @@ __global__ void fpt_lds_canary_kernel(int words, int spins, unsigned long long *
 long long fpt_lds_canary(int NB, int H, int Cin, int Cout, int iters, int canary_bytes) {
   using namespace fp;
   unsigned long long *dbad = nullptr;
-  if (hipMalloc((void **)&dbad, 8) != hipSuccess || hipMemset(dbad, 0, 8) != hipSuccess) return -1;
+  if (hipMalloc((void **)&dbad, 8) != hipSuccess || fp::memset_sync(dbad, 0, 8) != hipSuccess) return -1;
   std::atomic<int> stop{0};
   std::thread canary([&]() {
     hipStream_t s;
@@ -4277,7 +4277,7 @@ long long fpt_lds_canary(int NB, int H, int Cin, int Cout, int iters, int canary
   stop.store(1);
   canary.join();
   unsigned long long bad = 0;
-  (void)hipMemcpy(&bad, dbad, 8, hipMemcpyDeviceToHost);
+  (void)fp::memcpy_sync(&bad, dbad, 8, hipMemcpyDeviceToHost);
   (void)hipFree(dbad);
   return rc < 0 ? rc : (long long)bad;
 }
@@ -4343,7 +4343,7 @@ float fpt_attention_bench(int B, int T, int iters, int variant) {
   std::vector<__half> hq(nq);
   uint32_t st = 12345u;
   for (size_t i = 0; i < nq; i++) { st = st * 1664525u + 1013904223u; hq[i] = __float2half(((st >> 8) & 0xffff) / 65536.0f - 0.5f); }
-  if (hipMemcpy(dq.p, hq.data(), nq * 2, hipMemcpyHostToDevice) != hipSuccess) return -1.f;
+  if (fp::memcpy_sync(dq.p, hq.data(), nq * 2, hipMemcpyHostToDevice) != hipSuccess) return -1.f;
   Ctx c{nullptr, nullptr, nullptr};
   int saved = g_att_variant;
   g_att_variant = variant;
@@ -4386,7 +4386,7 @@ float fpt_mfma_peak(int iters, int waves_per_simd, int zero_operands, double *mh
   if (!ok || ms <= 0.f) return -1.f;
   if (mhz) {  // shader clock during the run: cycle counter against the 100 MHz wall clock
     unsigned long long h[2] = {0, 0};
-    if (hipMemcpy(h, clk.p, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) return -1.f;
+    if (fp::memcpy_sync(h, clk.p, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) return -1.f;
     *mhz = h[1] ? (double)h[0] / (double)h[1] * 100.0 : 0.0;
   }
   const double flops = (double)wgs * 4.0 * (double)iters * 8.0 * 16384.0;

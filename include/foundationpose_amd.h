@@ -147,6 +147,10 @@ int fp_register_shard_begin(fp_model *m, const void *rgb, const void *depth, con
                             float **feat_dev, float **poses_dev);
 int fp_register_shard_finish(fp_model *m, const float *all_feat_dev, const float *all_poses_dev, int N_total,
                              float out_pose[16], int *best_index, float *scores_host /* may be NULL */);
+/* Read a device buffer the library handed out (feat_dev / poses_dev above) back to the host: a copy ordered on the model's own
+ * stream + one synchronisation.  For callers without a HIP runtime of their own (the ctypes host side, tests); never uses the
+ * legacy stream (a plain hipMemcpy fails with hipErrorStreamCaptureImplicit while any thread of the process captures a graph). */
+int fp_download(fp_model *m, void *dst_host, const void *src_dev, size_t bytes);
 /* The same exchange without host stalls (what foundationpose_cpp_amd/distributed.py and bench.py --gpus N use):
  *   fp_register_shard_begin_packed : as above, but only ENQUEUES on the model's stream (fp_stream) and leaves one row
  *                                    [feature 512 | pose 16] per hypothesis in the CALLER's device buffer packed_dev

@@ -3,6 +3,11 @@ import sys
 
 import pytest
 
+try:                 # torch wheels bundle their own HIP / HSA runtime: it has to be the FIRST one loaded into the process -- a torch
+    import torch     # imported after libfoundationpose_amd.so (which links /opt/rocm's) finds "No HIP GPUs" 
+except ImportError:  # pragma: no cover
+    torch = None
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -414,3 +414,76 @@ def test_register_is_deterministic(model, syn_mesh, syn_scene):
     poses = [model.Register(syn_scene.rgb, syn_scene.depth, syn_scene.mask, syn_mesh.name)[1] for _ in range(3)]
     np.testing.assert_array_equal(poses[0], poses[1])
     np.testing.assert_array_equal(poses[0], poses[2])
+
+
+def _track_both_ways(mesh, scene, nets, hyp, Wd, H):
+    """Track from a HOST frame on a model that has never seen a whole frame (only the rows of the crop window are uploaded) vs Track
+    reading the whole frame in place from device memory"""
+    m1 = FoundationPose(mesh, scene.K, nets[0], nets[1], max_input_image_height=max(1080, H), max_input_image_width=max(1920, Wd))
+    m2 = FoundationPose(mesh, scene.K, nets[0], nets[1], max_input_image_height=max(1080, H), max_input_image_width=max(1920, Wd))
+    try:
+        ok1, p1 = m1.Track(scene.rgb, scene.depth, hyp, mesh.name)
+        assert ok1, m1.last_error
+        rgb, depth = torch.from_numpy(scene.rgb).cuda(), torch.from_numpy(scene.depth).cuda()
+        out = np.zeros(16, np.float32)
+        h16 = syn.to_colmajor(hyp[None].astype(np.float32))[0]
+        m2._must(m2._L.fp_track_ex(m2.handle, C.c_void_p(rgb.data_ptr()), C.c_void_p(depth.data_ptr()), 1, H, Wd, _p(h16),
+                                   mesh.name.encode(), 1, _p(out)))
+        return p1, syn.from_colmajor(out[None])[0]
+    finally:
+        m1.close()
+        m2.close()
+
+
+@pytest.mark.parametrize("Wd,H,ty", [(640, 480, -0.45), (640, 480, 0.45), (640, 480, -0.9), (640, 480, 0.9), (1280, 720, -0.02), (1280, 720, 0.385),
+                                     (1280, 720, -0.39)])
+def test_track_partial_row_upload_at_the_image_border(nets, syn_mesh, Wd, H, ty):
+    """the host-side estimate of the observed-crop window (fp_api.hip track_submit_impl: double precision + margin) against what the
+    kernels read: windows crossing row 0 / row H-1, windows entirely outside the frame (nothing is uploaded), 1280x720"""
+    scene = syn.make_scene(syn_mesh, Wd, H)
+    hyp = syn.perturb_pose(scene.gt_pose)
+    hyp[1, 3] = ty
+    v0 = scene.K[1, 2] + scene.K[1, 1] * ty / hyp[2, 3]
+    rad = scene.K[1, 1] * syn_mesh.diameter * 0.6 / hyp[2, 3]
+    kind = "outside" if (v0 + rad < 0 or v0 - rad > H) else ("border" if (v0 - rad < 0 or v0 + rad > H - 1) else "inside")
+    assert kind == ("outside" if abs(ty) > 0.8 else "inside" if abs(ty) < 0.1 else "border"), (kind, v0, rad)
+    p1, p2 = _track_both_ways(syn_mesh, scene, nets, hyp, Wd, H)
+    np.testing.assert_array_equal(p1, p2)
+
+
+def test_track_partial_row_upload_random_windows(nets, syn_mesh):
+    """60 random hypotheses (depth 0.3-1.5 m, rows far beyond both borders) on FRESH noise frames, one reused model: a row the host
+    estimate misses would still hold the previous frame's noise and change the pose"""
+    rng = np.random.default_rng(12)
+    K = syn.intrinsics()
+    m1 = FoundationPose(syn_mesh, K, nets[0], nets[1])
+    m2 = FoundationPose(syn_mesh, K, nets[0], nets[1])
+    base = syn.perturb_pose(syn.pose_matrix(syn.random_rotation(3), [0, 0, 0.7]).astype(np.float32))
+    out = np.zeros(16, np.float32)
+    try:
+        for k in range(60):
+            rgb = rng.integers(0, 256, (480, 640, 3), dtype=np.uint8)
+            depth = rng.uniform(0.2, 2.0, (480, 640)).astype(np.float32)
+            hyp = base.copy()
+            tz = rng.uniform(0.3, 1.5)
+            hyp[:3, 3] = [rng.uniform(-0.5, 0.5) * tz, rng.uniform(-1.2, 1.2) * tz, tz]
+            ok, p1 = m1.Track(rgb, depth, hyp, syn_mesh.name)
+            assert ok, m1.last_error
+            r_d, d_d = torch.from_numpy(rgb).cuda(), torch.from_numpy(depth).cuda()
+            h16 = syn.to_colmajor(hyp[None])[0]
+            m2._must(m2._L.fp_track_ex(m2.handle, C.c_void_p(r_d.data_ptr()), C.c_void_p(d_d.data_ptr()), 1, 480, 640, _p(h16),
+                                       syn_mesh.name.encode(), 1, _p(out)))
+            np.testing.assert_array_equal(p1, syn.from_colmajor(out[None])[0], err_msg=f"iteration {k}, t = {hyp[:3, 3]}")
+        # degenerate hypotheses: behind the camera / absurd translations must not crash the host-side window arithmetic
+        for t in ([0, 0, -0.5], [0, 1e30, 1e-5], [0, -1e30, 0.5], [0, 0, 1e-12]):
+            hyp = base.copy()
+            hyp[:3, 3] = t
+            ok, p1 = m1.Track(rgb, depth, hyp, syn_mesh.name)
+            m2._must(m2._L.fp_track_ex(m2.handle, C.c_void_p(r_d.data_ptr()), C.c_void_p(d_d.data_ptr()), 1, 480, 640,
+                                       _p(syn.to_colmajor(hyp[None])[0]), syn_mesh.name.encode(), 1, _p(out)))
+            assert ok
+            a, b = p1, syn.from_colmajor(out[None])[0]
+            assert np.array_equal(a, b) or (np.isnan(a) == np.isnan(b)).all(), t
+    finally:
+        m1.close()
+        m2.close()
