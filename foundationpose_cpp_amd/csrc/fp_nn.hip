@@ -520,6 +520,135 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
 }
 
 // -------------------------------------------------------------------------------------------------
+// conv_smallm_kernel [r3]: SMALL problems (Track: 1-2 images, a handful of objects) where every other schedule is a latency
+// chain.  At N = 1 a layer is a weight-streaming problem -- conv_512 is 1.9 GFLOP on 4.7 MB of weights, 400 output pixels -- and
+// the split-K schedules paid for their parallelism with an fp32 slab round trip and a SECOND launch per layer (9 reduce launches
+// = 47 us of a 335 us Track).  Here a workgroup owns 16*MI pixels x 64 channels and its four waves split the K-STEPS (wave w
+// takes steps w, w+4, ...): operands go global -> registers directly (no LDS staging, no barriers in the loop; three steps in
+// flight per wave), the four partial accumulators are summed through LDS in a fixed order (w0+w1+w2+w3) and wave 0 runs the usual
+// epilogue (bias, residual, ReLU, channel-concat addressing, positional table).  One launch per layer, every tensor written once.
+// Generic over the conv shapes of both networks (3x3 s1 / s2, the 4x4 space-to-depth stem, 1x1 Linear layers incl. the two weight
+// groups of the refiner heads): addressing is the implicit-GEMM one (ConvParams::koff + a per-lane row offset).
+// -------------------------------------------------------------------------------------------------
+// DEEP: the layer has at least 8 * PF K-steps, i.e. every wave at least 2 * PF: the prologue loads are then UNCONDITIONAL, which
+// is what lets the compiler prove how many loads are in flight at the head of the steady-state loop (s_waitcnt vmcnt(10 * (PF-1) + 1)
+// instead of vmcnt(1): with conditional prologue loads the in-order counter has to assume the shortest path).
+template <int MI, int NI, int DT, int ODT, bool POST, bool DEEP>  // NI = 4: 64 channels per workgroup (Cout % 128 == 0); NI = 2: 32 (the row permutation of Cout == 64 layers)
+__global__ __launch_bounds__(256, 2) void conv_smallm_kernel(const ConvParams p) {
+  static_assert(DT != DT_FP8, "2-byte operand types");
+  constexpr int PF = MI == 1 ? 4 : 3;         // K-steps in flight per wave (register budget: (2*NI + 2*MI) * 4 VGPRs per step)
+  extern __shared__ __attribute__((aligned(16))) unsigned char red[];  // 3 * NI * MI KB (dynamic, like every kernel launched through FP_LAUNCH)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n_tiles = p.Cout / (16 * NI);
+  // XCD placement for a WEIGHT-bound layer: hardware puts workgroup b on XCD b % 8, every XCD has its own L2, and at this size
+  // the weights (4.7 MB for conv_512) are the traffic.  All workgroups of one channel tile go to ONE XCD (or to 8 / n_tiles XCDs
+  // when the layer has fewer than 8 channel tiles), so each L2 pulls its 1/8 of the weights once instead of every L2 pulling all
+  // of them (the m-tile-major order of the big schedules would cost 8 x 4.7 MB of fabric traffic per layer here).
+  int mt, nt;
+  {
+    const int b = blockIdx.x, xcd = b & 7, within = b >> 3;
+    if (n_tiles >= 8) {              // n_tiles % 8 == 0 (checked by the launcher)
+      const int per = n_tiles >> 3;
+      nt = xcd + 8 * (within % per);
+      mt = within / per;
+    } else {                         // 1, 2 or 4 channel tiles: 8 / n_tiles XCDs share one
+      const int share = 8 / n_tiles;
+      nt = xcd / share;
+      mt = within * share + (xcd % share);
+    }
+  }
+  if (mt * (16 * MI) >= p.M) return;   // (grid padded to a multiple of 8)
+  const int m0 = mt * (16 * MI), n0 = nt * (16 * NI);
+  const int ohw = p.OH * p.OW;
+  const int IHp = p.H + 2 * p.ipad, IWp = p.W + 2 * p.ipad;
+  const int frow = lane & 15, fk = lane >> 4;
+  const int grp = p.grp_rows ? m0 / p.grp_rows : 0;
+  // per-lane operand addresses: X row of pixel fragment mi (rows past M re-read the last pixel, never stored), W row of tile ni
+  const unsigned char *xrow[MI];
+#pragma unroll
+  for (int mi = 0; mi < MI; mi++) {
+    int m = min(m0 + mi * 16 + frow, p.M - 1);
+    if (p.in_shared) m -= grp * p.grp_rows;
+    const int img = m / ohw, rem = m - img * ohw;
+    const int oh = rem / p.OW, ow = rem - oh * p.OW;
+    const int ih0 = oh * p.stride - p.pad + p.ipad, iw0 = ow * p.stride - p.pad + p.ipad;
+    xrow[mi] = p.in + ((size_t)(img * IHp + ih0) * IWp + iw0) * p.cin_b + fk * 16;
+  }
+  const unsigned char *wrow = p.w + (p.grp_rows ? (size_t)grp * p.grp_w_bytes : 0) + (size_t)(n0 + frow) * p.krow_b + fk * 16;
+  const size_t wtile = (size_t)16 * p.krow_b;
+
+  f4 acc[NI][MI];
+#pragma unroll
+  for (int a = 0; a < NI; a++)
+#pragma unroll
+    for (int b = 0; b < MI; b++) acc[a][b] = (f4){0.f, 0.f, 0.f, 0.f};
+
+  const int KT = p.krow_b >> 7;
+  const int n_my = (KT - wave + 3) >> 2;      // steps wave, wave+4, ...
+  i4 wf[PF][2][NI], xf[PF][2][MI];
+  auto load = [&](i4 (&w)[2][NI], i4 (&x)[2][MI], int kt) {
+    const unsigned ko = p.koff[kt];
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++) {
+#pragma unroll
+      for (int ni = 0; ni < NI; ni++) w[ks][ni] = *reinterpret_cast<const i4 *>(wrow + ni * wtile + (size_t)kt * 128 + ks * 64);
+#pragma unroll
+      for (int mi = 0; mi < MI; mi++) x[ks][mi] = *reinterpret_cast<const i4 *>(xrow[mi] + ko + ks * 64);
+    }
+  };
+#pragma unroll
+  for (int s = 0; s < PF; s++)
+    if (DEEP || s < n_my) load(wf[s], xf[s], wave + 4 * s);
+  // steady state WITHOUT conditions (every step has a successor PF steps ahead): the compiler's vmcnt bookkeeping stays exact, so
+  // PF - 1 steps of loads really are in flight under each step's MFMAs (with the conditions inside, every step waited for
+  // vmcnt(0): 21 us per conv_512 launch instead of the ~6 the L1 rate allows)
+  int i = 0;
+  for (; i + 2 * PF <= n_my; i += PF) {
+#pragma unroll
+    for (int s = 0; s < PF; s++) {
+      // (scheduling fences: hipcc otherwise gathers the loads of all slots at the end of the iteration, and the in-order vmcnt
+      // at the loop head then has to wait for nearly all of them -- s_waitcnt vmcnt(1) instead of vmcnt(10 * (PF - 1)))
+      __builtin_amdgcn_sched_barrier(0);
+      mma_kstep<DT, NI, MI>(acc, wf[s], xf[s]);
+      __builtin_amdgcn_sched_barrier(0);
+      load(wf[s], xf[s], wave + 4 * (i + s + PF));
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  // tail: at most 2*PF - 1 steps
+#pragma unroll
+  for (int s = 0; s < PF; s++) {
+    if (i + s < n_my) {
+      mma_kstep<DT, NI, MI>(acc, wf[s], xf[s]);
+      if (i + s + PF < n_my) load(wf[s], xf[s], wave + 4 * (i + s + PF));
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < PF; s++)
+    if (i + PF + s < n_my) mma_kstep<DT, NI, MI>(acc, wf[s], xf[s]);
+  // ---- fixed-order reduction of the four partial sums: waves 1..3 publish, wave 0 adds them in order and stores
+  if (wave > 0) {
+    f4 *dst = reinterpret_cast<f4 *>(red + (wave - 1) * (NI * MI * 1024)) + lane;
+#pragma unroll
+    for (int a = 0; a < NI; a++)
+#pragma unroll
+      for (int b = 0; b < MI; b++) dst[(a * MI + b) * 64] = acc[a][b];
+  }
+  __syncthreads();
+  if (wave > 0) return;
+#pragma unroll
+  for (int w = 0; w < 3; w++) {
+    const f4 *src = reinterpret_cast<const f4 *>(red + w * (NI * MI * 1024)) + lane;
+#pragma unroll
+    for (int a = 0; a < NI; a++)
+#pragma unroll
+      for (int b = 0; b < MI; b++) acc[a][b] += src[(a * MI + b) * 64];
+  }
+  conv_epilogue<MI, NI, DT, ODT, POST ? 4 : 0>(p, acc, m0, n0, lane);
+}
+
+// -------------------------------------------------------------------------------------------------
 // Ping-pong variant: 256 pixels x BN channels per workgroup, 8 waves = two groups of 4 (each group owns 128 pixel
 // rows with the usual 2x2 arrangement of 64 x BN/2 wave tiles, the W tile is shared).  The groups run in strict
 // anti-phase: while group 0 pulls its 16 operand fragments of K-step kt from LDS into registers and issues the LDS-DMA
@@ -3289,6 +3418,7 @@ FP_HOOK g_att_skv = 1;          // small attention grids on attention32_skv_kern
 FP_HOOK g_gemm_deep = 1;         // short-K layers of small problems on conv_deep_kernel<128> instead of the two-stage 128x128 tile
 FP_HOOK g_splitk_mid = 1;        // two split-K slices for long-K layers with 97..128 tiles (batches of ~8 objects)
 FP_HOOK g_small_deep = 18;     // small problems (Track): conv_deep_kernel<64> over ALL K-steps instead of split-K + reduce when K has at most this many 128-byte steps
+FP_HOOK g_smallm = 1;          // small problems (Track, a few objects) on conv_smallm_kernel: K split over the waves of a workgroup, no split-K slabs / reduce launch
 FP_HOOK g_att_variant = 1;     // 1 = attention32_kernel (8 = without the XCD remap); round-1 kernel: 2 remap + 16-B stores, 3 no XCD remap, 5 remap + 2-B stores, 7 neither
 
 // One launch = (once per launch site and element type, thread-safe through the function-local static) dynamic-LDS opt-in +
@@ -3368,6 +3498,42 @@ static int run_conv_dt(const Ctx &c, const char *tag, const ConvLayer &L, ConvPa
     p.partial = sk->splitk;
     return 0;
   };
+  // ---- small problems: one launch per layer, the K-steps split over the four waves of a workgroup (conv_smallm_kernel)
+  if constexpr (B2) {
+    const int cw = (L.Cout % 128 == 0) ? 64 : 32;         // channels per workgroup = the block of the host-side row permutation
+    const int t16 = ((p.M + 15) / 16) * (L.Cout / cw);
+    // Measured on Track (tools/profile_track.sh): layers of up to 18 K-steps 8.8-9.4 us against 11 us on the LDS-ring kernels; long-K
+    // layers do NOT win -- conv_512 (72 steps) 21 us against 12.3 + 5.2 us for split-K + reduce: operand-shaped global loads touch 16
+    // cache lines per instruction (64 bytes used of each) and the vector L1 retires them at ~16 B/clk, a quarter of what the
+    // LDS-DMA rows (8 lanes per 128-byte line) get.  g_smallm = 2 forces it for every K (A/B).
+    if (g_smallm && (KT < 32 || g_smallm == 2) && g_conv_variant == 0 && g_conv_ablate == 0 && L.Cout % cw == 0 && t16 <= 1024 * (64 / cw) &&
+        (!grp || grp->rows % 32 == 0) && ((L.Cout / cw) % 8 == 0 || 8 % (L.Cout / cw) == 0)) {
+      const int t32 = ((p.M + 31) / 32) * (L.Cout / cw);
+      const bool two = t32 >= 160;                        // 32-pixel tiles halve the weight stream once they still fill the chip
+      bool post = p.post != nullptr;
+      if constexpr (ODT == DT_FP8) post = false;
+      if (!post) p.post = nullptr;
+      ProfScope ps(c.prof, c.s, (std::string(tag) + "/conv_smallm_kernel").c_str(), flops, bytes);
+      // grid = 8 XCD lanes x ceil(workgroups / 8), see the kernel's placement rule
+      const int ntl = L.Cout / cw, mtl = two ? (p.M + 31) / 32 : (p.M + 15) / 16;
+      const int per_xcd = ntl >= 8 ? mtl * (ntl / 8) : (mtl + 8 / ntl - 1) / (8 / ntl);
+      const dim3 grid(8 * per_xcd);
+      const bool deep = KT >= 32;                          // every wave has >= 8 K-steps >= 2 * PF (PF = 4 / 3)
+#define FP_SMALLM(MI_, NI_, POST_)                                                                                          \
+  do {                                                                                                                      \
+    if (deep) FP_LAUNCH((conv_smallm_kernel<MI_, NI_, DT, ODT, POST_, true>), grid, dim3(256), 3 * NI_ * MI_ * 1024, c.s, p); \
+    else FP_LAUNCH((conv_smallm_kernel<MI_, NI_, DT, ODT, POST_, false>), grid, dim3(256), 3 * NI_ * MI_ * 1024, c.s, p);    \
+  } while (0)
+      if constexpr (ODT != DT_FP8) {
+        if (post && cw == 64) { if (two) FP_SMALLM(2, 4, true); else FP_SMALLM(1, 4, true); return 0; }
+        if (post) p.post = nullptr;                      // (no 32-channel layer carries a positional table)
+      }
+      if (cw == 64) { if (two) FP_SMALLM(2, 4, false); else FP_SMALLM(1, 4, false); }
+      else { if (two) FP_SMALLM(2, 2, false); else FP_SMALLM(1, 2, false); }
+#undef FP_SMALLM
+      return 0;
+    }
+  }
   const bool small_deep = !grp && g_small_deep > 0 && KT >= 4 && KT <= g_small_deep && L.Cout % 128 == 0 && ((p.M + 63) / 64) * (L.Cout / 128) >= 40 &&
                           ((p.M + 63) / 64) * (L.Cout / 128) <= 256;
   if (!small_deep && plan_splitk(p.M, g_splitk_target)) return 1;
@@ -4040,6 +4206,7 @@ void decode(const unsigned char *src, size_t n, int dt, float scale, float *dst)
 extern "C" {
 
 void fpt_set_att_variant(int v) { fp::g_att_variant = v; }
+void fpt_set_smallm(int v) { fp::g_smallm = v; }
 void fpt_set_conv_variant(int v) { fp::g_conv_variant = v; }
 void fpt_set_conv_ablate(int v) { fp::g_conv_ablate = v; }
 void fpt_set_splitk_target(int v) { fp::g_splitk_target = v; }
