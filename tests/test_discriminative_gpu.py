@@ -294,3 +294,31 @@ def test_sharded_register_1008_over_8_ranks(model, syn_mesh, syn_scene):
     assert np.sqrt((d ** 2).mean()) <= 0.02 * spread and np.abs(d).max() <= 0.25 * spread, (np.sqrt((d ** 2).mean()) / spread, np.abs(d).max() / spread)
     assert idx_w in np.argsort(-scores)[:3], (idx_w, np.argsort(-scores)[:5])
     np.testing.assert_array_equal(p16, rows[idx_w, 512:])
+
+
+def test_track_deltas_follow_torch(model, disc_nets, syn_mesh, syn_scene):
+    """Track (N = 1: the small-problem schedules -- conv_smallm_kernel, split-K, both refiner heads grouped into ONE launch per
+    layer) under the discriminating weights: 12 different hypotheses tracked one after the other; the refinement deltas, de-meaned
+    over the 12, against the torch deltas at the f16 bar.  A swapped head, a wrong group offset in the grouped launches or a
+    mis-reduced K split moves them by O(spread)."""
+    model.set_precision(FP_PREC_F16)
+    gt = syn_scene.gt_pose
+    hyps = np.stack([syn.perturb_pose(gt, deg=2.0 + 1.5 * k, trans=0.002 + 0.001 * k, seed=40 + k) for k in range(12)])
+    got = []
+    for h in hyps:
+        ok, p = model.Track(syn_scene.rgb, syn_scene.depth, h, syn_mesh.name)
+        assert ok, model.last_error
+        got.append(p)
+    got = np.stack(got)
+    p16 = syn.to_colmajor(hyps)
+    t, r = _torch(disc_nets[2], *_oracle_blobs(syn_mesh, syn_scene, p16, 1.2))
+    ref = syn.from_colmajor(fo.refine_post_process(p16, t, r, syn_mesh.diameter))
+    d_hip, d_ref = got[:, :3, 3] - hyps[:, :3, 3], ref[:, :3, 3] - hyps[:, :3, 3]
+    spread = d_ref.std(0)
+    assert (spread > 5e-4).all(), spread                               # the 12 translation deltas differ by >= 0.5 mm per axis
+    err = _dm(d_hip) - _dm(d_ref)
+    assert (np.abs(err).max(0) <= 0.06 * spread).all(), np.abs(err).max(0) / spread
+    assert (np.abs(d_hip.mean(0) - d_ref.mean(0)) <= 0.10 * spread).all()
+    ang = _rot_err_deg(got, ref)
+    rot_spread = _rot_err_deg(ref, hyps.astype(np.float32)).std()
+    assert rot_spread > 0.2 and ang.max() <= 0.10 * rot_spread * np.sqrt(3), (ang.max(), rot_spread)
