@@ -643,7 +643,12 @@ __global__ __launch_bounds__(256, 2) void conv_smallm_kernel(const ConvParams p)
 #pragma unroll
     for (int a = 0; a < NI; a++)
 #pragma unroll
-      for (int b = 0; b < MI; b++) acc[a][b] += src[(a * MI + b) * 64];
+      for (int b = 0; b < MI; b++) {
+        const f4 v = src[(a * MI + b) * 64];
+        // component-wise on purpose: a float4 add is legalised to v_pk_add_f32, which this library must not contain
+#pragma unroll
+        for (int r = 0; r < 4; r++) acc[a][b][r] = acc[a][b][r] + v[r];
+      }
   }
   conv_epilogue<MI, NI, DT, ODT, POST ? 4 : 0>(p, acc, m0, n0, lane);
 }
