@@ -24,6 +24,8 @@ namespace fp {
 void set_error(const std::string &msg);
 // fp_image_io.cpp: 8-bit PNG (grey / RGB / palette / alpha variants) -> RGB u8
 bool load_png_rgb(const std::string &path, std::vector<uint8_t> &rgb, int &H, int &W);
+// any texture container the library decodes (PNG incl. 16-bit / sub-byte / interlaced, BMP, PNM, TGA) -> RGB u8 like cv::imread + BGR2RGB
+bool load_texture_rgb(const std::string &path, std::vector<uint8_t> &rgb, int &H, int &W, std::string *why);
 // Synchronous copies / fills WITHOUT the legacy (null) stream: hipMemcpy / hipMemset fail with hipErrorStreamCaptureImplicit (906)
 // while ANY thread of the process captures a hipGraph (another model replaying its warm-up), so the library never touches the
 // legacy stream -- these go through a per-thread non-blocking utility stream and wait for it.

@@ -28,7 +28,7 @@
 
 namespace {
 
-using fp::load_png_rgb;  // PNG decode lives in fp_image_io.cpp
+using fp::load_texture_rgb;  // image decoders live in fp_image_io.cpp
 
 // ---------------------------------------------------------------- 3x3 symmetric eigen (Jacobi) ------------------------
 void eigen_sym3(const double A_in[9], double evals[3], double evecs[9] /* columns, row-major storage */) {
@@ -244,11 +244,12 @@ static fp_loaded_mesh *fp_mesh_load_obj_impl(const char *name, const char *mesh_
     }
     const bool named = !tex_path.empty();
     const bool present = named && std::ifstream(tex_path, std::ios::binary).good();
-    if (present && !load_png_rgb(tex_path, m->texture, m->th, m->tw)) {
-      // The reference decodes whatever cv::imread knows (JPEG, BMP, interlaced PNG ...); this loader reads non-interlaced
-      // 8-bit PNG only.  A texture file that EXISTS but cannot be decoded here must not silently become the grey default:
-      // the rendered crops would get the wrong colours and refine / score accuracy would drop without a trace.
-      fp::set_error("[MeshLoader] texture '" + tex_path + "' named by map_Kd cannot be decoded (supported: non-interlaced 8-bit PNG)");
+    std::string why;
+    if (present && !load_texture_rgb(tex_path, m->texture, m->th, m->tw, &why)) {
+      // The reference decodes whatever cv::imread knows; this loader reads PNG (any bit depth, interlaced or not), BMP, PNM and
+      // TGA.  A texture file that EXISTS but cannot be decoded here (JPEG, TIFF, WebP ...) must not silently become the grey
+      // default: the rendered crops would get the wrong colours and refine / score accuracy would drop without a trace.
+      fp::set_error("[MeshLoader] texture '" + tex_path + "' named by map_Kd cannot be decoded: " + why);
       return nullptr;
     }
     if (!present) {  // no map_Kd, or the file is missing: default texture map, like the reference (:217-222)

@@ -122,3 +122,96 @@ def test_shared_position_distinct_uv_splits_vertex(tmp_path):
     m = load_mesh("s", str(tmp_path / "s.obj"))
     assert len(m.vertices) == 5 and len(m.faces) == 2
     np.testing.assert_array_equal(m.faces, [[0, 1, 2], [3, 4, 2]])
+
+
+def _png_bytes(arr, bits, ctype, interlace=False, plte=None):
+    """minimal PNG encoder for the variants PIL cannot write (16-bit RGB(A), Adam7): filter type 0, arr = [H,W,ch] samples"""
+    import struct, zlib
+    H, W, ch = arr.shape
+
+    def pack_rows(a):
+        h, w, _ = a.shape
+        if bits == 16:
+            rows = a.astype(">u2").reshape(h, -1).view(np.uint8)
+        elif bits == 8:
+            rows = a.astype(np.uint8).reshape(h, -1)
+        else:
+            flat = a.reshape(h, -1).astype(np.uint8)
+            per = 8 // bits
+            padw = (-flat.shape[1]) % per
+            flat = np.pad(flat, ((0, 0), (0, padw)))
+            rows = np.zeros((h, flat.shape[1] // per), np.uint8)
+            for k in range(per):
+                rows |= flat[:, k::per] << (8 - bits * (k + 1))
+        return b"".join(b"\x00" + rows[y].tobytes() for y in range(h))
+    if interlace:
+        raw = b""
+        for x0, y0, dx, dy in ((0, 0, 8, 8), (4, 0, 8, 8), (0, 4, 4, 8), (2, 0, 4, 4), (0, 2, 2, 4), (1, 0, 2, 2), (0, 1, 1, 2)):
+            sub = arr[y0::dy, x0::dx]
+            if sub.shape[0] and sub.shape[1]:
+                raw += pack_rows(sub)
+    else:
+        raw = pack_rows(arr)
+
+    def chunk(t, d): return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d))
+    out = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", W, H, bits, ctype, 0, 0, 1 if interlace else 0))
+    if plte is not None:
+        out += chunk(b"PLTE", plte.astype(np.uint8).tobytes())
+    return out + chunk(b"IDAT", zlib.compress(raw, 6)) + chunk(b"IEND", b"")
+
+
+def test_texture_containers_like_cv_imread(tmp_path, small_mesh):
+    """what cv::imread(path) + BGR2RGB hands the reference (assimp_mesh_loader.cpp:216-223): every PNG bit depth / colour type, Adam7
+    interlacing, 16-bit samples >> 8, grey replicated, alpha dropped; BMP, PNM and TGA containers; JPEG is a loud error"""
+    rng = np.random.default_rng(3)
+    H, W = 21, 19                                         # not multiples of 8: ragged Adam7 passes, padded sub-byte rows
+
+    def tex(name):
+        return load_mesh("obj", _write_obj(str(tmp_path), small_mesh, texture=name)).texture
+    # --- PNG: 16-bit RGB / RGBA / grey / grey+alpha, 8-bit RGB, each plain and interlaced
+    for ctype, ch in ((2, 3), (6, 4), (0, 1), (4, 2)):
+        for bits in (8, 16):
+            a = rng.integers(0, 2 ** bits, size=(H, W, ch), dtype=np.uint32)
+            want = (a >> (bits - 8)).astype(np.uint8)
+            want = np.repeat(want[..., :1], 3, -1) if ch <= 2 else want[..., :3]
+            for il in (False, True):
+                (tmp_path / "v.png").write_bytes(_png_bytes(a, bits, ctype, il))
+                np.testing.assert_array_equal(tex("v.png"), want, err_msg=f"ctype {ctype} bits {bits} interlace {il}")
+    # --- sub-byte grey (scaled to 0..255) and palette images, plain and interlaced
+    for bits in (1, 2, 4):
+        a = rng.integers(0, 2 ** bits, size=(H, W, 1), dtype=np.uint32)
+        pal = rng.integers(0, 256, size=(2 ** bits, 3), dtype=np.uint8)
+        for il in (False, True):
+            (tmp_path / "g.png").write_bytes(_png_bytes(a, bits, 0, il))
+            np.testing.assert_array_equal(tex("g.png"), np.repeat((a * 255 // (2 ** bits - 1)).astype(np.uint8), 3, -1))
+            (tmp_path / "p.png").write_bytes(_png_bytes(a, bits, 3, il, plte=pal))
+            np.testing.assert_array_equal(tex("p.png"), pal[a[..., 0]])
+    # PIL's own writers agree (filters other than 0, optimised palettes)
+    img = rng.integers(0, 256, size=(H, W, 3), dtype=np.uint8)
+    Image.fromarray(img).convert("P", palette=Image.ADAPTIVE, colors=13).save(tmp_path / "pil4.png", bits=4)
+    np.testing.assert_array_equal(tex("pil4.png"), np.asarray(Image.open(tmp_path / "pil4.png").convert("RGB")))
+    Image.fromarray((img[..., 0] > 127)).save(tmp_path / "pil1.png")
+    np.testing.assert_array_equal(tex("pil1.png"), np.asarray(Image.open(tmp_path / "pil1.png").convert("RGB")))
+    g16 = rng.integers(0, 65536, size=(H, W), dtype=np.uint16)
+    Image.fromarray(g16).save(tmp_path / "pil16.png")
+    np.testing.assert_array_equal(tex("pil16.png"), np.repeat((g16 >> 8).astype(np.uint8)[..., None], 3, -1))
+    # --- BMP (24-bit, 32-bit, 8-bit palette), PNM (P6, P5, ASCII P3), TGA (raw, RLE, grey)
+    for mode, name, kw in (("RGB", "a.bmp", {}), ("RGBA", "b.bmp", {}), ("P", "c.bmp", {}), ("L", "d.bmp", {}),
+                           ("RGB", "e.ppm", {}), ("L", "f.pgm", {}),
+                           ("RGB", "g.tga", {}), ("RGB", "h.tga", {"compression": "tga_rle"}), ("RGBA", "i.tga", {}), ("L", "j.tga", {"compression": "tga_rle"})):
+        flat = img.copy()
+        flat[5:9] = flat[5]                                 # runs for the RLE packets
+        Image.fromarray(flat).convert(mode).save(tmp_path / name, **kw)
+        np.testing.assert_array_equal(tex(name), np.asarray(Image.open(tmp_path / name).convert("RGB")), err_msg=name)
+    (tmp_path / "k.ppm").write_text("P3\n# comment\n3 2\n15\n" + " ".join(str(v % 16) for v in range(18)) + "\n")
+    np.testing.assert_array_equal(tex("k.ppm"), ((np.arange(18) % 16).reshape(2, 3, 3) * 255 // 15).astype(np.uint8))
+    # --- a real JPEG (PIL writes one): named in the error, no silent grey texture
+    Image.fromarray(img).save(tmp_path / "real.jpg")
+    with pytest.raises(FoundationPoseError, match="JPEG textures are not supported"):
+        tex("real.jpg")
+    # truncated files of every container fail cleanly
+    for name in ("a.bmp", "e.ppm", "g.tga", "h.tga", "v.png"):
+        data = (tmp_path / name).read_bytes()
+        (tmp_path / ("cut_" + name)).write_bytes(data[:len(data) // 2])
+        with pytest.raises(FoundationPoseError, match="cannot be decoded"):
+            tex("cut_" + name)
