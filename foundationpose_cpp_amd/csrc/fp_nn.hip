@@ -169,6 +169,24 @@ __device__ __forceinline__ void glds16_asm(const void *gsrc, unsigned lds_addr) 
                : "v"(gsrc), "s"(lds_addr)
                : "memory");
 }
+// the same with the non-temporal cache policy, for the input tiles of the resident-halo kernels (each tile is staged once per
+// 64-channel chunk by at most two workgroups).  A/B build switch FP_X_NT (tools/ab_xnt.sh), OFF: measured [r3] the halo layers move
+// by -4...+1 %, inside the run-to-run noise of a box (+-3 %); the same policy on the X tiles of conv_big_pp / gemm_k32, which other
+// n-tiles re-read from L2, costs +4 % / +17 %.
+#ifndef FP_X_NT
+#define FP_X_NT 0
+#endif
+__device__ __forceinline__ void glds16_asm_x(const void *gsrc, unsigned lds_addr) {
+#if FP_X_NT
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(lds_addr)
+               : "memory");
+#else
+  glds16_asm(gsrc, lds_addr);
+#endif
+}
 
 struct ConvParams {
   const unsigned char *in;   // [NB, H+2*ipad, W+2*ipad, Cin]  (zero border of width ipad >= pad is physically present)
@@ -1227,7 +1245,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const ConvParams p) {
         int hy = q / HC, hx = q - hy * HC;
         int g = ((hx >> 1) & 1) | ((hy & 3) << 1);
         unsigned off = (unsigned)(q * p.cin_b + (((lane & 7) ^ g) << 4));
-        glds16_asm(src + off, lds_base + piece * 1024);
+        glds16_asm_x(src + off, lds_base + piece * 1024);
         __builtin_amdgcn_sched_barrier(0);  // one address at a time: 14 hoisted 64-bit addresses would spill accumulators
       }
     }
@@ -1436,7 +1454,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo8_kernel(const ConvParams p) 
         int hy = q / HC, hx = q - hy * HC;
         int g = ((hx >> 1) & 1) | ((hy & 3) << 1);
         unsigned off = (unsigned)(q * p.cin_b + (((lane & 7) ^ g) << 4));
-        glds16_asm(src + off, lds_base + piece * 1024);
+        glds16_asm_x(src + off, lds_base + piece * 1024);
         __builtin_amdgcn_sched_barrier(0);  // one address at a time: hoisted 64-bit addresses would spill accumulators
       }
     }
