@@ -1792,7 +1792,7 @@ __global__ __launch_bounds__(256, 2) void conv_s2_halo_kernel(const ConvParams p
 // workgroups per CU so one's prologue / epilogue runs under the other's MFMAs.  LDS rows are 64 bytes; the 16-byte
 // slot of (row, chunk) is chunk ^ f((row>>2)&3), f = {0,2,3,1} (conflict-free ds_read_b128 fragments).
 // -------------------------------------------------------------------------------------------------
-template <int ABL, int DT>  // timing ablations: 1 = no MFMAs, 2 = no loads after the first stage, 4 = no stores
+template <int ABL, int DT, bool LSTORE = false>  // timing ablations: 1 = no MFMAs, 2 = no loads after the first stage, 4 = no stores; LSTORE: epilogue through LDS
 __global__ __launch_bounds__(256, 2) void gemm_k32_kernel(const ConvParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int BM = 128, BN = 256;
@@ -1880,6 +1880,60 @@ __global__ __launch_bounds__(256, 2) void gemm_k32_kernel(const ConvParams p) {
       for (int mi = 0; mi < 4; mi++)
         acc[ni >> 2][ni & 3][mi] = mfma32<DT>(wf[ni], xf[mi], acc[ni >> 2][ni & 3][mi]);
     __builtin_amdgcn_s_setprio(0);
+  }
+  if constexpr (ABL == 0 && LSTORE) {
+    // [r3] epilogue through LDS: the accumulator layout gives every store instruction 16 rows x 64 bytes -- 16 cache lines, half
+    // of each -- and the vector memory path retires lines, not bytes (section 4.5 of DESIGN.md).  The wave's 64 x 128 tile is
+    // written to its own 16 KB of the (now idle) ring as finished output rows and leaves as 4 rows x 256 contiguous bytes per
+    // instruction.  Values are identical to conv_epilogue's (same operations in the same order).
+    __syncthreads();                                   // every wave is done reading the ring
+    unsigned char *tile = smem + wave * 16384;         // [64 rows][256 B], 16-byte chunk c stored at c ^ (row & 15)
+    const int g = lane >> 4, li = lane & 15;
+    const int mb = m0 + wm * 64, nb = n0 + wn * 128;
+    float bv[2][2][8];
+#pragma unroll
+    for (int h = 0; h < 2; h++)
+#pragma unroll
+      for (int k = 0; k < 2; k++) {
+        const float4 b0 = *reinterpret_cast<const float4 *>(p.bias + nb + h * 64 + 8 * g + 32 * k), b1 = *reinterpret_cast<const float4 *>(p.bias + nb + h * 64 + 8 * g + 32 * k + 4);
+        bv[h][k][0] = b0.x; bv[h][k][1] = b0.y; bv[h][k][2] = b0.z; bv[h][k][3] = b0.w; bv[h][k][4] = b1.x; bv[h][k][5] = b1.y; bv[h][k][6] = b1.z; bv[h][k][7] = b1.w;
+      }
+#pragma unroll
+    for (int mi = 0; mi < 4; mi++) {
+      const int row = mi * 16 + li, m = mb + row;
+      const bool ok = m < p.M;
+      i4 rv[2][2];
+      if (p.res) {
+#pragma unroll
+        for (int h = 0; h < 2; h++)
+#pragma unroll
+          for (int k = 0; k < 2; k++)
+            rv[h][k] = ok ? *reinterpret_cast<const i4 *>(p.res + ((size_t)m * p.res_ld + nb + h * 64 + 8 * g + 32 * k) * 2) : (i4){0, 0, 0, 0};
+      }
+#pragma unroll
+      for (int h = 0; h < 2; h++)
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+          typename ElemT<DT>::v8 ov;
+#pragma unroll
+          for (int e = 0; e < 8; e++) {
+            float v = acc[h][e & 3][mi][2 * k + (e >> 2)] + bv[h][k][e];
+            if (p.res) v += raw_elem<DT>(rv[h][k], e);
+            if (p.relu) v = fmaxf(v, 0.f);
+            ov[e] = (typename ElemT<DT>::t)v;
+          }
+          const int c = h * 8 + k * 4 + g;
+          *reinterpret_cast<typename ElemT<DT>::v8 *>(tile + row * 256 + ((c ^ (row & 15)) << 4)) = ov;
+        }
+    }
+    // (same-wave LDS write -> read: program order suffices, no barrier)
+#pragma unroll
+    for (int it = 0; it < 16; it++) {
+      const int row = it * 4 + (lane >> 4), c = lane & 15, m = mb + row;
+      const i4 v = *reinterpret_cast<const i4 *>(tile + row * 256 + ((c ^ (row & 15)) << 4));
+      if (m < p.M) *reinterpret_cast<i4 *>(p.out + ((size_t)m * p.out_ld + nb + c * 8) * 2) = v;
+    }
+    return;
   }
   conv_epilogue<4, 4, DT, DT, (ABL >> 2) & 1>(p, acc[0], m0 + wm * 64, n0 + wn * 128, lane);
   conv_epilogue<4, 4, DT, DT, (ABL >> 2) & 1>(p, acc[1], m0 + wm * 64, n0 + wn * 128 + 64, lane);
@@ -3441,6 +3495,7 @@ FP_HOOK g_att_skv = 1;          // small attention grids on attention32_skv_kern
 FP_HOOK g_gemm_deep = 1;         // short-K layers of small problems on conv_deep_kernel<128> instead of the two-stage 128x128 tile
 FP_HOOK g_splitk_mid = 1;        // two split-K slices for long-K layers with 97..128 tiles (batches of ~8 objects)
 FP_HOOK g_small_deep = 18;     // small problems (Track): conv_deep_kernel<64> over ALL K-steps instead of split-K + reduce when K has at most this many 128-byte steps
+FP_HOOK g_gemm_lds_store = 1;  // gemm_k32_kernel: output rows leave through LDS as whole 256-byte runs instead of 64-byte pieces per store instruction
 FP_HOOK g_smallm = 1;          // small problems (Track, a few objects) on conv_smallm_kernel: K split over the waves of a workgroup, no split-K slabs / reduce launch
 FP_HOOK g_att_variant = 1;     // 1 = attention32_kernel (8 = without the XCD remap); round-1 kernel: 2 remap + 16-B stores, 3 no XCD remap, 5 remap + 2-B stores, 7 neither
 
@@ -3579,7 +3634,8 @@ static int run_conv_dt(const Ctx &c, const char *tag, const ConvLayer &L, ConvPa
       if (DT == DT_F16 && g_gemm_kernel == 12) { FP_LAUNCH((gemm_k32_kernel<2, DT_F16>), grid, dim3(256), LDS_GEMM_K32, c.s, p); return 0; }
       if (DT == DT_F16 && g_gemm_kernel == 14) { FP_LAUNCH((gemm_k32_kernel<4, DT_F16>), grid, dim3(256), LDS_GEMM_K32, c.s, p); return 0; }
 #endif
-      FP_LAUNCH((gemm_k32_kernel<0, DT>), grid, dim3(256), LDS_GEMM_K32, c.s, p);
+      if (g_gemm_lds_store) FP_LAUNCH((gemm_k32_kernel<0, DT, true>), grid, dim3(256), LDS_GEMM_K32, c.s, p);
+      else FP_LAUNCH((gemm_k32_kernel<0, DT>), grid, dim3(256), LDS_GEMM_K32, c.s, p);
       return 0;
     }
   }
@@ -4230,6 +4286,7 @@ extern "C" {
 
 void fpt_set_att_variant(int v) { fp::g_att_variant = v; }
 void fpt_set_smallm(int v) { fp::g_smallm = v; }
+void fpt_set_gemm_lds_store(int v) { fp::g_gemm_lds_store = v; }
 void fpt_set_conv_variant(int v) { fp::g_conv_variant = v; }
 void fpt_set_conv_ablate(int v) { fp::g_conv_ablate = v; }
 void fpt_set_splitk_target(int v) { fp::g_splitk_target = v; }
