@@ -3495,6 +3495,7 @@ FP_HOOK g_att_skv = 1;          // small attention grids on attention32_skv_kern
 FP_HOOK g_gemm_deep = 1;         // short-K layers of small problems on conv_deep_kernel<128> instead of the two-stage 128x128 tile
 FP_HOOK g_splitk_mid = 1;        // two split-K slices for long-K layers with 97..128 tiles (batches of ~8 objects)
 FP_HOOK g_small_deep = 18;     // small problems (Track): conv_deep_kernel<64> over ALL K-steps instead of split-K + reduce when K has at most this many 128-byte steps
+FP_HOOK g_smallm_maxkt = 40;   // conv_smallm_kernel takes layers with fewer 128-byte K-steps than this (40 includes the 36-step conv_256 / conv_b2 layers: -3 us and 5 launches fewer per Track than 32)
 FP_HOOK g_gemm_lds_store = 1;  // gemm_k32_kernel: output rows leave through LDS as whole 256-byte runs instead of 64-byte pieces per store instruction
 FP_HOOK g_smallm = 1;          // small problems (Track, a few objects) on conv_smallm_kernel: K split over the waves of a workgroup, no split-K slabs / reduce launch
 FP_HOOK g_att_variant = 1;     // 1 = attention32_kernel (8 = without the XCD remap); round-1 kernel: 2 remap + 16-B stores, 3 no XCD remap, 5 remap + 2-B stores, 7 neither
@@ -3584,7 +3585,7 @@ static int run_conv_dt(const Ctx &c, const char *tag, const ConvLayer &L, ConvPa
     // layers do NOT win -- conv_512 (72 steps) 21 us against 12.3 + 5.2 us for split-K + reduce: operand-shaped global loads touch 16
     // cache lines per instruction (64 bytes used of each) and the vector L1 retires them at ~16 B/clk, a quarter of what the
     // LDS-DMA rows (8 lanes per 128-byte line) get.  g_smallm = 2 forces it for every K (A/B).
-    if (g_smallm && (KT < 32 || g_smallm == 2) && g_conv_variant == 0 && g_conv_ablate == 0 && L.Cout % cw == 0 && t16 <= 1024 * (64 / cw) &&
+    if (g_smallm && (KT < g_smallm_maxkt || g_smallm == 2) && g_conv_variant == 0 && g_conv_ablate == 0 && L.Cout % cw == 0 && t16 <= 1024 * (64 / cw) &&
         (!grp || grp->rows % 32 == 0) && ((L.Cout / cw) % 8 == 0 || 8 % (L.Cout / cw) == 0)) {
       const int t32 = ((p.M + 31) / 32) * (L.Cout / cw);
       const bool two = t32 >= 160;                        // 32-pixel tiles halve the weight stream once they still fill the chip
@@ -4286,6 +4287,7 @@ extern "C" {
 
 void fpt_set_att_variant(int v) { fp::g_att_variant = v; }
 void fpt_set_smallm(int v) { fp::g_smallm = v; }
+void fpt_set_smallm_maxkt(int v) { fp::g_smallm_maxkt = v; }
 void fpt_set_gemm_lds_store(int v) { fp::g_gemm_lds_store = v; }
 void fpt_set_conv_variant(int v) { fp::g_conv_variant = v; }
 void fpt_set_conv_ablate(int v) { fp::g_conv_ablate = v; }
