@@ -359,6 +359,98 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams &p, f4 (&acc)[NI]
   }, grp * p.Cout, p.res_shared ? grp * p.grp_rows : 0);
 }
 
+// [r3] The same epilogue with the stores staged through LDS.  conv_epilogue's store instruction covers 16 pixels x 64 bytes: 16 cache
+// lines, half of each, and the vector memory path retires lines, not bytes.  Here a wave writes its finished
+// 2-byte outputs to a private LDS tile ([rows][NI*32 bytes], 16-byte chunk c of row r at c ^ (r & 7)) together with each row's
+// output offset, and copies them out as whole NI*32-byte runs, 8 rows (NI = 4: 8 full lines) per instruction.  Values are
+// identical to conv_epilogue's (same operations in the same order).  `tile`: wave-private, HM*16*(NI*32) + HM*64 bytes; the MI
+// fragments go through it in groups of HM.  2-byte output types, no positional table.
+template <int MI, int NI, int DT, int ODT, int HM>
+__device__ __forceinline__ void conv_epilogue_lds(const ConvParams &p, f4 (&acc)[NI][MI], int m_base, int n_base, int lane, unsigned char *tile) {
+  static_assert(NI == 4 && ODT != DT_FP8 && MI % HM == 0, "64-channel wave tiles, 2-byte outputs");
+  constexpr int RB = NI * 32;                 // bytes per pixel row of the tile (64 channels x 2 B)
+  constexpr int res_es = elem_bytes(DT);
+  const int OHp = p.OH + 2 * p.opad, OWp = p.OW + 2 * p.opad;
+  const int RHp = p.OH + 2 * p.rpad, RWp = p.OW + 2 * p.rpad;
+  const int g = lane >> 4, li = lane & 15;
+  const int nl = n_base + 8 * g;
+  const int ohw = p.OH * p.OW;
+  unsigned *otab = reinterpret_cast<unsigned *>(tile + HM * 16 * RB);
+  float bv[2][8], sc[2][8];
+#pragma unroll
+  for (int k = 0; k < 2; k++) {
+    const float4 b0 = *reinterpret_cast<const float4 *>(p.bias + nl + 32 * k), b1 = *reinterpret_cast<const float4 *>(p.bias + nl + 32 * k + 4);
+    bv[k][0] = b0.x; bv[k][1] = b0.y; bv[k][2] = b0.z; bv[k][3] = b0.w; bv[k][4] = b1.x; bv[k][5] = b1.y; bv[k][6] = b1.z; bv[k][7] = b1.w;
+    if constexpr (DT == DT_FP8) {
+      const float4 s0 = *reinterpret_cast<const float4 *>(p.cscale + nl + 32 * k), s1 = *reinterpret_cast<const float4 *>(p.cscale + nl + 32 * k + 4);
+      sc[k][0] = s0.x; sc[k][1] = s0.y; sc[k][2] = s0.z; sc[k][3] = s0.w; sc[k][4] = s1.x; sc[k][5] = s1.y; sc[k][6] = s1.z; sc[k][7] = s1.w;
+    }
+  }
+#pragma unroll
+  for (int h0 = 0; h0 < MI; h0 += HM) {
+    // residual loads of the group first (stores count in vmcnt on CDNA4: nothing is stored before they are all issued)
+    i4 rv[HM][2];
+    bool ok[HM];
+    unsigned oo[HM];
+#pragma unroll
+    for (int q = 0; q < HM; q++) {
+      const int m = m_base + (h0 + q) * 16 + li;
+      ok[q] = m < p.M;
+      const int mm = ok[q] ? m : 0;
+      const int img = mm / ohw, rem = mm - img * ohw;
+      const int oh = rem / p.OW, ow = rem - oh * p.OW;
+      int choff = 0, oimg = img;
+      if (p.split_imgs > 0 && img >= p.split_imgs) { oimg = img - p.split_imgs; choff = p.Cout; }
+      oo[q] = ok[q] ? (unsigned)((((size_t)oimg * OHp + oh + p.opad) * OWp + ow + p.opad) * p.out_ld + choff) : 0xFFFFFFFFu;
+      if (p.res) {
+        const size_t rpix = ((size_t)img * RHp + oh + p.rpad) * RWp + ow + p.rpad;
+#pragma unroll
+        for (int k = 0; k < 2; k++) rv[q][k] = ok[q] ? load8_raw(p.res + (rpix * p.res_ld + nl + 32 * k) * res_es, DT) : (i4){0, 0, 0, 0};
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < HM; q++) {
+      const int mi = h0 + q, row = q * 16 + li;
+      if (g == 0) otab[row] = oo[q];
+#pragma unroll
+      for (int k = 0; k < 2; k++) {
+        i4 ov = {0, 0, 0, 0};
+#pragma unroll
+        for (int e2 = 0; e2 < 8; e2 += 2) {
+          float v2[2];
+#pragma unroll
+          for (int hh = 0; hh < 2; hh++) {
+            const int e = e2 + hh, jj = 2 * k + (e >> 2), ni = e & 3;
+            float v = acc[ni][mi][jj];
+            if constexpr (DT == DT_FP8) v = __builtin_fmaf(v, sc[k][e], bv[k][e]);
+            else v += bv[k][e];
+            if (p.res) {
+              if constexpr (DT == DT_FP8) v = __builtin_fmaf(raw_elem<DT>(rv[q][k], e), p.res_scale, v);
+              else v += raw_elem<DT>(rv[q][k], e);
+            }
+            if (p.relu) v = fmaxf(v, 0.f);
+            v2[hh] = v;
+          }
+          typedef typename ElemT<ODT>::t OE;
+          typedef OE oe2 __attribute__((ext_vector_type(2)));
+          const oe2 pr = {(OE)v2[0], (OE)v2[1]};
+          ov[e2 >> 1] = __builtin_bit_cast(int, pr);
+        }
+        const int c = k * 4 + g;
+        *reinterpret_cast<i4 *>(tile + row * RB + ((c ^ (row & 7)) << 4)) = ov;
+      }
+    }
+    // copy-out (same wave wrote the tile: program order suffices): lane -> (row = it*8 + lane/8, chunk = lane%8)
+#pragma unroll
+    for (int it = 0; it < HM * 2; it++) {
+      const int row = it * 8 + (lane >> 3), c = lane & 7;
+      const unsigned off = otab[row];
+      const i4 v = *reinterpret_cast<const i4 *>(tile + row * RB + ((c ^ (row & 7)) << 4));
+      if (off != 0xFFFFFFFFu) *reinterpret_cast<i4 *>(p.out + ((size_t)off + n_base + c * 8) * 2) = v;
+    }
+  }
+}
+
 // split-K partial slab (true channel order): per accumulator register j a lane owns NI consecutive channels
 template <int MI, int NI>
 __device__ __forceinline__ void conv_store_partial(const ConvParams &p, f4 (&acc)[NI][MI], int split, int m_base, int n_base, int lane) {
@@ -832,7 +924,7 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvParams p) {
 // two 64-KB LDS stages, one workgroup per CU.  Needs Cout % 256 == 0.
 // -------------------------------------------------------------------------------------------------
 // Ping-pong schedule of the 256 x 256 tile (see the slot comment inside).
-template <int ABL, int DT, int ODT = DT, bool POST = false>
+template <int ABL, int DT, int ODT = DT, bool POST = false, bool LSTORE = false>  // LSTORE: epilogue stores staged through LDS (conv_epilogue_lds)
 __global__ __launch_bounds__(512, 2) void conv_big_pp_kernel(const ConvParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int BM = 256, BN = 256;
@@ -1030,6 +1122,11 @@ __global__ __launch_bounds__(512, 2) void conv_big_pp_kernel(const ConvParams p)
     for (int a = 0; a < NI; a++)
 #pragma unroll
       for (int b = 0; b < MI; b++) asm volatile("" ::"v"(acc[a][b]));
+    return;
+  }
+  if constexpr (LSTORE && ABL == 0 && !POST && ODT != DT_FP8) {
+    __syncthreads();   // both ping-pong groups are done with the ring: 8 x (8 KB tile + 256 B offsets) of it become the staging area
+    conv_epilogue_lds<MI, NI, DT, ODT, 4>(p, acc, m0 + wm * 128, n0 + wn * 64, lane, smem + wave * (4 * 16 * 128 + 4 * 64));
     return;
   }
   conv_epilogue<MI, NI, DT, ODT, ((ABL >> 3) & 3) | (POST ? 4 : 0)>(p, acc, m0 + wm * 128, n0 + wn * 64, lane);
@@ -3496,6 +3593,7 @@ FP_HOOK g_gemm_deep = 1;         // short-K layers of small problems on conv_dee
 FP_HOOK g_splitk_mid = 1;        // two split-K slices for long-K layers with 97..128 tiles (batches of ~8 objects)
 FP_HOOK g_small_deep = 18;     // small problems (Track): conv_deep_kernel<64> over ALL K-steps instead of split-K + reduce when K has at most this many 128-byte steps
 FP_HOOK g_smallm_maxkt = 40;   // conv_smallm_kernel takes layers with fewer 128-byte K-steps than this (40 includes the 36-step conv_256 / conv_b2 layers: -3 us and 5 launches fewer per Track than 32)
+FP_HOOK g_conv_lds_store = 0;  // conv_big_pp_kernel: epilogue stores staged through LDS (whole 128-byte lines per store instruction).  OFF: measured [r3] conv_512 3.205 -> 3.227 / 3.184 -> 3.180 ms, i.e. nothing -- the 256x256 tile's store burst is not bound by the store shape (unlike gemm_k32_kernel's, -6 %)
 FP_HOOK g_gemm_lds_store = 1;  // gemm_k32_kernel: output rows leave through LDS as whole 256-byte runs instead of 64-byte pieces per store instruction
 FP_HOOK g_smallm = 1;          // small problems (Track, a few objects) on conv_smallm_kernel: K split over the waves of a workgroup, no split-K slabs / reduce launch
 FP_HOOK g_att_variant = 1;     // 1 = attention32_kernel (8 = without the XCD remap); round-1 kernel: 2 remap + 16-B stores, 3 no XCD remap, 5 remap + 2-B stores, 7 neither
@@ -3728,6 +3826,9 @@ static int run_conv_dt(const Ctx &c, const char *tag, const ConvLayer &L, ConvPa
 #endif
         if constexpr (ODT != DT_FP8) {
           if (!done && post_main) { FP_LAUNCH((conv_big_pp_kernel<0, DT, ODT, true>), grid, dim3(512), LDS_BIG, c.s, pb); done = true; }
+        }
+        if constexpr (ODT != DT_FP8) {
+          if (!done && g_conv_lds_store) { FP_LAUNCH((conv_big_pp_kernel<0, DT, ODT, false, true>), grid, dim3(512), LDS_BIG, c.s, pb); done = true; }
         }
         if (!done) FP_LAUNCH((conv_big_pp_kernel<0, DT, ODT>), grid, dim3(512), LDS_BIG, c.s, pb);
       }
@@ -4289,6 +4390,7 @@ void fpt_set_att_variant(int v) { fp::g_att_variant = v; }
 void fpt_set_smallm(int v) { fp::g_smallm = v; }
 void fpt_set_smallm_maxkt(int v) { fp::g_smallm_maxkt = v; }
 void fpt_set_gemm_lds_store(int v) { fp::g_gemm_lds_store = v; }
+void fpt_set_conv_lds_store(int v) { fp::g_conv_lds_store = v; }
 void fpt_set_conv_variant(int v) { fp::g_conv_variant = v; }
 void fpt_set_conv_ablate(int v) { fp::g_conv_ablate = v; }
 void fpt_set_splitk_target(int v) { fp::g_splitk_target = v; }
