@@ -271,9 +271,298 @@ static bool decode_tga(const std::vector<uint8_t> &b, std::vector<uint8_t> &rgb,
   return true;
 }
 
+// ---- baseline JPEG (sequential DCT, Huffman, 8 bit, 1 or 3 components, any 1x / 2x sampling, restart markers) ----
+// Decoded the way libjpeg(-turbo) does with its defaults -- which is what cv::imread hands the reference: the slow-but-accurate
+// integer IDCT (jidctint.c), "fancy" triangle upsampling of 2x-subsampled chroma (jdsample.c) and the fixed-point YCbCr -> RGB
+// tables (jdcolor.c) -- so textures come out bit-identical to the reference's (tests compare with PIL, which sits on libjpeg-turbo).
+// Progressive / arithmetic / 12-bit / CMYK files are refused by name.  EXIF orientation is ignored.
+namespace jpg {
+struct Huff { uint8_t bits[17] = {0}; uint8_t vals[256] = {0}; int mincode[17], maxcode[18], valptr[17]; bool ok = false; };
+struct Comp { int id = 0, h = 1, v = 1, tq = 0, td = 0, ta = 0; int bw = 0, bh = 0; std::vector<uint8_t> px; int stride = 0, rows = 0; int dcpred = 0; };
+static const uint8_t ZZ[64] = {0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28,
+                               35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+static void build(Huff &h) {
+  int code = 0, k = 0;
+  for (int l = 1; l <= 16; l++) {
+    h.valptr[l] = k; h.mincode[l] = code;
+    code += h.bits[l]; k += h.bits[l];
+    h.maxcode[l] = h.bits[l] ? code - 1 : -1;
+    code <<= 1;
+  }
+  h.maxcode[17] = 0x7fffffff;
+  h.ok = true;
+}
+struct Bits {
+  const uint8_t *p, *end; uint32_t acc = 0; int n = 0; bool hit_marker = false;
+  int bit() {
+    if (n == 0) {
+      uint8_t b = 0;
+      if (p < end && !hit_marker) {
+        b = *p++;
+        if (b == 0xFF) {
+          if (p < end && *p == 0) p++;            // stuffed zero
+          else { hit_marker = true; p--; b = 0; } // a marker: feed zeros, leave it for the caller
+        }
+      }
+      acc = b; n = 8;
+    }
+    n--;
+    return (acc >> n) & 1;
+  }
+  int get(int cnt) { int v = 0; while (cnt--) v = (v << 1) | bit(); return v; }
+  void reset() { n = 0; hit_marker = false; }
+};
+static int decode_sym(Bits &b, const Huff &h) {
+  int code = 0;
+  for (int l = 1; l <= 16; l++) {
+    code = (code << 1) | b.bit();
+    if (h.maxcode[l] >= 0 && code <= h.maxcode[l] && code >= h.mincode[l]) return h.vals[h.valptr[l] + code - h.mincode[l]];
+  }
+  return -1;
+}
+static inline int extend(int v, int t) { return v < (1 << (t - 1)) ? v - (1 << t) + 1 : v; }
+static inline int descale(long x, int n) { return (int)((x + (1L << (n - 1))) >> n); }
+// jidctint.c (libjpeg 6b / libjpeg-turbo jpeg_idct_islow): CONST_BITS 13, PASS1_BITS 2
+static void idct_islow(const int *in, uint8_t *out, int stride) {
+  constexpr long F0298 = 2446, F0390 = 3196, F0541 = 4433, F0765 = 6270, F0899 = 7373, F1175 = 9633, F1501 = 12299, F1847 = 15137, F1961 = 16069,
+                 F2053 = 16819, F2562 = 20995, F3072 = 25172;
+  int ws[64];
+  for (int c = 0; c < 8; c++) {
+    const int *p = in + c;
+    long z2 = p[16], z3 = p[48];
+    long z1 = (z2 + z3) * F0541;
+    long tmp2 = z1 + z3 * (-F1847), tmp3 = z1 + z2 * F0765;
+    z2 = p[0]; z3 = p[32];
+    long tmp0 = (z2 + z3) << 13, tmp1 = (z2 - z3) << 13;
+    long tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
+    tmp0 = p[56]; tmp1 = p[40]; tmp2 = p[24]; tmp3 = p[8];
+    z1 = tmp0 + tmp3; z2 = tmp1 + tmp2; z3 = tmp0 + tmp2; long z4 = tmp1 + tmp3; long z5 = (z3 + z4) * F1175;
+    tmp0 *= F0298; tmp1 *= F2053; tmp2 *= F3072; tmp3 *= F1501;
+    z1 *= -F0899; z2 *= -F2562; z3 *= -F1961; z4 *= -F0390;
+    z3 += z5; z4 += z5;
+    tmp0 += z1 + z3; tmp1 += z2 + z4; tmp2 += z2 + z3; tmp3 += z1 + z4;
+    int *w = ws + c;
+    w[0] = descale(tmp10 + tmp3, 11); w[56] = descale(tmp10 - tmp3, 11);
+    w[8] = descale(tmp11 + tmp2, 11); w[48] = descale(tmp11 - tmp2, 11);
+    w[16] = descale(tmp12 + tmp1, 11); w[40] = descale(tmp12 - tmp1, 11);
+    w[24] = descale(tmp13 + tmp0, 11); w[32] = descale(tmp13 - tmp0, 11);
+  }
+  auto lim = [](int x) { x += 128; return (uint8_t)(x < 0 ? 0 : x > 255 ? 255 : x); };
+  for (int r = 0; r < 8; r++) {
+    const int *p = ws + r * 8;
+    long z2 = p[2], z3 = p[6];
+    long z1 = (z2 + z3) * F0541;
+    long tmp2 = z1 + z3 * (-F1847), tmp3 = z1 + z2 * F0765;
+    long tmp0 = ((long)p[0] + p[4]) << 13, tmp1 = ((long)p[0] - p[4]) << 13;
+    long tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
+    tmp0 = p[7]; tmp1 = p[5]; tmp2 = p[3]; tmp3 = p[1];
+    z1 = tmp0 + tmp3; z2 = tmp1 + tmp2; z3 = tmp0 + tmp2; long z4 = tmp1 + tmp3; long z5 = (z3 + z4) * F1175;
+    tmp0 *= F0298; tmp1 *= F2053; tmp2 *= F3072; tmp3 *= F1501;
+    z1 *= -F0899; z2 *= -F2562; z3 *= -F1961; z4 *= -F0390;
+    z3 += z5; z4 += z5;
+    tmp0 += z1 + z3; tmp1 += z2 + z4; tmp2 += z2 + z3; tmp3 += z1 + z4;
+    uint8_t *o = out + (size_t)r * stride;
+    o[0] = lim(descale(tmp10 + tmp3, 18)); o[7] = lim(descale(tmp10 - tmp3, 18));
+    o[1] = lim(descale(tmp11 + tmp2, 18)); o[6] = lim(descale(tmp11 - tmp2, 18));
+    o[2] = lim(descale(tmp12 + tmp1, 18)); o[5] = lim(descale(tmp12 - tmp1, 18));
+    o[3] = lim(descale(tmp13 + tmp0, 18)); o[4] = lim(descale(tmp13 - tmp0, 18));
+  }
+}
+}  // namespace jpg
+
+static bool decode_jpeg(const std::vector<uint8_t> &b, std::vector<uint8_t> &rgb, int &H, int &W, std::string *why) {
+  using namespace jpg;
+  auto fail = [&](const char *m) { if (why) *why = m; return false; };
+  uint16_t qt[4][64] = {};
+  bool qok[4] = {false, false, false, false};
+  Huff hdc[4], hac[4];
+  std::vector<Comp> comps;
+  int restart = 0, hmax = 1, vmax = 1;
+  size_t pos = 2;
+  W = H = 0;
+  auto be16 = [&](size_t o) { return (int)((b[o] << 8) | b[o + 1]); };
+  while (pos + 4 <= b.size()) {
+    if (b[pos] != 0xFF) return fail("corrupt JPEG (marker expected)");
+    const int mk = b[pos + 1];
+    if (mk == 0xFF) { pos++; continue; }
+    pos += 2;
+    if (mk == 0xD8 || (mk >= 0xD0 && mk <= 0xD7) || mk == 0x01) continue;
+    if (mk == 0xD9) break;
+    if (pos + 2 > b.size()) return fail("truncated JPEG");
+    const int len = be16(pos);
+    if (len < 2 || pos + len > b.size()) return fail("truncated JPEG");
+    const size_t seg = pos + 2, end = pos + len;
+    if (mk == 0xC2 || mk == 0xC6 || mk == 0xCA || mk == 0xCE) return fail("progressive JPEG textures are not supported: re-save as baseline JPEG or PNG");
+    if (mk == 0xC9 || mk == 0xCB || mk == 0xCD || mk == 0xCF) return fail("arithmetic-coded JPEG textures are not supported");
+    if (mk == 0xC3 || mk == 0xC5 || mk == 0xC7) return fail("lossless / hierarchical JPEG textures are not supported");
+    if (mk == 0xDB) {
+      size_t q = seg;
+      while (q < end) {
+        const int pq = b[q] >> 4, tq = b[q] & 15;
+        q++;
+        if (tq > 3 || q + (pq ? 128 : 64) > end) return fail("corrupt JPEG (DQT)");
+        for (int i = 0; i < 64; i++) { qt[tq][ZZ[i]] = pq ? (uint16_t)be16(q + 2 * i) : b[q + i]; }
+        qok[tq] = true;
+        q += pq ? 128 : 64;
+      }
+    } else if (mk == 0xC4) {
+      size_t q = seg;
+      while (q < end) {
+        const int tc = b[q] >> 4, th = b[q] & 15;
+        q++;
+        if (th > 3 || tc > 1 || q + 16 > end) return fail("corrupt JPEG (DHT)");
+        Huff &h = tc ? hac[th] : hdc[th];
+        int n = 0;
+        for (int l = 1; l <= 16; l++) { h.bits[l] = b[q + l - 1]; n += h.bits[l]; }
+        q += 16;
+        if (n > 256 || q + n > end) return fail("corrupt JPEG (DHT)");
+        std::memcpy(h.vals, &b[q], n);
+        q += n;
+        build(h);
+      }
+    } else if (mk == 0xC0 || mk == 0xC1) {
+      if (len < 8) return fail("corrupt JPEG (SOF)");
+      if (b[seg] != 8) return fail("only 8-bit JPEG textures are supported");
+      H = be16(seg + 1); W = be16(seg + 3);
+      const int nc = b[seg + 5];
+      if (W <= 0 || H <= 0 || W > 16384 || H > 16384) return fail("corrupt JPEG (size)");
+      if (nc != 1 && nc != 3) return fail("JPEG textures must be greyscale or YCbCr (CMYK / YCCK are not supported)");
+      if (len < 8 + 3 * nc) return fail("corrupt JPEG (SOF)");
+      comps.resize(nc);
+      for (int i = 0; i < nc; i++) {
+        comps[i].id = b[seg + 6 + 3 * i]; comps[i].h = b[seg + 7 + 3 * i] >> 4; comps[i].v = b[seg + 7 + 3 * i] & 15; comps[i].tq = b[seg + 8 + 3 * i];
+        if (comps[i].h < 1 || comps[i].h > 2 || comps[i].v < 1 || comps[i].v > 2 || comps[i].tq > 3) return fail("unsupported JPEG sampling factors (1x / 2x only)");
+        hmax = std::max(hmax, comps[i].h); vmax = std::max(vmax, comps[i].v);
+      }
+      if (nc == 1) { comps[0].h = comps[0].v = 1; hmax = vmax = 1; }
+    } else if (mk == 0xDD) {
+      if (len >= 4) restart = be16(seg);
+    } else if (mk == 0xDA) {
+      if (comps.empty()) return fail("corrupt JPEG (scan before frame header)");
+      const int ns = b[seg];
+      if (ns != (int)comps.size() || len < 6 + 2 * ns) return fail("multi-scan baseline JPEG textures are not supported");
+      for (int i = 0; i < ns; i++) {
+        const int cid = b[seg + 1 + 2 * i];
+        Comp *c = nullptr;
+        for (auto &cc : comps) if (cc.id == cid) c = &cc;
+        if (!c) return fail("corrupt JPEG (SOS component)");
+        c->td = b[seg + 2 + 2 * i] >> 4; c->ta = b[seg + 2 + 2 * i] & 15;
+        if (c->td > 3 || c->ta > 3 || !hdc[c->td].ok || !hac[c->ta].ok || !qok[c->tq]) return fail("corrupt JPEG (missing table)");
+      }
+      // ---- entropy-coded data: MCUs of hmax x vmax blocks
+      const int mcuw = 8 * hmax, mcuh = 8 * vmax, mx = (W + mcuw - 1) / mcuw, my = (H + mcuh - 1) / mcuh;
+      for (auto &c : comps) {
+        c.bw = mx * c.h; c.bh = my * c.v; c.stride = c.bw * 8; c.rows = c.bh * 8;
+        c.px.assign((size_t)c.stride * c.rows, 0);
+        c.dcpred = 0;
+      }
+      Bits br{&b[end], b.data() + b.size()};
+      int blk[64], togo = restart, rst = 0;
+      for (int yy = 0; yy < my; yy++)
+        for (int xx = 0; xx < mx; xx++) {
+          if (restart && togo == 0) {
+            // byte-align, expect RSTn
+            br.reset();
+            const uint8_t *q = br.p;
+            while (q + 1 < br.end && !(q[0] == 0xFF && q[1] >= 0xD0 && q[1] <= 0xD7)) q++;
+            if (q + 1 >= br.end || q[1] != 0xD0 + (rst & 7)) return fail("corrupt JPEG (restart marker)");
+            br.p = q + 2; rst++;
+            togo = restart;
+            for (auto &c : comps) c.dcpred = 0;
+          }
+          for (auto &c : comps)
+            for (int by = 0; by < c.v; by++)
+              for (int bx = 0; bx < c.h; bx++) {
+                std::memset(blk, 0, sizeof(blk));
+                int t = decode_sym(br, hdc[c.td]);
+                if (t < 0 || t > 11) return fail("corrupt JPEG (DC code)");
+                const int diff = t ? extend(br.get(t), t) : 0;
+                c.dcpred += diff;
+                blk[0] = c.dcpred * qt[c.tq][0];
+                for (int k = 1; k < 64;) {
+                  const int rs = decode_sym(br, hac[c.ta]);
+                  if (rs < 0) return fail("corrupt JPEG (AC code)");
+                  const int r = rs >> 4, sz = rs & 15;
+                  if (sz == 0) { if (r == 15) { k += 16; continue; } break; }
+                  k += r;
+                  if (k > 63) return fail("corrupt JPEG (AC run)");
+                  blk[ZZ[k]] = extend(br.get(sz), sz) * qt[c.tq][ZZ[k]];
+                  k++;
+                }
+                idct_islow(blk, &c.px[(size_t)((yy * c.v + by) * 8) * c.stride + (size_t)(xx * c.h + bx) * 8], c.stride);
+              }
+          if (restart) togo--;
+        }
+      break;   // one scan
+    }
+    pos = end;
+  }
+  if (comps.empty() || comps[0].px.empty()) return fail("corrupt JPEG (no image data)");
+  // ---- upsample (libjpeg "fancy" triangle filters; edge rows / columns of the REAL component extent are replicated) and convert
+  std::vector<std::vector<uint8_t>> full(comps.size());
+  for (size_t ci = 0; ci < comps.size(); ci++) {
+    Comp &c = comps[ci];
+    const int cw = (W * c.h + hmax - 1) / hmax, chh = (H * c.v + vmax - 1) / vmax;   // downsampled_width / height
+    const bool h2 = c.h < hmax, v2 = c.v < vmax;
+    auto &o = full[ci];
+    o.assign((size_t)W * H, 0);
+    std::vector<int> colsum;
+    for (int y = 0; y < H; y++) {
+      const int sy = v2 ? y / 2 : y;
+      const uint8_t *r0 = &c.px[(size_t)std::min(sy, chh - 1) * c.stride];
+      const uint8_t *r1 = r0;
+      if (v2) { const int ny = (y & 1) ? std::min(sy + 1, chh - 1) : std::max(sy - 1, 0); r1 = &c.px[(size_t)ny * c.stride]; }
+      uint8_t *dst = &o[(size_t)y * W];
+      if (!h2 && !v2) { std::memcpy(dst, r0, W); continue; }
+      if (!h2) {   // h1v2: vertical triangle filter only (jdsample.c h1v2_fancy_upsample): (3*near + far + bias) >> 2, bias 1 for the upper, 2 for the lower output row
+        const int bias = (y & 1) ? 2 : 1;
+        for (int x = 0; x < W; x++) dst[x] = (uint8_t)((3 * r0[x] + r1[x] + bias) >> 2);
+        continue;
+      }
+      if (!v2) {   // h2v1
+        for (int x = 0; x < W; x++) {
+          const int i = x >> 1;
+          if (cw == 1) { dst[x] = r0[0]; continue; }
+          if (x == 0) dst[x] = r0[0];
+          else if (x == 2 * cw - 1) dst[x] = r0[cw - 1];
+          else if (x & 1) dst[x] = (uint8_t)((3 * r0[i] + r0[std::min(i + 1, cw - 1)] + 2) >> 2);
+          else dst[x] = (uint8_t)((3 * r0[i] + r0[i - 1] + 1) >> 2);
+        }
+        continue;
+      }
+      // h2v2: column sums 3*near + far, then the horizontal 3:1 filter on them
+      colsum.resize(cw);
+      for (int i = 0; i < cw; i++) colsum[i] = 3 * r0[i] + r1[i];
+      for (int x = 0; x < W; x++) {
+        const int i = x >> 1;
+        if (cw == 1) { dst[x] = (uint8_t)((colsum[0] * 4 + ((x & 1) ? 7 : 8)) >> 4); continue; }
+        if (x == 0) dst[x] = (uint8_t)((colsum[0] * 4 + 8) >> 4);
+        else if (x == 2 * cw - 1) dst[x] = (uint8_t)((colsum[cw - 1] * 4 + 7) >> 4);
+        else if (x & 1) dst[x] = (uint8_t)((colsum[i] * 3 + colsum[std::min(i + 1, cw - 1)] + 7) >> 4);
+        else dst[x] = (uint8_t)((colsum[i] * 3 + colsum[i - 1] + 8) >> 4);
+      }
+    }
+  }
+  rgb.resize((size_t)W * H * 3);
+  if (comps.size() == 1) {
+    for (size_t i = 0; i < (size_t)W * H; i++) rgb[3 * i] = rgb[3 * i + 1] = rgb[3 * i + 2] = full[0][i];
+    return true;
+  }
+  auto FIX = [](double v) { return (long)(v * 65536.0 + 0.5); };
+  const long f1402 = FIX(1.40200), f1772 = FIX(1.77200), f0714 = FIX(0.71414), f0344 = FIX(0.34414), half = 32768;
+  auto clamp8 = [](long x) { return (uint8_t)(x < 0 ? 0 : x > 255 ? 255 : x); };
+  for (size_t i = 0; i < (size_t)W * H; i++) {
+    const long y = full[0][i], cb = (long)full[1][i] - 128, cr = (long)full[2][i] - 128;
+    rgb[3 * i] = clamp8(y + ((f1402 * cr + half) >> 16));
+    rgb[3 * i + 1] = clamp8(y + ((-f0344 * cb + half - f0714 * cr) >> 16));
+    rgb[3 * i + 2] = clamp8(y + ((f1772 * cb + half) >> 16));
+  }
+  return true;
+}
+
 // Texture file -> 8-bit RGB the way cv::imread(path) + BGR2RGB delivers it (assimp_mesh_loader.cpp:216-223): grey replicated, alpha
-// dropped, palette expanded, 16-bit samples >> 8.  Containers: PNG (every bit depth / colour type, Adam7), BMP, PNM, TGA.  JPEG and
-// the rest of cv::imread's list need a codec this library does not carry: *why says so.
+// dropped, palette expanded, 16-bit samples >> 8.  Containers: PNG (every bit depth / colour type, Adam7), baseline JPEG, BMP, PNM, TGA.
+// Progressive JPEG and the rest of cv::imread's list (TIFF, WebP, ...) need codecs this library does not carry: *why says so.
 bool load_texture_rgb(const std::string &path, std::vector<uint8_t> &rgb, int &H, int &W, std::string *why) {
   std::ifstream f(path, std::ios::binary);
   if (!f) { if (why) *why = "cannot open"; return false; }
@@ -295,7 +584,7 @@ bool load_texture_rgb(const std::string &path, std::vector<uint8_t> &rgb, int &H
     }
     return true;
   }
-  if (b.size() >= 3 && b[0] == 0xFF && b[1] == 0xD8 && b[2] == 0xFF) return fail("JPEG textures are not supported (no JPEG codec in this library): convert the texture to PNG");
+  if (b.size() >= 3 && b[0] == 0xFF && b[1] == 0xD8 && b[2] == 0xFF) return decode_jpeg(b, rgb, H, W, why);
   if (b.size() >= 2 && b[0] == 'B' && b[1] == 'M') return decode_bmp(b, rgb, H, W) || fail("corrupt or unsupported BMP (supported: uncompressed 8 / 24 / 32 bit)");
   if (b.size() >= 2 && b[0] == 'P' && b[1] >= '1' && b[1] <= '6') return decode_pnm(b, rgb, H, W) || fail("corrupt or unsupported PNM (supported: P2 / P3 / P5 / P6)");
   const std::string ext = path.size() >= 4 ? path.substr(path.size() - 4) : "";

@@ -205,13 +205,41 @@ def test_texture_containers_like_cv_imread(tmp_path, small_mesh):
         np.testing.assert_array_equal(tex(name), np.asarray(Image.open(tmp_path / name).convert("RGB")), err_msg=name)
     (tmp_path / "k.ppm").write_text("P3\n# comment\n3 2\n15\n" + " ".join(str(v % 16) for v in range(18)) + "\n")
     np.testing.assert_array_equal(tex("k.ppm"), ((np.arange(18) % 16).reshape(2, 3, 3) * 255 // 15).astype(np.uint8))
-    # --- a real JPEG (PIL writes one): named in the error, no silent grey texture
-    Image.fromarray(img).save(tmp_path / "real.jpg")
-    with pytest.raises(FoundationPoseError, match="JPEG textures are not supported"):
-        tex("real.jpg")
+    # --- progressive JPEG: named in the error, no silent grey texture (baseline JPEG: test_jpeg_textures_bit_identical_to_libjpeg)
+    Image.fromarray(img).save(tmp_path / "prog.jpg", progressive=True)
+    with pytest.raises(FoundationPoseError, match="progressive JPEG textures are not supported"):
+        tex("prog.jpg")
     # truncated files of every container fail cleanly
-    for name in ("a.bmp", "e.ppm", "g.tga", "h.tga", "v.png"):
+    Image.fromarray(img).save(tmp_path / "base.jpg")
+    for name in ("a.bmp", "e.ppm", "g.tga", "h.tga", "v.png", "base.jpg"):
         data = (tmp_path / name).read_bytes()
         (tmp_path / ("cut_" + name)).write_bytes(data[:len(data) // 2])
         with pytest.raises(FoundationPoseError, match="cannot be decoded"):
             tex("cut_" + name)
+
+
+def test_jpeg_textures_bit_identical_to_libjpeg(tmp_path, small_mesh):
+    """baseline JPEG decoded like libjpeg(-turbo) with its defaults (= cv::imread): integer slow IDCT, fancy chroma upsampling,
+    fixed-point YCbCr -> RGB.  PIL sits on libjpeg-turbo: every pixel must be IDENTICAL, for every chroma sampling, odd sizes
+    (ragged MCUs, replicated edge rows / columns), greyscale, optimised Huffman tables, restart markers, coarse and fine quantisation"""
+    rng = np.random.default_rng(5)
+
+    def picture(h, w):
+        a = rng.integers(0, 256, size=(h // 4 + 2, w // 4 + 2, 3)).astype(np.float32)
+        a = np.kron(a, np.ones((4, 4, 1)))[:h, :w]
+        return np.clip(a + rng.normal(0, 8, a.shape), 0, 255).astype(np.uint8)
+    variants = [("444", dict(subsampling=0), "RGB"), ("422", dict(subsampling=1), "RGB"), ("420", dict(subsampling=2), "RGB"),
+                ("grey", {}, "L"), ("q25", dict(quality=25), "RGB"), ("q98", dict(quality=98, subsampling=2), "RGB"),
+                ("opt", dict(optimize=True, subsampling=2), "RGB"), ("rst", dict(restart_marker_blocks=3, subsampling=2), "RGB"),
+                ("rstrow", dict(restart_marker_rows=1), "RGB")]
+    for h, w in ((48, 64), (37, 53), (16, 8), (1, 1), (9, 17), (130, 7)):
+        img = picture(h, w)
+        for name, kw, mode in variants:
+            f = f"t_{h}x{w}_{name}.jpg"
+            Image.fromarray(img).convert(mode).save(tmp_path / f, **kw)
+            got = load_mesh("obj", _write_obj(str(tmp_path), small_mesh, texture=f)).texture
+            np.testing.assert_array_equal(got, np.asarray(Image.open(tmp_path / f).convert("RGB")), err_msg=f)
+    # CMYK is refused by name
+    Image.fromarray(picture(16, 16)).convert("CMYK").save(tmp_path / "cmyk.jpg")
+    with pytest.raises(FoundationPoseError, match="CMYK"):
+        load_mesh("obj", _write_obj(str(tmp_path), small_mesh, texture="cmyk.jpg"))
