@@ -74,6 +74,137 @@ std::string dirname_of(const std::string &p) {
 
 }  // namespace
 
+namespace {
+struct Corner { int v, t, n; };
+struct ParsedMesh {
+  std::vector<std::array<float, 3>> pos, nrm;
+  std::vector<std::array<float, 2>> uv;
+  std::vector<std::array<Corner, 3>> tris;
+  std::string mtllib, usemtl;     // OBJ: the texture is named by the material library
+  std::string texture_file;       // PLY: `comment TextureFile <name>` (what assimp turns into the diffuse texture)
+};
+
+// Stanford PLY (ascii / binary_little_endian / binary_big_endian): per-vertex x y z [nx ny nz] [s t | u v | texture_u texture_v],
+// faces as `property list <T> <T> vertex_indices|vertex_index` (polygons are fanned), optional per-face `texcoord` list (MeshLab's
+// per-wedge UVs), `comment TextureFile <file>`.  The BOP / YCB-V object models come in this form.
+bool parse_ply(const std::string &path, ParsedMesh &out, std::string &err) {
+  std::ifstream f(path, std::ios::binary);
+  if (!f) { err = "cannot open"; return false; }
+  std::string line;
+  if (!std::getline(f, line) || line.substr(0, 3) != "ply") { err = "not a PLY file"; return false; }
+  enum Fmt { ASCII, LE, BE } fmt = ASCII;
+  struct Prop { std::string name, type, ctype; bool list = false; };
+  struct Elem { std::string name; size_t count = 0; std::vector<Prop> props; };
+  std::vector<Elem> elems;
+  bool header_done = false;
+  while (std::getline(f, line)) {
+    if (!line.empty() && line.back() == '\r') line.pop_back();
+    std::istringstream ss(line);
+    std::string tag;
+    if (!(ss >> tag)) continue;
+    if (tag == "format") { std::string v; ss >> v; fmt = v == "ascii" ? ASCII : v == "binary_little_endian" ? LE : BE; }
+    else if (tag == "comment") { std::string k; ss >> k; if (k == "TextureFile") std::getline(ss >> std::ws, out.texture_file); }
+    else if (tag == "element") { Elem e; ss >> e.name >> e.count; elems.push_back(e); }
+    else if (tag == "property" && !elems.empty()) {
+      Prop pr; std::string t; ss >> t;
+      if (t == "list") { pr.list = true; ss >> pr.ctype >> pr.type >> pr.name; } else { pr.type = t; ss >> pr.name; }
+      elems.back().props.push_back(pr);
+    } else if (tag == "end_header") { header_done = true; break; }
+  }
+  if (!header_done) { err = "PLY header without end_header"; return false; }
+  auto tsize = [](const std::string &t) {
+    if (t == "char" || t == "uchar" || t == "int8" || t == "uint8") return 1;
+    if (t == "short" || t == "ushort" || t == "int16" || t == "uint16") return 2;
+    if (t == "int" || t == "uint" || t == "float" || t == "int32" || t == "uint32" || t == "float32") return 4;
+    if (t == "double" || t == "float64") return 8;
+    return 0;
+  };
+  bool bad = false;
+  auto read_num = [&](const std::string &t) -> double {
+    if (fmt == ASCII) { double v = 0; if (!(f >> v)) bad = true; return v; }
+    const int n = tsize(t);
+    unsigned char b[8] = {0};
+    if (n == 0 || !f.read((char *)b, n)) { bad = true; return 0; }
+    if (fmt == BE) std::reverse(b, b + n);
+    if (t == "float" || t == "float32") { float v; std::memcpy(&v, b, 4); return v; }
+    if (t == "double" || t == "float64") { double v; std::memcpy(&v, b, 8); return v; }
+    if (t == "char" || t == "int8") return (signed char)b[0];
+    if (t == "uchar" || t == "uint8") return b[0];
+    if (t == "short" || t == "int16") { int16_t v; std::memcpy(&v, b, 2); return v; }
+    if (t == "ushort" || t == "uint16") { uint16_t v; std::memcpy(&v, b, 2); return v; }
+    if (t == "int" || t == "int32") { int32_t v; std::memcpy(&v, b, 4); return v; }
+    uint32_t v; std::memcpy(&v, b, 4); return v;
+  };
+  bool has_uv = false, has_n = false;
+  std::map<std::tuple<int, float, float>, int> wedge_uv;
+  for (auto &e : elems) {
+    if (e.count > (size_t)1 << 28) { err = "PLY element count out of range"; return false; }
+    if (e.name == "vertex") {
+      int ix = -1, iy = -1, iz = -1, inx = -1, iny = -1, inz = -1, iu = -1, iv = -1;
+      for (size_t k = 0; k < e.props.size(); k++) {
+        const std::string &n = e.props[k].name;
+        if (e.props[k].list) { err = "PLY: list property on vertices is not supported"; return false; }
+        if (n == "x") ix = (int)k; else if (n == "y") iy = (int)k; else if (n == "z") iz = (int)k;
+        else if (n == "nx") inx = (int)k; else if (n == "ny") iny = (int)k; else if (n == "nz") inz = (int)k;
+        else if (n == "s" || n == "u" || n == "texture_u") iu = (int)k; else if (n == "t" || n == "v" || n == "texture_v") iv = (int)k;
+      }
+      if (ix < 0 || iy < 0 || iz < 0) { err = "PLY vertices without x / y / z"; return false; }
+      has_n = inx >= 0 && iny >= 0 && inz >= 0;
+      has_uv = iu >= 0 && iv >= 0;
+      std::vector<double> row(e.props.size());
+      out.pos.reserve(e.count);
+      for (size_t i = 0; i < e.count && !bad; i++) {
+        for (size_t k = 0; k < e.props.size(); k++) row[k] = read_num(e.props[k].type);
+        out.pos.push_back({(float)row[ix], (float)row[iy], (float)row[iz]});
+        if (has_n) out.nrm.push_back({(float)row[inx], (float)row[iny], (float)row[inz]});
+        if (has_uv) out.uv.push_back({(float)row[iu], (float)row[iv]});
+      }
+    } else if (e.name == "face") {
+      for (size_t i = 0; i < e.count && !bad; i++) {
+        std::vector<int> idx;
+        std::vector<float> wedge;
+        for (auto &pr : e.props) {
+          if (!pr.list) { (void)read_num(pr.type); continue; }
+          const long n = (long)read_num(pr.ctype);
+          if (n < 0 || n > 4096) { bad = true; break; }
+          for (long k = 0; k < n; k++) {
+            const double v = read_num(pr.type);
+            if (pr.name == "vertex_indices" || pr.name == "vertex_index") idx.push_back((int)v);
+            else if (pr.name == "texcoord") wedge.push_back((float)v);
+          }
+        }
+        if (bad || idx.size() < 3) continue;
+        std::vector<Corner> cs;
+        for (size_t k = 0; k < idx.size(); k++) {
+          Corner c{idx[k], has_uv ? idx[k] : -1, has_n ? idx[k] : -1};
+          if (wedge.size() == 2 * idx.size()) {     // per-wedge UVs win over per-vertex ones (MeshLab); equal (vertex, uv) pairs share an entry
+            const auto key = std::make_tuple(idx[k], wedge[2 * k], wedge[2 * k + 1]);
+            auto it = wedge_uv.find(key);
+            if (it == wedge_uv.end()) {
+              out.uv.push_back({wedge[2 * k], wedge[2 * k + 1]});
+              it = wedge_uv.emplace(key, (int)out.uv.size() - 1).first;
+            }
+            c.t = it->second;
+          }
+          cs.push_back(c);
+        }
+        for (size_t k = 2; k < cs.size(); k++) out.tris.push_back({cs[0], cs[k - 1], cs[k]});
+      }
+    } else {   // an element this loader does not use: skip its data
+      for (size_t i = 0; i < e.count && !bad; i++)
+        for (auto &pr : e.props) {
+          if (!pr.list) { (void)read_num(pr.type); continue; }
+          const long n = (long)read_num(pr.ctype);
+          if (n < 0 || n > 1 << 20) { bad = true; break; }
+          for (long k = 0; k < n; k++) (void)read_num(pr.type);
+        }
+    }
+  }
+  if (bad) { err = "truncated or malformed PLY body"; return false; }
+  return true;
+}
+}  // namespace
+
 struct fp_loaded_mesh {
   std::string name;
   std::vector<float> vertices, normals, texcoords;
@@ -91,13 +222,21 @@ extern "C" {
 
 static fp_loaded_mesh *fp_mesh_load_obj_impl(const char *name, const char *mesh_file_path) {
   if (!mesh_file_path || !*mesh_file_path) { fp::set_error("[AssimpMeshLoader] Got empty mesh_file_path !"); return nullptr; }
+  ParsedMesh pm;
+  std::vector<std::array<float, 3>> &pos = pm.pos, &nrm = pm.nrm;
+  std::vector<std::array<float, 2>> &uv = pm.uv;
+  std::vector<std::array<Corner, 3>> &tris = pm.tris;
+  std::string &mtllib = pm.mtllib, &usemtl = pm.usemtl;
+  const std::string path_s(mesh_file_path);
+  const std::string ext = path_s.size() >= 4 ? path_s.substr(path_s.size() - 4) : "";
+  const bool is_ply = ext == ".ply" || ext == ".PLY";
+  if (is_ply) {
+    std::string perr;
+    if (!parse_ply(path_s, pm, perr)) { fp::set_error("[AssimpMeshLoader] Failed to read mesh file: " + path_s + " (" + perr + ")"); return nullptr; }
+  } else {
   std::ifstream f(mesh_file_path);
   if (!f) { fp::set_error(std::string("[AssimpMeshLoader] Failed to read mesh file: ") + mesh_file_path); return nullptr; }
-  std::vector<std::array<float, 3>> pos, nrm;
-  std::vector<std::array<float, 2>> uv;
-  struct Corner { int v, t, n; };
-  std::vector<std::array<Corner, 3>> tris;
-  std::string mtllib, usemtl, line;
+  std::string line;
   bool first_object_done = false;
   while (std::getline(f, line)) {
     if (!line.empty() && line.back() == '\r') line.pop_back();
@@ -131,6 +270,7 @@ static fp_loaded_mesh *fp_mesh_load_obj_impl(const char *name, const char *mesh_
       }
       for (size_t i = 2; i < cs.size(); i++) tris.push_back({cs[0], cs[i - 1], cs[i]});
     }
+  }
   }
   if (tris.empty() || pos.empty()) { fp::set_error(std::string("[AssimpMeshLoader] Failed to read mesh file: ") + mesh_file_path); return nullptr; }
   std::unique_ptr<fp_loaded_mesh> owner(new fp_loaded_mesh());   // freed on every early return and if anything below throws
@@ -242,6 +382,7 @@ static fp_loaded_mesh *fp_mesh_load_obj_impl(const char *name, const char *mesh_
       if (tex_path.empty()) tex_path = first_map;
       if (!tex_path.empty()) tex_path = dirname_of(mesh_file_path) + "/" + tex_path;
     }
+    if (is_ply && !pm.texture_file.empty()) tex_path = dirname_of(mesh_file_path) + "/" + pm.texture_file;
     const bool named = !tex_path.empty();
     const bool present = named && std::ifstream(tex_path, std::ios::binary).good();
     std::string why;

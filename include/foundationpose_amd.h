@@ -54,8 +54,11 @@ typedef struct fp_mesh {
 } fp_mesh;
 
 /* ---- mesh loading: CreateAssimpMeshLoader(name, mesh_file_path) (mesh_loader.hpp:92-93, src/mesh_loader/assimp_mesh_loader.cpp:159-228)
- * without assimp/OpenCV: Wavefront OBJ + MTL map_Kd + 8-bit PNG.  Returns NULL (+ fp_last_error) where the reference throws:
- * empty path, unreadable file, no texture coordinates.  Missing texture -> 2x2 (100,100,100) like the reference. */
+ * without assimp/OpenCV.  Mesh files: Wavefront OBJ (+ MTL map_Kd) and Stanford PLY (ascii / binary, per-vertex or per-wedge UVs,
+ * `comment TextureFile`: the form of the BOP / YCB-V object models); the name is historical.  Textures: PNG (any bit depth, interlaced
+ * or not), baseline JPEG (decoded like libjpeg-turbo), BMP, PNM, TGA -> RGB u8 as cv::imread + BGR2RGB delivers it.  Returns NULL
+ * (+ fp_last_error) where the reference throws: empty path, unreadable file, no texture coordinates; also for a texture file that
+ * exists but cannot be decoded (never a silent grey texture).  Missing texture -> 2x2 (100,100,100) like the reference. */
 typedef struct fp_loaded_mesh fp_loaded_mesh;
 fp_loaded_mesh *fp_mesh_load_obj(const char *name, const char *mesh_file_path);
 void fp_mesh_free(fp_loaded_mesh *mesh);

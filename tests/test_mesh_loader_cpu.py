@@ -243,3 +243,84 @@ def test_jpeg_textures_bit_identical_to_libjpeg(tmp_path, small_mesh):
     Image.fromarray(picture(16, 16)).convert("CMYK").save(tmp_path / "cmyk.jpg")
     with pytest.raises(FoundationPoseError, match="CMYK"):
         load_mesh("obj", _write_obj(str(tmp_path), small_mesh, texture="cmyk.jpg"))
+
+
+def _write_ply(path, mesh, fmt="ascii", uv_names=("texture_u", "texture_v"), normals=True, texture="tex.png", wedge=False, quads=False,
+               extra_element=False):
+    """PLY the way the BOP / YCB-V object models (per-vertex texture_u / texture_v + `comment TextureFile`) and MeshLab (per-face
+    `texcoord` list) write it"""
+    import struct
+    v, n, uv, f = mesh.vertices, mesh.normals, mesh.texcoords, mesh.faces
+    be = fmt == "binary_big_endian"
+    hdr = ["ply", f"format {fmt} 1.0", "comment made by the test"]
+    if texture:
+        hdr.append(f"comment TextureFile {texture}")
+    if extra_element:
+        hdr += ["element camera 1", "property float view_px", "property list uchar int extras"]
+    hdr += [f"element vertex {len(v)}", "property float x", "property float y", "property float z"]
+    if normals:
+        hdr += ["property float nx", "property float ny", "property float nz"]
+    if uv_names and not wedge:
+        hdr += [f"property float {uv_names[0]}", f"property float {uv_names[1]}"]
+    hdr += ["property uchar red", f"element face {len(f) + (1 if quads else 0)}", "property list uchar int vertex_indices"]
+    if wedge:
+        hdr.append("property list uchar float texcoord")
+    hdr.append("end_header")
+    body_a, body_b = [], b""
+    e = ">" if be else "<"
+    if extra_element:
+        body_a.append("0.5 2 7 9")
+        body_b += struct.pack(e + "fBii", 0.5, 2, 7, 9)
+    for i in range(len(v)):
+        row = list(v[i]) + (list(n[i]) if normals else []) + (list(uv[i]) if uv_names and not wedge else [])
+        body_a.append(" ".join("%.9g" % x for x in row) + " 200")
+        body_b += struct.pack(e + "%df" % len(row), *row) + b"\xc8"
+    faces = [list(t) for t in f] + ([[0, 1, 2, 3]] if quads else [])
+    for t in faces:
+        la = f"{len(t)} " + " ".join(str(int(i)) for i in t)
+        lb = struct.pack(e + "B%di" % len(t), len(t), *[int(i) for i in t])
+        if wedge:
+            w = [c for i in t for c in uv[i]]
+            la += f" {len(w)} " + " ".join("%.9g" % x for x in w)
+            lb += struct.pack(e + "B%df" % len(w), len(w), *w)
+        body_a.append(la)
+        body_b += lb
+    with open(path, "wb") as fh:
+        fh.write(("\n".join(hdr) + "\n").encode())
+        fh.write(("\n".join(body_a) + "\n").encode() if fmt == "ascii" else body_b)
+    return path
+
+
+def test_ply_meshes_like_the_bop_models(tmp_path, small_mesh):
+    """PLY in ascii / little- / big-endian binary, per-vertex UVs under their three usual names, MeshLab's per-wedge UVs, a texture
+    named by `comment TextureFile` (what assimp turns into the diffuse texture), polygons, elements the loader does not use --
+    the same mesh as the OBJ route delivers"""
+    Image.fromarray(small_mesh.texture).save(tmp_path / "tex.png")
+    ref = load_mesh("obj", _write_obj(str(tmp_path), small_mesh))
+    for k, kw in enumerate([dict(fmt="ascii"), dict(fmt="binary_little_endian"), dict(fmt="binary_big_endian", uv_names=("s", "t")),
+                            dict(fmt="ascii", uv_names=("u", "v"), extra_element=True), dict(fmt="binary_little_endian", wedge=True, extra_element=True),
+                            dict(fmt="ascii", wedge=True, normals=False)]):
+        m = load_mesh("ply", _write_ply(str(tmp_path / f"m{k}.ply"), small_mesh, **kw))
+        assert m.faces.shape == ref.faces.shape, kw
+        np.testing.assert_allclose(m.vertices[m.faces], ref.vertices[ref.faces], rtol=1e-6, err_msg=str(kw))
+        np.testing.assert_allclose(m.texcoords[m.faces], ref.texcoords[ref.faces], rtol=1e-6, err_msg=str(kw))
+        if kw.get("normals", True):
+            np.testing.assert_allclose(m.normals[m.faces], ref.normals[ref.faces], rtol=1e-6, err_msg=str(kw))
+        else:   # computed (area-weighted) normals: close to the analytic ones of the ellipsoid
+            assert (np.einsum("fkc,fkc->fk", m.normals[m.faces], ref.normals[ref.faces]) > 0.97).all()
+        np.testing.assert_array_equal(m.texture, small_mesh.texture)
+        assert m.diameter == pytest.approx(ref.diameter, rel=1e-6)
+        np.testing.assert_allclose(m.center, ref.center, atol=1e-7)
+    # a polygon is fanned; no TextureFile -> the reference's grey default; no UVs -> the reference's error
+    m = load_mesh("ply", _write_ply(str(tmp_path / "q.ply"), small_mesh, quads=True, texture=None))
+    assert len(m.faces) == len(ref.faces) + 2 and m.texture.shape == (2, 2, 3) and (m.texture == 100).all()
+    with pytest.raises(FoundationPoseError, match="invalid texturecoords"):
+        load_mesh("ply", _write_ply(str(tmp_path / "nouv.ply"), small_mesh, uv_names=None))
+    # truncated body / broken header fail cleanly
+    data = open(tmp_path / "m1.ply", "rb").read()
+    open(tmp_path / "cut.ply", "wb").write(data[:len(data) // 2])
+    with pytest.raises(FoundationPoseError, match="Failed to read mesh file"):
+        load_mesh("ply", str(tmp_path / "cut.ply"))
+    open(tmp_path / "bad.ply", "wb").write(b"ply\nformat ascii 1.0\nelement vertex 3\n")
+    with pytest.raises(FoundationPoseError, match="Failed to read mesh file"):
+        load_mesh("ply", str(tmp_path / "bad.ply"))
