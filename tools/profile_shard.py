@@ -19,7 +19,8 @@ H, Wd = scene.depth.shape
 be = HipShardBackend(m, dev)
 if len(sys.argv) > 3:   # optional test hook: python tools/profile_shard.py 32 fpt_set_rem_small 1
     from foundationpose_cpp_amd import _lib
-    getattr(_lib.lib(), sys.argv[2])(int(sys.argv[3]))  # needs _lib.use_test_lib() (done at import below)
+    for hk, hv in zip(sys.argv[2::2], sys.argv[3::2]):   # any number of hook / value pairs
+        getattr(_lib.lib(), hk)(int(hv))  # needs _lib.use_test_lib() (done at import above)
 packed, _ = be.buffers(count, 1)
 def one():
     be.shard_begin_packed(rgb, depth, mask, H, Wd, mesh.name, 1, 0, count, packed, count)
