@@ -456,7 +456,7 @@ static bool decode_jpeg(const std::vector<uint8_t> &b, std::vector<uint8_t> &rgb
         c.px.assign((size_t)c.stride * c.rows, 0);
         c.dcpred = 0;
       }
-      Bits br{&b[end], b.data() + b.size()};
+      Bits br{b.data() + end, b.data() + b.size()};
       int blk[64], togo = restart, rst = 0;
       for (int yy = 0; yy < my; yy++)
         for (int xx = 0; xx < mx; xx++) {

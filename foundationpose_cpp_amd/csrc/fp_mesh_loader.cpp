@@ -152,7 +152,7 @@ bool parse_ply(const std::string &path, ParsedMesh &out, std::string &err) {
       has_n = inx >= 0 && iny >= 0 && inz >= 0;
       has_uv = iu >= 0 && iv >= 0;
       std::vector<double> row(e.props.size());
-      out.pos.reserve(e.count);
+      out.pos.reserve(std::min<size_t>(e.count, (size_t)1 << 20));   // (the count is file-supplied: no allocation by a corrupt header)
       for (size_t i = 0; i < e.count && !bad; i++) {
         for (size_t k = 0; k < e.props.size(); k++) row[k] = read_num(e.props[k].type);
         out.pos.push_back({(float)row[ix], (float)row[iy], (float)row[iz]});
