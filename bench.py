@@ -408,6 +408,36 @@ def main():
             v = max(L.fpt_mfma_peak(200000, 8, 0, C.byref(mhz)) for _ in range(2))
             if v > 0:
                 measured_peak, measured_mhz = round(float(v), 1), round(mhz.value)
+        # where the dominant kernel's other half goes: in-kernel clock probe of conv_halo_kernel on the conv_256 shape (test build,
+        # outside every timed region): shader clock the package allows under this load, cycles of a workgroup's main loop, and the
+        # share of them in which its SIMD's matrix pipe is issuing (2 co-resident waves x 72 K-steps x 40 MFMAs x 16 cycles)
+        clock_probe = None
+        if world == 1 and not args.no_mfma_peak and not args.track and args.dtype == "f16":
+            try:
+                from foundationpose_cpp_amd import _lib
+                Lt = _lib.test_lib()
+                rng = np.random.default_rng(0)
+                NBp = 126
+                xp = rng.standard_normal((NBp, 40, 40, 256), dtype=np.float32)
+                wp = (rng.standard_normal((256, 3, 3, 256), dtype=np.float32) / 48.0).astype(np.float32)
+                bp = np.zeros(256, np.float32)
+                op = np.zeros((NBp, 40, 40, 256), np.float32)
+                msf = C.c_float(0)
+                pp_ = lambda t: t.ctypes.data_as(C.c_void_p)  # noqa: E731
+                if Lt.fpt_clk_probe(1 << 16, None, None) == 0 and \
+                        Lt.fpt_conv(pp_(xp), pp_(wp), pp_(bp), None, NBp, 40, 40, 256, 256, 3, 3, 1, 1, 40, 40, 1, 0, pp_(op), 3, C.byref(msf)) == 0:
+                    mhz_p, cyc_p = C.c_double(0), C.c_double(0)
+                    Lt.fpt_clk_probe(-512, C.byref(mhz_p), C.byref(cyc_p))
+                    if cyc_p.value > 0:
+                        issue = 2 * 72 * 40 * 16 / cyc_p.value
+                        clock_probe = {"kernel": "conv_halo_kernel (conv_256 shape, 126 hypotheses)", "shader_clock_mhz": round(mhz_p.value),
+                                       "main_loop_cycles_per_workgroup": round(cyc_p.value),
+                                       "mfma_issue_share_of_main_loop": round(issue, 3),
+                                       "clock_vs_datasheet_2400": round(mhz_p.value / 2400.0, 3),
+                                       "what": "0.5 of the datasheet peak = issue share in the loop x loop share of a round (~0.84) x round fill x "
+                                               "clock / 2.4 GHz: the package's power limit, not the schedule, is the largest factor (DESIGN.md section 8)"}
+            except Exception as e:   # evidence only: never fail the bench over it
+                clock_probe = {"error": str(e)}
         res = {
             "metric": "Track fps (N=1)" if args.track else f"pose-hypotheses/sec (Register N={n_total}, {Wd}x{H})",
             "value": round(units * args.steps / dt, 2),
@@ -439,6 +469,7 @@ def main():
                 "peak_measured": measured_peak, "peak_measured_clock_mhz": measured_mhz,
                 "peak_measured_what": "register-resident f16 MFMA micro-benchmark on this box (fp8 MFMAs: 2x)",
                 "frac_of_measured": round(roof["achieved"] / (measured_peak * (2 if dv.get("fp8") else 1)), 4) if measured_peak else None,
+                "clock_probe": clock_probe,
                 "traffic": traffic, "traffic_source": traffic_src,
                 "traffic_kind": "committed rocprofv3 PMC passes of the same command (profiles/), NOT measured by this run" if traffic else None,
             }),
