@@ -275,10 +275,12 @@ static bool decode_tga(const std::vector<uint8_t> &b, std::vector<uint8_t> &rgb,
 // Decoded the way libjpeg(-turbo) does with its defaults -- which is what cv::imread hands the reference: the slow-but-accurate
 // integer IDCT (jidctint.c), "fancy" triangle upsampling of 2x-subsampled chroma (jdsample.c) and the fixed-point YCbCr -> RGB
 // tables (jdcolor.c) -- so textures come out bit-identical to the reference's (tests compare with PIL, which sits on libjpeg-turbo).
-// Progressive / arithmetic / 12-bit / CMYK files are refused by name.  EXIF orientation is ignored.
+// Progressive files (spectral selection + successive approximation, jdphuff.c) go through coefficient arrays and the same back end.
+// Arithmetic-coded / lossless / 12-bit / CMYK files are refused by name.  EXIF orientation is ignored.
 namespace jpg {
 struct Huff { uint8_t bits[17] = {0}; uint8_t vals[256] = {0}; int mincode[17], maxcode[18], valptr[17]; bool ok = false; };
-struct Comp { int id = 0, h = 1, v = 1, tq = 0, td = 0, ta = 0; int bw = 0, bh = 0; std::vector<uint8_t> px; int stride = 0, rows = 0; int dcpred = 0; };
+struct Comp { int id = 0, h = 1, v = 1, tq = 0, td = 0, ta = 0; int bw = 0, bh = 0; std::vector<uint8_t> px; int stride = 0, rows = 0; int dcpred = 0;
+              std::vector<int16_t> coef; /* progressive: [bh][bw][64], natural order */ };
 static const uint8_t ZZ[64] = {0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28,
                                35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
 static void build(Huff &h) {
@@ -378,6 +380,7 @@ static bool decode_jpeg(const std::vector<uint8_t> &b, std::vector<uint8_t> &rgb
   Huff hdc[4], hac[4];
   std::vector<Comp> comps;
   int restart = 0, hmax = 1, vmax = 1;
+  bool progressive = false, any_scan = false;
   size_t pos = 2;
   W = H = 0;
   auto be16 = [&](size_t o) { return (int)((b[o] << 8) | b[o + 1]); };
@@ -392,7 +395,7 @@ static bool decode_jpeg(const std::vector<uint8_t> &b, std::vector<uint8_t> &rgb
     const int len = be16(pos);
     if (len < 2 || pos + len > b.size()) return fail("truncated JPEG");
     const size_t seg = pos + 2, end = pos + len;
-    if (mk == 0xC2 || mk == 0xC6 || mk == 0xCA || mk == 0xCE) return fail("progressive JPEG textures are not supported: re-save as baseline JPEG or PNG");
+    if (mk == 0xC6 || mk == 0xCA || mk == 0xCE) return fail("differential / arithmetic progressive JPEG textures are not supported");
     if (mk == 0xC9 || mk == 0xCB || mk == 0xCD || mk == 0xCF) return fail("arithmetic-coded JPEG textures are not supported");
     if (mk == 0xC3 || mk == 0xC5 || mk == 0xC7) return fail("lossless / hierarchical JPEG textures are not supported");
     if (mk == 0xDB) {
@@ -420,7 +423,8 @@ static bool decode_jpeg(const std::vector<uint8_t> &b, std::vector<uint8_t> &rgb
         q += n;
         build(h);
       }
-    } else if (mk == 0xC0 || mk == 0xC1) {
+    } else if (mk == 0xC0 || mk == 0xC1 || mk == 0xC2) {
+      progressive = mk == 0xC2;
       if (len < 8) return fail("corrupt JPEG (SOF)");
       if (b[seg] != 8) return fail("only 8-bit JPEG textures are supported");
       H = be16(seg + 1); W = be16(seg + 3);
@@ -440,6 +444,122 @@ static bool decode_jpeg(const std::vector<uint8_t> &b, std::vector<uint8_t> &rgb
     } else if (mk == 0xDA) {
       if (comps.empty()) return fail("corrupt JPEG (scan before frame header)");
       const int ns = b[seg];
+      if (progressive) {
+        // ---- one scan of a progressive file (spectral selection Ss..Se, successive approximation Ah / Al) into the coefficient
+        // arrays; libjpeg's jdphuff.c decode_mcu_{DC,AC}_{first,refine} restated
+        if (ns < 1 || ns > (int)comps.size() || len < 6 + 2 * ns) return fail("corrupt JPEG (SOS)");
+        const int mcuw = 8 * hmax, mcuh = 8 * vmax, mx = (W + mcuw - 1) / mcuw, my = (H + mcuh - 1) / mcuh;
+        if (!any_scan)
+          for (auto &c : comps) { c.bw = mx * c.h; c.bh = my * c.v; c.coef.assign((size_t)c.bw * c.bh * 64, 0); }
+        any_scan = true;
+        std::vector<Comp *> sc;
+        for (int i = 0; i < ns; i++) {
+          Comp *c = nullptr;
+          for (auto &cc : comps) if (cc.id == b[seg + 1 + 2 * i]) c = &cc;
+          if (!c) return fail("corrupt JPEG (SOS component)");
+          c->td = b[seg + 2 + 2 * i] >> 4; c->ta = b[seg + 2 + 2 * i] & 15;
+          if (c->td > 3 || c->ta > 3) return fail("corrupt JPEG (SOS table)");
+          sc.push_back(c);
+        }
+        const int Ss = b[seg + 1 + 2 * ns], Se = b[seg + 2 + 2 * ns], Ah = b[seg + 3 + 2 * ns] >> 4, Al = b[seg + 3 + 2 * ns] & 15;
+        if (Ss > Se || Se > 63 || (Ss == 0 && Se != 0) || (Ss > 0 && ns != 1) || Al > 13) return fail("corrupt JPEG (progressive scan parameters)");
+        for (Comp *c : sc) {
+          if (Ss == 0 && Ah == 0 && !hdc[c->td].ok) return fail("corrupt JPEG (missing table)");
+          if (Ss > 0 && !hac[c->ta].ok) return fail("corrupt JPEG (missing table)");
+          c->dcpred = 0;
+        }
+        Bits br{b.data() + end, b.data() + b.size()};
+        int eobrun = 0, togo = restart, rst = 0;
+        bool bad = false;
+        auto do_block = [&](Comp &c, int16_t *cf) {
+          if (Ss == 0) {
+            if (Ah == 0) {
+              const int t = decode_sym(br, hdc[c.td]);
+              if (t < 0 || t > 11) { bad = true; return; }
+              c.dcpred += t ? extend(br.get(t), t) : 0;
+              cf[0] = (int16_t)(c.dcpred * (1 << Al));
+            } else if (br.bit()) cf[0] |= (int16_t)(1 << Al);
+            return;
+          }
+          if (Ah == 0) {
+            if (eobrun > 0) { eobrun--; return; }
+            for (int k = Ss; k <= Se; k++) {
+              const int rs = decode_sym(br, hac[c.ta]);
+              if (rs < 0) { bad = true; return; }
+              const int r = rs >> 4, sz = rs & 15;
+              if (sz) {
+                k += r;
+                if (k > 63) { bad = true; return; }
+                cf[ZZ[k]] = (int16_t)(extend(br.get(sz), sz) * (1 << Al));
+              } else if (r == 15) k += 15;
+              else { eobrun = (1 << r) - 1; if (r) eobrun += br.get(r); break; }
+            }
+            return;
+          }
+          const int p1 = 1 << Al, m1 = -(1 << Al);
+          int k = Ss;
+          if (eobrun == 0) {
+            for (; k <= Se; k++) {
+              const int rs = decode_sym(br, hac[c.ta]);
+              if (rs < 0) { bad = true; return; }
+              int r = rs >> 4, sz = rs & 15;
+              if (sz) { if (sz != 1) { bad = true; return; } sz = br.bit() ? p1 : m1; }
+              else if (r != 15) { eobrun = 1 << r; if (r) eobrun += br.get(r); break; }
+              do {
+                int16_t &co = cf[ZZ[k]];
+                if (co != 0) {
+                  if (br.bit() && (co & p1) == 0) co = (int16_t)(co + (co >= 0 ? p1 : m1));
+                } else if (--r < 0) break;
+                k++;
+              } while (k <= Se);
+              if (sz) { if (k > 63) { bad = true; return; } cf[ZZ[k]] = (int16_t)sz; }
+            }
+          }
+          if (eobrun > 0) {
+            for (; k <= Se; k++) {
+              int16_t &co = cf[ZZ[k]];
+              if (co != 0 && br.bit() && (co & p1) == 0) co = (int16_t)(co + (co >= 0 ? p1 : m1));
+            }
+            eobrun--;
+          }
+        };
+        auto maybe_restart = [&]() {
+          if (!restart || togo) return true;
+          br.reset();
+          const uint8_t *q = br.p;
+          while (q + 1 < br.end && !(q[0] == 0xFF && q[1] >= 0xD0 && q[1] <= 0xD7)) q++;
+          if (q + 1 >= br.end || q[1] != 0xD0 + (rst & 7)) return false;
+          br.p = q + 2; rst++;
+          togo = restart; eobrun = 0;
+          for (Comp *c : sc) c->dcpred = 0;
+          return true;
+        };
+        if (ns == 1) {      // non-interleaved: the component's own block grid (not padded to MCUs)
+          Comp &c = *sc[0];
+          const int cbw = ((W * c.h + hmax - 1) / hmax + 7) / 8, cbh = ((H * c.v + vmax - 1) / vmax + 7) / 8;
+          for (int by = 0; by < cbh && !bad; by++)
+            for (int bx = 0; bx < cbw && !bad; bx++) {
+              if (!maybe_restart()) return fail("corrupt JPEG (restart marker)");
+              do_block(c, &c.coef[((size_t)by * c.bw + bx) * 64]);
+              if (restart) togo--;
+            }
+        } else {
+          for (int yy = 0; yy < my && !bad; yy++)
+            for (int xx = 0; xx < mx && !bad; xx++) {
+              if (!maybe_restart()) return fail("corrupt JPEG (restart marker)");
+              for (Comp *c : sc)
+                for (int by = 0; by < c->v; by++)
+                  for (int bx = 0; bx < c->h; bx++) do_block(*c, &c->coef[((size_t)(yy * c->v + by) * c->bw + xx * c->h + bx) * 64]);
+              if (restart) togo--;
+            }
+        }
+        if (bad) return fail("corrupt JPEG (progressive entropy data)");
+        // next marker: skip the rest of the entropy-coded segment
+        const uint8_t *q = br.p;
+        while (q + 1 < br.end && !(q[0] == 0xFF && q[1] != 0 && !(q[1] >= 0xD0 && q[1] <= 0xD7))) q++;
+        pos = (size_t)(q - b.data());
+        continue;
+      }
       if (ns != (int)comps.size() || len < 6 + 2 * ns) return fail("multi-scan baseline JPEG textures are not supported");
       for (int i = 0; i < ns; i++) {
         const int cid = b[seg + 1 + 2 * i];
@@ -496,6 +616,20 @@ static bool decode_jpeg(const std::vector<uint8_t> &b, std::vector<uint8_t> &rgb
       break;   // one scan
     }
     pos = end;
+  }
+  if (progressive && any_scan) {
+    int blk[64];
+    for (auto &c : comps) {
+      if (!qok[c.tq]) return fail("corrupt JPEG (missing table)");
+      c.stride = c.bw * 8; c.rows = c.bh * 8;
+      c.px.assign((size_t)c.stride * c.rows, 0);
+      for (int by = 0; by < c.bh; by++)
+        for (int bx = 0; bx < c.bw; bx++) {
+          const int16_t *cf = &c.coef[((size_t)by * c.bw + bx) * 64];
+          for (int i = 0; i < 64; i++) blk[i] = (int)cf[i] * qt[c.tq][i];
+          idct_islow(blk, &c.px[(size_t)(by * 8) * c.stride + (size_t)bx * 8], c.stride);
+        }
+    }
   }
   if (comps.empty() || comps[0].px.empty()) return fail("corrupt JPEG (no image data)");
   // ---- upsample (libjpeg "fancy" triangle filters; edge rows / columns of the REAL component extent are replicated) and convert

@@ -56,7 +56,7 @@ typedef struct fp_mesh {
 /* ---- mesh loading: CreateAssimpMeshLoader(name, mesh_file_path) (mesh_loader.hpp:92-93, src/mesh_loader/assimp_mesh_loader.cpp:159-228)
  * without assimp/OpenCV.  Mesh files: Wavefront OBJ (+ MTL map_Kd) and Stanford PLY (ascii / binary, per-vertex or per-wedge UVs,
  * `comment TextureFile`: the form of the BOP / YCB-V object models); the name is historical.  Textures: PNG (any bit depth, interlaced
- * or not), baseline JPEG (decoded like libjpeg-turbo), BMP, PNM, TGA -> RGB u8 as cv::imread + BGR2RGB delivers it.  Returns NULL
+ * or not), baseline / progressive JPEG (decoded like libjpeg-turbo), BMP, PNM, TGA -> RGB u8 as cv::imread + BGR2RGB delivers it.  Returns NULL
  * (+ fp_last_error) where the reference throws: empty path, unreadable file, no texture coordinates; also for a texture file that
  * exists but cannot be decoded (never a silent grey texture).  Missing texture -> 2x2 (100,100,100) like the reference. */
 typedef struct fp_loaded_mesh fp_loaded_mesh;

@@ -205,10 +205,7 @@ def test_texture_containers_like_cv_imread(tmp_path, small_mesh):
         np.testing.assert_array_equal(tex(name), np.asarray(Image.open(tmp_path / name).convert("RGB")), err_msg=name)
     (tmp_path / "k.ppm").write_text("P3\n# comment\n3 2\n15\n" + " ".join(str(v % 16) for v in range(18)) + "\n")
     np.testing.assert_array_equal(tex("k.ppm"), ((np.arange(18) % 16).reshape(2, 3, 3) * 255 // 15).astype(np.uint8))
-    # --- progressive JPEG: named in the error, no silent grey texture (baseline JPEG: test_jpeg_textures_bit_identical_to_libjpeg)
-    Image.fromarray(img).save(tmp_path / "prog.jpg", progressive=True)
-    with pytest.raises(FoundationPoseError, match="progressive JPEG textures are not supported"):
-        tex("prog.jpg")
+    # (JPEG, baseline and progressive: test_jpeg_textures_bit_identical_to_libjpeg)
     # truncated files of every container fail cleanly
     Image.fromarray(img).save(tmp_path / "base.jpg")
     for name in ("a.bmp", "e.ppm", "g.tga", "h.tga", "v.png", "base.jpg"):
@@ -219,7 +216,7 @@ def test_texture_containers_like_cv_imread(tmp_path, small_mesh):
 
 
 def test_jpeg_textures_bit_identical_to_libjpeg(tmp_path, small_mesh):
-    """baseline JPEG decoded like libjpeg(-turbo) with its defaults (= cv::imread): integer slow IDCT, fancy chroma upsampling,
+    """baseline and progressive JPEG decoded like libjpeg(-turbo) with its defaults (= cv::imread): integer slow IDCT, fancy chroma upsampling,
     fixed-point YCbCr -> RGB.  PIL sits on libjpeg-turbo: every pixel must be IDENTICAL, for every chroma sampling, odd sizes
     (ragged MCUs, replicated edge rows / columns), greyscale, optimised Huffman tables, restart markers, coarse and fine quantisation"""
     rng = np.random.default_rng(5)
@@ -231,7 +228,11 @@ def test_jpeg_textures_bit_identical_to_libjpeg(tmp_path, small_mesh):
     variants = [("444", dict(subsampling=0), "RGB"), ("422", dict(subsampling=1), "RGB"), ("420", dict(subsampling=2), "RGB"),
                 ("grey", {}, "L"), ("q25", dict(quality=25), "RGB"), ("q98", dict(quality=98, subsampling=2), "RGB"),
                 ("opt", dict(optimize=True, subsampling=2), "RGB"), ("rst", dict(restart_marker_blocks=3, subsampling=2), "RGB"),
-                ("rstrow", dict(restart_marker_rows=1), "RGB")]
+                ("rstrow", dict(restart_marker_rows=1), "RGB"),
+                # progressive: spectral selection + successive approximation, interleaved DC and per-component AC scans
+                ("p444", dict(subsampling=0, progressive=True), "RGB"), ("p420", dict(subsampling=2, progressive=True), "RGB"),
+                ("pgrey", dict(progressive=True), "L"), ("p422q", dict(subsampling=1, progressive=True, quality=35), "RGB"),
+                ("prst", dict(progressive=True, restart_marker_blocks=2, subsampling=2), "RGB"), ("popt", dict(progressive=True, optimize=True, quality=95), "RGB")]
     for h, w in ((48, 64), (37, 53), (16, 8), (1, 1), (9, 17), (130, 7)):
         img = picture(h, w)
         for name, kw, mode in variants:
@@ -337,6 +338,8 @@ def test_loaders_survive_mutated_files(tmp_path, small_mesh):
         seeds[name] = (tmp_path / name).read_bytes()
     obj = _write_obj(str(tmp_path), small_mesh, texture="t.png")
     ok = bad = 0
+    Image.fromarray(img).save(tmp_path / "tp.jpg", progressive=True)
+    seeds["tp.jpg"] = (tmp_path / "tp.jpg").read_bytes()
     for name, data in seeds.items():
         for k in range(60):
             d = bytearray(data)
