@@ -276,7 +276,7 @@ static bool decode_tga(const std::vector<uint8_t> &b, std::vector<uint8_t> &rgb,
 // integer IDCT (jidctint.c), "fancy" triangle upsampling of 2x-subsampled chroma (jdsample.c) and the fixed-point YCbCr -> RGB
 // tables (jdcolor.c) -- so textures come out bit-identical to the reference's (tests compare with PIL, which sits on libjpeg-turbo).
 // Progressive files (spectral selection + successive approximation, jdphuff.c) go through coefficient arrays and the same back end.
-// Arithmetic-coded / lossless / 12-bit / CMYK files are refused by name.  EXIF orientation is ignored.
+// Arithmetic-coded / lossless / 12-bit / CMYK files are refused by name.  The EXIF orientation tag is applied, as cv::imread does.
 namespace jpg {
 struct Huff { uint8_t bits[17] = {0}; uint8_t vals[256] = {0}; int mincode[17], maxcode[18], valptr[17]; bool ok = false; };
 struct Comp { int id = 0, h = 1, v = 1, tq = 0, td = 0, ta = 0; int bw = 0, bh = 0; std::vector<uint8_t> px; int stride = 0, rows = 0; int dcpred = 0;
@@ -372,6 +372,31 @@ static void idct_islow(const int *in, uint8_t *out, int stride) {
 }
 }  // namespace jpg
 
+
+// EXIF orientation 1..8 -> the upright image (what cv::imread / PIL's ImageOps.exif_transpose deliver)
+static void apply_exif_orientation(std::vector<uint8_t> &rgb, int &H, int &W, int o) {
+  if (o <= 1 || o > 8) return;
+  const bool swap = o >= 5;
+  const int oh = swap ? W : H, ow = swap ? H : W;
+  std::vector<uint8_t> out((size_t)oh * ow * 3);
+  for (int y = 0; y < oh; y++)
+    for (int x = 0; x < ow; x++) {
+      int sx, sy;
+      switch (o) {
+        case 2: sx = W - 1 - x; sy = y; break;                 // mirrored horizontally
+        case 3: sx = W - 1 - x; sy = H - 1 - y; break;         // rotated 180
+        case 4: sx = x; sy = H - 1 - y; break;                 // mirrored vertically
+        case 5: sx = y; sy = x; break;                         // transposed
+        case 6: sx = y; sy = H - 1 - x; break;                 // rotate 90 clockwise to upright
+        case 7: sx = W - 1 - y; sy = H - 1 - x; break;         // transverse
+        default: sx = W - 1 - y; sy = x; break;                // 8: rotate 90 counter-clockwise to upright
+      }
+      std::memcpy(&out[((size_t)y * ow + x) * 3], &rgb[((size_t)sy * W + sx) * 3], 3);
+    }
+  rgb.swap(out);
+  H = oh; W = ow;
+}
+
 static bool decode_jpeg(const std::vector<uint8_t> &b, std::vector<uint8_t> &rgb, int &H, int &W, std::string *why) {
   using namespace jpg;
   auto fail = [&](const char *m) { if (why) *why = m; return false; };
@@ -381,6 +406,7 @@ static bool decode_jpeg(const std::vector<uint8_t> &b, std::vector<uint8_t> &rgb
   std::vector<Comp> comps;
   int restart = 0, hmax = 1, vmax = 1;
   bool progressive = false, any_scan = false;
+  int orientation = 1;
   size_t pos = 2;
   W = H = 0;
   auto be16 = [&](size_t o) { return (int)((b[o] << 8) | b[o + 1]); };
@@ -398,7 +424,19 @@ static bool decode_jpeg(const std::vector<uint8_t> &b, std::vector<uint8_t> &rgb
     if (mk == 0xC6 || mk == 0xCA || mk == 0xCE) return fail("differential / arithmetic progressive JPEG textures are not supported");
     if (mk == 0xC9 || mk == 0xCB || mk == 0xCD || mk == 0xCF) return fail("arithmetic-coded JPEG textures are not supported");
     if (mk == 0xC3 || mk == 0xC5 || mk == 0xC7) return fail("lossless / hierarchical JPEG textures are not supported");
-    if (mk == 0xDB) {
+    if (mk == 0xE1 && len >= 16 && !std::memcmp(&b[seg], "Exif\0\0", 6)) {
+      // EXIF orientation (tag 0x0112 in IFD0): cv::imread applies it to JPEG files, so the reference's texture comes out rotated
+      const size_t t0 = seg + 6;
+      const bool le = b[t0] == 'I';
+      auto r16 = [&](size_t o) { return o + 2 <= end ? (le ? b[o] | (b[o + 1] << 8) : (b[o] << 8) | b[o + 1]) : 0; };
+      auto r32 = [&](size_t o) { return o + 4 <= end ? (le ? (uint32_t)r16(o) | ((uint32_t)r16(o + 2) << 16) : ((uint32_t)r16(o) << 16) | (uint32_t)r16(o + 2)) : 0u; };
+      if ((b[t0] == 'I' || b[t0] == 'M') && r16(t0 + 2) == 42) {
+        const size_t ifd = t0 + r32(t0 + 4);
+        const int n = ifd + 2 <= end ? r16(ifd) : 0;
+        for (int i = 0; i < n && ifd + 2 + 12 * (size_t)(i + 1) <= end; i++)
+          if (r16(ifd + 2 + 12 * i) == 0x0112) { const int v = r16(ifd + 2 + 12 * i + 8); if (v >= 1 && v <= 8) orientation = v; }
+      }
+    } else if (mk == 0xDB) {
       size_t q = seg;
       while (q < end) {
         const int pq = b[q] >> 4, tq = b[q] & 15;
@@ -680,6 +718,7 @@ static bool decode_jpeg(const std::vector<uint8_t> &b, std::vector<uint8_t> &rgb
   rgb.resize((size_t)W * H * 3);
   if (comps.size() == 1) {
     for (size_t i = 0; i < (size_t)W * H; i++) rgb[3 * i] = rgb[3 * i + 1] = rgb[3 * i + 2] = full[0][i];
+    apply_exif_orientation(rgb, H, W, orientation);
     return true;
   }
   auto FIX = [](double v) { return (long)(v * 65536.0 + 0.5); };
@@ -691,6 +730,7 @@ static bool decode_jpeg(const std::vector<uint8_t> &b, std::vector<uint8_t> &rgb
     rgb[3 * i + 1] = clamp8(y + ((-f0344 * cb + half - f0714 * cr) >> 16));
     rgb[3 * i + 2] = clamp8(y + ((f1772 * cb + half) >> 16));
   }
+  apply_exif_orientation(rgb, H, W, orientation);
   return true;
 }
 

@@ -240,6 +240,15 @@ def test_jpeg_textures_bit_identical_to_libjpeg(tmp_path, small_mesh):
             Image.fromarray(img).convert(mode).save(tmp_path / f, **kw)
             got = load_mesh("obj", _write_obj(str(tmp_path), small_mesh, texture=f)).texture
             np.testing.assert_array_equal(got, np.asarray(Image.open(tmp_path / f).convert("RGB")), err_msg=f)
+    # EXIF orientation (all eight values) is applied, as cv::imread does: the upright image
+    from PIL import ImageOps
+    pic = picture(24, 40)
+    for o in range(1, 9):
+        ex = Image.Exif()
+        ex[0x0112] = o
+        Image.fromarray(pic).save(tmp_path / f"o{o}.jpg", exif=ex, subsampling=0)
+        got = load_mesh("obj", _write_obj(str(tmp_path), small_mesh, texture=f"o{o}.jpg")).texture
+        np.testing.assert_array_equal(got, np.asarray(ImageOps.exif_transpose(Image.open(tmp_path / f"o{o}.jpg")).convert("RGB")), err_msg=f"orientation {o}")
     # CMYK is refused by name
     Image.fromarray(picture(16, 16)).convert("CMYK").save(tmp_path / "cmyk.jpg")
     with pytest.raises(FoundationPoseError, match="CMYK"):
