@@ -828,9 +828,10 @@ static int read_frame_part(const char *path, const char *what, std::vector<uint1
 }
 
 static int fp_frame_size_impl(const char *rgb_path, int *H, int *W) {
-  std::vector<uint16_t> px;
-  int h, w, ch, bits;
-  if (read_frame_part(rgb_path, "rgb", px, h, w, ch, bits)) return 1;
+  std::vector<uint8_t> pix;
+  std::string why;
+  int h = 0, w = 0;
+  FP_CHECK(rgb_path && fp::load_texture_rgb(rgb_path, pix, h, w, &why), std::string("Failed reading rgb from path : ") + (rgb_path ? rgb_path : "(null)") + " (" + why + ")");
   *H = h;
   *W = w;
   return 0;
@@ -850,11 +851,12 @@ static int fp_read_rgb_depth_mask_impl(const char *rgb_path, const char *depth_p
   std::vector<uint16_t> px;
   int h, w, ch, bits;
   const size_t n = (size_t)H * W;
-  if (rgb) {
-    if (read_frame_part(rgb_path, "rgb", px, h, w, ch, bits)) return 1;
-    FP_CHECK(h == H && w == W && bits == 8, std::string("rgb image has an unexpected size or bit depth: ") + rgb_path);
-    for (size_t i = 0; i < n; i++)
-      for (int c = 0; c < 3; c++) rgb[i * 3 + c] = (uint8_t)px[i * ch + (ch >= 3 ? c : 0)];
+  if (rgb) {   // cv::imread + BGR2RGB: any container the library decodes (PNG, JPEG, BMP, PNM, TGA), 16-bit samples >> 8
+    std::vector<uint8_t> pix;
+    std::string why;
+    FP_CHECK(rgb_path && fp::load_texture_rgb(rgb_path, pix, h, w, &why), std::string("Failed reading rgb from path : ") + (rgb_path ? rgb_path : "(null)") + " (" + why + ")");
+    FP_CHECK(h == H && w == W, std::string("rgb image has an unexpected size: ") + rgb_path);
+    std::memcpy(rgb, pix.data(), n * 3);
   }
   if (depth) {
     if (read_frame_part(depth_path, "depth", px, h, w, ch, bits)) return 1;

@@ -63,6 +63,13 @@ def test_mask_channel_rule_and_png_variants(tmp_path):
         assert L.fp_image_read_png(str(tmp_path / name).encode(), None, None, None, None, _p(out), out.size) == 0
         ref = np.asarray(Image.open(tmp_path / name).convert("RGB" if mode == "P" else mode))
         np.testing.assert_array_equal(out.reshape(ref.shape), ref)
+    # rgb frames in the other containers cv::imread reads (JPEG, BMP): identical to PIL's decode; fp_frame_size too
+    for name, kw in (("r.jpg", {"quality": 90}), ("r.bmp", {})):
+        Image.fromarray(rgbm).save(tmp_path / name, **kw)
+        assert L.fp_read_rgb_depth_mask(str(tmp_path / name).encode(), None, None, H, W, _p(rgb), None, None) == 0, _lib.last_error()
+        np.testing.assert_array_equal(rgb, np.asarray(Image.open(tmp_path / name).convert("RGB")))
+        h, w = C.c_int(), C.c_int()
+        assert L.fp_frame_size(str(tmp_path / name).encode(), C.byref(h), C.byref(w)) == 0 and (h.value, w.value) == (H, W)
     # errors: reference CHECKs with "Failed reading ... from path" / "Failed open file"
     assert L.fp_read_rgb_depth_mask(b"/nonexistent.png", None, None, H, W, _p(rgb), None, None) != 0
     assert "Failed reading rgb from path" in _lib.last_error()
