@@ -191,6 +191,7 @@ __device__ __forceinline__ void glds16_asm_x(const void *gsrc, unsigned lds_addr
 struct ConvParams {
   const unsigned char *in;   // [NB, H+2*ipad, W+2*ipad, Cin]  (zero border of width ipad >= pad is physically present)
   const unsigned char *w;    // [Cout][K] in kernel K order (relayout_k), element type = the kernel's DT
+  const unsigned char *wfrag;  // the same weights in MFMA-fragment order (fragment_order; conv_smallm_kernel only), or null
   const float *bias;         // [Cout]
   const float *cscale;       // FP8 input: [Cout] activation scale * weight scale of the channel; null otherwise
   const unsigned char *res;  // optional residual [NB, OH+2*rpad, OW+2*rpad, res_ld], element type res_dt
@@ -685,7 +686,8 @@ __global__ __launch_bounds__(256, 2) void conv_smallm_kernel(const ConvParams p)
     const int ih0 = oh * p.stride - p.pad + p.ipad, iw0 = ow * p.stride - p.pad + p.ipad;
     xrow[mi] = p.in + ((size_t)(img * IHp + ih0) * IWp + iw0) * p.cin_b + fk * 16;
   }
-  const unsigned char *wrow = p.w + (p.grp_rows ? (size_t)grp * p.grp_w_bytes : 0) + (size_t)(n0 + frow) * p.krow_b + fk * 16;
+  // weights in fragment order (fragment_order): one wave instruction = 1 KB of consecutive bytes = 8 whole cache lines
+  const unsigned char *wrow = p.wfrag + (p.grp_rows ? (size_t)grp * p.grp_w_bytes : 0) + (size_t)(n0 >> 4) * ((size_t)16 * p.krow_b) + lane * 16;
   const size_t wtile = (size_t)16 * p.krow_b;
 
   f4 acc[NI][MI];
@@ -702,7 +704,7 @@ __global__ __launch_bounds__(256, 2) void conv_smallm_kernel(const ConvParams p)
 #pragma unroll
     for (int ks = 0; ks < 2; ks++) {
 #pragma unroll
-      for (int ni = 0; ni < NI; ni++) w[ks][ni] = *reinterpret_cast<const i4 *>(wrow + ni * wtile + (size_t)kt * 128 + ks * 64);
+      for (int ni = 0; ni < NI; ni++) w[ks][ni] = *reinterpret_cast<const i4 *>(wrow + ni * wtile + (size_t)kt * 2048 + ks * 1024);
 #pragma unroll
       for (int mi = 0; mi < MI; mi++) x[ks][mi] = *reinterpret_cast<const i4 *>(xrow[mi] + ko + ks * 64);
     }
@@ -758,6 +760,151 @@ __global__ __launch_bounds__(256, 2) void conv_smallm_kernel(const ConvParams p)
         // component-wise on purpose: a float4 add is legalised to v_pk_add_f32, which this library must not contain
 #pragma unroll
         for (int r = 0; r < 4; r++) acc[a][b][r] = acc[a][b][r] + v[r];
+      }
+  }
+  conv_epilogue<MI, NI, DT, ODT, POST ? 4 : 0>(p, acc, m0, n0, lane);
+}
+
+// -------------------------------------------------------------------------------------------------
+// conv_smallx_kernel [r3]: conv_smallm_kernel with BOTH operands in the shape the vector L1 likes (tools/bench_tcp.hip: the L1
+// serves a wave's 16-byte loads four lanes at a time, one clock per distinct cache line in the four -- 64 clocks for a load in
+// MFMA-operand shape, 18 for 1 KB of consecutive bytes or for 8 pixel rows of 128 bytes):
+//   * weights: global -> registers from the fragment-order copy (fragment_order), 1 KB of consecutive bytes per instruction;
+//   * input pixels: LDS-DMA into a ring PRIVATE to the wave (8 pixels x 128 bytes per instruction, the 16-byte chunks XOR-swizzled
+//     by the pixel on the source side), fragments read back with ds_read_b128 -- no workgroup barrier, the wave waits for its own
+//     DMA with the in-order vmcnt.
+// Every vector-memory instruction in the loop is an asm statement and the waits are counted by hand: L = 2 MI + 2 NI instructions
+// per K-step, PF steps in flight, step s is complete when at most (steps issued after s) * L are outstanding.  Same tiles, same
+// K split over the four waves, same fixed-order reduction and epilogue as conv_smallm_kernel: results are bit-identical.
+// -------------------------------------------------------------------------------------------------
+template <int MI, int NI, int DT, int ODT, bool POST>
+__global__ __launch_bounds__(256, 2) void conv_smallx_kernel(const ConvParams p) {
+  static_assert(DT != DT_FP8, "2-byte operand types");
+  constexpr int PF = MI == 1 ? 4 : 3;        // K-steps in flight per wave
+  constexpr int L = 2 * MI + 2 * NI;         // vector-memory instructions per K-step
+  constexpr int STAGE = MI * 2048, RING = PF * STAGE;
+  static_assert((PF - 1) * L <= 63, "vmcnt is a 6-bit counter");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [4 waves][PF stages][MI][16 pixels][128 B], then 3 * NI * MI KB for the reduction
+  unsigned char *red = smem + 4 * RING;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n_tiles = p.Cout / (16 * NI);
+  int mt, nt;  // XCD placement by channel tile, as in conv_smallm_kernel
+  {
+    const int b = blockIdx.x, xcd = b & 7, within = b >> 3;
+    if (n_tiles >= 8) {
+      const int per = n_tiles >> 3;
+      nt = xcd + 8 * (within % per);
+      mt = within / per;
+    } else {
+      const int share = 8 / n_tiles;
+      nt = xcd / share;
+      mt = within * share + (xcd % share);
+    }
+  }
+  if (mt * (16 * MI) >= p.M) return;
+  const int m0 = mt * (16 * MI), n0 = nt * (16 * NI);
+  const int ohw = p.OH * p.OW;
+  const int IHp = p.H + 2 * p.ipad, IWp = p.W + 2 * p.ipad;
+  const int grp = p.grp_rows ? m0 / p.grp_rows : 0;
+  // DMA sources: instruction (mi, j) stages pixels j*8 .. j*8+7 of fragment mi, lane -> (pixel = lane >> 3, chunk = (lane & 7) ^ pixel)
+  const unsigned char *xsrc[MI][2];
+#pragma unroll
+  for (int mi = 0; mi < MI; mi++)
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      int m = min(m0 + mi * 16 + j * 8 + (lane >> 3), p.M - 1);   // rows past M re-read the last pixel, never stored
+      if (p.in_shared) m -= grp * p.grp_rows;
+      const int img = m / ohw, rem = m - img * ohw;
+      const int oh = rem / p.OW, ow = rem - oh * p.OW;
+      const int ih0 = oh * p.stride - p.pad + p.ipad, iw0 = ow * p.stride - p.pad + p.ipad;
+      xsrc[mi][j] = p.in + ((size_t)(img * IHp + ih0) * IWp + iw0) * p.cin_b + (((lane & 7) ^ ((lane >> 3) & 7)) << 4);
+    }
+  const unsigned char *wrow = p.wfrag + (p.grp_rows ? (size_t)grp * p.grp_w_bytes : 0) + (size_t)(n0 >> 4) * ((size_t)16 * p.krow_b) + lane * 16;
+  const size_t wtile = (size_t)16 * p.krow_b;
+  const unsigned ring_lds = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem + wave * RING;
+  const int li = lane & 15, g = lane >> 4;
+  const unsigned char *xrd = smem + wave * RING + li * 128;
+  const int xsl[2] = {(g ^ (li & 7)) << 4, ((4 + g) ^ (li & 7)) << 4};
+
+  f4 acc[NI][MI];
+#pragma unroll
+  for (int a = 0; a < NI; a++)
+#pragma unroll
+    for (int b = 0; b < MI; b++) acc[a][b] = (f4){0.f, 0.f, 0.f, 0.f};
+
+  const int KT = p.krow_b >> 7;
+  const int n_my = (KT - wave + 3) >> 2;      // steps wave, wave+4, ...
+  i4 wf[PF][2][NI];
+  auto issue = [&](const int slot, i4 (&w)[2][NI], int kt) {
+    const unsigned ko = p.koff[kt];
+#pragma unroll
+    for (int mi = 0; mi < MI; mi++)
+#pragma unroll
+      for (int j = 0; j < 2; j++) glds16_asm(xsrc[mi][j] + ko, ring_lds + slot * STAGE + mi * 2048 + j * 1024);
+#pragma unroll
+    for (int ni = 0; ni < NI; ni++) {
+      const unsigned char *wp = wrow + ni * wtile + (size_t)kt * 2048;
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(w[0][ni]) : "v"(wp) : "memory");
+      asm volatile("global_load_dwordx4 %0, %1, off offset:1024" : "=v"(w[1][ni]) : "v"(wp) : "memory");
+    }
+  };
+  auto wait_steps = [&](int later) {  // wave-uniform: the number of K-steps issued after the one about to be consumed
+    if (later >= PF - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PF - 1) * L) : "memory");
+    else if (later == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * L) : "memory");
+    else if (later == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  };
+  auto consume = [&](const int slot, i4 (&w)[2][NI]) {
+    // (the weight registers are asm outputs: tie them to this point so that no MFMA is scheduled above the wait)
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+      for (int ni = 0; ni < NI; ni++) asm volatile("" : "+v"(w[ks][ni]));
+    __builtin_amdgcn_sched_barrier(0);
+    i4 x[2][MI];
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+      for (int mi = 0; mi < MI; mi++) x[ks][mi] = *reinterpret_cast<const i4 *>(xrd + slot * STAGE + mi * 2048 + xsl[ks]);
+    mma_kstep<DT, NI, MI>(acc, w, x);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  int issued = 0;
+#pragma unroll
+  for (int s = 0; s < PF; s++)
+    if (s < n_my) { issue(s, wf[s], wave + 4 * s); issued++; }
+  for (int base = 0; base < n_my; base += PF) {
+#pragma unroll
+    for (int s = 0; s < PF; s++) {
+      const int step = base + s;
+      if (step < n_my) {
+        wait_steps(issued - step - 1);
+        consume(s, wf[s]);
+        if (issued < n_my) { issue(s, wf[s], wave + 4 * issued); issued++; }   // (issued == step + PF here)
+      }
+    }
+  }
+  // ---- fixed-order reduction of the four partial sums: waves 1..3 publish, wave 0 adds them in order and stores
+  if (wave > 0) {
+    f4 *dst = reinterpret_cast<f4 *>(red + (wave - 1) * (NI * MI * 1024)) + lane;
+#pragma unroll
+    for (int a = 0; a < NI; a++)
+#pragma unroll
+      for (int b = 0; b < MI; b++) dst[(a * MI + b) * 64] = acc[a][b];
+  }
+  __syncthreads();
+  if (wave > 0) return;
+#pragma unroll
+  for (int w = 0; w < 3; w++) {
+    const f4 *src = reinterpret_cast<const f4 *>(red + w * (NI * MI * 1024)) + lane;
+#pragma unroll
+    for (int a = 0; a < NI; a++)
+#pragma unroll
+      for (int b = 0; b < MI; b++) {
+        const f4 v = src[(a * MI + b) * 64];
+#pragma unroll
+        for (int r = 0; r < 4; r++) acc[a][b][r] = acc[a][b][r] + v[r];   // (component-wise: no v_pk_add_f32)
       }
   }
   conv_epilogue<MI, NI, DT, ODT, POST ? 4 : 0>(p, acc, m0, n0, lane);
@@ -3103,6 +3250,7 @@ static bool read_fpw(const char *path, std::map<std::string, HostTensor> &out, s
 
 struct ConvLayer {
   unsigned char *w = nullptr;  // kernel layout, element type dt
+  unsigned char *wfrag = nullptr;  // 2-byte types: a second copy in MFMA-fragment order for conv_smallm_kernel (fragment_order)
   float *bias = nullptr;
   float *wscale = nullptr;     // FP8: [Cout] per-output-channel weight scale (w_real = w_stored * wscale)
   float *cscale = nullptr;     // FP8: [Cout] input activation scale * wscale (net_set_fp8_scales)
@@ -3232,6 +3380,14 @@ static bool make_grouped(Net *net, const ConvLayer &a, const ConvLayer &b, ConvL
   *g = a;
   g->w = w;
   g->bias = bias;
+  g->wfrag = nullptr;
+  if (a.wfrag && b.wfrag) {  // (a group's fragment-order copy has the size of its row-major copy: the same group stride serves both)
+    unsigned char *wf = nullptr;
+    if (hipMalloc((void **)&wf, 2 * nw) != hipSuccess) return false;
+    net->allocs.push_back(wf);
+    if (fp::memcpy_sync(wf, a.wfrag, nw, hipMemcpyDeviceToDevice) != hipSuccess || fp::memcpy_sync(wf + nw, b.wfrag, nw, hipMemcpyDeviceToDevice) != hipSuccess) return false;
+    g->wfrag = wf;
+  }
   return true;
 }
 
@@ -3272,13 +3428,35 @@ static std::vector<unsigned char> permute_rows(const std::vector<unsigned char> 
   return o;
 }
 
+// Fragment order for conv_smallm_kernel, which loads its weight operands global -> registers: the vector L1 serves a wave's
+// 16-byte loads four lanes at a time and takes one clock per DISTINCT cache line in each group of four (tools/bench_tcp.hip: a load in
+// MFMA-operand shape -- lane -> row lane & 15 -- costs 64 clocks per wave instruction at any row pitch, a load of 1 KB of
+// consecutive bytes 18).  So the bytes lane l needs for (16-row tile t, 128-byte K-step kt, half ks) are stored at
+//     ((t * KT + kt) * 2 + ks) * 1024 + l * 16       <-  row t*16 + (l & 15), bytes kt*128 + ks*64 + (l >> 4)*16 .. +15
+// Same size as the row-major copy; `w` is that copy ([Cout][row_bytes], rows already permuted).
+static std::vector<unsigned char> fragment_order(const std::vector<unsigned char> &w, int Cout, size_t row_bytes) {
+  const size_t KT = row_bytes / 128;
+  std::vector<unsigned char> o(w.size());
+  for (size_t t = 0; t < (size_t)Cout / 16; t++)
+    for (size_t kt = 0; kt < KT; kt++)
+      for (int ks = 0; ks < 2; ks++)
+        for (int l = 0; l < 64; l++)
+          std::memcpy(&o[((t * KT + kt) * 2 + ks) * 1024 + (size_t)l * 16], &w[(t * 16 + (l & 15)) * row_bytes + kt * 128 + ks * 64 + (size_t)(l >> 4) * 16], 16);
+  return o;
+}
+
 // [Cout][KH][KW][Cin] f32 rows -> device layer of element type dt
 static bool finish_layer(Net *net, const std::vector<float> &rows_f32, const std::vector<float> &bias, int Cout, int ntaps, int Cin,
                          int dt, ConvLayer *L) {
   const int K = ntaps * Cin, es = elem_bytes(dt);
   std::vector<float> rs;
   auto elems = to_elems(rows_f32, Cout, K, dt, &rs);
-  L->w = upload(net, permute_rows(relayout_k(elems, Cout, ntaps, Cin, es), Cout, (size_t)K * es));
+  const auto rows = permute_rows(relayout_k(elems, Cout, ntaps, Cin, es), Cout, (size_t)K * es);
+  L->w = upload(net, rows);
+  if (dt != DT_FP8 && ((size_t)K * es) % 128 == 0 && Cout % 16 == 0) {
+    L->wfrag = upload(net, fragment_order(rows, Cout, (size_t)K * es));
+    if (!L->wfrag) return false;
+  }
   L->bias = upload(net, bias);
   L->dt = dt;
   if (dt == DT_FP8) {
@@ -3592,9 +3770,10 @@ FP_HOOK g_att_skv = 1;          // small attention grids on attention32_skv_kern
 FP_HOOK g_gemm_deep = 1;         // short-K layers of small problems on conv_deep_kernel<128> instead of the two-stage 128x128 tile
 FP_HOOK g_splitk_mid = 1;        // two split-K slices for long-K layers with 97..128 tiles (batches of ~8 objects)
 FP_HOOK g_small_deep = 18;     // small problems (Track): conv_deep_kernel<64> over ALL K-steps instead of split-K + reduce when K has at most this many 128-byte steps
-FP_HOOK g_smallm_maxkt = 40;   // conv_smallm_kernel takes layers with fewer 128-byte K-steps than this (40 includes the 36-step conv_256 / conv_b2 layers: -3 us and 5 launches fewer per Track than 32)
+FP_HOOK g_smallm_maxkt = 80;   // conv_smallm_kernel takes layers with fewer 128-byte K-steps than this (40 includes the 36-step conv_256 / conv_b2 layers: -3 us and 5 launches fewer per Track than 32)
 FP_HOOK g_conv_lds_store = 0;  // conv_big_pp_kernel: epilogue stores staged through LDS (whole 128-byte lines per store instruction).  OFF: measured [r3] conv_512 3.205 -> 3.227 / 3.184 -> 3.180 ms, i.e. nothing -- the 256x256 tile's store burst is not bound by the store shape (unlike gemm_k32_kernel's, -6 %)
 FP_HOOK g_gemm_lds_store = 1;  // gemm_k32_kernel: output rows leave through LDS as whole 256-byte runs instead of 64-byte pieces per store instruction
+FP_HOOK g_smallm_maxt16 = 1024; // ... and with at most this many 16-pixel x 64-channel tiles (the grouped QKV of Track has 1200)
 FP_HOOK g_smallm = 1;          // small problems (Track, a few objects) on conv_smallm_kernel: K split over the waves of a workgroup, no split-K slabs / reduce launch
 FP_HOOK g_att_variant = 1;     // 1 = attention32_kernel (8 = without the XCD remap); round-1 kernel: 2 remap + 16-B stores, 3 no XCD remap, 5 remap + 2-B stores, 7 neither
 
@@ -3683,7 +3862,7 @@ static int run_conv_dt(const Ctx &c, const char *tag, const ConvLayer &L, ConvPa
     // layers do NOT win -- conv_512 (72 steps) 21 us against 12.3 + 5.2 us for split-K + reduce: operand-shaped global loads touch 16
     // cache lines per instruction (64 bytes used of each) and the vector L1 retires them at ~16 B/clk, a quarter of what the
     // LDS-DMA rows (8 lanes per 128-byte line) get.  g_smallm = 2 forces it for every K (A/B).
-    if (g_smallm && (KT < g_smallm_maxkt || g_smallm == 2) && g_conv_variant == 0 && g_conv_ablate == 0 && L.Cout % cw == 0 && t16 <= 1024 * (64 / cw) &&
+    if (g_smallm && L.wfrag && (KT < g_smallm_maxkt || g_smallm == 2) && g_conv_variant == 0 && g_conv_ablate == 0 && L.Cout % cw == 0 && t16 <= g_smallm_maxt16 * (64 / cw) &&
         (!grp || grp->rows % 32 == 0) && ((L.Cout / cw) % 8 == 0 || 8 % (L.Cout / cw) == 0)) {
       const int t32 = ((p.M + 31) / 32) * (L.Cout / cw);
       const bool two = t32 >= 160;                        // 32-pixel tiles halve the weight stream once they still fill the chip
@@ -3696,10 +3875,21 @@ static int run_conv_dt(const Ctx &c, const char *tag, const ConvLayer &L, ConvPa
       const int per_xcd = ntl >= 8 ? mtl * (ntl / 8) : (mtl + 8 / ntl - 1) / (8 / ntl);
       const dim3 grid(8 * per_xcd);
       const bool deep = KT >= 32;                          // every wave has >= 8 K-steps >= 2 * PF (PF = 4 / 3)
+#ifdef FP_TEST_HOOKS   // A/B (g_smallm == 3): the first version, input fragments global -> registers in operand shape
+#define FP_SMALLM_DIRECT(MI_, NI_, POST_)                                                                                     \
+    if (g_smallm == 3) {                                                                                                      \
+      if (deep) FP_LAUNCH((conv_smallm_kernel<MI_, NI_, DT, ODT, POST_, true>), grid, dim3(256), 3 * NI_ * MI_ * 1024, c.s, p); \
+      else FP_LAUNCH((conv_smallm_kernel<MI_, NI_, DT, ODT, POST_, false>), grid, dim3(256), 3 * NI_ * MI_ * 1024, c.s, p);    \
+      break;                                                                                                                  \
+    }
+#else
+#define FP_SMALLM_DIRECT(MI_, NI_, POST_)
+#endif
 #define FP_SMALLM(MI_, NI_, POST_)                                                                                          \
   do {                                                                                                                      \
-    if (deep) FP_LAUNCH((conv_smallm_kernel<MI_, NI_, DT, ODT, POST_, true>), grid, dim3(256), 3 * NI_ * MI_ * 1024, c.s, p); \
-    else FP_LAUNCH((conv_smallm_kernel<MI_, NI_, DT, ODT, POST_, false>), grid, dim3(256), 3 * NI_ * MI_ * 1024, c.s, p);    \
+    FP_SMALLM_DIRECT(MI_, NI_, POST_)                                                                                       \
+    FP_LAUNCH((conv_smallx_kernel<MI_, NI_, DT, ODT, POST_>), grid, dim3(256),                                              \
+              4 * ((MI_) == 1 ? 4 : 3) * (MI_) * 2048 + 3 * NI_ * MI_ * 1024, c.s, p);                                      \
   } while (0)
       if constexpr (ODT != DT_FP8) {
         if (post && cw == 64) { if (two) FP_SMALLM(2, 4, true); else FP_SMALLM(1, 4, true); return 0; }
@@ -3708,6 +3898,7 @@ static int run_conv_dt(const Ctx &c, const char *tag, const ConvLayer &L, ConvPa
       if (cw == 64) { if (two) FP_SMALLM(2, 4, false); else FP_SMALLM(1, 4, false); }
       else { if (two) FP_SMALLM(2, 2, false); else FP_SMALLM(1, 2, false); }
 #undef FP_SMALLM
+#undef FP_SMALLM_DIRECT
       return 0;
     }
   }
@@ -3952,7 +4143,7 @@ static int run_conv(const Ctx &c, const char *tag, const ConvLayer &L, const Act
   p.res_shared = grp && grp->res_shared;
   p.grp_w_bytes = grp ? (unsigned)((size_t)L.Cout * L.KH * L.KW * L.Cin * es) : 0;
   FP_CHECK(!grp || (grp->rows % 128 == 0 && L.KH == 1 && L.KW == 1 && NB == 2 * grp->rows && L.dt != DT_FP8), "grouped launch: unsupported shape");
-  p.in = (const unsigned char *)in.p; p.w = L.w; p.bias = L.bias; p.cscale = L.dt == DT_FP8 ? L.cscale : nullptr;
+  p.in = (const unsigned char *)in.p; p.w = L.w; p.wfrag = L.wfrag; p.bias = L.bias; p.cscale = L.dt == DT_FP8 ? L.cscale : nullptr;
   p.res = res ? (const unsigned char *)res->p : nullptr; p.out = (unsigned char *)out.p;
   p.out_dt = out.dt; p.res_dt = res ? res->dt : out.dt;
   p.res_scale = res ? res->scale : 1.f;
@@ -4389,6 +4580,7 @@ extern "C" {
 void fpt_set_att_variant(int v) { fp::g_att_variant = v; }
 void fpt_set_smallm(int v) { fp::g_smallm = v; }
 void fpt_set_smallm_maxkt(int v) { fp::g_smallm_maxkt = v; }
+void fpt_set_smallm_maxt16(int v) { fp::g_smallm_maxt16 = v; }
 void fpt_set_gemm_lds_store(int v) { fp::g_gemm_lds_store = v; }
 void fpt_set_conv_lds_store(int v) { fp::g_conv_lds_store = v; }
 void fpt_set_conv_variant(int v) { fp::g_conv_variant = v; }
