@@ -777,10 +777,10 @@ __global__ __launch_bounds__(256, 2) void conv_smallm_kernel(const ConvParams p)
 // per K-step, PF steps in flight, step s is complete when at most (steps issued after s) * L are outstanding.  Same tiles, same
 // K split over the four waves, same fixed-order reduction and epilogue as conv_smallm_kernel: results are bit-identical.
 // -------------------------------------------------------------------------------------------------
-template <int MI, int NI, int DT, int ODT, bool POST>
+template <int MI, int NI, int DT, int ODT, bool POST, int PFO = 0>
 __global__ __launch_bounds__(256, 2) void conv_smallx_kernel(const ConvParams p) {
   static_assert(DT != DT_FP8, "2-byte operand types");
-  constexpr int PF = MI == 1 ? 4 : 3;        // K-steps in flight per wave
+  constexpr int PF = PFO ? PFO : (MI == 1 ? 4 : 3);        // K-steps in flight per wave
   constexpr int L = 2 * MI + 2 * NI;         // vector-memory instructions per K-step
   constexpr int STAGE = MI * 2048, RING = PF * STAGE;
   static_assert((PF - 1) * L <= 63, "vmcnt is a 6-bit counter");
@@ -851,6 +851,7 @@ __global__ __launch_bounds__(256, 2) void conv_smallx_kernel(const ConvParams p)
   };
   auto wait_steps = [&](int later) {  // wave-uniform: the number of K-steps issued after the one about to be consumed
     if (later >= PF - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PF - 1) * L) : "memory");
+    else if (later == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * L <= 63 ? 3 * L : 63) : "memory");
     else if (later == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * L) : "memory");
     else if (later == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -3774,6 +3775,7 @@ FP_HOOK g_smallm_maxkt = 80;   // conv_smallm_kernel takes layers with fewer 128
 FP_HOOK g_conv_lds_store = 0;  // conv_big_pp_kernel: epilogue stores staged through LDS (whole 128-byte lines per store instruction).  OFF: measured [r3] conv_512 3.205 -> 3.227 / 3.184 -> 3.180 ms, i.e. nothing -- the 256x256 tile's store burst is not bound by the store shape (unlike gemm_k32_kernel's, -6 %)
 FP_HOOK g_gemm_lds_store = 1;  // gemm_k32_kernel: output rows leave through LDS as whole 256-byte runs instead of 64-byte pieces per store instruction
 FP_HOOK g_smallm_maxt16 = 1024; // ... and with at most this many 16-pixel x 64-channel tiles (the grouped QKV of Track has 1200)
+FP_HOOK g_smallx_pf = 0;       // A/B (test build): prefetch depth of conv_smallx_kernel<2,4> (4 or 2; 0 = the default 3)
 FP_HOOK g_smallm = 1;          // small problems (Track, a few objects) on conv_smallm_kernel: K split over the waves of a workgroup, no split-K slabs / reduce launch
 FP_HOOK g_att_variant = 1;     // 1 = attention32_kernel (8 = without the XCD remap); round-1 kernel: 2 remap + 16-B stores, 3 no XCD remap, 5 remap + 2-B stores, 7 neither
 
@@ -3877,6 +3879,11 @@ static int run_conv_dt(const Ctx &c, const char *tag, const ConvLayer &L, ConvPa
       const bool deep = KT >= 32;                          // every wave has >= 8 K-steps >= 2 * PF (PF = 4 / 3)
 #ifdef FP_TEST_HOOKS   // A/B (g_smallm == 3): the first version, input fragments global -> registers in operand shape
 #define FP_SMALLM_DIRECT(MI_, NI_, POST_)                                                                                     \
+    if (g_smallx_pf && MI_ == 2 && NI_ == 4 && !POST_ && DT == DT_F16 && ODT == DT_F16) {                                     \
+      if (g_smallx_pf == 4) FP_LAUNCH((conv_smallx_kernel<2, 4, DT_F16, DT_F16, false, 4>), grid, dim3(256), 4 * 4 * 2 * 2048 + 3 * 4 * 2 * 1024, c.s, p); \
+      else FP_LAUNCH((conv_smallx_kernel<2, 4, DT_F16, DT_F16, false, 2>), grid, dim3(256), 4 * 2 * 2 * 2048 + 3 * 4 * 2 * 1024, c.s, p); \
+      break;                                                                                                                  \
+    }                                                                                                                         \
     if (g_smallm == 3) {                                                                                                      \
       if (deep) FP_LAUNCH((conv_smallm_kernel<MI_, NI_, DT, ODT, POST_, true>), grid, dim3(256), 3 * NI_ * MI_ * 1024, c.s, p); \
       else FP_LAUNCH((conv_smallm_kernel<MI_, NI_, DT, ODT, POST_, false>), grid, dim3(256), 3 * NI_ * MI_ * 1024, c.s, p);    \
@@ -4580,6 +4587,7 @@ extern "C" {
 void fpt_set_att_variant(int v) { fp::g_att_variant = v; }
 void fpt_set_smallm(int v) { fp::g_smallm = v; }
 void fpt_set_smallm_maxkt(int v) { fp::g_smallm_maxkt = v; }
+void fpt_set_smallx_pf(int v) { fp::g_smallx_pf = v; }
 void fpt_set_smallm_maxt16(int v) { fp::g_smallm_maxt16 = v; }
 void fpt_set_gemm_lds_store(int v) { fp::g_gemm_lds_store = v; }
 void fpt_set_conv_lds_store(int v) { fp::g_conv_lds_store = v; }

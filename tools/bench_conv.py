@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--ablate", type=int, default=0)
     ap.add_argument("--only", default="")
     ap.add_argument("--clock", action="store_true")
+    ap.add_argument("--res", action="store_true", help="with a residual input (the second conv of a residual block)")
     ap.add_argument("--variant", type=int, default=0, help="0 auto, 1 = 128-px 2-stage kernel, 2 = 256-px 3-stage kernel")
     a = ap.parse_args()
     _lib.use_test_lib()
@@ -51,7 +52,8 @@ def main():
         out = np.zeros((NB, OH, OW, Cout), np.float32)
         ms = C.c_float(0)
         p = lambda t: t.ctypes.data_as(C.c_void_p)  # noqa: E731
-        rc = L.fpt_conv(p(x), p(w), p(b), None, NB, H, W, Cin, Cout, k, k, stride, pad, OH, OW, 1, 0, p(out), a.iters,
+        res = rng.standard_normal(out.shape, dtype=np.float32) if a.res and Cin == Cout and stride == 1 else None
+        rc = L.fpt_conv(p(x), p(w), p(b), p(res) if res is not None else None, NB, H, W, Cin, Cout, k, k, stride, pad, OH, OW, 1, 0, p(out), a.iters,
                         C.byref(ms))
         assert rc == 0, _lib.last_error()
         fl = 2.0 * NB * OH * OW * Cout * k * k * Cin

@@ -7,8 +7,12 @@ what each rank of a strong-scaled run executes besides the all-gather itself -- 
 import os, sys, tempfile, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from foundationpose_cpp_amd import FoundationPose, synthetic as syn, weights as W
+from foundationpose_cpp_amd import FoundationPose, synthetic as syn, weights as W, _lib
 from foundationpose_cpp_amd.distributed import HipShardBackend
+if len(sys.argv) >= 3:   # A/B: python tools/time_shard.py HOOK VALUE  (test build of the library)
+    _lib.use_test_lib()
+    getattr(_lib.lib(), sys.argv[1])(int(sys.argv[2]))
+    print(f"{sys.argv[1]}({sys.argv[2]})")
 
 dev = torch.device("cuda", 0)
 mesh = syn.make_mesh(); scene = syn.make_scene(mesh)
