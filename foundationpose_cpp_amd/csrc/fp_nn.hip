@@ -3864,7 +3864,7 @@ static int run_conv_dt(const Ctx &c, const char *tag, const ConvLayer &L, ConvPa
     // layers do NOT win -- conv_512 (72 steps) 21 us against 12.3 + 5.2 us for split-K + reduce: operand-shaped global loads touch 16
     // cache lines per instruction (64 bytes used of each) and the vector L1 retires them at ~16 B/clk, a quarter of what the
     // LDS-DMA rows (8 lanes per 128-byte line) get.  g_smallm = 2 forces it for every K (A/B).
-    if (g_smallm && L.wfrag && (KT < g_smallm_maxkt || g_smallm == 2) && g_conv_variant == 0 && g_conv_ablate == 0 && L.Cout % cw == 0 && t16 <= g_smallm_maxt16 * (64 / cw) &&
+    if (g_smallm && L.wfrag && (KT < g_smallm_maxkt || g_smallm >= 2) && g_conv_variant == 0 && g_conv_ablate == 0 && L.Cout % cw == 0 && t16 <= g_smallm_maxt16 * (64 / cw) &&
         (!grp || grp->rows % 32 == 0) && ((L.Cout / cw) % 8 == 0 || 8 % (L.Cout / cw) == 0)) {
       const int t32 = ((p.M + 31) / 32) * (L.Cout / cw);
       const bool two = t32 >= 160;                        // 32-pixel tiles halve the weight stream once they still fill the chip

@@ -110,6 +110,51 @@ def test_conv_alternative_schedules_match_torch(variant):
         L.fpt_set_conv_variant(0)
 
 
+@pytest.mark.parametrize("shape", [
+    # NB, H, W, Cin, Cout, k, stride, use_res        128-byte K-steps, tile
+    (1, 80, 80, 32, 64, 4, 1, False),      # stem: 8 steps, 32-channel tiles (the Cout = 64 row permutation)
+    (1, 80, 80, 64, 128, 3, 2, False),     # encodeA.1: 9 steps (the waves get 3 / 2 / 2 / 2)
+    (1, 40, 40, 128, 128, 3, 1, True),     # 18 steps
+    (1, 40, 40, 256, 256, 3, 1, True),     # 36 steps
+    (1, 40, 40, 256, 512, 3, 2, False),    # encodeAB.2: 36 steps, 16-pixel tiles
+    (1, 20, 20, 512, 512, 3, 1, True),     # 72 steps
+    (1, 13, 7, 128, 128, 3, 1, True),      # M = 91: the last tile has 11 real pixels
+    (2, 400, 1, 512, 512, 1, 1, True),     # Linear layer, 8 steps
+    (1, 3, 1, 512, 1536, 1, 1, False),     # M = 3
+])
+def test_small_problem_kernel_matches_torch_and_its_first_version(shape):
+    """conv_smallx_kernel (weights in fragment order, pixels through a per-wave LDS-DMA ring, hand-counted vmcnt) against torch,
+    and BIT-identical to conv_smallm_kernel (input pixels global -> registers in operand shape, compiler-counted waits): same tiles,
+    same K split over the waves, same reduction order -- only the way the operands travel differs."""
+    NB, H, Wd, Cin, Cout, k, stride, use_res = shape
+    L = _lib.test_lib()
+    rng = np.random.default_rng(11)
+    x = rng.normal(size=(NB, H, Wd, Cin)).astype(np.float32)
+    w = (rng.normal(size=(Cout, Cin, k, k)) / np.sqrt(Cin * k * k)).astype(np.float32)
+    b = rng.normal(size=Cout).astype(np.float32)
+    pad = 2 if k == 4 else (k - 1) // 2
+    OH = H if k == 4 else (H + 2 * pad - k) // stride + 1
+    OW = Wd if k == 4 else (Wd + 2 * pad - k) // stride + 1
+    res = rng.normal(size=(NB, OH, OW, Cout)).astype(np.float32) if use_res else None
+    if k == 4:
+        xt = torch.nn.functional.pad(torch.from_numpy(_h(x)).permute(0, 3, 1, 2), (2, 1, 2, 1))
+        ref = torch.relu(torch.nn.functional.conv2d(xt, torch.from_numpy(_h(w)), torch.from_numpy(b))).permute(0, 2, 3, 1).numpy()
+    else:
+        ref = _conv_ref(x, w, b, stride, pad, True, res)
+    try:
+        L.fpt_set_smallm(2)       # small-problem kernel whatever the K length
+        got = _conv_hip(x, w, b, stride, pad, True, res)
+        L.fpt_set_smallm(3)       # its first version
+        first = _conv_hip(x, w, b, stride, pad, True, res)
+        L.fpt_set_smallm(0)       # the LDS-ring / split-K schedules
+        other = _conv_hip(x, w, b, stride, pad, True, res)
+    finally:
+        L.fpt_set_smallm(1)
+    np.testing.assert_allclose(got, ref, rtol=2e-3, atol=2e-3)
+    np.testing.assert_array_equal(got, first)
+    np.testing.assert_allclose(got, other, rtol=2e-3, atol=2e-3)
+
+
 @pytest.mark.parametrize("rows,Cout,relu,use_res", [(66001, 512, True, True), (11111, 1536, False, False)])
 def test_linear_layers_two_workgroups_per_cu_kernel(rows, Cout, relu, use_res):
     """gemm_k32_kernel (Linear layers with >= 512 tiles): ragged last tile, residual + ReLU epilogue, both n-tile counts"""
