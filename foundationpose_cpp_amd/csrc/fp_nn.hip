@@ -1534,7 +1534,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const ConvParams p) {
 #pragma unroll
       for (int ks = 0; ks < 2; ks++, s++) {
         // W(s) (and, on a chunk's first step, the halo tile) landed; everyone finished reading step s-1
-        if ((tap == 0 && ks == 0) || s == S - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (((tap == 0 && ks == 0) && (!(ABL & 16) || s == 0)) || s == S - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         if (!(ABL & 1) || (tap == 0 && ks == 0)) __builtin_amdgcn_s_barrier();
         // s_barrier is IntrNoMem for the compiler: without this fence the fragment loads below may be placed ABOVE the
@@ -1544,7 +1544,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const ConvParams p) {
         if (s + 2 < S) issue_w(s + 2);
         const unsigned char *xs = smem + pix_off + (((ks * 4 + kg) ^ g) << 4);
         const unsigned char *ws = smem + wfo + (s % NWST) * WST;
-        if constexpr (ABL == 0) {  // (any ablation flag, e.g. 32: the round-1 schedule -- two halves of 5 fragments)
+        if constexpr ((ABL & ~16) == 0) {  // (any ablation flag but 16, e.g. 32: the round-1 schedule -- two halves of 5 fragments; 16: the halo tile is never reloaded)
           // X fragments in four groups (3,2,3,2 of MI = 10) through two small register sets: the LDS reads of group q+1 are in
           // flight while the MFMAs of group q issue, so only the first group of a K-step waits for the LDS with the matrix pipe idle
           static_assert(MI == 10, "group split written for 10 pixel fragments");
@@ -1577,7 +1577,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const ConvParams p) {
 #pragma unroll
           for (int i = 0; i < 2; i++) xb[i] = *reinterpret_cast<const i4 *>(xs + (8 + i) * 512);
           __builtin_amdgcn_sched_barrier(0);
-          if (tap == 8 && ks == 1 && ch + 1 < nch) {  // last reads of this chunk's halo tile are issued: refill it under the MFMAs
+          if (tap == 8 && ks == 1 && ch + 1 < nch && !(ABL & 16)) {  // last reads of this chunk's halo tile are issued: refill it under the MFMAs
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
@@ -3955,6 +3955,7 @@ static int run_conv_dt(const Ctx &c, const char *tag, const ConvLayer &L, ConvPa
       if (DT == DT_F16 && g_conv_ablate == 1) { FP_LAUNCH((conv_halo_kernel<40, 1, DT_F16>), grid, dim3(256), LDS_HALO40, c.s, p); return 0; }
       if (DT == DT_F16 && g_conv_ablate == 2) { FP_LAUNCH((conv_halo_kernel<40, 2, DT_F16>), grid, dim3(256), LDS_HALO40, c.s, p); return 0; }
       if (DT == DT_F16 && g_conv_ablate == 8) { FP_LAUNCH((conv_halo_kernel<40, 8, DT_F16>), grid, dim3(256), LDS_HALO40, c.s, p); return 0; }
+      if (DT == DT_F16 && g_conv_ablate == 16) { FP_LAUNCH((conv_halo_kernel<40, 16, DT_F16>), grid, dim3(256), LDS_HALO40, c.s, p); return 0; }
       if (DT == DT_F16 && g_conv_ablate == 32) { FP_LAUNCH((conv_halo_kernel<40, 32, DT_F16>), grid, dim3(256), LDS_HALO40, c.s, p); return 0; }
 #endif
       FP_LAUNCH((conv_halo_kernel<40, 0, DT>), grid, dim3(256), LDS_HALO40, c.s, p);

@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--ablate", type=int, default=0)
     ap.add_argument("--only", default="")
     ap.add_argument("--clock", action="store_true")
+    ap.add_argument("--hook", nargs=2, action="append", default=[], metavar=("NAME", "VALUE"), help="test hook to set first, e.g. --hook fpt_set_halo2 0")
     ap.add_argument("--res", action="store_true", help="with a residual input (the second conv of a residual block)")
     ap.add_argument("--variant", type=int, default=0, help="0 auto, 1 = 128-px 2-stage kernel, 2 = 256-px 3-stage kernel")
     a = ap.parse_args()
@@ -37,6 +38,8 @@ def main():
     L = _lib.lib()
     L.fpt_set_conv_variant(a.variant)
     L.fpt_set_conv_ablate(a.ablate)
+    for name, value in a.hook:
+        getattr(L, name)(int(value))
     rng = np.random.default_rng(0)
     tot_ms = tot_fl = 0.0
     shapes = [sh for sh in SHAPES if not a.only or a.only in sh[0]]
