@@ -169,6 +169,24 @@ __device__ __forceinline__ void glds16_asm(const void *gsrc, unsigned lds_addr) 
                : "v"(gsrc), "s"(lds_addr)
                : "memory");
 }
+// FOUR consecutive 1 KB pieces with ONE M0 set-up: the instruction's immediate offset is added to the global address AND to the
+// LDS address, so a source that is stored in LDS order (pack_gemm_w) needs no per-piece address arithmetic and no per-piece
+// M0 save / set / restore.  The 4 KB land at lds_addr + lane*16 + {0, 1024, 2048, 3072}.
+__device__ __forceinline__ void glds16x2_asm(const void *gsrc, unsigned lds_addr) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\tglobal_load_lds_dwordx4 %1, off offset:1024\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(lds_addr)
+               : "memory");
+}
+__device__ __forceinline__ void glds16x4_asm(const void *gsrc, unsigned lds_addr) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\tglobal_load_lds_dwordx4 %1, off offset:1024\n\t"
+               "global_load_lds_dwordx4 %1, off offset:2048\n\tglobal_load_lds_dwordx4 %1, off offset:3072\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(lds_addr)
+               : "memory");
+}
 // the same with the non-temporal cache policy, for the input tiles of the resident-halo kernels (each tile is staged once per
 // 64-channel chunk by at most two workgroups).  A/B build switch FP_X_NT (tools/ab_xnt.sh), OFF: measured [r3] the halo layers move
 // by -4...+1 %, inside the run-to-run noise of a box (+-3 %); the same policy on the X tiles of conv_big_pp / gemm_k32, which other
@@ -192,6 +210,8 @@ struct ConvParams {
   const unsigned char *in;   // [NB, H+2*ipad, W+2*ipad, Cin]  (zero border of width ipad >= pad is physically present)
   const unsigned char *w;    // [Cout][K] in kernel K order (relayout_k), element type = the kernel's DT
   const unsigned char *wfrag;  // the same weights in MFMA-fragment order (fragment_order; conv_smallm_kernel only), or null
+  const unsigned char *wpack;  // the same weights in the LDS-stage order of gemm_k32_kernel (1x1 layers) / conv_halo_kernel (3x3) (pack_stage_w), or null
+  const unsigned char *wpack128;  // ... in conv_big_pp_kernel's stage order (pack_stage_w128), or null
   const float *bias;         // [Cout]
   const float *cscale;       // FP8 input: [Cout] activation scale * weight scale of the channel; null otherwise
   const unsigned char *res;  // optional residual [NB, OH+2*rpad, OW+2*rpad, res_ld], element type res_dt
@@ -1120,8 +1140,11 @@ __global__ __launch_bounds__(512, 2) void conv_big_pp_kernel(const ConvParams p)
 #pragma unroll
     for (int i = 0; i < 4; i++) glds16_asm(xb + xoff[i], xs + (wave * 4 + i) * 1024);
   };
+  // (ConvParams::wpack128, pack_stage_w128) this wave's 4 KB of every K-step as one run: one address + one M0 per stage
+  const unsigned char *wpk = p.wpack128 ? p.wpack128 + ((size_t)nt * (p.krow_b >> 7) * 8 + wave) * 4096 + lane * 16 : nullptr;
   auto stage_w = [&](int kt, int buf) {
     const unsigned ws = lds_base + buf * STAGE + XB;
+    if (wpk) { glds16x4_asm(wpk + (size_t)kt * 32768, ws + wave * 4096); return; }
     const unsigned char *wb = w_b + (size_t)kt * 128;
 #pragma unroll
     for (int i = 0; i < 4; i++) glds16_asm(wb + woffv[i], ws + (wave * 4 + i) * 1024);
@@ -1501,9 +1524,12 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const ConvParams p) {
   unsigned woff[2];
 #pragma unroll
   for (int i = 0; i < 2; i++) woff[i] = (unsigned)((n0 + (wave * 2 + i) * 16 + prow) * p.krow_b + gch * 16);
+  // (ConvParams::wpack, pack_stage_w) this wave's 2 KB of every K-step as one run: one address + one M0 per stage
+  const unsigned char *wpk = p.wpack ? p.wpack + ((size_t)nt * (p.krow_b >> 6) * 4 + wave) * 2048 + lane * 16 : nullptr;
   auto issue_w = [&](int st) {
-    const unsigned char *wb = w_b + (size_t)st * 64;
     const unsigned dst = w_lds + (st % NWST) * WST;
+    if (wpk) { glds16x2_asm(wpk + (size_t)st * 8192, dst + wave * 2048); return; }
+    const unsigned char *wb = w_b + (size_t)st * 64;
 #pragma unroll
     for (int i = 0; i < 2; i++) glds16_asm(wb + woff[i], dst + (wave * 2 + i) * 1024);
   };
@@ -2037,7 +2063,7 @@ __global__ __launch_bounds__(256, 2) void conv_s2_halo_kernel(const ConvParams p
 // workgroups per CU so one's prologue / epilogue runs under the other's MFMAs.  LDS rows are 64 bytes; the 16-byte
 // slot of (row, chunk) is chunk ^ f((row>>2)&3), f = {0,2,3,1} (conflict-free ds_read_b128 fragments).
 // -------------------------------------------------------------------------------------------------
-template <int ABL, int DT, bool LSTORE = false>  // timing ablations: 1 = no MFMAs, 2 = no loads after the first stage, 4 = no stores; LSTORE: epilogue through LDS
+template <int ABL, int DT, bool LSTORE = false, bool WPACK = false>  // timing ablations: 1 = no MFMAs, 2 = no loads after the first stage, 4 = no stores; LSTORE: epilogue through LDS; WPACK: weights from the stage-order copy (ConvParams::wpack)
 __global__ __launch_bounds__(256, 2) void gemm_k32_kernel(const ConvParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int BM = 128, BN = 256;
@@ -2072,13 +2098,19 @@ __global__ __launch_bounds__(256, 2) void gemm_k32_kernel(const ConvParams p) {
   }
 #pragma unroll
   for (int i = 0; i < 4; i++) woff[i] = (unsigned)((n0 + (wave * 4 + i) * 16 + prow) * p.krow_b + gch * 16);
+  // (WPACK) this wave's 4 KB of K-step 0; a K-step is 4 waves x 4 KB further
+  const unsigned char *wpk = WPACK ? p.wpack + ((size_t)nt * S * 4 + wave) * 4096 + lane * 16 : nullptr;
   auto issue = [&](int st) {
     const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + (st % NST) * STAGE);
     const unsigned char *xb = in_b + (size_t)st * 64, *wb = w_b + (size_t)st * 64;
 #pragma unroll
     for (int i = 0; i < 2; i++) glds16_asm(xb + xoff[i], dst + (wave * 2 + i) * 1024);
+    if constexpr (WPACK) {
+      glds16x4_asm(wpk + (size_t)st * 16384, dst + XST + wave * 4096);
+    } else {
 #pragma unroll
-    for (int i = 0; i < 4; i++) glds16_asm(wb + woff[i], dst + XST + (wave * 4 + i) * 1024);
+      for (int i = 0; i < 4; i++) glds16_asm(wb + woff[i], dst + XST + (wave * 4 + i) * 1024);
+    }
   };
 
   f4 acc[2][4][4];  // [64-channel block][16-channel tile][16-row tile]
@@ -3252,6 +3284,8 @@ static bool read_fpw(const char *path, std::map<std::string, HostTensor> &out, s
 struct ConvLayer {
   unsigned char *w = nullptr;  // kernel layout, element type dt
   unsigned char *wfrag = nullptr;  // 2-byte types: a second copy in MFMA-fragment order for conv_smallm_kernel (fragment_order)
+  unsigned char *wpack = nullptr;  // a copy in the LDS-stage order of gemm_k32_kernel (Linear layers) / conv_halo_kernel (3x3 layers) (pack_stage_w)
+  unsigned char *wpack128 = nullptr;  // 3x3 layers with Cout % 256 == 0: a copy in conv_big_pp_kernel's stage order (pack_stage_w128)
   float *bias = nullptr;
   float *wscale = nullptr;     // FP8: [Cout] per-output-channel weight scale (w_real = w_stored * wscale)
   float *cscale = nullptr;     // FP8: [Cout] input activation scale * wscale (net_set_fp8_scales)
@@ -3382,6 +3416,8 @@ static bool make_grouped(Net *net, const ConvLayer &a, const ConvLayer &b, ConvL
   g->w = w;
   g->bias = bias;
   g->wfrag = nullptr;
+  g->wpack = nullptr;   // (the grouped launch never runs on gemm_k32_kernel)
+  g->wpack128 = nullptr;
   if (a.wfrag && b.wfrag) {  // (a group's fragment-order copy has the size of its row-major copy: the same group stride serves both)
     unsigned char *wf = nullptr;
     if (hipMalloc((void **)&wf, 2 * nw) != hipSuccess) return false;
@@ -3446,6 +3482,44 @@ static std::vector<unsigned char> fragment_order(const std::vector<unsigned char
   return o;
 }
 
+// Stage order for the kernels that stream a [TILE rows][64 B] weight stage per K-step through LDS-DMA (gemm_k32_kernel: TILE = 256,
+// conv_halo_kernel: TILE = 128): the PW pieces (16 rows x 64 B each; lane -> row = lane >> 2, swizzled 16-byte chunk) wave `w` of a
+// workgroup stages for (row tile nt, 64-byte K-step st) are stored as ONE run at ((nt * S + st) * 4 + w) * PW KB -- the DMA then
+// needs one address and one M0 per PW pieces (glds16x4_asm / glds16x2_asm), and every fetched cache line is used whole.
+static std::vector<unsigned char> pack_stage_w(const std::vector<unsigned char> &w, int Cout, size_t row_bytes, int TILE) {
+  const size_t S = row_bytes / 64;
+  const int PW = TILE / 64;
+  std::vector<unsigned char> o(w.size());
+  for (size_t nt = 0; nt < (size_t)Cout / TILE; nt++)
+    for (size_t st = 0; st < S; st++)
+      for (int wv = 0; wv < 4; wv++)
+        for (int i = 0; i < PW; i++)
+          for (int l = 0; l < 64; l++) {
+            const int prow = l >> 2, gch = (l & 3) ^ ((0x78 >> (((prow >> 2) & 3) * 2)) & 3);
+            std::memcpy(&o[(((nt * S + st) * 4 + wv) * PW + i) * 1024 + (size_t)l * 16],
+                        &w[(nt * TILE + (size_t)(wv * PW + i) * 16 + prow) * row_bytes + st * 64 + (size_t)gch * 16], 16);
+          }
+  return o;
+}
+
+// The same for conv_big_pp_kernel (256-row tiles, 128-byte K-steps, 8 waves x 4 pieces of 8 rows x 128 B; lane -> row = lane >> 3,
+// 16-byte chunk (lane & 7) ^ row): wave `w`'s 4 KB of (row tile nt, K-step kt) at ((nt * KT + kt) * 8 + w) * 4096.  Byte-level, so
+// it serves the FP8 layers too.
+static std::vector<unsigned char> pack_stage_w128(const std::vector<unsigned char> &w, int Cout, size_t row_bytes) {
+  const size_t KT = row_bytes / 128;
+  std::vector<unsigned char> o(w.size());
+  for (size_t nt = 0; nt < (size_t)Cout / 256; nt++)
+    for (size_t kt = 0; kt < KT; kt++)
+      for (int wv = 0; wv < 8; wv++)
+        for (int i = 0; i < 4; i++)
+          for (int l = 0; l < 64; l++) {
+            const int srow = l >> 3, g = (l & 7) ^ srow;
+            std::memcpy(&o[(((nt * KT + kt) * 8 + wv) * 4 + i) * 1024 + (size_t)l * 16],
+                        &w[(nt * 256 + (size_t)(wv * 4 + i) * 8 + srow) * row_bytes + kt * 128 + (size_t)g * 16], 16);
+          }
+  return o;
+}
+
 // [Cout][KH][KW][Cin] f32 rows -> device layer of element type dt
 static bool finish_layer(Net *net, const std::vector<float> &rows_f32, const std::vector<float> &bias, int Cout, int ntaps, int Cin,
                          int dt, ConvLayer *L) {
@@ -3457,6 +3531,17 @@ static bool finish_layer(Net *net, const std::vector<float> &rows_f32, const std
   if (dt != DT_FP8 && ((size_t)K * es) % 128 == 0 && Cout % 16 == 0) {
     L->wfrag = upload(net, fragment_order(rows, Cout, (size_t)K * es));
     if (!L->wfrag) return false;
+  }
+  if (dt != DT_FP8 && ntaps == 1 && ((size_t)K * es) % 64 == 0 && Cout % 256 == 0) {
+    L->wpack = upload(net, pack_stage_w(rows, Cout, (size_t)K * es, 256));      // gemm_k32_kernel
+    if (!L->wpack) return false;
+  } else if (dt != DT_FP8 && ntaps == 9 && Cin % 64 == 0 && Cout % 128 == 0) {
+    L->wpack = upload(net, pack_stage_w(rows, Cout, (size_t)K * es, 128));      // conv_halo_kernel
+    if (!L->wpack) return false;
+  }
+  if (ntaps == 9 && ((size_t)K * es) % 128 == 0 && Cout % 256 == 0) {
+    L->wpack128 = upload(net, pack_stage_w128(rows, Cout, (size_t)K * es));
+    if (!L->wpack128) return false;
   }
   L->bias = upload(net, bias);
   L->dt = dt;
@@ -3775,6 +3860,9 @@ FP_HOOK g_smallm_maxkt = 80;   // conv_smallm_kernel takes layers with fewer 128
 FP_HOOK g_conv_lds_store = 0;  // conv_big_pp_kernel: epilogue stores staged through LDS (whole 128-byte lines per store instruction).  OFF: measured [r3] conv_512 3.205 -> 3.227 / 3.184 -> 3.180 ms, i.e. nothing -- the 256x256 tile's store burst is not bound by the store shape (unlike gemm_k32_kernel's, -6 %)
 FP_HOOK g_gemm_lds_store = 1;  // gemm_k32_kernel: output rows leave through LDS as whole 256-byte runs instead of 64-byte pieces per store instruction
 FP_HOOK g_smallm_maxt16 = 1024; // ... and with at most this many 16-pixel x 64-channel tiles (the grouped QKV of Track has 1200)
+FP_HOOK g_gemm_wpack = 1;      // gemm_k32_kernel streams its weights from the stage-order copy (one address + one M0 per four LDS-DMA pieces)
+FP_HOOK g_big_wpack = 1;       // conv_big_pp_kernel streams its weights from the stage-order copy
+FP_HOOK g_halo_wpack = 1;      // conv_halo_kernel streams its weights from the stage-order copy
 FP_HOOK g_smallx_pf = 0;       // A/B (test build): prefetch depth of conv_smallx_kernel<2,4> (4 or 2; 0 = the default 3)
 FP_HOOK g_smallm = 1;          // small problems (Track, a few objects) on conv_smallm_kernel: K split over the waves of a workgroup, no split-K slabs / reduce launch
 FP_HOOK g_att_variant = 1;     // 1 = attention32_kernel (8 = without the XCD remap); round-1 kernel: 2 remap + 16-B stores, 3 no XCD remap, 5 remap + 2-B stores, 7 neither
@@ -3931,7 +4019,8 @@ static int run_conv_dt(const Ctx &c, const char *tag, const ConvLayer &L, ConvPa
       if (DT == DT_F16 && g_gemm_kernel == 12) { FP_LAUNCH((gemm_k32_kernel<2, DT_F16>), grid, dim3(256), LDS_GEMM_K32, c.s, p); return 0; }
       if (DT == DT_F16 && g_gemm_kernel == 14) { FP_LAUNCH((gemm_k32_kernel<4, DT_F16>), grid, dim3(256), LDS_GEMM_K32, c.s, p); return 0; }
 #endif
-      if (g_gemm_lds_store) FP_LAUNCH((gemm_k32_kernel<0, DT, true>), grid, dim3(256), LDS_GEMM_K32, c.s, p);
+      if (g_gemm_lds_store && g_gemm_wpack && L.wpack) FP_LAUNCH((gemm_k32_kernel<0, DT, true, true>), grid, dim3(256), LDS_GEMM_K32, c.s, p);
+      else if (g_gemm_lds_store) FP_LAUNCH((gemm_k32_kernel<0, DT, true>), grid, dim3(256), LDS_GEMM_K32, c.s, p);
       else FP_LAUNCH((gemm_k32_kernel<0, DT>), grid, dim3(256), LDS_GEMM_K32, c.s, p);
       return 0;
     }
@@ -3958,6 +4047,7 @@ static int run_conv_dt(const Ctx &c, const char *tag, const ConvLayer &L, ConvPa
       if (DT == DT_F16 && g_conv_ablate == 16) { FP_LAUNCH((conv_halo_kernel<40, 16, DT_F16>), grid, dim3(256), LDS_HALO40, c.s, p); return 0; }
       if (DT == DT_F16 && g_conv_ablate == 32) { FP_LAUNCH((conv_halo_kernel<40, 32, DT_F16>), grid, dim3(256), LDS_HALO40, c.s, p); return 0; }
 #endif
+      if (!g_halo_wpack) p.wpack = nullptr;
       FP_LAUNCH((conv_halo_kernel<40, 0, DT>), grid, dim3(256), LDS_HALO40, c.s, p);
     } else {
       ProfScope ps(c.prof, c.s, (tg + "/conv_halo8_kernel").c_str(), flops, bytes);
@@ -4151,7 +4241,7 @@ static int run_conv(const Ctx &c, const char *tag, const ConvLayer &L, const Act
   p.res_shared = grp && grp->res_shared;
   p.grp_w_bytes = grp ? (unsigned)((size_t)L.Cout * L.KH * L.KW * L.Cin * es) : 0;
   FP_CHECK(!grp || (grp->rows % 128 == 0 && L.KH == 1 && L.KW == 1 && NB == 2 * grp->rows && L.dt != DT_FP8), "grouped launch: unsupported shape");
-  p.in = (const unsigned char *)in.p; p.w = L.w; p.wfrag = L.wfrag; p.bias = L.bias; p.cscale = L.dt == DT_FP8 ? L.cscale : nullptr;
+  p.in = (const unsigned char *)in.p; p.w = L.w; p.wfrag = L.wfrag; p.wpack = L.wpack; p.wpack128 = g_big_wpack ? L.wpack128 : nullptr; p.bias = L.bias; p.cscale = L.dt == DT_FP8 ? L.cscale : nullptr;
   p.res = res ? (const unsigned char *)res->p : nullptr; p.out = (unsigned char *)out.p;
   p.out_dt = out.dt; p.res_dt = res ? res->dt : out.dt;
   p.res_scale = res ? res->scale : 1.f;
@@ -4589,6 +4679,9 @@ void fpt_set_att_variant(int v) { fp::g_att_variant = v; }
 void fpt_set_smallm(int v) { fp::g_smallm = v; }
 void fpt_set_smallm_maxkt(int v) { fp::g_smallm_maxkt = v; }
 void fpt_set_smallx_pf(int v) { fp::g_smallx_pf = v; }
+void fpt_set_gemm_wpack(int v) { fp::g_gemm_wpack = v; }
+void fpt_set_halo_wpack(int v) { fp::g_halo_wpack = v; }
+void fpt_set_big_wpack(int v) { fp::g_big_wpack = v; }
 void fpt_set_smallm_maxt16(int v) { fp::g_smallm_maxt16 = v; }
 void fpt_set_gemm_lds_store(int v) { fp::g_gemm_lds_store = v; }
 void fpt_set_conv_lds_store(int v) { fp::g_conv_lds_store = v; }
