@@ -1735,7 +1735,10 @@ __global__ __launch_bounds__(256, 2) void conv_halo8_kernel(const ConvParams p) 
   unsigned woff[4];
 #pragma unroll
   for (int i = 0; i < 4; i++) woff[i] = (unsigned)((n0 + (wave * 4 + i) * 8 + srow) * p.krow_b + (((lane & 7) ^ srow) << 4));
+  // (ConvParams::wpack, pack_stage_w128) this wave's 4 KB of every K-step as one run: one address + one M0 per stage
+  const unsigned char *wpk = p.wpack ? p.wpack + ((size_t)nt * (p.krow_b >> 7) * 4 + wave) * 4096 + lane * 16 : nullptr;
   auto issue_w = [&](int st) {
+    if (wpk) { glds16x4_asm(wpk + (size_t)st * 16384, w_lds + wave * 4096); return; }
     const unsigned char *wb = w_b + (size_t)st * 128;
 #pragma unroll
     for (int i = 0; i < 4; i++) glds16_asm(wb + woff[i], w_lds + (wave * 4 + i) * 1024);
@@ -3502,20 +3505,20 @@ static std::vector<unsigned char> pack_stage_w(const std::vector<unsigned char> 
   return o;
 }
 
-// The same for conv_big_pp_kernel (256-row tiles, 128-byte K-steps, 8 waves x 4 pieces of 8 rows x 128 B; lane -> row = lane >> 3,
-// 16-byte chunk (lane & 7) ^ row): wave `w`'s 4 KB of (row tile nt, K-step kt) at ((nt * KT + kt) * 8 + w) * 4096.  Byte-level, so
-// it serves the FP8 layers too.
-static std::vector<unsigned char> pack_stage_w128(const std::vector<unsigned char> &w, int Cout, size_t row_bytes) {
+// The same for the kernels with 128-byte K-steps: conv_big_pp_kernel (TILE = 256 rows, NW = 8 waves) and the FP8 conv_halo8_kernel
+// (TILE = 128, NW = 4); 4 pieces of 8 rows x 128 B per wave, lane -> row = lane >> 3, 16-byte chunk (lane & 7) ^ row: wave `w`'s 4 KB
+// of (row tile nt, K-step kt) at ((nt * KT + kt) * NW + w) * 4096.  Byte-level, so it serves every element type.
+static std::vector<unsigned char> pack_stage_w128(const std::vector<unsigned char> &w, int Cout, size_t row_bytes, int TILE, int NW) {
   const size_t KT = row_bytes / 128;
   std::vector<unsigned char> o(w.size());
-  for (size_t nt = 0; nt < (size_t)Cout / 256; nt++)
+  for (size_t nt = 0; nt < (size_t)Cout / TILE; nt++)
     for (size_t kt = 0; kt < KT; kt++)
-      for (int wv = 0; wv < 8; wv++)
+      for (int wv = 0; wv < NW; wv++)
         for (int i = 0; i < 4; i++)
           for (int l = 0; l < 64; l++) {
             const int srow = l >> 3, g = (l & 7) ^ srow;
-            std::memcpy(&o[(((nt * KT + kt) * 8 + wv) * 4 + i) * 1024 + (size_t)l * 16],
-                        &w[(nt * 256 + (size_t)(wv * 4 + i) * 8 + srow) * row_bytes + kt * 128 + (size_t)g * 16], 16);
+            std::memcpy(&o[(((nt * KT + kt) * NW + wv) * 4 + i) * 1024 + (size_t)l * 16],
+                        &w[(nt * TILE + (size_t)(wv * 4 + i) * 8 + srow) * row_bytes + kt * 128 + (size_t)g * 16], 16);
           }
   return o;
 }
@@ -3540,8 +3543,12 @@ static bool finish_layer(Net *net, const std::vector<float> &rows_f32, const std
     if (!L->wpack) return false;
   }
   if (ntaps == 9 && ((size_t)K * es) % 128 == 0 && Cout % 256 == 0) {
-    L->wpack128 = upload(net, pack_stage_w128(rows, Cout, (size_t)K * es));
+    L->wpack128 = upload(net, pack_stage_w128(rows, Cout, (size_t)K * es, 256, 8));   // conv_big_pp_kernel
     if (!L->wpack128) return false;
+  }
+  if (dt == DT_FP8 && ntaps == 9 && ((size_t)K * es) % 128 == 0 && Cout % 128 == 0) {
+    L->wpack = upload(net, pack_stage_w128(rows, Cout, (size_t)K * es, 128, 4));      // conv_halo8_kernel
+    if (!L->wpack) return false;
   }
   L->bias = upload(net, bias);
   L->dt = dt;
@@ -4051,6 +4058,7 @@ static int run_conv_dt(const Ctx &c, const char *tag, const ConvLayer &L, ConvPa
       FP_LAUNCH((conv_halo_kernel<40, 0, DT>), grid, dim3(256), LDS_HALO40, c.s, p);
     } else {
       ProfScope ps(c.prof, c.s, (tg + "/conv_halo8_kernel").c_str(), flops, bytes);
+      if (!g_halo_wpack) p.wpack = nullptr;
       FP_LAUNCH((conv_halo8_kernel), grid, dim3(256), LDS_HALO8, c.s, p);
     }
     return 0;

@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--only", default="")
     ap.add_argument("--clock", action="store_true")
     ap.add_argument("--hook", nargs=2, action="append", default=[], metavar=("NAME", "VALUE"), help="test hook to set first, e.g. --hook fpt_set_halo2 0")
+    ap.add_argument("--fp8", action="store_true", help="e4m3 operands and output (scales 1/16)")
     ap.add_argument("--res", action="store_true", help="with a residual input (the second conv of a residual block)")
     ap.add_argument("--variant", type=int, default=0, help="0 auto, 1 = 128-px 2-stage kernel, 2 = 256-px 3-stage kernel")
     a = ap.parse_args()
@@ -56,6 +57,14 @@ def main():
         ms = C.c_float(0)
         p = lambda t: t.ctypes.data_as(C.c_void_p)  # noqa: E731
         res = rng.standard_normal(out.shape, dtype=np.float32) if a.res and Cin == Cout and stride == 1 else None
+        if a.fp8:
+            L.fpt_conv_dt.argtypes = [C.c_void_p] * 4 + [C.c_int] * 13 + [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float]
+            rc = L.fpt_conv_dt(p(x), p(w), p(b), p(res) if res is not None else None, NB, H, W, Cin, Cout, k, k, stride, pad, OH, OW, 1, 0, p(out), a.iters,
+                               C.byref(ms), 2, 2, 1 / 16, 1 / 16, 1 / 16)
+            assert rc == 0, _lib.last_error()
+            fl = 2.0 * NB * OH * OW * Cout * k * k * Cin
+            print(f"{name:22s} [fp8] M={NB * OH * OW:8d} K={k * k * Cin:5d} N={Cout:5d}  {ms.value * 1e3:9.1f} us  {fl / ms.value / 1e9:8.1f} TF/s")
+            continue
         rc = L.fpt_conv(p(x), p(w), p(b), p(res) if res is not None else None, NB, H, W, Cin, Cout, k, k, stride, pad, OH, OW, 1, 0, p(out), a.iters,
                         C.byref(ms))
         assert rc == 0, _lib.last_error()
