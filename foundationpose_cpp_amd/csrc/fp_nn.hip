@@ -1141,10 +1141,11 @@ __global__ __launch_bounds__(512, 2) void conv_big_pp_kernel(const ConvParams p)
     for (int i = 0; i < 4; i++) glds16_asm(xb + xoff[i], xs + (wave * 4 + i) * 1024);
   };
   // (ConvParams::wpack128, pack_stage_w128) this wave's 4 KB of every K-step as one run: one address + one M0 per stage
-  const unsigned char *wpk = p.wpack128 ? p.wpack128 + ((size_t)nt * (p.krow_b >> 7) * 8 + wave) * 4096 + lane * 16 : nullptr;
+  const bool packed = p.wpack128 != nullptr;   // (wave-uniform: a scalar branch)
+  const unsigned char *wpk = p.wpack128 + ((size_t)nt * (p.krow_b >> 7) * 8 + wave) * 4096 + lane * 16;
   auto stage_w = [&](int kt, int buf) {
     const unsigned ws = lds_base + buf * STAGE + XB;
-    if (wpk) { glds16x4_asm(wpk + (size_t)kt * 32768, ws + wave * 4096); return; }
+    if (packed) { glds16x4_asm(wpk + (size_t)kt * 32768, ws + wave * 4096); return; }
     const unsigned char *wb = w_b + (size_t)kt * 128;
 #pragma unroll
     for (int i = 0; i < 4; i++) glds16_asm(wb + woffv[i], ws + (wave * 4 + i) * 1024);
@@ -1525,10 +1526,11 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const ConvParams p) {
 #pragma unroll
   for (int i = 0; i < 2; i++) woff[i] = (unsigned)((n0 + (wave * 2 + i) * 16 + prow) * p.krow_b + gch * 16);
   // (ConvParams::wpack, pack_stage_w) this wave's 2 KB of every K-step as one run: one address + one M0 per stage
-  const unsigned char *wpk = p.wpack ? p.wpack + ((size_t)nt * (p.krow_b >> 6) * 4 + wave) * 2048 + lane * 16 : nullptr;
+  const bool packed = p.wpack != nullptr;   // (wave-uniform: a scalar branch)
+  const unsigned char *wpk = p.wpack + ((size_t)nt * (p.krow_b >> 6) * 4 + wave) * 2048 + lane * 16;
   auto issue_w = [&](int st) {
     const unsigned dst = w_lds + (st % NWST) * WST;
-    if (wpk) { glds16x2_asm(wpk + (size_t)st * 8192, dst + wave * 2048); return; }
+    if (packed) { glds16x2_asm(wpk + (size_t)st * 8192, dst + wave * 2048); return; }
     const unsigned char *wb = w_b + (size_t)st * 64;
 #pragma unroll
     for (int i = 0; i < 2; i++) glds16_asm(wb + woff[i], dst + (wave * 2 + i) * 1024);
@@ -1736,9 +1738,10 @@ __global__ __launch_bounds__(256, 2) void conv_halo8_kernel(const ConvParams p) 
 #pragma unroll
   for (int i = 0; i < 4; i++) woff[i] = (unsigned)((n0 + (wave * 4 + i) * 8 + srow) * p.krow_b + (((lane & 7) ^ srow) << 4));
   // (ConvParams::wpack, pack_stage_w128) this wave's 4 KB of every K-step as one run: one address + one M0 per stage
-  const unsigned char *wpk = p.wpack ? p.wpack + ((size_t)nt * (p.krow_b >> 7) * 4 + wave) * 4096 + lane * 16 : nullptr;
+  const bool packed = p.wpack != nullptr;   // (wave-uniform: a scalar branch)
+  const unsigned char *wpk = p.wpack + ((size_t)nt * (p.krow_b >> 7) * 4 + wave) * 4096 + lane * 16;
   auto issue_w = [&](int st) {
-    if (wpk) { glds16x4_asm(wpk + (size_t)st * 16384, w_lds + wave * 4096); return; }
+    if (packed) { glds16x4_asm(wpk + (size_t)st * 16384, w_lds + wave * 4096); return; }
     const unsigned char *wb = w_b + (size_t)st * 128;
 #pragma unroll
     for (int i = 0; i < 4; i++) glds16_asm(wb + woff[i], w_lds + (wave * 4 + i) * 1024);
