@@ -47,6 +47,11 @@ hipError_t memset_sync(void *dst, int value, size_t bytes) {
   return e != hipSuccess ? e : hipStreamSynchronize(s);
 }
 std::atomic<unsigned long> g_alloc_epoch{0};
+#ifdef FP_TEST_HOOKS
+static int g_vertex_crop = 1;   // A/B (fpt_set_vertex_crop): Track's crop warp inside the vertex launch
+#else
+static constexpr int g_vertex_crop = 1;
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // Profiler
@@ -360,6 +365,14 @@ static int render_and_crop(fp_model *m, Target *t, int N, float crop_ratio, OutM
     ProfScope ps(&m->prof, s, "pose_setup");
     launch_pose_setup(s, poses_src ? poses_src : m->poses_dev, N, m->K, m->H, m->W, crop_ratio, t->mesh.diameter, recs);
   }
+  if (out_a && out_b && N <= 4 && !m->prof.on && !dbg_tri && !dbg_rast && g_vertex_crop &&
+      launch_setup_vertex_crop(s, t->mesh, poses_src ? poses_src : m->poses_dev, N, m->K, m->H, m->W, crop_ratio, t->mesh.diameter, recs, m->clip,
+                               m->attr, m->fmad, m->frame_dev, n_crop, mode, out_b)) {
+    // tiny batches (Track): set-up + vertex stage + crop warp were ONE launch; the rasteriser follows
+    launch_raster_shade(s, t->mesh, recs, N, m->clip, m->attr, mode, out_a, nullptr, nullptr, m->fmad);
+    FP_HIP_OK(hipGetLastError());
+    return 0;
+  }
   if (out_a) {
     {   // pose set-up (crop window, bounding box, projection) is computed inside the vertex kernel: one launch less per render
       ProfScope ps(&m->prof, s, "vertex", 0, (double)N * t->mesh.V * 32.0 + t->mesh.V * 24.0);
@@ -485,6 +498,7 @@ static int caught_exception() noexcept {
 extern "C" {
 
 #ifdef FP_TEST_HOOKS
+void fpt_set_vertex_crop(int v) { g_vertex_crop = v; }
 // A/B hook: hipGraph replay of the Track / Register bodies on or off for one model
 int fpt_model_use_graphs(fp_model *m, int on) {
   m->use_graphs = on != 0;
@@ -985,11 +999,15 @@ static int refine_iteration(fp_model *m, Target *t, int N, bool shared_b, const 
   checkpoint(m, 2, m->attr, (size_t)N * t->mesh.V * 16);
   checkpoint(m, 3, m->nn_in, (size_t)N * FP_NN_IN_IMG_HALFS * 2);
   checkpoint(m, 4, m->nn_in + half, (size_t)(shared_b ? 1 : N) * FP_NN_IN_IMG_HALFS * 2);
-  if (refiner_forward(m->stream, &m->prof, m->refiner, m->ws, m->nn_in, N, m->trans_dev, m->rot_dev, shared_b ? 1 : 0))
+  // N == 1 (Track): the head kernel applies RefinePostProcess itself (one launch less); profiling / digests keep the stages apart
+  const PoseUpdateFuse fuse{m->poses_dev, t->mesh.diameter, poses_in, result_out};
+  bool fused = false;
+  if (refiner_forward(m->stream, &m->prof, m->refiner, m->ws, m->nn_in, N, m->trans_dev, m->rot_dev, shared_b ? 1 : 0,
+                      (N == 1 && !m->prof.on && !m->digests) ? &fuse : nullptr, &fused))
     return 1;
   checkpoint(m, 5, m->trans_dev, (size_t)N * 12);
   checkpoint(m, 6, m->rot_dev, (size_t)N * 12);
-  {
+  if (!fused) {
     ProfScope ps(&m->prof, m->stream, "pose_update");
     launch_pose_update(m->stream, m->poses_dev, m->trans_dev, m->rot_dev, N, t->mesh.diameter, poses_in, result_out);
   }

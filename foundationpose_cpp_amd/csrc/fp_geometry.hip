@@ -192,22 +192,10 @@ struct PoseSetupArgs {
   int img_h, img_w;
   float crop_ratio, diameter;
 };
-template <bool FMAD, bool SETUP>
-__global__ void vertex_kernel(const float *__restrict__ verts, const float *__restrict__ normals, int V,
-                              PoseRec *__restrict__ recs, float4 *__restrict__ clip, float4 *__restrict__ attr,
-                              float4 *__restrict__ dbg, const PoseSetupArgs sa) {
-  const int v = blockIdx.x * blockDim.x + threadIdx.x;
-  const int n = blockIdx.y;
-#ifdef FP_TEST_HOOKS
-  const unsigned long long t_begin = dbg ? wall_clock64() : 0ull;
-#endif
-  if (v >= V) return;
-  PoseRec own;
-  if constexpr (SETUP) {
-    make_pose_rec(sa.poses, n, sa.K, sa.img_h, sa.img_w, sa.crop_ratio, sa.diameter, own);
-    if (v == 0) recs[n] = own;
-  }
-  const PoseRec &rec = SETUP ? own : recs[n];
+// one vertex of hypothesis n under the record `rec`
+template <bool FMAD>
+__device__ __forceinline__ void vertex_body(const float *__restrict__ verts, const float *__restrict__ normals, int V, int v, int n, const PoseRec &rec,
+                                            float4 *__restrict__ clip, float4 *__restrict__ attr, float4 *__restrict__ dbg, unsigned long long t_begin) {
   const float *M = rec.M, *pose = rec.pose;
   float x = verts[v * 3], y = verts[v * 3 + 1], z = verts[v * 3 + 2];
   float tx = dot3<FMAD>(M[0], x, M[4], y, M[8], z) + M[12];
@@ -241,7 +229,30 @@ __global__ void vertex_kernel(const float *__restrict__ verts, const float *__re
     dbg[((size_t)n * V + v) * 3 + 1] = make_float4(ux, uy, uz, val);
     dbg[((size_t)n * V + v) * 3 + 2] = make_float4((float)(t_end - t_begin), __uint_as_float(hwid), __uint_as_float((unsigned)(t_begin & 0xffffffffu)), 0.f);
   }
+#else
+  (void)dbg; (void)t_begin;
 #endif
+}
+
+template <bool FMAD, bool SETUP>
+__global__ void vertex_kernel(const float *__restrict__ verts, const float *__restrict__ normals, int V,
+                              PoseRec *__restrict__ recs, float4 *__restrict__ clip, float4 *__restrict__ attr,
+                              float4 *__restrict__ dbg, const PoseSetupArgs sa) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n = blockIdx.y;
+#ifdef FP_TEST_HOOKS
+  const unsigned long long t_begin = dbg ? wall_clock64() : 0ull;
+#else
+  const unsigned long long t_begin = 0ull;
+#endif
+  if (v >= V) return;
+  PoseRec own;
+  if constexpr (SETUP) {
+    make_pose_rec(sa.poses, n, sa.K, sa.img_h, sa.img_w, sa.crop_ratio, sa.diameter, own);
+    if (v == 0) recs[n] = own;
+  }
+  const PoseRec &rec = SETUP ? own : recs[n];
+  vertex_body<FMAD>(verts, normals, V, v, n, rec, clip, attr, dbg, t_begin);
 }
 
 #ifdef FP_TEST_HOOKS
@@ -809,18 +820,13 @@ void launch_sampler(hipStream_t s, const float *filtered_depth, const uint8_t *m
 // crop / warp of the observed RGB-D frame
 // ---------------------------------------------------------------------------------------------
 
+// one output pixel i (0 .. 160*160) of the observed crop of hypothesis n under the record `rec`
 template <int MODE>
-__global__ __launch_bounds__(256) void crop_kernel(const FrameRef *__restrict__ frame,
-                                                   int H, int W, float fx, float fy, float cx, float cy,
-                                                   const PoseRec *__restrict__ recs, float downscale,
-                                                   void *__restrict__ out_all) {
-  const int n = blockIdx.y;
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= CROP * CROP) return;
+__device__ __forceinline__ void crop_body(const FrameRef *__restrict__ frame, int H, int W, float fx, float fy, float cx, float cy,
+                                          const PoseRec &rec, float downscale, void *__restrict__ out_all, int n, int i) {
   const uint8_t *__restrict__ rgb = frame->rgb;
   const float *__restrict__ depth = frame->depth;
   const int y = i / CROP, x = i - y * CROP;
-  const PoseRec &rec = recs[n];
   float sxf = rec.m0 * (float)x + rec.m2, syf = rec.m4 * (float)y + rec.m5;
   // degenerate hypotheses (tz ~ 0: a crop window of 1e13 pixels) give source coordinates far outside any image, or NaN; clamp them
   // to +-2^24 BEFORE the float->int conversions so that x0 + 1 / the pointer arithmetic below cannot overflow (values inside
@@ -864,6 +870,59 @@ __global__ __launch_bounds__(256) void crop_kernel(const FrameRef *__restrict__ 
   } else {
     reinterpret_cast<uint4 *>(out_all)[s2d_index((size_t)n, y, x)] = pack6<MODE>(o);
   }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void crop_kernel(const FrameRef *__restrict__ frame,
+                                                   int H, int W, float fx, float fy, float cx, float cy,
+                                                   const PoseRec *__restrict__ recs, float downscale,
+                                                   void *__restrict__ out_all) {
+  const int n = blockIdx.y;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= CROP * CROP) return;
+  crop_body<MODE>(frame, H, W, fx, fy, cx, cy, recs[n], downscale, out_all, n, i);
+}
+
+// Tiny batches (Track): pose set-up + vertex stage + observed-crop warp in ONE launch.  Blocks [0, nvb) of a hypothesis are the
+// vertex kernel's; blocks [nvb, nvb + 100) warp the crop -- they cannot wait for the record a vertex block writes, so they compute
+// it themselves (make_pose_rec: the same function on the same inputs, identical values).  One launch-floor kernel less per Track.
+template <bool FMAD, int MODE>
+__global__ __launch_bounds__(256) void vertex_crop_kernel(const float *__restrict__ verts, const float *__restrict__ normals, int V, int nvb,
+                                                          PoseRec *__restrict__ recs, float4 *__restrict__ clip, float4 *__restrict__ attr,
+                                                          const PoseSetupArgs sa, const FrameRef *__restrict__ frame, int n_crop,
+                                                          void *__restrict__ out_b) {
+  const int n = blockIdx.y;
+  PoseRec own;
+  if ((int)blockIdx.x < nvb) {
+    const int v = blockIdx.x * 256 + threadIdx.x;
+    if (v >= V) return;
+    make_pose_rec(sa.poses, n, sa.K, sa.img_h, sa.img_w, sa.crop_ratio, sa.diameter, own);
+    if (v == 0) recs[n] = own;
+    vertex_body<FMAD>(verts, normals, V, v, n, own, clip, attr, nullptr, 0ull);
+    return;
+  }
+  const int i = ((int)blockIdx.x - nvb) * 256 + threadIdx.x;
+  if (n >= n_crop || i >= CROP * CROP) return;
+  make_pose_rec(sa.poses, n, sa.K, sa.img_h, sa.img_w, sa.crop_ratio, sa.diameter, own);
+  crop_body<MODE>(frame, sa.img_h, sa.img_w, sa.K.k[0], sa.K.k[4], sa.K.k[2], sa.K.k[5], own, sa.diameter / 2, out_b, n, i);
+}
+
+// returns false when the combination is not instantiated (fp32 blobs): the caller then launches the two kernels
+bool launch_setup_vertex_crop(hipStream_t s, const DeviceMesh &m, const float *poses_dev, int N, const float *K9_host, int img_h, int img_w,
+                              float crop_ratio, float diameter, PoseRec *recs, float4 *clip, float4 *attr, bool fmad, const FrameRef *frame,
+                              int n_crop, OutMode mode, void *out_b) {
+  if (mode == OUT_F32X6) return false;
+  PoseSetupArgs sa;
+  sa.poses = poses_dev;
+  for (int i = 0; i < 9; i++) sa.K.k[i] = K9_host[i];
+  sa.img_h = img_h; sa.img_w = img_w; sa.crop_ratio = crop_ratio; sa.diameter = diameter;
+  const int nvb = (m.V + 255) / 256;
+  const dim3 grid(nvb + (CROP * CROP + 255) / 256, N);
+#define FP_VC(F, M) hipLaunchKernelGGL((vertex_crop_kernel<F, M>), grid, dim3(256), 0, s, m.verts, m.normals, m.V, nvb, recs, clip, attr, sa, frame, n_crop, out_b)
+  if (mode == OUT_BF16X8) { if (fmad) FP_VC(true, OUT_BF16X8); else FP_VC(false, OUT_BF16X8); }
+  else { if (fmad) FP_VC(true, OUT_F16X8); else FP_VC(false, OUT_F16X8); }
+#undef FP_VC
+  return true;
 }
 
 void launch_crop(hipStream_t s, const FrameRef *frame, int H, int W, const float *K, const PoseRec *recs,
@@ -970,35 +1029,7 @@ __global__ void pose_update_kernel(float *poses, const float *__restrict__ trans
                                    const float *poses_in, float *extra_out) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
-  const float NORM = 0.349065850398865f;
-  float P[16];
-  for (int k = 0; k < 16; k++) P[k] = poses_in[(size_t)i * 16 + k];
-  float td[3], v[3];
-  for (int k = 0; k < 3; k++) { td[k] = trans[i * 3 + k] * (diameter / 2); v[k] = tanhf(rot[i * 3 + k]) * NORM; }
-  float n2 = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
-  float ang = sqrtf(n2);
-  float ax[3] = {v[0], v[1], v[2]};
-  if (n2 > 0.0f) { ax[0] /= ang; ax[1] /= ang; ax[2] /= ang; }
-  float s = sinf(ang), c = cosf(ang);
-  float sa[3] = {s * ax[0], s * ax[1], s * ax[2]}, ca[3] = {(1.0f - c) * ax[0], (1.0f - c) * ax[1], (1.0f - c) * ax[2]};
-  float R[9], tmp;
-  tmp = ca[0] * ax[1]; R[1] = tmp - sa[2]; R[3] = tmp + sa[2];
-  tmp = ca[0] * ax[2]; R[2] = tmp + sa[1]; R[6] = tmp - sa[1];
-  tmp = ca[1] * ax[2]; R[5] = tmp - sa[0]; R[7] = tmp + sa[0];
-  R[0] = ca[0] * ax[0] + c; R[4] = ca[1] * ax[1] + c; R[8] = ca[2] * ax[2] + c;
-  float O[16];
-  for (int k = 0; k < 16; k++) O[k] = P[k];
-  O[12] = P[12] + td[0]; O[13] = P[13] + td[1]; O[14] = P[14] + td[2];
-  for (int r = 0; r < 3; r++)
-    for (int cc = 0; cc < 3; cc++) {
-      float sacc = R[0 * 3 + r] * P[cc * 4 + 0];
-      sacc = sacc + R[1 * 3 + r] * P[cc * 4 + 1];
-      sacc = sacc + R[2 * 3 + r] * P[cc * 4 + 2];
-      O[cc * 4 + r] = sacc;
-    }
-  for (int k = 0; k < 16; k++) poses[(size_t)i * 16 + k] = O[k];
-  if (extra_out)
-    for (int k = 0; k < 16; k++) extra_out[(size_t)i * 16 + k] = O[k];
+  pose_update_one(poses, trans, rot, i, diameter, poses_in, extra_out);
 }
 
 void launch_pose_update(hipStream_t s, float *poses, const float *trans, const float *rot, int N, float diameter, const float *poses_in,

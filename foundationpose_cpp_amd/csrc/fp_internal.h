@@ -121,6 +121,47 @@ void launch_vertex(hipStream_t s, const DeviceMesh &m, const PoseRec *recs, int 
 // the two above in ONE launch (recs is an output)
 void launch_setup_vertex(hipStream_t s, const DeviceMesh &m, const float *poses_dev, int N, const float *K9_host, int img_h, int img_w,
                          float crop_ratio, float diameter, PoseRec *recs, float4 *clip, float4 *attr, bool fmad);
+#ifdef __HIPCC__
+// RefinePostProcess for hypothesis i (foundationpose.cpp:360-406): one function for pose_update_kernel and for the Track head
+// kernel of fp_nn.hip that applies it in place (one launch less per frame); identical arithmetic in both.
+__device__ __forceinline__ void pose_update_one(float *poses, const float *__restrict__ trans, const float *__restrict__ rot, int i, float diameter,
+                                                const float *poses_in, float *extra_out) {
+  const float NORM = 0.349065850398865f;
+  float P[16];
+  for (int k = 0; k < 16; k++) P[k] = poses_in[(size_t)i * 16 + k];
+  float td[3], v[3];
+  for (int k = 0; k < 3; k++) { td[k] = trans[i * 3 + k] * (diameter / 2); v[k] = tanhf(rot[i * 3 + k]) * NORM; }
+  float n2 = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
+  float ang = sqrtf(n2);
+  float ax[3] = {v[0], v[1], v[2]};
+  if (n2 > 0.0f) { ax[0] /= ang; ax[1] /= ang; ax[2] /= ang; }
+  float s = sinf(ang), c = cosf(ang);
+  float sa[3] = {s * ax[0], s * ax[1], s * ax[2]}, ca[3] = {(1.0f - c) * ax[0], (1.0f - c) * ax[1], (1.0f - c) * ax[2]};
+  float R[9], tmp;
+  tmp = ca[0] * ax[1]; R[1] = tmp - sa[2]; R[3] = tmp + sa[2];
+  tmp = ca[0] * ax[2]; R[2] = tmp + sa[1]; R[6] = tmp - sa[1];
+  tmp = ca[1] * ax[2]; R[5] = tmp - sa[0]; R[7] = tmp + sa[0];
+  R[0] = ca[0] * ax[0] + c; R[4] = ca[1] * ax[1] + c; R[8] = ca[2] * ax[2] + c;
+  float O[16];
+  for (int k = 0; k < 16; k++) O[k] = P[k];
+  O[12] = P[12] + td[0]; O[13] = P[13] + td[1]; O[14] = P[14] + td[2];
+  for (int r = 0; r < 3; r++)
+    for (int cc = 0; cc < 3; cc++) {
+      float sacc = R[0 * 3 + r] * P[cc * 4 + 0];
+      sacc = sacc + R[1 * 3 + r] * P[cc * 4 + 1];
+      sacc = sacc + R[2 * 3 + r] * P[cc * 4 + 2];
+      O[cc * 4 + r] = sacc;
+    }
+  for (int k = 0; k < 16; k++) poses[(size_t)i * 16 + k] = O[k];
+  if (extra_out)
+    for (int k = 0; k < 16; k++) extra_out[(size_t)i * 16 + k] = O[k];
+}
+#endif
+struct FrameRef;
+// tiny batches: the same + the observed-crop warp of hypotheses [0, n_crop) in ONE launch (false: not available for this output mode)
+bool launch_setup_vertex_crop(hipStream_t s, const DeviceMesh &m, const float *poses_dev, int N, const float *K9_host, int img_h, int img_w,
+                              float crop_ratio, float diameter, PoseRec *recs, float4 *clip, float4 *attr, bool fmad, const FrameRef *frame,
+                              int n_crop, OutMode mode, void *out_b);
 void launch_raster_shade(hipStream_t s, const DeviceMesh &m, const PoseRec *recs, int N, const float4 *clip,
                          const float4 *attr, OutMode mode, void *out, int32_t *tri_id_dbg, float *rast_dbg, bool fmad);
 #ifdef FP_TEST_HOOKS

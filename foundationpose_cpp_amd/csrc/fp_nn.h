@@ -39,8 +39,17 @@ void nn_scratch_debug_info(const NNScratch *, const void **buf, size_t *bytes, c
 // (channels r,g,b,x,y,z,0,0) with a zero border of 2, rendered crops A in images [0,N), observed crops B in [N,2N).
 // Outputs are device pointers.
 // shared_b != 0: all N hypotheses share ONE observed crop, stored as image N of nn_in (Register's first refine iteration)
+// fuse (N == 1 only, may be null): the head kernel also applies RefinePostProcess to the pose -- one launch less per Track; the caller then
+// skips its pose_update launch when *fused_out is set
+struct PoseUpdateFuse {
+  float *poses;            // [16] updated in place (or from poses_in)
+  float diameter;
+  const float *poses_in;   // null = poses
+  float *extra_out;        // optional second copy of the result
+};
 int refiner_forward(hipStream_t s, Profiler *prof, const Net *net, NNScratch *ws, const void *nn_in, int N,
-                    float *trans_dev /*[N,3]*/, float *rot_dev /*[N,3]*/, int shared_b = 0);
+                    float *trans_dev /*[N,3]*/, float *rot_dev /*[N,3]*/, int shared_b = 0, const PoseUpdateFuse *fuse = nullptr,
+                    bool *fused_out = nullptr);
 int scorer_features(hipStream_t s, Profiler *prof, const Net *net, NNScratch *ws, const void *nn_in, int N,
                     float *feat_dev /*[N,512]*/);
 int scorer_head(hipStream_t s, Profiler *prof, const Net *net, NNScratch *ws, const float *feats_dev, int n_total,

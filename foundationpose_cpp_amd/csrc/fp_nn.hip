@@ -3225,6 +3225,26 @@ __global__ __launch_bounds__(256) void small_linear2_kernel(const SmallLinear2 a
 // cat[i][:, :, C:2C] = cat[0][:, :, C:2C] for i in 1..N-1 (bordered [N,HP,WP,2C] tensor, interior pixels only); CB = bytes
 // of C channels.  Used when every hypothesis shares one observed crop (Register's first refine iteration: the sampler
 // gives all 252 poses the same translation, foundationpose_sampling.cpp:388-391, so transf_input is identical for all of them).
+// Track's last kernel: both Linear(512,3) heads (waves 0..5: one output each, the same summation as small_linear2_kernel) and, once
+// they are stored, RefinePostProcess of the one hypothesis (pose_update_one) -- small_linear2_kernel + pose_update_kernel in one launch
+__global__ __launch_bounds__(384) void small_linear2_pose_kernel(const SmallLinear2 a, int C, const PoseUpdateFuse f) {
+  __shared__ float out[6];
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int h = wv / 3, o = wv - h * 3;
+  const float *x = a.x[h], *W = a.W[h];
+  float s = 0.f;
+  for (int c = lane; c < C; c += 64) s += x[c] * W[(size_t)o * C + c];
+#pragma unroll
+  for (int k = 32; k > 0; k >>= 1) s += __shfl_xor(s, k);
+  if (lane == 0) {
+    const float y = s + a.bias[h][o];
+    a.y[h][o] = y;
+    out[wv] = y;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) pose_update_one(f.poses, out, out + 3, 0, f.diameter, f.poses_in ? f.poses_in : f.poses, f.extra_out);
+}
+
 __global__ void broadcast_b_kernel(unsigned char *__restrict__ cat, int N, int HP, int WP, int H, int W, int pad, int CB) {
   const int chunks = CB / 16;
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -3870,6 +3890,7 @@ FP_HOOK g_smallm_maxkt = 80;   // conv_smallm_kernel takes layers with fewer 128
 FP_HOOK g_conv_lds_store = 0;  // conv_big_pp_kernel: epilogue stores staged through LDS (whole 128-byte lines per store instruction).  OFF: measured [r3] conv_512 3.205 -> 3.227 / 3.184 -> 3.180 ms, i.e. nothing -- the 256x256 tile's store burst is not bound by the store shape (unlike gemm_k32_kernel's, -6 %)
 FP_HOOK g_gemm_lds_store = 1;  // gemm_k32_kernel: output rows leave through LDS as whole 256-byte runs instead of 64-byte pieces per store instruction
 FP_HOOK g_smallm_maxt16 = 1024; // ... and with at most this many 16-pixel x 64-channel tiles (the grouped QKV of Track has 1200)
+FP_HOOK g_fuse_pose = 1;       // Track: both Linear(512,3) heads + RefinePostProcess in one kernel (small_linear2_pose_kernel)
 FP_HOOK g_gemm_wpack = 1;      // gemm_k32_kernel streams its weights from the stage-order copy (one address + one M0 per four LDS-DMA pieces)
 FP_HOOK g_big_wpack = 1;       // conv_big_pp_kernel streams its weights from the stage-order copy
 FP_HOOK g_halo_wpack = 1;      // conv_halo_kernel streams its weights from the stage-order copy
@@ -4501,7 +4522,8 @@ static int run_trunk(const Ctx &c, const Arena &a, const void *nn_in, int N, int
 }
 
 int refiner_forward(hipStream_t s, Profiler *prof, const Net *net, NNScratch *ws, const void *nn_in, int N,
-                    float *trans_dev, float *rot_dev, int shared_b) {
+                    float *trans_dev, float *rot_dev, int shared_b, const PoseUpdateFuse *fuse, bool *fused_out) {
+  if (fused_out) *fused_out = false;
   FP_CHECK(net && !net->scorer, "refiner_forward: wrong network");
   FP_CHECK(net_fp8_ready(net), "[FoundationPose] FP8 precision needs activation scales: call fp_calibrate_fp8 first");
   if (ensure_scratch(ws, N, s)) return 1;
@@ -4532,7 +4554,11 @@ int refiner_forward(hipStream_t s, Profiler *prof, const Net *net, NNScratch *ws
     {
       ProfScope ps(c.prof, c.s, "small_linear", 2.0 * 2 * T0.head.out * T0.head.in, 0);
       SmallLinear2 a{{ws->f32, ws->f32 + EMBED}, {T0.head.w, R0.head.w}, {T0.head.b, R0.head.b}, {trans_dev, rot_dev}};
-      hipLaunchKernelGGL(small_linear2_kernel, dim3((unsigned)((T0.head.out + 3) / 4), 2), dim3(256), 0, c.s, a, 1, T0.head.out, T0.head.in);
+      if (fuse && g_fuse_pose && T0.head.out == 3 && R0.head.out == 3) {
+        hipLaunchKernelGGL(small_linear2_pose_kernel, dim3(1), dim3(384), 0, c.s, a, T0.head.in, *fuse);
+        if (fused_out) *fused_out = true;
+      } else
+        hipLaunchKernelGGL(small_linear2_kernel, dim3((unsigned)((T0.head.out + 3) / 4), 2), dim3(256), 0, c.s, a, 1, T0.head.out, T0.head.in);
     }
     FP_HIP_OK(hipGetLastError());
     return 0;
@@ -4691,6 +4717,7 @@ void fpt_set_smallm(int v) { fp::g_smallm = v; }
 void fpt_set_smallm_maxkt(int v) { fp::g_smallm_maxkt = v; }
 void fpt_set_smallx_pf(int v) { fp::g_smallx_pf = v; }
 void fpt_set_gemm_wpack(int v) { fp::g_gemm_wpack = v; }
+void fpt_set_fuse_pose(int v) { fp::g_fuse_pose = v; }
 void fpt_set_halo_wpack(int v) { fp::g_halo_wpack = v; }
 void fpt_set_big_wpack(int v) { fp::g_big_wpack = v; }
 void fpt_set_smallm_maxt16(int v) { fp::g_smallm_maxt16 = v; }
