@@ -126,6 +126,9 @@ void launch_setup_vertex(hipStream_t s, const DeviceMesh &m, const float *poses_
 // kernel of fp_nn.hip that applies it in place (one launch less per frame); identical arithmetic in both.
 __device__ __forceinline__ void pose_update_one(float *poses, const float *__restrict__ trans, const float *__restrict__ rot, int i, float diameter,
                                                 const float *poses_in, float *extra_out) {
+  // fp_geometry.hip is compiled with -ffp-contract=off (the oracle's float model), fp_nn.hip is not: pin it
+  // here so that both translation units evaluate exactly the same operations
+#pragma clang fp contract(off)
   const float NORM = 0.349065850398865f;
   float P[16];
   for (int k = 0; k < 16; k++) P[k] = poses_in[(size_t)i * 16 + k];

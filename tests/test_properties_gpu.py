@@ -7,10 +7,14 @@ where running the CPU oracle + PyTorch-CPU networks would take minutes:
   * Register == the composition of the stage operators the reference's orchestrator calls
     (foundationpose.cpp:181-228), at N = 1008 and at 1280x720 with a textured and an untextured mesh.
 """
+import os
+
 import numpy as np
 import pytest
 
 from foundationpose_cpp_amd import FoundationPose, synthetic as syn, weights as W
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 
@@ -321,3 +325,46 @@ def test_two_models_stay_exact_while_foreign_kernels_share_the_gpu(wpaths, syn_m
     [m.close() for m in models]
     assert busy["iters"] > 20, "the foreign stream did not run alongside"
     assert not bad[0] and not bad[1], (len(bad[0]), len(bad[1]), bad[0][:5], bad[1][:5])
+
+
+_FUSION_SCRIPT = r"""
+import os, sys, tempfile
+import numpy as np
+import torch  # noqa: F401  (first: one HIP runtime)
+from foundationpose_cpp_amd import _lib
+_lib.use_test_lib()
+from foundationpose_cpp_amd import FoundationPose, synthetic as syn, weights as W
+L = _lib.lib()
+mesh = syn.make_mesh(); scene = syn.make_scene(mesh)
+d = tempfile.mkdtemp(); rp, sp = os.path.join(d, "r.fpw"), os.path.join(d, "s.fpw")
+W.pack_synthetic("refiner", rp); W.pack_synthetic("scorer", sp)
+hyp = syn.perturb_pose(scene.gt_pose)
+for vc in (0, 1):
+    for fu in (0, 1):
+        L.fpt_set_vertex_crop(vc); L.fpt_set_fuse_pose(fu)
+        m = FoundationPose(mesh, scene.K, rp, sp)
+        poses = []
+        for it in range(4):          # eager call, graph capture, graph replays
+            ok, pose = m.Track(scene.rgb, scene.depth, hyp, mesh.name, refine_itr=2 if it == 3 else 1)
+            assert ok
+            poses.append(pose)
+        m.close()
+        print("POSES", vc, fu, " ".join(np.asarray(poses, np.float32).tobytes().hex() for _ in (0,)))
+"""
+
+
+@pytest.mark.gpu
+def test_track_launch_fusions_do_not_change_a_bit(tmp_path):
+    """Track's fused launches (pose set-up + vertex stage + crop warp in one kernel; both Linear(512,3) heads + RefinePostProcess in
+    one kernel) against the separate kernels they replace, in the test build where both forms exist: every pose of an eager call, a
+    graph capture, a replay and a two-iteration Track is bit-identical in all four combinations."""
+    import subprocess
+    import sys
+    script = tmp_path / "fusions.py"
+    script.write_text(_FUSION_SCRIPT)
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    res = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600, env=env)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l.split() for l in res.stdout.splitlines() if l.startswith("POSES")]
+    assert len(lines) == 4
+    assert len({l[3] for l in lines}) == 1, [(l[1], l[2]) for l in lines]
