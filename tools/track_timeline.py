@@ -8,10 +8,11 @@ rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
 its, cur = [], None
 for r in rows:
     n = r["Kernel_Name"]
-    if "vertex_kernel" in n and cur is None: cur = [r]
+    # one Track replay: from the (fused) vertex kernel to the kernel that updates the pose
+    if "vertex_crop_kernel" in n and cur is None: cur = [r]
     elif cur is not None:
         cur.append(r)
-        if "pose_update" in n: its.append(cur); cur = None
+        if "small_linear2_pose_kernel" in n: its.append(cur); cur = None
 it = its[len(its) // 2]
 t0 = prev = int(it[0]["Start_Timestamp"])
 agg = {}
