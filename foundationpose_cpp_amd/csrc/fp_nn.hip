@@ -5045,6 +5045,42 @@ float fpt_attention_bench(int B, int T, int iters, int variant) {
 }
 
 // sustained dense fp16 MFMA rate in TFLOP/s (whole chip, `waves_per_simd` waves on every SIMD); negative on failure
+// the same with v_mfma_f32_32x32x16_f16 (4 independent 32x32 accumulators): half the instructions and half the operand reads per flop
+__global__ __launch_bounds__(256) void mfma_peak32_kernel(float *out, int iters, int zero_operands, unsigned long long *clk) {
+  using fp::h8;
+  typedef float f16v __attribute__((ext_vector_type(16)));
+  const int lane = threadIdx.x & 63;
+  h8 a, b;
+  unsigned st = 2654435761u * (unsigned)(blockIdx.x * 256 + threadIdx.x + 1);
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    st = st * 1664525u + 1013904223u;
+    a[i] = (_Float16)(((st >> 8) & 0xffff) / 65536.0f - 0.5f);
+    st = st * 1664525u + 1013904223u;
+    b[i] = (_Float16)(((st >> 8) & 0xffff) / 65536.0f - 0.5f);
+    if (zero_operands) { a[i] = 0; b[i] = 0; }
+  }
+  unsigned long long c0 = 0, w0 = 0;
+  if (clk && blockIdx.x == 0 && threadIdx.x == 0) { c0 = __builtin_readcyclecounter(); w0 = wall_clock64(); }
+  f16v acc[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++)
+#pragma unroll
+    for (int e = 0; e < 16; e++) acc[j][e] = 0.f;
+  for (int i = 0; i < iters; i++) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc[j]) : "v"(a), "v"(b));
+  }
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+  float sum = 0.f;
+#pragma unroll
+  for (int j = 0; j < 4; j++)
+#pragma unroll
+    for (int e = 0; e < 16; e++) sum += acc[j][e];
+  if (sum == 12345.678f) out[lane] = sum;
+  if (clk && blockIdx.x == 0 && threadIdx.x == 0) { clk[0] = __builtin_readcyclecounter() - c0; clk[1] = wall_clock64() - w0; }
+}
+
 float fpt_mfma_peak(int iters, int waves_per_simd, int zero_operands, double *mhz) {
   hipStream_t s;
   if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return -1.f;
@@ -5057,9 +5093,13 @@ float fpt_mfma_peak(int iters, int waves_per_simd, int zero_operands, double *mh
   DevBuf<unsigned long long> clk(2);
   hipEvent_t e0, e1;
   if (!out.p || !clk.p || hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return -1.f;
-  hipLaunchKernelGGL(mfma_peak_kernel, dim3(wgs), dim3(256), 0, s, out.p, iters / 4, zero_operands, (unsigned long long *)nullptr);  // warm-up / clock ramp
+  const bool big = (zero_operands & 2) != 0;   // bit 1: the 32x32x16 form (same flops per iteration: 4 x 32768 = 8 x 16384)
+  zero_operands &= 1;
+  if (big) hipLaunchKernelGGL(mfma_peak32_kernel, dim3(wgs), dim3(256), 0, s, out.p, iters / 4, zero_operands, (unsigned long long *)nullptr);
+  else hipLaunchKernelGGL(mfma_peak_kernel, dim3(wgs), dim3(256), 0, s, out.p, iters / 4, zero_operands, (unsigned long long *)nullptr);  // warm-up / clock ramp
   (void)hipEventRecord(e0, s);
-  hipLaunchKernelGGL(mfma_peak_kernel, dim3(wgs), dim3(256), 0, s, out.p, iters, zero_operands, clk.p);
+  if (big) hipLaunchKernelGGL(mfma_peak32_kernel, dim3(wgs), dim3(256), 0, s, out.p, iters, zero_operands, clk.p);
+  else hipLaunchKernelGGL(mfma_peak_kernel, dim3(wgs), dim3(256), 0, s, out.p, iters, zero_operands, clk.p);
   (void)hipEventRecord(e1, s);
   float ms = -1.f;
   const bool ok = hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(&ms, e0, e1) == hipSuccess;

@@ -10,11 +10,11 @@ _lib.use_test_lib()
 L = _lib.lib()
 L.fpt_mfma_peak.restype = C.c_float
 L.fpt_mfma_peak.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
-for zero in (0, 1):
+for zero in (0, 1, 2):   # 2 = random operands, v_mfma_f32_32x32x16_f16 instead of 16x16x32
     for w in (1, 2, 4, 8):
         out = []
         for _ in range(3):
             mhz = C.c_double(0)
             v = L.fpt_mfma_peak(200000, w, zero, C.byref(mhz))
             out.append(f"{v:.0f} TF/s @ {mhz.value:.0f} MHz")
-        print(f"{'zero' if zero else 'random'} operands, waves/SIMD {w}: " + "   ".join(out))
+        print(f"{ {0: 'random', 1: 'zero', 2: 'random, 32x32x16'}[zero] } operands, waves/SIMD {w}: " + "   ".join(out))
