@@ -212,6 +212,7 @@ struct ConvParams {
   const unsigned char *wfrag;  // the same weights in MFMA-fragment order (fragment_order; conv_smallm_kernel only), or null
   const unsigned char *wpack;  // the same weights in the LDS-stage order of gemm_k32_kernel (1x1 layers) / conv_halo_kernel (3x3) (pack_stage_w), or null
   const unsigned char *wpack128;  // ... in conv_big_pp_kernel's stage order (pack_stage_w128), or null
+  const unsigned char *wdeep;     // ... in conv_deep_kernel's stage order (pack_stage_w128 with 128-row tiles, 4 waves), or null
   const float *bias;         // [Cout]
   const float *cscale;       // FP8 input: [Cout] activation scale * weight scale of the channel; null otherwise
   const unsigned char *res;  // optional residual [NB, OH+2*rpad, OW+2*rpad, res_ld], element type res_dt
@@ -2274,6 +2275,10 @@ __global__ __launch_bounds__(256, 2) void conv_deep_kernel(const ConvParams p) {
   for (int i = 0; i < WP; i++) woff[i] = (unsigned)((n0 + (wave * WP + i) * 8 + srow) * p.krow_b + g * 16);
   const unsigned char *in_b = p.in;
   const unsigned char *w_b = p.w + (p.grp_rows ? (size_t)(m0 / p.grp_rows) * p.grp_w_bytes : 0);
+  // (ConvParams::wdeep, pack_stage_w128) this wave's 4 KB of every K-step as one run: one address + one M0 per stage -- in this
+  // kernel (8 MFMAs per wave and K-step at BM = 64) the LDS-DMA issue IS the K-step time
+  const bool packed = p.wdeep != nullptr;   // (wave-uniform: a scalar branch)
+  const unsigned char *wpk = p.wdeep + (p.grp_rows ? (size_t)(m0 / p.grp_rows) * p.grp_w_bytes : 0) + ((size_t)nt * (p.krow_b >> 7) * 4 + wave) * 4096 + lane * 16;
   const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
   auto issue = [&](int kt) {
     const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + (kt % NST) * STAGE);
@@ -2281,6 +2286,7 @@ __global__ __launch_bounds__(256, 2) void conv_deep_kernel(const ConvParams p) {
     const unsigned char *wb = w_b + (size_t)kt * 128;
 #pragma unroll
     for (int i = 0; i < XP; i++) glds16_asm(xb + xoff[i], dst + (wave * XP + i) * 1024);
+    if (packed) { glds16x4_asm(wpk + (size_t)kt * 16384, dst + XB + wave * 4096); return; }
 #pragma unroll
     for (int i = 0; i < WP; i++) glds16_asm(wb + woff[i], dst + XB + (wave * WP + i) * 1024);
   };
@@ -3312,6 +3318,7 @@ struct ConvLayer {
   unsigned char *wfrag = nullptr;  // 2-byte types: a second copy in MFMA-fragment order for conv_smallm_kernel (fragment_order)
   unsigned char *wpack = nullptr;  // a copy in the LDS-stage order of gemm_k32_kernel (Linear layers) / conv_halo_kernel (3x3 layers) (pack_stage_w)
   unsigned char *wpack128 = nullptr;  // 3x3 layers with Cout % 256 == 0: a copy in conv_big_pp_kernel's stage order (pack_stage_w128)
+  unsigned char *wdeep = nullptr;     // Cout % 128 == 0, 128-byte K-steps: a copy in conv_deep_kernel's stage order (FP8 3x3 layers: = wpack, the same order)
   float *bias = nullptr;
   float *wscale = nullptr;     // FP8: [Cout] per-output-channel weight scale (w_real = w_stored * wscale)
   float *cscale = nullptr;     // FP8: [Cout] input activation scale * wscale (net_set_fp8_scales)
@@ -3451,6 +3458,14 @@ static bool make_grouped(Net *net, const ConvLayer &a, const ConvLayer &b, ConvL
     if (fp::memcpy_sync(wf, a.wfrag, nw, hipMemcpyDeviceToDevice) != hipSuccess || fp::memcpy_sync(wf + nw, b.wfrag, nw, hipMemcpyDeviceToDevice) != hipSuccess) return false;
     g->wfrag = wf;
   }
+  g->wdeep = nullptr;
+  if (a.wdeep && b.wdeep) {
+    unsigned char *wd = nullptr;
+    if (hipMalloc((void **)&wd, 2 * nw) != hipSuccess) return false;
+    net->allocs.push_back(wd);
+    if (fp::memcpy_sync(wd, a.wdeep, nw, hipMemcpyDeviceToDevice) != hipSuccess || fp::memcpy_sync(wd + nw, b.wdeep, nw, hipMemcpyDeviceToDevice) != hipSuccess) return false;
+    g->wdeep = wd;
+  }
   return true;
 }
 
@@ -3572,6 +3587,10 @@ static bool finish_layer(Net *net, const std::vector<float> &rows_f32, const std
   if (dt == DT_FP8 && ntaps == 9 && ((size_t)K * es) % 128 == 0 && Cout % 128 == 0) {
     L->wpack = upload(net, pack_stage_w128(rows, Cout, (size_t)K * es, 128, 4));      // conv_halo8_kernel
     if (!L->wpack) return false;
+    L->wdeep = L->wpack;                                                             // conv_deep_kernel: the same order
+  } else if (((size_t)K * es) % 128 == 0 && Cout % 128 == 0) {
+    L->wdeep = upload(net, pack_stage_w128(rows, Cout, (size_t)K * es, 128, 4));      // conv_deep_kernel
+    if (!L->wdeep) return false;
   }
   L->bias = upload(net, bias);
   L->dt = dt;
@@ -3892,6 +3911,7 @@ FP_HOOK g_gemm_lds_store = 1;  // gemm_k32_kernel: output rows leave through LDS
 FP_HOOK g_smallm_maxt16 = 1024; // ... and with at most this many 16-pixel x 64-channel tiles (the grouped QKV of Track has 1200)
 FP_HOOK g_fuse_pose = 1;       // Track: both Linear(512,3) heads + RefinePostProcess in one kernel (small_linear2_pose_kernel)
 FP_HOOK g_gemm_wpack = 1;      // gemm_k32_kernel streams its weights from the stage-order copy (one address + one M0 per four LDS-DMA pieces)
+FP_HOOK g_deep_wpack = 1;      // conv_deep_kernel streams its weights from the stage-order copy
 FP_HOOK g_big_wpack = 1;       // conv_big_pp_kernel streams its weights from the stage-order copy
 FP_HOOK g_halo_wpack = 1;      // conv_halo_kernel streams its weights from the stage-order copy
 FP_HOOK g_smallx_pf = 0;       // A/B (test build): prefetch depth of conv_smallx_kernel<2,4> (4 or 2; 0 = the default 3)
@@ -4273,7 +4293,7 @@ static int run_conv(const Ctx &c, const char *tag, const ConvLayer &L, const Act
   p.res_shared = grp && grp->res_shared;
   p.grp_w_bytes = grp ? (unsigned)((size_t)L.Cout * L.KH * L.KW * L.Cin * es) : 0;
   FP_CHECK(!grp || (grp->rows % 128 == 0 && L.KH == 1 && L.KW == 1 && NB == 2 * grp->rows && L.dt != DT_FP8), "grouped launch: unsupported shape");
-  p.in = (const unsigned char *)in.p; p.w = L.w; p.wfrag = L.wfrag; p.wpack = L.wpack; p.wpack128 = g_big_wpack ? L.wpack128 : nullptr; p.bias = L.bias; p.cscale = L.dt == DT_FP8 ? L.cscale : nullptr;
+  p.in = (const unsigned char *)in.p; p.w = L.w; p.wfrag = L.wfrag; p.wpack = L.wpack; p.wpack128 = g_big_wpack ? L.wpack128 : nullptr; p.wdeep = g_deep_wpack ? L.wdeep : nullptr; p.bias = L.bias; p.cscale = L.dt == DT_FP8 ? L.cscale : nullptr;
   p.res = res ? (const unsigned char *)res->p : nullptr; p.out = (unsigned char *)out.p;
   p.out_dt = out.dt; p.res_dt = res ? res->dt : out.dt;
   p.res_scale = res ? res->scale : 1.f;
@@ -4720,6 +4740,7 @@ void fpt_set_gemm_wpack(int v) { fp::g_gemm_wpack = v; }
 void fpt_set_fuse_pose(int v) { fp::g_fuse_pose = v; }
 void fpt_set_halo_wpack(int v) { fp::g_halo_wpack = v; }
 void fpt_set_big_wpack(int v) { fp::g_big_wpack = v; }
+void fpt_set_deep_wpack(int v) { fp::g_deep_wpack = v; }
 void fpt_set_smallm_maxt16(int v) { fp::g_smallm_maxt16 = v; }
 void fpt_set_gemm_lds_store(int v) { fp::g_gemm_lds_store = v; }
 void fpt_set_conv_lds_store(int v) { fp::g_conv_lds_store = v; }
