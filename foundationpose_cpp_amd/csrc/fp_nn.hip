@@ -989,6 +989,9 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvParams p) {
   const unsigned char *w_b = p.w;
   const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
 
+  // (ConvParams::wdeep: the 16 pieces of a 128-row x 128-byte stage in piece order -- this wave's two are one 2 KB run)
+  const bool packed = BN == 128 && p.wdeep != nullptr;   // (wave-uniform: a scalar branch)
+  const unsigned char *wpk = p.wdeep + ((size_t)nt * (p.krow_b >> 7) * 16 + wave * 2) * 1024 + lane * 16;
   auto stage = [&](int kt, int buf) {
     const unsigned xs = lds_base + buf * STAGE;
     const unsigned ws = xs + XB;
@@ -996,6 +999,7 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvParams p) {
     const unsigned char *wb = w_b + (size_t)kt * 128;
 #pragma unroll
     for (int i = 0; i < 4; i++) glds16_asm(xb + xoff[i], xs + (wave * 4 + i) * 1024);
+    if (packed) { glds16x2_asm(wpk + (size_t)kt * 16384, ws + wave * 2048); return; }
 #pragma unroll
     for (int i = 0; i < WPIECES; i++) glds16_asm(wb + woffv[i], ws + (wave * WPIECES + i) * 1024);
   };
