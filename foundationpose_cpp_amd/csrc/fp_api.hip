@@ -48,6 +48,11 @@ hipError_t memset_sync(void *dst, int value, size_t bytes) {
 }
 std::atomic<unsigned long> g_alloc_epoch{0};
 #ifdef FP_TEST_HOOKS
+static int g_upload_cols = 1;   // A/B (fpt_set_upload_cols): Track from host frames uploads the crop window's rectangle, not whole rows
+#else
+static constexpr int g_upload_cols = 1;
+#endif
+#ifdef FP_TEST_HOOKS
 static int g_vertex_crop = 1;   // A/B (fpt_set_vertex_crop): Track's crop warp inside the vertex launch
 #else
 static constexpr int g_vertex_crop = 1;
@@ -401,7 +406,7 @@ static void checkpoint(fp_model *m, int slot, const void *buf, size_t bytes) {
   if (e != hipSuccess) std::fprintf(stderr, "checkpoint %d (%p, %zu B): %s\n", slot, buf, bytes, hipGetErrorString(e));
 }
 
-static int upload_frame_async(fp_model *m, const void *rgb, const void *depth, int memspace, int H, int W, int row0 = 0, int row1 = -1);
+static int upload_frame_async(fp_model *m, const void *rgb, const void *depth, int memspace, int H, int W, int row0 = 0, int row1 = -1, int col0 = 0, int col1 = -1);
 static int set_rotation_grid(fp_model *m, int steps);
 
 static void drop_graph(fp_model::GraphSlot &g) {
@@ -499,6 +504,7 @@ extern "C" {
 
 #ifdef FP_TEST_HOOKS
 void fpt_set_vertex_crop(int v) { g_vertex_crop = v; }
+void fpt_set_upload_cols(int v) { g_upload_cols = v; }
 // A/B hook: hipGraph replay of the Track / Register bodies on or off for one model
 int fpt_model_use_graphs(fp_model *m, int on) {
   m->use_graphs = on != 0;
@@ -715,7 +721,7 @@ int fp_synchronize(fp_model *m) try {
 // asynchronous: the caller of this helper synchronises m->stream before the host frame can go away
 // row0 / row1 (host frames): only rows [row0, row1) are needed by the caller (Track: the observed-crop window) -- the rest of the
 // model's copy keeps whatever an earlier frame left there
-static int upload_frame_async(fp_model *m, const void *rgb, const void *depth, int memspace, int H, int W, int row0, int row1) {
+static int upload_frame_async(fp_model *m, const void *rgb, const void *depth, int memspace, int H, int W, int row0, int row1, int col0, int col1) {
   Target *t = nullptr;
   if (check_frame_args(m, H, W, nullptr, &t)) return 1;
   FP_CHECK(rgb && depth, "[FoundationPose] Got INVALID rgb/depth ptr");
@@ -737,9 +743,20 @@ static int upload_frame_async(fp_model *m, const void *rgb, const void *depth, i
     if (row1 < 0 || row1 > H) row1 = H;
     row0 = std::max(0, std::min(row0, row1));
     m->frame_partial = row0 > 0 || row1 < H;
+    if (col1 < 0 || col1 > W) col1 = W;
+    col0 = std::max(0, std::min(col0, col1));
     const size_t o = (size_t)row0 * W, n = (size_t)(row1 - row0) * W;
-    ProfScope ps(&m->prof, m->stream, "h2d_frame", 0, (double)n * 7);
-    if (n) {
+    const size_t cw = (size_t)(col1 - col0);
+    ProfScope ps(&m->prof, m->stream, "h2d_frame", 0, (double)(row1 - row0) * cw * 7);
+    if (n && cw && g_upload_cols && cw * 2 <= (size_t)W) {
+      // the window is less than half the frame wide: a 2-D copy of the rectangle (same device pitch: the kernels index whole frames)
+      m->frame_partial = true;
+      const size_t oc = o + col0;
+      FP_HIP_OK(hipMemcpy2DAsync(m->rgb_own + oc * 3, (size_t)W * 3, (const uint8_t *)rgb + oc * 3, (size_t)W * 3, cw * 3, (size_t)(row1 - row0),
+                                 hipMemcpyHostToDevice, m->stream));
+      FP_HIP_OK(hipMemcpy2DAsync(m->depth_own + oc, (size_t)W * 4, (const float *)depth + oc, (size_t)W * 4, cw * 4, (size_t)(row1 - row0),
+                                 hipMemcpyHostToDevice, m->stream));
+    } else if (n) {
       FP_HIP_OK(hipMemcpyAsync(m->rgb_own + o * 3, (const uint8_t *)rgb + o * 3, n * 3, hipMemcpyHostToDevice, m->stream));
       FP_HIP_OK(hipMemcpyAsync(m->depth_own + o, (const float *)depth + o, n * 4, hipMemcpyHostToDevice, m->stream));
     }
@@ -1189,12 +1206,16 @@ static int track_submit_impl(fp_model *m, const void *rgb, const void *depth, in
   const bool graphable = m->use_graphs && !m->prof.on && !m->digests && !m->calibrating && refine_itr >= 1;
   // a single refine iteration reads the frame only inside the observed-crop window of the hypothesis (ComputeCropWindowTF,
   // foundationpose_render.cpp:25-70, restated on the host in double with a margin): host frames upload just those rows
-  int row0 = 0, row1 = -1;
+  int row0 = 0, row1 = -1, col0 = 0, col1 = -1;
   if (memspace != FP_DEVICE && refine_itr == 1) {
     const double r = (double)t->mesh.diameter * 1.2 / 2, tx = hyp_pose[12], ty = hyp_pose[13], tz = hyp_pose[14];
     auto proj_v = [&](double x, double y, double z) {
       const double q1 = m->K[3] * x + m->K[4] * y + m->K[5] * z, q2 = m->K[6] * x + m->K[7] * y + m->K[8] * z;
       return q1 / q2;
+    };
+    auto proj_u = [&](double x, double y, double z) {
+      const double q0 = m->K[0] * x + m->K[1] * y + m->K[2] * z, q2 = m->K[6] * x + m->K[7] * y + m->K[8] * z;
+      return q0 / q2;
     };
     if (tz > 1e-6) {
       const double v0 = proj_v(tx, ty, tz);
@@ -1208,11 +1229,18 @@ static int track_submit_impl(fp_model *m, const void *rgb, const void *depth, in
         else if (v0 > -(double)H && v0 < 2.0 * H) {
           row0 = (int)std::floor(v0 - rad) - 4;
           row1 = (int)std::ceil(v0 + rad) + 5;
+          // the window is a square of the same radius around (u0, v0): its columns, with the same margin
+          const double u0 = proj_u(tx, ty, tz);
+          if (std::isfinite(u0) && u0 > -(double)W && u0 < 2.0 * W) {
+            col0 = (int)std::floor(u0 - rad) - 4;
+            col1 = (int)std::ceil(u0 + rad) + 5;
+            if (col1 <= 0 || col0 >= W) { col0 = 0; col1 = -1; }   // (a window beside the frame: keep whole rows)
+          }
         }
       }
     }
   }
-  if (upload_frame_async(m, rgb, depth, memspace, H, W, row0, row1)) return 1;
+  if (upload_frame_async(m, rgb, depth, memspace, H, W, row0, row1, col0, col1)) return 1;
   if (!m->track_io) {
     FP_HIP_OK(hipHostMalloc((void **)&m->track_io, 32 * sizeof(float), hipHostMallocDefault));
     FP_HIP_OK(hipHostGetDevicePointer((void **)&m->track_io_dev, m->track_io, 0));
