@@ -3909,7 +3909,7 @@ FP_HOOK g_att_skv = 1;          // small attention grids on attention32_skv_kern
 FP_HOOK g_gemm_deep = 1;         // short-K layers of small problems on conv_deep_kernel<128> instead of the two-stage 128x128 tile
 FP_HOOK g_splitk_mid = 1;        // two split-K slices for long-K layers with 97..128 tiles (batches of ~8 objects)
 FP_HOOK g_small_deep = 18;     // small problems (Track): conv_deep_kernel<64> over ALL K-steps instead of split-K + reduce when K has at most this many 128-byte steps
-FP_HOOK g_smallm_maxkt = 80;   // conv_smallm_kernel takes layers with fewer 128-byte K-steps than this (40 includes the 36-step conv_256 / conv_b2 layers: -3 us and 5 launches fewer per Track than 32)
+FP_HOOK g_smallm_maxkt = 80;   // the small-problem kernel takes layers with fewer 128-byte K-steps than this: every layer of both networks (72 for conv_512); 40 was the limit of its first version
 FP_HOOK g_conv_lds_store = 0;  // conv_big_pp_kernel: epilogue stores staged through LDS (whole 128-byte lines per store instruction).  OFF: measured [r3] conv_512 3.205 -> 3.227 / 3.184 -> 3.180 ms, i.e. nothing -- the 256x256 tile's store burst is not bound by the store shape (unlike gemm_k32_kernel's, -6 %)
 FP_HOOK g_gemm_lds_store = 1;  // gemm_k32_kernel: output rows leave through LDS as whole 256-byte runs instead of 64-byte pieces per store instruction
 FP_HOOK g_smallm_maxt16 = 1024; // ... and with at most this many 16-pixel x 64-channel tiles (the grouped QKV of Track has 1200)
@@ -3999,14 +3999,14 @@ static int run_conv_dt(const Ctx &c, const char *tag, const ConvLayer &L, ConvPa
     p.partial = sk->splitk;
     return 0;
   };
-  // ---- small problems: one launch per layer, the K-steps split over the four waves of a workgroup (conv_smallm_kernel)
+  // ---- small problems: one launch per layer, the K-steps split over the four waves of a workgroup (conv_smallx_kernel)
   if constexpr (B2) {
     const int cw = (L.Cout % 128 == 0) ? 64 : 32;         // channels per workgroup = the block of the host-side row permutation
     const int t16 = ((p.M + 15) / 16) * (L.Cout / cw);
-    // Measured on Track (tools/profile_track.sh): layers of up to 18 K-steps 8.8-9.4 us against 11 us on the LDS-ring kernels; long-K
-    // layers do NOT win -- conv_512 (72 steps) 21 us against 12.3 + 5.2 us for split-K + reduce: operand-shaped global loads touch 16
-    // cache lines per instruction (64 bytes used of each) and the vector L1 retires them at ~16 B/clk, a quarter of what the
-    // LDS-DMA rows (8 lanes per 128-byte line) get.  g_smallm = 2 forces it for every K (A/B).
+    // Measured on Track (tools/profile_track.sh, profiles/r03g_track_timeline.txt): 5.6-7.2 us for the layers of up to 18 K-steps, 8.5-9.1
+    // for the 36-step ones, 10.2-10.6 for conv_512 (72 steps; 12.8 + 5.5 us as split-K + reduce).  The first version
+    // (conv_smallm_kernel: both operands global -> registers in MFMA-operand shape, 64 clocks of the vector L1 per instruction) lost on
+    // the long-K layers (21 us); g_smallm = 3 selects it for A/B, g_smallm = 2 forces the small-problem kernel for every size.
     if (g_smallm && L.wfrag && (KT < g_smallm_maxkt || g_smallm >= 2) && g_conv_variant == 0 && g_conv_ablate == 0 && L.Cout % cw == 0 && t16 <= g_smallm_maxt16 * (64 / cw) &&
         (!grp || grp->rows % 32 == 0) && ((L.Cout / cw) % 8 == 0 || 8 % (L.Cout / cw) == 0)) {
       const int t32 = ((p.M + 31) / 32) * (L.Cout / cw);
