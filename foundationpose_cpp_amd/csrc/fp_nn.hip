@@ -22,7 +22,14 @@
 //     conv_pp32_kernel<512,128> 32-wide K-steps, 4-stage ring; the same stride-2 conv below ~30 hypotheses.
 //     conv_igemm_kernel<BN>     128 x BN tile, 2 workgroups per CU, optional split-K (+ conv_splitk_reduce_kernel) and
 //                               weight groups along M: left-over rows, small batches (Track).
+//     conv_smallx_kernel [r3]   small problems (Track, a few objects): one launch per layer, K split over the waves of a workgroup;
+//                               weights global -> registers from a copy in MFMA-fragment order, pixels through a per-wave LDS-DMA
+//                               ring -- both in the one address shape the vector L1 serves at full rate (tools/bench_tcp.hip).
 //     conv_igemm3 / conv_pp / conv_big kernels: earlier schedules kept behind fpt_set_conv_variant for A/B.
+//   Weight layouts [r3]: besides the row-major [Cout][K] copy every layer carries the copies its schedules stream from -- fragment
+//   order (conv_smallx), LDS-stage order for gemm_k32 / conv_halo / conv_halo8 / conv_big_pp / conv_deep + conv_pp (pack_stage_w,
+//   pack_stage_w128): a wave's 2-4 LDS-DMA pieces of a stage are ONE contiguous run, so one address and one M0 serve them (the
+//   instruction's immediate offset moves the global AND the LDS address) and every fetched cache line is used whole.
 //   attention_kernel       softmax(QK^T/sqrt(d))V for 4 heads x 128, any sequence length (400 tokens per hypothesis, or
 //                          the N hypotheses of the score-net's cross attention): S^T = K Q^T on MFMA so a softmax row is
 //                          lane-local, P feeds the PV MFMA straight from registers (k-slot permutation shared with V^T).
