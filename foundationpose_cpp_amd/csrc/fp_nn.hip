@@ -4860,6 +4860,64 @@ int fpt_conv_dt(const float *x, const float *w, const float *bias, const float *
   decode(ho.data(), nout, out_dt, out_scale, out);
   return 0;
 }
+// Host-only check of the weight layouts (no GPU): every (tile, K-step, lane) address a kernel forms into fragment_order /
+// pack_stage_w / pack_stage_w128 must hold the bytes the same lane would have fetched from the row-major copy.
+// Returns the number of mismatching 16-byte pieces (0 = all layouts agree), -1 for unsupported sizes.
+long long fpt_check_weight_layouts(int Cout, int row_bytes) {
+  using namespace fp;
+  if (Cout % 256 || row_bytes % 128) return -1;
+  std::vector<unsigned char> rows((size_t)Cout * row_bytes);
+  unsigned st = 12345u;
+  for (auto &b : rows) { st = st * 1664525u + 1013904223u; b = (unsigned char)(st >> 24); }
+  long long bad = 0;
+  auto same = [&](const unsigned char *a, const unsigned char *b) { return std::memcmp(a, b, 16) == 0; };
+  const size_t KT = row_bytes / 128, S = row_bytes / 64;
+  {  // conv_smallx_kernel: wrow = frag + (n0 >> 4) * 16 * krow_b + lane * 16;  + ni * 16 * krow_b + kt * 2048 + ks * 1024
+    const auto f = fragment_order(rows, Cout, row_bytes);
+    for (size_t t = 0; t < (size_t)Cout / 16; t++)
+      for (size_t kt = 0; kt < KT; kt++)
+        for (int ks = 0; ks < 2; ks++)
+          for (int l = 0; l < 64; l++)
+            bad += !same(&f[t * 16 * row_bytes + kt * 2048 + (size_t)ks * 1024 + (size_t)l * 16],
+                         &rows[(t * 16 + (l & 15)) * row_bytes + kt * 128 + (size_t)ks * 64 + (size_t)(l >> 4) * 16]);
+  }
+  for (int TILE : {256, 128}) {  // gemm_k32_kernel (4 pieces per wave) / conv_halo_kernel (2): row = lane >> 2, swizzled chunk
+    const auto pk = pack_stage_w(rows, Cout, row_bytes, TILE);
+    const int PW = TILE / 64;
+    for (size_t nt = 0; nt < (size_t)Cout / TILE; nt++)
+      for (size_t s2 = 0; s2 < S; s2++)
+        for (int wv = 0; wv < 4; wv++)
+          for (int i = 0; i < PW; i++)
+            for (int l = 0; l < 64; l++) {
+              const int prow = l >> 2, gch = (l & 3) ^ ((0x78 >> (((prow >> 2) & 3) * 2)) & 3);
+              // the kernel: base of (nt, wave) + s2 * (4 waves * PW KB) + i * 1024 + lane * 16
+              const size_t at = ((nt * S * 4 + wv) * PW) * 1024 + s2 * (size_t)(4 * PW * 1024) + (size_t)i * 1024 + (size_t)l * 16;
+              bad += !same(&pk[at], &rows[(nt * TILE + (size_t)(wv * PW + i) * 16 + prow) * row_bytes + s2 * 64 + (size_t)gch * 16]);
+            }
+  }
+  for (int cfg = 0; cfg < 2; cfg++) {  // conv_big_pp_kernel (256 rows, 8 waves) / conv_deep_kernel, conv_halo8_kernel (128 rows, 4 waves)
+    const int TILE = cfg ? 128 : 256, NW = cfg ? 4 : 8;
+    const auto pk = pack_stage_w128(rows, Cout, row_bytes, TILE, NW);
+    for (size_t nt = 0; nt < (size_t)Cout / TILE; nt++)
+      for (size_t kt = 0; kt < KT; kt++)
+        for (int wv = 0; wv < NW; wv++)
+          for (int i = 0; i < 4; i++)
+            for (int l = 0; l < 64; l++) {
+              const int srow = l >> 3, g = (l & 7) ^ srow;
+              const size_t at = ((nt * KT * NW + wv) * 4096) + kt * (size_t)(NW * 4096) + (size_t)i * 1024 + (size_t)l * 16;
+              bad += !same(&pk[at], &rows[(nt * TILE + (size_t)(wv * 4 + i) * 8 + srow) * row_bytes + kt * 128 + (size_t)g * 16]);
+              // conv_pp_kernel<128> reads the 128-row form as 8 waves x 2 pieces: piece P = 2 * wave + i at P KB of the (nt, kt) block
+              if (cfg && i < 2) {
+                for (int w8 = wv * 2; w8 < wv * 2 + 2; w8++) {
+                  const size_t at8 = (nt * KT * 16 + (size_t)w8 * 2) * 1024 + kt * 16384 + (size_t)i * 1024 + (size_t)l * 16;
+                  bad += !same(&pk[at8], &rows[(nt * 128 + (size_t)(w8 * 2 + i) * 8 + srow) * row_bytes + kt * 128 + (size_t)g * 16]);
+                }
+              }
+            }
+  }
+  return bad;
+}
+
 int fpt_conv(const float *x, const float *w, const float *bias, const float *res, int NB, int H, int W, int Cin, int Cout,
              int KH, int KW, int stride, int pad, int OH, int OW, int relu, int split_imgs, float *out, int iters,
              float *ms_out) {
