@@ -807,7 +807,8 @@ __global__ __launch_bounds__(256, 2) void conv_smallm_kernel(const ConvParams p)
 // -------------------------------------------------------------------------------------------------
 template <int MI, int NI, int DT, int ODT, bool POST, int PFO = 0>
 __global__ __launch_bounds__(256, 2) void conv_smallx_kernel(const ConvParams p) {
-  static_assert(DT != DT_FP8, "2-byte operand types");
+  // (every element type: operands travel as raw 16-byte pieces, a 128-byte K-step is 64 two-byte or 128 one-byte channels; mma_kstep
+  // picks the MFMA.  FP8 layers: Track / a few objects in FP8 mode no longer fall back to the split-K schedules)
   constexpr int PF = PFO ? PFO : (MI == 1 ? 4 : 3);        // K-steps in flight per wave
   constexpr int L = 2 * MI + 2 * NI;         // vector-memory instructions per K-step
   constexpr int STAGE = MI * 2048, RING = PF * STAGE;
@@ -3580,7 +3581,7 @@ static bool finish_layer(Net *net, const std::vector<float> &rows_f32, const std
   auto elems = to_elems(rows_f32, Cout, K, dt, &rs);
   const auto rows = permute_rows(relayout_k(elems, Cout, ntaps, Cin, es), Cout, (size_t)K * es);
   L->w = upload(net, rows);
-  if (dt != DT_FP8 && ((size_t)K * es) % 128 == 0 && Cout % 16 == 0) {
+  if (((size_t)K * es) % 128 == 0 && Cout % 16 == 0) {   // (byte-level: every element type)
     L->wfrag = upload(net, fragment_order(rows, Cout, (size_t)K * es));
     if (!L->wfrag) return false;
   }
@@ -4007,7 +4008,7 @@ static int run_conv_dt(const Ctx &c, const char *tag, const ConvLayer &L, ConvPa
     return 0;
   };
   // ---- small problems: one launch per layer, the K-steps split over the four waves of a workgroup (conv_smallx_kernel)
-  if constexpr (B2) {
+  if (B2 || L.Cout % 128 == 0) {                         // (FP8 layers all have Cout % 128 == 0: 64-channel tiles only)
     const int cw = (L.Cout % 128 == 0) ? 64 : 32;         // channels per workgroup = the block of the host-side row permutation
     const int t16 = ((p.M + 15) / 16) * (L.Cout / cw);
     // Measured on Track (tools/profile_track.sh, profiles/r03g_track_timeline.txt): 5.6-7.2 us for the layers of up to 18 K-steps, 8.5-9.1
@@ -4044,7 +4045,7 @@ static int run_conv_dt(const Ctx &c, const char *tag, const ConvLayer &L, ConvPa
 #endif
 #define FP_SMALLM(MI_, NI_, POST_)                                                                                          \
   do {                                                                                                                      \
-    FP_SMALLM_DIRECT(MI_, NI_, POST_)                                                                                       \
+    if constexpr (B2) { FP_SMALLM_DIRECT(MI_, NI_, POST_) }                                                                 \
     FP_LAUNCH((conv_smallx_kernel<MI_, NI_, DT, ODT, POST_>), grid, dim3(256),                                              \
               4 * ((MI_) == 1 ? 4 : 3) * (MI_) * 2048 + 3 * NI_ * MI_ * 1024, c.s, p);                                      \
   } while (0)
@@ -4053,7 +4054,7 @@ static int run_conv_dt(const Ctx &c, const char *tag, const ConvLayer &L, ConvPa
         if (post) p.post = nullptr;                      // (no 32-channel layer carries a positional table)
       }
       if (cw == 64) { if (two) FP_SMALLM(2, 4, false); else FP_SMALLM(1, 4, false); }
-      else { if (two) FP_SMALLM(2, 2, false); else FP_SMALLM(1, 2, false); }
+      else if constexpr (B2) { if (two) FP_SMALLM(2, 2, false); else FP_SMALLM(1, 2, false); }
 #undef FP_SMALLM
 #undef FP_SMALLM_DIRECT
       return 0;
