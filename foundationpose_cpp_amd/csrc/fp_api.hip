@@ -15,6 +15,7 @@
 #include <map>
 #include <memory>
 #include <mutex>
+#include <shared_mutex>
 
 #include "fp_internal.h"
 #include "fp_nn.h"
@@ -476,13 +477,34 @@ __global__ void unpack_shards_kernel(const float *__restrict__ gathered, int n_t
 // of two models are never co-resident.  This is the round-1 behaviour; it exists because the packed-f32 erratum behind the
 // removal of that lock was mitigated, not reproduced in isolation.  The pipelined fp_track_submit /
 // fp_track_wait pair is not covered (it exists to overlap models).
+// Lifetime lock [r3]: every compute entry point holds it SHARED for the duration of the call, fp_create / fp_destroy / fp_net_create /
+// fp_net_destroy hold it EXCLUSIVE -- a model is never built or torn down (hundreds of allocations, uploads, a stream) while another
+// thread of the process is inside a Register / Track call capturing or replaying its graphs.  (Two of ~20 runs of the widened
+// concurrency test died with SIGSEGV inside fp_register_shard_begin on two threads while the main thread was inside fp_create;
+// the calls themselves share nothing but the HIP runtime.)  Calls still run concurrently with each other; GPU work already enqueued
+// keeps running during a creation.  Nested entry points (fp_register_ex -> shard_begin) take it once (thread-local depth).
+static std::shared_mutex g_life_rw;
+static thread_local int g_life_depth = 0;
+struct LifeExclusive {
+  LifeExclusive() { g_life_rw.lock(); }
+  ~LifeExclusive() { g_life_rw.unlock(); }
+};
 struct SerialGuard {
   std::unique_lock<std::recursive_mutex> lk;
+  bool shared_held = false;
   SerialGuard() {
+    if (g_life_depth++ == 0) { g_life_rw.lock_shared(); shared_held = true; }
     static const bool on = [] { const char *e = std::getenv("FP_SERIALIZE_MODELS"); return e && *e && *e != '0'; }();
     static std::recursive_mutex mu;
     if (on) lk = std::unique_lock<std::recursive_mutex>(mu);
   }
+  ~SerialGuard() {
+    if (lk.owns_lock()) lk.unlock();
+    --g_life_depth;
+    if (shared_held) g_life_rw.unlock_shared();
+  }
+  SerialGuard(const SerialGuard &) = delete;
+  SerialGuard &operator=(const SerialGuard &) = delete;
 };
 
 // Exception barrier of the C ABI: every entry point below that can allocate on the host (std::vector / std::string / new) is a
@@ -611,15 +633,17 @@ static OutMode nn_mode(const fp_model *m) {
   return n && net_input_dt(n) == DT_BF16 ? OUT_BF16X8 : OUT_F16X8;
 }
 
+static void destroy_model_impl(fp_model *m);
 fp_model *fp_create(const fp_mesh *meshes, int n_meshes, const float K[9], const char *refiner_weights,
                     const char *scorer_weights, int max_h, int max_w) try {
+  LifeExclusive life;   // not while another thread is inside a call (see SerialGuard)
   if (!meshes || n_meshes <= 0 || !K) { set_error("[FoundationPose] fp_create: invalid arguments"); return nullptr; }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
     set_error("[FoundationPose] no HIP device available (this library has no CPU path)");
     return nullptr;
   }
-  std::unique_ptr<fp_model, void (*)(fp_model *)> m(new fp_model(), fp_destroy);  // a failed construction releases what it had allocated
+  std::unique_ptr<fp_model, void (*)(fp_model *)> m(new fp_model(), destroy_model_impl);  // a failed construction releases what it had allocated
   std::memcpy(m->K, K, sizeof(float) * 9);
   if (max_h > 0) m->max_h = max_h;
   if (max_w > 0) m->max_w = max_w;
@@ -635,7 +659,7 @@ fp_model *fp_create(const fp_mesh *meshes, int n_meshes, const float K[9], const
     if (!src.vertices || !src.normals || !src.texcoords || !src.faces || !src.texture || src.num_vertices <= 0 ||
         src.num_faces <= 0 || src.tex_height <= 0 || src.tex_width <= 0) {
       set_error("[FoundationPose Renderer] Failed to load textured mesh!!!");
-      fp_destroy(m.release());
+      destroy_model_impl(m.release());
       return nullptr;
     }
     Target t;
@@ -663,19 +687,19 @@ fp_model *fp_create(const fp_mesh *meshes, int n_meshes, const float K[9], const
     m->targets.push_back(t);
     if (!ok) {
       set_error("[FoundationPose Renderer] Failed to prepare buffer!!!");
-      fp_destroy(m.release());
+      destroy_model_impl(m.release());
       return nullptr;
     }
   }
-  if (set_rotation_grid(m.get(), m->inplane_steps)) { fp_destroy(m.release()); return nullptr; }
+  if (set_rotation_grid(m.get(), m->inplane_steps)) { destroy_model_impl(m.release()); return nullptr; }
   if (refiner_weights) m->refiner_path = refiner_weights;
   if (scorer_weights) m->scorer_path = scorer_weights;
-  if (select_precision(m.get(), PREC_F16)) { fp_destroy(m.release()); return nullptr; }
-  if (hipMalloc((void **)&m->argmax_dev, sizeof(int)) != hipSuccess) { fp_destroy(m.release()); return nullptr; }
+  if (select_precision(m.get(), PREC_F16)) { destroy_model_impl(m.release()); return nullptr; }
+  if (hipMalloc((void **)&m->argmax_dev, sizeof(int)) != hipSuccess) { destroy_model_impl(m.release()); return nullptr; }
   return m.release();
 } FP_CATCH_PTR
 
-void fp_destroy(fp_model *m) {
+static void destroy_model_impl(fp_model *m) {
   if (!m) return;
   if (m->stream) (void)hipStreamSynchronize(m->stream);
   invalidate_graphs(m);
@@ -704,8 +728,13 @@ void fp_destroy(fp_model *m) {
   if (m->stream) (void)hipStreamDestroy(m->stream);
   delete m;
 }
+void fp_destroy(fp_model *m) {
+  LifeExclusive life;   // not while another thread is inside a call (see SerialGuard)
+  destroy_model_impl(m);
+}
 
 int fp_set_inplane_steps(fp_model *m, int steps) try {
+  SerialGuard serial;
   FP_CHECK(m && steps >= 1 && steps <= 360, "[FoundationPose] fp_set_inplane_steps: invalid arguments");
   FP_HIP_OK(hipStreamSynchronize(m->stream));
   return set_rotation_grid(m, steps);
@@ -713,6 +742,7 @@ int fp_set_inplane_steps(fp_model *m, int steps) try {
 int fp_num_hypotheses(const fp_model *m) { return m ? m->n_hyp() : 0; }
 void *fp_stream(fp_model *m) { return m ? (void *)m->stream : nullptr; }
 int fp_synchronize(fp_model *m) try {
+  SerialGuard serial;
   FP_CHECK(m, "null model");
   FP_HIP_OK(hipStreamSynchronize(m->stream));
   return 0;
@@ -774,12 +804,14 @@ static int upload_frame_async(fp_model *m, const void *rgb, const void *depth, i
 }
 
 int fp_upload_frame(fp_model *m, const void *rgb, const void *depth, int memspace, int H, int W) try {
+  SerialGuard serial;
   if (upload_frame_async(m, rgb, depth, memspace, H, W)) return 1;
   if (memspace == FP_HOST) FP_HIP_OK(hipStreamSynchronize(m->stream));  // the host frame may be released on return
   return 0;
 } FP_CATCH_INT
 
 int fp_get_xyz_map(fp_model *m, float *xyz_host) try {
+  SerialGuard serial;
   FP_CHECK(m && m->depth && xyz_host, "[FoundationPose] fp_get_xyz_map: no frame uploaded");
   FP_CHECK(!m->frame_partial, "[FoundationPose] the last call (Track from a host frame) uploaded only its crop window: call fp_upload_frame first");
   size_t px = (size_t)m->H * m->W;
@@ -803,6 +835,7 @@ static int run_depth_filters(fp_model *m) {
 }
 
 int fp_filter_depth(fp_model *m, float *eroded_out, float *bilateral_out) try {
+  SerialGuard serial;
   FP_CHECK(m && m->depth, "[FoundationPose] fp_filter_depth: no frame uploaded");
   FP_CHECK(!m->frame_partial, "[FoundationPose] the last call (Track from a host frame) uploaded only its crop window: call fp_upload_frame first");
   size_t px = (size_t)m->H * m->W;
@@ -870,6 +903,7 @@ static int sampler_status(fp_model *m) {
 }
 
 int fp_get_hyp_poses(fp_model *m, const void *mask, int memspace, float *poses_out, int *n_out) try {
+  SerialGuard serial;
   FP_CHECK(m && poses_out, "[FoundationPose] fp_get_hyp_poses: invalid arguments");
   const int n = m->n_hyp();
   if (sample_hypotheses_async(m, m->targets.empty() ? nullptr : &m->targets[0], mask, memspace, 0, n)) return 1;
@@ -897,6 +931,7 @@ static int upload_poses(fp_model *m, Target *t, const float *poses, int N) {
 
 int fp_render_and_transform(fp_model *m, const char *target_name, const float *poses, int N, float crop_ratio,
                             float *render_out, float *transf_out, int out_memspace) try {
+  SerialGuard serial;
   FP_CHECK(m && poses && N > 0, "[FoundationposeRender] The transform matrix vector is empty");
   FP_CHECK(m->depth != nullptr, "[FoundationPose] fp_render_and_transform: no frame uploaded");
   FP_CHECK(!m->frame_partial, "[FoundationPose] the last call (Track from a host frame) uploaded only its crop window: call fp_upload_frame first");
@@ -921,6 +956,7 @@ int fp_render_and_transform(fp_model *m, const char *target_name, const float *p
 
 int fp_debug_rasterize(fp_model *m, const char *target_name, const float *poses, int N, float crop_ratio,
                        int32_t *tri_id, float *rast_out) try {
+  SerialGuard serial;
   FP_CHECK(m && poses && N > 0, "[FoundationposeRender] The transform matrix vector is empty");
   FP_CHECK(m->H > 0, "[FoundationPose] fp_debug_rasterize: no frame uploaded (image size unknown)");
   Target *t = m->find(target_name ? target_name : "");
@@ -957,6 +993,7 @@ static int pack_blobs(fp_model *m, const float *render_input, const float *trans
 
 int fp_refiner_infer(fp_model *m, const float *render_input, const float *transf_input, int memspace, int N,
                      float *trans_out, float *rot_out) try {
+  SerialGuard serial;
   FP_CHECK(m && m->refiner, "[FoundationPose] refiner weights not loaded");
   if (pack_blobs(m, render_input, transf_input, memspace, N)) return 1;
   if (refiner_forward(m->stream, &m->prof, m->refiner, m->ws, m->nn_in, N, m->trans_dev, m->rot_dev)) return 1;
@@ -968,6 +1005,7 @@ int fp_refiner_infer(fp_model *m, const float *render_input, const float *transf
 
 int fp_scorer_infer(fp_model *m, const float *render_input, const float *transf_input, int memspace, int N,
                     float *scores_out) try {
+  SerialGuard serial;
   FP_CHECK(m && m->scorer, "[FoundationPose] scorer weights not loaded");
   if (pack_blobs(m, render_input, transf_input, memspace, N)) return 1;
   if (scorer_features(m->stream, &m->prof, m->scorer, m->ws, m->nn_in, N, m->feat_dev)) return 1;
@@ -979,6 +1017,7 @@ int fp_scorer_infer(fp_model *m, const float *render_input, const float *transf_
 
 int fp_refine_post_process(fp_model *m, const char *target_name, const float *poses, const float *trans,
                            const float *rot, int N, float *poses_out) try {
+  SerialGuard serial;
   FP_CHECK(m && poses && trans && rot && poses_out && N > 0, "[FoundationPose] fp_refine_post_process: invalid arguments");
   Target *t = m->find(target_name ? target_name : "");
   FP_CHECK(t != nullptr, "[FoundationPose] unknown target_name");
@@ -993,6 +1032,7 @@ int fp_refine_post_process(fp_model *m, const char *target_name, const float *po
 } FP_CATCH_INT
 
 int fp_argmax(fp_model *m, const float *scores, int N, int *index_out) try {
+  SerialGuard serial;
   FP_CHECK(m && scores && index_out && N > 0, "[FoundationPose] fp_argmax: invalid arguments");
   if (ensure_capacity(m, N, 0)) return 1;
   FP_HIP_OK(hipMemcpyAsync(m->scores_dev, scores, (size_t)N * 4, hipMemcpyHostToDevice, m->stream));
@@ -1035,6 +1075,7 @@ static int refine_iteration(fp_model *m, Target *t, int N, bool shared_b, const 
 int fp_register_shard_begin(fp_model *m, const void *rgb, const void *depth, const void *mask, int memspace, int H,
                             int W, const char *target_name, int refine_itr, int shard_begin, int shard_count,
                             float **feat_dev, float **poses_dev) try {
+  SerialGuard serial;
   Target *t = nullptr;
   if (check_frame_args(m, H, W, target_name ? target_name : "", &t)) return 1;
   FP_CHECK(m->refiner && m->scorer, "[FoundationPose] refiner/scorer weights not loaded");
@@ -1075,6 +1116,7 @@ int fp_register_shard_begin(fp_model *m, const void *rgb, const void *depth, con
 
 int fp_register_shard_finish(fp_model *m, const float *all_feat_dev, const float *all_poses_dev, int N_total,
                              float out_pose[16], int *best_index, float *scores_host) try {
+  SerialGuard serial;
   FP_CHECK(m && m->scorer && all_feat_dev && all_poses_dev && N_total > 0 && out_pose,
            "[FoundationPose] fp_register_shard_finish: invalid arguments");
   float *scores = m->scores_dev;
@@ -1122,6 +1164,7 @@ int fp_register_shard_finish(fp_model *m, const float *all_feat_dev, const float
 } FP_CATCH_INT
 
 int fp_download(fp_model *m, void *dst_host, const void *src_dev, size_t bytes) try {
+  SerialGuard serial;
   FP_CHECK(m && dst_host && src_dev, "[FoundationPose] fp_download: invalid arguments");
   if (bytes) FP_HIP_OK(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, m->stream));
   FP_HIP_OK(hipStreamSynchronize(m->stream));
@@ -1132,6 +1175,7 @@ int fp_download(fp_model *m, void *dst_host, const void *src_dev, size_t bytes) 
 int fp_register_shard_begin_packed(fp_model *m, const void *rgb, const void *depth, const void *mask, int memspace, int H,
                                    int W, const char *target_name, int refine_itr, int shard_begin, int shard_count,
                                    float *packed_dev, int rows_per_rank) try {
+  SerialGuard serial;
   FP_CHECK(m && packed_dev && rows_per_rank >= shard_count && shard_count >= 0, "[FoundationPose] fp_register_shard_begin_packed: invalid arguments");
   float *feat = nullptr, *poses = nullptr;
   if (shard_count > 0) {
@@ -1158,6 +1202,7 @@ int fp_register_shard_begin_packed(fp_model *m, const void *rgb, const void *dep
 } FP_CATCH_INT
 
 int fp_register_shard_finish_packed(fp_model *m, const float *gathered_dev, int n_total, float out_pose[16], int *best_index) try {
+  SerialGuard serial;
   FP_CHECK(m && gathered_dev && n_total > 0 && out_pose, "[FoundationPose] fp_register_shard_finish_packed: invalid arguments");
   if (n_total > m->gath_cap) {
     FP_HIP_OK(hipStreamSynchronize(m->stream));
@@ -1266,6 +1311,7 @@ static int track_submit_impl(fp_model *m, const void *rgb, const void *depth, in
 
 int fp_track_submit(fp_model *m, const void *rgb, const void *depth, int memspace, int H, int W, const float hyp_pose[16],
                     const char *target_name, int refine_itr) try {
+  SerialGuard serial;
   const int rc = track_submit_impl(m, rgb, depth, memspace, H, W, hyp_pose, target_name, refine_itr);
   // a failure after the upload was enqueued must not leave H2D copies of the caller's host frame in flight
   if (rc && m && m->stream) (void)hipStreamSynchronize(m->stream);
@@ -1273,6 +1319,7 @@ int fp_track_submit(fp_model *m, const void *rgb, const void *depth, int memspac
 } FP_CATCH_INT
 
 int fp_track_wait(fp_model *m, float out_pose[16]) try {
+  SerialGuard serial;
   FP_CHECK(m && out_pose, "[FoundationPose] fp_track_wait: invalid arguments");
   FP_CHECK(m->track_pending, "[FoundationPose] fp_track_wait: nothing was submitted");
   m->track_pending = false;
@@ -1366,6 +1413,7 @@ int fp_track(fp_model *m, const uint8_t *rgb, const float *depth, int H, int W, 
 } FP_CATCH_INT
 
 int fp_set_precision(fp_model *m, int precision) try {
+  SerialGuard serial;
   FP_CHECK(m != nullptr, "[FoundationPose] null model");
   FP_HIP_OK(hipStreamSynchronize(m->stream));
   FP_CHECK(precision != PREC_FP8 || m->calibrated,
@@ -1413,6 +1461,7 @@ int fp_get_calibration(const fp_model *m, float amax_out[32]) try {
   return 0;
 } FP_CATCH_INT
 int fp_set_calibration(fp_model *m, const float amax[32]) try {
+  SerialGuard serial;
   FP_CHECK(m && amax, "[FoundationPose] fp_set_calibration: invalid arguments");
   FP_HIP_OK(hipStreamSynchronize(m->stream));
   std::memcpy(m->calib_amax, amax, sizeof(m->calib_amax));
@@ -1455,7 +1504,9 @@ static int net_blob_index(const fp_net *n, const char *name, bool *out) {
   return -1;
 }
 
+static void destroy_net_impl(fp_net *n);
 fp_net *fp_net_create(const char *weights_path, int is_scorer, int max_batch) try {
+  LifeExclusive life;   // (see SerialGuard)
   if (!weights_path || max_batch <= 0) { set_error("[FoundationPose] fp_net_create: invalid arguments"); return nullptr; }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { set_error("[FoundationPose] no HIP device available (this library has no CPU path)"); return nullptr; }
@@ -1471,11 +1522,11 @@ fp_net *fp_net_create(const char *weights_path, int is_scorer, int max_batch) tr
   for (int i = 0; ok && i < 2; i++) ok = !dev_alloc(&n->in_dev[i], in_elems) && !dev_alloc(&n->out_dev[i], (size_t)max_batch * 3);
   ok = ok && !dev_alloc(&n->feat_dev, (size_t)max_batch * 512) && !dev_alloc(&n->nn_in, (size_t)2 * max_batch * FP_NN_IN_IMG_HALFS);
   ok = ok && hipMemsetAsync(n->nn_in, 0, (size_t)2 * max_batch * FP_NN_IN_IMG_HALFS * sizeof(__half), n->stream) == hipSuccess;
-  if (!ok) { set_error("[FoundationPose] fp_net_create: device allocation failed"); fp_net_destroy(n.release()); return nullptr; }
+  if (!ok) { set_error("[FoundationPose] fp_net_create: device allocation failed"); destroy_net_impl(n.release()); return nullptr; }
   return n.release();
 } FP_CATCH_PTR
 
-void fp_net_destroy(fp_net *n) {
+static void destroy_net_impl(fp_net *n) {
   if (!n) return;
   if (n->stream) (void)hipStreamSynchronize(n->stream);
   for (int i = 0; i < 2; i++) {
@@ -1488,6 +1539,10 @@ void fp_net_destroy(fp_net *n) {
   if (n->ws) nn_scratch_free(n->ws);
   if (n->stream) (void)hipStreamDestroy(n->stream);
   delete n;
+}
+void fp_net_destroy(fp_net *n) {
+  LifeExclusive life;
+  destroy_net_impl(n);
 }
 
 // raw pointer of a blob in the given memory space (BlobsTensor::GetTensor(name)->RawPtr()); NULL + fp_last_error for an
@@ -1509,6 +1564,7 @@ int fp_net_max_batch(const fp_net *n) { return n ? n->max_batch : 0; }
 // SyncInfer: inputs are taken from the blobs' FP_HOST or FP_DEVICE copies (render_loc / transf_loc), outputs are left in
 // the device blobs and, with out_loc == FP_HOST, copied to the host blobs as well; returns when they are complete.
 int fp_net_infer(fp_net *n, int batch, int render_loc, int transf_loc, int out_loc) try {
+  SerialGuard serial;
   FP_CHECK(n && batch > 0 && batch <= n->max_batch, "[FoundationPose] fp_net_infer: batch out of range");
   const size_t px = (size_t)batch * FP_CROP_HW * FP_CROP_HW;
   const int locs[2] = {render_loc, transf_loc};
