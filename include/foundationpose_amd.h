@@ -16,7 +16,8 @@
  *     (the reference returns bool + a glog line, D6F/src/foundationpose_utils.hpp:76-84).
  *   - not re-entrant per model (like the reference: one renderer / scratch set per target,
  *     D6F/src/foundationpose.cpp:103-105); DIFFERENT models may be driven from different threads concurrently, each runs
- *     on its own non-blocking stream and their kernels overlap on the GPU.
+ *     on its own non-blocking stream and their kernels overlap on the GPU.  fp_create / fp_destroy (fp_net_create / fp_net_destroy) are
+ *     exclusive against every other call of the process: they wait for calls in progress and hold new ones back while they run.
  *   - memspace arguments: FP_HOST pointers are ordinary host memory, FP_DEVICE pointers are HIP device memory on
  *     the model's device (lets callers keep frames resident in HBM).
  */
