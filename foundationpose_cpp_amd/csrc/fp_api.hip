@@ -485,9 +485,11 @@ __global__ void unpack_shards_kernel(const float *__restrict__ gathered, int n_t
 // keeps running during a creation.  Nested entry points (fp_register_ex -> shard_begin) take it once (thread-local depth).
 static std::shared_mutex g_life_rw;
 static thread_local int g_life_depth = 0;
-struct LifeExclusive {
-  LifeExclusive() { g_life_rw.lock(); }
-  ~LifeExclusive() { g_life_rw.unlock(); }
+struct LifeExclusive {   // (entry points nested inside -- fp_calibrate_fp8 runs a Register -- see depth > 0 and take nothing)
+  LifeExclusive() { g_life_rw.lock(); ++g_life_depth; }
+  ~LifeExclusive() { --g_life_depth; g_life_rw.unlock(); }
+  LifeExclusive(const LifeExclusive &) = delete;
+  LifeExclusive &operator=(const LifeExclusive &) = delete;
 };
 struct SerialGuard {
   std::unique_lock<std::recursive_mutex> lk;
@@ -1413,7 +1415,7 @@ int fp_track(fp_model *m, const uint8_t *rgb, const float *depth, int H, int W, 
 } FP_CATCH_INT
 
 int fp_set_precision(fp_model *m, int precision) try {
-  SerialGuard serial;
+  LifeExclusive life;   // may load the networks of a precision: as exclusive as fp_create
   FP_CHECK(m != nullptr, "[FoundationPose] null model");
   FP_HIP_OK(hipStreamSynchronize(m->stream));
   FP_CHECK(precision != PREC_FP8 || m->calibrated,
@@ -1435,7 +1437,7 @@ int fp_get_float_model(const fp_model *m) { return m ? (m->fmad ? 1 : 0) : -1; }
 // every trunk activation of both networks; the per-tensor scales of the FP8 networks follow from it.
 int fp_calibrate_fp8(fp_model *m, const void *rgb, const void *depth, const void *mask, int memspace, int H, int W,
                      const char *target_name) try {
-  SerialGuard serial;
+  LifeExclusive life;   // loads the FP8 networks; the Register inside nests (depth > 0)
   FP_CHECK(m != nullptr, "[FoundationPose] null model");
   FP_CHECK(!m->refiner_path.empty() && !m->scorer_path.empty(), "[FoundationPose] fp_calibrate_fp8 needs both networks");
   const int prev = m->prec;
