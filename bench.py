@@ -303,7 +303,7 @@ def main():
             "metric": "Track fps (N=1)", "value": round(ksteps / td, 1), "unit": "frames/s", "ms_per_frame": round(td / ksteps * 1e3, 4),
             "host_frame_value": round(ksteps / thh, 1), "host_frame_ms": round(thh / ksteps * 1e3, 4), "steps": ksteps,
             "pipelined": pipelined,
-            "roofline": {"bound": "launch latency (one hipGraph of 28 dependent kernels), not MFMA", "algorithmic_gflop_per_frame": round(tflops / 1e9, 2),
+            "roofline": {"bound": "launch latency (one hipGraph of 26 dependent kernels), not MFMA", "algorithmic_gflop_per_frame": round(tflops / 1e9, 2),
                          "achieved": round(tflops / (td / ksteps) / 1e12, 1), "peak": PEAK_FP16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(tflops / (td / ksteps) / 1e12 / PEAK_FP16_TFLOPS, 4)},
         }
