@@ -17,7 +17,7 @@ from . import _lib
 from .synthetic import Mesh, from_colmajor, to_colmajor
 
 FP_HOST, FP_DEVICE = 0, 1
-FP_PREC_F16, FP_PREC_BF16, FP_PREC_FP8 = 0, 1, 2   # include/foundationpose_amd.h
+FP_PREC_F16, FP_PREC_BF16, FP_PREC_FP8, FP_PREC_INT8 = 0, 1, 2, 3   # include/foundationpose_amd.h
 CROP = 160
 
 
@@ -298,20 +298,33 @@ class FoundationPose:
 
     # ---- network precision (include/foundationpose_amd.h "network precision") ---------------------
     def set_precision(self, precision: int):
-        """FP_PREC_F16 (the reference's TensorRT --fp16 engines, default) / FP_PREC_BF16 / FP_PREC_FP8 (after calibrate_fp8)."""
+        """FP_PREC_F16 (the reference's TensorRT --fp16 engines, default) / FP_PREC_BF16 / FP_PREC_FP8, FP_PREC_INT8 (after calibrate)."""
         self._must(self._L.fp_set_precision(self._h, precision))
 
     @property
     def precision(self) -> int:
         return self._L.fp_get_precision(self._h)
 
-    def calibrate_fp8(self, rgb, depth, mask, target_name: str):
-        """One f16 Register of the frame with |max| collection on the trunk activations -> FP8 activation scales."""
+    def calibrate(self, rgb, depth, mask, target_name: str, precision: int = FP_PREC_INT8):
+        """Post-training quantisation of the 8-bit precision on one frame: f16 statistics -> per-channel scales -> bias correction."""
         rgb, depth, mask = self._frame(rgb, depth, mask)
         if rgb is None:
             raise FoundationPoseError(self.last_error)
-        self._must(self._L.fp_calibrate_fp8(self._h, _p(rgb), _p(depth), _p(mask), FP_HOST, depth.shape[0], depth.shape[1],
-                                            target_name.encode()))
+        self._must(self._L.fp_calibrate(self._h, _p(rgb), _p(depth), _p(mask), FP_HOST, depth.shape[0], depth.shape[1],
+                                        target_name.encode(), precision))
+
+    def calibrate_fp8(self, rgb, depth, mask, target_name: str):
+        self.calibrate(rgb, depth, mask, target_name, FP_PREC_FP8)
+
+    def get_calibration_blob(self, precision: int) -> bytes:
+        n = self._L.fp_calibration_size()
+        buf = np.zeros(n, np.uint8)
+        self._must(self._L.fp_get_calibration_blob(self._h, precision, _p(buf), n))
+        return buf.tobytes()
+
+    def set_calibration_blob(self, blob: bytes):
+        buf = np.frombuffer(blob, np.uint8).copy()
+        self._must(self._L.fp_set_calibration_blob(self._h, _p(buf), buf.size))
 
     def get_calibration(self):
         out = np.zeros(32, np.float32)

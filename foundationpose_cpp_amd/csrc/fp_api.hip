@@ -262,8 +262,8 @@ struct fp_model {
   // networks per precision (loaded on demand from the weight files), activation arenas per precision (the border
   // positions of a tensor depend on its element size, so an arena serves one precision)
   std::string refiner_path, scorer_path;
-  Net *refiner_p[3] = {nullptr, nullptr, nullptr}, *scorer_p[3] = {nullptr, nullptr, nullptr};
-  NNScratch *ws_p[3] = {nullptr, nullptr, nullptr};
+  Net *refiner_p[N_PREC] = {nullptr}, *scorer_p[N_PREC] = {nullptr};
+  NNScratch *ws_p[N_PREC] = {nullptr};
   int prec = PREC_F16;
   // float model of the rendering stage: true = multiply-adds contracted like the reference's nvcc -fmad=true build
   // (fp_geometry.hip "float model"), false = every operation separately rounded
@@ -271,8 +271,14 @@ struct fp_model {
   Net *refiner = nullptr, *scorer = nullptr;  // = refiner_p[prec], scorer_p[prec]
   NNScratch *ws = nullptr;                    // = ws_p[prec]
   bool calibrating = false;
-  float calib_amax[2][16];                    // [refiner, scorer] trunk activation |max| of the last calibration
+  // calibration of the 8-bit precisions (fp_calibrate): [refiner, scorer] per-channel |max| / mean of the 15 trunk activations of
+  // the f16 networks on the calibration frame ([15][512] each), and per 8-bit precision the solved corrections (bias [13][512], token
+  // [512]); they are applied to a precision's networks when those are loaded / re-calibrated
+  std::vector<float> calib_amax[2], calib_mean[2];
   bool calibrated = false;
+  std::vector<float> calib_bias_fix[N_PREC][2], calib_tok_fix[N_PREC][2];
+  std::vector<float> calib_out_fix[N_PREC][2];   // output-layer correction: refiner [8] (trans 3 | rot 3 | 0 0), scorer [512]
+  std::vector<float> calib_out_mean[2];          // means of the f16 networks' outputs on the calibration frame (same shapes)
   // pinned staging for hypothesis poses: Register returns from its asynchronous section while the H2D copy may still be
   // queued, so the source must outlive the call (a local std::vector did not: found by the two-model serving test)
   float *track_io = nullptr, *track_io_dev = nullptr;  // host-pinned [hypothesis 16 | refined pose 16] of Track and its device address
@@ -608,7 +614,7 @@ const char *fp_last_error(void) { return g_last_error.c_str(); }
 
 // networks of precision `prec` (loaded on first use) become the model's current ones
 static int select_precision(fp_model *m, int prec) {
-  FP_CHECK(prec == PREC_F16 || prec == PREC_BF16 || prec == PREC_FP8, "[FoundationPose] unknown precision");
+  FP_CHECK(prec == PREC_F16 || prec == PREC_BF16 || prec == PREC_FP8 || prec == PREC_INT8, "[FoundationPose] unknown precision");
   std::string err;
   if (!m->refiner_path.empty() && !m->refiner_p[prec]) {
     m->refiner_p[prec] = net_load(m->refiner_path.c_str(), false, prec, &err);
@@ -618,11 +624,17 @@ static int select_precision(fp_model *m, int prec) {
     m->scorer_p[prec] = net_load(m->scorer_path.c_str(), true, prec, &err);
     FP_CHECK(m->scorer_p[prec] != nullptr, "[FoundationPose] Failed to load scorer weights: " + err);
   }
-  if (prec == PREC_FP8 && m->calibrated) {
-    if (m->refiner_p[prec] && !net_fp8_ready(m->refiner_p[prec]) && net_set_fp8_scales(m->refiner_p[prec], m->calib_amax[0])) return 1;
-    if (m->scorer_p[prec] && !net_fp8_ready(m->scorer_p[prec]) && net_set_fp8_scales(m->scorer_p[prec], m->calib_amax[1])) return 1;
+  if ((prec == PREC_FP8 || prec == PREC_INT8) && m->calibrated) {
+    Net *nets[2] = {m->refiner_p[prec], m->scorer_p[prec]};
+    for (int k = 0; k < 2; k++)
+      if (nets[k] && !net_q8_ready(nets[k]) &&
+          net_apply_q8(nets[k], m->calib_amax[k].data(), m->calib_bias_fix[prec][k].empty() ? nullptr : m->calib_bias_fix[prec][k].data(),
+                       m->calib_tok_fix[prec][k].empty() ? nullptr : m->calib_tok_fix[prec][k].data(), true))
+        return 1;
+    for (int k = 0; k < 2; k++)
+      if (nets[k] && !m->calib_out_fix[prec][k].empty() && net_q8_set_out_fix(nets[k], m->calib_out_fix[prec][k].data())) return 1;
   }
-  if (!m->ws_p[prec]) m->ws_p[prec] = nn_scratch_create();
+  if (!m->ws_p[prec]) m->ws_p[prec] = nn_scratch_create(prec);
   m->prec = prec;
   m->refiner = m->refiner_p[prec];
   m->scorer = m->scorer_p[prec];
@@ -722,7 +734,7 @@ static void destroy_model_impl(fp_model *m) {
   if (m->frame_dev) (void)hipFree(m->frame_dev);
   dev_free(m->grid_dev); dev_free(m->samp_state); dev_free(m->samp_vals); dev_free(m->mask_dev);
   if (m->digests) (void)hipFree(m->digests);
-  for (int i = 0; i < 3; i++) {
+  for (int i = 0; i < N_PREC; i++) {
     if (m->refiner_p[i]) net_free(m->refiner_p[i]);
     if (m->scorer_p[i]) net_free(m->scorer_p[i]);
     if (m->ws_p[i]) nn_scratch_free(m->ws_p[i]);
@@ -1418,13 +1430,14 @@ int fp_set_precision(fp_model *m, int precision) try {
   LifeExclusive life;   // may load the networks of a precision: as exclusive as fp_create
   FP_CHECK(m != nullptr, "[FoundationPose] null model");
   FP_HIP_OK(hipStreamSynchronize(m->stream));
-  FP_CHECK(precision != PREC_FP8 || m->calibrated,
-           "[FoundationPose] FP8 precision needs activation scales: call fp_calibrate_fp8 (or fp_load_calibration) first");
+  FP_CHECK(!(precision == PREC_FP8 || precision == PREC_INT8) || m->calibrated,
+           "[FoundationPose] the 8-bit precisions need a calibration: call fp_calibrate / fp_calibrate_fp8 (or fp_set_calibration_blob) first");
   return select_precision(m, precision);
 } FP_CATCH_INT
 int fp_get_precision(const fp_model *m) { return m ? m->prec : -1; }
 
 int fp_set_float_model(fp_model *m, int fmad) try {
+  LifeExclusive life;   // destroys the captured graphs: not while another thread is inside a call
   FP_CHECK(m != nullptr, "[FoundationPose] null model");
   FP_HIP_OK(hipStreamSynchronize(m->stream));
   m->fmad = fmad != 0;
@@ -1433,43 +1446,200 @@ int fp_set_float_model(fp_model *m, int fmad) try {
 } FP_CATCH_INT
 int fp_get_float_model(const fp_model *m) { return m ? (m->fmad ? 1 : 0) : -1; }
 
-// Post-training static quantisation for FP_PREC_FP8: one Register of the given frame in f16 with |max| collection on
-// every trunk activation of both networks; the per-tensor scales of the FP8 networks follow from it.
-int fp_calibrate_fp8(fp_model *m, const void *rgb, const void *depth, const void *mask, int memspace, int H, int W,
-                     const char *target_name) try {
-  LifeExclusive life;   // loads the FP8 networks; the Register inside nests (depth > 0)
+// Post-training static quantisation for the 8-bit precisions (FP_PREC_FP8 / FP_PREC_INT8):
+//   1. one Register of the frame in f16 records, per channel of the 15 trunk activations of both networks, |max| and the mean;
+//   2. the 8-bit networks are quantised with per-channel activation scales folded into their weights (net_apply_q8);
+//   3. bias correction (Nagel et al., "Data-free quantization through weight equalization and bias correction", 2019 -- here with
+//      data): layer by layer, in trunk order, a Register of the 8-bit model measures the per-channel mean of the layer's output and
+//      the difference to the f16 mean goes into its bias (two sweeps over the 13 layers);
+//   4. what is left of the mean shift of the TOKEN tensor goes into the positional table.
+// The pose is discarded; the model's precision is unchanged.  ~30 Registers, once per deployment (fp_get_calibration_blob).
+static int calibrate_impl(fp_model *m, const void *rgb, const void *depth, const void *mask, int memspace, int H, int W, const char *target_name,
+                          int precision) {
   FP_CHECK(m != nullptr, "[FoundationPose] null model");
-  FP_CHECK(!m->refiner_path.empty() && !m->scorer_path.empty(), "[FoundationPose] fp_calibrate_fp8 needs both networks");
+  FP_CHECK(precision == PREC_FP8 || precision == PREC_INT8, "[FoundationPose] fp_calibrate: precision must be FP_PREC_FP8 or FP_PREC_INT8");
+  FP_CHECK(!m->refiner_path.empty() && !m->scorer_path.empty(), "[FoundationPose] fp_calibrate needs both networks");
   const int prev = m->prec;
   if (select_precision(m, PREC_F16)) return 1;
-  net_calib_begin(m->refiner, m->stream);
-  net_calib_begin(m->scorer, m->stream);
-  m->calibrating = true;
   float pose[16];
-  int rc = fp_register_ex(m, rgb, depth, mask, memspace, H, W, target_name, 1, pose);
-  m->calibrating = false;
-  int rc2 = net_calib_end(m->refiner, m->stream, m->calib_amax[0]) | net_calib_end(m->scorer, m->stream, m->calib_amax[1]);
-  if (rc || rc2) { (void)select_precision(m, prev == PREC_FP8 ? PREC_F16 : prev); return 1; }
+  constexpr size_t NS = (size_t)15 * 512;
+  // means over the hypotheses of what the networks hand to the pose update / the cross-hypothesis head (still in the model's buffers
+  // after a Register): refiner trans | rot, scorer pooled features
+  auto output_means = [&](std::vector<float> (&out)[2]) -> int {
+    const int N = m->n_hyp();
+    std::vector<float> t((size_t)N * 3), r((size_t)N * 3), f((size_t)N * 512);
+    FP_HIP_OK(hipMemcpyAsync(t.data(), m->trans_dev, t.size() * 4, hipMemcpyDeviceToHost, m->stream));
+    FP_HIP_OK(hipMemcpyAsync(r.data(), m->rot_dev, r.size() * 4, hipMemcpyDeviceToHost, m->stream));
+    FP_HIP_OK(hipMemcpyAsync(f.data(), m->feat_dev, f.size() * 4, hipMemcpyDeviceToHost, m->stream));
+    FP_HIP_OK(hipStreamSynchronize(m->stream));
+    out[0].assign(8, 0.f); out[1].assign(512, 0.f);
+    for (int c = 0; c < 3; c++) {
+      double a = 0, b = 0;
+      for (int i = 0; i < N; i++) { a += t[(size_t)i * 3 + c]; b += r[(size_t)i * 3 + c]; }
+      out[0][c] = (float)(a / N); out[0][3 + c] = (float)(b / N);
+    }
+    for (int c = 0; c < 512; c++) {
+      double a = 0;
+      for (int i = 0; i < N; i++) a += f[(size_t)i * 512 + c];
+      out[1][c] = (float)(a / N);
+    }
+    return 0;
+  };
+  auto registered = [&](int mode, int only_act, std::vector<float> *amax, std::vector<float> (&mean)[2]) -> int {
+    Net *nets[2] = {m->refiner, m->scorer};
+    for (Net *n : nets) net_calib_begin(n, m->stream, mode, only_act);
+    m->calibrating = true;
+    int rc = fp_register_ex(m, rgb, depth, mask, memspace, H, W, target_name, 1, pose);
+    m->calibrating = false;
+    for (int k = 0; k < 2; k++) {
+      mean[k].assign(NS, 0.f);
+      if (amax) amax[k].assign(NS, 0.f);
+      rc |= net_calib_end(nets[k], m->stream, amax ? amax[k].data() : nullptr, mean[k].data());
+    }
+    return rc;
+  };
+  if (registered(1, -1, m->calib_amax, m->calib_mean)) { (void)select_precision(m, (prev == PREC_FP8 || prev == PREC_INT8) ? PREC_F16 : prev); return 1; }
+  if (output_means(m->calib_out_mean)) return 1;
   m->calibrated = true;
-  // scales of already loaded FP8 networks are refreshed; otherwise they are applied when FP8 is first selected
-  if (m->refiner_p[PREC_FP8] && net_set_fp8_scales(m->refiner_p[PREC_FP8], m->calib_amax[0])) return 1;
-  if (m->scorer_p[PREC_FP8] && net_set_fp8_scales(m->scorer_p[PREC_FP8], m->calib_amax[1])) return 1;
+  // quantise (or re-quantise) this precision's networks without corrections
+  for (int k = 0; k < 2; k++) {
+    m->calib_bias_fix[precision][k].assign((size_t)13 * 512, 0.f); m->calib_tok_fix[precision][k].assign(512, 0.f);
+    m->calib_out_fix[precision][k].assign(k == 0 ? 8 : 512, 0.f);
+  }
+  {
+    Net *loaded[2] = {m->refiner_p[precision], m->scorer_p[precision]};
+    for (int k = 0; k < 2; k++)
+      if (loaded[k] && (net_apply_q8(loaded[k], m->calib_amax[k].data(), m->calib_bias_fix[precision][k].data(), m->calib_tok_fix[precision][k].data(), true) ||
+                        net_q8_set_out_fix(loaded[k], m->calib_out_fix[precision][k].data()))) return 1;
+  }
+  if (select_precision(m, precision)) return 1;   // (loads and quantises them otherwise)
+  invalidate_graphs(m);
+  Net *qn[2] = {m->refiner, m->scorer};
+  std::vector<float> mq[2];
+  auto target = [&](int k, int a, int c) {   // f16 mean the output channel c of the layer writing activation a should have
+    const std::vector<float> &t = m->calib_mean[k];
+    return a == 5 ? 0.5f * (t[a * 512 + c] + t[a * 512 + c + 128]) : t[a * 512 + c];
+  };
+  constexpr int n_sweeps = 2;   // (tools/q8_check.py, round 4: 0 / 1 / 2 / 3 sweeps -> 88 / 93 / 95-100 / 98 % of the refined poses within 1 mm / 1 deg of the f16 path)
+  for (int sweep = 0; sweep < n_sweeps; sweep++)
+    for (int layer = 0; layer < 13; layer++) {
+      const int a = layer + 2, C = net_q8_bias_channels(layer);
+      if (registered(2, a, nullptr, mq)) return 1;
+      for (int k = 0; k < 2; k++) {
+        std::vector<float> &fix = m->calib_bias_fix[precision][k];
+        for (int c = 0; c < C; c++) {
+          const float got = a == 5 ? 0.5f * (mq[k][a * 512 + c] + mq[k][a * 512 + c + 128]) : mq[k][a * 512 + c];
+          fix[(size_t)layer * 512 + c] += target(k, a, c) - got;
+        }
+        if (net_apply_q8(qn[k], m->calib_amax[k].data(), fix.data(), m->calib_tok_fix[precision][k].data(), false)) return 1;
+      }
+    }
+  if (registered(2, 14, nullptr, mq)) return 1;
+  for (int k = 0; k < 2; k++) {
+    for (int c = 0; c < 512; c++) m->calib_tok_fix[precision][k][c] = m->calib_mean[k][14 * 512 + c] - mq[k][14 * 512 + c];
+    if (net_apply_q8(qn[k], m->calib_amax[k].data(), m->calib_bias_fix[precision][k].data(), m->calib_tok_fix[precision][k].data(), false)) return 1;
+  }
+  // 5. what is left at the OUTPUTS (the heads are non-linear in the token mean): the mean refiner outputs / pooled score feature of
+  //    the 8-bit model on this frame are moved onto the f16 model's through the output layers' biases
+  {
+    if (registered(2, 14, nullptr, mq)) return 1;
+    std::vector<float> om[2];
+    if (output_means(om)) return 1;
+    for (int k = 0; k < 2; k++) {
+      for (size_t c = 0; c < om[k].size(); c++) m->calib_out_fix[precision][k][c] = m->calib_out_mean[k][c] - om[k][c];
+      if (net_q8_set_out_fix(qn[k], m->calib_out_fix[precision][k].data())) return 1;
+    }
+  }
   invalidate_graphs(m);
   return select_precision(m, prev);
+}
+int fp_calibrate(fp_model *m, const void *rgb, const void *depth, const void *mask, int memspace, int H, int W, const char *target_name,
+                 int precision) try {
+  LifeExclusive life;   // loads networks; the Registers inside nest (depth > 0)
+  const int prev = m ? m->prec : 0;
+  const int rc = calibrate_impl(m, rgb, depth, mask, memspace, H, W, target_name, precision);
+  if (rc && m) {   // leave the model usable
+    m->calibrating = false;
+    (void)hipStreamSynchronize(m->stream);
+    const bool q8_prev = prev == PREC_FP8 || prev == PREC_INT8;
+    (void)select_precision(m, q8_prev && !net_q8_ready(m->refiner_p[prev] ? m->refiner_p[prev] : m->scorer_p[prev]) ? PREC_F16 : prev);
+  }
+  return rc;
 } FP_CATCH_INT
-int fp_get_calibration(const fp_model *m, float amax_out[32]) try {
-  FP_CHECK(m && m->calibrated && amax_out, "[FoundationPose] no calibration available");
-  std::memcpy(amax_out, m->calib_amax, sizeof(m->calib_amax));
+int fp_calibrate_fp8(fp_model *m, const void *rgb, const void *depth, const void *mask, int memspace, int H, int W,
+                     const char *target_name) try {
+  return fp_calibrate(m, rgb, depth, mask, memspace, H, W, target_name, PREC_FP8);
+} FP_CATCH_INT
+
+// ---- the calibration record: [magic "FPQ8", version, precision, 0] + amax [2][15][512] + bias_fix [2][13][512] + tok_fix [2][512] + out_fix [8 | 512] (f32)
+static constexpr uint32_t kCalibMagic = 0x38515046u;
+static constexpr size_t kCalibFloats = (size_t)2 * 15 * 512 + (size_t)2 * 13 * 512 + (size_t)2 * 512 + 8 + 512;
+size_t fp_calibration_size(void) { return 16 + kCalibFloats * sizeof(float); }
+int fp_get_calibration_blob(const fp_model *m, int precision, void *out, size_t capacity) try {
+  FP_CHECK(m && out && (precision == PREC_FP8 || precision == PREC_INT8), "[FoundationPose] fp_get_calibration_blob: invalid arguments");
+  FP_CHECK(m->calibrated && !m->calib_bias_fix[precision][0].empty(), "[FoundationPose] no calibration available for this precision");
+  FP_CHECK(capacity >= fp_calibration_size(), "[FoundationPose] fp_get_calibration_blob: buffer too small (fp_calibration_size)");
+  uint32_t hdr[4] = {kCalibMagic, 1u, (uint32_t)precision, 0u};
+  unsigned char *p = (unsigned char *)out;
+  std::memcpy(p, hdr, 16); p += 16;
+  for (int k = 0; k < 2; k++) { std::memcpy(p, m->calib_amax[k].data(), 15 * 512 * 4); p += 15 * 512 * 4; }
+  for (int k = 0; k < 2; k++) { std::memcpy(p, m->calib_bias_fix[precision][k].data(), 13 * 512 * 4); p += 13 * 512 * 4; }
+  for (int k = 0; k < 2; k++) { std::memcpy(p, m->calib_tok_fix[precision][k].data(), 512 * 4); p += 512 * 4; }
+  for (int k = 0; k < 2; k++) { const size_t n = k == 0 ? 8 : 512; std::memcpy(p, m->calib_out_fix[precision][k].data(), n * 4); p += n * 4; }
   return 0;
 } FP_CATCH_INT
+int fp_set_calibration_blob(fp_model *m, const void *blob, size_t bytes) try {
+  LifeExclusive life;
+  FP_CHECK(m && blob && bytes == fp_calibration_size(), "[FoundationPose] fp_set_calibration_blob: invalid arguments / size");
+  uint32_t hdr[4];
+  const unsigned char *p = (const unsigned char *)blob;
+  std::memcpy(hdr, p, 16); p += 16;
+  FP_CHECK(hdr[0] == kCalibMagic && hdr[1] == 1u && (hdr[2] == (uint32_t)PREC_FP8 || hdr[2] == (uint32_t)PREC_INT8), "[FoundationPose] not a calibration record of this library version");
+  const int precision = (int)hdr[2];
+  FP_HIP_OK(hipStreamSynchronize(m->stream));
+  for (int k = 0; k < 2; k++) { m->calib_amax[k].assign((const float *)p, (const float *)p + 15 * 512); p += 15 * 512 * 4; }
+  for (int k = 0; k < 2; k++) { m->calib_bias_fix[precision][k].assign((const float *)p, (const float *)p + 13 * 512); p += 13 * 512 * 4; }
+  for (int k = 0; k < 2; k++) { m->calib_tok_fix[precision][k].assign((const float *)p, (const float *)p + 512); p += 512 * 4; }
+  for (int k = 0; k < 2; k++) { const size_t n = k == 0 ? 8 : 512; m->calib_out_fix[precision][k].assign((const float *)p, (const float *)p + n); p += n * 4; }
+  for (int k = 0; k < 2; k++)
+    for (float v : m->calib_amax[k]) FP_CHECK(std::isfinite(v) && v >= 0.f, "[FoundationPose] calibration record holds non-finite values");
+  m->calibrated = true;
+  Net *loaded[2] = {m->refiner_p[precision], m->scorer_p[precision]};
+  for (int k = 0; k < 2; k++)
+    if (loaded[k] && (net_apply_q8(loaded[k], m->calib_amax[k].data(), m->calib_bias_fix[precision][k].data(), m->calib_tok_fix[precision][k].data(), true) ||
+                      net_q8_set_out_fix(loaded[k], m->calib_out_fix[precision][k].data()))) return 1;
+  invalidate_graphs(m);
+  return 0;
+} FP_CATCH_INT
+// legacy per-tensor view (round 2/3 API): |max| over the channels of each trunk activation, [refiner 16 | scorer 16]
+int fp_get_calibration(const fp_model *m, float amax_out[32]) try {
+  FP_CHECK(m && m->calibrated && amax_out, "[FoundationPose] no calibration available");
+  for (int k = 0; k < 2; k++)
+    for (int a = 0; a < 16; a++) {
+      float v = 0.f;
+      if (a < 15) for (int c = 0; c < 512; c++) v = std::max(v, m->calib_amax[k][a * 512 + c]);
+      amax_out[k * 16 + a] = v;
+    }
+  return 0;
+} FP_CATCH_INT
+// legacy: per-tensor |max| only -> every channel of a tensor gets the tensor's scale, no bias / token correction (FP8 networks)
 int fp_set_calibration(fp_model *m, const float amax[32]) try {
-  SerialGuard serial;
+  LifeExclusive life;
   FP_CHECK(m && amax, "[FoundationPose] fp_set_calibration: invalid arguments");
   FP_HIP_OK(hipStreamSynchronize(m->stream));
-  std::memcpy(m->calib_amax, amax, sizeof(m->calib_amax));
+  for (int k = 0; k < 2; k++) {
+    m->calib_amax[k].assign((size_t)15 * 512, 0.f);
+    for (int a = 0; a < 15; a++)
+      for (int c = 0; c < 512; c++) m->calib_amax[k][a * 512 + c] = amax[k * 16 + a];
+    for (int pr : {PREC_FP8, PREC_INT8}) { m->calib_bias_fix[pr][k].assign((size_t)13 * 512, 0.f); m->calib_tok_fix[pr][k].assign(512, 0.f); m->calib_out_fix[pr][k].assign(k == 0 ? 8 : 512, 0.f); }
+  }
   m->calibrated = true;
-  if (m->refiner_p[PREC_FP8] && net_set_fp8_scales(m->refiner_p[PREC_FP8], m->calib_amax[0])) return 1;
-  if (m->scorer_p[PREC_FP8] && net_set_fp8_scales(m->scorer_p[PREC_FP8], m->calib_amax[1])) return 1;
+  for (int pr : {PREC_FP8, PREC_INT8}) {
+    Net *loaded[2] = {m->refiner_p[pr], m->scorer_p[pr]};
+    for (int k = 0; k < 2; k++)
+      if (loaded[k] && (net_apply_q8(loaded[k], m->calib_amax[k].data(), m->calib_bias_fix[pr][k].data(), m->calib_tok_fix[pr][k].data(), true) ||
+                        net_q8_set_out_fix(loaded[k], m->calib_out_fix[pr][k].data()))) return 1;
+  }
   invalidate_graphs(m);
   return 0;
 } FP_CATCH_INT
@@ -1518,7 +1688,7 @@ fp_net *fp_net_create(const char *weights_path, int is_scorer, int max_batch) tr
   std::string err;
   n->net = net_load(weights_path, n->scorer, PREC_F16, &err);
   if (!n->net) { set_error("[FoundationPose] Failed to load network weights: " + err); return nullptr; }
-  n->ws = nn_scratch_create();
+  n->ws = nn_scratch_create(PREC_F16);
   const size_t in_elems = (size_t)max_batch * FP_CROP_HW * FP_CROP_HW * 6;
   bool ok = hipStreamCreateWithFlags(&n->stream, hipStreamNonBlocking) == hipSuccess;
   for (int i = 0; ok && i < 2; i++) ok = !dev_alloc(&n->in_dev[i], in_elems) && !dev_alloc(&n->out_dev[i], (size_t)max_batch * 3);

@@ -7,11 +7,15 @@
 namespace fp {
 
 // element types of device tensors / MFMA operands
-enum { DT_F16 = 0, DT_BF16 = 1, DT_FP8 = 2 };
+// DT_FP8 = OCP e4m3 (v_mfma_f32_16x16x128_f8f6f4), DT_I8 = signed 8-bit integers (v_mfma_i32_16x16x64_i8; activations are unsigned
+// 8-bit values stored with an offset of -128).  Output-type codes of the convolution kernels additionally use DT_DUAL_FP8 /
+// DT_DUAL_I8: an f16 tensor (the residual stream) AND its 8-bit copy (the next convolution's operand) written by one epilogue.
+enum { DT_F16 = 0, DT_BF16 = 1, DT_FP8 = 2, DT_I8 = 3, DT_DUAL_FP8 = 4, DT_DUAL_I8 = 5 };
 // network precision (include/foundationpose_amd.h FP_PREC_*): F16 = the reference's TensorRT --fp16 engines; BF16 = every
 // tensor and MFMA operand in bf16 (BASELINE configs[1]); FP8 = the 3x3 trunk convolutions from encodeA.2 on in OCP e4m3
-// with per-channel weight / per-tensor activation scales, everything else f16 (BASELINE configs[4])
-enum { PREC_F16 = 0, PREC_BF16 = 1, PREC_FP8 = 2 };
+// with per-channel weight / activation scales, everything else f16 (BASELINE configs[4]); INT8 = the same layers on 8-bit
+// integers (same matrix-pipe rate class, 5-7x lower rounding noise on the activations: DESIGN.md section 4.4)
+enum { PREC_F16 = 0, PREC_BF16 = 1, PREC_FP8 = 2, PREC_INT8 = 3, N_PREC = 4 };
 
 struct Net;        // packed weights of one network, resident in HBM
 struct NNScratch;  // activation buffers, grown on demand (one object per precision: border positions depend on element size)
@@ -22,15 +26,21 @@ Net *net_load(const char *path, bool is_scorer, int prec, std::string *err);
 void net_free(Net *);
 int net_precision(const Net *);
 int net_input_dt(const Net *);   // element type the network expects for nn_in (DT_F16 or DT_BF16)
-bool net_fp8_ready(const Net *); // false only for an FP8 network whose activation scales have not been set
+bool net_q8_ready(const Net *);  // false only for an 8-bit network (PREC_FP8 / PREC_INT8) that has not been given a calibration
 
-// FP8 calibration: run a 2-byte network between begin / end to collect |max| of its 15 trunk activations, then hand the
-// result to the FP8 network of the same weights.
-void net_calib_begin(Net *net, hipStream_t s);
-int net_calib_end(Net *net, hipStream_t s, float amax_out[16]);
-int net_set_fp8_scales(Net *fp8_net, const float amax[16]);
+// Calibration of the 8-bit networks (fp_api.hip: fp_calibrate).  While a network runs between begin / end its trunk records per-channel
+// statistics of its 15 activations ([15][512] floats each): mode 1 (the f16 network) |max| and sum of the values, mode 2 (an 8-bit
+// network) the sum of the de-quantised values.  net_apply_q8 turns amax (+ the solved bias / token corrections, null = zero) into
+// per-channel activation scales folded into re-quantised weights, corrected biases and the corrected positional table;
+// weights = false rebuilds only the biases / the table (the correction sweeps).
+void net_calib_begin(Net *net, hipStream_t s, int mode, int only_act = -1);   // only_act >= 0: record that activation only
+int net_calib_end(Net *net, hipStream_t s, float *amax_out, float *mean_out);   // [15][512] each; means over the interior pixels
+int net_apply_q8(Net *q8_net, const float *amax /*[15][512]*/, const float *bias_fix /*[13][512]*/, const float *tok_fix /*[512]*/, bool weights);
+int net_q8_set_out_fix(Net *q8_net, const float *fix /* refiner: [6] trans | rot biases; scorer: [512] pooled-feature bias */);
+void net_q8_get_fix(const Net *q8_net, float *bias_fix /*[13][512]*/, float *tok_fix /*[512]*/);
+int net_q8_bias_channels(int layer);   // output channels of 8-bit layer 0..12 (layer i writes trunk activation i + 2)
 
-NNScratch *nn_scratch_create();
+NNScratch *nn_scratch_create(int prec);
 void nn_scratch_free(NNScratch *);
 // debug (cross-model corruption checks): the activation arena and the f32 side buffer
 void nn_scratch_debug_info(const NNScratch *, const void **buf, size_t *bytes, const void **f32, size_t *f32_bytes);

@@ -78,16 +78,36 @@ __device__ __forceinline__ f4 mfma32(i4 a, i4 b, f4 c) {  // one 16x16x32 step o
 __device__ __forceinline__ f4 mfma128_fp8(i8 a, i8 b, f4 c) {
   return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 0 /*A: fp8 e4m3*/, 0 /*B: fp8 e4m3*/, 0, 0, 0, 0);
 }
+// 8-bit operand types: DT_FP8 and DT_I8 share the byte geometry (a 128-byte LDS row = 128 channels = one 32-byte operand per lane
+// group: chunks kg and 4+kg) and differ only in the matrix instruction.  DT_I8: the same 32 bytes feed TWO
+// v_mfma_i32_16x16x64_i8 (16 cycles each = the 32 cycles of the one 128-wide FP8 instruction); the int32 accumulators live in
+// the same f4 registers as raw bits (float 0.0 == int 0), the epilogue converts.
+__host__ __device__ constexpr bool is_q8(int dt) { return dt == DT_FP8 || dt == DT_I8; }
+template <int DT>
+__device__ __forceinline__ f4 mfma8(i8 a, i8 b, f4 c) {
+  static_assert(is_q8(DT), "8-bit operand types");
+  if constexpr (DT == DT_FP8) return mfma128_fp8(a, b, c);
+  else {
+    i4 ci = __builtin_bit_cast(i4, c);
+    ci = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_shufflevector(a, a, 0, 1, 2, 3), __builtin_shufflevector(b, b, 0, 1, 2, 3), ci, 0, 0, 0);
+    ci = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_shufflevector(a, a, 4, 5, 6, 7), __builtin_shufflevector(b, b, 4, 5, 6, 7), ci, 0, 0, 0);
+    return __builtin_bit_cast(f4, ci);
+  }
+}
+// output-type codes (fp_nn.h): which tensors an epilogue writes
+__host__ __device__ constexpr bool odt_dual(int odt) { return odt == DT_DUAL_FP8 || odt == DT_DUAL_I8; }
+__host__ __device__ constexpr int odt_q(int odt) { return odt == DT_DUAL_FP8 ? DT_FP8 : odt == DT_DUAL_I8 ? DT_I8 : is_q8(odt) ? odt : -1; }   // 8-bit type written, or -1
+__host__ __device__ constexpr int odt_16(int odt) { return odt_dual(odt) ? DT_F16 : is_q8(odt) ? -1 : odt; }                                  // 2-byte type written, or -1
 // all MFMAs of one 128-byte K-step: w[ks][ni] / x[ks][mi] are the two 16-byte fragment reads of each row
 template <int DT, int NI, int MI>
 __device__ __forceinline__ void mma_kstep(f4 (&acc)[NI][MI], const i4 (&w)[2][NI], const i4 (&x)[2][MI]) {
-  if constexpr (DT == DT_FP8) {
+  if constexpr (is_q8(DT)) {
 #pragma unroll
     for (int ni = 0; ni < NI; ni++) {
       const i8 wv = __builtin_shufflevector(w[0][ni], w[1][ni], 0, 1, 2, 3, 4, 5, 6, 7);
 #pragma unroll
       for (int mi = 0; mi < MI; mi++)
-        acc[ni][mi] = mfma128_fp8(wv, __builtin_shufflevector(x[0][mi], x[1][mi], 0, 1, 2, 3, 4, 5, 6, 7), acc[ni][mi]);
+        acc[ni][mi] = mfma8<DT>(wv, __builtin_shufflevector(x[0][mi], x[1][mi], 0, 1, 2, 3, 4, 5, 6, 7), acc[ni][mi]);
     }
   } else {
 #pragma unroll
@@ -159,7 +179,7 @@ __device__ __forceinline__ void store8(unsigned char *ptr, int dt, const float (
     *reinterpret_cast<h8 *>(ptr) = v;
   }
 }
-__host__ __device__ constexpr int elem_bytes(int dt) { return dt == DT_FP8 ? 1 : 2; }
+__host__ __device__ constexpr int elem_bytes(int dt) { return (dt == DT_FP8 || dt == DT_I8) ? 1 : 2; }
 
 // =================================================================================================
 // implicit-GEMM convolution
@@ -224,13 +244,14 @@ struct ConvParams {
   const float *cscale;       // FP8 input: [Cout] activation scale * weight scale of the channel; null otherwise
   const unsigned char *res;  // optional residual [NB, OH+2*rpad, OW+2*rpad, res_ld], element type res_dt
   unsigned char *out;        // [NB', OH+2*opad, OW+2*opad, out_ld], element type out_dt
+  unsigned char *out2;       // DT_DUAL_* outputs: the 8-bit copy (same shape, 1 byte per element); null otherwise
+  const float *oinv;         // DT_DUAL_* outputs: [out_ld channels... indexed by the layer's OUTPUT channel] 1 / scale of the 8-bit copy
   int NB, H, W, Cin, OH, OW, Cout, KH, KW, stride, pad;
   int ipad, opad, rpad;
   int M, Ktot, relu, out_ld, res_ld, split_imgs;
   int cin_b;      // bytes per input pixel  (Cin  * element size)
   int krow_b;     // bytes per weight row   (Ktot * element size); K-steps of 128 bytes: krow_b >> 7, of 64 bytes: krow_b >> 6
   int out_dt, res_dt;          // DT_* of the output / residual tensors
-  float res_scale, out_inv;    // FP8 tensors: residual real value = stored * res_scale; stored output = real * out_inv
   int ntaps;  // KH*KW; for Cin >= 64 the K order is (128-byte channel chunk outer, tap inner) so the taps of a chunk
               // are consecutive K-steps and their overlapping input pixels are re-read while still L2-resident
   // byte offset of K-step kt's X slab relative to a row's (tap 0, channel 0) address; host-filled, read with s_load
@@ -259,27 +280,50 @@ struct ConvParams {
 // twice the store instructions; the 256x256 kernel spent 13 us of a 70 us workgroup in its store burst).
 // All bias and residual loads are issued BEFORE the first store: on CDNA4 stores also count in vmcnt, so a load issued
 // behind a store cannot be waited for without draining the store.
-// DT = the kernel's operand type = the residual's element type: an FP8 kernel multiplies by the per-channel dequantisation
-// scale first.  ODT = the output element type (differs from DT only in the two layers at a precision boundary).
+// DT = the kernel's operand type.  8-bit kernels (DT_FP8 / DT_I8) [r4]: acc (float, or int32 bits for DT_I8) * cscale[c] + bias[c]
+// -- cscale = the weight row's scale; the per-INPUT-channel activation scales are folded into the weights before they are quantised
+// (net_apply_q8) -- and the residual is ALWAYS f16 (the skip path of the 8-bit networks is never re-quantised).
+// ODT = what is written (fp_nn.h):
+//   2-byte type            p.out, as before;
+//   DT_FP8 / DT_I8         p.out only, no scaling here: the consumer's per-channel scales are folded into this layer's cscale / bias
+//                          on the host (legal because these layers have no residual and end in a ReLU);
+//   DT_DUAL_FP8 / _I8      an f16 tensor at p.out (the residual stream) AND its 8-bit copy at p.out2 = value * oinv[c] (the next
+//                          convolution's operand); both tensors have the same shape / border, so one element offset serves both.
 // The epilogue covers channel tiles [NI0, NI0 + NI) of an accumulator array of NIT tiles (the stem: two 32-channel passes
 // over its 4 tiles; the array is passed whole so that it stays in registers).
+__device__ __forceinline__ int pack4_fp8(float a, float b, float c, float d) {
+  int w = __builtin_amdgcn_cvt_pk_fp8_f32(sat_fp8(a), sat_fp8(b), 0, false);
+  return __builtin_amdgcn_cvt_pk_fp8_f32(sat_fp8(c), sat_fp8(d), w, true);
+}
+// unsigned 8-bit activations (round to nearest even, saturating to [0, 255]) stored with an offset of -128 (x ^ 0x80) so that the
+// signed-integer MFMA can consume them; the offset's contribution, 128 * sum_k w, is folded into the consumer's bias on the host
+__device__ __forceinline__ int pack4_u8(float a, float b, float c, float d) {
+  unsigned w = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_rintf(a), 0, 0u);
+  w = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_rintf(b), 1, w);
+  w = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_rintf(c), 2, w);
+  w = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_rintf(d), 3, w);
+  return (int)(w ^ 0x80808080u);
+}
 template <int MI, int NI, int DT, int ODT, int EABL = 0, int NIT = NI, int NI0 = 0, class PixFn>  // EABL: 1 = no stores, 2 = no residual loads (timing ablations / layers without residual), 4 = add ConvParams::post
 __device__ __forceinline__ void conv_epilogue_px(const ConvParams &p, f4 (&acc)[NIT][MI], int n_base, int lane, PixFn pix,
                                                  int bias_off = 0, int res_img_off = 0) {
   static_assert(NI == 4 || NI == 2, "wave covers 64 or 32 channels");
   constexpr int NS = NI / 2;  // 8-channel stores per pixel per lane
+  constexpr int O16 = odt_16(ODT), OQ = odt_q(ODT);
+  constexpr bool DUAL = odt_dual(ODT);
+  constexpr int RDT = is_q8(DT) ? DT_F16 : DT;
   const int OHp = p.OH + 2 * p.opad, OWp = p.OW + 2 * p.opad;
   const int RHp = p.OH + 2 * p.rpad, RWp = p.OW + 2 * p.rpad;
   const int g = lane >> 4;
   const int nl = n_base + 8 * g;  // store k covers channels nl + 32*k .. +7
-  constexpr int oes = elem_bytes(ODT), res_es = elem_bytes(DT);
+  constexpr int res_es = elem_bytes(RDT);
   // pass 1, in place: acc = acc [* dequantisation scale] + bias (8 channels of bias / scale live at a time)
 #pragma unroll
   for (int k = 0; k < NS; k++) {
     float bv[8], sc[8];
     float4 b0 = *reinterpret_cast<const float4 *>(p.bias + bias_off + nl + 32 * k), b1 = *reinterpret_cast<const float4 *>(p.bias + bias_off + nl + 32 * k + 4);
     bv[0] = b0.x; bv[1] = b0.y; bv[2] = b0.z; bv[3] = b0.w; bv[4] = b1.x; bv[5] = b1.y; bv[6] = b1.z; bv[7] = b1.w;
-    if constexpr (DT == DT_FP8) {
+    if constexpr (is_q8(DT)) {
       float4 s0 = *reinterpret_cast<const float4 *>(p.cscale + bias_off + nl + 32 * k), s1 = *reinterpret_cast<const float4 *>(p.cscale + bias_off + nl + 32 * k + 4);
       sc[0] = s0.x; sc[1] = s0.y; sc[2] = s0.z; sc[3] = s0.w; sc[4] = s1.x; sc[5] = s1.y; sc[6] = s1.z; sc[7] = s1.w;
     }
@@ -289,15 +333,26 @@ __device__ __forceinline__ void conv_epilogue_px(const ConvParams &p, f4 (&acc)[
       const int ni = (NI == 4) ? (e & 3) : (e & 1);
 #pragma unroll
       for (int mi = 0; mi < MI; mi++) {
-        if constexpr (DT == DT_FP8) acc[NI0 + ni][mi][jj] = __builtin_fmaf(acc[NI0 + ni][mi][jj], sc[e], bv[e]);
+        // (__float_as_int takes the element BY VALUE: __builtin_bit_cast on a vector-element lvalue reads element 0 of the vector)
+        if constexpr (DT == DT_I8) acc[NI0 + ni][mi][jj] = __builtin_fmaf((float)__float_as_int(acc[NI0 + ni][mi][jj]), sc[e], bv[e]);
+        else if constexpr (DT == DT_FP8) acc[NI0 + ni][mi][jj] = __builtin_fmaf(acc[NI0 + ni][mi][jj], sc[e], bv[e]);
         else acc[NI0 + ni][mi][jj] += bv[e];
       }
     }
   }
+  float oi[DUAL ? NS : 1][8];  // DUAL: 1 / (scale of output channel c in the 8-bit copy)
+  if constexpr (DUAL) {
+#pragma unroll
+    for (int k = 0; k < NS; k++) {
+      float4 s0 = *reinterpret_cast<const float4 *>(p.oinv + nl + 32 * k), s1 = *reinterpret_cast<const float4 *>(p.oinv + nl + 32 * k + 4);
+      oi[k][0] = s0.x; oi[k][1] = s0.y; oi[k][2] = s0.z; oi[k][3] = s0.w; oi[k][4] = s1.x; oi[k][5] = s1.y; oi[k][6] = s1.z; oi[k][7] = s1.w;
+    }
+  }
   // pixels in groups of at most 8 fragments (4 with a positional table): a group's residual / table values stay in registers
   constexpr bool POST = (EABL & 4) != 0;
-  static_assert(!POST || ODT != DT_FP8, "the positional table is added to 2-byte outputs");
-  constexpr int GB = POST ? (MI > 4 ? 4 : MI) : (MI > 8 ? (MI + 1) / 2 : MI);
+  static_assert(!POST || (O16 >= 0 && !DUAL), "the positional table is added to plain 2-byte outputs");
+  // (8-bit kernels: groups of 4 -- their f16 residual values are twice the bytes of the operands and the FP8 instantiations sit at the register limit)
+  constexpr int GB = (POST || is_q8(DT)) ? (MI > 4 ? 4 : MI) : (MI > 8 ? (MI + 1) / 2 : MI);
 #pragma unroll
   for (int g0 = 0; g0 < MI; g0 += GB) {
   size_t oofs[GB];
@@ -321,7 +376,7 @@ __device__ __forceinline__ void conv_epilogue_px(const ConvParams &p, f4 (&acc)[
       size_t rpix = ((size_t)(img - res_img_off) * RHp + oh + p.rpad) * RWp + ow + p.rpad;
 #pragma unroll
       for (int k = 0; k < NS; k++)
-        rv[k][gi] = ok[gi] ? load8_raw(p.res + (rpix * p.res_ld + nl + 32 * k) * res_es, DT) : (i4){0, 0, 0, 0};
+        rv[k][gi] = ok[gi] ? load8_raw(p.res + (rpix * p.res_ld + nl + 32 * k) * res_es, RDT) : (i4){0, 0, 0, 0};
     }
   }
 #pragma unroll
@@ -331,41 +386,41 @@ __device__ __forceinline__ void conv_epilogue_px(const ConvParams &p, f4 (&acc)[
     if (!ok[gi]) continue;
 #pragma unroll
     for (int k = 0; k < NS; k++) {
-      i4 ov = {0, 0, 0, 0};  // packed output: 8 two-byte values, or 8 FP8 bytes in ov[0..1]
+      i4 ov = {0, 0, 0, 0};  // packed 2-byte output: 8 values
+      i2 oq = {0, 0};        // packed 8-bit output: 8 bytes
 #pragma unroll
-      for (int e2 = 0; e2 < 8; e2 += 2) {
-        float v2[2];
+      for (int e4 = 0; e4 < 8; e4 += 4) {
+        float v4[4];
 #pragma unroll
-        for (int h = 0; h < 2; h++) {
-          const int e = e2 + h;
+        for (int h = 0; h < 4; h++) {
+          const int e = e4 + h;
           const int jj = (NI == 4) ? 2 * k + (e >> 2) : (e >> 1);
           const int ni = (NI == 4) ? (e & 3) : (e & 1);
           float v = acc[NI0 + ni][mi][jj];
-          if (p.res && !(EABL & 2)) {
-            if constexpr (DT == DT_FP8) v = __builtin_fmaf(raw_elem<DT>(rv[k][gi], e), p.res_scale, v);
-            else v += raw_elem<DT>(rv[k][gi], e);
-          }
+          if (p.res && !(EABL & 2)) v += raw_elem<RDT>(rv[k][gi], e);
           if (p.relu) v = fmaxf(v, 0.f);
-          if constexpr (ODT == DT_FP8) v = sat_fp8(v * p.out_inv);
-          if constexpr (POST) v = (float)(typename ElemT<ODT>::t)v + raw_elem<ODT>(pv[k][gi], e);  // = add_pos_embed_kernel on the stored value
-          v2[h] = v;
+          if constexpr (POST) v = (float)(typename ElemT<O16 < 0 ? DT_F16 : O16>::t)v + raw_elem<O16 < 0 ? DT_F16 : O16>(pv[k][gi], e);  // = add_pos_embed_kernel on the stored value
+          v4[h] = v;
         }
-        if constexpr (ODT == DT_FP8) {
-          if (e2 == 0) ov[0] = __builtin_amdgcn_cvt_pk_fp8_f32(v2[0], v2[1], ov[0], false);
-          else if (e2 == 2) ov[0] = __builtin_amdgcn_cvt_pk_fp8_f32(v2[0], v2[1], ov[0], true);
-          else if (e2 == 4) ov[1] = __builtin_amdgcn_cvt_pk_fp8_f32(v2[0], v2[1], ov[1], false);
-          else ov[1] = __builtin_amdgcn_cvt_pk_fp8_f32(v2[0], v2[1], ov[1], true);
-        } else {
-          typedef typename ElemT<ODT>::t OE;
+        if constexpr (O16 >= 0) {
+          typedef typename ElemT<O16 < 0 ? DT_F16 : O16>::t OE;
           typedef OE oe2 __attribute__((ext_vector_type(2)));
-          const oe2 pr = {(OE)v2[0], (OE)v2[1]};
-          ov[e2 >> 1] = __builtin_bit_cast(int, pr);
+          const oe2 p0 = {(OE)v4[0], (OE)v4[1]}, p1 = {(OE)v4[2], (OE)v4[3]};
+          ov[e4 >> 1] = __builtin_bit_cast(int, p0);
+          ov[(e4 >> 1) + 1] = __builtin_bit_cast(int, p1);
+        }
+        if constexpr (OQ >= 0) {
+          if constexpr (DUAL) {
+#pragma unroll
+            for (int h = 0; h < 4; h++) v4[h] *= oi[k][e4 + h];
+          }
+          if constexpr (OQ == DT_FP8) oq[e4 >> 2] = pack4_fp8(v4[0], v4[1], v4[2], v4[3]);
+          else oq[e4 >> 2] = pack4_u8(v4[0], v4[1], v4[2], v4[3]);
         }
       }
-      unsigned char *dst = p.out + (oofs[gi] + nl + 32 * k) * oes;
-      if (EABL & 1) asm volatile("" ::"v"(ov));
-      else if constexpr (ODT == DT_FP8) *reinterpret_cast<i2 *>(dst) = (i2){ov[0], ov[1]};
-      else *reinterpret_cast<i4 *>(dst) = ov;
+      if (EABL & 1) { asm volatile("" ::"v"(ov)); asm volatile("" ::"v"(oq)); continue; }
+      if constexpr (O16 >= 0) *reinterpret_cast<i4 *>(p.out + (oofs[gi] + nl + 32 * k) * 2) = ov;
+      if constexpr (OQ >= 0) *reinterpret_cast<i2 *>((DUAL ? p.out2 : p.out) + (oofs[gi] + nl + 32 * k)) = oq;
     }
   }
   }
@@ -396,7 +451,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams &p, f4 (&acc)[NI]
 // fragments go through it in groups of HM.  2-byte output types, no positional table.
 template <int MI, int NI, int DT, int ODT, int HM>
 __device__ __forceinline__ void conv_epilogue_lds(const ConvParams &p, f4 (&acc)[NI][MI], int m_base, int n_base, int lane, unsigned char *tile) {
-  static_assert(NI == 4 && ODT != DT_FP8 && MI % HM == 0, "64-channel wave tiles, 2-byte outputs");
+  static_assert(NI == 4 && !is_q8(DT) && odt_q(ODT) < 0 && MI % HM == 0, "64-channel wave tiles, 2-byte operands and outputs");
   constexpr int RB = NI * 32;                 // bytes per pixel row of the tile (64 channels x 2 B)
   constexpr int res_es = elem_bytes(DT);
   const int OHp = p.OH + 2 * p.opad, OWp = p.OW + 2 * p.opad;
@@ -405,15 +460,11 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvParams &p, f4 (&acc)
   const int nl = n_base + 8 * g;
   const int ohw = p.OH * p.OW;
   unsigned *otab = reinterpret_cast<unsigned *>(tile + HM * 16 * RB);
-  float bv[2][8], sc[2][8];
+  float bv[2][8];
 #pragma unroll
   for (int k = 0; k < 2; k++) {
     const float4 b0 = *reinterpret_cast<const float4 *>(p.bias + nl + 32 * k), b1 = *reinterpret_cast<const float4 *>(p.bias + nl + 32 * k + 4);
     bv[k][0] = b0.x; bv[k][1] = b0.y; bv[k][2] = b0.z; bv[k][3] = b0.w; bv[k][4] = b1.x; bv[k][5] = b1.y; bv[k][6] = b1.z; bv[k][7] = b1.w;
-    if constexpr (DT == DT_FP8) {
-      const float4 s0 = *reinterpret_cast<const float4 *>(p.cscale + nl + 32 * k), s1 = *reinterpret_cast<const float4 *>(p.cscale + nl + 32 * k + 4);
-      sc[k][0] = s0.x; sc[k][1] = s0.y; sc[k][2] = s0.z; sc[k][3] = s0.w; sc[k][4] = s1.x; sc[k][5] = s1.y; sc[k][6] = s1.z; sc[k][7] = s1.w;
-    }
   }
 #pragma unroll
   for (int h0 = 0; h0 < MI; h0 += HM) {
@@ -451,12 +502,8 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvParams &p, f4 (&acc)
           for (int hh = 0; hh < 2; hh++) {
             const int e = e2 + hh, jj = 2 * k + (e >> 2), ni = e & 3;
             float v = acc[ni][mi][jj];
-            if constexpr (DT == DT_FP8) v = __builtin_fmaf(v, sc[k][e], bv[k][e]);
-            else v += bv[k][e];
-            if (p.res) {
-              if constexpr (DT == DT_FP8) v = __builtin_fmaf(raw_elem<DT>(rv[q][k], e), p.res_scale, v);
-              else v += raw_elem<DT>(rv[q][k], e);
-            }
+            v += bv[k][e];
+            if (p.res) v += raw_elem<DT>(rv[q][k], e);
             if (p.relu) v = fmaxf(v, 0.f);
             v2[hh] = v;
           }
@@ -617,7 +664,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
       if (VAR & 1) __builtin_amdgcn_s_setprio(0);
       return;
     }
-    if constexpr (DT != DT_FP8) {
+    if constexpr (!is_q8(DT)) {
 #pragma unroll
     for (int ks = 0; ks < 2; ks++) {
       i4 xf[4], wf[NREP];
@@ -674,7 +721,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
 // instead of vmcnt(1): with conditional prologue loads the in-order counter has to assume the shortest path).
 template <int MI, int NI, int DT, int ODT, bool POST, bool DEEP>  // NI = 4: 64 channels per workgroup (Cout % 128 == 0); NI = 2: 32 (the row permutation of Cout == 64 layers)
 __global__ __launch_bounds__(256, 2) void conv_smallm_kernel(const ConvParams p) {
-  static_assert(DT != DT_FP8, "2-byte operand types");
+  static_assert(!is_q8(DT), "2-byte operand types");
   constexpr int PF = MI == 1 ? 4 : 3;         // K-steps in flight per wave (register budget: (2*NI + 2*MI) * 4 VGPRs per step)
   extern __shared__ __attribute__((aligned(16))) unsigned char red[];  // 3 * NI * MI KB (dynamic, like every kernel launched through FP_LAUNCH)
   const int tid = threadIdx.x, lane = tid & 63;
@@ -934,7 +981,10 @@ __global__ __launch_bounds__(256, 2) void conv_smallx_kernel(const ConvParams p)
       for (int b = 0; b < MI; b++) {
         const f4 v = src[(a * MI + b) * 64];
 #pragma unroll
-        for (int r = 0; r < 4; r++) acc[a][b][r] = acc[a][b][r] + v[r];   // (component-wise: no v_pk_add_f32)
+        for (int r = 0; r < 4; r++) {
+          if constexpr (DT == DT_I8) acc[a][b][r] = __int_as_float(__float_as_int(acc[a][b][r]) + __float_as_int(v[r]));   // int32 partial sums
+          else acc[a][b][r] = acc[a][b][r] + v[r];   // (component-wise: no v_pk_add_f32)
+        }
       }
   }
   conv_epilogue<MI, NI, DT, ODT, POST ? 4 : 0>(p, acc, m0, n0, lane);
@@ -1230,7 +1280,7 @@ __global__ __launch_bounds__(512, 2) void conv_big_pp_kernel(const ConvParams p)
     }                                                                    \
   } while (0)
 
-  if constexpr (DT == DT_FP8) {
+  if constexpr (is_q8(DT)) {
     i8 xv[MI / 2], wv[NI];
     auto ld0 = [&](int buf) {
       const unsigned char *sb = smem + buf * STAGE;
@@ -1255,7 +1305,7 @@ __global__ __launch_bounds__(512, 2) void conv_big_pp_kernel(const ConvParams p)
 #pragma unroll
       for (int ni = 0; ni < NI; ni++)
 #pragma unroll
-        for (int j = 0; j < MI / 2; j++) acc[ni][j] = mfma128_fp8(wv[ni], xv[j], acc[ni][j]);
+        for (int j = 0; j < MI / 2; j++) acc[ni][j] = mfma8<DT>(wv[ni], xv[j], acc[ni][j]);
       __builtin_amdgcn_s_setprio(0);
     };
     auto mf1 = [&]() {
@@ -1263,7 +1313,7 @@ __global__ __launch_bounds__(512, 2) void conv_big_pp_kernel(const ConvParams p)
 #pragma unroll
       for (int ni = 0; ni < NI; ni++)
 #pragma unroll
-        for (int j = 0; j < MI / 2; j++) acc[ni][MI / 2 + j] = mfma128_fp8(wv[ni], xv[j], acc[ni][MI / 2 + j]);
+        for (int j = 0; j < MI / 2; j++) acc[ni][MI / 2 + j] = mfma8<DT>(wv[ni], xv[j], acc[ni][MI / 2 + j]);
       __builtin_amdgcn_s_setprio(0);
     };
     FP_PP_LOOP(ld0, ld1, mf0, mf1);
@@ -1309,7 +1359,7 @@ __global__ __launch_bounds__(512, 2) void conv_big_pp_kernel(const ConvParams p)
       for (int b = 0; b < MI; b++) asm volatile("" ::"v"(acc[a][b]));
     return;
   }
-  if constexpr (LSTORE && ABL == 0 && !POST && ODT != DT_FP8) {
+  if constexpr (LSTORE && ABL == 0 && !POST && !is_q8(DT) && odt_q(ODT) < 0) {
     __syncthreads();   // both ping-pong groups are done with the ring: 8 x (8 KB tile + 256 B offsets) of it become the staging area
     conv_epilogue_lds<MI, NI, DT, ODT, 4>(p, acc, m0 + wm * 128, n0 + wn * 64, lane, smem + wave * (4 * 16 * 128 + 4 * 64));
     return;
@@ -1485,7 +1535,7 @@ __global__ __launch_bounds__(512, 2) void conv_pp32_kernel(const ConvParams p) {
 // -------------------------------------------------------------------------------------------------
 template <int TW, int ABL, int DT>  // ABL (timing ablations, wrong results): 1 no per-step barrier, 2 no MFMAs, 4 X fragments read once
 __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const ConvParams p) {
-  static_assert(DT != DT_FP8, "2-byte element types (64-channel chunks); the FP8 sibling is conv_halo8_kernel");
+  static_assert(!is_q8(DT), "2-byte element types (64-channel chunks); the 8-bit sibling is conv_halo8_kernel");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int TH = 8, HC = TW + 2, HPX = (TH + 2) * HC;
   constexpr int HPIECES = (HPX + 7) / 8, HALO_B = HPIECES * 1024;
@@ -1699,7 +1749,9 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const ConvParams p) {
 //   X operands are read two pixel blocks at a time under the MFMAs (160 accumulators + 32 + 16 operand registers).
 //   Weight stage layout: 128-byte rows, 16-byte slot = chunk ^ (row & 7) (the implicit-GEMM kernels' swizzle).
 // -------------------------------------------------------------------------------------------------
+template <int DT, int ODT>   // DT = DT_FP8 / DT_I8; ODT = DT (a block's first conv) or DT_DUAL_* (its second: f16 stream + 8-bit copy)
 __global__ __launch_bounds__(256, 2) void conv_halo8_kernel(const ConvParams p) {
+  static_assert(is_q8(DT), "8-bit operand types (128-channel chunks); the 2-byte sibling is conv_halo_kernel");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int TW = 40, TH = 8, HC = TW + 2, HPX = (TH + 2) * HC;
   constexpr int HPIECES = (HPX + 7) / 8, HALO_B = HPIECES * 1024;
@@ -1821,14 +1873,14 @@ __global__ __launch_bounds__(256, 2) void conv_halo8_kernel(const ConvParams p) 
         }
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int ni = 0; ni < NI; ni++) acc[ni][m] = mfma128_fp8(wv[ni], xv[m & 1], acc[ni][m]);
+        for (int ni = 0; ni < NI; ni++) acc[ni][m] = mfma8<DT>(wv[ni], xv[m & 1], acc[ni][m]);
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
   }
   if (p.clk && tid == 0) { p.clk[blockIdx.x * 4 + 2] = __builtin_readcyclecounter(); p.clk[blockIdx.x * 4 + 3] = wall_clock64(); }
-  conv_epilogue_px<MI, NI, DT_FP8, DT_FP8>(p, acc, n0 + wn * 64, lane, [&](int mi, int &oimg, int &oh, int &ow) {
+  conv_epilogue_px<MI, NI, DT, ODT>(p, acc, n0 + wn * 64, lane, [&](int mi, int &oimg, int &oh, int &ow) {
     oimg = img;
     oh = ty0 + wm * 4 + dy;
     ow = mi * 4 + dx;
@@ -2374,7 +2426,8 @@ __global__ __launch_bounds__(256, 2) void conv_deep_kernel(const ConvParams p) {
   conv_epilogue<MI, 4, DT, ODT, POST ? 4 : 0>(p, acc, m0 + wm * (BM / 2), n0 + wn * 64, lane);
 }
 
-// split-K reduction + the conv epilogue: out = relu(sum_s partial[s] * scale + bias + res); thread = (pixel, 8 channels)
+// split-K reduction + the conv epilogue: out = relu(sum_s partial[s] + bias + res); thread = (pixel, 8 channels).  2-byte networks
+// only: the 8-bit layers never split K across workgroups (run_conv_dt: plan_splitk).
 __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvParams p) {
   const int nq = p.Cout / 8;
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -2397,7 +2450,6 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvParam
   const int grp = p.grp_rows ? m / p.grp_rows : 0;
 #pragma unroll
   for (int e = 0; e < 8; e++) {
-    if (p.cscale) v[e] *= p.cscale[grp * p.Cout + n + e];
     v[e] += p.bias[grp * p.Cout + n + e];
   }
   const int ohw = p.OH * p.OW;
@@ -2411,12 +2463,11 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvParam
     float r[8];
     decode8(load8_raw(p.res + (rpix * p.res_ld + n) * elem_bytes(p.res_dt), p.res_dt), p.res_dt, r);
 #pragma unroll
-    for (int e = 0; e < 8; e++) v[e] += r[e] * p.res_scale;
+    for (int e = 0; e < 8; e++) v[e] += r[e];
   }
 #pragma unroll
   for (int e = 0; e < 8; e++) {
     if (p.relu) v[e] = fmaxf(v[e], 0.f);
-    v[e] *= p.out_inv;
   }
   if (p.post) {  // (2-byte output types only)
     float pe[8];
@@ -3332,9 +3383,14 @@ struct ConvLayer {
   unsigned char *wpack128 = nullptr;  // 3x3 layers with Cout % 256 == 0: a copy in conv_big_pp_kernel's stage order (pack_stage_w128)
   unsigned char *wdeep = nullptr;     // Cout % 128 == 0, 128-byte K-steps: a copy in conv_deep_kernel's stage order (FP8 3x3 layers: = wpack, the same order)
   float *bias = nullptr;
-  float *wscale = nullptr;     // FP8: [Cout] per-output-channel weight scale (w_real = w_stored * wscale)
-  float *cscale = nullptr;     // FP8: [Cout] input activation scale * wscale (net_set_fp8_scales)
+  float *cscale = nullptr;     // 8-bit layers: [Cout] dequantisation scale of the accumulator (weight-row scale, times the consumer's
+                               // inverse activation scale when the output is 8-bit only: net_apply_q8)
   int dt = DT_F16;
+  // 8-bit layers keep what net_apply_q8 needs to (re-)quantise them at calibration time: f32 rows [Cout][tap][Cin] and bias
+  std::vector<float> rows_f32, bias_f32;
+  std::vector<float> q_sw;     // per-row weight scale of the current quantisation
+  std::vector<double> q_sum;   // DT_I8: per-row sum of the quantised weights
+  int ntaps = 0;
   int Cin = 0, Cout = 0, KH = 0, KW = 0, stride = 1, pad = 0;
   int algo_K = 0;  // algorithmic reduction length for FLOP accounting (the s2d stem pads 7x7x6=294 to 512)
 };
@@ -3372,12 +3428,24 @@ struct Net {
   MHA att, att_cross;                // scorer
   LinearF32 score_lin;
   void *pe = nullptr;                // [400,512], act_dt
-  // FP8: per-tensor activation scales (real = stored * scale) of the trunk, set by net_set_fp8_scales
-  bool fp8_ready = false;
-  float act_scale[N_TRUNK_ACT];
-  // calibration (2-byte nets): per-activation |max| collected on the device while the trunk runs
-  float *calib_dev = nullptr;
-  bool calib_on = false;
+  // 8-bit networks (PREC_FP8 / PREC_INT8), set by net_apply_q8: per-CHANNEL activation scales of the trunk tensors that feed an
+  // 8-bit convolution (real = stored * scale, DT_I8: real = (stored + 128) * scale); act_oinv = 1 / scale on the device for the
+  // producers that write an f16 stream tensor together with its 8-bit copy (DT_DUAL_*); bias_fix / tok_fix = the bias correction
+  // solved by the calibration sweeps (fp_api.hip: fp_calibrate)
+  bool q8_ready = false;
+  int qdt = DT_FP8;                                  // element type of the 8-bit layers
+  std::vector<float> act_scale[N_TRUNK_ACT];         // host, [channels of the activation]
+  float *act_oinv[N_TRUNK_ACT] = {nullptr};          // device
+  float *act_scale_dev[N_TRUNK_ACT] = {nullptr};     // device copy of act_scale (calibration statistics of 8-bit tensors)
+  std::vector<float> bias_fix[13], tok_fix;          // host
+  std::vector<float> out_bias0, out_fix;             // output-layer biases as loaded (refiner: trans 3 | rot 3; scorer: att.out_proj 512) and their correction
+  std::vector<float> pe_host;                        // the positional table in f32 (tok_fix is added to the device copy)
+  // calibration: per-channel |max| and sum of the 15 trunk activations collected on the device while the trunk runs
+  // ([N_TRUNK_ACT][512] each); calib_mode 1 = |max| + sum (2-byte networks), 2 = sum only (8-bit networks, dequantised)
+  float *calib_amax = nullptr, *calib_sum = nullptr;
+  int calib_mode = 0;
+  int calib_only = -1;                               // >= 0: record this activation only (the sequential correction sweeps)
+  mutable double calib_count[N_TRUNK_ACT] = {0};     // interior pixels summed per activation (host side)
   std::vector<void *> allocs;
   ~Net() {
     for (void *p : allocs) (void)hipFree(p);
@@ -3420,25 +3488,16 @@ static uint8_t f32_to_e4m3_bits(float x) {
   if (E > 8 || (E == 8 && r > 14)) return (uint8_t)(sign | 0x7e);
   return (uint8_t)(sign | ((E + 7) << 3) | (r - 8));
 }
-// rows of `K` floats -> kernel element bytes; FP8 rows are divided by their own scale (amax / 448) first
+// rows of `K` floats -> kernel element bytes (2-byte types; the 8-bit layers go through quantise_q8)
 static std::vector<unsigned char> to_elems(const std::vector<float> &w, int rows, int K, int dt, std::vector<float> *row_scale) {
-  const int es = elem_bytes(dt);
-  std::vector<unsigned char> o((size_t)rows * K * es);
+  std::vector<unsigned char> o((size_t)rows * K * 2);
   if (row_scale) row_scale->assign(rows, 1.f);
   for (int r = 0; r < rows; r++) {
     const float *src = &w[(size_t)r * K];
-    if (dt == DT_FP8) {
-      float amax = 0.f;
-      for (int k = 0; k < K; k++) amax = std::max(amax, std::fabs(src[k]));
-      const float sc = amax > 0.f ? amax / 448.f : 1.f;
-      if (row_scale) (*row_scale)[r] = sc;
-      for (int k = 0; k < K; k++) o[(size_t)r * K + k] = f32_to_e4m3_bits(src[k] / sc);
-    } else {
-      uint16_t *dst = reinterpret_cast<uint16_t *>(&o[(size_t)r * K * 2]);
-      for (int k = 0; k < K; k++) {
-        if (dt == DT_BF16) dst[k] = f32_to_bf16_bits(src[k]);
-        else { __half h = __float2half(src[k]); std::memcpy(&dst[k], &h, 2); }
-      }
+    uint16_t *dst = reinterpret_cast<uint16_t *>(&o[(size_t)r * K * 2]);
+    for (int k = 0; k < K; k++) {
+      if (dt == DT_BF16) dst[k] = f32_to_bf16_bits(src[k]);
+      else { __half h = __float2half(src[k]); std::memcpy(&dst[k], &h, 2); }
     }
   }
   return o;
@@ -3573,45 +3632,89 @@ static std::vector<unsigned char> pack_stage_w128(const std::vector<unsigned cha
   return o;
 }
 
-// [Cout][KH][KW][Cin] f32 rows -> device layer of element type dt
-static bool finish_layer(Net *net, const std::vector<float> &rows_f32, const std::vector<float> &bias, int Cout, int ntaps, int Cin,
-                         int dt, ConvLayer *L) {
+// device copy of a host vector: allocated the first time, overwritten in place afterwards (re-calibration of an 8-bit network)
+template <typename T>
+static bool put(Net *net, T *&dst, const std::vector<T> &h) {
+  if (!dst) { dst = upload(net, h); return dst != nullptr; }
+  return fp::memcpy_sync(dst, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice) == hipSuccess;
+}
+static bool put_bytes(Net *net, unsigned char *&dst, const std::vector<unsigned char> &h) { return put<unsigned char>(net, dst, h); }
+
+// element bytes [Cout][tap][Cin] -> every device layout the layer's schedules stream from
+static bool upload_layouts(Net *net, const std::vector<unsigned char> &elems, int Cout, int ntaps, int Cin, int dt, ConvLayer *L) {
   const int K = ntaps * Cin, es = elem_bytes(dt);
-  std::vector<float> rs;
-  auto elems = to_elems(rows_f32, Cout, K, dt, &rs);
   const auto rows = permute_rows(relayout_k(elems, Cout, ntaps, Cin, es), Cout, (size_t)K * es);
-  L->w = upload(net, rows);
+  if (!put_bytes(net, L->w, rows)) return false;
   if (((size_t)K * es) % 128 == 0 && Cout % 16 == 0) {   // (byte-level: every element type)
-    L->wfrag = upload(net, fragment_order(rows, Cout, (size_t)K * es));
-    if (!L->wfrag) return false;
+    if (!put_bytes(net, L->wfrag, fragment_order(rows, Cout, (size_t)K * es))) return false;
   }
-  if (dt != DT_FP8 && ntaps == 1 && ((size_t)K * es) % 64 == 0 && Cout % 256 == 0) {
-    L->wpack = upload(net, pack_stage_w(rows, Cout, (size_t)K * es, 256));      // gemm_k32_kernel
-    if (!L->wpack) return false;
-  } else if (dt != DT_FP8 && ntaps == 9 && Cin % 64 == 0 && Cout % 128 == 0) {
-    L->wpack = upload(net, pack_stage_w(rows, Cout, (size_t)K * es, 128));      // conv_halo_kernel
-    if (!L->wpack) return false;
+  if (!is_q8(dt) && ntaps == 1 && ((size_t)K * es) % 64 == 0 && Cout % 256 == 0) {
+    if (!put_bytes(net, L->wpack, pack_stage_w(rows, Cout, (size_t)K * es, 256))) return false;      // gemm_k32_kernel
+  } else if (!is_q8(dt) && ntaps == 9 && Cin % 64 == 0 && Cout % 128 == 0) {
+    if (!put_bytes(net, L->wpack, pack_stage_w(rows, Cout, (size_t)K * es, 128))) return false;      // conv_halo_kernel
   }
   if (ntaps == 9 && ((size_t)K * es) % 128 == 0 && Cout % 256 == 0) {
-    L->wpack128 = upload(net, pack_stage_w128(rows, Cout, (size_t)K * es, 256, 8));   // conv_big_pp_kernel
-    if (!L->wpack128) return false;
+    if (!put_bytes(net, L->wpack128, pack_stage_w128(rows, Cout, (size_t)K * es, 256, 8))) return false;   // conv_big_pp_kernel
   }
-  if (dt == DT_FP8 && ntaps == 9 && ((size_t)K * es) % 128 == 0 && Cout % 128 == 0) {
-    L->wpack = upload(net, pack_stage_w128(rows, Cout, (size_t)K * es, 128, 4));      // conv_halo8_kernel
-    if (!L->wpack) return false;
-    L->wdeep = L->wpack;                                                             // conv_deep_kernel: the same order
+  if (is_q8(dt) && ntaps == 9 && ((size_t)K * es) % 128 == 0 && Cout % 128 == 0) {
+    if (!put_bytes(net, L->wpack, pack_stage_w128(rows, Cout, (size_t)K * es, 128, 4))) return false;      // conv_halo8_kernel
+    L->wdeep = L->wpack;                                                                                   // conv_deep_kernel: the same order
   } else if (((size_t)K * es) % 128 == 0 && Cout % 128 == 0) {
-    L->wdeep = upload(net, pack_stage_w128(rows, Cout, (size_t)K * es, 128, 4));      // conv_deep_kernel
-    if (!L->wdeep) return false;
+    if (!put_bytes(net, L->wdeep, pack_stage_w128(rows, Cout, (size_t)K * es, 128, 4))) return false;      // conv_deep_kernel
   }
-  L->bias = upload(net, bias);
+  return true;
+}
+
+// 8-bit quantisation of a layer's rows with the per-INPUT-channel activation scales folded in first (w'[co][tap][ci] = w * s_in[ci];
+// s_in = null: all 1): per output row a scale sw (FP8: amax / 448, OCP e4m3, RNE, saturating; I8: amax / 127, RNE) and, for I8, the
+// row sum of the quantised integers (the -128 offset of the unsigned activations contributes 128 * sum to every accumulator).
+static std::vector<unsigned char> quantise_q8(const ConvLayer &L, int dt, const float *s_in, std::vector<float> *sw, std::vector<double> *qsum) {
+  const int K = L.ntaps * L.Cin;
+  std::vector<unsigned char> o((size_t)L.Cout * K);
+  sw->assign(L.Cout, 1.f);
+  qsum->assign(L.Cout, 0.0);
+  std::vector<float> wf(K);
+  for (int co = 0; co < L.Cout; co++) {
+    const float *src = &L.rows_f32[(size_t)co * K];
+    float amax = 0.f;
+    for (int k = 0; k < K; k++) {
+      wf[k] = s_in ? src[k] * s_in[k % L.Cin] : src[k];
+      amax = std::max(amax, std::fabs(wf[k]));
+    }
+    const float sc = amax > 0.f ? amax / (dt == DT_FP8 ? 448.f : 127.f) : 1.f;
+    (*sw)[co] = sc;
+    double qs = 0;
+    for (int k = 0; k < K; k++) {
+      if (dt == DT_FP8) o[(size_t)co * K + k] = f32_to_e4m3_bits(wf[k] / sc);
+      else {
+        const int q = (int)std::max(-127.f, std::min(127.f, std::nearbyint(wf[k] / sc)));
+        o[(size_t)co * K + k] = (unsigned char)(signed char)q;
+        qs += q;
+      }
+    }
+    (*qsum)[co] = qs;
+  }
+  return o;
+}
+
+// [Cout][KH][KW][Cin] f32 rows -> device layer of element type dt.  8-bit layers are quantised with unit activation scales here
+// (so that every buffer exists) and again, with the calibrated scales, by net_apply_q8.
+static bool finish_layer(Net *net, const std::vector<float> &rows_f32, const std::vector<float> &bias, int Cout, int ntaps, int Cin,
+                         int dt, ConvLayer *L) {
+  const int K = ntaps * Cin;
   L->dt = dt;
-  if (dt == DT_FP8) {
-    L->wscale = upload(net, rs);
-    L->cscale = upload(net, rs);  // activation scale 1 until net_set_fp8_scales
-    if (!L->wscale || !L->cscale) return false;
+  L->ntaps = ntaps;
+  if (is_q8(dt)) {
+    L->rows_f32 = rows_f32;
+    L->bias_f32 = bias;
+    std::vector<float> sw;
+    std::vector<double> qsum;
+    const auto elems = quantise_q8(*L, dt, nullptr, &sw, &qsum);
+    if (!upload_layouts(net, elems, Cout, ntaps, Cin, dt, L)) return false;
+    return put(net, L->bias, bias) && put(net, L->cscale, sw);
   }
-  return L->w && L->bias;
+  if (!upload_layouts(net, to_elems(rows_f32, Cout, K, dt, nullptr), Cout, ntaps, Cin, dt, L)) return false;
+  return put(net, L->bias, bias);
 }
 
 // PyTorch conv weight [Cout,Cin,KH,KW] -> kernel layout; the layer must have exactly the expected shape (the kernels and
@@ -3697,12 +3800,12 @@ static Net *net_load_impl(const char *path, bool is_scorer, int prec, std::strin
   std::unique_ptr<Net> net(new Net());
   net->scorer = is_scorer;
   net->prec = prec;
-  // PREC_FP8: the 3x3 trunk convolutions from encodeA.2 on (91 % of the FLOPs) run on FP8 operands; the stem and encodeA.1
-  // (bandwidth-bound, K = 294 / 576) and the transformer part stay in f16
+  // PREC_FP8 / PREC_INT8: the 3x3 trunk convolutions from encodeA.2 on (91 % of the FLOPs) run on 8-bit operands; the stem and
+  // encodeA.1 (bandwidth-bound, K = 294 / 576) and the transformer part stay in f16
   const int adt = prec == PREC_BF16 ? DT_BF16 : DT_F16;
-  const int tdt = prec == PREC_FP8 ? DT_FP8 : adt;
+  const int tdt = prec == PREC_FP8 ? DT_FP8 : prec == PREC_INT8 ? DT_I8 : adt;
   net->act_dt = adt;
-  for (int i = 0; i < N_TRUNK_ACT; i++) net->act_scale[i] = 1.f;
+  net->qdt = tdt;
   bool ok = make_stem(net.get(), m, "encodeA.0", adt, &net->a0, err) && make_conv(net.get(), m, "encodeA.1", 2, 128, 64, 3, adt, &net->a1, err);
   for (int i = 0; ok && i < 2; i++)
     for (int j = 0; ok && j < 2; j++) {
@@ -3744,14 +3847,17 @@ static Net *net_load_impl(const char *path, bool is_scorer, int prec, std::strin
         pe[(size_t)t * EMBED + 2 * i + 1] = std::cos((float)t * div);
       }
     net->pe = upload(net.get(), to_elems(pe, 400, EMBED, adt, nullptr));
+    net->pe_host = pe;
     ok = net->pe != nullptr;
     if (!ok) *err = "device allocation failed";
   }
   if (ok) {
     float *c = nullptr;
-    ok = hipMalloc((void **)&c, N_TRUNK_ACT * sizeof(float)) == hipSuccess && fp::memset_sync(c, 0, N_TRUNK_ACT * sizeof(float)) == hipSuccess;
+    const size_t nb = (size_t)2 * N_TRUNK_ACT * 512 * sizeof(float);
+    ok = hipMalloc((void **)&c, nb) == hipSuccess && fp::memset_sync(c, 0, nb) == hipSuccess;
     if (c) net->allocs.push_back(c);
-    net->calib_dev = c;
+    net->calib_amax = c;
+    net->calib_sum = c + N_TRUNK_ACT * 512;
     if (!ok) *err = "device allocation failed";
   }
   if (!ok) return nullptr;
@@ -3770,41 +3876,150 @@ Net *net_load(const char *path, bool is_scorer, int prec, std::string *err) {
 void net_free(Net *n) { delete n; }
 int net_precision(const Net *n) { return n->prec; }
 int net_input_dt(const Net *n) { return n->act_dt; }
-bool net_fp8_ready(const Net *n) { return n->prec != PREC_FP8 || n->fp8_ready; }
+bool net_q8_ready(const Net *n) { return !(n->prec == PREC_FP8 || n->prec == PREC_INT8) || n->q8_ready; }
 
-// ---- FP8 calibration --------------------------------------------------------------------------------
-void net_calib_begin(Net *net, hipStream_t s) {
-  (void)hipMemsetAsync(net->calib_dev, 0, N_TRUNK_ACT * sizeof(float), s);
-  net->calib_on = true;
+// ---- calibration of the 8-bit networks ------------------------------------------------------------------
+// Statistics: while calib_mode != 0 the trunk records, per channel of each of its 15 activations, |max| (mode 1) and the sum of
+// the stored values (8-bit tensors: de-quantised) -- fp_api.hip turns the sums into means.
+void net_calib_begin(Net *net, hipStream_t s, int mode, int only_act) {
+  (void)hipMemsetAsync(net->calib_amax, 0, (size_t)2 * N_TRUNK_ACT * 512 * sizeof(float), s);
+  net->calib_mode = mode;
+  net->calib_only = only_act;
+  for (int i = 0; i < N_TRUNK_ACT; i++) net->calib_count[i] = 0;
 }
-int net_calib_end(Net *net, hipStream_t s, float amax_out[16]) {
-  net->calib_on = false;
-  for (int i = 0; i < 16; i++) amax_out[i] = 0.f;
-  FP_HIP_OK(hipMemcpyAsync(amax_out, net->calib_dev, N_TRUNK_ACT * sizeof(float), hipMemcpyDeviceToHost, s));
+// sum_out: per-channel MEANS over the interior pixels of the recorded activations (sums / pixel count)
+int net_calib_end(Net *net, hipStream_t s, float *amax_out /*[15][512] or null*/, float *sum_out /*[15][512]*/) {
+  net->calib_mode = 0;
+  net->calib_only = -1;
+  if (amax_out) FP_HIP_OK(hipMemcpyAsync(amax_out, net->calib_amax, (size_t)N_TRUNK_ACT * 512 * sizeof(float), hipMemcpyDeviceToHost, s));
+  if (sum_out) FP_HIP_OK(hipMemcpyAsync(sum_out, net->calib_sum, (size_t)N_TRUNK_ACT * 512 * sizeof(float), hipMemcpyDeviceToHost, s));
   FP_HIP_OK(hipStreamSynchronize(s));
+  if (sum_out)
+    for (int a = 0; a < N_TRUNK_ACT; a++)
+      if (net->calib_count[a] > 0)
+        for (int c = 0; c < 512; c++) sum_out[a * 512 + c] = (float)(sum_out[a * 512 + c] / net->calib_count[a]);
   return 0;
 }
-// input activation of every FP8 layer: {layer, activation id}
-static void fp8_layers(Net *n, ConvLayer *(&L)[13], int (&in_act)[13]) {
+// the 13 8-bit layers in trunk order; layer i reads activation i + 1 and writes activation i + 2
+static void q8_layers(Net *n, ConvLayer *(&L)[13]) {
   ConvLayer *l[13] = {&n->ra[0][0], &n->ra[0][1], &n->ra[1][0], &n->ra[1][1], &n->rb[0][0], &n->rb[0][1], &n->rb[1][0],
                       &n->rb[1][1], &n->b2, &n->rc[0][0], &n->rc[0][1], &n->rc[1][0], &n->rc[1][1]};
-  for (int i = 0; i < 13; i++) { L[i] = l[i]; in_act[i] = i + 1; }
+  for (int i = 0; i < 13; i++) L[i] = l[i];
 }
-int net_set_fp8_scales(Net *net, const float amax[16]) {
-  FP_CHECK(net->prec == PREC_FP8, "net_set_fp8_scales: not an FP8 network");
-  // amax of the calibration frame maps to 224 = half of the e4m3 range: one binade of headroom before saturation
-  for (int i = 0; i < N_TRUNK_ACT; i++) net->act_scale[i] = amax[i] > 0.f ? amax[i] / 224.f : 1.f;
-  ConvLayer *L[13];
-  int in_act[13];
-  fp8_layers(net, L, in_act);
-  for (int i = 0; i < 13; i++) {
-    std::vector<float> ws(L[i]->Cout), cs(L[i]->Cout);
-    FP_HIP_OK(fp::memcpy_sync(ws.data(), L[i]->wscale, ws.size() * 4, hipMemcpyDeviceToHost));
-    for (size_t k = 0; k < ws.size(); k++) cs[k] = ws[k] * net->act_scale[in_act[i]];
-    FP_HIP_OK(fp::memcpy_sync(L[i]->cscale, cs.data(), cs.size() * 4, hipMemcpyHostToDevice));
+// channels of trunk activation a (a = 1..14)
+static int act_channels(int a) { return a <= 4 ? 128 : a <= 9 ? 256 : 512; }
+// layer i's output goes ONLY to the next 8-bit convolution (a block's first conv): the consumer's scales fold into cscale / bias
+static bool q8_folded_out(int i) { return i == 0 || i == 2 || i == 4 || i == 6 || i == 9 || i == 11; }
+int net_q8_bias_channels(int layer) { return layer < 4 ? 128 : layer < 8 ? 256 : 512; }
+
+// One 8-bit layer: (weights) quantise its rows with the input-channel scales s_in folded in and upload every layout; then the epilogue
+// tables.  accumulator -> real value: acc * sw (+ DT_I8: 128 * sw * sum_k q, the offset of the unsigned activations) + bias + fix;
+// s_out_fold != null (the output is 8-bit ONLY): the consumer's inverse scales multiply both (legal: no residual, ReLU).
+static int apply_q8_layer(Net *net, ConvLayer &l, int dt, const float *s_in, const float *bias_fix, const float *s_out_fold, bool weights) {
+  const int Cout = l.Cout;
+  if (weights) {
+    std::vector<float> sw;
+    std::vector<double> qsum;
+    const auto elems = quantise_q8(l, dt, s_in, &sw, &qsum);
+    if (!upload_layouts(net, elems, Cout, l.ntaps, l.Cin, dt, &l)) { set_error("net_apply_q8: device upload failed"); return 1; }
+    l.q_sw = sw; l.q_sum = qsum;
   }
-  net->fp8_ready = true;
+  std::vector<float> cs(Cout), bs(Cout);
+  for (int co = 0; co < Cout; co++) {
+    double b = (double)l.bias_f32[co] + (bias_fix ? bias_fix[co] : 0.f);
+    if (dt == DT_I8) b += 128.0 * l.q_sw[co] * l.q_sum[co];
+    double c = l.q_sw[co];
+    if (s_out_fold) { const double inv = 1.0 / s_out_fold[co]; b *= inv; c *= inv; }
+    cs[co] = (float)c; bs[co] = (float)b;
+  }
+  if (!put(net, l.cscale, cs) || !put(net, l.bias, bs)) { set_error("net_apply_q8: device upload failed"); return 1; }
   return 0;
+}
+
+// Applies a calibration to an 8-bit network: amax [15][512] = per-channel |max| of the trunk activations of the f16 network on
+// the calibration frame; bias_fix [13][512] (may be null = zeros) and tok_fix [512] (may be null) = the solved bias correction.
+// weights = false: only the biases / the positional table are rebuilt (the correction sweeps).
+//   scale of activation a, channel c:  FP8: amax / 224 (one binade of headroom below the e4m3 maximum 448)
+//                                      I8 : amax * 1.25 / 255 (unsigned 8-bit: every tensor here is a ReLU output)
+//   (amax floored at 1/1024 of the tensor's largest channel)
+//   the concat tensor (activation 5) gets the SAME scale for channel c of its a-half and its b-half, so that its producer (128
+//   output channels, two image groups) indexes one table.
+int net_apply_q8(Net *net, const float *amax, const float *bias_fix, const float *tok_fix, bool weights) {
+  FP_CHECK(net->prec == PREC_FP8 || net->prec == PREC_INT8, "net_apply_q8: not an 8-bit network");
+  const int dt = net->qdt;
+  ConvLayer *L[13];
+  q8_layers(net, L);
+  if (weights) {
+    for (int a = 1; a <= 13; a++) {
+      const int C = act_channels(a);
+      std::vector<float> sc(C);
+      // a channel that is (almost) dead on the calibration frame gets the floor tensor-|max| / 1024, NOT a scale of 1: the scales are
+      // folded into the consumer's weights, and one large scale would take the whole range of every weight row
+      float tmax = 0.f;
+      for (int c = 0; c < C; c++) tmax = std::max(tmax, amax[a * 512 + c]);
+      if (!(tmax > 0.f)) tmax = 1.f;
+      for (int c = 0; c < C; c++) {
+        float m = amax[a * 512 + c];
+        if (a == 5) m = std::max(amax[a * 512 + (c & 127)], amax[a * 512 + (c & 127) + 128]);
+        m = std::max(m, tmax * (1.f / 1024.f));
+        sc[c] = dt == DT_FP8 ? m / 224.f : m * 1.25f / 255.f;
+      }
+      net->act_scale[a] = sc;
+      std::vector<float> inv(C);
+      for (int c = 0; c < C; c++) inv[c] = 1.f / sc[c];
+      if (!put(net, net->act_oinv[a], inv) || !put(net, net->act_scale_dev[a], sc)) { set_error("net_apply_q8: device upload failed"); return 1; }
+    }
+  }
+  FP_CHECK(!net->act_scale[1].empty(), "net_apply_q8: bias update before the scales were set");
+  for (int i = 0; i < 13; i++) {
+    ConvLayer &l = *L[i];
+    const int Cout = l.Cout;
+    if (bias_fix) net->bias_fix[i].assign(bias_fix + (size_t)i * 512, bias_fix + (size_t)i * 512 + Cout);
+    else if (net->bias_fix[i].empty()) net->bias_fix[i].assign(Cout, 0.f);
+  }
+  for (int i = 0; i < 13; i++)
+    if (apply_q8_layer(net, *L[i], dt, net->act_scale[i + 1].data(), net->bias_fix[i].data(),
+                       q8_folded_out(i) ? net->act_scale[i + 2].data() : nullptr, weights)) return 1;
+  if (tok_fix) net->tok_fix.assign(tok_fix, tok_fix + EMBED);
+  else if (net->tok_fix.empty()) net->tok_fix.assign(EMBED, 0.f);
+  {  // positional table + token correction (the trunk's last epilogue adds the table to the rounded token)
+    std::vector<float> pe(net->pe_host);
+    for (int t = 0; t < 400; t++)
+      for (int c = 0; c < EMBED; c++) pe[(size_t)t * EMBED + c] += net->tok_fix[c];
+    const auto e = to_elems(pe, 400, EMBED, net->act_dt, nullptr);
+    if (fp::memcpy_sync(net->pe, e.data(), e.size(), hipMemcpyHostToDevice) != hipSuccess) { set_error("net_apply_q8: device upload failed"); return 1; }
+  }
+  net->q8_ready = true;
+  return 0;
+}
+// Output-layer correction of an 8-bit network: fix (refiner: [trans 3 | rot 3], scorer: [512] on the pooled score feature) is added to
+// the biases of the f32 output layers (Linear(512,3) x 2 / att.out_proj) -- the last stage of the calibration's bias correction.
+int net_q8_set_out_fix(Net *net, const float *fix) {
+  const int n = net->scorer ? EMBED : 6;
+  if (net->out_bias0.empty()) {
+    net->out_bias0.resize(n);
+    if (net->scorer) FP_HIP_OK(fp::memcpy_sync(net->out_bias0.data(), net->att.out_proj_f32.b, EMBED * 4, hipMemcpyDeviceToHost));
+    else {
+      FP_HIP_OK(fp::memcpy_sync(net->out_bias0.data(), net->trans.head.b, 12, hipMemcpyDeviceToHost));
+      FP_HIP_OK(fp::memcpy_sync(net->out_bias0.data() + 3, net->rot.head.b, 12, hipMemcpyDeviceToHost));
+    }
+  }
+  net->out_fix.assign(fix, fix + n);
+  std::vector<float> b(n);
+  for (int i = 0; i < n; i++) b[i] = net->out_bias0[i] + fix[i];
+  if (net->scorer) FP_HIP_OK(fp::memcpy_sync(net->att.out_proj_f32.b, b.data(), EMBED * 4, hipMemcpyHostToDevice));
+  else {
+    FP_HIP_OK(fp::memcpy_sync(net->trans.head.b, b.data(), 12, hipMemcpyHostToDevice));
+    FP_HIP_OK(fp::memcpy_sync(net->rot.head.b, b.data() + 3, 12, hipMemcpyHostToDevice));
+  }
+  return 0;
+}
+void net_q8_get_fix(const Net *net, float *bias_fix /*[13][512]*/, float *tok_fix /*[512]*/) {
+  std::memset(bias_fix, 0, sizeof(float) * 13 * 512);
+  std::memset(tok_fix, 0, sizeof(float) * 512);
+  for (int i = 0; i < 13; i++)
+    for (size_t c = 0; c < net->bias_fix[i].size(); c++) bias_fix[(size_t)i * 512 + c] = net->bias_fix[i][c];
+  for (size_t c = 0; c < net->tok_fix.size(); c++) tok_fix[c] = net->tok_fix[c];
 }
 
 // =================================================================================================
@@ -3813,6 +4028,8 @@ int net_set_fp8_scales(Net *net, const float amax[16]) {
 
 struct NNScratch {
   int cap = 0;
+  int q8 = 0;       // 0: 2-byte network; DT_FP8 / DT_I8: the arena also carries 1-byte slots for the 8-bit operand copies, whose zero
+                    // border is the byte 0x00 (FP8) / 0x80 (I8: unsigned 0 stored with the offset of -128)
   unsigned char *buf = nullptr;
   float *f32 = nullptr;
   // cross-attention head over all gathered hypotheses (sized by n_total, independent of the local shard)
@@ -3831,7 +4048,11 @@ struct NNScratch {
     if (head_f32) (void)hipFree(head_f32);
   }
 };
-NNScratch *nn_scratch_create() { return new NNScratch(); }
+NNScratch *nn_scratch_create(int prec) {
+  NNScratch *w = new NNScratch();
+  w->q8 = prec == PREC_FP8 ? DT_FP8 : prec == PREC_INT8 ? DT_I8 : 0;
+  return w;
+}
 
 void nn_scratch_free(NNScratch *w) { delete w; }
 
@@ -3845,8 +4066,10 @@ static constexpr size_t SZ_512 = 22ull * 22 * 512 * 2;
 static constexpr size_t SZ_TOK = 400ull * 512 * 2;            // token buffers (no border)
 static constexpr size_t SZ_QKV = 400ull * 1536 * 2;
 static constexpr size_t PER_HYP = SZ_STEM + 3 * SZ_128 + 3 * SZ_256 + 3 * SZ_512 + SZ_QKV + 4 * SZ_TOK;
+static constexpr size_t PER_HYP_Q8 = (3 * SZ_128 + 3 * SZ_256 + 3 * SZ_512) / 2;   // the 1-byte copies (8-bit networks only)
+static size_t per_hyp_bytes(const NNScratch *w) { return PER_HYP + (w->q8 ? PER_HYP_Q8 : 0); }
 void nn_scratch_debug_info(const NNScratch *w, const void **buf, size_t *bytes, const void **f32, size_t *f32_bytes) {
-  *buf = w->buf; *bytes = (size_t)w->cap * PER_HYP;
+  *buf = w->buf; *bytes = (size_t)w->cap * per_hyp_bytes(w);
   *f32 = w->f32; *f32_bytes = (size_t)w->cap * EMBED * sizeof(float);
 }
 
@@ -3857,11 +4080,12 @@ static int ensure_scratch(NNScratch *ws, int N, hipStream_t s) {
   ws->buf = nullptr; ws->f32 = nullptr; ws->cap = 0;
   int cap = std::max(N, 8);
   g_alloc_epoch++;
-  FP_HIP_OK(hipMalloc((void **)&ws->buf, (size_t)cap * PER_HYP));
+  FP_HIP_OK(hipMalloc((void **)&ws->buf, (size_t)cap * per_hyp_bytes(ws)));
   FP_HIP_OK(hipMalloc((void **)&ws->f32, (size_t)cap * EMBED * sizeof(float)));
   // the zero borders are written here once and never again: every producer stores interiors only, and the arena is
   // carved by CAPACITY (not by the current N), so an image slot's border never moves
   FP_HIP_OK(hipMemsetAsync(ws->buf, 0, (size_t)cap * PER_HYP, s));
+  if (ws->q8) FP_HIP_OK(hipMemsetAsync(ws->buf + (size_t)cap * PER_HYP, ws->q8 == DT_I8 ? 0x80 : 0, (size_t)cap * PER_HYP_Q8, s));
   ws->cap = cap;
   return 0;
 }
@@ -3957,8 +4181,9 @@ struct ConvGroup {  // two weight groups along M (see ConvParams::grp_rows); L h
 template <int DT, int ODT>
 static int run_conv_dt(const Ctx &c, const char *tag, const ConvLayer &L, ConvParams &p, int NB, int H, int W, int ipad,
                        bool has_res, int split_imgs, const ConvGroup *grp) {
-  constexpr bool B2 = DT != DT_FP8;  // 2-byte element type: the 64-byte-row kernels exist
+  constexpr bool B2 = !is_q8(DT);    // 2-byte element type: the 64-byte-row kernels exist
   constexpr bool SAME = DT == ODT;   // kernels without an ODT parameter write their operand type
+  constexpr bool QOUT = odt_q(ODT) >= 0;   // an 8-bit tensor is written (alone or next to the f16 stream tensor)
   const int KT = p.krow_b / 128;
   bool post_main = false;  // ConvParams::post handled by the 256x256 rounds + deep-ring left-over (see below)
   double flops = 2.0 * (double)p.M * p.Cout * (L.algo_K > 0 ? L.algo_K : p.Ktot);
@@ -3980,7 +4205,7 @@ static int run_conv_dt(const Ctx &c, const char *tag, const ConvLayer &L, ConvPa
   auto plan_splitk = [&](int rows, int target) -> int {
     const int mt = (rows + 127) / 128;
     const int tiles = mt * (L.Cout % 128 == 0 ? L.Cout / 128 : L.Cout / 64);
-    if (KT < g_splitk_min_kt) return 0;
+    if (KT < g_splitk_min_kt || is_q8(DT)) return 0;
     if (tiles > 96) {
       // a little above the split-K range (a batch of ~8 objects): long-K layers still leave half the chip idle for 72 K-steps;
       // two slices per tile while the grid fits one round of the 256 CUs
@@ -4020,7 +4245,7 @@ static int run_conv_dt(const Ctx &c, const char *tag, const ConvLayer &L, ConvPa
       const int t32 = ((p.M + 31) / 32) * (L.Cout / cw);
       const bool two = t32 >= 160;                        // 32-pixel tiles halve the weight stream once they still fill the chip
       bool post = p.post != nullptr;
-      if constexpr (ODT == DT_FP8) post = false;
+      if constexpr (QOUT) post = false;
       if (!post) p.post = nullptr;
       ProfScope ps(c.prof, c.s, (std::string(tag) + "/conv_smallm_kernel").c_str(), flops, bytes);
       // grid = 8 XCD lanes x ceil(workgroups / 8), see the kernel's placement rule
@@ -4049,7 +4274,7 @@ static int run_conv_dt(const Ctx &c, const char *tag, const ConvLayer &L, ConvPa
     FP_LAUNCH((conv_smallx_kernel<MI_, NI_, DT, ODT, POST_>), grid, dim3(256),                                              \
               4 * ((MI_) == 1 ? 4 : 3) * (MI_) * 2048 + 3 * NI_ * MI_ * 1024, c.s, p);                                      \
   } while (0)
-      if constexpr (ODT != DT_FP8) {
+      if constexpr (!QOUT) {
         if (post && cw == 64) { if (two) FP_SMALLM(2, 4, true); else FP_SMALLM(1, 4, true); return 0; }
         if (post) p.post = nullptr;                      // (no 32-channel layer carries a positional table)
       }
@@ -4097,10 +4322,10 @@ static int run_conv_dt(const Ctx &c, const char *tag, const ConvLayer &L, ConvPa
     }
   }
   // 3x3 / stride 1 on 40x40 maps with the input tile resident in LDS; measured crossover vs the implicit-GEMM tiles: ~32 hypotheses
-  if (SAME && !grp && halo_ok && L.KH == 3 && L.KW == 3 && L.stride == 1 && L.pad == 1 && ipad == 1 && W == 40 && H % 8 == 0 &&
+  if ((SAME || (!B2 && odt_q(ODT) == DT)) && !grp && halo_ok && L.KH == 3 && L.KW == 3 && L.stride == 1 && L.pad == 1 && ipad == 1 && W == 40 && H % 8 == 0 &&
       p.cin_b % 128 == 0 && L.Cout % 128 == 0 && p.ksplit == 1 && (force || NB * (H / 8) * (L.Cout / 128) >= 300)) {
     const dim3 grid(NB * (H / 8) * (L.Cout / 128));
-    if constexpr (!SAME) {
+    if constexpr (B2 && !SAME) {
     } else if constexpr (B2) {
       ProfScope ps(c.prof, c.s, (tg + "/conv_halo_kernel").c_str(), flops, bytes);
 #ifdef FP_TEST_HOOKS
@@ -4112,10 +4337,10 @@ static int run_conv_dt(const Ctx &c, const char *tag, const ConvLayer &L, ConvPa
 #endif
       if (!g_halo_wpack) p.wpack = nullptr;
       FP_LAUNCH((conv_halo_kernel<40, 0, DT>), grid, dim3(256), LDS_HALO40, c.s, p);
-    } else {
+    } else if constexpr (odt_q(ODT) == DT) {
       ProfScope ps(c.prof, c.s, (tg + "/conv_halo8_kernel").c_str(), flops, bytes);
       if (!g_halo_wpack) p.wpack = nullptr;
-      FP_LAUNCH((conv_halo8_kernel), grid, dim3(256), LDS_HALO8, c.s, p);
+      FP_LAUNCH((conv_halo8_kernel<DT, ODT>), grid, dim3(256), LDS_HALO8, c.s, p);
     }
     return 0;
   }
@@ -4141,7 +4366,7 @@ static int run_conv_dt(const Ctx &c, const char *tag, const ConvLayer &L, ConvPa
       }
     }
   }
-  if constexpr (!(DT == DT_F16 && ODT == DT_FP8))  // (encodeA.1 has 128 output channels: no 256-wide instantiation of the f16 -> FP8 boundary)
+  if constexpr (!(DT == DT_F16 && QOUT))  // (encodeA.1 has 128 output channels: no 256-wide instantiation of the f16 -> 8-bit boundary)
   if (!grp && (g_conv_variant == 5 || g_conv_variant == 0 || g_conv_variant == 8) && L.Cout % 256 == 0 && p.ksplit == 1 && KT >= 2) {
     // 256x256 tiles for as many FULL rounds of the 256 CUs as the problem has, the remaining rows on smaller tiles
     const int nt2 = L.Cout / 256;
@@ -4177,10 +4402,10 @@ static int run_conv_dt(const Ctx &c, const char *tag, const ConvLayer &L, ConvPa
           }
         }
 #endif
-        if constexpr (ODT != DT_FP8) {
+        if constexpr (!QOUT) {
           if (!done && post_main) { FP_LAUNCH((conv_big_pp_kernel<0, DT, ODT, true>), grid, dim3(512), LDS_BIG, c.s, pb); done = true; }
         }
-        if constexpr (ODT != DT_FP8) {
+        if constexpr (!QOUT && B2) {
           if (!done && g_conv_lds_store) { FP_LAUNCH((conv_big_pp_kernel<0, DT, ODT, false, true>), grid, dim3(512), LDS_BIG, c.s, pb); done = true; }
         }
         if (!done) FP_LAUNCH((conv_big_pp_kernel<0, DT, ODT>), grid, dim3(512), LDS_BIG, c.s, pb);
@@ -4226,7 +4451,7 @@ static int run_conv_dt(const Ctx &c, const char *tag, const ConvLayer &L, ConvPa
         rows = rest;
       }
       ProfScope ps(c.prof, c.s, (tg + "/conv_deep_kernel").c_str(), flops, bytes);
-      if constexpr (ODT != DT_FP8) {
+      if constexpr (!QOUT) {
         if (post_main) {
           FP_LAUNCH((conv_deep_kernel<64, DT, ODT, true>), dim3(((rows + 63) / 64) * n128), dim3(256), LDS_DEEP64, c.s, p);
           return 0;
@@ -4290,26 +4515,29 @@ static int run_conv_dt(const Ctx &c, const char *tag, const ConvLayer &L, ConvPa
 
 // post / post_fused: a positional table the layer may add to its output (see ConvParams::post); *post_fused tells the
 // caller whether the schedule that ran did (otherwise the caller launches add_pos_embed_kernel)
+// out2 / oinv (8-bit networks): the layer also writes the 8-bit copy of its f16 output, value * oinv[channel] (DT_DUAL_*)
 static int run_conv(const Ctx &c, const char *tag, const ConvLayer &L, const Act &in, int NB, int H, int W, int ipad,
                     const Act &out, int opad, bool relu, const Act *res = nullptr, int rpad = 0, int split_imgs = 0,
-                    const ConvGroup *grp = nullptr, const void *post = nullptr, bool *post_fused = nullptr) {
+                    const ConvGroup *grp = nullptr, const void *post = nullptr, bool *post_fused = nullptr, const Act *out2 = nullptr,
+                    const float *oinv = nullptr) {
   ConvParams p;
+  p.out2 = out2 ? (unsigned char *)out2->p : nullptr;
+  p.oinv = oinv;
+  FP_CHECK(!out2 || (out.dt == DT_F16 && is_q8(out2->dt) && oinv && !grp && !post), "run_conv: unsupported dual output");
   p.post = (const unsigned char *)post;
   if (post_fused) *post_fused = false;
   FP_CHECK(in.dt == L.dt, "run_conv: input element type does not match the layer's weights");
-  FP_CHECK(L.dt != DT_FP8 || L.cscale, "run_conv: FP8 layer without scales");
+  FP_CHECK(!is_q8(L.dt) || L.cscale, "run_conv: 8-bit layer without scales");
   const int es = elem_bytes(L.dt);
   p.clk = g_clk_probe;
   p.grp_rows = grp ? grp->rows : 0;
   p.in_shared = grp && grp->in_shared;
   p.res_shared = grp && grp->res_shared;
   p.grp_w_bytes = grp ? (unsigned)((size_t)L.Cout * L.KH * L.KW * L.Cin * es) : 0;
-  FP_CHECK(!grp || (grp->rows % 128 == 0 && L.KH == 1 && L.KW == 1 && NB == 2 * grp->rows && L.dt != DT_FP8), "grouped launch: unsupported shape");
-  p.in = (const unsigned char *)in.p; p.w = L.w; p.wfrag = L.wfrag; p.wpack = L.wpack; p.wpack128 = g_big_wpack ? L.wpack128 : nullptr; p.wdeep = g_deep_wpack ? L.wdeep : nullptr; p.bias = L.bias; p.cscale = L.dt == DT_FP8 ? L.cscale : nullptr;
+  FP_CHECK(!grp || (grp->rows % 128 == 0 && L.KH == 1 && L.KW == 1 && NB == 2 * grp->rows && !is_q8(L.dt)), "grouped launch: unsupported shape");
+  p.in = (const unsigned char *)in.p; p.w = L.w; p.wfrag = L.wfrag; p.wpack = L.wpack; p.wpack128 = g_big_wpack ? L.wpack128 : nullptr; p.wdeep = g_deep_wpack ? L.wdeep : nullptr; p.bias = L.bias; p.cscale = is_q8(L.dt) ? L.cscale : nullptr;
   p.res = res ? (const unsigned char *)res->p : nullptr; p.out = (unsigned char *)out.p;
   p.out_dt = out.dt; p.res_dt = res ? res->dt : out.dt;
-  p.res_scale = res ? res->scale : 1.f;
-  p.out_inv = out.dt == DT_FP8 ? 1.f / out.scale : 1.f;
   p.NB = NB; p.H = H; p.W = W; p.Cin = L.Cin;
   p.KH = L.KH; p.KW = L.KW; p.stride = L.stride; p.pad = L.pad;
   p.ipad = ipad; p.opad = opad; p.rpad = rpad;
@@ -4344,15 +4572,23 @@ static int run_conv(const Ctx &c, const char *tag, const ConvLayer &L, const Act
     }
   }
   const bool hr = res != nullptr;
-  FP_CHECK(!res || res->dt == L.dt, "run_conv: the residual must have the layer's operand type");
-  FP_CHECK(!post || (opad == 0 && split_imgs == 0 && out.dt != DT_FP8 && post_fused), "run_conv: positional table on an unsupported layer");
+  FP_CHECK(!res || res->dt == (is_q8(L.dt) ? DT_F16 : L.dt), "run_conv: the residual must have the layer's operand type (f16 for the 8-bit layers)");
+  FP_CHECK(!post || (opad == 0 && split_imgs == 0 && !is_q8(out.dt) && post_fused), "run_conv: positional table on an unsupported layer");
   struct PostReport {  // the split-K decision is taken inside run_conv_dt (p.ksplit)
     ConvParams &p; bool *flag;
     ~PostReport() { if (flag) *flag = p.post != nullptr; }  // (run_conv_dt clears p.post when no schedule that ran implements it)
   } post_report{p, post_fused};
+  if (out2) {
+    if (L.dt == DT_FP8 && out2->dt == DT_FP8) return run_conv_dt<DT_FP8, DT_DUAL_FP8>(c, tag, L, p, NB, H, W, ipad, hr, split_imgs, grp);
+    if (L.dt == DT_I8 && out2->dt == DT_I8) return run_conv_dt<DT_I8, DT_DUAL_I8>(c, tag, L, p, NB, H, W, ipad, hr, split_imgs, grp);
+    if (L.dt == DT_F16 && out2->dt == DT_FP8) return run_conv_dt<DT_F16, DT_DUAL_FP8>(c, tag, L, p, NB, H, W, ipad, hr, split_imgs, grp);
+    if (L.dt == DT_F16 && out2->dt == DT_I8) return run_conv_dt<DT_F16, DT_DUAL_I8>(c, tag, L, p, NB, H, W, ipad, hr, split_imgs, grp);
+    FP_CHECK(false, "run_conv: unsupported combination of operand / dual-output element types");
+  }
   if (L.dt == DT_FP8 && out.dt == DT_FP8) return run_conv_dt<DT_FP8, DT_FP8>(c, tag, L, p, NB, H, W, ipad, hr, split_imgs, grp);
   if (L.dt == DT_FP8 && out.dt == DT_F16) return run_conv_dt<DT_FP8, DT_F16>(c, tag, L, p, NB, H, W, ipad, hr, split_imgs, grp);
-  if (L.dt == DT_F16 && out.dt == DT_FP8) return run_conv_dt<DT_F16, DT_FP8>(c, tag, L, p, NB, H, W, ipad, hr, split_imgs, grp);
+  if (L.dt == DT_I8 && out.dt == DT_I8) return run_conv_dt<DT_I8, DT_I8>(c, tag, L, p, NB, H, W, ipad, hr, split_imgs, grp);
+  if (L.dt == DT_I8 && out.dt == DT_F16) return run_conv_dt<DT_I8, DT_F16>(c, tag, L, p, NB, H, W, ipad, hr, split_imgs, grp);
   if (L.dt == DT_BF16 && out.dt == DT_BF16) return run_conv_dt<DT_BF16, DT_BF16>(c, tag, L, p, NB, H, W, ipad, hr, split_imgs, grp);
   if (L.dt == DT_F16 && out.dt == DT_F16) return run_conv_dt<DT_F16, DT_F16>(c, tag, L, p, NB, H, W, ipad, hr, split_imgs, grp);
   FP_CHECK(false, "run_conv: unsupported combination of operand / output element types");
@@ -4449,29 +4685,66 @@ static void run_token_mean(const Ctx &c, int dt, const void *x, float *out, int 
   else hipLaunchKernelGGL(token_mean_kernel<DT_F16>, dim3(B, EMBED / 64), dim3(256), 0, c.s, (const _Float16 *)x, out, T, tstride ? tstride : T);
 }
 
-// calibration: |max| of a tensor (2-byte element type) folded into slot[0] (bits of a non-negative float order like ints)
+// calibration statistics of a trunk activation [pixels incl. the zero border][C]: per channel |max| (optional) and the sum of the
+// values -- 8-bit tensors de-quantised with their per-channel scale (DT_I8: (stored ^ 0x80) * scale).  Border pixels hold 0 and
+// add nothing.  thread = (8 channels, a strided set of pixels); f32 atomics (one-time calibration, not on the serving path).
 template <int DT>
-__global__ __launch_bounds__(256) void amax_kernel(const typename ElemT<DT>::v8 *__restrict__ x, size_t n8, float *__restrict__ slot) {
-  float m = 0.f;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
-    const typename ElemT<DT>::v8 v = x[i];
+__global__ __launch_bounds__(256) void chan_stats_kernel(const unsigned char *__restrict__ x, size_t pixels, int C, const float *__restrict__ scale,
+                                                         float *__restrict__ amax, float *__restrict__ sum) {
+  const int groups = C / 8;
+  const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x, nthreads = (size_t)gridDim.x * 256;
+  const int cg = (int)(t % groups);
+  const size_t p0 = t / groups, pstride = nthreads / groups;
+  if (p0 >= pstride) return;   // (threads beyond the last whole group of `groups`)
+  float m[8], sacc[8], sc[8];
 #pragma unroll
-    for (int e = 0; e < 8; e++) m = fmaxf(m, fabsf((float)v[e]));
+  for (int e = 0; e < 8; e++) { m[e] = 0.f; sacc[e] = 0.f; sc[e] = (is_q8(DT) && scale) ? scale[cg * 8 + e] : 1.f; }
+  for (size_t px = p0; px < pixels; px += pstride) {
+    float f[8];
+    if constexpr (DT == DT_I8) {
+      const i2 v = *reinterpret_cast<const i2 *>(x + px * C + cg * 8);
+#pragma unroll
+      for (int e = 0; e < 8; e++) f[e] = (float)(((unsigned)v[e >> 2] >> ((e & 3) * 8) & 0xffu) ^ 0x80u) * sc[e];
+    } else {
+      decode8(load8_raw(x + (px * C + cg * 8) * elem_bytes(DT), DT), DT, f);
+      if constexpr (DT == DT_FP8) {
+#pragma unroll
+        for (int e = 0; e < 8; e++) f[e] *= sc[e];
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; e++) { m[e] = fmaxf(m[e], fabsf(f[e])); sacc[e] += f[e]; }
   }
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(reinterpret_cast<int *>(slot), __float_as_int(m));
+  for (int e = 0; e < 8; e++) {
+    if (amax && m[e] > 0.f) atomicMax(reinterpret_cast<int *>(amax + cg * 8 + e), __float_as_int(m[e]));   // (bits of non-negative floats order like ints)
+    if (sacc[e] != 0.f) atomicAdd(sum + cg * 8 + e, sacc[e]);
+  }
 }
-static void calib_record(const Ctx &c, int act_id, const void *buf, size_t bytes) {
-  if (!c.net->calib_on) return;
-  const size_t n8 = bytes / 16;
-  if (c.net->act_dt == DT_BF16) hipLaunchKernelGGL(amax_kernel<DT_BF16>, dim3(1024), dim3(256), 0, c.s, (const b8 *)buf, n8, c.net->calib_dev + act_id);
-  else hipLaunchKernelGGL(amax_kernel<DT_F16>, dim3(1024), dim3(256), 0, c.s, (const h8 *)buf, n8, c.net->calib_dev + act_id);
+// act_id: trunk activation (0..14); dt / scale describe the tensor at `buf`
+static void calib_record(const Ctx &c, int act_id, const void *buf, size_t pixels, int C, int dt, const float *scale = nullptr) {
+  if (!c.net->calib_mode || (c.net->calib_only >= 0 && c.net->calib_only != act_id)) return;
+  // interior pixels: the padded tensors are [images][h+2][w+2] with h = w (40x40 / 20x20 maps), the token tensor has no border
+  {
+    double interior = (double)pixels;
+    if (act_id <= 9) interior = (double)pixels / (42.0 * 42.0) * 1600.0;
+    else if (act_id <= 13) interior = (double)pixels / (22.0 * 22.0) * 400.0;
+    c.net->calib_count[act_id] += interior;
+  }
+  float *amax = c.net->calib_mode == 1 ? c.net->calib_amax + act_id * 512 : nullptr, *sum = c.net->calib_sum + act_id * 512;
+  const unsigned char *x = (const unsigned char *)buf;
+  const int groups = C / 8;
+  const dim3 grid((unsigned)((size_t)1024 * groups / 256)), blk(256);   // 1024 pixel lanes per channel group
+  if (dt == DT_BF16) hipLaunchKernelGGL(chan_stats_kernel<DT_BF16>, grid, blk, 0, c.s, x, pixels, C, scale, amax, sum);
+  else if (dt == DT_FP8) hipLaunchKernelGGL(chan_stats_kernel<DT_FP8>, grid, blk, 0, c.s, x, pixels, C, scale, amax, sum);
+  else if (dt == DT_I8) hipLaunchKernelGGL(chan_stats_kernel<DT_I8>, grid, blk, 0, c.s, x, pixels, C, scale, amax, sum);
+  else hipLaunchKernelGGL(chan_stats_kernel<DT_F16>, grid, blk, 0, c.s, x, pixels, C, scale, amax, sum);
 }
 
 // arena carve (by capacity, see ensure_scratch)
 struct Arena {
   unsigned char *stem, *x128[3], *x256[3], *x512[3], *tokens, *qkv, *att, *y1, *y2;
+  unsigned char *q128[3], *q256[3], *q512[3];   // 8-bit networks: 1-byte operand copies
 };
 static Arena carve(NNScratch *ws) {
   Arena a;
@@ -4486,70 +4759,135 @@ static Arena carve(NNScratch *ws) {
   a.att = p; p += cap * SZ_TOK;
   a.y1 = p; p += cap * SZ_TOK;
   a.y2 = p; p += cap * SZ_TOK;
+  for (int i = 0; i < 3; i++) { a.q128[i] = p; p += cap * SZ_128 / 2; }
+  for (int i = 0; i < 3; i++) { a.q256[i] = p; p += cap * SZ_256 / 2; }
+  for (int i = 0; i < 3; i++) { a.q512[i] = p; p += cap * SZ_512 / 2; }   // (only allocated for 8-bit networks; never touched otherwise)
   return a;
+}
+
+// the last trunk convolution writes the un-bordered token tensor; whoever did not fuse the positional table adds it here
+static void add_pos_embed(const Ctx &c, const Arena &a, int N) {
+  const Net *net = c.net;
+  size_t rows = (size_t)N * 400;
+  ProfScope ps(c.prof, c.s, "add_pos_embed", 0, (double)rows * EMBED * 4.0);
+  size_t chunks = rows * (EMBED / 8);
+  const dim3 grid((unsigned)((chunks + 255) / 256));
+  if (net->act_dt == DT_BF16) hipLaunchKernelGGL(add_pos_embed_kernel<DT_BF16>, grid, dim3(256), 0, c.s, (__bf16 *)a.tokens, (const __bf16 *)net->pe, 400, rows);
+  else hipLaunchKernelGGL(add_pos_embed_kernel<DT_F16>, grid, dim3(256), 0, c.s, (_Float16 *)a.tokens, (const _Float16 *)net->pe, 400, rows);
+}
+static void broadcast_b(const Ctx &c, unsigned char *cat, int N, int cb /* bytes of the b-half of a pixel */) {
+  ProfScope ps(c.prof, c.s, "broadcast_b", 0, (double)N * 1600 * 2 * cb);
+  size_t total = (size_t)(N - 1) * 1600 * (cb / 16);
+  hipLaunchKernelGGL(broadcast_b_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c.s, cat, N, 42, 42, 40, 40, 1, cb);
+}
+
+// 8-bit trunk (PREC_FP8 / PREC_INT8) [r4].  The 13 3x3 convolutions from encodeA.2 on read 8-bit operands; what differs from the
+// round-3 FP8 trunk: (1) the RESIDUAL STREAM stays f16 -- a block's second conv (and encodeA.1 / encodeAB.2, whose outputs start a
+// stream) writes the f16 tensor and, in the same epilogue, its 8-bit copy for the next conv (DT_DUAL_*), so the skip path is never
+// re-quantised; (2) activation scales are per CHANNEL and folded into the consumer's weights before those are quantised; (3) biases
+// carry the calibration's bias correction, the positional table the token correction (net_apply_q8).
+static int run_trunk_q8(const Ctx &c, const Arena &a, const void *nn_in, int N, int n_b) {
+  const Net *net = c.net;
+  const int NB2 = N + n_b, q = net->qdt;
+  auto F = [&](void *p) { return Act{p, DT_F16, 1.f}; };
+  auto Q = [&](void *p) { return Act{p, q, 1.f}; };
+  const size_t P1 = (size_t)NB2 * 42 * 42, P2 = (size_t)N * 42 * 42, P5 = (size_t)N * 22 * 22;
+  const Act in = F(const_cast<void *>(nn_in)), stem = F(a.stem);
+  if (run_conv(c, "conv_stem", net->a0, in, NB2, 80, 80, 2, stem, 1, true)) return 1;
+  // encodeA.1 (f16 operands) starts the 128-channel stream: f16 x0 + 8-bit copy
+  const Act x0 = F(a.x128[0]), x0q = Q(a.q128[0]), x1q = Q(a.q128[1]), x2 = F(a.x128[2]), x2q = Q(a.q128[2]);
+  if (run_conv(c, "conv_a1", net->a1, stem, NB2, 80, 80, 1, x0, 1, true, nullptr, 0, 0, nullptr, nullptr, nullptr, &x0q, net->act_oinv[1])) return 1;
+  if (run_conv(c, "conv_128", net->ra[0][0], x0q, NB2, 40, 40, 1, x1q, 1, true)) return 1;
+  calib_record(c, 2, a.q128[1], P1, 128, q, net->act_scale_dev[2]);
+  if (run_conv(c, "conv_128", net->ra[0][1], x1q, NB2, 40, 40, 1, x2, 1, true, &x0, 1, 0, nullptr, nullptr, nullptr, &x2q, net->act_oinv[3])) return 1;
+  calib_record(c, 3, a.x128[2], P1, 128, DT_F16);
+  if (run_conv(c, "conv_128", net->ra[1][0], x2q, NB2, 40, 40, 1, x1q, 1, true)) return 1;
+  calib_record(c, 4, a.q128[1], P1, 128, q, net->act_scale_dev[4]);
+  // the last encodeA conv writes the a|b channel concat (f16 + 8-bit copy)
+  const Act cat = F(a.x256[0]), catq = Q(a.q256[0]);
+  if (run_conv(c, "conv_128", net->ra[1][1], x1q, NB2, 40, 40, 1, cat, 1, true, &x2, 1, N, nullptr, nullptr, nullptr, &catq, net->act_oinv[5])) return 1;
+  if (n_b == 1 && N > 1) {  // image N landed in cat[0][..,128:256]; replicate it for the other hypotheses (both copies)
+    broadcast_b(c, a.x256[0], N, 256);
+    broadcast_b(c, a.q256[0], N, 128);
+  }
+  calib_record(c, 5, a.x256[0], P2, 256, DT_F16);
+  const Act y1q = Q(a.q256[1]), y2 = F(a.x256[2]), y2q = Q(a.q256[2]), y0 = F(a.x256[1]), y0q = Q(a.q256[0]);
+  if (run_conv(c, "conv_256", net->rb[0][0], catq, N, 40, 40, 1, y1q, 1, true)) return 1;
+  calib_record(c, 6, a.q256[1], P2, 256, q, net->act_scale_dev[6]);
+  if (run_conv(c, "conv_256", net->rb[0][1], y1q, N, 40, 40, 1, y2, 1, true, &cat, 1, 0, nullptr, nullptr, nullptr, &y2q, net->act_oinv[7])) return 1;
+  calib_record(c, 7, a.x256[2], P2, 256, DT_F16);
+  if (run_conv(c, "conv_256", net->rb[1][0], y2q, N, 40, 40, 1, y1q, 1, true)) return 1;
+  calib_record(c, 8, a.q256[1], P2, 256, q, net->act_scale_dev[8]);
+  // (y0 feeds only encodeAB.2: its f16 copy is written but never read -- 0.2 GB per launch; an 8-bit-only output with a residual
+  //  cannot fold the consumer's scales into the bias)
+  if (run_conv(c, "conv_256", net->rb[1][1], y1q, N, 40, 40, 1, y0, 1, true, &y2, 1, 0, nullptr, nullptr, nullptr, &y0q, net->act_oinv[9])) return 1;
+  calib_record(c, 9, a.x256[1], P2, 256, DT_F16);
+  const Act z0 = F(a.x512[0]), z0q = Q(a.q512[0]), z1q = Q(a.q512[1]), z2 = F(a.x512[2]), z2q = Q(a.q512[2]);
+  if (run_conv(c, "conv_b2", net->b2, y0q, N, 40, 40, 1, z0, 1, true, nullptr, 0, 0, nullptr, nullptr, nullptr, &z0q, net->act_oinv[10])) return 1;
+  calib_record(c, 10, a.x512[0], P5, 512, DT_F16);
+  if (run_conv(c, "conv_512", net->rc[0][0], z0q, N, 20, 20, 1, z1q, 1, true)) return 1;
+  calib_record(c, 11, a.q512[1], P5, 512, q, net->act_scale_dev[11]);
+  if (run_conv(c, "conv_512", net->rc[0][1], z1q, N, 20, 20, 1, z2, 1, true, &z0, 1, 0, nullptr, nullptr, nullptr, &z2q, net->act_oinv[12])) return 1;
+  calib_record(c, 12, a.x512[2], P5, 512, DT_F16);
+  if (run_conv(c, "conv_512", net->rc[1][0], z2q, N, 20, 20, 1, z1q, 1, true)) return 1;
+  calib_record(c, 13, a.q512[1], P5, 512, q, net->act_scale_dev[13]);
+  const Act tok = F(a.tokens);
+  bool pe_done = false;
+  if (run_conv(c, "conv_512", net->rc[1][1], z1q, N, 20, 20, 1, tok, 0, true, &z2, 1, 0, nullptr, net->pe, &pe_done)) return 1;
+  if (!pe_done) add_pos_embed(c, a, N);
+  calib_record(c, 14, a.tokens, (size_t)N * 400, 512, DT_F16);
+  return 0;
 }
 
 // shared CNN trunk: nn_in [2N,84,84,32] (s2d, border 2) -> tokens [N,400,512] + positional embedding
 // n_b = number of observed-crop (B) images following the N rendered (A) images: N, or 1 when all hypotheses share it
 static int run_trunk(const Ctx &c, const Arena &a, const void *nn_in, int N, int n_b) {
   const Net *net = c.net;
+  if (net->prec == PREC_FP8 || net->prec == PREC_INT8) return run_trunk_q8(c, a, nn_in, N, n_b);
   const int NB2 = N + n_b;
-  const int adt = net->act_dt;                                  // nn_in, stem output, tokens
-  const int tdt = net->prec == PREC_FP8 ? DT_FP8 : adt;         // trunk activations from encodeA.1's output on
-  const float *sc = net->act_scale;                             // all 1 unless FP8
-  auto T = [&](void *p, int id) { return Act{p, tdt, tdt == DT_FP8 ? sc[id] : 1.f}; };
-  const size_t tes = elem_bytes(tdt);
-  const Act in{const_cast<void *>(nn_in), adt, 1.f}, stem{a.stem, adt, 1.f};
+  const int adt = net->act_dt;
+  auto T = [&](void *p) { return Act{p, adt, 1.f}; };
+  const size_t P1 = (size_t)NB2 * 42 * 42, P2 = (size_t)N * 42 * 42, P5 = (size_t)N * 22 * 22;
+  const Act in = T(const_cast<void *>(nn_in)), stem = T(a.stem);
   if (run_conv(c, "conv_stem", net->a0, in, NB2, 80, 80, 2, stem, 1, true)) return 1;
-  calib_record(c, 0, a.stem, (size_t)NB2 * 82 * 82 * 64 * 2);
-  const Act x0 = T(a.x128[0], 1), x1 = T(a.x128[1], 2), x2 = T(a.x128[2], 3), x1b = T(a.x128[1], 4), cat = T(a.x256[0], 5);
+  const Act x0 = T(a.x128[0]), x1 = T(a.x128[1]), x2 = T(a.x128[2]), cat = T(a.x256[0]);
   if (run_conv(c, "conv_a1", net->a1, stem, NB2, 80, 80, 1, x0, 1, true)) return 1;
-  calib_record(c, 1, a.x128[0], (size_t)NB2 * 42 * 42 * 128 * 2);
+  calib_record(c, 1, a.x128[0], P1, 128, adt);
   // encodeA residual blocks @40x40x128; the last conv writes the a|b channel concat directly
   if (run_conv(c, "conv_128", net->ra[0][0], x0, NB2, 40, 40, 1, x1, 1, true)) return 1;
-  calib_record(c, 2, a.x128[1], (size_t)NB2 * 42 * 42 * 128 * 2);
+  calib_record(c, 2, a.x128[1], P1, 128, adt);
   if (run_conv(c, "conv_128", net->ra[0][1], x1, NB2, 40, 40, 1, x2, 1, true, &x0, 1)) return 1;
-  calib_record(c, 3, a.x128[2], (size_t)NB2 * 42 * 42 * 128 * 2);
-  if (run_conv(c, "conv_128", net->ra[1][0], x2, NB2, 40, 40, 1, x1b, 1, true)) return 1;
-  calib_record(c, 4, a.x128[1], (size_t)NB2 * 42 * 42 * 128 * 2);
-  if (run_conv(c, "conv_128", net->ra[1][1], x1b, NB2, 40, 40, 1, cat, 1, true, &x2, 1, N)) return 1;
-  if (n_b == 1 && N > 1) {  // image N landed in cat[0][..,128:256]; replicate it for the other hypotheses
-    ProfScope ps(c.prof, c.s, "broadcast_b", 0, (double)N * 1600 * 256);
-    size_t total = (size_t)(N - 1) * 1600 * (128 * tes / 16);
-    hipLaunchKernelGGL(broadcast_b_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c.s, a.x256[0], N, 42, 42, 40, 40, 1, (int)(128 * tes));
-  }
-  calib_record(c, 5, a.x256[0], (size_t)N * 42 * 42 * 256 * 2);
+  calib_record(c, 3, a.x128[2], P1, 128, adt);
+  if (run_conv(c, "conv_128", net->ra[1][0], x2, NB2, 40, 40, 1, x1, 1, true)) return 1;
+  calib_record(c, 4, a.x128[1], P1, 128, adt);
+  if (run_conv(c, "conv_128", net->ra[1][1], x1, NB2, 40, 40, 1, cat, 1, true, &x2, 1, N)) return 1;
+  if (n_b == 1 && N > 1) broadcast_b(c, a.x256[0], N, 256);  // image N landed in cat[0][..,128:256]; replicate it for the other hypotheses
+  calib_record(c, 5, a.x256[0], P2, 256, adt);
   // encodeAB
-  const Act y1 = T(a.x256[1], 6), y2 = T(a.x256[2], 7), y1b = T(a.x256[1], 8), y0 = T(a.x256[0], 9);
+  const Act y1 = T(a.x256[1]), y2 = T(a.x256[2]), y0 = T(a.x256[0]);
   if (run_conv(c, "conv_256", net->rb[0][0], cat, N, 40, 40, 1, y1, 1, true)) return 1;
-  calib_record(c, 6, a.x256[1], (size_t)N * 42 * 42 * 256 * 2);
+  calib_record(c, 6, a.x256[1], P2, 256, adt);
   if (run_conv(c, "conv_256", net->rb[0][1], y1, N, 40, 40, 1, y2, 1, true, &cat, 1)) return 1;
-  calib_record(c, 7, a.x256[2], (size_t)N * 42 * 42 * 256 * 2);
-  if (run_conv(c, "conv_256", net->rb[1][0], y2, N, 40, 40, 1, y1b, 1, true)) return 1;
-  calib_record(c, 8, a.x256[1], (size_t)N * 42 * 42 * 256 * 2);
-  if (run_conv(c, "conv_256", net->rb[1][1], y1b, N, 40, 40, 1, y0, 1, true, &y2, 1)) return 1;
-  calib_record(c, 9, a.x256[0], (size_t)N * 42 * 42 * 256 * 2);
-  const Act z0 = T(a.x512[0], 10), z1 = T(a.x512[1], 11), z2 = T(a.x512[2], 12), z1b = T(a.x512[1], 13);
+  calib_record(c, 7, a.x256[2], P2, 256, adt);
+  if (run_conv(c, "conv_256", net->rb[1][0], y2, N, 40, 40, 1, y1, 1, true)) return 1;
+  calib_record(c, 8, a.x256[1], P2, 256, adt);
+  if (run_conv(c, "conv_256", net->rb[1][1], y1, N, 40, 40, 1, y0, 1, true, &y2, 1)) return 1;
+  calib_record(c, 9, a.x256[0], P2, 256, adt);
+  const Act z0 = T(a.x512[0]), z1 = T(a.x512[1]), z2 = T(a.x512[2]);
   if (run_conv(c, "conv_b2", net->b2, y0, N, 40, 40, 1, z0, 1, true)) return 1;
-  calib_record(c, 10, a.x512[0], (size_t)N * 22 * 22 * 512 * 2);
+  calib_record(c, 10, a.x512[0], P5, 512, adt);
   if (run_conv(c, "conv_512", net->rc[0][0], z0, N, 20, 20, 1, z1, 1, true)) return 1;
-  calib_record(c, 11, a.x512[1], (size_t)N * 22 * 22 * 512 * 2);
+  calib_record(c, 11, a.x512[1], P5, 512, adt);
   if (run_conv(c, "conv_512", net->rc[0][1], z1, N, 20, 20, 1, z2, 1, true, &z0, 1)) return 1;
-  calib_record(c, 12, a.x512[2], (size_t)N * 22 * 22 * 512 * 2);
-  if (run_conv(c, "conv_512", net->rc[1][0], z2, N, 20, 20, 1, z1b, 1, true)) return 1;
-  calib_record(c, 13, a.x512[1], (size_t)N * 22 * 22 * 512 * 2);
+  calib_record(c, 12, a.x512[2], P5, 512, adt);
+  if (run_conv(c, "conv_512", net->rc[1][0], z2, N, 20, 20, 1, z1, 1, true)) return 1;
+  calib_record(c, 13, a.x512[1], P5, 512, adt);
   // last conv writes the un-bordered token tensor [N,400,512] (2-byte type in every precision)
-  const Act tok{a.tokens, adt, 1.f};
+  const Act tok = T(a.tokens);
   bool pe_done = false;
-  if (run_conv(c, "conv_512", net->rc[1][1], z1b, N, 20, 20, 1, tok, 0, true, &z2, 1, 0, nullptr, net->pe, &pe_done)) return 1;
-  if (!pe_done) {
-    size_t rows = (size_t)N * 400;
-    ProfScope ps(c.prof, c.s, "add_pos_embed", 0, (double)rows * EMBED * 4.0);
-    size_t chunks = rows * (EMBED / 8);
-    const dim3 grid((unsigned)((chunks + 255) / 256));
-    if (adt == DT_BF16) hipLaunchKernelGGL(add_pos_embed_kernel<DT_BF16>, grid, dim3(256), 0, c.s, (__bf16 *)a.tokens, (const __bf16 *)net->pe, 400, rows);
-    else hipLaunchKernelGGL(add_pos_embed_kernel<DT_F16>, grid, dim3(256), 0, c.s, (_Float16 *)a.tokens, (const _Float16 *)net->pe, 400, rows);
-  }
+  if (run_conv(c, "conv_512", net->rc[1][1], z1, N, 20, 20, 1, tok, 0, true, &z2, 1, 0, nullptr, net->pe, &pe_done)) return 1;
+  if (!pe_done) add_pos_embed(c, a, N);
+  calib_record(c, 14, a.tokens, (size_t)N * 400, 512, adt);
   return 0;
 }
 
@@ -4557,7 +4895,7 @@ int refiner_forward(hipStream_t s, Profiler *prof, const Net *net, NNScratch *ws
                     float *trans_dev, float *rot_dev, int shared_b, const PoseUpdateFuse *fuse, bool *fused_out) {
   if (fused_out) *fused_out = false;
   FP_CHECK(net && !net->scorer, "refiner_forward: wrong network");
-  FP_CHECK(net_fp8_ready(net), "[FoundationPose] FP8 precision needs activation scales: call fp_calibrate_fp8 first");
+  FP_CHECK(net_q8_ready(net), "[FoundationPose] the 8-bit precisions need a calibration: call fp_calibrate (fp_calibrate_fp8) first");
   if (ensure_scratch(ws, N, s)) return 1;
   Ctx c{s, prof, net, ws};
   const Arena a = carve(ws);
@@ -4617,7 +4955,7 @@ int refiner_forward(hipStream_t s, Profiler *prof, const Net *net, NNScratch *ws
 
 int scorer_features(hipStream_t s, Profiler *prof, const Net *net, NNScratch *ws, const void *nn_in, int N, float *feat_dev) {
   FP_CHECK(net && net->scorer, "scorer_features: wrong network");
-  FP_CHECK(net_fp8_ready(net), "[FoundationPose] FP8 precision needs activation scales: call fp_calibrate_fp8 first");
+  FP_CHECK(net_q8_ready(net), "[FoundationPose] the 8-bit precisions need a calibration: call fp_calibrate (fp_calibrate_fp8) first");
   if (ensure_scratch(ws, N, s)) return 1;
   Ctx c{s, prof, net, ws};
   const Arena a = carve(ws);
@@ -4718,14 +5056,10 @@ std::vector<__half> to_half(const float *src, size_t n) {
   for (size_t i = 0; i < n; i++) h[i] = __float2half(src[i]);
   return h;
 }
-// float <-> element bytes of a tensor (FP8: stored = real / scale)
+// float <-> element bytes of a 2-byte tensor
 std::vector<unsigned char> encode(const float *src, size_t n, int dt, float scale) {
+  (void)scale;
   std::vector<float> tmp(src, src + n);
-  if (dt == fp::DT_FP8) {
-    std::vector<unsigned char> o(n);
-    for (size_t i = 0; i < n; i++) o[i] = fp::f32_to_e4m3_bits(src[i] / scale);
-    return o;
-  }
   return fp::to_elems(tmp, 1, (int)n, dt, nullptr);
 }
 float e4m3_to_f32(unsigned char b) {
@@ -4799,8 +5133,8 @@ int fpt_clk_probe(int blocks, double *mhz_out, double *loop_cycles_out) {
 
 // x [NB,H,W,Cin] NHWC f32, w [Cout,KH,KW,Cin] f32, bias [Cout], res (optional) [NB,OH,OW,Cout]
 // -> out f32 [NB,OH,OW,Cout] (or, with split_imgs > 0, [NB-split,OH,OW,2*Cout]).  iters > 1: returns mean ms in *ms_out.
-// dt = element type of x / w / res on the device (DT_*), out_dt = element type of the output.  FP8 tensors are stored as
-// real / scale (in_scale, res_scale, out_scale); FP8 weights are quantised per output channel exactly like net_load does.
+// dt = element type of x / w / res on the device (DT_F16 / DT_BF16), out_dt = element type of the output; the scale arguments are
+// ignored (kept for the callers' signature).  8-bit layers: fpt_conv_q8.
 int fpt_conv_dt(const float *x, const float *w, const float *bias, const float *res, int NB, int H, int W, int Cin, int Cout,
                 int KH, int KW, int stride, int pad, int OH, int OW, int relu, int split_imgs, float *out, int iters,
                 float *ms_out, int dt, int out_dt, float in_scale, float res_scale, float out_scale) {
@@ -4830,12 +5164,7 @@ int fpt_conv_dt(const float *x, const float *w, const float *bias, const float *
   ConvLayer L;
   L.Cin = Cin; L.Cout = Cout; L.KH = KH; L.KW = KW; L.stride = stride; L.pad = pad;
   FP_CHECK(finish_layer(&net, std::vector<float>(w, w + nw), std::vector<float>(bias, bias + Cout), Cout, KH * KW, Cin, dt, &L), "fpt_conv: weight upload failed");
-  if (dt == DT_FP8) {
-    std::vector<float> cs(Cout);
-    FP_HIP_OK(fp::memcpy_sync(cs.data(), L.wscale, (size_t)Cout * 4, hipMemcpyDeviceToHost));
-    for (auto &v : cs) v *= in_scale;
-    FP_HIP_OK(fp::memcpy_sync(L.cscale, cs.data(), (size_t)Cout * 4, hipMemcpyHostToDevice));
-  }
+  FP_CHECK(!is_q8(dt) && !is_q8(out_dt), "fpt_conv_dt: 2-byte element types only (8-bit layers: fpt_conv_q8)");
   Ctx c{nullptr, nullptr, &net};
   (void)OH; (void)OW;
   const Act ain{dx.p, dt, in_scale}, aout{dout.p, out_dt, out_scale}, ares{dres.p, dt, res_scale};
@@ -4859,6 +5188,141 @@ int fpt_conv_dt(const float *x, const float *w, const float *bias, const float *
   std::vector<unsigned char> ho(nout * oes);
   FP_HIP_OK(fp::memcpy_sync(ho.data(), dout.p, ho.size(), hipMemcpyDeviceToHost));
   decode(ho.data(), nout, out_dt, out_scale, out);
+  return 0;
+}
+// One 8-bit convolution exactly as the 8-bit trunk runs it (net_apply_q8 / run_trunk_q8).
+//   x [NB,H,W,Cin] f32 (>= 0 for DT_I8), s_in [Cin] per-channel activation scales: the device input is e4m3(x / s) or
+//   (clamp(rint(x / s), 0, 255) ^ 0x80) with a border of "zero" bytes; w [Cout,KH,KW,Cin] f32 is quantised per row AFTER s_in is folded
+//   in; res (optional) [NB,OH,OW,Cout] is f16 on the device.
+//   mode 0: 8-bit output only, the consumer's scales s_out [Cout] folded into the epilogue tables -> outq (de-quantised values)
+//   mode 1: f16 output only -> out16;  mode 2: f16 output + its 8-bit copy (value / s_out[c]) -> out16, outq
+// split_imgs > 0: the a|b channel concat ([NB - split, OH, OW, 2 * Cout]; s_out still indexed by the layer's output channel).
+// wq_out (optional) [Cout*KH*KW*Cin]: the de-quantised weights the device used (w' / s_in, i.e. comparable with w), sw_out [Cout].
+int fpt_conv_q8(const float *x, const float *s_in, const float *w, const float *bias, const float *res, int NB, int H, int W, int Cin, int Cout,
+                int KH, int KW, int stride, int pad, int OH, int OW, int relu, int split_imgs, int mode, const float *s_out, float *out16,
+                float *outq, int iters, float *ms_out, int dt, float *wq_out) {
+  using namespace fp;
+  FP_CHECK(is_q8(dt) && mode >= 0 && mode <= 2, "fpt_conv_q8: invalid arguments");
+  const int ip = pad, Hp = H + 2 * ip, Wp = W + 2 * ip;
+  const size_t nx = (size_t)NB * Hp * Wp * Cin, nw = (size_t)Cout * KH * KW * Cin, M = (size_t)NB * OH * OW, nout = M * Cout;
+  DevBuf<unsigned char> dx(nx), dres(nout * 2), d16(nout * 2), dq(nout);
+  FP_CHECK(dx.p && dres.p && d16.p && dq.p, "fpt_conv_q8: allocation failed");
+  std::vector<unsigned char> hx(nx, dt == DT_I8 ? 0x80 : 0x00);
+  for (int n = 0; n < NB; n++)
+    for (int y = 0; y < H; y++)
+      for (int xx = 0; xx < W; xx++)
+        for (int c = 0; c < Cin; c++) {
+          const float v = x[(((size_t)n * H + y) * W + xx) * Cin + c] / s_in[c];
+          unsigned char b;
+          if (dt == DT_FP8) b = f32_to_e4m3_bits(v);
+          else b = (unsigned char)((int)std::max(0.f, std::min(255.f, std::nearbyint(v))) ^ 0x80);
+          hx[(((size_t)n * Hp + y + ip) * Wp + xx + ip) * Cin + c] = b;
+        }
+  FP_HIP_OK(fp::memcpy_sync(dx.p, hx.data(), nx, hipMemcpyHostToDevice));
+  FP_HIP_OK(fp::memset_sync(d16.p, 0, nout * 2));
+  FP_HIP_OK(fp::memset_sync(dq.p, dt == DT_I8 ? 0x80 : 0, nout));
+  if (res) {
+    auto hr = encode(res, nout, DT_F16, 1.f);
+    FP_HIP_OK(fp::memcpy_sync(dres.p, hr.data(), hr.size(), hipMemcpyHostToDevice));
+  }
+  Net net;
+  net.prec = dt == DT_FP8 ? PREC_FP8 : PREC_INT8;
+  net.qdt = dt;
+  ConvLayer L;
+  L.Cin = Cin; L.Cout = Cout; L.KH = KH; L.KW = KW; L.stride = stride; L.pad = pad;
+  FP_CHECK(finish_layer(&net, std::vector<float>(w, w + nw), std::vector<float>(bias, bias + Cout), Cout, KH * KW, Cin, dt, &L), "fpt_conv_q8: weight upload failed");
+  if (apply_q8_layer(&net, L, dt, s_in, nullptr, mode == 0 ? s_out : nullptr, true)) return 1;
+  if (wq_out) {  // what the device multiplies with, de-quantised and with s_in divided out again
+    std::vector<float> sw; std::vector<double> qs;
+    const auto e = quantise_q8(L, dt, s_in, &sw, &qs);
+    for (size_t i = 0; i < nw; i++) {
+      const int co = (int)(i / ((size_t)KH * KW * Cin)), ci = (int)(i % Cin);
+      const float q = dt == DT_FP8 ? e4m3_to_f32(e[i]) : (float)(signed char)e[i];
+      wq_out[i] = q * sw[co] / s_in[ci];
+    }
+  }
+  float *oinv_dev = nullptr;
+  if (mode == 2) {
+    std::vector<float> inv(Cout);
+    for (int c2 = 0; c2 < Cout; c2++) inv[c2] = 1.f / s_out[c2];
+    oinv_dev = upload(&net, inv);
+    FP_CHECK(oinv_dev, "fpt_conv_q8: allocation failed");
+  }
+  Ctx c{nullptr, nullptr, &net};
+  (void)OH; (void)OW;
+  const Act ain{dx.p, dt, 1.f}, a16{d16.p, DT_F16, 1.f}, aq{dq.p, dt, 1.f}, ares{dres.p, DT_F16, 1.f};
+  auto once = [&]() {
+    if (mode == 0) return run_conv(c, "t", L, ain, NB, H, W, ip, aq, 0, relu != 0, res ? &ares : nullptr, 0, split_imgs);
+    if (mode == 1) return run_conv(c, "t", L, ain, NB, H, W, ip, a16, 0, relu != 0, res ? &ares : nullptr, 0, split_imgs);
+    return run_conv(c, "t", L, ain, NB, H, W, ip, a16, 0, relu != 0, res ? &ares : nullptr, 0, split_imgs, nullptr, nullptr, nullptr, &aq, oinv_dev);
+  };
+  if (once()) return 1;
+  FP_HIP_OK(hipDeviceSynchronize());
+  if (iters > 1) {
+    hipEvent_t e0, e1;
+    FP_HIP_OK(hipEventCreate(&e0));
+    FP_HIP_OK(hipEventCreate(&e1));
+    FP_HIP_OK(hipEventRecord(e0, nullptr));
+    for (int i = 0; i < iters; i++)
+      if (once()) return 1;
+    FP_HIP_OK(hipEventRecord(e1, nullptr));
+    FP_HIP_OK(hipEventSynchronize(e1));
+    float ms = 0;
+    FP_HIP_OK(hipEventElapsedTime(&ms, e0, e1));
+    if (ms_out) *ms_out = ms / iters;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+  }
+  if (mode >= 1 && out16) {
+    std::vector<unsigned char> ho(nout * 2);
+    FP_HIP_OK(fp::memcpy_sync(ho.data(), d16.p, ho.size(), hipMemcpyDeviceToHost));
+    decode(ho.data(), nout, DT_F16, 1.f, out16);
+  }
+  if (mode != 1 && outq) {
+    std::vector<unsigned char> ho(nout);
+    FP_HIP_OK(fp::memcpy_sync(ho.data(), dq.p, nout, hipMemcpyDeviceToHost));
+    // output layout [.., 2*Cout] with the concat: channel index modulo Cout selects the scale
+    for (size_t i = 0; i < nout; i++) {
+      const int ch = (int)(i % (split_imgs > 0 ? 2 * (size_t)Cout : (size_t)Cout)) % Cout;
+      const float q = dt == DT_FP8 ? e4m3_to_f32(ho[i]) : (float)(ho[i] ^ 0x80);
+      outq[i] = q * s_out[ch];
+    }
+  }
+  return 0;
+}
+// The f16 -> 8-bit boundary layer (encodeA.1 of the 8-bit networks): f16 operands, f16 stream output + 8-bit copy (value / s_out[c]).
+int fpt_conv_f16_dual(const float *x, const float *w, const float *bias, int NB, int H, int W, int Cin, int Cout, int KH, int KW, int stride,
+                      int pad, int OH, const float *s_out, float *out16, float *outq, int qdt) {
+  using namespace fp;
+  FP_CHECK(is_q8(qdt), "fpt_conv_f16_dual: qdt must be an 8-bit type");
+  const int ip = pad, Hp = H + 2 * ip, Wp = W + 2 * ip, OW = OH;
+  const size_t nx = (size_t)NB * Hp * Wp * Cin, nw = (size_t)Cout * KH * KW * Cin, nout = (size_t)NB * OH * OW * Cout;
+  DevBuf<unsigned char> dx(nx * 2), d16(nout * 2), dq(nout);
+  FP_CHECK(dx.p && d16.p && dq.p, "fpt_conv_f16_dual: allocation failed");
+  std::vector<float> xp(nx, 0.f);
+  for (int n = 0; n < NB; n++)
+    for (int y = 0; y < H; y++)
+      for (int xx = 0; xx < W; xx++)
+        for (int c = 0; c < Cin; c++) xp[(((size_t)n * Hp + y + ip) * Wp + xx + ip) * Cin + c] = x[(((size_t)n * H + y) * W + xx) * Cin + c];
+  auto hx = encode(xp.data(), nx, DT_F16, 1.f);
+  FP_HIP_OK(fp::memcpy_sync(dx.p, hx.data(), hx.size(), hipMemcpyHostToDevice));
+  Net net;
+  ConvLayer L;
+  L.Cin = Cin; L.Cout = Cout; L.KH = KH; L.KW = KW; L.stride = stride; L.pad = pad;
+  FP_CHECK(finish_layer(&net, std::vector<float>(w, w + nw), std::vector<float>(bias, bias + Cout), Cout, KH * KW, Cin, DT_F16, &L), "fpt_conv_f16_dual: weight upload failed");
+  std::vector<float> inv(Cout);
+  for (int c2 = 0; c2 < Cout; c2++) inv[c2] = 1.f / s_out[c2];
+  float *oinv_dev = upload(&net, inv);
+  FP_CHECK(oinv_dev, "fpt_conv_f16_dual: allocation failed");
+  Ctx c{nullptr, nullptr, &net};
+  const Act ain{dx.p, DT_F16, 1.f}, a16{d16.p, DT_F16, 1.f}, aq{dq.p, qdt, 1.f};
+  if (run_conv(c, "t", L, ain, NB, H, W, ip, a16, 0, true, nullptr, 0, 0, nullptr, nullptr, nullptr, &aq, oinv_dev)) return 1;
+  FP_HIP_OK(hipDeviceSynchronize());
+  std::vector<unsigned char> h16(nout * 2), hq(nout);
+  FP_HIP_OK(fp::memcpy_sync(h16.data(), d16.p, h16.size(), hipMemcpyDeviceToHost));
+  FP_HIP_OK(fp::memcpy_sync(hq.data(), dq.p, nout, hipMemcpyDeviceToHost));
+  decode(h16.data(), nout, DT_F16, 1.f, out16);
+  for (size_t i = 0; i < nout; i++) outq[i] = (qdt == DT_FP8 ? e4m3_to_f32(hq[i]) : (float)(hq[i] ^ 0x80)) * s_out[i % Cout];
   return 0;
 }
 // Host-only check of the weight layouts (no GPU): every (tile, K-step, lane) address a kernel forms into fragment_order /

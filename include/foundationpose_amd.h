@@ -205,21 +205,37 @@ int fp_net_infer(fp_net *net, int batch, int render_loc, int transf_loc, int out
 
 /* ---- network precision ----------------------------------------------------------------------------------------------
  * The reference runs TensorRT engines built with --fp16 (tools/cvt_onnx2trt.bash:3-15): FP_PREC_F16 is the default and
- * the parity baseline.  FP_PREC_BF16: every tensor and MFMA operand in bf16 (BASELINE configs[1]).  FP_PREC_FP8: the 3x3
- * trunk convolutions from encodeA.2 on (91 % of the FLOPs) on OCP e4m3 operands (v_mfma_f32_16x16x128_f8f6f4) with
- * per-output-channel weight scales and static per-tensor activation scales, everything else f16 (BASELINE configs[4]);
- * needs fp_calibrate_fp8 / fp_set_calibration first.  Networks of a precision are built from the weight files given to
- * fp_create the first time the precision is selected. */
+ * the parity baseline.  FP_PREC_BF16: every tensor and MFMA operand in bf16 (BASELINE configs[1]).
+ * FP_PREC_FP8 / FP_PREC_INT8 (BASELINE configs[4], the 8-bit MFMA conv path): the 13 3x3 trunk convolutions from encodeA.2 on
+ * (91 % of the FLOPs) on 8-bit operands -- OCP e4m3 (v_mfma_f32_16x16x128_f8f6f4) or signed / unsigned 8-bit integers
+ * (v_mfma_i32_16x16x64_i8, the same matrix-pipe rate class) -- with per-output-channel weight scales, per-input-channel
+ * activation scales folded into the weights, an f16 residual stream (a skip connection is never re-quantised) and a data-driven
+ * bias correction; everything else f16.  Both need fp_calibrate / fp_set_calibration_blob first.  INT8 is the one that holds the
+ * parity bars of the discriminating test networks: uniform 8-bit steps over a ReLU output's range round 5-7x finer than e4m3's
+ * 3 mantissa bits (DESIGN.md section 4.4 has the measurements).  Networks of a precision are built from the weight files given
+ * to fp_create the first time the precision is selected. */
 #define FP_PREC_F16 0
 #define FP_PREC_BF16 1
 #define FP_PREC_FP8 2
+#define FP_PREC_INT8 3
 int fp_set_precision(fp_model *m, int precision);
 int fp_get_precision(const fp_model *m);
-/* Post-training static quantisation: one Register of the frame in f16 with |max| collection on the 15 trunk activations
- * of both networks.  The pose is discarded; the model's precision is unchanged. */
+/* Post-training static quantisation for `precision` (FP_PREC_FP8 / FP_PREC_INT8) on one frame: a Register in f16 collects per-channel
+ * |max| and mean of the 15 trunk activations of both networks, the 8-bit networks are quantised from them, then ~27 Registers of
+ * the 8-bit model solve the bias correction layer by layer.  The pose is discarded; the model's precision is unchanged.
+ * fp_calibrate_fp8 = fp_calibrate(..., FP_PREC_FP8) (the round-2 name). */
+int fp_calibrate(fp_model *m, const void *rgb, const void *depth, const void *mask, int memspace, int H, int W,
+                 const char *target_name, int precision);
 int fp_calibrate_fp8(fp_model *m, const void *rgb, const void *depth, const void *mask, int memspace, int H, int W,
                      const char *target_name);
-/* The collected |max| values ([refiner 16 | scorer 16], 15 used each) so that a deployment can calibrate once and reuse. */
+/* The calibration record of a precision (scales + corrections, fp_calibration_size() bytes, versioned) so that a deployment
+ * calibrates once and reuses it; fp_set_calibration_blob reads the precision from the record. */
+size_t fp_calibration_size(void);
+int fp_get_calibration_blob(const fp_model *m, int precision, void *out, size_t capacity);
+int fp_set_calibration_blob(fp_model *m, const void *blob, size_t bytes);
+/* Per-tensor view of the same (the round-2 interface): |max| per trunk activation, [refiner 16 | scorer 16], 15 used each.
+ * fp_set_calibration gives every channel of a tensor the tensor's scale and NO corrections -- the round-3 behaviour, kept for
+ * records made then; prefer the blob. */
 int fp_get_calibration(const fp_model *m, float amax_out[32]);
 int fp_set_calibration(fp_model *m, const float amax[32]);
 

@@ -122,13 +122,22 @@ public:
   }
 
   // ---- options the reference does not have ----
-  // element type of both networks: FP_PREC_F16 (default, the reference's TensorRT --fp16), FP_PREC_BF16, FP_PREC_FP8 (after CalibrateFp8 / SetCalibration)
+  // element type of both networks: FP_PREC_F16 (default, the reference's TensorRT --fp16), FP_PREC_BF16, FP_PREC_FP8 / FP_PREC_INT8 (after Calibrate)
   bool SetPrecision(int precision) { return ok(fp_set_precision(h_, precision)); }
   int precision() const { return fp_get_precision(h_); }
   // one f16 Register of a representative frame that records the per-activation maxima the static FP8 quantisation needs
   bool CalibrateFp8(const ImageU8 &rgb, const ImageF32 &depth, const ImageU8 &mask, const std::string &target_name) {
     return ok(fp_calibrate_fp8(h_, rgb.data, depth.data, mask.data, FP_HOST, depth.rows, depth.cols, target_name.c_str()));
   }
+  // post-training quantisation of an 8-bit precision on a representative frame (scales + bias correction); the record can be saved and restored
+  bool Calibrate(const ImageU8 &rgb, const ImageF32 &depth, const ImageU8 &mask, const std::string &target_name, int precision) {
+    return ok(fp_calibrate(h_, rgb.data, depth.data, mask.data, FP_HOST, depth.rows, depth.cols, target_name.c_str(), precision));
+  }
+  bool GetCalibrationBlob(int precision, std::vector<unsigned char> &blob) const {
+    blob.resize(fp_calibration_size());
+    return fp_get_calibration_blob(h_, precision, blob.data(), blob.size()) == 0;
+  }
+  bool SetCalibrationBlob(const std::vector<unsigned char> &blob) { return ok(fp_set_calibration_blob(h_, blob.data(), blob.size())); }
   bool GetCalibration(std::array<float, 32> &amax) const { return fp_get_calibration(h_, amax.data()) == 0; }
   bool SetCalibration(const std::array<float, 32> &amax) { return ok(fp_set_calibration(h_, amax.data())); }
   // float model of the rendering stage: FP_FLOAT_FMAD (default: contracted like the reference's nvcc build) or FP_FLOAT_SEPARATE

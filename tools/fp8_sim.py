@@ -27,7 +27,8 @@ LAYERS = ["encodeA.2.conv1", "encodeA.2.conv2", "encodeA.3.conv1", "encodeA.3.co
 MODE = os.environ.get("MODE", "fp8")   # fp8 | int8 (per-tensor u8 activations) | int8c (per-input-channel u8 activations)
 AMARGIN = float(os.environ.get("AMARGIN", "1.25"))
 POSTBC = int(os.environ.get("POSTBC", "0")); POSTGAIN = float(os.environ.get("POSTGAIN", "1.0"))
-SWEEPS = int(os.environ.get("SWEEPS", "1"))
+CLIPK = float(os.environ.get("CLIPK", "0")); FLOOR = float(os.environ.get("FLOOR", "0"))
+SWEEPS = int(os.environ.get("SWEEPS", "1")); JACOBI = int(os.environ.get("JACOBI", "0"))
 
 
 def q8(x, scale):
@@ -129,6 +130,9 @@ class Trunk:
             if amax_out is not None:
                 amax_out[i] = max(amax_out.get(i, 0.0), float(t.abs().max()))
                 c = t.abs().amax(dim=(0, 2, 3))
+                if CLIPK > 0:   # clip the range at mean + K sigma of the channel (never above its |max|)
+                    c = torch.minimum(c, t.mean(dim=(0, 2, 3)) + CLIPK * t.std(dim=(0, 2, 3)))
+                if FLOOR > 0: c = torch.maximum(c, c.max() * FLOOR)
                 amax_out[("c", i)] = torch.maximum(amax_out[("c", i)], c) if ("c", i) in amax_out else c
         note(1, x)
         x = self.store(x, 0, 1, True)
@@ -219,10 +223,14 @@ def main():
                 # sequential bias correction on the calibration batch: layer by layer, match the per-channel mean of the
                 # pre-activation output to the exact network's
                 for it in range(bc):
-                    for i, name in enumerate(LAYERS):
-                        if not mask[i]: continue
+                    if JACOBI:
                         t.record = {}
                         t.forward(Ac, Bc)
+                    for i, name in enumerate(LAYERS):
+                        if not mask[i]: continue
+                        if not JACOBI:
+                            t.record = {}
+                            t.forward(Ac, Bc)
                         key = ("post:" + name) if POSTBC else name
                         d = (rec_exact[key] - t.record[key]) * (POSTGAIN if POSTBC else 1.0)
                         t.bias_fix[name] = t.bias_fix.get(name, 0) + d
