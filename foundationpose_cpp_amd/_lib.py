@@ -14,7 +14,7 @@ CSRC = os.path.join(_HERE, "csrc")
 
 # every symbol include/foundationpose_amd.h declares
 SYMBOLS = [
-    "fp_create", "fp_destroy", "fp_last_error", "fp_set_inplane_steps", "fp_num_hypotheses",
+    "fp_create", "fp_create_on", "fp_device", "fp_register_sharded", "fp_destroy", "fp_last_error", "fp_set_inplane_steps", "fp_num_hypotheses",
     "fp_register", "fp_track", "fp_register_ex", "fp_track_ex", "fp_track_submit", "fp_track_wait", "fp_track_multi",
     "fp_upload_frame", "fp_get_xyz_map", "fp_get_hyp_poses", "fp_filter_depth",
     "fp_render_and_transform", "fp_debug_rasterize", "fp_refiner_infer", "fp_scorer_infer",
@@ -60,6 +60,8 @@ def lib() -> C.CDLL:
         getattr(L, s)  # raises AttributeError if the library does not export the symbol
     L.fp_create.restype = C.c_void_p
     L.fp_create.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int]
+    L.fp_create_on.restype = C.c_void_p
+    L.fp_create_on.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int]
     L.fp_destroy.argtypes = [C.c_void_p]
     L.fp_destroy.restype = None
     L.fp_last_error.restype = C.c_char_p
@@ -106,6 +108,7 @@ def lib() -> C.CDLL:
         "fp_register_shard_begin_packed": [vp, vp, vp, vp, ci, ci, ci, cs, ci, ci, ci, vp, ci],
         "fp_register_shard_finish_packed": [vp, vp, ci, vp, vp],
         "fp_download": [vp, vp, vp, C.c_size_t],
+        "fp_register_sharded": [vp, vp, vp, vp, vp, ci, ci, ci, cs, ci, vp, vp], "fp_device": [vp],
         "fp_profile_enable": [vp, ci], "fp_profile_reset": [vp], "fp_profile_report": [vp, vp, ci],
         "fp_synchronize": [vp], "fp_mesh_orient_bounds": [vp, vp, vp],
         "fp_set_precision": [vp, ci], "fp_get_precision": [vp], "fp_calibrate_fp8": [vp, vp, vp, vp, ci, ci, ci, cs],

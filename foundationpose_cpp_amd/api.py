@@ -63,7 +63,8 @@ class FoundationPose:
     """CreateFoundationPoseModel (foundationpose.hpp:99-105) equivalent."""
 
     def __init__(self, meshes, K, refiner_weights: str | None = None, scorer_weights: str | None = None,
-                 max_input_image_height: int = 1080, max_input_image_width: int = 1920):
+                 max_input_image_height: int = 1080, max_input_image_width: int = 1920, device: int = -1):
+        """device: HIP device the model lives on (-1 = the calling thread's current device); every call switches to it and back."""
         self._L = _lib.lib()
         if isinstance(meshes, Mesh):
             meshes = [meshes]
@@ -85,10 +86,10 @@ class FoundationPose:
             arr[i].diameter = float(m.diameter)
             arr[i].center = (C.c_float * 3)(*[float(x) for x in m.center])
         self.K = np.ascontiguousarray(K, np.float32)
-        h = self._L.fp_create(C.cast(arr, C.c_void_p), len(meshes), _p(self.K),
-                              refiner_weights.encode() if refiner_weights else None,
-                              scorer_weights.encode() if scorer_weights else None,
-                              max_input_image_height, max_input_image_width)
+        h = self._L.fp_create_on(device, C.cast(arr, C.c_void_p), len(meshes), _p(self.K),
+                                 refiner_weights.encode() if refiner_weights else None,
+                                 scorer_weights.encode() if scorer_weights else None,
+                                 max_input_image_height, max_input_image_width)
         if not h:
             raise FoundationPoseError(_lib.last_error())
         self._h = C.c_void_p(h)
@@ -291,6 +292,10 @@ class FoundationPose:
     # ---- float model of the rendering stage (1 = contracted like nvcc -fmad=true, default; 0 = separate roundings) ----
     def set_float_model(self, fmad: int):
         self._must(self._L.fp_set_float_model(self._h, int(fmad)))
+
+    @property
+    def device(self) -> int:
+        return self._L.fp_device(self._h)
 
     @property
     def float_model(self) -> int:

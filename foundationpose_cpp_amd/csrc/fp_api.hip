@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <dlfcn.h>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -30,21 +31,78 @@ static thread_local std::string g_last_error;
 // 48-63 while waves of another queue's kernel share the SIMD -- and the fix are in DESIGN.md section 9.)
 void set_error(const std::string &msg) { g_last_error = msg; }
 
-static hipStream_t utility_stream() {
-  static thread_local hipStream_t s = nullptr;   // lives as long as the thread's HIP context; never destroyed explicitly
-  if (!s && hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) s = nullptr;
-  return s;
+// One non-blocking utility stream per (host thread, device): a stream belongs to the device that was current when it was created, and
+// a thread that drives models on several GPUs must not enqueue a copy for device B on a stream of device A.  (They live as long as
+// the thread's HIP context; at most one per thread and device -- creation / loading / calibration paths only.)
+static hipError_t utility_stream(hipStream_t *out) {
+  static thread_local hipStream_t streams[64] = {nullptr};
+  int d = 0;
+  hipError_t e = hipGetDevice(&d);
+  if (e != hipSuccess) return e;
+  if (d < 0 || d >= 64) return hipErrorInvalidDevice;
+  if (!streams[d] && (e = hipStreamCreateWithFlags(&streams[d], hipStreamNonBlocking)) != hipSuccess) { streams[d] = nullptr; return e; }
+  *out = streams[d];
+  return hipSuccess;
+}
+// Host <-> device copies go through a PINNED staging buffer of the calling thread (two 4 MB halves, double-buffered) instead of
+// handing the caller's pageable memory to hipMemcpyAsync.  Reason [r4]: the round-3 "SIGSEGV beside fp_create" was caught with a native
+// backtrace (tools/segv_trace.c): fp_create -> net_load -> upload -> memcpy_sync -> hipMemcpyAsync -> libhsa-runtime64, a fault inside
+// the HSA runtime's handling of a PAGEABLE source while another thread of the process (PyTorch kernels on its own stream) keeps the
+// queues busy -- no capture, no second model involved.  With pinned sources the runtime never locks / stages user pages and the
+// path that faulted is not taken; it is also the faster copy.
+static hipError_t staging(unsigned char **buf, size_t *half) {
+  static thread_local unsigned char *p = nullptr;
+  constexpr size_t HALF = (size_t)4 << 20;
+  if (!p) {
+    const hipError_t e = hipHostMalloc((void **)&p, 2 * HALF, hipHostMallocPortable);
+    if (e != hipSuccess) { p = nullptr; return e; }
+  }
+  *buf = p; *half = HALF;
+  return hipSuccess;
 }
 hipError_t memcpy_sync(void *dst, const void *src, size_t bytes, hipMemcpyKind kind) {
-  hipStream_t s = utility_stream();
-  if (!s) return hipErrorUnknown;
-  hipError_t e = hipMemcpyAsync(dst, src, bytes, kind, s);
-  return e != hipSuccess ? e : hipStreamSynchronize(s);
+  hipStream_t s = nullptr;
+  hipError_t e = utility_stream(&s);
+  if (e != hipSuccess) return e;
+  if (kind != hipMemcpyHostToDevice && kind != hipMemcpyDeviceToHost) {
+    e = hipMemcpyAsync(dst, src, bytes, kind, s);
+    return e != hipSuccess ? e : hipStreamSynchronize(s);
+  }
+  unsigned char *stage = nullptr;
+  size_t half = 0;
+  if ((e = staging(&stage, &half)) != hipSuccess) return e;
+  hipEvent_t done[2] = {nullptr, nullptr};
+  for (auto &ev : done) if ((e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess) { if (done[0]) (void)hipEventDestroy(done[0]); return e; }
+  size_t off = 0;
+  int slot = 0;
+  bool used[2] = {false, false};
+  while (off < bytes && e == hipSuccess) {
+    const size_t n = std::min(half, bytes - off);
+    unsigned char *h = stage + slot * half;
+    if (used[slot]) e = hipEventSynchronize(done[slot]);   // the copy that last used this half has finished
+    if (e != hipSuccess) break;
+    if (kind == hipMemcpyHostToDevice) {
+      std::memcpy(h, (const unsigned char *)src + off, n);
+      e = hipMemcpyAsync((unsigned char *)dst + off, h, n, hipMemcpyHostToDevice, s);
+      if (e == hipSuccess) e = hipEventRecord(done[slot], s);
+      used[slot] = true;
+    } else {   // device -> host: wait for the chunk, then hand it over
+      e = hipMemcpyAsync(h, (const unsigned char *)src + off, n, hipMemcpyDeviceToHost, s);
+      if (e == hipSuccess) e = hipStreamSynchronize(s);
+      if (e == hipSuccess) std::memcpy((unsigned char *)dst + off, h, n);
+    }
+    off += n;
+    slot ^= 1;
+  }
+  const hipError_t e2 = hipStreamSynchronize(s);
+  for (auto &ev : done) (void)hipEventDestroy(ev);
+  return e != hipSuccess ? e : e2;
 }
 hipError_t memset_sync(void *dst, int value, size_t bytes) {
-  hipStream_t s = utility_stream();
-  if (!s) return hipErrorUnknown;
-  hipError_t e = hipMemsetAsync(dst, value, bytes, s);
+  hipStream_t s = nullptr;
+  hipError_t e = utility_stream(&s);
+  if (e != hipSuccess) return e;
+  e = hipMemsetAsync(dst, value, bytes, s);
   return e != hipSuccess ? e : hipStreamSynchronize(s);
 }
 std::atomic<unsigned long> g_alloc_epoch{0};
@@ -206,6 +264,7 @@ struct Target {
 };
 
 struct fp_model {
+  int device = 0;            // the HIP device the model lives on (fp_create_on); every entry point makes it current for its duration
   hipStream_t stream = nullptr;
   Profiler prof;
   float K[9];
@@ -256,6 +315,8 @@ struct fp_model {
   int scores_all_cap = 0;
   float *gath_feat = nullptr, *gath_poses = nullptr;  // [n_total,512] / [n_total,16] unpacked from the all-gathered rows
   int gath_cap = 0;
+  float *shard_send = nullptr, *shard_recv = nullptr;  // fp_register_sharded: persistent exchange buffers [per,528] / [world*per,528]
+  size_t shard_send_cap = 0, shard_recv_cap = 0;
   int32_t *dbg_tri = nullptr;
   float *dbg_rast = nullptr;
 
@@ -497,10 +558,26 @@ struct LifeExclusive {   // (entry points nested inside -- fp_calibrate_fp8 runs
   LifeExclusive(const LifeExclusive &) = delete;
   LifeExclusive &operator=(const LifeExclusive &) = delete;
 };
+// Device affinity [r4]: a model remembers the device it was created on and every entry point makes that device current for the
+// duration of the call (and puts the caller's device back), so a single-process multi-GPU host -- one thread per GPU, or one thread
+// walking over the models -- cannot launch a model's work on the wrong device.
+struct DeviceScope {
+  int prev = -1;
+  bool switched = false;
+  explicit DeviceScope(int dev) {
+    if (dev < 0) return;
+    int cur = -1;
+    if (hipGetDevice(&cur) == hipSuccess && cur != dev && hipSetDevice(dev) == hipSuccess) { prev = cur; switched = true; }
+  }
+  ~DeviceScope() { if (switched) (void)hipSetDevice(prev); }
+  DeviceScope(const DeviceScope &) = delete;
+  DeviceScope &operator=(const DeviceScope &) = delete;
+};
 struct SerialGuard {
   std::unique_lock<std::recursive_mutex> lk;
   bool shared_held = false;
-  SerialGuard() {
+  DeviceScope dev;
+  explicit SerialGuard(int device) : dev(device) {
     if (g_life_depth++ == 0) { g_life_rw.lock_shared(); shared_held = true; }
     static const bool on = [] { const char *e = std::getenv("FP_SERIALIZE_MODELS"); return e && *e && *e != '0'; }();
     static std::recursive_mutex mu;
@@ -648,8 +725,8 @@ static OutMode nn_mode(const fp_model *m) {
 }
 
 static void destroy_model_impl(fp_model *m);
-fp_model *fp_create(const fp_mesh *meshes, int n_meshes, const float K[9], const char *refiner_weights,
-                    const char *scorer_weights, int max_h, int max_w) try {
+fp_model *fp_create_on(int device, const fp_mesh *meshes, int n_meshes, const float K[9], const char *refiner_weights,
+                       const char *scorer_weights, int max_h, int max_w) try {
   LifeExclusive life;   // not while another thread is inside a call (see SerialGuard)
   if (!meshes || n_meshes <= 0 || !K) { set_error("[FoundationPose] fp_create: invalid arguments"); return nullptr; }
   int ndev = 0;
@@ -657,7 +734,11 @@ fp_model *fp_create(const fp_mesh *meshes, int n_meshes, const float K[9], const
     set_error("[FoundationPose] no HIP device available (this library has no CPU path)");
     return nullptr;
   }
+  if (device < 0 && hipGetDevice(&device) != hipSuccess) { set_error("[FoundationPose] hipGetDevice failed"); return nullptr; }   // -1: the caller's current device
+  if (device >= ndev) { set_error("[FoundationPose] fp_create_on: no such device"); return nullptr; }
+  DeviceScope on_device(device);
   std::unique_ptr<fp_model, void (*)(fp_model *)> m(new fp_model(), destroy_model_impl);  // a failed construction releases what it had allocated
+  m->device = device;
   std::memcpy(m->K, K, sizeof(float) * 9);
   if (max_h > 0) m->max_h = max_h;
   if (max_w > 0) m->max_w = max_w;
@@ -713,8 +794,15 @@ fp_model *fp_create(const fp_mesh *meshes, int n_meshes, const float K[9], const
   return m.release();
 } FP_CATCH_PTR
 
+fp_model *fp_create(const fp_mesh *meshes, int n_meshes, const float K[9], const char *refiner_weights,
+                    const char *scorer_weights, int max_h, int max_w) try {
+  return fp_create_on(-1, meshes, n_meshes, K, refiner_weights, scorer_weights, max_h, max_w);
+} FP_CATCH_PTR
+int fp_device(const fp_model *m) { return m ? m->device : -1; }
+
 static void destroy_model_impl(fp_model *m) {
   if (!m) return;
+  DeviceScope on_device(m->device);
   if (m->stream) (void)hipStreamSynchronize(m->stream);
   invalidate_graphs(m);
   if (m->multi_io) (void)hipHostFree(m->multi_io);
@@ -726,7 +814,7 @@ static void destroy_model_impl(fp_model *m) {
   dev_free(m->recs); dev_free(m->poses_dev); dev_free(m->clip); dev_free(m->attr); dev_free(m->nn_in);
   dev_free(m->blob_a); dev_free(m->blob_b); dev_free(m->trans_dev); dev_free(m->rot_dev); dev_free(m->scores_dev);
   dev_free(m->feat_dev); dev_free(m->argmax_dev); dev_free(m->scores_all); dev_free(m->best_pose_dev);
-  dev_free(m->gath_feat); dev_free(m->gath_poses);
+  dev_free(m->gath_feat); dev_free(m->gath_poses); dev_free(m->shard_send); dev_free(m->shard_recv);
   if (m->result_pinned) (void)hipHostFree(m->result_pinned); dev_free(m->dbg_tri); dev_free(m->dbg_rast);
   if (m->poses_pinned) (void)hipHostFree(m->poses_pinned);
   if (m->track_io) (void)hipHostFree(m->track_io);
@@ -748,7 +836,7 @@ void fp_destroy(fp_model *m) {
 }
 
 int fp_set_inplane_steps(fp_model *m, int steps) try {
-  SerialGuard serial;
+  SerialGuard serial(m ? m->device : -1);
   FP_CHECK(m && steps >= 1 && steps <= 360, "[FoundationPose] fp_set_inplane_steps: invalid arguments");
   FP_HIP_OK(hipStreamSynchronize(m->stream));
   return set_rotation_grid(m, steps);
@@ -756,7 +844,7 @@ int fp_set_inplane_steps(fp_model *m, int steps) try {
 int fp_num_hypotheses(const fp_model *m) { return m ? m->n_hyp() : 0; }
 void *fp_stream(fp_model *m) { return m ? (void *)m->stream : nullptr; }
 int fp_synchronize(fp_model *m) try {
-  SerialGuard serial;
+  SerialGuard serial(m ? m->device : -1);
   FP_CHECK(m, "null model");
   FP_HIP_OK(hipStreamSynchronize(m->stream));
   return 0;
@@ -818,14 +906,14 @@ static int upload_frame_async(fp_model *m, const void *rgb, const void *depth, i
 }
 
 int fp_upload_frame(fp_model *m, const void *rgb, const void *depth, int memspace, int H, int W) try {
-  SerialGuard serial;
+  SerialGuard serial(m ? m->device : -1);
   if (upload_frame_async(m, rgb, depth, memspace, H, W)) return 1;
   if (memspace == FP_HOST) FP_HIP_OK(hipStreamSynchronize(m->stream));  // the host frame may be released on return
   return 0;
 } FP_CATCH_INT
 
 int fp_get_xyz_map(fp_model *m, float *xyz_host) try {
-  SerialGuard serial;
+  SerialGuard serial(m ? m->device : -1);
   FP_CHECK(m && m->depth && xyz_host, "[FoundationPose] fp_get_xyz_map: no frame uploaded");
   FP_CHECK(!m->frame_partial, "[FoundationPose] the last call (Track from a host frame) uploaded only its crop window: call fp_upload_frame first");
   size_t px = (size_t)m->H * m->W;
@@ -849,7 +937,7 @@ static int run_depth_filters(fp_model *m) {
 }
 
 int fp_filter_depth(fp_model *m, float *eroded_out, float *bilateral_out) try {
-  SerialGuard serial;
+  SerialGuard serial(m ? m->device : -1);
   FP_CHECK(m && m->depth, "[FoundationPose] fp_filter_depth: no frame uploaded");
   FP_CHECK(!m->frame_partial, "[FoundationPose] the last call (Track from a host frame) uploaded only its crop window: call fp_upload_frame first");
   size_t px = (size_t)m->H * m->W;
@@ -917,7 +1005,7 @@ static int sampler_status(fp_model *m) {
 }
 
 int fp_get_hyp_poses(fp_model *m, const void *mask, int memspace, float *poses_out, int *n_out) try {
-  SerialGuard serial;
+  SerialGuard serial(m ? m->device : -1);
   FP_CHECK(m && poses_out, "[FoundationPose] fp_get_hyp_poses: invalid arguments");
   const int n = m->n_hyp();
   if (sample_hypotheses_async(m, m->targets.empty() ? nullptr : &m->targets[0], mask, memspace, 0, n)) return 1;
@@ -945,7 +1033,7 @@ static int upload_poses(fp_model *m, Target *t, const float *poses, int N) {
 
 int fp_render_and_transform(fp_model *m, const char *target_name, const float *poses, int N, float crop_ratio,
                             float *render_out, float *transf_out, int out_memspace) try {
-  SerialGuard serial;
+  SerialGuard serial(m ? m->device : -1);
   FP_CHECK(m && poses && N > 0, "[FoundationposeRender] The transform matrix vector is empty");
   FP_CHECK(m->depth != nullptr, "[FoundationPose] fp_render_and_transform: no frame uploaded");
   FP_CHECK(!m->frame_partial, "[FoundationPose] the last call (Track from a host frame) uploaded only its crop window: call fp_upload_frame first");
@@ -970,7 +1058,7 @@ int fp_render_and_transform(fp_model *m, const char *target_name, const float *p
 
 int fp_debug_rasterize(fp_model *m, const char *target_name, const float *poses, int N, float crop_ratio,
                        int32_t *tri_id, float *rast_out) try {
-  SerialGuard serial;
+  SerialGuard serial(m ? m->device : -1);
   FP_CHECK(m && poses && N > 0, "[FoundationposeRender] The transform matrix vector is empty");
   FP_CHECK(m->H > 0, "[FoundationPose] fp_debug_rasterize: no frame uploaded (image size unknown)");
   Target *t = m->find(target_name ? target_name : "");
@@ -1007,7 +1095,7 @@ static int pack_blobs(fp_model *m, const float *render_input, const float *trans
 
 int fp_refiner_infer(fp_model *m, const float *render_input, const float *transf_input, int memspace, int N,
                      float *trans_out, float *rot_out) try {
-  SerialGuard serial;
+  SerialGuard serial(m ? m->device : -1);
   FP_CHECK(m && m->refiner, "[FoundationPose] refiner weights not loaded");
   if (pack_blobs(m, render_input, transf_input, memspace, N)) return 1;
   if (refiner_forward(m->stream, &m->prof, m->refiner, m->ws, m->nn_in, N, m->trans_dev, m->rot_dev)) return 1;
@@ -1019,7 +1107,7 @@ int fp_refiner_infer(fp_model *m, const float *render_input, const float *transf
 
 int fp_scorer_infer(fp_model *m, const float *render_input, const float *transf_input, int memspace, int N,
                     float *scores_out) try {
-  SerialGuard serial;
+  SerialGuard serial(m ? m->device : -1);
   FP_CHECK(m && m->scorer, "[FoundationPose] scorer weights not loaded");
   if (pack_blobs(m, render_input, transf_input, memspace, N)) return 1;
   if (scorer_features(m->stream, &m->prof, m->scorer, m->ws, m->nn_in, N, m->feat_dev)) return 1;
@@ -1031,7 +1119,7 @@ int fp_scorer_infer(fp_model *m, const float *render_input, const float *transf_
 
 int fp_refine_post_process(fp_model *m, const char *target_name, const float *poses, const float *trans,
                            const float *rot, int N, float *poses_out) try {
-  SerialGuard serial;
+  SerialGuard serial(m ? m->device : -1);
   FP_CHECK(m && poses && trans && rot && poses_out && N > 0, "[FoundationPose] fp_refine_post_process: invalid arguments");
   Target *t = m->find(target_name ? target_name : "");
   FP_CHECK(t != nullptr, "[FoundationPose] unknown target_name");
@@ -1046,13 +1134,18 @@ int fp_refine_post_process(fp_model *m, const char *target_name, const float *po
 } FP_CATCH_INT
 
 int fp_argmax(fp_model *m, const float *scores, int N, int *index_out) try {
-  SerialGuard serial;
+  SerialGuard serial(m ? m->device : -1);
   FP_CHECK(m && scores && index_out && N > 0, "[FoundationPose] fp_argmax: invalid arguments");
   if (ensure_capacity(m, N, 0)) return 1;
   FP_HIP_OK(hipMemcpyAsync(m->scores_dev, scores, (size_t)N * 4, hipMemcpyHostToDevice, m->stream));
   launch_argmax(m->stream, m->scores_dev, N, m->argmax_dev);
-  FP_HIP_OK(hipMemcpyAsync(index_out, m->argmax_dev, 4, hipMemcpyDeviceToHost, m->stream));
+  int idx = -1;
+  FP_HIP_OK(hipMemcpyAsync(&idx, m->argmax_dev, 4, hipMemcpyDeviceToHost, m->stream));
   FP_HIP_OK(hipStreamSynchronize(m->stream));
+  // the kernel flags non-finite scores with -2 (used by the sharded Register); the reference's getMaxScoreIndex always returns an
+  // index in [0, N): here a NaN score is an error, never an out-of-range index
+  FP_CHECK(idx >= 0 && idx < N, "[FoundationPose] fp_argmax: scores are not finite");
+  *index_out = idx;
   return 0;
 } FP_CATCH_INT
 
@@ -1089,7 +1182,7 @@ static int refine_iteration(fp_model *m, Target *t, int N, bool shared_b, const 
 int fp_register_shard_begin(fp_model *m, const void *rgb, const void *depth, const void *mask, int memspace, int H,
                             int W, const char *target_name, int refine_itr, int shard_begin, int shard_count,
                             float **feat_dev, float **poses_dev) try {
-  SerialGuard serial;
+  SerialGuard serial(m ? m->device : -1);
   Target *t = nullptr;
   if (check_frame_args(m, H, W, target_name ? target_name : "", &t)) return 1;
   FP_CHECK(m->refiner && m->scorer, "[FoundationPose] refiner/scorer weights not loaded");
@@ -1130,7 +1223,7 @@ int fp_register_shard_begin(fp_model *m, const void *rgb, const void *depth, con
 
 int fp_register_shard_finish(fp_model *m, const float *all_feat_dev, const float *all_poses_dev, int N_total,
                              float out_pose[16], int *best_index, float *scores_host) try {
-  SerialGuard serial;
+  SerialGuard serial(m ? m->device : -1);
   FP_CHECK(m && m->scorer && all_feat_dev && all_poses_dev && N_total > 0 && out_pose,
            "[FoundationPose] fp_register_shard_finish: invalid arguments");
   float *scores = m->scores_dev;
@@ -1178,7 +1271,7 @@ int fp_register_shard_finish(fp_model *m, const float *all_feat_dev, const float
 } FP_CATCH_INT
 
 int fp_download(fp_model *m, void *dst_host, const void *src_dev, size_t bytes) try {
-  SerialGuard serial;
+  SerialGuard serial(m ? m->device : -1);
   FP_CHECK(m && dst_host && src_dev, "[FoundationPose] fp_download: invalid arguments");
   if (bytes) FP_HIP_OK(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, m->stream));
   FP_HIP_OK(hipStreamSynchronize(m->stream));
@@ -1189,7 +1282,7 @@ int fp_download(fp_model *m, void *dst_host, const void *src_dev, size_t bytes) 
 int fp_register_shard_begin_packed(fp_model *m, const void *rgb, const void *depth, const void *mask, int memspace, int H,
                                    int W, const char *target_name, int refine_itr, int shard_begin, int shard_count,
                                    float *packed_dev, int rows_per_rank) try {
-  SerialGuard serial;
+  SerialGuard serial(m ? m->device : -1);
   FP_CHECK(m && packed_dev && rows_per_rank >= shard_count && shard_count >= 0, "[FoundationPose] fp_register_shard_begin_packed: invalid arguments");
   float *feat = nullptr, *poses = nullptr;
   if (shard_count > 0) {
@@ -1216,7 +1309,7 @@ int fp_register_shard_begin_packed(fp_model *m, const void *rgb, const void *dep
 } FP_CATCH_INT
 
 int fp_register_shard_finish_packed(fp_model *m, const float *gathered_dev, int n_total, float out_pose[16], int *best_index) try {
-  SerialGuard serial;
+  SerialGuard serial(m ? m->device : -1);
   FP_CHECK(m && gathered_dev && n_total > 0 && out_pose, "[FoundationPose] fp_register_shard_finish_packed: invalid arguments");
   if (n_total > m->gath_cap) {
     FP_HIP_OK(hipStreamSynchronize(m->stream));
@@ -1235,9 +1328,101 @@ int fp_register_shard_finish_packed(fp_model *m, const float *gathered_dev, int 
   return rc;
 } FP_CATCH_INT
 
+// ---- native sharded Register: begin -> ONE ncclAllGather (RCCL over xGMI) on the model's stream -> finish.  No torch, no events
+// across runtimes: the collective is ordered by the stream itself.  RCCL is bound at first use with dlopen / dlsym -- first an
+// already loaded copy (a Python host has torch's bundled librccl in the process: a communicator made by torch.distributed belongs to
+// THAT copy), otherwise librccl.so.1 of the ROCm installation -- so that the library itself has no link-time RCCL dependency and
+// geometry-only / single-GPU users never load it.
+namespace {
+typedef int (*nccl_allgather_fn)(const void *, void *, size_t, int, void *, hipStream_t);
+typedef const char *(*nccl_errstr_fn)(int);
+typedef int (*nccl_count_fn)(void *, int *);
+struct RcclApi {
+  nccl_allgather_fn all_gather = nullptr;
+  nccl_errstr_fn err = nullptr;
+  nccl_count_fn count = nullptr, user_rank = nullptr;
+  std::string why;
+};
+const RcclApi &rccl_api() {
+  static const RcclApi api = [] {
+    RcclApi a;
+    void *h = nullptr;
+    for (const char *name : {"librccl.so.1", "librccl.so"}) if (!h) h = dlopen(name, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);   // a copy that is already in the process
+    for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) if (!h) h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+    if (!h) { a.why = std::string("cannot load librccl: ") + (dlerror() ? dlerror() : "?"); return a; }
+    a.all_gather = (nccl_allgather_fn)dlsym(h, "ncclAllGather");
+    a.err = (nccl_errstr_fn)dlsym(h, "ncclGetErrorString");
+    a.count = (nccl_count_fn)dlsym(h, "ncclCommCount");
+    a.user_rank = (nccl_count_fn)dlsym(h, "ncclCommUserRank");
+    if (!a.all_gather || !a.err || !a.count || !a.user_rank) { a.why = "librccl lacks ncclAllGather / ncclCommCount / ncclCommUserRank"; a.all_gather = nullptr; }
+    return a;
+  }();
+  return api;
+}
+__global__ void poison_rows_kernel(float *p, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = __int_as_float(0x7fc00000);
+}
+}  // namespace
+
+int fp_register_sharded(fp_model *m, void *nccl_comm, const void *rgb, const void *depth, const void *mask, int memspace, int H, int W,
+                        const char *target_name, int refine_itr, float out_pose[16], int *best_index) try {
+  SerialGuard serial(m ? m->device : -1);
+  FP_CHECK(m && nccl_comm && out_pose, "[FoundationPose] fp_register_sharded: invalid arguments");
+  const RcclApi &nccl = rccl_api();
+  FP_CHECK(nccl.all_gather != nullptr, "[FoundationPose] fp_register_sharded: " + nccl.why);
+  int world = 0, rank = -1, rc;
+  if ((rc = nccl.count(nccl_comm, &world)) != 0 || (rc = nccl.user_rank(nccl_comm, &rank)) != 0 || world < 1 || rank < 0 || rank >= world) {
+    set_error(std::string("[FoundationPose] fp_register_sharded: bad communicator: ") + (rc ? nccl.err(rc) : "rank / size out of range"));
+    return 1;
+  }
+  const int n_total = m->n_hyp();
+  const int per = (n_total + world - 1) / world;
+  const int begin = std::min(rank * per, n_total), count = std::min(per, n_total - begin);
+  // persistent exchange buffers (grown on demand; a Register never allocates in steady state)
+  const size_t need_send = (size_t)per * 528, need_recv = (size_t)world * per * 528;
+  if (need_send > m->shard_send_cap) {
+    FP_HIP_OK(hipStreamSynchronize(m->stream));
+    dev_free(m->shard_send); m->shard_send_cap = 0;
+    if (dev_alloc(&m->shard_send, need_send)) return 1;
+    m->shard_send_cap = need_send;
+  }
+  if (need_recv > m->shard_recv_cap) {
+    FP_HIP_OK(hipStreamSynchronize(m->stream));
+    dev_free(m->shard_recv); m->shard_recv_cap = 0;
+    if (dev_alloc(&m->shard_recv, need_recv)) return 1;
+    m->shard_recv_cap = need_recv;
+  }
+  // a failure on THIS rank must not leave the others inside the collective: join it with NaN rows (every rank's finish reports
+  // them) and return the error afterwards
+  const int rc_begin = fp_register_shard_begin_packed(m, rgb, depth, mask, memspace, H, W, target_name, refine_itr, begin, count, m->shard_send, per);
+  std::string begin_error;
+  if (rc_begin) {
+    begin_error = g_last_error;
+    m->shard_sampler_pending = false;
+    hipLaunchKernelGGL(poison_rows_kernel, dim3((unsigned)((need_send + 255) / 256)), dim3(256), 0, m->stream, m->shard_send, need_send);
+  }
+  if (world > 1) {
+    rc = nccl.all_gather(m->shard_send, m->shard_recv, need_send, 7 /* ncclFloat32 */, nccl_comm, m->stream);
+    if (rc != 0) {
+      (void)hipStreamSynchronize(m->stream);
+      set_error(std::string("[FoundationPose] ncclAllGather failed: ") + nccl.err(rc));
+      return 1;
+    }
+  } else {
+    FP_HIP_OK(hipMemcpyAsync(m->shard_recv, m->shard_send, need_send * sizeof(float), hipMemcpyDeviceToDevice, m->stream));
+  }
+  if (rc_begin) {
+    (void)hipStreamSynchronize(m->stream);
+    set_error(begin_error);
+    return 1;
+  }
+  return fp_register_shard_finish_packed(m, m->shard_recv, n_total, out_pose, best_index);
+} FP_CATCH_INT
+
 int fp_register_ex(fp_model *m, const void *rgb, const void *depth, const void *mask, int memspace, int H, int W,
                    const char *target_name, int refine_itr, float out_pose[16]) try {
-  SerialGuard serial;
+  SerialGuard serial(m ? m->device : -1);
   FP_CHECK(m != nullptr, "[FoundationPose] null model");
   float *feat = nullptr, *poses = nullptr;
   m->defer_begin_sync = true;  // begin + finish back to back on one stream: a single synchronisation, at the end
@@ -1325,7 +1510,7 @@ static int track_submit_impl(fp_model *m, const void *rgb, const void *depth, in
 
 int fp_track_submit(fp_model *m, const void *rgb, const void *depth, int memspace, int H, int W, const float hyp_pose[16],
                     const char *target_name, int refine_itr) try {
-  SerialGuard serial;
+  SerialGuard serial(m ? m->device : -1);
   const int rc = track_submit_impl(m, rgb, depth, memspace, H, W, hyp_pose, target_name, refine_itr);
   // a failure after the upload was enqueued must not leave H2D copies of the caller's host frame in flight
   if (rc && m && m->stream) (void)hipStreamSynchronize(m->stream);
@@ -1333,7 +1518,7 @@ int fp_track_submit(fp_model *m, const void *rgb, const void *depth, int memspac
 } FP_CATCH_INT
 
 int fp_track_wait(fp_model *m, float out_pose[16]) try {
-  SerialGuard serial;
+  SerialGuard serial(m ? m->device : -1);
   FP_CHECK(m && out_pose, "[FoundationPose] fp_track_wait: invalid arguments");
   FP_CHECK(m->track_pending, "[FoundationPose] fp_track_wait: nothing was submitted");
   m->track_pending = false;
@@ -1346,7 +1531,7 @@ int fp_track_wait(fp_model *m, float out_pose[16]) try {
 // Track is launch-latency-bound at N = 1, so K objects cost little more than one (tools/bench_multi_track.py).
 int fp_track_multi(fp_model *m, const void *rgb, const void *depth, int memspace, int H, int W, int K, const float *hyp_poses,
                    const char *const *target_names, int refine_itr, float *out_poses) try {
-  SerialGuard serial;
+  SerialGuard serial(m ? m->device : -1);
   FP_CHECK(m != nullptr, "[FoundationPose] null model");
   FP_CHECK(K >= 1 && K <= 64 && hyp_poses && target_names && out_poses, "[FoundationPose] fp_track_multi: invalid arguments (1..64 objects)");
   FP_CHECK(m->refiner, "[FoundationPose] refiner weights not loaded");
@@ -1410,7 +1595,7 @@ int fp_track_multi(fp_model *m, const void *rgb, const void *depth, int memspace
 
 int fp_track_ex(fp_model *m, const void *rgb, const void *depth, int memspace, int H, int W, const float hyp_pose[16],
                 const char *target_name, int refine_itr, float out_pose[16]) try {
-  SerialGuard serial;
+  SerialGuard serial(m ? m->device : -1);
   FP_CHECK(out_pose, "[FoundationPose] Track: null pose");
   // an earlier fp_track_submit that is still in flight is the caller's to wait for: refuse without touching it
   FP_CHECK(!m || !m->track_pending, "[FoundationPose] Track: a submitted Track has not been waited for (fp_track_wait)");
@@ -1429,6 +1614,7 @@ int fp_track(fp_model *m, const uint8_t *rgb, const float *depth, int H, int W, 
 int fp_set_precision(fp_model *m, int precision) try {
   LifeExclusive life;   // may load the networks of a precision: as exclusive as fp_create
   FP_CHECK(m != nullptr, "[FoundationPose] null model");
+  DeviceScope on_device(m->device);
   FP_HIP_OK(hipStreamSynchronize(m->stream));
   FP_CHECK(!(precision == PREC_FP8 || precision == PREC_INT8) || m->calibrated,
            "[FoundationPose] the 8-bit precisions need a calibration: call fp_calibrate / fp_calibrate_fp8 (or fp_set_calibration_blob) first");
@@ -1439,6 +1625,7 @@ int fp_get_precision(const fp_model *m) { return m ? m->prec : -1; }
 int fp_set_float_model(fp_model *m, int fmad) try {
   LifeExclusive life;   // destroys the captured graphs: not while another thread is inside a call
   FP_CHECK(m != nullptr, "[FoundationPose] null model");
+  DeviceScope on_device(m->device);
   FP_HIP_OK(hipStreamSynchronize(m->stream));
   m->fmad = fmad != 0;
   invalidate_graphs(m);
@@ -1556,6 +1743,7 @@ static int calibrate_impl(fp_model *m, const void *rgb, const void *depth, const
 int fp_calibrate(fp_model *m, const void *rgb, const void *depth, const void *mask, int memspace, int H, int W, const char *target_name,
                  int precision) try {
   LifeExclusive life;   // loads networks; the Registers inside nest (depth > 0)
+  DeviceScope on_device(m ? m->device : -1);
   const int prev = m ? m->prec : 0;
   const int rc = calibrate_impl(m, rgb, depth, mask, memspace, H, W, target_name, precision);
   if (rc && m) {   // leave the model usable
@@ -1591,6 +1779,7 @@ int fp_get_calibration_blob(const fp_model *m, int precision, void *out, size_t 
 int fp_set_calibration_blob(fp_model *m, const void *blob, size_t bytes) try {
   LifeExclusive life;
   FP_CHECK(m && blob && bytes == fp_calibration_size(), "[FoundationPose] fp_set_calibration_blob: invalid arguments / size");
+  DeviceScope on_device(m->device);
   uint32_t hdr[4];
   const unsigned char *p = (const unsigned char *)blob;
   std::memcpy(hdr, p, 16); p += 16;
@@ -1626,6 +1815,7 @@ int fp_get_calibration(const fp_model *m, float amax_out[32]) try {
 int fp_set_calibration(fp_model *m, const float amax[32]) try {
   LifeExclusive life;
   FP_CHECK(m && amax, "[FoundationPose] fp_set_calibration: invalid arguments");
+  DeviceScope on_device(m->device);
   FP_HIP_OK(hipStreamSynchronize(m->stream));
   for (int k = 0; k < 2; k++) {
     m->calib_amax[k].assign((size_t)15 * 512, 0.f);
@@ -1650,6 +1840,7 @@ int fp_set_calibration(fp_model *m, const float amax[32]) try {
 // 410-436); include/infer_core_amd.hpp puts those C++ names on top of these calls.
 // ------------------------------------------------------------------------------------------------
 struct fp_net {
+  int device = 0;
   hipStream_t stream = nullptr;
   Net *net = nullptr;
   NNScratch *ws = nullptr;
@@ -1683,6 +1874,7 @@ fp_net *fp_net_create(const char *weights_path, int is_scorer, int max_batch) tr
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { set_error("[FoundationPose] no HIP device available (this library has no CPU path)"); return nullptr; }
   std::unique_ptr<fp_net> n(new fp_net());
+  if (hipGetDevice(&n->device) != hipSuccess) { set_error("[FoundationPose] hipGetDevice failed"); return nullptr; }
   n->scorer = is_scorer != 0;
   n->max_batch = max_batch;
   std::string err;
@@ -1700,6 +1892,7 @@ fp_net *fp_net_create(const char *weights_path, int is_scorer, int max_batch) tr
 
 static void destroy_net_impl(fp_net *n) {
   if (!n) return;
+  DeviceScope on_device(n->device);
   if (n->stream) (void)hipStreamSynchronize(n->stream);
   for (int i = 0; i < 2; i++) {
     dev_free(n->in_dev[i]); dev_free(n->out_dev[i]);
@@ -1736,7 +1929,7 @@ int fp_net_max_batch(const fp_net *n) { return n ? n->max_batch : 0; }
 // SyncInfer: inputs are taken from the blobs' FP_HOST or FP_DEVICE copies (render_loc / transf_loc), outputs are left in
 // the device blobs and, with out_loc == FP_HOST, copied to the host blobs as well; returns when they are complete.
 int fp_net_infer(fp_net *n, int batch, int render_loc, int transf_loc, int out_loc) try {
-  SerialGuard serial;
+  SerialGuard serial(n ? n->device : -1);
   FP_CHECK(n && batch > 0 && batch <= n->max_batch, "[FoundationPose] fp_net_infer: batch out of range");
   const size_t px = (size_t)batch * FP_CROP_HW * FP_CROP_HW;
   const int locs[2] = {render_loc, transf_loc};
@@ -1766,17 +1959,20 @@ int fp_net_infer(fp_net *n, int batch, int render_loc, int transf_loc, int out_l
 
 int fp_profile_enable(fp_model *m, int on) try {
   FP_CHECK(m, "null model");
+  SerialGuard serial(m->device);
   m->prof.on = on != 0;
   return 0;
 } FP_CATCH_INT
 int fp_profile_reset(fp_model *m) try {
   FP_CHECK(m, "null model");
+  SerialGuard serial(m->device);
   (void)hipStreamSynchronize(m->stream);
   m->prof.reset();
   return 0;
 } FP_CATCH_INT
 int fp_profile_report(fp_model *m, char *buf, int buf_len) try {
   FP_CHECK(m && buf && buf_len > 0, "fp_profile_report: invalid arguments");
+  SerialGuard serial(m->device);
   (void)hipStreamSynchronize(m->stream);
   m->prof.collect();
   std::string out;

@@ -639,10 +639,10 @@ template <int MODE, int STRIP_ROWS, bool FMAD>
 static void launch_raster_tall(hipStream_t s, const DeviceMesh &m, const PoseRec *recs, int N, const float4 *clip,
                                const float4 *attr, void *out) {
   size_t lds = (size_t)STRIP_ROWS * CROP * sizeof(unsigned long long);
-  // once per instantiation, thread-safe (function-local static): opt in to > 64 KB of dynamic LDS
-  static const hipError_t attr_rc = hipFuncSetAttribute((const void *)raster_shade_kernel<MODE, STRIP_ROWS, 1024, FMAD>,
-                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  (void)attr_rc;
+  // once per instantiation and device: opt in to > 64 KB of dynamic LDS
+  static PerDeviceOnce attr_once;
+  if (attr_once.first())
+    (void)hipFuncSetAttribute((const void *)raster_shade_kernel<MODE, STRIP_ROWS, 1024, FMAD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL((raster_shade_kernel<MODE, STRIP_ROWS, 1024, FMAD>), dim3(CROP / STRIP_ROWS, N), dim3(1024), lds, s, m.faces, m.F,
                      m.V, m.uvs, m.tex, m.TH, m.TW, m.diameter / 2, recs, clip, attr, out, nullptr, nullptr);
 }

@@ -17,6 +17,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <cstdint>
 #include <fstream>
 #include <string>
 #include <vector>
@@ -171,6 +172,7 @@ static bool decode_bmp(const std::vector<uint8_t> &b, std::vector<uint8_t> &rgb,
   const int bpp = (int)le16(28);
   const uint32_t comp = le32(30);
   const bool bottom_up = hs > 0;
+  if (hs == INT32_MIN) return false;   // (std::abs of it is undefined)
   const int h = std::abs(hs);
   if (w <= 0 || h <= 0 || w > 16384 || h > 16384 || !(comp == 0 || (comp == 3 && bpp == 32)) || !(bpp == 8 || bpp == 24 || bpp == 32)) return false;
   const size_t stride = (((size_t)w * bpp + 31) / 32) * 4;
@@ -211,20 +213,22 @@ static bool decode_pnm(const std::vector<uint8_t> &b, std::vector<uint8_t> &rgb,
   if (!next_int(w) || !next_int(h) || !next_int(mx) || w <= 0 || h <= 0 || w > 16384 || h > 16384 || mx <= 0 || mx > 65535) return false;
   const int ch = (kind == 3 || kind == 6) ? 3 : 1;
   const size_t n = (size_t)w * h * ch;
-  std::vector<long> v(n);
+  // every sample takes at least one byte of the file (binary: bs bytes; ASCII: a digit + a separator): check before allocating
+  if (n > b.size()) return false;
+  std::vector<uint16_t> v(n);
   if (kind >= 5) {
     pos++;                               // the single whitespace byte after maxval
     const int bs = mx > 255 ? 2 : 1;
     if (pos + n * bs > b.size()) return false;
-    for (size_t i = 0; i < n; i++) v[i] = bs == 2 ? ((long)b[pos + 2 * i] << 8 | b[pos + 2 * i + 1]) : b[pos + i];
+    for (size_t i = 0; i < n; i++) v[i] = bs == 2 ? (uint16_t)((unsigned)b[pos + 2 * i] << 8 | b[pos + 2 * i + 1]) : b[pos + i];
   } else {
-    for (size_t i = 0; i < n; i++) if (!next_int(v[i])) return false;
+    for (size_t i = 0; i < n; i++) { long t; if (!next_int(t)) return false; v[i] = (uint16_t)std::min<long>(t, 65535); }
   }
   W = (int)w; H = (int)h;
   rgb.resize((size_t)w * h * 3);
   for (size_t i = 0; i < (size_t)w * h; i++)
     for (int c = 0; c < 3; c++) {
-      const long s = std::min(v[i * ch + (ch == 3 ? c : 0)], mx);
+      const long s = std::min<long>(v[i * ch + (ch == 3 ? c : 0)], mx);
       rgb[i * 3 + c] = (uint8_t)(mx == 255 ? s : mx > 255 ? (s >> 8) : s * 255 / mx);   // 16-bit -> 8-bit like cv::imread (>> 8)
     }
   return true;
@@ -234,10 +238,12 @@ static bool decode_tga(const std::vector<uint8_t> &b, std::vector<uint8_t> &rgb,
   if (b.size() < 18) return false;
   const int idlen = b[0], cmap = b[1], type = b[2], w = b[12] | (b[13] << 8), h = b[14] | (b[15] << 8), bpp = b[16], desc = b[17];
   const bool rle = type == 10 || type == 11, grey = type == 3 || type == 11;
-  if (cmap != 0 || !(type == 2 || type == 3 || type == 10 || type == 11) || w <= 0 || h <= 0) return false;
+  if (cmap != 0 || !(type == 2 || type == 3 || type == 10 || type == 11) || w <= 0 || h <= 0 || w > 16384 || h > 16384) return false;
   if (!((grey && bpp == 8) || (!grey && (bpp == 24 || bpp == 32)))) return false;
   const int bs = bpp / 8;
   size_t pos = 18 + (size_t)idlen;
+  // raw: the pixels are in the file; RLE: a packet of <= 128 pixels takes at least 1 + bs bytes -- check before allocating
+  if (!rle ? pos + (size_t)w * h * bs > b.size() : ((size_t)w * h + 127) / 128 * (size_t)(1 + bs) > b.size()) return false;
   std::vector<uint8_t> pix((size_t)w * h * bs);
   if (!rle) {
     if (pos + pix.size() > b.size()) return false;
@@ -462,6 +468,9 @@ static bool decode_jpeg(const std::vector<uint8_t> &b, std::vector<uint8_t> &rgb
         build(h);
       }
     } else if (mk == 0xC0 || mk == 0xC1 || mk == 0xC2) {
+      // one frame header per image: a second one (a spliced file) would change the geometry under coefficient arrays that were
+      // sized by the first
+      if (!comps.empty()) return fail("corrupt JPEG (second frame header)");
       progressive = mk == 0xC2;
       if (len < 8) return fail("corrupt JPEG (SOF)");
       if (b[seg] != 8) return fail("only 8-bit JPEG textures are supported");
@@ -578,7 +587,9 @@ static bool decode_jpeg(const std::vector<uint8_t> &b, std::vector<uint8_t> &rgb
           for (int by = 0; by < cbh && !bad; by++)
             for (int bx = 0; bx < cbw && !bad; bx++) {
               if (!maybe_restart()) return fail("corrupt JPEG (restart marker)");
-              do_block(c, &c.coef[((size_t)by * c.bw + bx) * 64]);
+              const size_t at = ((size_t)by * c.bw + bx) * 64;
+              if (at + 64 > c.coef.size()) return fail("corrupt JPEG (block outside the frame)");
+              do_block(c, &c.coef[at]);
               if (restart) togo--;
             }
         } else {
@@ -587,7 +598,11 @@ static bool decode_jpeg(const std::vector<uint8_t> &b, std::vector<uint8_t> &rgb
               if (!maybe_restart()) return fail("corrupt JPEG (restart marker)");
               for (Comp *c : sc)
                 for (int by = 0; by < c->v; by++)
-                  for (int bx = 0; bx < c->h; bx++) do_block(*c, &c->coef[((size_t)(yy * c->v + by) * c->bw + xx * c->h + bx) * 64]);
+                  for (int bx = 0; bx < c->h; bx++) {
+                    const size_t at = ((size_t)(yy * c->v + by) * c->bw + xx * c->h + bx) * 64;
+                    if (at + 64 > c->coef.size()) return fail("corrupt JPEG (block outside the frame)");
+                    do_block(*c, &c->coef[at]);
+                  }
               if (restart) togo--;
             }
         }
@@ -735,8 +750,8 @@ static bool decode_jpeg(const std::vector<uint8_t> &b, std::vector<uint8_t> &rgb
 }
 
 // Texture file -> 8-bit RGB the way cv::imread(path) + BGR2RGB delivers it (assimp_mesh_loader.cpp:216-223): grey replicated, alpha
-// dropped, palette expanded, 16-bit samples >> 8.  Containers: PNG (every bit depth / colour type, Adam7), baseline JPEG, BMP, PNM, TGA.
-// Progressive JPEG and the rest of cv::imread's list (TIFF, WebP, ...) need codecs this library does not carry: *why says so.
+// dropped, palette expanded, 16-bit samples >> 8.  Containers: PNG (every bit depth / colour type, Adam7), baseline and progressive JPEG,
+// BMP, PNM, TGA.  The rest of cv::imread's list (TIFF, WebP, arithmetic-coded / CMYK JPEG, ...) needs codecs this library does not carry: *why says so.
 bool load_texture_rgb(const std::string &path, std::vector<uint8_t> &rgb, int &H, int &W, std::string *why) {
   std::ifstream f(path, std::ios::binary);
   if (!f) { if (why) *why = "cannot open"; return false; }
@@ -763,7 +778,7 @@ bool load_texture_rgb(const std::string &path, std::vector<uint8_t> &rgb, int &H
   if (b.size() >= 2 && b[0] == 'P' && b[1] >= '1' && b[1] <= '6') return decode_pnm(b, rgb, H, W) || fail("corrupt or unsupported PNM (supported: P2 / P3 / P5 / P6)");
   const std::string ext = path.size() >= 4 ? path.substr(path.size() - 4) : "";
   if (ext == ".tga" || ext == ".TGA") return decode_tga(b, rgb, H, W) || fail("corrupt or unsupported TGA (supported: true-colour / grey, raw or RLE)");
-  return fail("unknown image container (supported: PNG, BMP, PNM, TGA)");
+  return fail("unknown image container (supported: PNG, baseline / progressive JPEG, BMP, PNM, TGA)");
 }
 
 // 8-bit view as RGB (grey replicated, alpha dropped); kept for callers that insist on an 8-bit PNG

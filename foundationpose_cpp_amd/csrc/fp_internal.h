@@ -24,13 +24,25 @@ namespace fp {
 void set_error(const std::string &msg);
 // fp_image_io.cpp: 8-bit PNG (grey / RGB / palette / alpha variants) -> RGB u8
 bool load_png_rgb(const std::string &path, std::vector<uint8_t> &rgb, int &H, int &W);
-// any texture container the library decodes (PNG incl. 16-bit / sub-byte / interlaced, BMP, PNM, TGA) -> RGB u8 like cv::imread + BGR2RGB
+// any texture container the library decodes (PNG incl. 16-bit / sub-byte / interlaced, baseline + progressive JPEG, BMP, PNM, TGA) -> RGB u8 like cv::imread + BGR2RGB
 bool load_texture_rgb(const std::string &path, std::vector<uint8_t> &rgb, int &H, int &W, std::string *why);
 // Synchronous copies / fills WITHOUT the legacy (null) stream: hipMemcpy / hipMemset fail with hipErrorStreamCaptureImplicit (906)
 // while ANY thread of the process captures a hipGraph (another model replaying its warm-up), so the library never touches the
 // legacy stream -- these go through a per-thread non-blocking utility stream and wait for it.
 hipError_t memcpy_sync(void *dst, const void *src, size_t bytes, hipMemcpyKind kind);
 hipError_t memset_sync(void *dst, int value, size_t bytes);
+// Per-DEVICE once flag for launch sites that opt a kernel into > 64 KB of dynamic LDS: hipFuncSetAttribute acts on the current
+// device's copy of the function, so a process that drives several GPUs (one model per device) has to repeat it on each.
+struct PerDeviceOnce {
+  std::atomic<unsigned long long> done{0};
+  bool first() {   // true exactly for the first caller on each device (devices >= 64: always true, harmless)
+    int d = 0;
+    (void)hipGetDevice(&d);
+    if (d < 0 || d >= 64) return true;
+    const unsigned long long bit = 1ull << d;
+    return !(done.fetch_or(bit) & bit);
+  }
+};
 // bumped whenever a device buffer that kernels may have baked into a captured hipGraph is (re)allocated
 extern std::atomic<unsigned long> g_alloc_epoch;
 #define FP_HIP_OK(expr)                                                                              \

@@ -169,7 +169,10 @@ bool parse_ply(const std::string &path, ParsedMesh &out, std::string &err) {
           if (n < 0 || n > 4096) { bad = true; break; }
           for (long k = 0; k < n; k++) {
             const double v = read_num(pr.type);
-            if (pr.name == "vertex_indices" || pr.name == "vertex_index") idx.push_back((int)v);
+            if (pr.name == "vertex_indices" || pr.name == "vertex_index") {
+              if (!(v >= 0.0 && v < 2147483647.0)) { bad = true; break; }   // (range-checked as a double: the cast of NaN / out-of-range values is undefined)
+              idx.push_back((int)v);
+            }
             else if (pr.name == "texcoord") wedge.push_back((float)v);
           }
         }

@@ -4154,12 +4154,11 @@ FP_HOOK g_smallx_pf = 0;       // A/B (test build): prefetch depth of conv_small
 FP_HOOK g_smallm = 1;          // small problems (Track, a few objects) on conv_smallm_kernel: K split over the waves of a workgroup, no split-K slabs / reduce launch
 FP_HOOK g_att_variant = 1;     // 1 = attention32_kernel (8 = without the XCD remap); round-1 kernel: 2 remap + 16-B stores, 3 no XCD remap, 5 remap + 2-B stores, 7 neither
 
-// One launch = (once per launch site and element type, thread-safe through the function-local static) dynamic-LDS opt-in +
-// the launch itself.
+// One launch = (once per launch site, element type and DEVICE) dynamic-LDS opt-in + the launch itself.
 #define FP_LAUNCH(KERN, grid, block, lds_bytes, stream, ...)                                                                        \
   do {                                                                                                                              \
-    static const hipError_t fp_attr_rc_ = hipFuncSetAttribute((const void *)(KERN), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-    (void)fp_attr_rc_;                                                                                                              \
+    static fp::PerDeviceOnce fp_attr_once_;                                                                                         \
+    if (fp_attr_once_.first()) (void)hipFuncSetAttribute((const void *)(KERN), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
     hipLaunchKernelGGL((KERN), grid, block, lds_bytes, stream, __VA_ARGS__);                                                        \
   } while (0)
 

@@ -16,7 +16,8 @@
  *     (the reference returns bool + a glog line, D6F/src/foundationpose_utils.hpp:76-84).
  *   - not re-entrant per model (like the reference: one renderer / scratch set per target,
  *     D6F/src/foundationpose.cpp:103-105); DIFFERENT models may be driven from different threads concurrently, each runs
- *     on its own non-blocking stream and their kernels overlap on the GPU.  fp_create / fp_destroy (fp_net_create / fp_net_destroy) are
+ *     on its own non-blocking stream and their kernels overlap on the GPU.  fp_create / fp_destroy (fp_net_create / fp_net_destroy) and the
+ *     entry points that load or rebuild networks (fp_set_precision, fp_calibrate*, fp_set_calibration*, fp_set_float_model) are
  *     exclusive against every other call of the process: they wait for calls in progress and hold new ones back while they run.
  *   - memspace arguments: FP_HOST pointers are ordinary host memory, FP_DEVICE pointers are HIP device memory on
  *     the model's device (lets callers keep frames resident in HBM).
@@ -73,6 +74,13 @@ int fp_mesh_orient_bounds(const fp_loaded_mesh *mesh, float orient_bounds[16], f
  * engines of simple_tests/src/test_foundationpose.cpp:13-14).  NULL = geometry-only model (NN entry points fail). */
 fp_model *fp_create(const fp_mesh *meshes, int n_meshes, const float K[9], const char *refiner_weights,
                     const char *scorer_weights, int max_input_image_height, int max_input_image_width);
+/* The same on HIP device `device` (-1 = the calling thread's current device, which is what fp_create uses).  A model remembers its
+ * device: every entry point makes it current for the duration of the call and restores the caller's afterwards, so a process that
+ * drives several GPUs -- one host thread per GPU, the natural C++ shape of SURVEY.md section 8e, or one thread walking over the
+ * models -- cannot launch a model's work on the wrong device.  FP_DEVICE pointers handed to a model must live on ITS device. */
+fp_model *fp_create_on(int device, const fp_mesh *meshes, int n_meshes, const float K[9], const char *refiner_weights,
+                       const char *scorer_weights, int max_input_image_height, int max_input_image_width);
+int fp_device(const fp_model *m);
 void fp_destroy(fp_model *m);
 const char *fp_last_error(void);
 /* number of in-plane rotations per icosphere view: 6 -> 252 hypotheses (reference), 24 -> 1008 (SURVEY.md §8a note). */
@@ -136,7 +144,8 @@ int fp_scorer_infer(fp_model *m, const float *render_input, const float *transf_
 /* RefinePostProcess (src/foundationpose.cpp:360-406): host in/out. */
 int fp_refine_post_process(fp_model *m, const char *target_name, const float *poses, const float *trans,
                            const float *rot, int N, float *poses_out);
-/* getMaxScoreIndex (src/foundationpose_decoder.cu:24-35): first maximum wins. scores host [N]. */
+/* getMaxScoreIndex (src/foundationpose_decoder.cu:24-35): first maximum wins. scores host [N].  A NaN among the scores is an error
+ * (the reference always returns an index in [0, N); thrust::max_element's answer on NaNs is unspecified). */
 int fp_argmax(fp_model *m, const float *scores, int N, int *index_out);
 
 /* ---- hypothesis sharding over GPUs (new).  One process per GPU calls:
@@ -168,6 +177,17 @@ int fp_register_shard_begin_packed(fp_model *m, const void *rgb, const void *dep
                                    int W, const char *target_name, int refine_itr, int shard_begin, int shard_count,
                                    float *packed_dev, int rows_per_rank);
 int fp_register_shard_finish_packed(fp_model *m, const float *gathered_dev, int n_total, float out_pose[16], int *best_index);
+
+/* The whole sharded Register as ONE call, natively ("one ncclAllGather (RCCL over xGMI)"): every rank (one
+ * model per GPU; ranks may be processes or threads of one process) passes its RCCL communicator (ncclComm_t as void*; rank and
+ * world size are read from it).  Rank r refines and scores hypotheses [r * ceil(N / world), ...) of the fp_num_hypotheses() grid,
+ * the rows [feature 512 | pose 16] are exchanged by one ncclAllGather enqueued on the model's stream (no host synchronisation,
+ * no staging copies, persistent buffers), and every rank evaluates the cross-hypothesis head and the arg-max redundantly: all
+ * ranks return the same pose / index without a second collective.  A rank whose own half fails still joins the collective (with
+ * NaN rows, which every other rank reports) so that nobody hangs.  RCCL is bound at first use (dlopen: a copy already in the
+ * process, else librccl.so.1): the library has no link-time RCCL dependency.  world == 1 works without RCCL traffic. */
+int fp_register_sharded(fp_model *m, void *nccl_comm, const void *rgb, const void *depth, const void *mask, int memspace, int H, int W,
+                        const char *target_name, int refine_itr, float out_pose[16], int *best_index /* may be NULL */);
 
 /* ---- frame / dataset I/O of the acceptance harness (simple_tests/include/tests/help_func.hpp) without OpenCV ----
  * dataset layout test_data/download.md:6-15: <dir>/cam_K.txt, rgb/<id>.png, depth/<id>.png (u16 mm), masks/<id>.png, mesh/ */

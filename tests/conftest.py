@@ -50,3 +50,12 @@ def disc_nets(tmp_path_factory, disc_cal):
     rs = W.pack_synthetic("refiner", rp, DISC_SEED, disc_cal)
     ss = W.pack_synthetic("scorer", sp, DISC_SEED, disc_cal)
     return rp, sp, NT.build("refiner", rs), NT.build("scorer", ss)
+
+
+def pytest_runtest_setup(item):
+    """crash hunts on the GPU box (no gdb there): FP_SEGV_TRACE=<path of tools/_bin/libsegv_trace.so> re-installs a native-backtrace
+    SIGSEGV handler before every test (the HIP runtime and faulthandler install their own on the way)."""
+    so = os.environ.get("FP_SEGV_TRACE")
+    if so:
+        import ctypes
+        ctypes.CDLL(so).segv_trace_install()

@@ -72,3 +72,36 @@ def test_cpp_demo_sequence_matches_python_and_oracle(tmp_path):
         res = subprocess.run([exe, "--data", root, "--refiner", rp, "--scorer", sp, "--mode", mode, "--reps", "3"],
                              capture_output=True, text=True, timeout=600)
         assert res.returncode == 0 and "average fps" in res.stdout, res.stdout + res.stderr
+
+
+def test_native_sharded_register_demo(tmp_path):
+    """examples/fp_demo_mgpu.cpp: fp_create_on + fp_register_sharded (the library issues the ncclAllGather itself, RCCL bound with dlopen)
+    in a plain C++ process -- no torch, no Python.  One rank here (the GPU box has one device): the communicator, the persistent
+    exchange buffers and the packed begin / finish halves all run; the result must equal the unsharded fp_register and the Python API's."""
+    from foundationpose_cpp_amd import FoundationPose
+    root = str(tmp_path / "synthetic0")
+    D.write_synthetic_sequence(root, n_frames=1)
+    rp, sp = str(tmp_path / "r.fpw"), str(tmp_path / "s.fpw")
+    W.pack_synthetic("refiner", rp)
+    W.pack_synthetic("scorer", sp)
+    exe = str(tmp_path / "fp_demo_mgpu")
+    libdir = os.path.join(ROOT, "foundationpose_cpp_amd")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-std=c++17", "-w", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "fp_demo_mgpu.cpp"),
+                           "-o", exe, "-L", libdir, "-lfoundationpose_amd", f"-Wl,-rpath,{libdir}", "-lrccl", "-lpthread"])
+    res = subprocess.run([exe, "--data", root, "--refiner", rp, "--scorer", sp, "--ranks", "1", "--reps", "3"], capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout + res.stderr
+    print(res.stdout)
+    line = [l for l in res.stdout.splitlines() if l.startswith("pose ")][0]
+    pose_c = syn.from_colmajor(np.array([float(v) for v in line.split()[1:]], np.float32)[None])[0]
+    assert "max |sharded - unsharded| pose element 0" in res.stdout          # bit-identical to fp_register in the same process
+    seq = D.Sequence(root)
+    mesh = load_mesh("object", seq.mesh_path())
+    m = FoundationPose(mesh, seq.K, rp, sp, device=0)
+    try:
+        assert m.device == 0
+        rgb, depth, mask = seq.frame(0, with_mask=True)
+        ok, pose_py = m.Register(rgb, depth, mask, mesh.name)
+        assert ok, m.last_error
+        np.testing.assert_allclose(pose_c, pose_py, rtol=0, atol=1e-6)
+    finally:
+        m.close()
