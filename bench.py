@@ -455,7 +455,7 @@ def main():
                     traffic, traffic_src = round(rec["traffic_bytes_per_launch"]), os.path.relpath(pmc_path, ROOT)
         # what the matrix pipes sustain on THIS box with every SIMD busy (register-resident MFMAs, random operands): the
         # datasheet 2.5 PFLOP/s assumes 2.4 GHz, under MFMA load the power limit holds the clock near 2.0 GHz
-        measured_peak, measured_mhz = None, None
+        measured_peak, measured_mhz, peak_detail = None, None, None
         if world == 1 and not args.no_mfma_peak:
             from foundationpose_cpp_amd import _lib
             L = _lib.test_lib()   # the micro-benchmark kernel lives in the test build
@@ -465,6 +465,32 @@ def main():
             v = max(L.fpt_mfma_peak(200000, 8, 0, C.byref(mhz)) for _ in range(2))
             if v > 0:
                 measured_peak, measured_mhz = round(float(v), 1), round(mhz.value)
+            # the evidence behind "power-limited": both MFMA shapes with random and with all-zero operands (zero operands toggle no
+            # data-path bits: same instruction stream, less power, higher clock), and the package power / clocks rocm-smi reports
+            # WHILE the random-operand kernel runs (sampled from this thread, the kernel loops on another)
+            peak_detail = {}
+            for tag, code in (("16x16x32_random", 0), ("16x16x32_zero", 1), ("32x32x16_random", 2), ("32x32x16_zero", 3)):
+                m2 = C.c_double(0)
+                v2 = max(L.fpt_mfma_peak(200000, 8, code, C.byref(m2)) for _ in range(2))
+                peak_detail[tag] = {"tflops": round(float(v2), 1), "shader_clock_mhz": round(m2.value)}
+            try:
+                import subprocess, threading
+                stop = threading.Event()
+
+                def burn():
+                    while not stop.is_set():
+                        L.fpt_mfma_peak(400000, 8, 0, None)
+                th = threading.Thread(target=burn)
+                th.start()
+                time.sleep(0.4)
+                smi = subprocess.run(["rocm-smi", "--showpower", "--showclocks", "--showmaxpower", "--json"], capture_output=True, text=True, timeout=20)
+                stop.set()
+                th.join()
+                card = next(iter(json.loads(smi.stdout).values()))
+                keep = {k: v for k, v in card.items() if any(t in k.lower() for t in ("power", "sclk", "mclk", "fclk"))}
+                peak_detail["rocm_smi_under_mfma_load"] = keep
+            except Exception as e:     # (no rocm-smi on the box / unexpected output: the clocks above are the evidence)
+                peak_detail["rocm_smi_under_mfma_load"] = {"error": str(e)[:200]}
         # where the dominant kernel's other half goes: in-kernel clock probe of conv_halo_kernel on the conv_256 shape (test build,
         # outside every timed region): shader clock the package allows under this load, cycles of a workgroup's main loop, and the
         # share of them in which its SIMD's matrix pipe is issuing (2 co-resident waves x 72 K-steps x 40 MFMAs x 16 cycles)
@@ -520,7 +546,7 @@ def main():
                             "call; vs_baseline = host_frame.value / 705.6 when that leg ran (N=1 default run), else value / 705.6",
             },
             "roofline": dict(roof, **{
-                "peak_measured": measured_peak, "peak_measured_clock_mhz": measured_mhz,
+                "peak_measured": measured_peak, "peak_measured_clock_mhz": measured_mhz, "peak_measured_detail": peak_detail,
                 "peak_measured_what": "register-resident f16 MFMA micro-benchmark on this box (fp8 MFMAs: 2x)",
                 "frac_of_measured": round(roof["achieved"] / (measured_peak * (2 if dv.get("fp8") else 1)), 4) if measured_peak else None,
                 "clock_probe": clock_probe,

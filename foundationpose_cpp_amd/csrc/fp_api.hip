@@ -31,11 +31,12 @@ static thread_local std::string g_last_error;
 // 48-63 while waves of another queue's kernel share the SIMD -- and the fix are in DESIGN.md section 9.)
 void set_error(const std::string &msg) { g_last_error = msg; }
 
-// One non-blocking utility stream per (host thread, device): a stream belongs to the device that was current when it was created, and
-// a thread that drives models on several GPUs must not enqueue a copy for device B on a stream of device A.  (They live as long as
-// the thread's HIP context; at most one per thread and device -- creation / loading / calibration paths only.)
+// One non-blocking utility stream per DEVICE, shared by all host threads under a lock (creation / loading / calibration paths only:
+// nothing on the serving path uses it).  Per device, not per thread: a stream belongs to the device that was current when it was
+// created, and a stream made by a transient host thread would outlive that thread inside the runtime.
+static std::mutex g_util_mu;
 static hipError_t utility_stream(hipStream_t *out) {
-  static thread_local hipStream_t streams[64] = {nullptr};
+  static hipStream_t streams[64] = {nullptr};
   int d = 0;
   hipError_t e = hipGetDevice(&d);
   if (e != hipSuccess) return e;
@@ -44,14 +45,11 @@ static hipError_t utility_stream(hipStream_t *out) {
   *out = streams[d];
   return hipSuccess;
 }
-// Host <-> device copies go through a PINNED staging buffer of the calling thread (two 4 MB halves, double-buffered) instead of
-// handing the caller's pageable memory to hipMemcpyAsync.  Reason [r4]: the round-3 "SIGSEGV beside fp_create" was caught with a native
-// backtrace (tools/segv_trace.c): fp_create -> net_load -> upload -> memcpy_sync -> hipMemcpyAsync -> libhsa-runtime64, a fault inside
-// the HSA runtime's handling of a PAGEABLE source while another thread of the process (PyTorch kernels on its own stream) keeps the
-// queues busy -- no capture, no second model involved.  With pinned sources the runtime never locks / stages user pages and the
-// path that faulted is not taken; it is also the faster copy.
+// Host <-> device copies of the creation / loading / calibration paths go through a PINNED staging buffer (two 4 MB halves,
+// double-buffered) instead of handing the caller's pageable memory to hipMemcpyAsync: the runtime never has to lock or stage user
+// pages, and it is the faster copy.  (Also tried against the fp_create SIGSEGV of DESIGN.md section 9; the fault is elsewhere.)
 static hipError_t staging(unsigned char **buf, size_t *half) {
-  static thread_local unsigned char *p = nullptr;
+  static unsigned char *p = nullptr;   // (under g_util_mu)
   constexpr size_t HALF = (size_t)4 << 20;
   if (!p) {
     const hipError_t e = hipHostMalloc((void **)&p, 2 * HALF, hipHostMallocPortable);
@@ -61,6 +59,7 @@ static hipError_t staging(unsigned char **buf, size_t *half) {
   return hipSuccess;
 }
 hipError_t memcpy_sync(void *dst, const void *src, size_t bytes, hipMemcpyKind kind) {
+  std::lock_guard<std::mutex> lk(g_util_mu);
   hipStream_t s = nullptr;
   hipError_t e = utility_stream(&s);
   if (e != hipSuccess) return e;
@@ -99,6 +98,7 @@ hipError_t memcpy_sync(void *dst, const void *src, size_t bytes, hipMemcpyKind k
   return e != hipSuccess ? e : e2;
 }
 hipError_t memset_sync(void *dst, int value, size_t bytes) {
+  std::lock_guard<std::mutex> lk(g_util_mu);
   hipStream_t s = nullptr;
   hipError_t e = utility_stream(&s);
   if (e != hipSuccess) return e;
@@ -106,6 +106,60 @@ hipError_t memset_sync(void *dst, int value, size_t bytes) {
   return e != hipSuccess ? e : hipStreamSynchronize(s);
 }
 std::atomic<unsigned long> g_alloc_epoch{0};
+
+// ---- streams are RECYCLED, never destroyed [r4]: destroyed models park their stream here, new models take one.  (Tried as a remedy for
+// the fp_create SIGSEGV under a concurrent PyTorch stream -- a signal wait inside the HIP 7.0 runtime PyTorch bundles, DESIGN.md
+// section 9 -- where it changed nothing; kept because a serving process that adds and removes objects should not churn HSA queues.)
+namespace {
+std::mutex g_stream_pool_mu;
+std::vector<std::pair<int, hipStream_t>> g_stream_pool;   // (device, stream)
+}  // namespace
+hipError_t stream_acquire(hipStream_t *out) {
+  int d = 0;
+  hipError_t e = hipGetDevice(&d);
+  if (e != hipSuccess) return e;
+  {
+    std::lock_guard<std::mutex> lk(g_stream_pool_mu);
+    for (size_t i = 0; i < g_stream_pool.size(); i++)
+      if (g_stream_pool[i].first == d) {
+        *out = g_stream_pool[i].second;
+        g_stream_pool.erase(g_stream_pool.begin() + (long)i);
+        return hipSuccess;
+      }
+  }
+  return hipStreamCreateWithFlags(out, hipStreamNonBlocking);   // non-blocking: no implicit synchronisation with the legacy null stream
+}
+void stream_release(hipStream_t s) {   // (the caller has synchronised it; its device is current)
+  int d = 0;
+  if (!s || hipGetDevice(&d) != hipSuccess) return;
+  std::lock_guard<std::mutex> lk(g_stream_pool_mu);
+  g_stream_pool.emplace_back(d, s);
+}
+
+// ---- roctx (fp_internal.h): bound once, no-ops when the library is not there
+namespace {
+struct RoctxApi {
+  int (*push)(const char *) = nullptr;
+  int (*pop)() = nullptr;
+};
+const RoctxApi &roctx_api() {
+  static const RoctxApi api = [] {
+    RoctxApi a;
+    void *h = nullptr;
+    for (const char *name : {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so"})
+      if (!h) h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+    if (h) {
+      a.push = (int (*)(const char *))dlsym(h, "roctxRangePushA");
+      a.pop = (int (*)())dlsym(h, "roctxRangePop");
+      if (!a.push || !a.pop) a.push = nullptr, a.pop = nullptr;
+    }
+    return a;
+  }();
+  return api;
+}
+}  // namespace
+void roctx_push(const char *name) { if (roctx_api().push) (void)roctx_api().push(name); }
+void roctx_pop() { if (roctx_api().pop) (void)roctx_api().pop(); }
 #ifdef FP_TEST_HOOKS
 static int g_upload_cols = 1;   // A/B (fpt_set_upload_cols): Track from host frames uploads the crop window's rectangle, not whole rows
 #else
@@ -743,7 +797,7 @@ fp_model *fp_create_on(int device, const fp_mesh *meshes, int n_meshes, const fl
   if (max_h > 0) m->max_h = max_h;
   if (max_w > 0) m->max_w = max_w;
   // non-blocking: no implicit synchronisation with the legacy null stream (other models' threads, the caller's framework)
-  if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess) { set_error("[FoundationPose] Failed to create stream"); return nullptr; }
+  if (stream_acquire(&m->stream) != hipSuccess) { set_error("[FoundationPose] Failed to create stream"); return nullptr; }
   if (hipMalloc((void **)&m->frame_dev, sizeof(FrameRef)) != hipSuccess ||
       hipHostMalloc((void **)&m->frame_pinned, 8 * sizeof(FrameRef), hipHostMallocDefault) != hipSuccess) {
     set_error("[FoundationPose] Failed to allocate the frame record");
@@ -827,7 +881,7 @@ static void destroy_model_impl(fp_model *m) {
     if (m->scorer_p[i]) net_free(m->scorer_p[i]);
     if (m->ws_p[i]) nn_scratch_free(m->ws_p[i]);
   }
-  if (m->stream) (void)hipStreamDestroy(m->stream);
+  if (m->stream) { (void)hipStreamSynchronize(m->stream); stream_release(m->stream); }
   delete m;
 }
 void fp_destroy(fp_model *m) {
@@ -1154,6 +1208,7 @@ int fp_argmax(fp_model *m, const float *scores, int N, int *index_out) try {
 // the translation (foundationpose_render.cpp:59, foundationpose_render.cu:78-80) -- is computed and encoded once.
 // poses_in / result_out (Track): the poses are read from / the refined poses also written to host-pinned memory
 static int refine_iteration(fp_model *m, Target *t, int N, bool shared_b, const float *poses_in = nullptr, float *result_out = nullptr) {
+  RoctxRange range("refine_iteration (render + crop @1.2, refine-net, pose update)");
   const size_t half = (size_t)N * FP_NN_IN_IMG_HALFS;
   if (render_and_crop(m, t, N, 1.2f /* refine_mode_crop_ratio_ foundationpose.cpp:87 */, nn_mode(m), m->nn_in,
                       m->nn_in + half, nullptr, nullptr, shared_b ? 1 : N, poses_in))
@@ -1183,6 +1238,7 @@ int fp_register_shard_begin(fp_model *m, const void *rgb, const void *depth, con
                             int W, const char *target_name, int refine_itr, int shard_begin, int shard_count,
                             float **feat_dev, float **poses_dev) try {
   SerialGuard serial(m ? m->device : -1);
+  RoctxRange range("fp_register_shard_begin (sampler + refine + score trunk)");
   Target *t = nullptr;
   if (check_frame_args(m, H, W, target_name ? target_name : "", &t)) return 1;
   FP_CHECK(m->refiner && m->scorer, "[FoundationPose] refiner/scorer weights not loaded");
@@ -1198,9 +1254,13 @@ int fp_register_shard_begin(fp_model *m, const void *rgb, const void *depth, con
   if (run_graphed(m, m->rg, t, H, W, refine_itr, N, graphable, [&]() {
         for (int it = 0; it < refine_itr; it++)
           if (refine_iteration(m, t, N, it == 0 && N > 1)) return 1;  // sampler output: one translation for all hypotheses
-        if (render_and_crop(m, t, N, 1.1f /* score_mode_crop_ratio_ foundationpose.cpp:88 */, nn_mode(m), m->nn_in,
-                            m->nn_in + half, nullptr, nullptr))
-          return 1;
+        {
+          RoctxRange r2("render + crop @1.1 (score mode)");
+          if (render_and_crop(m, t, N, 1.1f /* score_mode_crop_ratio_ foundationpose.cpp:88 */, nn_mode(m), m->nn_in,
+                              m->nn_in + half, nullptr, nullptr))
+            return 1;
+        }
+        RoctxRange r3("score-net trunk + self-attention");
         checkpoint(m, 8, m->clip, (size_t)N * t->mesh.V * 16);
         checkpoint(m, 9, m->attr, (size_t)N * t->mesh.V * 16);
         checkpoint(m, 10, m->nn_in, (size_t)N * FP_NN_IN_IMG_HALFS * 2);
@@ -1226,6 +1286,7 @@ int fp_register_shard_finish(fp_model *m, const float *all_feat_dev, const float
   SerialGuard serial(m ? m->device : -1);
   FP_CHECK(m && m->scorer && all_feat_dev && all_poses_dev && N_total > 0 && out_pose,
            "[FoundationPose] fp_register_shard_finish: invalid arguments");
+  RoctxRange range("fp_register_shard_finish (cross-hypothesis head + arg-max)");
   float *scores = m->scores_dev;
   if (N_total > m->cap) {  // gathered hypotheses of all ranks: a persistent buffer, not a malloc/free per Register
     if (N_total > m->scores_all_cap) {
@@ -1442,6 +1503,7 @@ int fp_register(fp_model *m, const uint8_t *rgb, const float *depth, const uint8
 // model's stream and hands the pose over.  One host thread can so keep several models (objects) in flight at once.
 static int track_submit_impl(fp_model *m, const void *rgb, const void *depth, int memspace, int H, int W, const float hyp_pose[16],
                              const char *target_name, int refine_itr) {
+  RoctxRange range("fp_track_submit");
   Target *t = nullptr;
   if (check_frame_args(m, H, W, target_name ? target_name : "", &t)) return 1;
   FP_CHECK(m->refiner, "[FoundationPose] refiner weights not loaded");
@@ -1882,7 +1944,7 @@ fp_net *fp_net_create(const char *weights_path, int is_scorer, int max_batch) tr
   if (!n->net) { set_error("[FoundationPose] Failed to load network weights: " + err); return nullptr; }
   n->ws = nn_scratch_create(PREC_F16);
   const size_t in_elems = (size_t)max_batch * FP_CROP_HW * FP_CROP_HW * 6;
-  bool ok = hipStreamCreateWithFlags(&n->stream, hipStreamNonBlocking) == hipSuccess;
+  bool ok = stream_acquire(&n->stream) == hipSuccess;
   for (int i = 0; ok && i < 2; i++) ok = !dev_alloc(&n->in_dev[i], in_elems) && !dev_alloc(&n->out_dev[i], (size_t)max_batch * 3);
   ok = ok && !dev_alloc(&n->feat_dev, (size_t)max_batch * 512) && !dev_alloc(&n->nn_in, (size_t)2 * max_batch * FP_NN_IN_IMG_HALFS);
   ok = ok && hipMemsetAsync(n->nn_in, 0, (size_t)2 * max_batch * FP_NN_IN_IMG_HALFS * sizeof(__half), n->stream) == hipSuccess;
@@ -1902,7 +1964,7 @@ static void destroy_net_impl(fp_net *n) {
   dev_free(n->feat_dev); dev_free(n->nn_in);
   if (n->net) net_free(n->net);
   if (n->ws) nn_scratch_free(n->ws);
-  if (n->stream) (void)hipStreamDestroy(n->stream);
+  if (n->stream) { (void)hipStreamSynchronize(n->stream); stream_release(n->stream); }
   delete n;
 }
 void fp_net_destroy(fp_net *n) {

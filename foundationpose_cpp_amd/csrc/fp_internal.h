@@ -84,14 +84,29 @@ struct Profiler {
   ProfEntry *cur = nullptr;
   hipEvent_t cur_start = nullptr;
 };
+// roctx ranges (SURVEY.md section 5 "tracing / profiling": roctx + rocprofv3): every ProfScope -- one per kernel launch site, named
+// "<layer>/<kernel>" -- and the stage scopes of fp_api.hip (RoctxRange) push / pop a range, so `rocprofv3 --marker-trace` sees
+// labelled stages instead of a stream of 60 anonymous kernels.  The roctx library is bound at first use with dlopen
+// (librocprofiler-sdk-roctx, else libroctx64); without it the calls are no-ops.  Host-side markers: inside a replayed hipGraph
+// there is no host code per launch, so profile with graphs off (the first, eager call of a configuration) to see per-launch ranges.
+void roctx_push(const char *name);
+void roctx_pop();
+struct RoctxRange {
+  explicit RoctxRange(const char *name) { roctx_push(name); }
+  ~RoctxRange() { roctx_pop(); }
+  RoctxRange(const RoctxRange &) = delete;
+  RoctxRange &operator=(const RoctxRange &) = delete;
+};
 struct ProfScope {
   Profiler *p;
   hipStream_t s;
   ProfScope(Profiler *p_, hipStream_t s_, const char *name, double flops = 0, double bytes = 0) : p(p_), s(s_) {
+    roctx_push(name);
     if (p && p->on) p->begin(s, name, flops, bytes);
   }
   ~ProfScope() {
     if (p && p->on) p->end(s);
+    roctx_pop();
   }
 };
 

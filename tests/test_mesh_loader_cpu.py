@@ -385,3 +385,31 @@ def test_loaders_survive_mutated_files(tmp_path, small_mesh):
             except FoundationPoseError:
                 bad += 1
     assert ok > 50 and bad > 50, (ok, bad)      # both outcomes occur; the point is that the process is still here
+
+
+def test_spliced_jpeg_and_header_lies_are_errors(tmp_path, small_mesh):
+    """Round-3 review: (1) a progressive JPEG without its EOI followed by a LARGER progressive JPEG without its SOI made the second SOF
+    re-size the frame under coefficient arrays sized by the first (heap overflow): a second frame header is now `corrupt JPEG`, also
+    baseline-after-progressive; (2) raw containers whose headers promise more pixels than the file holds fail before they allocate."""
+    rng = np.random.default_rng(11)
+    small = tmp_path / "small.jpg"; big = tmp_path / "big.jpg"; base = tmp_path / "base.jpg"
+    Image.fromarray(rng.integers(0, 256, size=(16, 16, 3), dtype=np.uint8)).save(small, progressive=True)
+    Image.fromarray(rng.integers(0, 256, size=(512, 512, 3), dtype=np.uint8)).save(big, progressive=True, subsampling=0)
+    Image.fromarray(rng.integers(0, 256, size=(512, 512, 3), dtype=np.uint8)).save(base)
+    a = small.read_bytes()
+    assert a[-2:] == b"\xff\xd9"
+    for second in (big, base):
+        b = second.read_bytes()
+        assert b[:2] == b"\xff\xd8"
+        (tmp_path / "spliced.jpg").write_bytes(a[:-2] + b[2:])
+        with pytest.raises(FoundationPoseError) as e:
+            load_mesh("obj", _write_obj(str(tmp_path), small_mesh, texture="spliced.jpg"))
+        assert "second frame header" in str(e.value), str(e.value)
+    # TGA: 18-byte header claiming 60000 x 60000 true-colour pixels; PNM: header claiming 16000 x 16000 with 10 bytes of data
+    (tmp_path / "lie.tga").write_bytes(bytes([0, 0, 2, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0x60, 0xEA, 0x60, 0xEA, 24, 0]))
+    (tmp_path / "lie.ppm").write_bytes(b"P3\n16000 16000\n255\n1 2 3\n")
+    bmp = bytearray(54); bmp[0:2] = b"BM"; bmp[10] = 54; bmp[14] = 40; bmp[18:22] = (16).to_bytes(4, "little"); bmp[22:26] = (0x80000000).to_bytes(4, "little"); bmp[28] = 24
+    (tmp_path / "lie.bmp").write_bytes(bytes(bmp))
+    for name in ("lie.tga", "lie.ppm", "lie.bmp"):
+        with pytest.raises(FoundationPoseError):
+            load_mesh("obj", _write_obj(str(tmp_path), small_mesh, texture=name))

@@ -7,19 +7,24 @@
 #include <stdio.h>
 #include <string.h>
 #include <unistd.h>
+#include <fcntl.h>
+#include <stdlib.h>
 #include <sys/syscall.h>
+static int g_fd = 2;   // FP_SEGV_TRACE_FILE: write there (pytest captures fd 2)
 static void handler(int sig, siginfo_t *si, void *ctx) {
   (void)ctx;
   void *bt[64];
   char msg[128];
   int n = snprintf(msg, sizeof msg, "\n[segv_trace] signal %d at address %p, thread %ld\n", sig, si ? si->si_addr : 0, (long)syscall(SYS_gettid));
-  (void)!write(2, msg, n);
+  (void)!write(g_fd, msg, n);
   n = backtrace(bt, 64);
-  backtrace_symbols_fd(bt, n, 2);
+  backtrace_symbols_fd(bt, n, g_fd);
   signal(sig, SIG_DFL);
   raise(sig);
 }
 __attribute__((constructor)) void segv_trace_install(void) {
+  const char *f = getenv("FP_SEGV_TRACE_FILE");
+  if (f && g_fd == 2) { int fd = open(f, O_WRONLY | O_CREAT | O_APPEND, 0644); if (fd >= 0) g_fd = fd; }
   struct sigaction sa;
   memset(&sa, 0, sizeof sa);
   sa.sa_sigaction = handler;
