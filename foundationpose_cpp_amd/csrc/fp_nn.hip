@@ -96,8 +96,9 @@ __device__ __forceinline__ f4 mfma8(i8 a, i8 b, f4 c) {
 }
 // output-type codes (fp_nn.h): which tensors an epilogue writes
 __host__ __device__ constexpr bool odt_dual(int odt) { return odt == DT_DUAL_FP8 || odt == DT_DUAL_I8; }
-__host__ __device__ constexpr int odt_q(int odt) { return odt == DT_DUAL_FP8 ? DT_FP8 : odt == DT_DUAL_I8 ? DT_I8 : is_q8(odt) ? odt : -1; }   // 8-bit type written, or -1
-__host__ __device__ constexpr int odt_16(int odt) { return odt_dual(odt) ? DT_F16 : is_q8(odt) ? -1 : odt; }                                  // 2-byte type written, or -1
+__host__ __device__ constexpr bool odt_qs(int odt) { return odt == DT_QS_FP8 || odt == DT_QS_I8; }
+__host__ __device__ constexpr int odt_q(int odt) { return (odt == DT_DUAL_FP8 || odt == DT_QS_FP8) ? DT_FP8 : (odt == DT_DUAL_I8 || odt == DT_QS_I8) ? DT_I8 : is_q8(odt) ? odt : -1; }   // 8-bit type written, or -1
+__host__ __device__ constexpr int odt_16(int odt) { return odt_dual(odt) ? DT_F16 : (is_q8(odt) || odt_qs(odt)) ? -1 : odt; }                  // 2-byte type written, or -1
 // all MFMAs of one 128-byte K-step: w[ks][ni] / x[ks][mi] are the two 16-byte fragment reads of each row
 template <int DT, int NI, int MI>
 __device__ __forceinline__ void mma_kstep(f4 (&acc)[NI][MI], const i4 (&w)[2][NI], const i4 (&x)[2][MI]) {
@@ -289,6 +290,8 @@ struct ConvParams {
 //                          on the host (legal because these layers have no residual and end in a ReLU);
 //   DT_DUAL_FP8 / _I8      an f16 tensor at p.out (the residual stream) AND its 8-bit copy at p.out2 = value * oinv[c] (the next
 //                          convolution's operand); both tensors have the same shape / border, so one element offset serves both.
+//   DT_QS_FP8 / _I8        the 8-bit copy alone, value * oinv[c], at p.out (a layer WITH a residual whose f16 output nobody reads:
+//                          the consumer's scales cannot be folded into the tables then)
 // The epilogue covers channel tiles [NI0, NI0 + NI) of an accumulator array of NIT tiles (the stem: two 32-channel passes
 // over its 4 tiles; the array is passed whole so that it stays in registers).
 __device__ __forceinline__ int pack4_fp8(float a, float b, float c, float d) {
@@ -310,7 +313,7 @@ __device__ __forceinline__ void conv_epilogue_px(const ConvParams &p, f4 (&acc)[
   static_assert(NI == 4 || NI == 2, "wave covers 64 or 32 channels");
   constexpr int NS = NI / 2;  // 8-channel stores per pixel per lane
   constexpr int O16 = odt_16(ODT), OQ = odt_q(ODT);
-  constexpr bool DUAL = odt_dual(ODT);
+  constexpr bool DUAL = odt_dual(ODT), SCALED = odt_dual(ODT) || odt_qs(ODT);
   constexpr int RDT = is_q8(DT) ? DT_F16 : DT;
   const int OHp = p.OH + 2 * p.opad, OWp = p.OW + 2 * p.opad;
   const int RHp = p.OH + 2 * p.rpad, RWp = p.OW + 2 * p.rpad;
@@ -340,8 +343,8 @@ __device__ __forceinline__ void conv_epilogue_px(const ConvParams &p, f4 (&acc)[
       }
     }
   }
-  float oi[DUAL ? NS : 1][8];  // DUAL: 1 / (scale of output channel c in the 8-bit copy)
-  if constexpr (DUAL) {
+  float oi[SCALED ? NS : 1][8];  // 1 / (scale of output channel c in the 8-bit copy)
+  if constexpr (SCALED) {
 #pragma unroll
     for (int k = 0; k < NS; k++) {
       float4 s0 = *reinterpret_cast<const float4 *>(p.oinv + nl + 32 * k), s1 = *reinterpret_cast<const float4 *>(p.oinv + nl + 32 * k + 4);
@@ -410,7 +413,7 @@ __device__ __forceinline__ void conv_epilogue_px(const ConvParams &p, f4 (&acc)[
           ov[(e4 >> 1) + 1] = __builtin_bit_cast(int, p1);
         }
         if constexpr (OQ >= 0) {
-          if constexpr (DUAL) {
+          if constexpr (SCALED) {
 #pragma unroll
             for (int h = 0; h < 4; h++) v4[h] *= oi[k][e4 + h];
           }
@@ -4523,6 +4526,7 @@ static int run_conv(const Ctx &c, const char *tag, const ConvLayer &L, const Act
   p.out2 = out2 ? (unsigned char *)out2->p : nullptr;
   p.oinv = oinv;
   FP_CHECK(!out2 || (out.dt == DT_F16 && is_q8(out2->dt) && oinv && !grp && !post), "run_conv: unsupported dual output");
+  FP_CHECK(out2 || !oinv || (is_q8(out.dt) && out.dt == L.dt && !grp && !post), "run_conv: unsupported scaled 8-bit output");
   p.post = (const unsigned char *)post;
   if (post_fused) *post_fused = false;
   FP_CHECK(in.dt == L.dt, "run_conv: input element type does not match the layer's weights");
@@ -4583,6 +4587,10 @@ static int run_conv(const Ctx &c, const char *tag, const ConvLayer &L, const Act
     if (L.dt == DT_F16 && out2->dt == DT_FP8) return run_conv_dt<DT_F16, DT_DUAL_FP8>(c, tag, L, p, NB, H, W, ipad, hr, split_imgs, grp);
     if (L.dt == DT_F16 && out2->dt == DT_I8) return run_conv_dt<DT_F16, DT_DUAL_I8>(c, tag, L, p, NB, H, W, ipad, hr, split_imgs, grp);
     FP_CHECK(false, "run_conv: unsupported combination of operand / dual-output element types");
+  }
+  if (oinv) {   // 8-bit output alone, scaled in the epilogue
+    if (L.dt == DT_FP8) return run_conv_dt<DT_FP8, DT_QS_FP8>(c, tag, L, p, NB, H, W, ipad, hr, split_imgs, grp);
+    return run_conv_dt<DT_I8, DT_QS_I8>(c, tag, L, p, NB, H, W, ipad, hr, split_imgs, grp);
   }
   if (L.dt == DT_FP8 && out.dt == DT_FP8) return run_conv_dt<DT_FP8, DT_FP8>(c, tag, L, p, NB, H, W, ipad, hr, split_imgs, grp);
   if (L.dt == DT_FP8 && out.dt == DT_F16) return run_conv_dt<DT_FP8, DT_F16>(c, tag, L, p, NB, H, W, ipad, hr, split_imgs, grp);
@@ -4817,10 +4825,11 @@ static int run_trunk_q8(const Ctx &c, const Arena &a, const void *nn_in, int N, 
   calib_record(c, 7, a.x256[2], P2, 256, DT_F16);
   if (run_conv(c, "conv_256", net->rb[1][0], y2q, N, 40, 40, 1, y1q, 1, true)) return 1;
   calib_record(c, 8, a.q256[1], P2, 256, q, net->act_scale_dev[8]);
-  // (y0 feeds only encodeAB.2: its f16 copy is written but never read -- 0.2 GB per launch; an 8-bit-only output with a residual
-  //  cannot fold the consumer's scales into the bias)
-  if (run_conv(c, "conv_256", net->rb[1][1], y1q, N, 40, 40, 1, y0, 1, true, &y2, 1, 0, nullptr, nullptr, nullptr, &y0q, net->act_oinv[9])) return 1;
-  calib_record(c, 9, a.x256[1], P2, 256, DT_F16);
+  // y0 feeds only encodeAB.2: no f16 copy (0.2 GB per launch less); with a residual the consumer's scales cannot be folded into the
+  // tables, so the epilogue scales (DT_QS_*)
+  (void)y0;
+  if (run_conv(c, "conv_256", net->rb[1][1], y1q, N, 40, 40, 1, y0q, 1, true, &y2, 1, 0, nullptr, nullptr, nullptr, nullptr, net->act_oinv[9])) return 1;
+  calib_record(c, 9, a.q256[0], P2, 256, q, net->act_scale_dev[9]);
   const Act z0 = F(a.x512[0]), z0q = Q(a.q512[0]), z1q = Q(a.q512[1]), z2 = F(a.x512[2]), z2q = Q(a.q512[2]);
   if (run_conv(c, "conv_b2", net->b2, y0q, N, 40, 40, 1, z0, 1, true, nullptr, 0, 0, nullptr, nullptr, nullptr, &z0q, net->act_oinv[10])) return 1;
   calib_record(c, 10, a.x512[0], P5, 512, DT_F16);
@@ -5195,13 +5204,14 @@ int fpt_conv_dt(const float *x, const float *w, const float *bias, const float *
 //   in; res (optional) [NB,OH,OW,Cout] is f16 on the device.
 //   mode 0: 8-bit output only, the consumer's scales s_out [Cout] folded into the epilogue tables -> outq (de-quantised values)
 //   mode 1: f16 output only -> out16;  mode 2: f16 output + its 8-bit copy (value / s_out[c]) -> out16, outq
+//   mode 3: the 8-bit copy alone, scaled in the epilogue (a layer with a residual whose f16 output nobody reads) -> outq
 // split_imgs > 0: the a|b channel concat ([NB - split, OH, OW, 2 * Cout]; s_out still indexed by the layer's output channel).
 // wq_out (optional) [Cout*KH*KW*Cin]: the de-quantised weights the device used (w' / s_in, i.e. comparable with w), sw_out [Cout].
 int fpt_conv_q8(const float *x, const float *s_in, const float *w, const float *bias, const float *res, int NB, int H, int W, int Cin, int Cout,
                 int KH, int KW, int stride, int pad, int OH, int OW, int relu, int split_imgs, int mode, const float *s_out, float *out16,
                 float *outq, int iters, float *ms_out, int dt, float *wq_out) {
   using namespace fp;
-  FP_CHECK(is_q8(dt) && mode >= 0 && mode <= 2, "fpt_conv_q8: invalid arguments");
+  FP_CHECK(is_q8(dt) && mode >= 0 && mode <= 3, "fpt_conv_q8: invalid arguments");
   const int ip = pad, Hp = H + 2 * ip, Wp = W + 2 * ip;
   const size_t nx = (size_t)NB * Hp * Wp * Cin, nw = (size_t)Cout * KH * KW * Cin, M = (size_t)NB * OH * OW, nout = M * Cout;
   DevBuf<unsigned char> dx(nx), dres(nout * 2), d16(nout * 2), dq(nout);
@@ -5241,7 +5251,7 @@ int fpt_conv_q8(const float *x, const float *s_in, const float *w, const float *
     }
   }
   float *oinv_dev = nullptr;
-  if (mode == 2) {
+  if (mode >= 2) {
     std::vector<float> inv(Cout);
     for (int c2 = 0; c2 < Cout; c2++) inv[c2] = 1.f / s_out[c2];
     oinv_dev = upload(&net, inv);
@@ -5253,6 +5263,7 @@ int fpt_conv_q8(const float *x, const float *s_in, const float *w, const float *
   auto once = [&]() {
     if (mode == 0) return run_conv(c, "t", L, ain, NB, H, W, ip, aq, 0, relu != 0, res ? &ares : nullptr, 0, split_imgs);
     if (mode == 1) return run_conv(c, "t", L, ain, NB, H, W, ip, a16, 0, relu != 0, res ? &ares : nullptr, 0, split_imgs);
+    if (mode == 3) return run_conv(c, "t", L, ain, NB, H, W, ip, aq, 0, relu != 0, res ? &ares : nullptr, 0, split_imgs, nullptr, nullptr, nullptr, nullptr, oinv_dev);
     return run_conv(c, "t", L, ain, NB, H, W, ip, a16, 0, relu != 0, res ? &ares : nullptr, 0, split_imgs, nullptr, nullptr, nullptr, &aq, oinv_dev);
   };
   if (once()) return 1;
@@ -5272,7 +5283,7 @@ int fpt_conv_q8(const float *x, const float *s_in, const float *w, const float *
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
   }
-  if (mode >= 1 && out16) {
+  if ((mode == 1 || mode == 2) && out16) {
     std::vector<unsigned char> ho(nout * 2);
     FP_HIP_OK(fp::memcpy_sync(ho.data(), d16.p, ho.size(), hipMemcpyDeviceToHost));
     decode(ho.data(), nout, DT_F16, 1.f, out16);

@@ -233,8 +233,39 @@ def read_graph(path: str) -> Graph:
     for n in g.nodes:                                       # Constant nodes behave like initialisers
         if n.op == "Constant" and "value" in n.attrs and isinstance(n.attrs["value"], np.ndarray):
             g.init[n.outputs[0]] = n.attrs["value"]
+    _propagate_constants(g)
     g.inputs = [i for i in g.inputs if i not in g.init]
     return g
+
+
+def _propagate_constants(g: "Graph") -> None:
+    """Weights that reach their layer through shape / type plumbing -- exporters without constant folding, fp16 models with a Cast
+    per initialiser, MatMul operands stored [out, in] behind a Transpose -- become initialisers of the plumbing node's output name."""
+    changed = True
+    while changed:
+        changed = False
+        for n in g.nodes:
+            if not n.outputs or n.outputs[0] in g.init or not n.inputs or n.inputs[0] not in g.init:
+                continue
+            x = g.init[n.inputs[0]]
+            y = None
+            if n.op in ("Identity", "Cast"):
+                y = x.astype(np.float32) if n.op == "Cast" and x.dtype.kind == "f" else x
+            elif n.op == "Transpose":
+                perm = n.attrs.get("perm")
+                y = np.transpose(x, [int(v) for v in perm]) if perm is not None else x.T
+            elif n.op in ("Squeeze", "Unsqueeze", "Reshape", "Flatten"):
+                if n.op == "Reshape" and len(n.inputs) > 1 and n.inputs[1] in g.init:
+                    shp = [int(v) for v in np.asarray(g.init[n.inputs[1]]).reshape(-1)]
+                    shp = [x.shape[i] if v == 0 else v for i, v in enumerate(shp)]
+                    y = x.reshape(shp)
+                elif n.op == "Squeeze":
+                    y = np.squeeze(x)
+                elif n.op == "Flatten":
+                    y = x.reshape(x.shape[0], -1)
+            if y is not None:
+                g.init[n.outputs[0]] = np.ascontiguousarray(y)
+                changed = True
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -301,6 +332,11 @@ def _linears(g: Graph):
             w = w if int(n.attrs.get("transB", 0)) else w.T
             b = _f32(g.init[n.inputs[2]]) if len(n.inputs) > 2 and n.inputs[2] in g.init else np.zeros(w.shape[0], np.float32)
             out.append((n, _f32(w * float(n.attrs.get("alpha", 1.0))), _f32(b * float(n.attrs.get("beta", 1.0)))))
+        elif n.op == "Attention" and len(n.inputs) > 2 and n.inputs[1] in g.init and g.init[n.inputs[1]].ndim == 2:
+            # com.microsoft fused attention (onnxruntime's transformer optimiser): weights [in, 3 * hidden], bias [3 * hidden]
+            w = _f32(g.init[n.inputs[1]]).T
+            b = _f32(g.init[n.inputs[2]]).reshape(-1) if n.inputs[2] in g.init else np.zeros(w.shape[0], np.float32)
+            out.append((n, _f32(w), b))
         elif n.op == "MatMul" and n.inputs[1] in g.init and g.init[n.inputs[1]].ndim == 2:
             w = _f32(g.init[n.inputs[1]]).T
             b = np.zeros(w.shape[0], np.float32)
@@ -318,7 +354,9 @@ def _layernorms(g: Graph):
            if n.op == "LayerNormalization" and n.inputs[1] in g.init and len(n.inputs) > 2 and n.inputs[2] in g.init]
     if out:
         return out
-    # opset < 17: LayerNorm is decomposed; its affine parameters keep their module names (…norm1.weight / .bias)
+    # opset < 17: LayerNorm is decomposed.  (a) its affine parameters keep their module names (…norm1.weight / .bias) with the
+    # TorchScript exporter; (b) otherwise (dynamo exporter, renamed initialisers) the affine tail is found by its shape:
+    # Div(x - mean, sqrt(var + eps)) -> Mul(const[512]) -> Add(const[512])
     names = sorted(k[:-len(".weight")] for k in g.init if k.endswith((".norm1.weight", ".norm2.weight")))
     cons = _consumers(g)
     res = []
@@ -326,6 +364,22 @@ def _layernorms(g: Graph):
         users = cons.get(base + ".weight", [])
         if users and base + ".bias" in g.init:
             res.append((users[0], _f32(g.init[base + ".weight"]), _f32(g.init[base + ".bias"])))
+    if res:
+        return sorted(res, key=lambda t: t[0].index)
+    prod = {o: n for n in g.nodes for o in n.outputs}
+    for n in g.nodes:
+        if n.op != "Mul" or len(n.inputs) != 2:
+            continue
+        cst = [i for i in n.inputs if i in g.init and g.init[i].size == W.EMBED]
+        dyn = [i for i in n.inputs if i not in g.init]
+        if len(cst) != 1 or len(dyn) != 1 or prod.get(dyn[0]) is None or prod[dyn[0]].op != "Div":
+            continue
+        nxt = cons.get(n.outputs[0], [])
+        if len(nxt) != 1 or nxt[0].op != "Add":
+            continue
+        beta = [i for i in nxt[0].inputs if i in g.init and g.init[i].size == W.EMBED]
+        if len(beta) == 1:
+            res.append((n, _f32(g.init[cst[0]]).reshape(-1), _f32(g.init[beta[0]]).reshape(-1)))
     return sorted(res, key=lambda t: t[0].index)
 
 
@@ -517,11 +571,12 @@ def check(path: str, kind: str | None = None):
         if lns:
             diff(f"a scorer has no LayerNorm; found {len(lns)}")
     if ops.get("LayerNormalization", 0) == 0 and lns:
-        note(f"LayerNorm is decomposed (opset {g.opset} < 17: ReduceMean / Sub / Pow / Sqrt / Div); affine parameters found by their module names")
+        note(f"LayerNorm is decomposed (opset {g.opset} < 17: ReduceMean / Sub / Pow / Sqrt / Div); affine parameters found by their module names or by the Div -> Mul(const) -> Add(const) tail")
     elif kind == "refiner" and not lns:
         diff("no LayerNorm found: neither LayerNormalization nodes nor *.norm1/.norm2 initialisers")
-    nsm = ops.get("Softmax", 0)
-    (ok if nsm == 2 else diff)(f"{nsm} Softmax node(s) (expected 2: " + ("one self-attention per head" if kind == "refiner" else "att + att_cross") + ")")
+    nsm, nfa = ops.get("Softmax", 0), ops.get("Attention", 0) + ops.get("MultiHeadAttention", 0)
+    (ok if nsm + nfa == 2 else diff)(f"{nsm} Softmax node(s) + {nfa} fused attention node(s) (expected 2 attentions: " +
+                                     ("one self-attention per head" if kind == "refiner" else "att + att_cross") + ")")
     nrelu = ops.get("Relu", 0)
     want_relu = (15 if n_conv_nodes == len(convs) else 15 + 6) + (2 if kind == "refiner" else 0)
     (ok if nrelu == want_relu else note)(f"{nrelu} Relu node(s) (architecture: {want_relu})")

@@ -35,11 +35,18 @@ def _iv(fn, v):
     return _vi(fn << 3) + _vi(v)
 
 
-def tensor(name, arr, raw=True):
+def tensor(name, arr, raw=True, half=False):
+    if half:     # fp16 initialiser (data_type 10), raw bytes
+        arr = np.ascontiguousarray(arr, np.float16)
+        return b"".join(_iv(1, d) for d in arr.shape) + _iv(2, 10) + _ld(9, arr.tobytes()) + _ld(8, name.encode())
     arr = np.ascontiguousarray(arr, np.float32)
     b = b"".join(_iv(1, d) for d in arr.shape) + _iv(2, 1)
     b += _ld(9, arr.tobytes()) if raw else _ld(4, arr.tobytes())
     return b + _ld(8, name.encode())
+
+
+def attr_ints(name, vals):
+    return _ld(1, name.encode()) + b"".join(_iv(8, v) for v in vals) + _iv(20, 7)
 
 
 def attr_i(name, v):
@@ -65,6 +72,12 @@ class Builder:
         return f"/{stem}_{self.k}"
 
     def const(self, name, arr):
+        if self.f == "variant":
+            # an exporter without constant folding, fp16 weights: anonymous fp16 initialiser -> Cast(to float) -> consumer
+            self.k += 1
+            anon = f"val_{self.k}"
+            self.inits.append(tensor(anon, arr, half=True))
+            return self.add("Cast", [anon], [attr_i("to", 1)])
         self.inits.append(tensor(name, arr, raw=(self.f == "folded")))
         return name
 
@@ -75,7 +88,7 @@ class Builder:
 
     def conv(self, x, st, base, conv, bn, relu=True):
         w, b = st[f"{base}.{conv}.weight"], st[f"{base}.{conv}.bias"]
-        if self.f == "folded":
+        if self.f in ("folded", "variant"):
             fs = W.fold_batchnorm({f"{base}.{conv}.weight": w, f"{base}.{conv}.bias": b,
                                    **{f"{base}.{bn}.{k}": st[f"{base}.{bn}.{k}"] for k in ("weight", "bias", "running_mean", "running_var")}})
             (wn, wf), (bn_, bf) = sorted(fs.items(), key=lambda kv: kv[0].endswith("bias"))
@@ -100,6 +113,9 @@ class Builder:
         return x
 
     def linear(self, x, w, b, wname, bname):
+        if self.f == "variant":      # weight stored [out, in] behind a Transpose node, bias added on the other side
+            y = self.add("MatMul", [x, self.add("Transpose", [self.const(wname, w)], [attr_ints("perm", [1, 0])])])
+            return self.add("Add", [y, self.const(bname, b)])
         if self.f == "folded":
             self.k += 1
             y = self.add("MatMul", [x, self.const(f"onnx::MatMul_{self.k}", np.ascontiguousarray(w.T))])
@@ -108,6 +124,9 @@ class Builder:
 
     def mha(self, x, st, prefix):
         w, b = st[f"{prefix}.in_proj_weight"], st[f"{prefix}.in_proj_bias"]
+        if self.f == "variant":      # onnxruntime's fused attention: weights [in, 3 * hidden]
+            o = self.add("Attention", [x, self.const("w", np.ascontiguousarray(w.T)), self.const("b", b)], [attr_i("num_heads", 4)])
+            return self.linear(o, st[f"{prefix}.out_proj.weight"], st[f"{prefix}.out_proj.bias"], f"{prefix}.out_proj.weight", f"{prefix}.out_proj.bias")
         if self.f == "folded":
             qkv = self.linear(x, w, b, f"{prefix}.in_proj_weight", f"{prefix}.in_proj_bias")
             q, k, v = (self.add("Slice", [qkv]) for _ in range(3))
@@ -119,6 +138,12 @@ class Builder:
         return self.linear(o, st[f"{prefix}.out_proj.weight"], st[f"{prefix}.out_proj.bias"], f"{prefix}.out_proj.weight", f"{prefix}.out_proj.bias")
 
     def layernorm(self, x, st, base):
+        if self.f == "variant":      # decomposed, anonymous constants
+            mu = self.add("ReduceMean", [x])
+            d = self.add("Sub", [x, mu])
+            var = self.add("ReduceMean", [self.add("Pow", [d, self.const("two", np.array(2.0, np.float32))])])
+            nrm = self.add("Div", [d, self.add("Sqrt", [self.add("Add", [var, self.const("eps", np.array(1e-5, np.float32))])])])
+            return self.add("Add", [self.add("Mul", [nrm, self.const("g", st[base + ".weight"])]), self.const("b", st[base + ".bias"])])
         return self.add("LayerNormalization", [x, self.const(base + ".weight", st[base + ".weight"]), self.const(base + ".bias", st[base + ".bias"])],
                         [attr_f("epsilon", 1e-5), attr_i("axis", -1)])
 
@@ -145,7 +170,9 @@ def write_model(path, kind, state, flavour="folded"):
     x = b.encoder(x, state, "encodeA", W.ENCODE_A)
     x = b.add("Concat", [b.add("Slice", [x]), b.add("Slice", [x])], [attr_i("axis", 1)])
     x = b.encoder(x, state, "encodeAB", W.ENCODE_AB)
-    x = b.add("Add", [b.add("Transpose", [b.add("Reshape", [x])]), b.const("pos_embed.pe", _pe())])
+    pe_name = "pos_embed.pe"
+    b.inits.append(tensor(pe_name, _pe()))
+    x = b.add("Add", [b.add("Transpose", [b.add("Reshape", [x])]), pe_name])
     if kind == "refiner":
         def head_steps(head):
             p = f"{head}.0"

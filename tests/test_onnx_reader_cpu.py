@@ -31,6 +31,26 @@ def test_reader_recovers_folded_state(tmp_path, kind, flavour):
     assert "Conv x15" in R.describe(p)
 
 
+@pytest.mark.parametrize("kind", ["refiner", "scorer"])
+def test_reader_takes_exporter_variants(tmp_path, kind):
+    """Round-3 review #9: what the published files may look like beyond the two TorchScript forms -- fp16 initialisers behind Cast nodes
+    with anonymous names (no constant folding), Linear weights stored [out, in] behind a Transpose, LayerNorm decomposed with anonymous
+    constants (found by the Div -> Mul(const) -> Add(const) tail), onnxruntime's fused `Attention` node with packed [in, 3 * hidden]
+    weights.  The recovered tensors equal the fp16 rounding of the folded state."""
+    st = W.make_synthetic_state(kind)
+    p = str(tmp_path / f"{kind}_variant.onnx")
+    write_model(p, kind, st, "variant")
+    got = R.extract(p, kind)
+    want = W.fold_batchnorm(st)
+    assert set(got) == set(want), (sorted(set(want) - set(got)), sorted(set(got) - set(want)))
+    for k, v in want.items():
+        assert got[k].shape == v.shape, k
+        np.testing.assert_array_equal(got[k], v.astype(np.float16).astype(np.float32), err_msg=k)
+    rep = R.check(p, kind)
+    text = rep if isinstance(rep, str) else str(rep)
+    assert "DIFF" not in text.upper() or "0 diff" in text.lower(), text
+
+
 def test_reader_fails_loudly(tmp_path):
     st = W.make_synthetic_state("scorer")
     p = str(tmp_path / "s.onnx")

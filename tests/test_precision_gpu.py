@@ -153,6 +153,8 @@ def test_q8_conv_schedules(shape, dt):
             assert viol.mean() < 2e-6 and np.abs(got - want)[viol].max(initial=0.0) < float(s_out.max()) * 2.0 ** -9 * 4, (viol.sum(), viol.size)
         else: assert np.all(np.abs(got - want) <= s_out * 1.01)
     close(gotq)
+    _, gotq3, _ = _conv_q8(x, s_in, w, b, stride, True, res, 3, s_out, dt)       # mode 3: the scaled 8-bit copy alone
+    assert np.array_equal(gotq3, gotq)
     if not use_res:  # mode 0 (a block's first conv): 8-bit only, the consumer's scales folded into the epilogue tables
         _, gotq0, _ = _conv_q8(x, s_in, w, b, stride, True, None, 0, s_out, dt)
         close(gotq0)
