@@ -152,7 +152,7 @@ def main():
     from foundationpose_cpp_amd import FoundationPose, synthetic as syn, weights as W
     from foundationpose_cpp_amd.api import FP_PREC_BF16, FP_PREC_F16, FP_PREC_FP8, FP_PREC_INT8
     Q8_PREC = {"fp8": FP_PREC_FP8, "int8": FP_PREC_INT8}
-    from foundationpose_cpp_amd.distributed import HipShardBackend, sharded_register
+    from foundationpose_cpp_amd.distributed import HipShardBackend, NativeRcclComm, sharded_register, sharded_register_native
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -194,6 +194,14 @@ def main():
     mask = torch.from_numpy(scene.mask).to(dev)
     H, Wd = scene.depth.shape
     backend = HipShardBackend(model, dev)
+    # N > 1: the library's own collective (fp_register_sharded: ncclAllGather on the model's stream); the torch.distributed exchange
+    # (HipShardBackend) stays as the fall-back if a communicator cannot be made
+    native_comm = None
+    if (world > 1 or force_shard) and os.environ.get("FP_BENCH_TORCH_COLLECTIVE", "0") != "1":
+        try:
+            native_comm = NativeRcclComm(dist, dev)
+        except Exception as e:   # noqa: BLE001
+            print(f"[bench] native RCCL communicator unavailable ({e}); using torch.distributed for the all-gather", file=sys.stderr)
     out_pose = np.zeros(16, np.float32)
     hyp16 = syn.to_colmajor(syn.perturb_pose(scene.gt_pose))
     hyp44 = syn.perturb_pose(scene.gt_pose)
@@ -213,6 +221,8 @@ def main():
             track_dev()
         elif world == 1 and not force_shard:
             register_dev()
+        elif native_comm is not None:
+            sharded_register_native(model, native_comm, rgb, depth, mask, H, Wd, mesh.name, 1)
         else:
             sharded_register(backend, dist, n_total, rgb, depth, mask, H, Wd, mesh.name, 1)
 
@@ -323,6 +333,8 @@ def main():
         def step1008():
             if world == 1 and not force_shard:
                 register_dev()
+            elif native_comm is not None:
+                sharded_register_native(model, native_comm, rgb, depth, mask, H, Wd, mesh.name, 1)
             else:
                 sharded_register(backend, dist, 1008, rgb, depth, mask, H, Wd, mesh.name, 1)
         k8 = max(3, args.steps // 4)
@@ -541,7 +553,8 @@ def main():
                 "precision": PRECISION_TEXT[args.dtype],
                 "calibration": "fp_calibrate on the bench frame itself" if args.dtype in Q8 else None,
                 "parallelism": f"hyp-shard x{world}" if world > 1 else "single GPU",
-                "collective": "1 RCCL all-gather [n_local,528] f32 per Register" if world > 1 else "none",
+                "collective": ("1 ncclAllGather [n_local,528] f32 per Register, issued by the library on its own stream (fp_register_sharded)" if native_comm is not None
+                               else "1 RCCL all-gather [n_local,528] f32 per Register (torch.distributed)") if world > 1 or force_shard else "none",
                 "baseline": "reference README.md:37-41 Register 2.8 fps x 252 = 705.6 hyp/s on RTX 4060 (TensorRT fp16), timed around the host-frame "
                             "call; vs_baseline = host_frame.value / 705.6 when that leg ran (N=1 default run), else value / 705.6",
             },

@@ -95,3 +95,58 @@ def sharded_register(backend, dist, n_total, rgb, depth, mask, H, W, name, refin
     # contiguous shards of `per` rows: the gathered rows are already in global hypothesis order, padding only at the end.
     # NaN rows of a failed rank make every other rank's finish fail too ("scores are not finite ...", fp_register_shard_finish)
     return backend.shard_finish_packed(gathered, n_total)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The native path (round 4): the library issues the ncclAllGather itself (fp_register_sharded, include/foundationpose_amd.h) on its own
+# stream -- no torch tensors, no events across runtimes.  A Python host only has to hand over an RCCL communicator; torch.distributed
+# does not expose its ncclComm_t, so one is made here with the SAME librccl the process already holds (torch's bundled copy, which is
+# also the one the library binds with dlopen(RTLD_NOLOAD)): rank 0 draws a ncclUniqueId, torch.distributed broadcasts its 128 bytes
+# (control plane only), every rank calls ncclCommInitRank.
+class _NcclUniqueId(C.Structure):
+    _fields_ = [("internal", C.c_char * 128)]
+
+
+class NativeRcclComm:
+    def __init__(self, dist, device):
+        import os
+        import torch
+        path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        self._lib = C.CDLL(path if os.path.exists(path) else "librccl.so.1")
+        L = self._lib
+        L.ncclGetUniqueId.argtypes = [C.POINTER(_NcclUniqueId)]
+        L.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, _NcclUniqueId, C.c_int]
+        L.ncclCommDestroy.argtypes = [C.c_void_p]
+        L.ncclGetErrorString.restype = C.c_char_p
+        world = dist.get_world_size() if dist.is_initialized() else 1
+        rank = dist.get_rank() if dist.is_initialized() else 0
+        uid = _NcclUniqueId()
+        if rank == 0:
+            self._check(L.ncclGetUniqueId(C.byref(uid)), "ncclGetUniqueId")
+        if world > 1:
+            t = torch.tensor(list(bytes(uid)), dtype=torch.uint8, device=device)
+            dist.broadcast(t, 0)
+            C.memmove(C.byref(uid), bytes(t.cpu().tolist()), 128)
+        torch.cuda.set_device(device)
+        self.comm = C.c_void_p()
+        self._check(L.ncclCommInitRank(C.byref(self.comm), world, uid, rank), "ncclCommInitRank")
+        self.world, self.rank = world, rank
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise RuntimeError(f"{what}: {self._lib.ncclGetErrorString(rc).decode()}")
+
+    def close(self):
+        if self.comm:
+            self._lib.ncclCommDestroy(self.comm)
+            self.comm = C.c_void_p()
+
+
+def sharded_register_native(model, comm: NativeRcclComm, rgb, depth, mask, H, W, name, refine_itr=1):
+    """One Register sharded over comm.world ranks through fp_register_sharded (device-resident frame tensors).  -> (pose16, index)"""
+    out = np.zeros(16, np.float32)
+    idx = C.c_int(-1)
+    model._must(model._L.fp_register_sharded(model.handle, comm.comm, C.c_void_p(rgb.data_ptr()), C.c_void_p(depth.data_ptr()),
+                                             C.c_void_p(mask.data_ptr()), 1, H, W, name.encode(), refine_itr,
+                                             out.ctypes.data_as(C.c_void_p), C.byref(idx)))
+    return out, idx.value

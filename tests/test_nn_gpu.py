@@ -553,3 +553,30 @@ def test_track_partial_row_upload_random_windows(nets, syn_mesh):
     finally:
         m1.close()
         m2.close()
+
+
+def test_native_sharded_register_world_1(model, syn_mesh, syn_scene):
+    """fp_register_sharded through the Python host: an RCCL communicator of size 1 made with the process's librccl (NativeRcclComm), the
+    library's own begin -> exchange -> finish on its stream; the result is the unsharded Register's, bit for bit.  (The C++ twin with
+    ncclCommInitAll is examples/fp_demo_mgpu.cpp, tests/test_demo_gpu.py; the arithmetic of N > 1 is covered by the gloo tests.)"""
+    import torch.distributed as dist
+    from foundationpose_cpp_amd.distributed import NativeRcclComm, sharded_register_native
+    dev = torch.device("cuda", 0)
+    comm = NativeRcclComm(dist, dev)
+    try:
+        assert comm.world == 1 and comm.rank == 0
+        rgb, depth, mask = (torch.from_numpy(x).to(dev) for x in (syn_scene.rgb, syn_scene.depth, syn_scene.mask))
+        ok, ref = model.Register(syn_scene.rgb, syn_scene.depth, syn_scene.mask, syn_mesh.name)
+        assert ok, model.last_error
+        for _ in range(3):      # eager, capture, replay
+            pose16, idx = sharded_register_native(model, comm, rgb, depth, mask, 480, 640, syn_mesh.name)
+            np.testing.assert_array_equal(syn.from_colmajor(pose16[None])[0], ref)
+            assert 0 <= idx < model.num_hypotheses
+        # a bad mask fails like the unsharded call, and the model stays usable
+        with pytest.raises(Exception) as e:
+            sharded_register_native(model, comm, rgb, depth, torch.zeros_like(mask), 480, 640, syn_mesh.name)
+        assert "Mask is all zero" in str(e.value)
+        pose16, _ = sharded_register_native(model, comm, rgb, depth, mask, 480, 640, syn_mesh.name)
+        np.testing.assert_array_equal(syn.from_colmajor(pose16[None])[0], ref)
+    finally:
+        comm.close()
