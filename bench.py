@@ -216,6 +216,24 @@ def main():
                                             C.c_void_p(mask.data_ptr()), 1, H, Wd, mesh.name.encode(), 1,
                                             out_pose.ctypes.data_as(C.c_void_p)))
 
+    # the native collective must give what the torch.distributed exchange gives, on every rank; otherwise all ranks fall back together
+    if native_comm is not None and not args.track:
+        agree = 1
+        try:
+            p_n, i_n = sharded_register_native(model, native_comm, rgb, depth, mask, H, Wd, mesh.name, 1)
+        except Exception as e:   # noqa: BLE001
+            print(f"[bench] rank {rank}: fp_register_sharded failed ({e})", file=sys.stderr)
+            agree = 0
+        p_t, i_t = sharded_register(backend, dist, n_total, rgb, depth, mask, H, Wd, mesh.name, 1)
+        if agree and (i_n != i_t or not np.array_equal(p_n, p_t)):
+            print(f"[bench] rank {rank}: native and torch.distributed sharded Registers disagree (winner {i_n} vs {i_t})", file=sys.stderr)
+            agree = 0
+        flag = torch.tensor([agree], dtype=torch.int32, device=dev)
+        if world > 1:
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            native_comm = None
+
     def step():
         if args.track:
             track_dev()

@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <dlfcn.h>
+#include <link.h>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -1408,7 +1409,15 @@ const RcclApi &rccl_api() {
   static const RcclApi api = [] {
     RcclApi a;
     void *h = nullptr;
-    for (const char *name : {"librccl.so.1", "librccl.so"}) if (!h) h = dlopen(name, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);   // a copy that is already in the process
+    // a copy that is already in the process, whatever its file name / soname (torch wheels ship `torch/lib/librccl.so`): the
+    // communicator the caller hands over was made by THAT copy
+    std::string loaded;
+    dl_iterate_phdr([](struct dl_phdr_info *info, size_t, void *out) {
+      if (info->dlpi_name && std::strstr(info->dlpi_name, "librccl")) { *(std::string *)out = info->dlpi_name; return 1; }
+      return 0;
+    }, &loaded);
+    if (!loaded.empty()) h = dlopen(loaded.c_str(), RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
+    for (const char *name : {"librccl.so.1", "librccl.so"}) if (!h) h = dlopen(name, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
     for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) if (!h) h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
     if (!h) { a.why = std::string("cannot load librccl: ") + (dlerror() ? dlerror() : "?"); return a; }
     a.all_gather = (nccl_allgather_fn)dlsym(h, "ncclAllGather");

@@ -53,8 +53,11 @@ def qa(x, amax_t, amax_c):
     return (x / sc).round().clamp(0, 255) * sc
 
 
+HALF = os.environ.get("HALF", "f16")   # storage type of the non-8-bit tensors: f16 | bf16 (the bf16 precision's arithmetic limit)
+
+
 def qh(x):
-    return x.half().float()
+    return x.bfloat16().float() if HALF == "bf16" else x.half().float()
 
 
 class Trunk:
@@ -215,7 +218,7 @@ def main():
         else:
             line += f"  argmax {out[:,0].argmax()} vs {ref[:,0].argmax()} rank-of-winner {list(np.argsort(-ref[:,0])).index(out[:,0].argmax())}"
         print(line, flush=True)
-    report("f16 everywhere", f16)
+    report(f"{HALF} everywhere (trunk storage + weights; heads fp32)", f16)
     def run(mask, stream_f16, bc, tag, tokfix=False):
         with torch.no_grad():
             t = Trunk(folded, mask, stream_f16, amax)
