@@ -9,13 +9,16 @@ carries `host_frame` (the reference's calling convention: host frames, H2D insid
   N = 1  : workload = BASELINE.json configs[2] "Register, N=252 hypotheses, 640x480, single MI355X, fp16".
   N > 1  : one process per GPU (torch.distributed.run), the SAME workload strong-scaled -- BASELINE.json's metric is "Register
            N=252 ... at 1/2/4/8 GPUs": the 252 hypotheses are sharded in contiguous slices of ceil(252/N) per GPU, ONE RCCL
-           all-gather of one row per hypothesis [pooled score feature 512 | pose 16] f32, then every rank runs the
-           cross-hypothesis attention + arg-max redundantly.  The line also carries `n1008` = BASELINE configs[3] (1008
+           all-gather of one row per hypothesis [pooled score feature 512 | pose 16] f32 -- issued by the LIBRARY on its own
+           stream (fp_register_sharded; torch.distributed only broadcasts the ncclUniqueId and is the fall-back exchange) --
+           then every rank runs the cross-hypothesis attention + arg-max redundantly.  The line also carries `n1008` = BASELINE configs[3] (1008
            hypotheses sharded the same way).  `--weak` keeps 252 hypotheses PER GPU (252*N in total) instead; `--hyps M` picks
            any total.
   Extra legs of the default N = 1 run (outside the headline's timed region, a few steps each, every one with its own roofline):
-           `host_frame`, `track` (incl. pipelined / batched serving), `track_bf16` (configs[1]), `fp8_720p` and
-           `fp8_720p_untextured` (configs[4]: 1280x720, e4m3 trunk convolutions, activation scales calibrated on the bench frame).
+           `host_frame`, `track` (incl. pipelined / batched serving), `track_bf16` (configs[1]), and configs[4] at 1280x720 in both
+           8-bit precisions: `int8_720p`, `int8_720p_untextured`, `fp8_720p`, `fp8_720p_untextured` (8-bit trunk convolutions,
+           calibrated on the bench frame, DISCRIMINATING synthetic weights) -- each with an `accuracy` object: refined-pose deltas
+           against the f16 path, winner, teacher-forced rank, whether the 1 deg / 1 mm bar is met for >= 95 % of the hypotheses.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
   roofline     -- dominant kernel (the conv/linear implicit-GEMM kernel with the largest share of the step, MFMA-bound):
