@@ -1856,13 +1856,19 @@ int fp_set_calibration_blob(fp_model *m, const void *blob, size_t bytes) try {
   std::memcpy(hdr, p, 16); p += 16;
   FP_CHECK(hdr[0] == kCalibMagic && hdr[1] == 1u && (hdr[2] == (uint32_t)PREC_FP8 || hdr[2] == (uint32_t)PREC_INT8), "[FoundationPose] not a calibration record of this library version");
   const int precision = (int)hdr[2];
+  {   // every float of the record must be finite (and the |max| values non-negative) BEFORE anything of the model is touched
+    std::vector<float> tmp(kCalibFloats);   // (the caller's buffer need not be aligned)
+    std::memcpy(tmp.data(), p, kCalibFloats * sizeof(float));
+    const float *f = tmp.data();
+    for (size_t i = 0; i < kCalibFloats; i++) FP_CHECK(std::isfinite(f[i]), "[FoundationPose] calibration record holds non-finite values");
+    for (size_t i = 0; i < (size_t)2 * 15 * 512; i++) FP_CHECK(f[i] >= 0.f, "[FoundationPose] calibration record holds a negative |max|");
+  }
   FP_HIP_OK(hipStreamSynchronize(m->stream));
-  for (int k = 0; k < 2; k++) { m->calib_amax[k].assign((const float *)p, (const float *)p + 15 * 512); p += 15 * 512 * 4; }
-  for (int k = 0; k < 2; k++) { m->calib_bias_fix[precision][k].assign((const float *)p, (const float *)p + 13 * 512); p += 13 * 512 * 4; }
-  for (int k = 0; k < 2; k++) { m->calib_tok_fix[precision][k].assign((const float *)p, (const float *)p + 512); p += 512 * 4; }
-  for (int k = 0; k < 2; k++) { const size_t n = k == 0 ? 8 : 512; m->calib_out_fix[precision][k].assign((const float *)p, (const float *)p + n); p += n * 4; }
-  for (int k = 0; k < 2; k++)
-    for (float v : m->calib_amax[k]) FP_CHECK(std::isfinite(v) && v >= 0.f, "[FoundationPose] calibration record holds non-finite values");
+  auto take = [&](std::vector<float> &dst, size_t n) { dst.resize(n); std::memcpy(dst.data(), p, n * 4); p += n * 4; };
+  for (int k = 0; k < 2; k++) take(m->calib_amax[k], 15 * 512);
+  for (int k = 0; k < 2; k++) take(m->calib_bias_fix[precision][k], 13 * 512);
+  for (int k = 0; k < 2; k++) take(m->calib_tok_fix[precision][k], 512);
+  for (int k = 0; k < 2; k++) take(m->calib_out_fix[precision][k], k == 0 ? 8 : 512);
   m->calibrated = true;
   Net *loaded[2] = {m->refiner_p[precision], m->scorer_p[precision]};
   for (int k = 0; k < 2; k++)
