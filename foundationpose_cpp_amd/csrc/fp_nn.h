@@ -11,7 +11,9 @@ namespace fp {
 // 8-bit values stored with an offset of -128).  Output-type codes of the convolution kernels additionally use DT_DUAL_FP8 /
 // DT_DUAL_I8: an f16 tensor (the residual stream) AND its 8-bit copy (the next convolution's operand) written by one epilogue.
 // DT_QS_*: the 8-bit copy ALONE, scaled in the epilogue (a layer with a residual whose f16 output nobody reads).
-enum { DT_F16 = 0, DT_BF16 = 1, DT_FP8 = 2, DT_I8 = 3, DT_DUAL_FP8 = 4, DT_DUAL_I8 = 5, DT_QS_FP8 = 6, DT_QS_I8 = 7 };
+// DT_QSR_I8 / DT_F16RQ_I8: the residual operand is the 8-bit stream copy itself (INT8 networks: no f16 stream at all); output = the
+// scaled 8-bit copy alone / an f16 tensor (the token tensor).
+enum { DT_F16 = 0, DT_BF16 = 1, DT_FP8 = 2, DT_I8 = 3, DT_DUAL_FP8 = 4, DT_DUAL_I8 = 5, DT_QS_FP8 = 6, DT_QS_I8 = 7, DT_QSR_I8 = 8, DT_F16RQ_I8 = 9 };
 // network precision (include/foundationpose_amd.h FP_PREC_*): F16 = the reference's TensorRT --fp16 engines; BF16 = every
 // tensor and MFMA operand in bf16 (BASELINE configs[1]); FP8 = the 3x3 trunk convolutions from encodeA.2 on in OCP e4m3
 // with per-channel weight / activation scales, everything else f16 (BASELINE configs[4]); INT8 = the same layers on 8-bit
