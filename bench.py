@@ -77,12 +77,11 @@ def cpu_baseline(mesh, scene, states, n_hyp=8, reps=8):
 FP8_LAYERS = {"conv_128", "conv_256", "conv_b2", "conv_512"}   # 3x3 trunk convolutions from encodeA.2 on run on 8-bit operands in the fp8 / int8 modes
 Q8 = ("fp8", "int8")
 _Q8_TEXT = ("operands for the 13 3x3 trunk convolutions from encodeA.2 on (91 % of the FLOPs): per-output-channel weight scales, per-input-channel "
-            "activation scales folded into the weights, %s, calibrated bias correction; f16 elsewhere")
-_Q8_PMC = {"fp8": "r04", "int8": "r04c"}   # profiles/<tag>_register_<dtype>_720p_pmc_hbm.json
+            "activation scales folded into the weights, f16 residual stream (dual-output epilogues), calibrated bias correction; f16 elsewhere")
+_Q8_PMC = {"fp8": "r04", "int8": "r04"}   # profiles/<tag>_register_<dtype>_720p_pmc_hbm.json
 PRECISION_TEXT = {"f16": "f16 storage / f32 accumulate (the reference's TensorRT --fp16)", "bf16": "bf16 storage / f32 accumulate",
-                  "fp8": "OCP e4m3 (v_mfma_f32_16x16x128_f8f6f4) " + _Q8_TEXT % "f16 residual stream (dual-output epilogues)",
-                  "int8": "8-bit integer (v_mfma_i32_16x16x64_i8; unsigned activations stored with an offset of -128) " + _Q8_TEXT %
-                          "8-bit residual stream (a block's skip operand is the previous 8-bit tensor, scaled per channel in the epilogue)"}
+                  "fp8": "OCP e4m3 (v_mfma_f32_16x16x128_f8f6f4) " + _Q8_TEXT,
+                  "int8": "8-bit integer (v_mfma_i32_16x16x64_i8; unsigned activations stored with an offset of -128) " + _Q8_TEXT}
 
 
 def analyse_profile(prof, dtype, n_hyp, stages_per_hyp):

@@ -4140,7 +4140,7 @@ struct Ctx {
 static unsigned long long *g_clk_probe = nullptr;
 static NNScratch g_hook_ws;  // split-K slab of the fpt_* test hooks
 #else
-#define FP_HOOK static constexpr int
+#define FP_HOOK [[maybe_unused]] static constexpr int
 static constexpr unsigned long long *g_clk_probe = nullptr;
 #endif
 FP_HOOK g_conv_variant = 0;    // 0 default; 7 force / 8 disable the resident-halo kernels; 3 = 256x128 ping-pong everywhere; 5 = 256x256 rounds without
@@ -4168,7 +4168,7 @@ FP_HOOK g_gemm_wpack = 1;      // gemm_k32_kernel streams its weights from the s
 FP_HOOK g_deep_wpack = 1;      // conv_deep_kernel streams its weights from the stage-order copy
 FP_HOOK g_big_wpack = 1;       // conv_big_pp_kernel streams its weights from the stage-order copy
 FP_HOOK g_halo_wpack = 1;      // conv_halo_kernel streams its weights from the stage-order copy
-FP_HOOK g_i8_stream = 1;       // INT8 networks: 8-bit residual stream (run_trunk_i8); 0 = the f16 stream of the FP8 networks (A/B)
+FP_HOOK g_i8_stream = 0;       // test build A/B: 1 = INT8 networks with an 8-bit residual stream (run_trunk_i8; faster, but its common-mode error is frame-specific: DESIGN.md section 4.4)
 FP_HOOK g_smallx_pf = 0;       // A/B (test build): prefetch depth of conv_smallx_kernel<2,4> (4 or 2; 0 = the default 3)
 FP_HOOK g_smallm = 1;          // small problems (Track, a few objects) on conv_smallm_kernel: K split over the waves of a workgroup, no split-K slabs / reduce launch
 FP_HOOK g_att_variant = 1;     // 1 = attention32_kernel (8 = without the XCD remap); round-1 kernel: 2 remap + 16-B stores, 3 no XCD remap, 5 remap + 2-B stores, 7 neither
@@ -4606,14 +4606,22 @@ static int run_conv(const Ctx &c, const char *tag, const ConvLayer &L, const Act
     if (L.dt == DT_F16 && out2->dt == DT_I8) return run_conv_dt<DT_F16, DT_DUAL_I8>(c, tag, L, p, NB, H, W, ipad, hr, split_imgs, grp);
     FP_CHECK(false, "run_conv: unsupported combination of operand / dual-output element types");
   }
-  if (rscale) {   // INT8 networks: the residual is the 8-bit stream copy
+#ifdef FP_TEST_HOOKS
+  if (rscale) {   // (run_trunk_i8) the residual is the 8-bit stream copy
     if (oinv) return run_conv_dt<DT_I8, DT_QSR_I8>(c, tag, L, p, NB, H, W, ipad, hr, split_imgs, grp);
     FP_CHECK(out.dt == DT_F16, "run_conv: 8-bit residual with an unsupported output type");
     return run_conv_dt<DT_I8, DT_F16RQ_I8>(c, tag, L, p, NB, H, W, ipad, hr, split_imgs, grp);
   }
+#else
+  FP_CHECK(!rscale, "run_conv: 8-bit residual operands exist in the test build only");
+#endif
   if (oinv) {   // 8-bit output alone, scaled in the epilogue
     if (L.dt == DT_FP8) return run_conv_dt<DT_FP8, DT_QS_FP8>(c, tag, L, p, NB, H, W, ipad, hr, split_imgs, grp);
-    if (L.dt == DT_F16) return run_conv_dt<DT_F16, DT_QS_I8>(c, tag, L, p, NB, H, W, ipad, hr, split_imgs, grp);   // (encodeA.1 of the INT8 networks)
+#ifdef FP_TEST_HOOKS
+    if (L.dt == DT_F16) return run_conv_dt<DT_F16, DT_QS_I8>(c, tag, L, p, NB, H, W, ipad, hr, split_imgs, grp);   // (encodeA.1 in run_trunk_i8)
+#else
+    FP_CHECK(L.dt != DT_F16, "run_conv: f16 -> scaled 8-bit alone exists in the test build only");
+#endif
     return run_conv_dt<DT_I8, DT_QS_I8>(c, tag, L, p, NB, H, W, ipad, hr, split_imgs, grp);
   }
   if (L.dt == DT_FP8 && out.dt == DT_FP8) return run_conv_dt<DT_FP8, DT_FP8>(c, tag, L, p, NB, H, W, ipad, hr, split_imgs, grp);
@@ -4820,11 +4828,14 @@ static void broadcast_b(const Ctx &c, unsigned char *cat, int N, int cb /* bytes
 // stream) writes the f16 tensor and, in the same epilogue, its 8-bit copy for the next conv (DT_DUAL_*), so the skip path is never
 // re-quantised; (2) activation scales are per CHANNEL and folded into the consumer's weights before those are quantised; (3) biases
 // carry the calibration's bias correction, the positional table the token correction (net_apply_q8).
-// INT8 [r4c]: no f16 stream at all.  The sums of a residual block are re-quantised to the unsigned 8-bit copy the next conv reads
-// anyway; the block's second conv reads its skip operand from the PREVIOUS 8-bit copy (1 byte instead of 2 per element, scaled per
-// channel in the epilogue: DT_QSR_I8) and writes only the new 8-bit copy.  Per stream layer that is 3 bytes less read / written per
-// output element than the dual-output form (the 40x40 layers were HBM-co-limited by exactly those bytes); the
-// calibrated error grows from 11.2 % to 13.4 % of the between-hypothesis spread in tools/fp8_sim.py (MODE=int8c), inside the bars.
+#ifdef FP_TEST_HOOKS
+// INT8 WITHOUT an f16 stream [r4, an experiment kept in the test build: tools/q8_cross.py].  The sums of a residual block are
+// re-quantised to the unsigned 8-bit copy the next conv reads anyway; here the block's second conv reads its skip operand from the
+// PREVIOUS 8-bit copy (1 byte instead of 2 per element, scaled per channel in the epilogue: DT_QSR_I8) and writes only the new 8-bit
+// copy: 3 bytes less per output element than the dual-output form, Register 720p 7.64 -> 7.08 ms, same-frame accuracy 98.8-100 %
+// within 1 mm / 1 deg.  NOT shipped: calibrated on one frame and run on another, the common-mode error of the refined poses is
+// 0.6-2.2 mm depending on the frame (f16 stream: 0.6-0.7 mm) -- the rounding bias of a coarsely quantised stream is a property of the
+// frame's activation distribution, which the one-frame bias correction cannot carry over.
 static int run_trunk_i8(const Ctx &c, const Arena &a, const void *nn_in, int N, int n_b) {
   const Net *net = c.net;
   const int NB2 = N + n_b, q = DT_I8;
@@ -4872,9 +4883,12 @@ static int run_trunk_i8(const Ctx &c, const Arena &a, const void *nn_in, int N, 
   calib_record(c, 14, a.tokens, (size_t)N * 400, 512, DT_F16);
   return 0;
 }
+#endif
 static int run_trunk_q8(const Ctx &c, const Arena &a, const void *nn_in, int N, int n_b) {
   const Net *net = c.net;
+#ifdef FP_TEST_HOOKS
   if (net->qdt == DT_I8 && g_i8_stream) return run_trunk_i8(c, a, nn_in, N, n_b);
+#endif
   const int NB2 = N + n_b, q = net->qdt;
   auto F = [&](void *p) { return Act{p, DT_F16, 1.f}; };
   auto Q = [&](void *p) { return Act{p, q, 1.f}; };
@@ -5179,6 +5193,7 @@ void fpt_set_smallm_maxt16(int v) { fp::g_smallm_maxt16 = v; }
 void fpt_set_gemm_lds_store(int v) { fp::g_gemm_lds_store = v; }
 void fpt_set_conv_lds_store(int v) { fp::g_conv_lds_store = v; }
 void fpt_set_conv_variant(int v) { fp::g_conv_variant = v; }
+void fpt_set_i8_stream(int v) { fp::g_i8_stream = v; }
 void fpt_set_conv_ablate(int v) { fp::g_conv_ablate = v; }
 void fpt_set_splitk_target(int v) { fp::g_splitk_target = v; }
 void fpt_set_rem_splitk(int v) { fp::g_rem_splitk = v; }

@@ -479,31 +479,36 @@ def test_int8_calibration_carries_over_to_another_frame(disc_nets, syn_mesh):
     """The calibration is a property of the deployment, not of the frame: calibrate INT8 on ONE scene (object at 0.70 m, rotation seed 1),
     then Register a DIFFERENT scene (object elsewhere, another rotation, its own noise) without re-calibrating -- refined poses against
     the f16 path on that second scene.  (Every other 8-bit test and the bench legs calibrate on the frame they then measure: scales,
-    bias / token / output corrections were all derived from it.)  Measured: 84.5 % within 1 mm / 1 deg (same frame: 99.6-100 %), p95 1.13 mm /
-    0.33 deg, worst 1.38 mm, winner = teacher-forced rank 1, score correlation 0.986 -- the common-mode part of the correction is
-    frame-specific; the bar here is the cross-frame level, the same-frame tests hold the 95 % bar."""
+    bias / token / output corrections were all derived from it.)  Measured: 82-90 % within 1 mm / 1 deg on two other scenes (same frame:
+    99.2-100 %), p95 1.1-1.2 mm / 0.25-0.35 deg, worst 1.4 mm, common-mode shift 0.6-0.7 mm, score correlation 0.986-0.994 -- the common-mode
+    part of the correction is frame-specific; the bar here is the cross-frame level, the same-frame tests hold the 95 % bar.  (The variant
+    with an 8-bit residual stream, tools/q8_cross.py, lands anywhere between 0 % and 83 % here and was not shipped for that reason.)"""
     s1 = syn.make_scene(syn_mesh)
-    s2 = syn.make_scene(syn_mesh, t=(-0.03, 0.02, 0.62), rot_seed=9)
+    others = [syn.make_scene(syn_mesh, t=(-0.03, 0.02, 0.62), rot_seed=9), syn.make_scene(syn_mesh, t=(0.04, -0.03, 0.80), rot_seed=4)]
     m = FoundationPose(syn_mesh, syn.intrinsics(), disc_nets[0], disc_nets[1])
     try:
         m.calibrate(s1.rgb, s1.depth, s1.mask, syn_mesh.name, FP_PREC_INT8)
-        ok, p16, idx16, sc16, ref16, _ = m.register_detailed(s2.rgb, s2.depth, s2.mask, syn_mesh.name)
-        assert ok, m.last_error
-        m.set_precision(FP_PREC_INT8)
-        ok, p8, idx8, sc8, ref8, _ = m.register_detailed(s2.rgb, s2.depth, s2.mask, syn_mesh.name)
-        assert ok, m.last_error
-        dmm = np.linalg.norm(ref8[:, :3, 3] - ref16[:, :3, 3], axis=1) * 1e3
-        ddeg = _rot_deg(ref8, ref16)
-        frac = float(np.mean((dmm < 1.0) & (ddeg < 1.0)))
-        m.set_precision(FP_PREC_F16)
-        m.upload_frame(s2.rgb, s2.depth)
-        sc_tf = m.scorer_infer(*m.render_and_transform(syn_mesh.name, ref8, 1.1))
-        rank = int((sc_tf > sc_tf[idx8]).sum())
-        regret = float((sc_tf.max() - sc_tf[idx8]) / (sc_tf.max() - np.median(sc_tf)))
-        print(f"INT8 calibrated on scene 1, measured on scene 2: mm p95 {np.percentile(dmm, 95):.3f} max {dmm.max():.3f}, deg p95 {np.percentile(ddeg, 95):.3f} "
-              f"max {ddeg.max():.3f}; within 1 mm / 1 deg: {frac * 100:.1f} %; teacher-forced rank of the winner {rank} (regret {regret:.4f}); score corr {np.corrcoef(sc8, sc_tf)[0, 1]:.4f}")
-        assert frac >= 0.75 and np.percentile(dmm, 95) < 1.5 and dmm.max() < 2.0 and np.percentile(ddeg, 95) < 1.0, (frac, np.percentile(dmm, 95))
-        assert rank < 13 and regret < 0.08 and np.corrcoef(sc8, sc_tf)[0, 1] > 0.95, (rank, regret)
+        for k, s2 in enumerate(others):
+            m.set_precision(FP_PREC_F16)
+            ok, p16, idx16, sc16, ref16, _ = m.register_detailed(s2.rgb, s2.depth, s2.mask, syn_mesh.name)
+            assert ok, m.last_error
+            m.set_precision(FP_PREC_INT8)
+            ok, p8, idx8, sc8, ref8, _ = m.register_detailed(s2.rgb, s2.depth, s2.mask, syn_mesh.name)
+            assert ok, m.last_error
+            dmm = np.linalg.norm(ref8[:, :3, 3] - ref16[:, :3, 3], axis=1) * 1e3
+            ddeg = _rot_deg(ref8, ref16)
+            frac = float(np.mean((dmm < 1.0) & (ddeg < 1.0)))
+            cm = float(np.linalg.norm((ref8[:, :3, 3] - ref16[:, :3, 3]).mean(0)) * 1e3)
+            m.set_precision(FP_PREC_F16)
+            m.upload_frame(s2.rgb, s2.depth)
+            sc_tf = m.scorer_infer(*m.render_and_transform(syn_mesh.name, ref8, 1.1))
+            rank = int((sc_tf > sc_tf[idx8]).sum())
+            regret = float((sc_tf.max() - sc_tf[idx8]) / (sc_tf.max() - np.median(sc_tf)))
+            print(f"INT8 calibrated on scene 1, measured on other scene {k + 1}: mm p95 {np.percentile(dmm, 95):.3f} max {dmm.max():.3f} (common-mode {cm:.3f}), "
+                  f"deg p95 {np.percentile(ddeg, 95):.3f} max {ddeg.max():.3f}; within 1 mm / 1 deg: {frac * 100:.1f} %; teacher-forced rank of the winner {rank} "
+                  f"(regret {regret:.4f}); score corr {np.corrcoef(sc8, sc_tf)[0, 1]:.4f}")
+            assert frac >= 0.70 and np.percentile(dmm, 95) < 1.5 and dmm.max() < 2.0 and np.percentile(ddeg, 95) < 1.0 and cm < 1.0, (frac, np.percentile(dmm, 95), cm)
+            assert rank < 13 and regret < 0.08 and np.corrcoef(sc8, sc_tf)[0, 1] > 0.95, (rank, regret)
     finally:
         m.close()
 
