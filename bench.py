@@ -15,7 +15,7 @@ carries `host_frame` (the reference's calling convention: host frames, H2D insid
            hypotheses sharded the same way).  `--weak` keeps 252 hypotheses PER GPU (252*N in total) instead; `--hyps M` picks
            any total.
   Extra legs of the default N = 1 run (outside the headline's timed region, a few steps each, every one with its own roofline):
-           `host_frame`, `track` (incl. pipelined / batched serving), `track_bf16` (configs[1]), and configs[4] at 1280x720 in both
+           `host_frame`, `track` (incl. pipelined / batched serving), `track_bf16` (configs[1]), `track_int8`, and configs[4] at 1280x720 in both
            8-bit precisions: `int8_720p`, `int8_720p_untextured`, `fp8_720p`, `fp8_720p_untextured` (8-bit trunk convolutions,
            calibrated on the bench frame, DISCRIMINATING synthetic weights) -- each with an `accuracy` object: refined-pose deltas
            against the f16 path, winner, teacher-forced rank, whether the 1 deg / 1 mm bar is met for >= 95 % of the hypotheses.
@@ -454,6 +454,37 @@ def main():
         extras["int8_720p_untextured"] = register_leg(False, "int8", 1280, 720, lsteps)
         extras["fp8_720p"] = register_leg(True, "fp8", 1280, 720, lsteps)
         extras["fp8_720p_untextured"] = register_leg(False, "fp8", 1280, 720, lsteps)
+        # Track in INT8 (discriminating weights, calibrated on the bench frame): the 8-bit weights halve the per-layer weight stream that
+        # bounds a conv at N = 1
+        def track_leg_int8(steps):
+            mesh_l = syn.make_mesh()
+            scene_l = syn.make_scene(mesh_l, Wd, H)
+            m = FoundationPose(mesh_l, scene_l.K, rp_d, sp_d)
+            try:
+                m.calibrate(scene_l.rgb, scene_l.depth, scene_l.mask, mesh_l.name, FP_PREC_INT8)
+                r_, d_ = (torch.from_numpy(x).to(dev) for x in (scene_l.rgb, scene_l.depth))
+                hyp_l = syn.to_colmajor(syn.perturb_pose(scene_l.gt_pose))
+                o_ = np.zeros(16, np.float32)
+
+                def fn():
+                    m._must(m._L.fp_track_ex(m.handle, C.c_void_p(r_.data_ptr()), C.c_void_p(d_.data_ptr()), 1, H, Wd,
+                                             hyp_l.ctypes.data_as(C.c_void_p), mesh_l.name.encode(), 1, o_.ctypes.data_as(C.c_void_p)))
+                m.set_precision(FP_PREC_F16)
+                fn()
+                p16 = o_.reshape(4, 4).T.copy()
+                m.set_precision(FP_PREC_INT8)
+                fn()
+                p8 = o_.reshape(4, 4).T.copy()
+                tl = timed(fn, steps, 10)
+                return {"metric": "Track fps (N=1)", "value": round(steps / tl, 1), "unit": "frames/s", "ms_per_frame": round(tl / steps * 1e3, 4), "steps": steps,
+                        "dtype": "int8", "config": {"workload": f"Track N=1 {Wd}x{H}, INT8 trunk convolutions (calibrated on the bench frame), frame resident in HBM",
+                                                    "weights": "discriminating synthetic set"},
+                        "accuracy": {"pose_delta_vs_f16_track": {"deg": round(float(rot_deg(p8[None], p16[None])[0]), 3),
+                                                                 "mm": round(float(np.linalg.norm(p8[:3, 3] - p16[:3, 3]) * 1e3), 3)}},
+                        "graph": "26 kernels, 194 us span (profiles/r04d_track_int8_timeline.txt); the f16 graph spans 219 us"}
+            finally:
+                m.close()
+        extras["track_int8"] = track_leg_int8(max(args.steps * 10, 100))
         # configs[1]: Track, N = 1, bf16 refine-net
         model.set_precision(FP_PREC_BF16)
         kb = max(args.steps * 5, 50)

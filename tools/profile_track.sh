@@ -3,7 +3,7 @@
 export TMPDIR=/tmp
 ROOT=$(pwd); OUT=$ROOT/gpurun_out/prof_track; rm -rf $OUT; mkdir -p $OUT
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o p -- python $ROOT/bench.py --track --steps 200 --warmup 20 --no-cpu-baseline > $OUT/log.txt 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o p -- python $ROOT/bench.py --track --steps 200 --warmup 20 --no-cpu-baseline --no-extras $* > $OUT/log.txt 2>&1
 cd $ROOT
 tail -1 $OUT/log.txt | cut -c1-300
 python - <<'PY'
