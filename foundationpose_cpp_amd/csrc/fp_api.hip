@@ -11,6 +11,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <dlfcn.h>
 #include <link.h>
@@ -397,7 +398,8 @@ struct fp_model {
   std::vector<float> calib_out_mean[2];          // means of the f16 networks' outputs on the calibration frame (same shapes)
   // pinned staging for hypothesis poses: Register returns from its asynchronous section while the H2D copy may still be
   // queued, so the source must outlive the call (a local std::vector did not: found by the two-model serving test)
-  float *track_io = nullptr, *track_io_dev = nullptr;  // host-pinned [hypothesis 16 | refined pose 16] of Track and its device address
+  float *track_io = nullptr, *track_io_dev = nullptr;  // host-pinned [hypothesis 16 | refined pose 16 | done flag] of Track and its device address
+  bool track_flag_armed = false;   // the submitted Track ends in the kernel that raises the done flag (fp_track_wait polls it)
   float *poses_pinned = nullptr;
   int poses_pinned_cap = 0;
   unsigned long long *digests = nullptr;  // [16] device, debug checkpoints (null = off)
@@ -1208,7 +1210,8 @@ int fp_argmax(fp_model *m, const float *scores, int N, int *index_out) try {
 // shared_b: all N poses have the same translation (fresh sampler output), so the observed crop -- which depends only on
 // the translation (foundationpose_render.cpp:59, foundationpose_render.cu:78-80) -- is computed and encoded once.
 // poses_in / result_out (Track): the poses are read from / the refined poses also written to host-pinned memory
-static int refine_iteration(fp_model *m, Target *t, int N, bool shared_b, const float *poses_in = nullptr, float *result_out = nullptr) {
+static int refine_iteration(fp_model *m, Target *t, int N, bool shared_b, const float *poses_in = nullptr, float *result_out = nullptr,
+                            unsigned *done_flag = nullptr) {
   RoctxRange range("refine_iteration (render + crop @1.2, refine-net, pose update)");
   const size_t half = (size_t)N * FP_NN_IN_IMG_HALFS;
   if (render_and_crop(m, t, N, 1.2f /* refine_mode_crop_ratio_ foundationpose.cpp:87 */, nn_mode(m), m->nn_in,
@@ -1220,7 +1223,7 @@ static int refine_iteration(fp_model *m, Target *t, int N, bool shared_b, const 
   checkpoint(m, 3, m->nn_in, (size_t)N * FP_NN_IN_IMG_HALFS * 2);
   checkpoint(m, 4, m->nn_in + half, (size_t)(shared_b ? 1 : N) * FP_NN_IN_IMG_HALFS * 2);
   // N == 1 (Track): the head kernel applies RefinePostProcess itself (one launch less); profiling / digests keep the stages apart
-  const PoseUpdateFuse fuse{m->poses_dev, t->mesh.diameter, poses_in, result_out};
+  const PoseUpdateFuse fuse{m->poses_dev, t->mesh.diameter, poses_in, result_out, done_flag};
   bool fused = false;
   if (refiner_forward(m->stream, &m->prof, m->refiner, m->ws, m->nn_in, N, m->trans_dev, m->rot_dev, shared_b ? 1 : 0,
                       (N == 1 && !m->prof.on && !m->digests) ? &fuse : nullptr, &fused))
@@ -1557,9 +1560,10 @@ static int track_submit_impl(fp_model *m, const void *rgb, const void *depth, in
   }
   if (upload_frame_async(m, rgb, depth, memspace, H, W, row0, row1, col0, col1)) return 1;
   if (!m->track_io) {
-    FP_HIP_OK(hipHostMalloc((void **)&m->track_io, 32 * sizeof(float), hipHostMallocDefault));
+    FP_HIP_OK(hipHostMalloc((void **)&m->track_io, 48 * sizeof(float), hipHostMallocCoherent));   // (fine-grained: the done flag is read while the graph is still running)
     FP_HIP_OK(hipHostGetDevicePointer((void **)&m->track_io_dev, m->track_io, 0));
   }
+  m->track_flag_armed = false;
   if (refine_itr <= 0) {  // no refinement requested: the hypothesis is the answer (the reference's loop runs zero times)
     std::memcpy(m->track_io + 16, hyp_pose, 64);
     m->track_pending = true;
@@ -1569,12 +1573,22 @@ static int track_submit_impl(fp_model *m, const void *rgb, const void *depth, in
   // the hypothesis goes in and the refined pose comes out through host-pinned memory the kernels address directly: no copy
   // kernels around the graph (two of the ~50 launches of a Track)
   std::memcpy(m->track_io, hyp_pose, 64);
+  // completion flag (own cache line of the pinned block): cleared here, raised by the last kernel after it stored the refined pose.
+  // Armed only when that kernel is the fused head + pose-update kernel (not while profiling / taking digests: separate stages there)
+  volatile unsigned *flag = reinterpret_cast<volatile unsigned *>(m->track_io + 32);
+  *flag = 0u;
+  const bool armed = !m->prof.on && !m->digests && refiner_fuses_pose(m->refiner);
   if (run_graphed(m, m->tg, t, H, W, refine_itr, 1, graphable, [&]() {
-        for (int it = 0; it < refine_itr; it++)
-          if (refine_iteration(m, t, 1, false, it == 0 ? m->track_io_dev : nullptr, it == refine_itr - 1 ? m->track_io_dev + 16 : nullptr)) return 1;
+        for (int it = 0; it < refine_itr; it++) {
+          const bool last = it == refine_itr - 1;
+          if (refine_iteration(m, t, 1, false, it == 0 ? m->track_io_dev : nullptr, last ? m->track_io_dev + 16 : nullptr,
+                               last ? reinterpret_cast<unsigned *>(m->track_io_dev + 32) : nullptr))
+            return 1;
+        }
         return 0;
       }))
     return 1;
+  m->track_flag_armed = armed;
   m->track_pending = true;
   return 0;
 }
@@ -1593,6 +1607,24 @@ int fp_track_wait(fp_model *m, float out_pose[16]) try {
   FP_CHECK(m && out_pose, "[FoundationPose] fp_track_wait: invalid arguments");
   FP_CHECK(m->track_pending, "[FoundationPose] fp_track_wait: nothing was submitted");
   m->track_pending = false;
+  if (m->track_flag_armed) {
+    // the last kernel of the Track raises a flag in host-pinned memory right after it stored the pose there: poll that instead of the
+    // stream (later work on the model's stream is ordered behind the graph anyway).  Bounded: a fault, or a graph captured under
+    // other settings, falls through to the stream wait, which also reports the error.
+    m->track_flag_armed = false;
+    volatile unsigned *flag = reinterpret_cast<volatile unsigned *>(m->track_io + 32);
+    const auto t0 = std::chrono::steady_clock::now();
+    unsigned spins = 0;
+    while (*flag == 0u) {
+      __builtin_ia32_pause();
+      if ((++spins & 1023u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) break;
+    }
+    if (*flag != 0u) {
+      std::atomic_thread_fence(std::memory_order_acquire);
+      std::memcpy(out_pose, m->track_io + 16, 64);
+      return 0;
+    }
+  }
   FP_HIP_OK(hipStreamSynchronize(m->stream));
   std::memcpy(out_pose, m->track_io + 16, 64);
   return 0;

@@ -59,7 +59,9 @@ struct PoseUpdateFuse {
   float diameter;
   const float *poses_in;   // null = poses
   float *extra_out;        // optional second copy of the result
+  unsigned *done_flag;     // optional (host-pinned): set to 1, system scope, AFTER the result is stored -- fp_track_wait polls it
 };
+bool refiner_fuses_pose(const Net *net);   // N == 1: the head kernel applies RefinePostProcess itself (and raises done_flag)
 int refiner_forward(hipStream_t s, Profiler *prof, const Net *net, NNScratch *ws, const void *nn_in, int N,
                     float *trans_dev /*[N,3]*/, float *rot_dev /*[N,3]*/, int shared_b = 0, const PoseUpdateFuse *fuse = nullptr,
                     bool *fused_out = nullptr);

@@ -3327,7 +3327,12 @@ __global__ __launch_bounds__(384) void small_linear2_pose_kernel(const SmallLine
     out[wv] = y;
   }
   __syncthreads();
-  if (threadIdx.x == 0) pose_update_one(f.poses, out, out + 3, 0, f.diameter, f.poses_in ? f.poses_in : f.poses, f.extra_out);
+  if (threadIdx.x == 0) {
+    pose_update_one(f.poses, out, out + 3, 0, f.diameter, f.poses_in ? f.poses_in : f.poses, f.extra_out);
+    // Track's completion signal: the refined pose above went to host-pinned memory; release it to the host and raise the flag the
+    // waiting thread polls (an end-of-graph hipStreamSynchronize costs the host ~10 us more than this store takes to arrive)
+    if (f.done_flag) __hip_atomic_store(f.done_flag, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 }
 
 __global__ void broadcast_b_kernel(unsigned char *__restrict__ cat, int N, int HP, int WP, int H, int W, int pad, int CB) {
@@ -4993,6 +4998,9 @@ static int run_trunk(const Ctx &c, const Arena &a, const void *nn_in, int N, int
   return 0;
 }
 
+bool refiner_fuses_pose(const Net *net) {
+  return net && !net->scorer && g_grouped_heads && g_fuse_pose && net->trans.head.out == 3 && net->rot.head.out == 3;
+}
 int refiner_forward(hipStream_t s, Profiler *prof, const Net *net, NNScratch *ws, const void *nn_in, int N,
                     float *trans_dev, float *rot_dev, int shared_b, const PoseUpdateFuse *fuse, bool *fused_out) {
   if (fused_out) *fused_out = false;
