@@ -2669,7 +2669,7 @@ __global__ __launch_bounds__(ATT_QROWS * 4, 2) void attention_kernel(const typen
 //     transpose read): [32 keys][16 d] sub-tiles of 1 KB (+32 B so the staging writes of one instruction spread over all
 //     banks), a 16-lane group reads one [4 keys][16 d] block = 128 contiguous bytes;
 //   * K rows (256 B) are XOR-swizzled by 16-byte slot (slot ^= key & 15): conflict-free staging writes and fragment reads;
-//   * two LDS buffers, ONE barrier per key block: tile kb+1 is written (from registers loaded two iterations earlier) while
+//   * two LDS buffers, ONE barrier per key block: tile kb+1 is written (from registers loaded three iterations earlier [r4]) while
 //     tile kb is consumed, the global loads of tiles kb+2 / kb+3 are in flight (two register sets);
 //   * all K fragments of a block are requested at once, all V^T fragments right after the QK MFMAs so their latency runs under the
 //     softmax (asm reads + one explicit wait: hipcc otherwise sinks each read to its first use); the cross-row max / sum use
@@ -2740,17 +2740,28 @@ __global__ __launch_bounds__(NW * 64, 2) void attention32_kernel(const typename 
 
   // staging: thread -> (key = idx >> 4, 16-byte chunk = idx & 15), idx = tid + 256 j: coalesced 256-byte rows
   const int nkb = (T + 31) / 32;
-  // two register sets: tile kb+1 (written to LDS during block kb) and tile kb+2 (in flight for a whole block longer)
-  i4 kreg[2][NJ], vreg[2][NJ];
+  // three register sets: tile kb+1 (written to LDS during block kb), tiles kb+2 and kb+3 in flight -- a tile's loads have three blocks
+  // to arrive (with two sets the staging-only pipeline and the compute-only pipeline added up: tools/bench_attn.py V=17,30)
+  i4 kreg[3][NJ], vreg[3][NJ];
   auto load_tile = [&](int kb, i4 (&kr)[NJ], i4 (&vr)[NJ]) {
 #pragma unroll
     for (int j = 0; j < NJ; j++) {
       const int idx = tid + j * (NW * 64);
       const int row = min(kb * 32 + (idx >> 4), T - 1);
       const E *src = base + (size_t)row * rowstride + (idx & 15) * 8;
-      kr[j] = *reinterpret_cast<const i4 *>(src + EMBED);
-      vr[j] = *reinterpret_cast<const i4 *>(src + 2 * EMBED);
+      // asm loads: the compiler's own vmcnt bookkeeping collapses to vmcnt(0) at the joins of this loop (every store_tile then waited
+      // for the tile requested one block earlier); the waits are counted by hand in wait_tile
+      asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(kr[j]) : "v"(src), "n"(EMBED * (int)sizeof(E)));
+      asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(vr[j]) : "v"(src), "n"(2 * EMBED * (int)sizeof(E)));
     }
+  };
+  // the set's 2 NJ loads have landed when at most `newer` younger loads are outstanding (vmcnt retires in order)
+  auto wait_tile = [&](int newer_tiles, i4 (&kr)[NJ], i4 (&vr)[NJ]) {
+    if (newer_tiles >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * NJ) : "memory");
+    else if (newer_tiles == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NJ) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int j = 0; j < NJ; j++) asm volatile("" : "+v"(kr[j]), "+v"(vr[j]));
   };
   auto store_tile = [&](int buf, const i4 (&kr)[NJ], const i4 (&vr)[NJ]) {
     unsigned char *sb = smem + buf * BUF;
@@ -2763,9 +2774,17 @@ __global__ __launch_bounds__(NW * 64, 2) void attention32_kernel(const typename 
     }
   };
   load_tile(0, kreg[0], vreg[0]);
+  wait_tile(0, kreg[0], vreg[0]);
+#pragma unroll
+  for (int qi = 0; qi < 2; qi++)  // a use of Q the compiler sees: its own wait for these loads happens here, not in front of the MFMAs of every block
+#pragma unroll
+    for (int ds = 0; ds < 4; ds++) asm volatile("" : "+v"(qf[qi][ds]));
   store_tile(0, kreg[0], vreg[0]);
-  if (nkb > 1) load_tile(1, kreg[1], vreg[1]);   // odd tiles travel in set 1, even tiles in set 0
-  if (nkb > 2) load_tile(2, kreg[0], vreg[0]);
+  if (!(ABL & 1)) {  // (loads nobody consumes would land in registers the compiler has already handed out again)
+    if (nkb > 1) load_tile(1, kreg[1], vreg[1]);   // tile t travels in set t % 3
+    if (nkb > 2) load_tile(2, kreg[2], vreg[2]);
+    if (nkb > 3) load_tile(3, kreg[0], vreg[0]);
+  }
   __syncthreads();
 
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
@@ -2774,7 +2793,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attention32_kernel(const typename 
   for (int ds = 0; ds < 4; ds++) koff[ds] = (unsigned)(li * 256 + (((ds * 4 + g) ^ li) << 4));
   const unsigned voff = (unsigned)((g * 4 + (li >> 2)) * 32 + (li & 3) * 8);
 
-  auto block = [&](const int kb, i4 (&kr)[NJ], i4 (&vr)[NJ]) {   // kr / vr hold tile kb+1 on entry, tile kb+3 on exit
+  auto block = [&](const int kb, i4 (&kr)[NJ], i4 (&vr)[NJ]) {   // kr / vr hold tile kb+1 on entry, tile kb+4 on exit
     f4 st[2][2];  // [query tile][key tile]: st[qi][kt][r] = S[key = kt*16 + g*4 + r][q = qi*16 + li]
     if (ABL & 8) {
 #pragma unroll
@@ -2819,8 +2838,11 @@ __global__ __launch_bounds__(NW * 64, 2) void attention32_kernel(const typename 
       if (ABL & 32) {
 #pragma unroll
         for (int j = 0; j < NJ; j++) asm volatile("" ::"v"(kr[j]), "v"(vr[j]));
-      } else store_tile((kb + 1) & 1, kr, vr);
-      if (kb + 3 < nkb && !(ABL & 16)) load_tile(kb + 3, kr, vr);
+      } else {
+        wait_tile(ABL & 16 ? 0 : min(2, nkb - 2 - kb), kr, vr);  // tiles kb+2, kb+3 (where they exist) were requested after this one
+        store_tile((kb + 1) & 1, kr, vr);
+      }
+      if (kb + 4 < nkb && !(ABL & 16)) load_tile(kb + 4, kr, vr);
     }
     if (active) {
       i4 pf[2];
@@ -2841,7 +2863,10 @@ __global__ __launch_bounds__(NW * 64, 2) void attention32_kernel(const typename 
         float mx = vmax_f32(vmax_f32(vmax_f32(st[qi][0][0], st[qi][0][1]), vmax_f32(st[qi][0][2], st[qi][0][3])),
                             vmax_f32(vmax_f32(st[qi][1][0], st[qi][1][1]), vmax_f32(st[qi][1][2], st[qi][1][3])));
         mx = rows_max(mx);
-        const float m_new = vmax_f32(m_run[qi], mx);
+        // lazy maximum [r4]: the reference point of the exponentials only moves when the block's maximum exceeds it by more than 2^8
+        // (p <= 256 is harmless in f16 / bf16, the sums are f32 and O / l use the same reference), so the 64-multiply rescale of
+        // O^T runs a few times per sequence instead of in most blocks
+        const float m_new = (mx * sl2e > m_run[qi] * sl2e + 8.0f) ? mx : m_run[qi];
         const float mc = m_new * sl2e;
         const float alpha = __builtin_amdgcn_exp2f(m_run[qi] * sl2e - mc);  // m_run = -inf on the first block -> 0
         float psum = 0.f;
@@ -2884,9 +2909,10 @@ __global__ __launch_bounds__(NW * 64, 2) void attention32_kernel(const typename 
     }
     __syncthreads();
   };
-  for (int kb = 0; kb < nkb; kb += 2) {
+  for (int kb = 0; kb < nkb; kb += 3) {
     block(kb, kreg[1], vreg[1]);
-    if (kb + 1 < nkb) block(kb + 1, kreg[0], vreg[0]);
+    if (kb + 1 < nkb) block(kb + 1, kreg[2], vreg[2]);
+    if (kb + 2 < nkb) block(kb + 2, kreg[0], vreg[0]);
   }
   if (!active) return;
   // O tile of the wave through LDS (both buffers are free now; 8 KB per wave) -> whole 256-byte rows
