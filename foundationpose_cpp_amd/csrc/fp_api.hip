@@ -391,8 +391,11 @@ struct fp_model {
   // calibration of the 8-bit precisions (fp_calibrate): [refiner, scorer] per-channel |max| / mean of the 15 trunk activations of
   // the f16 networks on the calibration frame ([15][512] each), and per 8-bit precision the solved corrections (bias [13][512], token
   // [512]); they are applied to a precision's networks when those are loaded / re-calibrated
-  std::vector<float> calib_amax[2], calib_mean[2];
-  bool calibrated = false;
+  std::vector<float> calib_amax[2], calib_mean[2];   // the statistics pass of the calibration in progress
+  // the |max| record each 8-bit precision was quantised with (empty = not calibrated).  Per precision: two precisions may have been
+  // calibrated on different frames, and a blob must carry the statistics ITS corrections were solved against
+  std::vector<float> calib_amax_q[N_PREC][2];
+  bool calibrated(int prec) const { return prec >= 0 && prec < N_PREC && !calib_amax_q[prec][0].empty(); }
   std::vector<float> calib_bias_fix[N_PREC][2], calib_tok_fix[N_PREC][2];
   std::vector<float> calib_out_fix[N_PREC][2];   // output-layer correction: refiner [8] (trans 3 | rot 3 | 0 0), scorer [512]
   std::vector<float> calib_out_mean[2];          // means of the f16 networks' outputs on the calibration frame (same shapes)
@@ -758,11 +761,11 @@ static int select_precision(fp_model *m, int prec) {
     m->scorer_p[prec] = net_load(m->scorer_path.c_str(), true, prec, &err);
     FP_CHECK(m->scorer_p[prec] != nullptr, "[FoundationPose] Failed to load scorer weights: " + err);
   }
-  if ((prec == PREC_FP8 || prec == PREC_INT8) && m->calibrated) {
+  if ((prec == PREC_FP8 || prec == PREC_INT8) && m->calibrated(prec)) {
     Net *nets[2] = {m->refiner_p[prec], m->scorer_p[prec]};
     for (int k = 0; k < 2; k++)
       if (nets[k] && !net_q8_ready(nets[k]) &&
-          net_apply_q8(nets[k], m->calib_amax[k].data(), m->calib_bias_fix[prec][k].empty() ? nullptr : m->calib_bias_fix[prec][k].data(),
+          net_apply_q8(nets[k], m->calib_amax_q[prec][k].data(), m->calib_bias_fix[prec][k].empty() ? nullptr : m->calib_bias_fix[prec][k].data(),
                        m->calib_tok_fix[prec][k].empty() ? nullptr : m->calib_tok_fix[prec][k].data(), true))
         return 1;
     for (int k = 0; k < 2; k++)
@@ -1422,7 +1425,11 @@ const RcclApi &rccl_api() {
     if (!loaded.empty()) h = dlopen(loaded.c_str(), RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
     for (const char *name : {"librccl.so.1", "librccl.so"}) if (!h) h = dlopen(name, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
     for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) if (!h) h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
-    if (!h) { a.why = std::string("cannot load librccl: ") + (dlerror() ? dlerror() : "?"); return a; }
+    if (!h) {
+      const char *why = dlerror();   // (one call: dlerror clears the message it returns)
+      a.why = std::string("cannot load librccl: ") + (why ? why : "?");
+      return a;
+    }
     a.all_gather = (nccl_allgather_fn)dlsym(h, "ncclAllGather");
     a.err = (nccl_errstr_fn)dlsym(h, "ncclGetErrorString");
     a.count = (nccl_count_fn)dlsym(h, "ncclCommCount");
@@ -1719,8 +1726,8 @@ int fp_set_precision(fp_model *m, int precision) try {
   FP_CHECK(m != nullptr, "[FoundationPose] null model");
   DeviceScope on_device(m->device);
   FP_HIP_OK(hipStreamSynchronize(m->stream));
-  FP_CHECK(!(precision == PREC_FP8 || precision == PREC_INT8) || m->calibrated,
-           "[FoundationPose] the 8-bit precisions need a calibration: call fp_calibrate / fp_calibrate_fp8 (or fp_set_calibration_blob) first");
+  FP_CHECK(!(precision == PREC_FP8 || precision == PREC_INT8) || m->calibrated(precision),
+           "[FoundationPose] an 8-bit precision needs its calibration: call fp_calibrate for it (or fp_set_calibration_blob with its record) first");
   return select_precision(m, precision);
 } FP_CATCH_INT
 int fp_get_precision(const fp_model *m) { return m ? m->prec : -1; }
@@ -1790,7 +1797,7 @@ static int calibrate_impl(fp_model *m, const void *rgb, const void *depth, const
   };
   if (registered(1, -1, m->calib_amax, m->calib_mean)) { (void)select_precision(m, (prev == PREC_FP8 || prev == PREC_INT8) ? PREC_F16 : prev); return 1; }
   if (output_means(m->calib_out_mean)) return 1;
-  m->calibrated = true;
+  for (int k = 0; k < 2; k++) m->calib_amax_q[precision][k] = m->calib_amax[k];
   // quantise (or re-quantise) this precision's networks without corrections
   for (int k = 0; k < 2; k++) {
     m->calib_bias_fix[precision][k].assign((size_t)13 * 512, 0.f); m->calib_tok_fix[precision][k].assign(512, 0.f);
@@ -1799,7 +1806,7 @@ static int calibrate_impl(fp_model *m, const void *rgb, const void *depth, const
   {
     Net *loaded[2] = {m->refiner_p[precision], m->scorer_p[precision]};
     for (int k = 0; k < 2; k++)
-      if (loaded[k] && (net_apply_q8(loaded[k], m->calib_amax[k].data(), m->calib_bias_fix[precision][k].data(), m->calib_tok_fix[precision][k].data(), true) ||
+      if (loaded[k] && (net_apply_q8(loaded[k], m->calib_amax_q[precision][k].data(), m->calib_bias_fix[precision][k].data(), m->calib_tok_fix[precision][k].data(), true) ||
                         net_q8_set_out_fix(loaded[k], m->calib_out_fix[precision][k].data()))) return 1;
   }
   if (select_precision(m, precision)) return 1;   // (loads and quantises them otherwise)
@@ -1821,13 +1828,13 @@ static int calibrate_impl(fp_model *m, const void *rgb, const void *depth, const
           const float got = a == 5 ? 0.5f * (mq[k][a * 512 + c] + mq[k][a * 512 + c + 128]) : mq[k][a * 512 + c];
           fix[(size_t)layer * 512 + c] += target(k, a, c) - got;
         }
-        if (net_apply_q8(qn[k], m->calib_amax[k].data(), fix.data(), m->calib_tok_fix[precision][k].data(), false)) return 1;
+        if (net_apply_q8(qn[k], m->calib_amax_q[precision][k].data(), fix.data(), m->calib_tok_fix[precision][k].data(), false)) return 1;
       }
     }
   if (registered(2, 14, nullptr, mq)) return 1;
   for (int k = 0; k < 2; k++) {
     for (int c = 0; c < 512; c++) m->calib_tok_fix[precision][k][c] = m->calib_mean[k][14 * 512 + c] - mq[k][14 * 512 + c];
-    if (net_apply_q8(qn[k], m->calib_amax[k].data(), m->calib_bias_fix[precision][k].data(), m->calib_tok_fix[precision][k].data(), false)) return 1;
+    if (net_apply_q8(qn[k], m->calib_amax_q[precision][k].data(), m->calib_bias_fix[precision][k].data(), m->calib_tok_fix[precision][k].data(), false)) return 1;
   }
   // 5. what is left at the OUTPUTS (the heads are non-linear in the token mean): the mean refiner outputs / pooled score feature of
   //    the 8-bit model on this frame are moved onto the f16 model's through the output layers' biases
@@ -1868,12 +1875,12 @@ static constexpr size_t kCalibFloats = (size_t)2 * 15 * 512 + (size_t)2 * 13 * 5
 size_t fp_calibration_size(void) { return 16 + kCalibFloats * sizeof(float); }
 int fp_get_calibration_blob(const fp_model *m, int precision, void *out, size_t capacity) try {
   FP_CHECK(m && out && (precision == PREC_FP8 || precision == PREC_INT8), "[FoundationPose] fp_get_calibration_blob: invalid arguments");
-  FP_CHECK(m->calibrated && !m->calib_bias_fix[precision][0].empty(), "[FoundationPose] no calibration available for this precision");
+  FP_CHECK(m->calibrated(precision) && !m->calib_bias_fix[precision][0].empty(), "[FoundationPose] no calibration available for this precision");
   FP_CHECK(capacity >= fp_calibration_size(), "[FoundationPose] fp_get_calibration_blob: buffer too small (fp_calibration_size)");
   uint32_t hdr[4] = {kCalibMagic, 1u, (uint32_t)precision, 0u};
   unsigned char *p = (unsigned char *)out;
   std::memcpy(p, hdr, 16); p += 16;
-  for (int k = 0; k < 2; k++) { std::memcpy(p, m->calib_amax[k].data(), 15 * 512 * 4); p += 15 * 512 * 4; }
+  for (int k = 0; k < 2; k++) { std::memcpy(p, m->calib_amax_q[precision][k].data(), 15 * 512 * 4); p += 15 * 512 * 4; }
   for (int k = 0; k < 2; k++) { std::memcpy(p, m->calib_bias_fix[precision][k].data(), 13 * 512 * 4); p += 13 * 512 * 4; }
   for (int k = 0; k < 2; k++) { std::memcpy(p, m->calib_tok_fix[precision][k].data(), 512 * 4); p += 512 * 4; }
   for (int k = 0; k < 2; k++) { const size_t n = k == 0 ? 8 : 512; std::memcpy(p, m->calib_out_fix[precision][k].data(), n * 4); p += n * 4; }
@@ -1897,25 +1904,25 @@ int fp_set_calibration_blob(fp_model *m, const void *blob, size_t bytes) try {
   }
   FP_HIP_OK(hipStreamSynchronize(m->stream));
   auto take = [&](std::vector<float> &dst, size_t n) { dst.resize(n); std::memcpy(dst.data(), p, n * 4); p += n * 4; };
-  for (int k = 0; k < 2; k++) take(m->calib_amax[k], 15 * 512);
+  for (int k = 0; k < 2; k++) take(m->calib_amax_q[precision][k], 15 * 512);
   for (int k = 0; k < 2; k++) take(m->calib_bias_fix[precision][k], 13 * 512);
   for (int k = 0; k < 2; k++) take(m->calib_tok_fix[precision][k], 512);
   for (int k = 0; k < 2; k++) take(m->calib_out_fix[precision][k], k == 0 ? 8 : 512);
-  m->calibrated = true;
   Net *loaded[2] = {m->refiner_p[precision], m->scorer_p[precision]};
   for (int k = 0; k < 2; k++)
-    if (loaded[k] && (net_apply_q8(loaded[k], m->calib_amax[k].data(), m->calib_bias_fix[precision][k].data(), m->calib_tok_fix[precision][k].data(), true) ||
+    if (loaded[k] && (net_apply_q8(loaded[k], m->calib_amax_q[precision][k].data(), m->calib_bias_fix[precision][k].data(), m->calib_tok_fix[precision][k].data(), true) ||
                       net_q8_set_out_fix(loaded[k], m->calib_out_fix[precision][k].data()))) return 1;
   invalidate_graphs(m);
   return 0;
 } FP_CATCH_INT
 // legacy per-tensor view (round 2/3 API): |max| over the channels of each trunk activation, [refiner 16 | scorer 16]
 int fp_get_calibration(const fp_model *m, float amax_out[32]) try {
-  FP_CHECK(m && m->calibrated && amax_out, "[FoundationPose] no calibration available");
+  FP_CHECK(m && amax_out && (m->calibrated(PREC_FP8) || m->calibrated(PREC_INT8)), "[FoundationPose] no calibration available");
+  const int pr = m->calibrated(PREC_FP8) ? PREC_FP8 : PREC_INT8;   // (the round-2 API knew FP8 only)
   for (int k = 0; k < 2; k++)
     for (int a = 0; a < 16; a++) {
       float v = 0.f;
-      if (a < 15) for (int c = 0; c < 512; c++) v = std::max(v, m->calib_amax[k][a * 512 + c]);
+      if (a < 15) for (int c = 0; c < 512; c++) v = std::max(v, m->calib_amax_q[pr][k][a * 512 + c]);
       amax_out[k * 16 + a] = v;
     }
   return 0;
@@ -1927,16 +1934,18 @@ int fp_set_calibration(fp_model *m, const float amax[32]) try {
   DeviceScope on_device(m->device);
   FP_HIP_OK(hipStreamSynchronize(m->stream));
   for (int k = 0; k < 2; k++) {
-    m->calib_amax[k].assign((size_t)15 * 512, 0.f);
+    std::vector<float> rec((size_t)15 * 512, 0.f);
     for (int a = 0; a < 15; a++)
-      for (int c = 0; c < 512; c++) m->calib_amax[k][a * 512 + c] = amax[k * 16 + a];
-    for (int pr : {PREC_FP8, PREC_INT8}) { m->calib_bias_fix[pr][k].assign((size_t)13 * 512, 0.f); m->calib_tok_fix[pr][k].assign(512, 0.f); m->calib_out_fix[pr][k].assign(k == 0 ? 8 : 512, 0.f); }
+      for (int c = 0; c < 512; c++) rec[a * 512 + c] = amax[k * 16 + a];
+    for (int pr : {PREC_FP8, PREC_INT8}) {
+      m->calib_amax_q[pr][k] = rec;
+      m->calib_bias_fix[pr][k].assign((size_t)13 * 512, 0.f); m->calib_tok_fix[pr][k].assign(512, 0.f); m->calib_out_fix[pr][k].assign(k == 0 ? 8 : 512, 0.f);
+    }
   }
-  m->calibrated = true;
   for (int pr : {PREC_FP8, PREC_INT8}) {
     Net *loaded[2] = {m->refiner_p[pr], m->scorer_p[pr]};
     for (int k = 0; k < 2; k++)
-      if (loaded[k] && (net_apply_q8(loaded[k], m->calib_amax[k].data(), m->calib_bias_fix[pr][k].data(), m->calib_tok_fix[pr][k].data(), true) ||
+      if (loaded[k] && (net_apply_q8(loaded[k], m->calib_amax_q[pr][k].data(), m->calib_bias_fix[pr][k].data(), m->calib_tok_fix[pr][k].data(), true) ||
                         net_q8_set_out_fix(loaded[k], m->calib_out_fix[pr][k].data()))) return 1;
   }
   invalidate_graphs(m);

@@ -2863,10 +2863,12 @@ __global__ __launch_bounds__(NW * 64, 2) void attention32_kernel(const typename 
         float mx = vmax_f32(vmax_f32(vmax_f32(st[qi][0][0], st[qi][0][1]), vmax_f32(st[qi][0][2], st[qi][0][3])),
                             vmax_f32(vmax_f32(st[qi][1][0], st[qi][1][1]), vmax_f32(st[qi][1][2], st[qi][1][3])));
         mx = rows_max(mx);
-        // lazy maximum [r4]: the reference point of the exponentials only moves when the block's maximum exceeds it by more than 2^8
-        // (p <= 256 is harmless in f16 / bf16, the sums are f32 and O / l use the same reference), so the 64-multiply rescale of
-        // O^T runs a few times per sequence instead of in most blocks
-        const float m_new = (mx * sl2e > m_run[qi] * sl2e + 8.0f) ? mx : m_run[qi];
+        // (ABL 64, test build: a LAZY reference -- it only moves when the block maximum exceeds it by more than 2^8, which skips most of
+        // the 64-multiply rescales of O^T: 213 -> 204 us per launch.  Not shipped: mathematically the same, but a row whose threshold
+        // decision flips under a 1e-3 perturbation of its inputs gets a different f16 rounding of ALL its P values, and the score-net's
+        // pooled feature then moves by up to 1.3x the between-hypothesis spread between a shard of 32 and the full batch
+        // (tools/ab_shard_att.py); with the exact running maximum the rounding pattern is shared and the two agree to 0.12x.)
+        const float m_new = (ABL & 64) ? ((mx * sl2e > m_run[qi] * sl2e + 8.0f) ? mx : m_run[qi]) : vmax_f32(m_run[qi], mx);
         const float mc = m_new * sl2e;
         const float alpha = __builtin_amdgcn_exp2f(m_run[qi] * sl2e - mc);  // m_run = -inf on the first block -> 0
         float psum = 0.f;
@@ -4685,6 +4687,7 @@ static void launch_attention(const Ctx &c, const void *qkv, void *out, int B, in
     else if (g_att_variant == 7) hipLaunchKernelGGL((attention_kernel<64, false, false, DT>), grid, blk, 0, c.s, q, o, T, nq, tstride);
     else if (g_att_variant == 9)  // 8 waves = 256 query rows per workgroup (K/V staged half as often; 9 % slower: the two waves of a SIMD run in lockstep)
       hipLaunchKernelGGL((attention32_kernel<true, DT, 0, 8>), dim3((unsigned)(((T + 255) / 256) * HEADS * B)), dim3(512), 0, c.s, q, o, T, (T + 255) / 256, tstride, ld);
+    else if (g_att_variant == 10) hipLaunchKernelGGL((attention32_kernel<true, DT, 64>), dim3((unsigned)(((T + 127) / 128) * HEADS * B)), blk, 0, c.s, q, o, T, (T + 127) / 128, tstride, ld);
     else if (g_att_variant == 8) hipLaunchKernelGGL((attention32_kernel<false, DT>), dim3((unsigned)(((T + 127) / 128) * HEADS * B)), blk, 0, c.s, q, o, T, (T + 127) / 128, tstride, ld);
     else if (g_att_variant >= 16 && g_att_variant < 32) {
       const dim3 g32((unsigned)(((T + 127) / 128) * HEADS * B));

@@ -232,7 +232,8 @@ int fp_net_infer(fp_net *net, int batch, int render_loc, int transf_loc, int out
  * (91 % of the FLOPs) on 8-bit operands -- OCP e4m3 (v_mfma_f32_16x16x128_f8f6f4) or signed / unsigned 8-bit integers
  * (v_mfma_i32_16x16x64_i8, the same matrix-pipe rate class) -- with per-output-channel weight scales, per-input-channel
  * activation scales folded into the weights, an f16 residual stream (a skip connection is never re-quantised) and a data-driven
- * bias correction; everything else f16.  Both need fp_calibrate / fp_set_calibration_blob first.  INT8 is the one that holds the
+ * bias correction; everything else f16.  Each needs ITS OWN fp_calibrate / fp_set_calibration_blob first (the record holds the
+ * statistics and the corrections solved against them; fp_set_calibration, the round-2 per-tensor form, serves both).  INT8 is the one that holds the
  * parity bars of the discriminating test networks: uniform 8-bit steps over a ReLU output's range round 5-7x finer than e4m3's
  * 3 mantissa bits (DESIGN.md section 4.4 has the measurements).  Networks of a precision are built from the weight files given
  * to fp_create the first time the precision is selected. */

@@ -392,6 +392,11 @@ def test_q8_needs_calibration(nets, syn_mesh, syn_scene):
             assert m.precision == FP_PREC_F16
         # the round-2 per-tensor interface still works (every channel gets the tensor's scale, no corrections)
         m.calibrate(syn_scene.rgb, syn_scene.depth, syn_scene.mask, syn_mesh.name, FP_PREC_FP8)
+        with pytest.raises(Exception) as e:      # a calibration belongs to ITS precision (statistics + the corrections solved against them)
+            m.set_precision(FP_PREC_INT8)
+        assert "calibrat" in str(e.value)
+        with pytest.raises(Exception):
+            m.get_calibration_blob(FP_PREC_INT8)
         cal = m.get_calibration()
         m2 = FoundationPose(syn_mesh, syn.intrinsics(), nets[0], nets[1])
         try:
