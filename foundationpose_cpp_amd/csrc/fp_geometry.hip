@@ -610,16 +610,34 @@ __global__ __launch_bounds__(NT) void raster_shade_kernel(
   }
 }
 
+#ifdef FP_TEST_HOOKS
+static int g_strip_threads = 0;  // A/B (test build): threads per 8-row strip workgroup for small batches, 0 = by batch size
+void set_raster_strip_threads(int t) { g_strip_threads = t; }
+#else
+static constexpr int g_strip_threads = 0;
+#endif
+
 template <int MODE, int STRIP_ROWS, bool FMAD>
 static void launch_raster_shade_t(hipStream_t s, const DeviceMesh &m, const PoseRec *recs, int N, const float4 *clip,
                                   const float4 *attr, void *out, int32_t *tri_id_dbg, float *rast_dbg) {
   size_t lds = (size_t)STRIP_ROWS * CROP * sizeof(unsigned long long);
   dim3 grid(CROP / STRIP_ROWS, N), block(256);
   float downscale = m.diameter / 2;
-  if (STRIP_ROWS == 8 && N <= 4 && MODE != OUT_F32X6 && !tri_id_dbg && !rast_dbg) {
-    hipLaunchKernelGGL((raster_shade_kernel<MODE, STRIP_ROWS, 1024, FMAD>), grid, dim3(1024), lds, s, m.faces, m.F, m.V, m.uvs,
-                       m.tex, m.TH, m.TW, downscale, recs, clip, attr, out, tri_id_dbg, rast_dbg);
-    return;
+  // small batches (a few objects, a 32-hypothesis shard of a strong-scaled Register): the launch is a latency chain of F / NT dependent
+  // triangle iterations per strip, not throughput -- 16 waves per strip while two such workgroups per CU hold the whole grid
+  // (20 strips x N <= 512), 8 waves up to where 8-row strips are used at all (N < 48).  [r4] tools/profile_shard.py: N = 12: 55 -> 29 us per
+  // launch; from N ~ 32 on the launch is bound by the gather rate of the 20x redundant triangle set-up instead (64 us at any width)
+  if (STRIP_ROWS == 8 && MODE != OUT_F32X6 && !tri_id_dbg && !rast_dbg && g_strip_threads != 256) {
+    if (g_strip_threads == 1024 || (g_strip_threads == 0 && N <= 25)) {
+      hipLaunchKernelGGL((raster_shade_kernel<MODE, STRIP_ROWS, 1024, FMAD>), grid, dim3(1024), lds, s, m.faces, m.F, m.V, m.uvs,
+                         m.tex, m.TH, m.TW, downscale, recs, clip, attr, out, tri_id_dbg, rast_dbg);
+      return;
+    }
+    if (g_strip_threads == 512 || (g_strip_threads == 0 && N < 48)) {
+      hipLaunchKernelGGL((raster_shade_kernel<MODE, STRIP_ROWS, 512, FMAD>), grid, dim3(512), lds, s, m.faces, m.F, m.V, m.uvs,
+                         m.tex, m.TH, m.TW, downscale, recs, clip, attr, out, tri_id_dbg, rast_dbg);
+      return;
+    }
   }
   hipLaunchKernelGGL((raster_shade_kernel<MODE, STRIP_ROWS, 256, FMAD>), grid, block, lds, s, m.faces, m.F, m.V, m.uvs, m.tex,
                      m.TH, m.TW, downscale, recs, clip, attr, out, tri_id_dbg, rast_dbg);

@@ -5245,6 +5245,7 @@ void fpt_set_att_skv(int v) { fp::g_att_skv = v; }
 void fpt_set_splitk_deep(int v) { fp::g_splitk_deep = v; }
 void fpt_set_splitk_min_kt(int v) { fp::g_splitk_min_kt = v; }
 void fpt_set_raster_strip_rows(int r) { fp::set_raster_strip_rows(r); }
+void fpt_set_raster_strip_threads(int t) { fp::set_raster_strip_threads(t); }
 
 // clock probe: allocate room for `blocks` records, run convs, then read back mean shader MHz and mean main-loop cycles
 int fpt_clk_probe(int blocks, double *mhz_out, double *loop_cycles_out) {
