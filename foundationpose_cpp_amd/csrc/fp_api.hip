@@ -169,8 +169,10 @@ static constexpr int g_upload_cols = 1;
 #endif
 #ifdef FP_TEST_HOOKS
 static int g_vertex_crop = 1;   // A/B (fpt_set_vertex_crop): Track's crop warp inside the vertex launch
+static int g_tri_rows = 1;      // A/B (fpt_set_tri_rows): per-triangle row ranges, so that a strip of the rasteriser skips the triangles that miss it
 #else
 static constexpr int g_vertex_crop = 1;
+static constexpr int g_tri_rows = 1;
 #endif
 
 // ------------------------------------------------------------------------------------------------
@@ -358,6 +360,8 @@ struct fp_model {
   PoseRec *recs = nullptr;
   float *poses_dev = nullptr;
   float4 *clip = nullptr, *attr = nullptr;
+  unsigned *tri_rows = nullptr;   // [cap, max_faces] row range of every triangle of every hypothesis (launch_tri_rows)
+  size_t tri_cap = 0, max_faces = 0;
   __half *nn_in = nullptr;                  // [2*cap,84,84,32] (s2d, zero border 2)
   float *blob_a = nullptr, *blob_b = nullptr;  // [cap,160,160,6] f32 (blob-mode entry points only)
   float *trans_dev = nullptr, *rot_dev = nullptr, *scores_dev = nullptr, *feat_dev = nullptr;
@@ -464,6 +468,13 @@ static int ensure_capacity(fp_model *m, int N, size_t V) {
     if (dev_alloc(&m->attr, (size_t)m->cap * V)) return 1;
     m->vert_cap = (size_t)m->cap * V;
   }
+  if (V > 0 && (size_t)m->cap * m->max_faces > m->tri_cap) {   // (sized for the largest mesh of the model: any target may be rendered)
+    g_alloc_epoch++;
+    dev_free(m->tri_rows);
+    m->tri_cap = 0;
+    if (dev_alloc(&m->tri_rows, (size_t)m->cap * m->max_faces)) return 1;
+    m->tri_cap = (size_t)m->cap * m->max_faces;
+  }
   return 0;
 }
 
@@ -502,7 +513,9 @@ static int render_and_crop(fp_model *m, Target *t, int N, float crop_ratio, OutM
       launch_setup_vertex_crop(s, t->mesh, poses_src ? poses_src : m->poses_dev, N, m->K, m->H, m->W, crop_ratio, t->mesh.diameter, recs, m->clip,
                                m->attr, m->fmad, m->frame_dev, n_crop, mode, out_b)) {
     // tiny batches (Track): set-up + vertex stage + crop warp were ONE launch; the rasteriser follows
-    launch_raster_shade(s, t->mesh, recs, N, m->clip, m->attr, mode, out_a, nullptr, nullptr, m->fmad);
+    unsigned *rows = g_tri_rows && m->tri_rows && raster_wants_tri_rows(N) && (size_t)N * t->mesh.F <= m->tri_cap ? m->tri_rows : nullptr;
+    if (rows) launch_tri_rows(s, t->mesh, N, m->clip, rows);
+    launch_raster_shade(s, t->mesh, recs, N, m->clip, m->attr, mode, out_a, nullptr, nullptr, m->fmad, rows);
     FP_HIP_OK(hipGetLastError());
     return 0;
   }
@@ -512,8 +525,13 @@ static int render_and_crop(fp_model *m, Target *t, int N, float crop_ratio, OutM
       launch_setup_vertex(s, t->mesh, poses_src ? poses_src : m->poses_dev, N, m->K, m->H, m->W, crop_ratio, t->mesh.diameter, recs,
                           m->clip, m->attr, m->fmad);
     }
+    unsigned *rows = g_tri_rows && m->tri_rows && raster_wants_tri_rows(N) && (size_t)N * t->mesh.F <= m->tri_cap ? m->tri_rows : nullptr;
+    if (rows) {
+      ProfScope ps(&m->prof, s, "tri_rows", 0, (double)N * t->mesh.F * (12.0 + 48.0 + 4.0));
+      launch_tri_rows(s, t->mesh, N, m->clip, rows);
+    }
     ProfScope ps(&m->prof, s, "raster_shade", 0, (double)N * (out_bytes + t->mesh.V * 32.0 + t->mesh.F * 12.0));
-    launch_raster_shade(s, t->mesh, recs, N, m->clip, m->attr, mode, out_a, dbg_tri, dbg_rast, m->fmad);
+    launch_raster_shade(s, t->mesh, recs, N, m->clip, m->attr, mode, out_a, dbg_tri, dbg_rast, m->fmad, rows);
   }
   if (out_b) {
     ProfScope ps(&m->prof, s, "crop_warp", 0, (double)n_crop * out_bytes);
@@ -671,6 +689,7 @@ extern "C" {
 
 #ifdef FP_TEST_HOOKS
 void fpt_set_vertex_crop(int v) { g_vertex_crop = v; }
+void fpt_set_tri_rows(int v) { g_tri_rows = v; }
 void fpt_set_upload_cols(int v) { g_upload_cols = v; }
 // A/B hook: hipGraph replay of the Track / Register bodies on or off for one model
 int fpt_model_use_graphs(fp_model *m, int on) {
@@ -840,6 +859,7 @@ fp_model *fp_create_on(int device, const fp_mesh *meshes, int n_meshes, const fl
     ok = ok && fp::memcpy_sync(d.faces, f.data(), f.size() * 4, hipMemcpyHostToDevice) == hipSuccess;
     ok = ok && fp::memcpy_sync(d.tex, src.texture, (size_t)d.TH * d.TW * 3, hipMemcpyHostToDevice) == hipSuccess;
     m->targets.push_back(t);
+    m->max_faces = std::max(m->max_faces, (size_t)t.mesh.F);
     if (!ok) {
       set_error("[FoundationPose Renderer] Failed to prepare buffer!!!");
       destroy_model_impl(m.release());
@@ -871,7 +891,7 @@ static void destroy_model_impl(fp_model *m) {
     dev_free(t.mesh.verts); dev_free(t.mesh.normals); dev_free(t.mesh.uvs); dev_free(t.mesh.faces); dev_free(t.mesh.tex);
   }
   dev_free(m->rgb_own); dev_free(m->depth_own); dev_free(m->erode); dev_free(m->bilat); dev_free(m->xyz);
-  dev_free(m->recs); dev_free(m->poses_dev); dev_free(m->clip); dev_free(m->attr); dev_free(m->nn_in);
+  dev_free(m->recs); dev_free(m->poses_dev); dev_free(m->clip); dev_free(m->attr); dev_free(m->tri_rows); dev_free(m->nn_in);
   dev_free(m->blob_a); dev_free(m->blob_b); dev_free(m->trans_dev); dev_free(m->rot_dev); dev_free(m->scores_dev);
   dev_free(m->feat_dev); dev_free(m->argmax_dev); dev_free(m->scores_all); dev_free(m->best_pose_dev);
   dev_free(m->gath_feat); dev_free(m->gath_poses); dev_free(m->shard_send); dev_free(m->shard_recv);

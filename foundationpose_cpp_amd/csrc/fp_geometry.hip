@@ -458,6 +458,55 @@ __device__ __noinline__ void raster_clipped(float4 v0, float4 v1, float4 v2, uns
   }
 }
 
+// [r4] Row range of every triangle, once per hypothesis: a strip of the rasteriser below then only sets up the triangles whose rows
+// meet it (each strip used to walk ALL triangles: 40 strips x F set-ups for one Track crop; 58 us at 20 k triangles, 186 us at 82 k).
+// The range is what raster_one would compute -- the same snapped vertices, the same bounding-box arithmetic -- so a triangle that is
+// skipped is one raster_one would have left at its bounding-box test; triangles on the clipping path get the whole crop, culled or
+// degenerate ones the empty range.  Packed lo | hi << 16; empty = 1 | 0 << 16.
+constexpr unsigned TRI_ROWS_EMPTY = 1u, TRI_ROWS_ALL = (unsigned)(CROP - 1) << 16;
+__global__ __launch_bounds__(256) void tri_rows_kernel(const int32_t *__restrict__ faces, int F, int V, const float4 *__restrict__ clip_all,
+                                                       unsigned *__restrict__ rows_all) {
+  const int f = blockIdx.x * 256 + threadIdx.x, n = blockIdx.y;
+  if (f >= F) return;
+  const float4 *clip = clip_all + (size_t)n * V;
+  unsigned out = TRI_ROWS_EMPTY;
+  const int i0 = faces[f * 3], i1 = faces[f * 3 + 1], i2 = faces[f * 3 + 2];
+  if ((unsigned)i0 < (unsigned)V && (unsigned)i1 < (unsigned)V && (unsigned)i2 < (unsigned)V) {
+    const float4 v0 = clip[i0], v1 = clip[i1], v2 = clip[i2];
+    bool culled = false;
+    if ((v0.w < fabsf(v0.x)) | (v0.w < fabsf(v0.y)) | (v0.w < fabsf(v0.z))) {
+      culled = ((v0.w < +v0.x) & (v1.w < +v1.x) & (v2.w < +v2.x)) | ((v0.w < -v0.x) & (v1.w < -v1.x) & (v2.w < -v2.x)) |
+               ((v0.w < +v0.y) & (v1.w < +v1.y) & (v2.w < +v2.y)) | ((v0.w < -v0.y) & (v1.w < -v1.y) & (v2.w < -v2.y)) |
+               ((v0.w < +v0.z) & (v1.w < +v1.z) & (v2.w < +v2.z)) | ((v0.w < -v0.z) & (v1.w < -v1.z) & (v2.w < -v2.z));
+    }
+    if (!culled) {
+      out = TRI_ROWS_ALL;   // the clipping path: every strip looks at it
+      if ((v0.w >= fabsf(v0.z)) & (v1.w >= fabsf(v1.z)) & (v2.w >= fabsf(v2.z))) {
+        const float vs = (float)(CROP << (CR_SUBPIXEL_LOG2 - 1));
+        const float rw0 = 1.0f / v0.w, rw1 = 1.0f / v1.w, rw2 = 1.0f / v2.w;
+        const int ax = f32_to_s32_sat(v0.x * rw0 * vs), ay = f32_to_s32_sat(v0.y * rw0 * vs);
+        const int bx_ = f32_to_s32_sat(v1.x * rw1 * vs), by_ = f32_to_s32_sat(v1.y * rw1 * vs);
+        const int cx = f32_to_s32_sat(v2.x * rw2 * vs), cy = f32_to_s32_sat(v2.y * rw2 * vs);
+        const int loxy = min(imin3(ax, bx_, cx), imin3(ay, by_, cy));
+        const int hixy = max(imax3(ax, bx_, cx), imax3(ay, by_, cy));
+        const int aabbLimit = (1 << (CR_MAXVIEWPORT_LOG2 + CR_SUBPIXEL_LOG2)) - 1;
+        if (loxy >= -32768 && hixy <= 32767 && hixy - loxy <= aabbLimit) {   // the fast path: raster_one's own tests
+          const int area = (bx_ - ax) * (cy - ay) - (by_ - ay) * (cx - ax);
+          const int bx = (CROP - 1) << (CR_SUBPIXEL_LOG2 - 1);
+          const int px0 = max((imin3(ax, bx_, cx) + bx + 15) >> 4, 0), px1 = min((imax3(ax, bx_, cx) + bx) >> 4, CROP - 1);
+          const int py0 = max((imin3(ay, by_, cy) + bx + 15) >> 4, 0), py1 = min((imax3(ay, by_, cy) + bx) >> 4, CROP - 1);
+          out = (area == 0 || px0 > px1 || py0 > py1) ? TRI_ROWS_EMPTY : ((unsigned)py0 | ((unsigned)py1 << 16));
+        }
+      }
+    }
+  }
+  rows_all[(size_t)n * F + f] = out;
+}
+void launch_tri_rows(hipStream_t s, const DeviceMesh &m, int N, const float4 *clip, unsigned *rows) {
+  hipLaunchKernelGGL(tri_rows_kernel, dim3((m.F + 255) / 256, N), dim3(256), 0, s, m.faces, m.F, m.V, clip, rows);
+}
+constexpr int TRI_LIST = 8192;   // capacity of the rasteriser's list of triangles that meet its strip (32 KB of LDS)
+
 // NT threads per workgroup: 256 normally; 1024 for tiny batches (Track), where the kernel is bound by the latency of the
 // F/NT dependent triangle iterations of each strip rather than by throughput
 template <int MODE, int STRIP_ROWS, int NT, bool FMAD>
@@ -465,7 +514,7 @@ __global__ __launch_bounds__(NT) void raster_shade_kernel(
     const int32_t *__restrict__ faces, int F, int V, const float *__restrict__ uvs, const uint8_t *__restrict__ tex,
     int TH, int TW, float downscale, const PoseRec *__restrict__ recs, const float4 *__restrict__ clip_all,
     const float4 *__restrict__ attr_all, void *__restrict__ out_all, int32_t *__restrict__ tri_id_dbg,
-    float *__restrict__ rast_dbg) {
+    float *__restrict__ rast_dbg, const unsigned *__restrict__ tri_rows_all) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned long long *zbuf = reinterpret_cast<unsigned long long *>(smem);
   const int strip = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
@@ -510,7 +559,55 @@ __global__ __launch_bounds__(NT) void raster_shade_kernel(
   };
   auto valid = [&](const Tri &t) { return (unsigned)t.i0 < (unsigned)V && (unsigned)t.i1 < (unsigned)V && (unsigned)t.i2 < (unsigned)V; };
   const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  {
+  if (tri_rows_all) {
+    // [r4] compacted: every thread tests the row ranges of 4 triangles per slab (4 coalesced bytes each, the loads independent) and
+    // appends the ones that meet this strip to an LDS list; the list is set up and rasterised when another slab might not fit, and at
+    // the end -- for a 4-row strip of a 20 k-triangle mesh that is ONE pass over ~1 000 survivors instead of 20 dependent
+    // index -> vertex -> set-up iterations per thread.  The list order varies from run to run; the z-buffer keys (depth, triangle id)
+    // make the result independent of it.
+    static_assert(TRI_LIST >= 8 * NT, "a slab of 4 NT triangles must fit behind the flush threshold");
+    unsigned *list = reinterpret_cast<unsigned *>(zbuf + STRIP_ROWS * CROP);
+    unsigned *count = list + TRI_LIST;
+    const unsigned *tri_rows = tri_rows_all + (size_t)n * F;
+    const unsigned row_last = (unsigned)(row0 + STRIP_ROWS - 1);
+    if (tid == 0) *count = 0u;
+    __syncthreads();
+    auto flush = [&]() {   // (called by all threads, after a barrier that follows the last append)
+      const int nl = (int)*count;
+      // software-pipelined like the full walk below: vertices of entry k+1 and indices of entry k+2 in flight
+      auto entry = [&](int k) { return k < nl ? load_idx((int)list[k]) : Tri{-1, -1, -1}; };
+      Tri cur = entry(tid), nxt = entry(tid + NT);
+      bool ok = valid(cur);
+      float4 v0 = ok ? clip[cur.i0] : zero4, v1 = ok ? clip[cur.i1] : zero4, v2 = ok ? clip[cur.i2] : zero4;
+      for (int k = tid; k < nl; k += NT) {
+        const bool okn = valid(nxt);
+        const float4 w0 = okn ? clip[nxt.i0] : zero4, w1 = okn ? clip[nxt.i1] : zero4, w2 = okn ? clip[nxt.i2] : zero4;
+        const Tri nn = entry(k + 2 * NT);
+        if (ok) process((int)list[k], v0, v1, v2);
+        v0 = w0; v1 = w1; v2 = w2; ok = okn; nxt = nn;
+      }
+    };
+    for (int base = 0; base < F; base += 4 * NT) {
+      unsigned r[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int f = base + u * NT + tid;
+        r[u] = f < F ? tri_rows[f] : TRI_ROWS_EMPTY;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++)
+        if ((r[u] & 0xffffu) <= row_last && (r[u] >> 16) >= (unsigned)row0) list[atomicAdd(count, 1u)] = (unsigned)(base + u * NT + tid);
+      __syncthreads();
+      // uniform decision: the second barrier also keeps the next slab's appends behind every thread's read of the count
+      if (__syncthreads_or(*count > (unsigned)(TRI_LIST - 4 * NT) && base + 4 * NT < F)) {
+        flush();
+        __syncthreads();
+        if (tid == 0) *count = 0u;
+        __syncthreads();
+      }
+    }
+    flush();
+  } else {
     Tri cur = load_idx(tid), nxt = load_idx(tid + NT);
     bool ok = valid(cur);
     float4 v0 = ok ? clip[cur.i0] : zero4, v1 = ok ? clip[cur.i1] : zero4, v2 = ok ? clip[cur.i2] : zero4;
@@ -610,6 +707,10 @@ __global__ __launch_bounds__(NT) void raster_shade_kernel(
   }
 }
 
+// the row ranges of the launch in progress (launch_raster_shade sets it; the launchers below are plain host code of the same call)
+static thread_local const unsigned *t_tri_rows = nullptr;
+static size_t tri_list_lds() { return t_tri_rows ? (size_t)TRI_LIST * 4 + 16 : 0; }
+
 #ifdef FP_TEST_HOOKS
 static int g_strip_threads = 0;  // A/B (test build): threads per 8-row strip workgroup for small batches, 0 = by batch size
 void set_raster_strip_threads(int t) { g_strip_threads = t; }
@@ -620,7 +721,7 @@ static constexpr int g_strip_threads = 0;
 template <int MODE, int STRIP_ROWS, bool FMAD>
 static void launch_raster_shade_t(hipStream_t s, const DeviceMesh &m, const PoseRec *recs, int N, const float4 *clip,
                                   const float4 *attr, void *out, int32_t *tri_id_dbg, float *rast_dbg) {
-  size_t lds = (size_t)STRIP_ROWS * CROP * sizeof(unsigned long long);
+  size_t lds = (size_t)STRIP_ROWS * CROP * sizeof(unsigned long long) + tri_list_lds();
   dim3 grid(CROP / STRIP_ROWS, N), block(256);
   float downscale = m.diameter / 2;
   // small batches (a few objects, a 32-hypothesis shard of a strong-scaled Register): the launch is a latency chain of F / NT dependent
@@ -630,17 +731,23 @@ static void launch_raster_shade_t(hipStream_t s, const DeviceMesh &m, const Pose
   if (STRIP_ROWS == 8 && MODE != OUT_F32X6 && !tri_id_dbg && !rast_dbg && g_strip_threads != 256) {
     if (g_strip_threads == 1024 || (g_strip_threads == 0 && N <= 25)) {
       hipLaunchKernelGGL((raster_shade_kernel<MODE, STRIP_ROWS, 1024, FMAD>), grid, dim3(1024), lds, s, m.faces, m.F, m.V, m.uvs,
-                         m.tex, m.TH, m.TW, downscale, recs, clip, attr, out, tri_id_dbg, rast_dbg);
+                         m.tex, m.TH, m.TW, downscale, recs, clip, attr, out, tri_id_dbg, rast_dbg, t_tri_rows);
       return;
     }
     if (g_strip_threads == 512 || (g_strip_threads == 0 && N < 48)) {
       hipLaunchKernelGGL((raster_shade_kernel<MODE, STRIP_ROWS, 512, FMAD>), grid, dim3(512), lds, s, m.faces, m.F, m.V, m.uvs,
-                         m.tex, m.TH, m.TW, downscale, recs, clip, attr, out, tri_id_dbg, rast_dbg);
+                         m.tex, m.TH, m.TW, downscale, recs, clip, attr, out, tri_id_dbg, rast_dbg, t_tri_rows);
       return;
     }
   }
+  if constexpr (STRIP_ROWS >= 40) {   // (test-build strip heights: z-buffer + list exceed the 64 KB a kernel gets without asking)
+    static PerDeviceOnce attr_once;
+    if (attr_once.first())
+      (void)hipFuncSetAttribute((const void *)raster_shade_kernel<MODE, STRIP_ROWS, 256, FMAD>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)((size_t)STRIP_ROWS * CROP * sizeof(unsigned long long) + (size_t)TRI_LIST * 4 + 16));
+  }
   hipLaunchKernelGGL((raster_shade_kernel<MODE, STRIP_ROWS, 256, FMAD>), grid, block, lds, s, m.faces, m.F, m.V, m.uvs, m.tex,
-                     m.TH, m.TW, downscale, recs, clip, attr, out, tri_id_dbg, rast_dbg);
+                     m.TH, m.TW, downscale, recs, clip, attr, out, tri_id_dbg, rast_dbg, t_tri_rows);
 }
 
 #ifdef FP_TEST_HOOKS
@@ -656,19 +763,26 @@ static constexpr int g_strip_rows_override = 0;
 template <int MODE, int STRIP_ROWS, bool FMAD>
 static void launch_raster_tall(hipStream_t s, const DeviceMesh &m, const PoseRec *recs, int N, const float4 *clip,
                                const float4 *attr, void *out) {
-  size_t lds = (size_t)STRIP_ROWS * CROP * sizeof(unsigned long long);
+  size_t lds = (size_t)STRIP_ROWS * CROP * sizeof(unsigned long long);   // (no triangle list: raster_wants_tri_rows)
   // once per instantiation and device: opt in to > 64 KB of dynamic LDS
   static PerDeviceOnce attr_once;
   if (attr_once.first())
-    (void)hipFuncSetAttribute((const void *)raster_shade_kernel<MODE, STRIP_ROWS, 1024, FMAD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void *)raster_shade_kernel<MODE, STRIP_ROWS, 1024, FMAD>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds);
   hipLaunchKernelGGL((raster_shade_kernel<MODE, STRIP_ROWS, 1024, FMAD>), dim3(CROP / STRIP_ROWS, N), dim3(1024), lds, s, m.faces, m.F,
-                     m.V, m.uvs, m.tex, m.TH, m.TW, m.diameter / 2, recs, clip, attr, out, nullptr, nullptr);
+                     m.V, m.uvs, m.tex, m.TH, m.TW, m.diameter / 2, recs, clip, attr, out, nullptr, nullptr, nullptr);
 }
+
+// Row ranges pay where a crop is cut into many short strips (Track: 40, small batches: 20 or 8); the two 80-row strips of a full
+// Register batch meet half of the triangles each, and the extra launch + list passes cost what the skipped set-ups save
+// (tools/mesh_size_sweep.py: N = 252, 20 k triangles, 412 -> 396 us of rasteriser + the range kernel).
+static int strip_rows_for(int N) { return g_strip_rows_override ? g_strip_rows_override : (N >= 100 ? 1080 : (N >= 48 ? 20 : 8)); }
+bool raster_wants_tri_rows(int N) { return strip_rows_for(N) < 1000; }
 
 template <int MODE, bool FMAD>
 static void launch_raster_mode(hipStream_t s, const DeviceMesh &m, const PoseRec *recs, int N, const float4 *clip,
                                const float4 *attr, void *out, int32_t *tri_id_dbg, float *rast_dbg) {
-  int rows = g_strip_rows_override ? g_strip_rows_override : (N >= 100 ? 1080 : (N >= 48 ? 20 : 8));  // (tools/ab_raster_strips.py: 8-row strips win up to ~40 hypotheses)
+  int rows = strip_rows_for(N);  // (tools/ab_raster_strips.py: 8-row strips win up to ~40 hypotheses)
   if (rows > 1000 && MODE != OUT_F32X6 && !tri_id_dbg && !rast_dbg) {
     if (rows == 1080) { launch_raster_tall<MODE, 80, FMAD>(s, m, recs, N, clip, attr, out); return; }
 #ifdef FP_TEST_HOOKS
@@ -685,16 +799,18 @@ static void launch_raster_mode(hipStream_t s, const DeviceMesh &m, const PoseRec
   // one or two hypotheses (Track): 4-row strips with 1024 threads -- the shading pass covers the strip in ONE iteration
   // (640 pixels; 8 rows = 1280 pixels took two, the second a quarter full) and a strip meets half as many triangles
   if ((rows == 4 || (rows == 8 && N <= 2 && !g_strip_rows_override)) && MODE != OUT_F32X6 && !tri_id_dbg && !rast_dbg) {
-    const size_t lds = (size_t)4 * CROP * sizeof(unsigned long long);
+    const size_t lds = (size_t)4 * CROP * sizeof(unsigned long long) + tri_list_lds();
     hipLaunchKernelGGL((raster_shade_kernel<MODE, 4, 1024, FMAD>), dim3(CROP / 4, N), dim3(1024), lds, s, m.faces, m.F, m.V, m.uvs,
-                       m.tex, m.TH, m.TW, m.diameter / 2, recs, clip, attr, out, tri_id_dbg, rast_dbg);
+                       m.tex, m.TH, m.TW, m.diameter / 2, recs, clip, attr, out, tri_id_dbg, rast_dbg, t_tri_rows);
     return;
   }
   launch_raster_shade_t<MODE, 8, FMAD>(s, m, recs, N, clip, attr, out, tri_id_dbg, rast_dbg);
 }
 
 void launch_raster_shade(hipStream_t s, const DeviceMesh &m, const PoseRec *recs, int N, const float4 *clip,
-                         const float4 *attr, OutMode mode, void *out, int32_t *tri_id_dbg, float *rast_dbg, bool fmad) {
+                         const float4 *attr, OutMode mode, void *out, int32_t *tri_id_dbg, float *rast_dbg, bool fmad,
+                         const unsigned *tri_rows) {
+  t_tri_rows = tri_rows;
 #define FP_RASTER_MODE(MODE)                                                                                      \
   do {                                                                                                            \
     if (fmad) launch_raster_mode<MODE, true>(s, m, recs, N, clip, attr, out, tri_id_dbg, rast_dbg);               \

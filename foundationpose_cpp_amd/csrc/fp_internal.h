@@ -192,8 +192,12 @@ struct FrameRef;
 bool launch_setup_vertex_crop(hipStream_t s, const DeviceMesh &m, const float *poses_dev, int N, const float *K9_host, int img_h, int img_w,
                               float crop_ratio, float diameter, PoseRec *recs, float4 *clip, float4 *attr, bool fmad, const FrameRef *frame,
                               int n_crop, OutMode mode, void *out_b);
+// tri_rows: [N, F] row ranges from launch_tri_rows of the same clip coordinates (a strip then skips the triangles that miss it), or null
+void launch_tri_rows(hipStream_t s, const DeviceMesh &m, int N, const float4 *clip, unsigned *rows);
+bool raster_wants_tri_rows(int N);   // false for batches that are rendered in two tall strips per crop
 void launch_raster_shade(hipStream_t s, const DeviceMesh &m, const PoseRec *recs, int N, const float4 *clip,
-                         const float4 *attr, OutMode mode, void *out, int32_t *tri_id_dbg, float *rast_dbg, bool fmad);
+                         const float4 *attr, OutMode mode, void *out, int32_t *tri_id_dbg, float *rast_dbg, bool fmad,
+                         const unsigned *tri_rows = nullptr);
 #ifdef FP_TEST_HOOKS
 void set_raster_strip_rows(int rows);  // 0 = automatic (A/B hook)
 void set_raster_strip_threads(int threads);  // 0 = by batch size; 256 / 512 / 1024 (A/B hook, 8-row strips)
