@@ -468,12 +468,15 @@ static int ensure_capacity(fp_model *m, int N, size_t V) {
     if (dev_alloc(&m->attr, (size_t)m->cap * V)) return 1;
     m->vert_cap = (size_t)m->cap * V;
   }
-  if (V > 0 && (size_t)m->cap * m->max_faces > m->tri_cap) {   // (sized for the largest mesh of the model: any target may be rendered)
+  // row ranges: for the largest mesh of the model (any target may be rendered) and for the batch sizes that are rendered in short
+  // strips (raster_wants_tri_rows: below 100 hypotheses; a larger batch falls back to the full walk when the buffer is too small)
+  const size_t tri_need = (size_t)std::min(m->cap, 99) * m->max_faces;
+  if (V > 0 && tri_need > m->tri_cap) {
     g_alloc_epoch++;
     dev_free(m->tri_rows);
     m->tri_cap = 0;
-    if (dev_alloc(&m->tri_rows, (size_t)m->cap * m->max_faces)) return 1;
-    m->tri_cap = (size_t)m->cap * m->max_faces;
+    if (dev_alloc(&m->tri_rows, tri_need)) return 1;
+    m->tri_cap = tri_need;
   }
   return 0;
 }
