@@ -169,10 +169,12 @@ static constexpr int g_upload_cols = 1;
 #endif
 #ifdef FP_TEST_HOOKS
 static int g_vertex_crop = 1;   // A/B (fpt_set_vertex_crop): Track's crop warp inside the vertex launch
+static int g_tri_rows_all_batches = 0;   // A/B (fpt_set_tri_rows(2)): size the buffer for large batches too
 static int g_tri_rows = 1;      // A/B (fpt_set_tri_rows): per-triangle row ranges, so that a strip of the rasteriser skips the triangles that miss it
 #else
 static constexpr int g_vertex_crop = 1;
 static constexpr int g_tri_rows = 1;
+static constexpr int g_tri_rows_all_batches = 0;
 #endif
 
 // ------------------------------------------------------------------------------------------------
@@ -470,7 +472,7 @@ static int ensure_capacity(fp_model *m, int N, size_t V) {
   }
   // row ranges: for the largest mesh of the model (any target may be rendered) and for the batch sizes that are rendered in short
   // strips (raster_wants_tri_rows: below 100 hypotheses; a larger batch falls back to the full walk when the buffer is too small)
-  const size_t tri_need = (size_t)std::min(m->cap, 99) * m->max_faces;
+  const size_t tri_need = (size_t)(g_tri_rows_all_batches ? m->cap : std::min(m->cap, 99)) * m->max_faces;
   if (V > 0 && tri_need > m->tri_cap) {
     g_alloc_epoch++;
     dev_free(m->tri_rows);
@@ -692,7 +694,7 @@ extern "C" {
 
 #ifdef FP_TEST_HOOKS
 void fpt_set_vertex_crop(int v) { g_vertex_crop = v; }
-void fpt_set_tri_rows(int v) { g_tri_rows = v; }
+void fpt_set_tri_rows(int v) { g_tri_rows = v != 0; g_tri_rows_all_batches = v == 2; }
 void fpt_set_upload_cols(int v) { g_upload_cols = v; }
 // A/B hook: hipGraph replay of the Track / Register bodies on or off for one model
 int fpt_model_use_graphs(fp_model *m, int on) {

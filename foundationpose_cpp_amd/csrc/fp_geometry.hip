@@ -712,6 +712,12 @@ static thread_local const unsigned *t_tri_rows = nullptr;
 static size_t tri_list_lds() { return t_tri_rows ? (size_t)TRI_LIST * 4 + 16 : 0; }
 
 #ifdef FP_TEST_HOOKS
+static int g_tri_rows_tall = 0;  // A/B (test build): row ranges for the tall strips of large batches too
+void set_tri_rows_tall(int v) { g_tri_rows_tall = v; }
+#else
+static constexpr int g_tri_rows_tall = 0;
+#endif
+#ifdef FP_TEST_HOOKS
 static int g_strip_threads = 0;  // A/B (test build): threads per 8-row strip workgroup for small batches, 0 = by batch size
 void set_raster_strip_threads(int t) { g_strip_threads = t; }
 #else
@@ -763,21 +769,22 @@ static constexpr int g_strip_rows_override = 0;
 template <int MODE, int STRIP_ROWS, bool FMAD>
 static void launch_raster_tall(hipStream_t s, const DeviceMesh &m, const PoseRec *recs, int N, const float4 *clip,
                                const float4 *attr, void *out) {
-  size_t lds = (size_t)STRIP_ROWS * CROP * sizeof(unsigned long long);   // (no triangle list: raster_wants_tri_rows)
+  const size_t lds_max = (size_t)STRIP_ROWS * CROP * sizeof(unsigned long long) + (size_t)TRI_LIST * 4 + 16;
+  size_t lds = (size_t)STRIP_ROWS * CROP * sizeof(unsigned long long) + tri_list_lds();
   // once per instantiation and device: opt in to > 64 KB of dynamic LDS
   static PerDeviceOnce attr_once;
   if (attr_once.first())
     (void)hipFuncSetAttribute((const void *)raster_shade_kernel<MODE, STRIP_ROWS, 1024, FMAD>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)lds);
+                              (int)lds_max);
   hipLaunchKernelGGL((raster_shade_kernel<MODE, STRIP_ROWS, 1024, FMAD>), dim3(CROP / STRIP_ROWS, N), dim3(1024), lds, s, m.faces, m.F,
-                     m.V, m.uvs, m.tex, m.TH, m.TW, m.diameter / 2, recs, clip, attr, out, nullptr, nullptr, nullptr);
+                     m.V, m.uvs, m.tex, m.TH, m.TW, m.diameter / 2, recs, clip, attr, out, nullptr, nullptr, t_tri_rows);
 }
 
 // Row ranges pay where a crop is cut into many short strips (Track: 40, small batches: 20 or 8); the two 80-row strips of a full
 // Register batch meet half of the triangles each, and the extra launch + list passes cost what the skipped set-ups save
 // (tools/mesh_size_sweep.py: N = 252, 20 k triangles, 412 -> 396 us of rasteriser + the range kernel).
 static int strip_rows_for(int N) { return g_strip_rows_override ? g_strip_rows_override : (N >= 100 ? 1080 : (N >= 48 ? 20 : 8)); }
-bool raster_wants_tri_rows(int N) { return strip_rows_for(N) < 1000; }
+bool raster_wants_tri_rows(int N) { return strip_rows_for(N) < 1000 || g_tri_rows_tall; }
 
 template <int MODE, bool FMAD>
 static void launch_raster_mode(hipStream_t s, const DeviceMesh &m, const PoseRec *recs, int N, const float4 *clip,

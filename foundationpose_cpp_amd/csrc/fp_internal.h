@@ -200,6 +200,7 @@ void launch_raster_shade(hipStream_t s, const DeviceMesh &m, const PoseRec *recs
                          const unsigned *tri_rows = nullptr);
 #ifdef FP_TEST_HOOKS
 void set_raster_strip_rows(int rows);  // 0 = automatic (A/B hook)
+void set_tri_rows_tall(int v);
 void set_raster_strip_threads(int threads);  // 0 = by batch size; 256 / 512 / 1024 (A/B hook, 8-row strips)
 #endif
 // the frame a replayed hipGraph reads: kernels inside graphs take the frame through this device-resident record, so a caller's
