@@ -503,6 +503,7 @@ __global__ __launch_bounds__(256) void tri_rows_kernel(const int32_t *__restrict
   rows_all[(size_t)n * F + f] = out;
 }
 void launch_tri_rows(hipStream_t s, const DeviceMesh &m, int N, const float4 *clip, unsigned *rows) {
+  if (m.F <= 0 || N <= 0) return;
   hipLaunchKernelGGL(tri_rows_kernel, dim3((m.F + 255) / 256, N), dim3(256), 0, s, m.faces, m.F, m.V, clip, rows);
 }
 constexpr int TRI_LIST = 8192;   // capacity of the rasteriser's list of triangles that meet its strip (32 KB of LDS)
