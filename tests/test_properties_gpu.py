@@ -437,3 +437,81 @@ def test_track_launch_fusions_do_not_change_a_bit(tmp_path):
     lines = [l.split() for l in res.stdout.splitlines() if l.startswith("POSES")]
     assert len(lines) == 4
     assert len({l[3] for l in lines}) == 1, [(l[1], l[2]) for l in lines]
+
+
+_RASTER_AB_SCRIPT = r"""
+import ctypes, os, sys, hashlib, tempfile
+import numpy as np
+import torch  # (first: one HIP runtime)
+from foundationpose_cpp_amd import _lib
+_lib.use_test_lib()
+from foundationpose_cpp_amd import FoundationPose, synthetic as syn, weights as W
+from foundationpose_cpp_amd.distributed import HipShardBackend
+L = _lib.lib()
+L.fpt_read_buffer.restype = ctypes.c_longlong
+L.fpt_read_buffer.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_longlong]
+mesh = syn.make_mesh(subdiv=5); scene = syn.make_scene(mesh)       # 20 480 triangles
+d = tempfile.mkdtemp(); rp, sp = os.path.join(d, "r.fpw"), os.path.join(d, "s.fpw")
+W.pack_synthetic("refiner", rp); W.pack_synthetic("scorer", sp)
+m = FoundationPose(mesh, scene.K, rp, sp)
+L.fpt_model_use_graphs(m.handle, 0)                                 # (a replayed graph would keep the launches it was captured with)
+m.upload_frame(scene.rgb, scene.depth)
+base = m.get_hyp_poses(scene.mask)
+edge = []                                                           # poses that leave the crop / come close to the camera: the clipping path
+for i, p in enumerate(base[:6]):
+    q = np.array(p, np.float32).copy()
+    q[i % 2, 3] += 0.5 * mesh.diameter * (1 if i % 4 < 2 else -1)
+    if i >= 4: q[2, 3] = 0.6 * mesh.diameter
+    edge.append(q)
+# (1) the reference-blob path (f32, 256-thread strips): with / without the row ranges, edge poses included
+for n in (1, 3, 12, 33, 60):
+    poses = (np.concatenate([np.stack(edge), base[:max(n - len(edge), 0)]])[:n]) if n > 1 else base[:1]
+    for rows in (1, 0):
+        L.fpt_set_tri_rows(rows)
+        a, b = m.render_and_transform(mesh.name, poses, 1.2)
+        print("BLOB", "f32", n, rows, 0, hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest(), float(np.abs(a).sum()))
+# (2) the product path (f16 network tensor of a Register slice / of Track): row ranges x waves per strip
+dev = torch.device("cuda", 0)
+rgb, depth, mask = (torch.from_numpy(x).to(dev) for x in (scene.rgb, scene.depth, scene.mask))
+be = HipShardBackend(m, dev)
+IMG = 84 * 84 * 32 * 2
+H, Wd = scene.depth.shape
+for n in (1, 3, 12, 33, 60):
+    packed, _ = be.buffers(n, 1)
+    for rows, threads in ((1, 0), (0, 0), (1, 256), (0, 256), (1, 1024)):
+        L.fpt_set_tri_rows(rows); L.fpt_set_raster_strip_threads(threads)
+        if n == 1:
+            ok, _ = m.Track(scene.rgb, scene.depth, syn.perturb_pose(scene.gt_pose), mesh.name)
+            assert ok
+        else:
+            be.shard_begin_packed(rgb, depth, mask, H, Wd, mesh.name, 1, 0, n, packed, n)
+            m.synchronize()
+        buf = np.zeros(n * IMG, np.uint8)
+        got = L.fpt_read_buffer(m.handle, 3, buf.ctypes.data_as(ctypes.c_void_p), buf.nbytes)
+        assert got == buf.nbytes, got
+        print("BLOB", "f16", n, rows, threads, hashlib.sha256(buf.tobytes()).hexdigest(), float(buf.astype(np.float64).sum()))
+m.close()
+"""
+
+
+@pytest.mark.gpu
+def test_rasteriser_row_ranges_and_strip_widths_do_not_change_a_bit(tmp_path):
+    """[r4] The product path of the rasteriser (f16 network tensor) with and without the per-triangle row ranges + LDS compaction, and
+    with 4 / 8 / 16 waves per strip, in the test build where the switches exist: batches of 1 (Track: 4-row strips), 3, 12 (8-row
+    strips, 16 waves), 33 (8 waves) and 60 (20-row strips) hypotheses of a 20 k-triangle mesh, including poses on the clipping path,
+    give byte-identical tensors in every combination (the compaction order varies between runs; the z-buffer keys hide it)."""
+    import subprocess
+    import sys
+    script = tmp_path / "raster_ab.py"
+    script.write_text(_RASTER_AB_SCRIPT)
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    res = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600, env=env)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l.split() for l in res.stdout.splitlines() if l.startswith("BLOB")]
+    assert len(lines) == 10 + 25, res.stdout[-2000:]
+    for kind in ("f32", "f16"):
+        for n in ("1", "3", "12", "33", "60"):
+            group = [l for l in lines if l[1] == kind and l[2] == n]
+            assert len(group) == (2 if kind == "f32" else 5)
+            assert len({l[5] for l in group}) == 1, [(kind, n, l[3], l[4], l[5][:12]) for l in group]
+            assert float(group[0][6]) > 0.0            # something was rendered
