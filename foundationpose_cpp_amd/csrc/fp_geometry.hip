@@ -588,13 +588,17 @@ __global__ __launch_bounds__(NT) void raster_shade_kernel(
         v0 = w0; v1 = w1; v2 = w2; ok = okn; nxt = nn;
       }
     };
-    for (int base = 0; base < F; base += 4 * NT) {
-      unsigned r[4];
+    auto load_slab = [&](int base, unsigned (&r)[4]) {
 #pragma unroll
       for (int u = 0; u < 4; u++) {
         const int f = base + u * NT + tid;
         r[u] = f < F ? tri_rows[f] : TRI_ROWS_EMPTY;
       }
+    };
+    unsigned r[4], rn[4];
+    load_slab(0, r);
+    for (int base = 0; base < F; base += 4 * NT) {
+      load_slab(base + 4 * NT, rn);   // the next slab's ranges travel under this slab's appends and barriers
 #pragma unroll
       for (int u = 0; u < 4; u++)
         if ((r[u] & 0xffffu) <= row_last && (r[u] >> 16) >= (unsigned)row0) list[atomicAdd(count, 1u)] = (unsigned)(base + u * NT + tid);
@@ -606,6 +610,8 @@ __global__ __launch_bounds__(NT) void raster_shade_kernel(
         if (tid == 0) *count = 0u;
         __syncthreads();
       }
+#pragma unroll
+      for (int u = 0; u < 4; u++) r[u] = rn[u];
     }
     flush();
   } else {
