@@ -603,8 +603,11 @@ __global__ __launch_bounds__(NT) void raster_shade_kernel(
       for (int u = 0; u < 4; u++)
         if ((r[u] & 0xffffu) <= row_last && (r[u] >> 16) >= (unsigned)row0) list[atomicAdd(count, 1u)] = (unsigned)(base + u * NT + tid);
       __syncthreads();
-      // uniform decision: the second barrier also keeps the next slab's appends behind every thread's read of the count
-      if (__syncthreads_or(*count > (unsigned)(TRI_LIST - 4 * NT) && base + 4 * NT < F)) {
+      // every thread reads the same count between two barriers (the second keeps the next slab's appends behind the reads): a uniform
+      // decision without a workgroup reduction
+      const bool full = *count > (unsigned)(TRI_LIST - 4 * NT) && base + 4 * NT < F;
+      __syncthreads();
+      if (full) {
         flush();
         __syncthreads();
         if (tid == 0) *count = 0u;
