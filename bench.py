@@ -342,7 +342,7 @@ def main():
             "metric": "Track fps (N=1)", "value": round(ksteps / td, 1), "unit": "frames/s", "ms_per_frame": round(td / ksteps * 1e3, 4),
             "host_frame_value": round(ksteps / thh, 1), "host_frame_ms": round(thh / ksteps * 1e3, 4), "steps": ksteps,
             "pipelined": pipelined,
-            "roofline": {"bound": "launch latency (one hipGraph of 27 dependent kernels), not MFMA", "algorithmic_gflop_per_frame": round(tflops / 1e9, 2),
+            "roofline": {"bound": "launch latency (one hipGraph of 26 dependent kernels), not MFMA", "algorithmic_gflop_per_frame": round(tflops / 1e9, 2),
                          "achieved": round(tflops / (td / ksteps) / 1e12, 1), "peak": PEAK_FP16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(tflops / (td / ksteps) / 1e12 / PEAK_FP16_TFLOPS, 4)},
         }
@@ -481,7 +481,7 @@ def main():
                                                     "weights": "discriminating synthetic set"},
                         "accuracy": {"pose_delta_vs_f16_track": {"deg": round(float(rot_deg(p8[None], p16[None])[0]), 3),
                                                                  "mm": round(float(np.linalg.norm(p8[:3, 3] - p16[:3, 3]) * 1e3), 3)}},
-                        "graph": "27 kernels (26 + the triangle row-range kernel of the rasteriser); 26 spanned 194 us before it (profiles/r04d_track_int8_timeline.txt), the f16 graph now spans 212.5 us (profiles/r04f_track_timeline.txt)"}
+                        "graph": "26 kernels (the triangles' row ranges are computed inside the vertex + crop launch); the INT8 graph spanned 194 us before the row-range rasteriser (profiles/r04d_track_int8_timeline.txt), the f16 graph spans ~207 us (profiles/r04i_track_timeline.txt)"}
             finally:
                 m.close()
         extras["track_int8"] = track_leg_int8(max(args.steps * 10, 100))

@@ -168,7 +168,7 @@ static int g_upload_cols = 1;   // A/B (fpt_set_upload_cols): Track from host fr
 static constexpr int g_upload_cols = 1;
 #endif
 #ifdef FP_TEST_HOOKS
-static int g_vertex_crop = 1;   // A/B (fpt_set_vertex_crop): Track's crop warp inside the vertex launch
+static int g_vertex_crop = 1;   // A/B (fpt_set_vertex_crop): Track's crop warp (and, unless 2, the triangles' row ranges) inside the vertex launch
 static int g_tri_rows_all_batches = 0;   // A/B (fpt_set_tri_rows(2)): size the buffer for large batches too
 static int g_tri_rows = 1;      // A/B (fpt_set_tri_rows): per-triangle row ranges, so that a strip of the rasteriser skips the triangles that miss it
 #else
@@ -514,12 +514,13 @@ static int render_and_crop(fp_model *m, Target *t, int N, float crop_ratio, OutM
     ProfScope ps(&m->prof, s, "pose_setup");
     launch_pose_setup(s, poses_src ? poses_src : m->poses_dev, N, m->K, m->H, m->W, crop_ratio, t->mesh.diameter, recs);
   }
+  unsigned *const rows_small = g_tri_rows && m->tri_rows && raster_wants_tri_rows(N) && (size_t)N * t->mesh.F <= m->tri_cap ? m->tri_rows : nullptr;
   if (out_a && out_b && N <= 4 && !m->prof.on && !dbg_tri && !dbg_rast && g_vertex_crop &&
       launch_setup_vertex_crop(s, t->mesh, poses_src ? poses_src : m->poses_dev, N, m->K, m->H, m->W, crop_ratio, t->mesh.diameter, recs, m->clip,
-                               m->attr, m->fmad, m->frame_dev, n_crop, mode, out_b)) {
-    // tiny batches (Track): set-up + vertex stage + crop warp were ONE launch; the rasteriser follows
-    unsigned *rows = g_tri_rows && m->tri_rows && raster_wants_tri_rows(N) && (size_t)N * t->mesh.F <= m->tri_cap ? m->tri_rows : nullptr;
-    if (rows) launch_tri_rows(s, t->mesh, N, m->clip, rows);
+                               m->attr, m->fmad, m->frame_dev, n_crop, mode, out_b, g_vertex_crop == 2 ? nullptr : rows_small)) {
+    // tiny batches (Track): set-up + vertex stage + crop warp + the triangles' row ranges were ONE launch; the rasteriser follows
+    unsigned *rows = rows_small;
+    if (rows && g_vertex_crop == 2) launch_tri_rows(s, t->mesh, N, m->clip, rows);   // A/B: the row ranges as their own launch
     launch_raster_shade(s, t->mesh, recs, N, m->clip, m->attr, mode, out_a, nullptr, nullptr, m->fmad, rows);
     FP_HIP_OK(hipGetLastError());
     return 0;

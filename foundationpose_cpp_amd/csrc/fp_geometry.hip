@@ -192,12 +192,12 @@ struct PoseSetupArgs {
   int img_h, img_w;
   float crop_ratio, diameter;
 };
-// one vertex of hypothesis n under the record `rec`
+// clip-space position of one model vertex: the ONE place this arithmetic is written (the vertex stage stores it, the fused
+// row-range blocks of vertex_crop_kernel recompute it for the three corners of their triangle -- same expressions, no
+// contraction in this translation unit, hence the same bits)
 template <bool FMAD>
-__device__ __forceinline__ void vertex_body(const float *__restrict__ verts, const float *__restrict__ normals, int V, int v, int n, const PoseRec &rec,
-                                            float4 *__restrict__ clip, float4 *__restrict__ attr, float4 *__restrict__ dbg, unsigned long long t_begin) {
-  const float *M = rec.M, *pose = rec.pose;
-  float x = verts[v * 3], y = verts[v * 3 + 1], z = verts[v * 3 + 2];
+__device__ __forceinline__ float4 clip_of(const PoseRec &rec, float x, float y, float z) {
+  const float *M = rec.M;
   float tx = dot3<FMAD>(M[0], x, M[4], y, M[8], z) + M[12];
   float ty = dot3<FMAD>(M[1], x, M[5], y, M[9], z) + M[13];
   float tz = dot3<FMAD>(M[2], x, M[6], y, M[10], z) + M[14];
@@ -207,6 +207,16 @@ __device__ __forceinline__ void vertex_body(const float *__restrict__ verts, con
   c.y = mad<FMAD>(tw, rec.a31, ty * rec.a11);
   c.z = tz;
   c.w = tw;
+  return c;
+}
+
+// one vertex of hypothesis n under the record `rec`
+template <bool FMAD>
+__device__ __forceinline__ void vertex_body(const float *__restrict__ verts, const float *__restrict__ normals, int V, int v, int n, const PoseRec &rec,
+                                            float4 *__restrict__ clip, float4 *__restrict__ attr, float4 *__restrict__ dbg, unsigned long long t_begin) {
+  const float *pose = rec.pose;
+  float x = verts[v * 3], y = verts[v * 3 + 1], z = verts[v * 3 + 2];
+  const float4 c = clip_of<FMAD>(rec, x, y, z);
   float4 a;
   a.x = dot3<FMAD>(pose[0], x, pose[4], y, pose[8], z) + pose[12];
   a.y = dot3<FMAD>(pose[1], x, pose[5], y, pose[9], z) + pose[13];
@@ -464,15 +474,9 @@ __device__ __noinline__ void raster_clipped(float4 v0, float4 v1, float4 v2, uns
 // skipped is one raster_one would have left at its bounding-box test; triangles on the clipping path get the whole crop, culled or
 // degenerate ones the empty range.  Packed lo | hi << 16; empty = 1 | 0 << 16.
 constexpr unsigned TRI_ROWS_EMPTY = 1u, TRI_ROWS_ALL = (unsigned)(CROP - 1) << 16;
-__global__ __launch_bounds__(256) void tri_rows_kernel(const int32_t *__restrict__ faces, int F, int V, const float4 *__restrict__ clip_all,
-                                                       unsigned *__restrict__ rows_all) {
-  const int f = blockIdx.x * 256 + threadIdx.x, n = blockIdx.y;
-  if (f >= F) return;
-  const float4 *clip = clip_all + (size_t)n * V;
+__device__ __forceinline__ unsigned tri_rows_of(const float4 v0, const float4 v1, const float4 v2) {
   unsigned out = TRI_ROWS_EMPTY;
-  const int i0 = faces[f * 3], i1 = faces[f * 3 + 1], i2 = faces[f * 3 + 2];
-  if ((unsigned)i0 < (unsigned)V && (unsigned)i1 < (unsigned)V && (unsigned)i2 < (unsigned)V) {
-    const float4 v0 = clip[i0], v1 = clip[i1], v2 = clip[i2];
+  {
     bool culled = false;
     if ((v0.w < fabsf(v0.x)) | (v0.w < fabsf(v0.y)) | (v0.w < fabsf(v0.z))) {
       culled = ((v0.w < +v0.x) & (v1.w < +v1.x) & (v2.w < +v2.x)) | ((v0.w < -v0.x) & (v1.w < -v1.x) & (v2.w < -v2.x)) |
@@ -500,6 +504,16 @@ __global__ __launch_bounds__(256) void tri_rows_kernel(const int32_t *__restrict
       }
     }
   }
+  return out;
+}
+__global__ __launch_bounds__(256) void tri_rows_kernel(const int32_t *__restrict__ faces, int F, int V, const float4 *__restrict__ clip_all,
+                                                       unsigned *__restrict__ rows_all) {
+  const int f = blockIdx.x * 256 + threadIdx.x, n = blockIdx.y;
+  if (f >= F) return;
+  const float4 *clip = clip_all + (size_t)n * V;
+  unsigned out = TRI_ROWS_EMPTY;
+  const int i0 = faces[f * 3], i1 = faces[f * 3 + 1], i2 = faces[f * 3 + 2];
+  if ((unsigned)i0 < (unsigned)V && (unsigned)i1 < (unsigned)V && (unsigned)i2 < (unsigned)V) out = tri_rows_of(clip[i0], clip[i1], clip[i2]);
   rows_all[(size_t)n * F + f] = out;
 }
 void launch_tri_rows(hipStream_t s, const DeviceMesh &m, int N, const float4 *clip, unsigned *rows) {
@@ -1041,9 +1055,29 @@ template <bool FMAD, int MODE>
 __global__ __launch_bounds__(256) void vertex_crop_kernel(const float *__restrict__ verts, const float *__restrict__ normals, int V, int nvb,
                                                           PoseRec *__restrict__ recs, float4 *__restrict__ clip, float4 *__restrict__ attr,
                                                           const PoseSetupArgs sa, const FrameRef *__restrict__ frame, int n_crop,
-                                                          void *__restrict__ out_b) {
+                                                          void *__restrict__ out_b, const int32_t *__restrict__ faces, int F,
+                                                          unsigned *__restrict__ tri_rows) {
   const int n = blockIdx.y;
   PoseRec own;
+  constexpr int NCB = (CROP * CROP + 255) / 256;
+  if ((int)blockIdx.x >= nvb + NCB) {
+    // [r4] row-range blocks (present when tri_rows != null): the range of a triangle needs its three clip positions, which the
+    // vertex blocks of THIS launch are still writing -- so they are recomputed here from the model vertices (clip_of: the
+    // same expressions on the same record, identical values), and the separate tri_rows_kernel launch disappears
+    const int f = ((int)blockIdx.x - nvb - NCB) * 256 + threadIdx.x;
+    if (f >= F) return;
+    unsigned out = TRI_ROWS_EMPTY;
+    const int i0 = faces[f * 3], i1 = faces[f * 3 + 1], i2 = faces[f * 3 + 2];
+    if ((unsigned)i0 < (unsigned)V && (unsigned)i1 < (unsigned)V && (unsigned)i2 < (unsigned)V) {
+      make_pose_rec(sa.poses, n, sa.K, sa.img_h, sa.img_w, sa.crop_ratio, sa.diameter, own);
+      const float4 c0 = clip_of<FMAD>(own, verts[i0 * 3], verts[i0 * 3 + 1], verts[i0 * 3 + 2]);
+      const float4 c1 = clip_of<FMAD>(own, verts[i1 * 3], verts[i1 * 3 + 1], verts[i1 * 3 + 2]);
+      const float4 c2 = clip_of<FMAD>(own, verts[i2 * 3], verts[i2 * 3 + 1], verts[i2 * 3 + 2]);
+      out = tri_rows_of(c0, c1, c2);
+    }
+    tri_rows[(size_t)n * F + f] = out;
+    return;
+  }
   if ((int)blockIdx.x < nvb) {
     const int v = blockIdx.x * 256 + threadIdx.x;
     if (v >= V) return;
@@ -1061,15 +1095,16 @@ __global__ __launch_bounds__(256) void vertex_crop_kernel(const float *__restric
 // returns false when the combination is not instantiated (fp32 blobs): the caller then launches the two kernels
 bool launch_setup_vertex_crop(hipStream_t s, const DeviceMesh &m, const float *poses_dev, int N, const float *K9_host, int img_h, int img_w,
                               float crop_ratio, float diameter, PoseRec *recs, float4 *clip, float4 *attr, bool fmad, const FrameRef *frame,
-                              int n_crop, OutMode mode, void *out_b) {
+                              int n_crop, OutMode mode, void *out_b, unsigned *tri_rows) {
   if (mode == OUT_F32X6) return false;
   PoseSetupArgs sa;
   sa.poses = poses_dev;
   for (int i = 0; i < 9; i++) sa.K.k[i] = K9_host[i];
   sa.img_h = img_h; sa.img_w = img_w; sa.crop_ratio = crop_ratio; sa.diameter = diameter;
   const int nvb = (m.V + 255) / 256;
-  const dim3 grid(nvb + (CROP * CROP + 255) / 256, N);
-#define FP_VC(F, M) hipLaunchKernelGGL((vertex_crop_kernel<F, M>), grid, dim3(256), 0, s, m.verts, m.normals, m.V, nvb, recs, clip, attr, sa, frame, n_crop, out_b)
+  const int ntb = tri_rows && m.F > 0 ? (m.F + 255) / 256 : 0;   // row-range blocks (the rasteriser's tri_rows of these poses)
+  const dim3 grid(nvb + (CROP * CROP + 255) / 256 + ntb, N);
+#define FP_VC(FM_, MD_) hipLaunchKernelGGL((vertex_crop_kernel<FM_, MD_>), grid, dim3(256), 0, s, m.verts, m.normals, m.V, nvb, recs, clip, attr, sa, frame, n_crop, out_b, m.faces, m.F, tri_rows)
   if (mode == OUT_BF16X8) { if (fmad) FP_VC(true, OUT_BF16X8); else FP_VC(false, OUT_BF16X8); }
   else { if (fmad) FP_VC(true, OUT_F16X8); else FP_VC(false, OUT_F16X8); }
 #undef FP_VC

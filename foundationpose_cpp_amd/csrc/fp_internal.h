@@ -188,10 +188,11 @@ __device__ __forceinline__ void pose_update_one(float *poses, const float *__res
 }
 #endif
 struct FrameRef;
-// tiny batches: the same + the observed-crop warp of hypotheses [0, n_crop) in ONE launch (false: not available for this output mode)
+// tiny batches: the same + the observed-crop warp of hypotheses [0, n_crop) in ONE launch (false: not available for this output mode);
+// tri_rows non-null: the launch also leaves the [N, F] row ranges launch_tri_rows would compute from its clip coordinates
 bool launch_setup_vertex_crop(hipStream_t s, const DeviceMesh &m, const float *poses_dev, int N, const float *K9_host, int img_h, int img_w,
                               float crop_ratio, float diameter, PoseRec *recs, float4 *clip, float4 *attr, bool fmad, const FrameRef *frame,
-                              int n_crop, OutMode mode, void *out_b);
+                              int n_crop, OutMode mode, void *out_b, unsigned *tri_rows);
 // tri_rows: [N, F] row ranges from launch_tri_rows of the same clip coordinates (a strip then skips the triangles that miss it), or null
 void launch_tri_rows(hipStream_t s, const DeviceMesh &m, int N, const float4 *clip, unsigned *rows);
 bool raster_wants_tri_rows(int N);   // false for batches that are rendered in two tall strips per crop

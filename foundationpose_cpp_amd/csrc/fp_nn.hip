@@ -942,7 +942,8 @@ static int ensure_scratch(NNScratch *ws, int N, hipStream_t s) {
   int cap = std::max(N, 8);
   g_alloc_epoch++;
   FP_HIP_OK(hipMalloc((void **)&ws->buf, (size_t)cap * per_hyp_bytes(ws)));
-  FP_HIP_OK(hipMalloc((void **)&ws->f32, (size_t)cap * EMBED * sizeof(float)));
+  FP_HIP_OK(hipMalloc((void **)&ws->f32, ((size_t)cap * EMBED + 16) * sizeof(float)));   // + the arrival counter of token_mean_pose_kernel
+  FP_HIP_OK(hipMemsetAsync(ws->f32 + (size_t)cap * EMBED, 0, 16 * sizeof(float), s));
   // the zero borders are written here once and never again: every producer stores interiors only, and the arena is
   // carved by CAPACITY (not by the current N), so an image slot's border never moves
   FP_HIP_OK(hipMemsetAsync(ws->buf, 0, (size_t)cap * PER_HYP, s));
@@ -1006,7 +1007,7 @@ FP_HOOK g_smallm_maxkt = 80;   // the small-problem kernel takes layers with few
 FP_HOOK g_conv_lds_store = 0;  // conv_big_pp_kernel: epilogue stores staged through LDS (whole 128-byte lines per store instruction).  OFF: measured [r3] conv_512 3.205 -> 3.227 / 3.184 -> 3.180 ms, i.e. nothing -- the 256x256 tile's store burst is not bound by the store shape (unlike gemm_k32_kernel's, -6 %)
 FP_HOOK g_gemm_lds_store = 1;  // gemm_k32_kernel: output rows leave through LDS as whole 256-byte runs instead of 64-byte pieces per store instruction
 FP_HOOK g_smallm_maxt16 = 1024; // ... and with at most this many 16-pixel x 64-channel tiles (the grouped QKV of Track has 1200)
-FP_HOOK g_fuse_pose = 1;       // Track: both Linear(512,3) heads + RefinePostProcess in one kernel (small_linear2_pose_kernel)
+FP_HOOK g_fuse_pose = 1;       // Track: 1 = both Linear(512,3) heads + RefinePostProcess in one kernel (small_linear2_pose_kernel), 0 = two kernels, 2 = A/B: the token mean in that kernel too (token_mean_pose_kernel, last-arriver; not faster)
 FP_HOOK g_gemm_wpack = 1;      // gemm_k32_kernel streams its weights from the stage-order copy (one address + one M0 per four LDS-DMA pieces)
 FP_HOOK g_deep_wpack = 1;      // conv_deep_kernel streams its weights from the stage-order copy
 FP_HOOK g_big_wpack = 1;       // conv_big_pp_kernel streams its weights from the stage-order copy
@@ -1869,6 +1870,21 @@ int refiner_forward(hipStream_t s, Profiler *prof, const Net *net, NNScratch *ws
     if (run_gemm(c, "gemm_512", net->g_lin2, a.y1, 2 * G, a.att, false, a.y2, &g_own)) return 1;   // + residual x1
     // (two sequences only: LayerNorm over 800 workgroup-rows + a 16-workgroup mean beat the one-workgroup-per-sequence fused kernel, 11 vs 20 us)
     run_layernorm(c, dt, a.att, T0.ln2, a.y1, 2 * G, &R0.ln2, G);
+#ifdef FP_TEST_HOOKS
+    if (fuse && g_fuse_pose == 2 && T0.head.out == 3 && R0.head.out == 3 && T0.head.in == EMBED) {
+      // A/B (test build): token mean + both heads + RefinePostProcess as one launch whose last workgroup runs the heads -- measured
+      // no faster than the two launches (14.0 us against 6.0 + 6.6 in the replayed graph: the release / acquire pair and the 16
+      // same-address atomics across XCDs cost what the launch did), DESIGN.md section 8
+      ProfScope ps(c.prof, c.s, "token_mean", 0, 2.0 * 400 * EMBED * 2.0);
+      SmallLinear2 sl{{ws->f32, ws->f32 + EMBED}, {T0.head.w, R0.head.w}, {T0.head.b, R0.head.b}, {trans_dev, rot_dev}};
+      unsigned *arrivals = reinterpret_cast<unsigned *>(ws->f32 + (size_t)ws->cap * EMBED);
+      if (dt == DT_BF16) hipLaunchKernelGGL(token_mean_pose_kernel<DT_BF16>, dim3(2, EMBED / 64), dim3(384), 0, c.s, (const __bf16 *)a.y1, ws->f32, 400, G, arrivals, sl, T0.head.in, *fuse);
+      else hipLaunchKernelGGL(token_mean_pose_kernel<DT_F16>, dim3(2, EMBED / 64), dim3(384), 0, c.s, (const _Float16 *)a.y1, ws->f32, 400, G, arrivals, sl, T0.head.in, *fuse);
+      if (fused_out) *fused_out = true;
+      FP_HIP_OK(hipGetLastError());
+      return 0;
+    }
+#endif
     run_token_mean(c, dt, a.y1, ws->f32, 2, 400, G);
     {
       ProfScope ps(c.prof, c.s, "small_linear", 2.0 * 2 * T0.head.out * T0.head.in, 0);

@@ -408,8 +408,8 @@ mesh = syn.make_mesh(); scene = syn.make_scene(mesh)
 d = tempfile.mkdtemp(); rp, sp = os.path.join(d, "r.fpw"), os.path.join(d, "s.fpw")
 W.pack_synthetic("refiner", rp); W.pack_synthetic("scorer", sp)
 hyp = syn.perturb_pose(scene.gt_pose)
-for vc in (0, 1):
-    for fu in (0, 1):
+for vc in (0, 1, 2):            # 2: fused vertex + crop launch, the triangles' row ranges as their own launch
+    for fu in (0, 1, 2):         # 1: heads + RefinePostProcess in one launch (the product), 2: the token mean in that launch too (A/B)
         L.fpt_set_vertex_crop(vc); L.fpt_set_fuse_pose(fu)
         m = FoundationPose(mesh, scene.K, rp, sp)
         poses = []
@@ -424,9 +424,10 @@ for vc in (0, 1):
 
 @pytest.mark.gpu
 def test_track_launch_fusions_do_not_change_a_bit(tmp_path):
-    """Track's fused launches (pose set-up + vertex stage + crop warp in one kernel; both Linear(512,3) heads + RefinePostProcess in
-    one kernel) against the separate kernels they replace, in the test build where both forms exist: every pose of an eager call, a
-    graph capture, a replay and a two-iteration Track is bit-identical in all four combinations."""
+    """Track's fused launches (pose set-up + vertex stage + crop warp + the triangles' row ranges in one kernel; both Linear(512,3) heads
+    + RefinePostProcess in one kernel; the A/B form whose last workgroup also ran the token mean) against the separate kernels they
+    replace, in the test build where every form exists: every pose of an eager call, a graph capture, a replay and a two-iteration
+    Track is bit-identical in all nine combinations."""
     import subprocess
     import sys
     script = tmp_path / "fusions.py"
@@ -435,7 +436,7 @@ def test_track_launch_fusions_do_not_change_a_bit(tmp_path):
     res = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600, env=env)
     assert res.returncode == 0, res.stderr[-2000:]
     lines = [l.split() for l in res.stdout.splitlines() if l.startswith("POSES")]
-    assert len(lines) == 4
+    assert len(lines) == 9
     assert len({l[3] for l in lines}) == 1, [(l[1], l[2]) for l in lines]
 
 
@@ -478,8 +479,9 @@ IMG = 84 * 84 * 32 * 2
 H, Wd = scene.depth.shape
 for n in (1, 3, 12, 33, 60):
     packed, _ = be.buffers(n, 1)
-    for rows, threads in ((1, 0), (0, 0), (1, 256), (0, 256), (1, 1024)):
+    for rows, threads, vc in ((1, 0, 1), (0, 0, 1), (1, 256, 1), (0, 256, 1), (1, 1024, 1), (1, 0, 2)):
         L.fpt_set_tri_rows(rows); L.fpt_set_raster_strip_threads(threads)
+        L.fpt_set_vertex_crop(vc)       # 1: row ranges computed inside the vertex + crop launch of tiny batches, 2: by tri_rows_kernel
         if n == 1:
             ok, _ = m.Track(scene.rgb, scene.depth, syn.perturb_pose(scene.gt_pose), mesh.name)
             assert ok
@@ -508,10 +510,10 @@ def test_rasteriser_row_ranges_and_strip_widths_do_not_change_a_bit(tmp_path):
     res = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600, env=env)
     assert res.returncode == 0, res.stderr[-2000:]
     lines = [l.split() for l in res.stdout.splitlines() if l.startswith("BLOB")]
-    assert len(lines) == 10 + 25, res.stdout[-2000:]
+    assert len(lines) == 10 + 30, res.stdout[-2000:]
     for kind in ("f32", "f16"):
         for n in ("1", "3", "12", "33", "60"):
             group = [l for l in lines if l[1] == kind and l[2] == n]
-            assert len(group) == (2 if kind == "f32" else 5)
+            assert len(group) == (2 if kind == "f32" else 6)
             assert len({l[5] for l in group}) == 1, [(kind, n, l[3], l[4], l[5][:12]) for l in group]
             assert float(group[0][6]) > 0.0            # something was rendered
