@@ -163,7 +163,7 @@ const RoctxApi &roctx_api() {
 void roctx_push(const char *name) { if (roctx_api().push) (void)roctx_api().push(name); }
 void roctx_pop() { if (roctx_api().pop) (void)roctx_api().pop(); }
 #ifdef FP_TEST_HOOKS
-static int g_upload_cols = 1;   // A/B (fpt_set_upload_cols): Track from host frames uploads the crop window's rectangle, not whole rows
+static int g_upload_cols = 1;   // A/B (fpt_set_upload_cols): Track from host frames uploads the crop window's rectangle, not whole rows (1: packed into pinned memory with its frame record, one 1-D copy; 2: two 2-D copies straight from the caller's pageable frame)
 #else
 static constexpr int g_upload_cols = 1;
 #endif
@@ -338,6 +338,10 @@ struct fp_model {
   uint8_t *rgb_own = nullptr;
   float *depth_own = nullptr;
   FrameRef *frame_dev = nullptr, *frame_pinned = nullptr;  // what kernels inside graphs read the frame through
+  // [r4] frame_dev heads a device block [FrameRef | 64 | packed window]: Track's crop window of a host frame is packed (record, rgb
+  // rows, depth rows) into the pinned twin win_stage and arrives with ONE copy, record included
+  uint8_t *win_stage = nullptr;
+  size_t win_cap = 0;             // bytes of either block (0: no window path)
   FrameRef frame_pub = {nullptr, nullptr};                 // last published value
   unsigned frame_pub_count = 0;
   float *multi_io = nullptr, *multi_io_dev = nullptr;  // host-pinned [K poses in | K poses out] of fp_track_multi
@@ -829,7 +833,9 @@ fp_model *fp_create_on(int device, const fp_mesh *meshes, int n_meshes, const fl
   if (max_w > 0) m->max_w = max_w;
   // non-blocking: no implicit synchronisation with the legacy null stream (other models' threads, the caller's framework)
   if (stream_acquire(&m->stream) != hipSuccess) { set_error("[FoundationPose] Failed to create stream"); return nullptr; }
-  if (hipMalloc((void **)&m->frame_dev, sizeof(FrameRef)) != hipSuccess ||
+  static_assert(sizeof(FrameRef) <= 64, "the packed window starts 64 bytes into the frame block");
+  m->win_cap = 64 + (size_t)m->max_h * m->max_w * 7 / 2 + 256;   // a window that takes this path is at most half the frame wide
+  if (hipMalloc((void **)&m->frame_dev, m->win_cap) != hipSuccess ||
       hipHostMalloc((void **)&m->frame_pinned, 8 * sizeof(FrameRef), hipHostMallocDefault) != hipSuccess) {
     set_error("[FoundationPose] Failed to allocate the frame record");
     return nullptr;
@@ -905,6 +911,7 @@ static void destroy_model_impl(fp_model *m) {
   if (m->poses_pinned) (void)hipHostFree(m->poses_pinned);
   if (m->track_io) (void)hipHostFree(m->track_io);
   if (m->frame_pinned) (void)hipHostFree(m->frame_pinned);
+  if (m->win_stage) (void)hipHostFree(m->win_stage);
   if (m->frame_dev) (void)hipFree(m->frame_dev);
   dev_free(m->grid_dev); dev_free(m->samp_state); dev_free(m->samp_vals); dev_free(m->mask_dev);
   if (m->digests) (void)hipFree(m->digests);
@@ -969,10 +976,40 @@ static int upload_frame_async(fp_model *m, const void *rgb, const void *depth, i
     if (n && cw && g_upload_cols && cw * 2 <= (size_t)W) {
       // the window is less than half the frame wide: a 2-D copy of the rectangle (same device pitch: the kernels index whole frames)
       m->frame_partial = true;
-      const size_t oc = o + col0;
-      FP_HIP_OK(hipMemcpy2DAsync(m->rgb_own + oc * 3, (size_t)W * 3, (const uint8_t *)rgb + oc * 3, (size_t)W * 3, cw * 3, (size_t)(row1 - row0),
+      const size_t oc = o + col0, nr = (size_t)(row1 - row0);
+      const size_t rgb_bytes = (nr * cw * 3 + 63) & ~(size_t)63, total = 64 + rgb_bytes + nr * cw * 4;
+      if (g_upload_cols == 1 && total <= m->win_cap) {
+        // [r4] The caller's frame is pageable: a 2-D copy from it is staged inside the runtime and holds the calling thread until it
+        // is done (two of them: ~48 us of a 260 us Track).  The window is packed here into the model's own pinned block instead (a
+        // few hundred short memcpys, ~0.2 MB) TOGETHER with the frame record that describes it, and leaves with ONE asynchronous
+        // 1-D copy (2-D copies from pinned memory are no alternative: 1.07 ms per Track); crop_body reads the packed window through
+        // the record's pitch and virtual origins.  The caller's buffers are free again when this function returns.  The pinned
+        // block is reused by the next call: a model's Track is waited for (fp_track_wait) before its next submission.
+        if (!m->win_stage) FP_HIP_OK(hipHostMalloc((void **)&m->win_stage, m->win_cap, hipHostMallocDefault));
+        uint8_t *dev_block = reinterpret_cast<uint8_t *>(m->frame_dev);
+        uint8_t *sr = m->win_stage + 64;
+        float *sd = reinterpret_cast<float *>(m->win_stage + 64 + rgb_bytes);
+        const uint8_t *ur = (const uint8_t *)rgb + oc * 3;
+        const float *ud = (const float *)depth + oc;
+        for (size_t r = 0; r < nr; r++) {
+          std::memcpy(sr + r * cw * 3, ur + r * (size_t)W * 3, cw * 3);
+          std::memcpy(sd + r * cw, ud + r * (size_t)W, cw * 4);
+        }
+        FrameRef rec;
+        const long long org = (long long)row0 * (long long)cw + col0;   // packed index of frame pixel (0, 0)
+        rec.rgb = dev_block + 64 - org * 3;
+        rec.depth = reinterpret_cast<const float *>(dev_block + 64 + rgb_bytes) - org;
+        rec.pitch = (int)cw;
+        rec.wx0 = col0; rec.wx1 = col1; rec.wy0 = row0; rec.wy1 = row1;
+        std::memcpy(m->win_stage, &rec, sizeof(rec));
+        FP_HIP_OK(hipMemcpyAsync(dev_block, m->win_stage, total, hipMemcpyHostToDevice, m->stream));
+        m->frame_pub = rec;
+        m->rgb = m->rgb_own; m->depth = m->depth_own;   // (hold nothing of this frame: frame_partial)
+        return 0;
+      }
+      FP_HIP_OK(hipMemcpy2DAsync(m->rgb_own + oc * 3, (size_t)W * 3, (const uint8_t *)rgb + oc * 3, (size_t)W * 3, cw * 3, nr,
                                  hipMemcpyHostToDevice, m->stream));
-      FP_HIP_OK(hipMemcpy2DAsync(m->depth_own + oc, (size_t)W * 4, (const float *)depth + oc, (size_t)W * 4, cw * 4, (size_t)(row1 - row0),
+      FP_HIP_OK(hipMemcpy2DAsync(m->depth_own + oc, (size_t)W * 4, (const float *)depth + oc, (size_t)W * 4, cw * 4, nr,
                                  hipMemcpyHostToDevice, m->stream));
     } else if (n) {
       FP_HIP_OK(hipMemcpyAsync(m->rgb_own + o * 3, (const uint8_t *)rgb + o * 3, n * 3, hipMemcpyHostToDevice, m->stream));
@@ -984,6 +1021,7 @@ static int upload_frame_async(fp_model *m, const void *rgb, const void *depth, i
   if (m->frame_pub.rgb != m->rgb || m->frame_pub.depth != m->depth) {
     // (a ring of pinned records: the asynchronous shard entry points return before the copy has run)
     FrameRef *slot = m->frame_pinned + (m->frame_pub_count++ & 7);
+    *slot = FrameRef{};   // whole frame: no pitch, no window
     slot->rgb = m->rgb; slot->depth = m->depth;
     FP_HIP_OK(hipMemcpyAsync(m->frame_dev, slot, sizeof(FrameRef), hipMemcpyHostToDevice, m->stream));
     m->frame_pub = *slot;

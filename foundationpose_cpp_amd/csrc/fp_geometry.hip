@@ -991,6 +991,11 @@ __device__ __forceinline__ void crop_body(const FrameRef *__restrict__ frame, in
                                           const PoseRec &rec, float downscale, void *__restrict__ out_all, int n, int i) {
   const uint8_t *__restrict__ rgb = frame->rgb;
   const float *__restrict__ depth = frame->depth;
+  // (whole frames: P = W and the window tests are always true; a packed window never lacks a pixel this function reads -- the
+  // host-side window estimate has a margin and tests/test_nn_gpu.py compares against whole frames -- the tests only make an
+  // estimate that were wrong read a zero instead of foreign memory)
+  const int P = frame->pitch > 0 ? frame->pitch : W;
+  const int wx0 = frame->wx0, wy0 = frame->wy0, wx1 = frame->wx1, wy1 = frame->wy1;
   const int y = i / CROP, x = i - y * CROP;
   float sxf = rec.m0 * (float)x + rec.m2, syf = rec.m4 * (float)y + rec.m5;
   // degenerate hypotheses (tz ~ 0: a crop window of 1e13 pixels) give source coordinates far outside any image, or NaN; clamp them
@@ -1002,9 +1007,9 @@ __device__ __forceinline__ void crop_body(const FrameRef *__restrict__ frame, in
   {
     int x0 = (int)floorf(sxf), y0 = (int)floorf(syf);
     float ax = sxf - (float)x0, ay = syf - (float)y0;
-    bool vx0 = x0 >= 0 && x0 < W, vx1 = x0 + 1 >= 0 && x0 + 1 < W;
-    bool vy0 = y0 >= 0 && y0 < H, vy1 = y0 + 1 >= 0 && y0 + 1 < H;
-    const uint8_t *r0 = rgb + ((size_t)y0 * W + x0) * 3, *r1 = rgb + ((size_t)(y0 + 1) * W + x0) * 3;
+    bool vx0 = x0 >= 0 && x0 < W && x0 >= wx0 && x0 < wx1, vx1 = x0 + 1 >= 0 && x0 + 1 < W && x0 + 1 >= wx0 && x0 + 1 < wx1;
+    bool vy0 = y0 >= 0 && y0 < H && y0 >= wy0 && y0 < wy1, vy1 = y0 + 1 >= 0 && y0 + 1 < H && y0 + 1 >= wy0 && y0 + 1 < wy1;
+    const uint8_t *r0 = rgb + ((long long)y0 * P + x0) * 3, *r1 = rgb + ((long long)(y0 + 1) * P + x0) * 3;
     float w00 = (1.0f - ax) * (1.0f - ay), w10 = ax * (1.0f - ay), w01 = (1.0f - ax) * ay, w11 = ax * ay;
     for (int ch = 0; ch < 3; ch++) {
       float p00 = (vy0 && vx0) ? (float)r0[ch] : 0.0f, p10 = (vy0 && vx1) ? (float)r0[3 + ch] : 0.0f;
@@ -1018,8 +1023,8 @@ __device__ __forceinline__ void crop_body(const FrameRef *__restrict__ frame, in
   {
     int xn = (int)floorf(sxf + 0.5f), yn = (int)floorf(syf + 0.5f);
     float p0 = 0, p1 = 0, p2 = 0;
-    if (xn >= 0 && xn < W && yn >= 0 && yn < H) {
-      float d = depth[(size_t)yn * W + xn];
+    if (xn >= 0 && xn < W && yn >= 0 && yn < H && xn >= wx0 && xn < wx1 && yn >= wy0 && yn < wy1) {
+      float d = depth[(long long)yn * P + xn];
       if (!(d < 0.001f)) { p0 = ((float)xn - cx) * d / fx; p1 = ((float)yn - cy) * d / fy; p2 = d; }
     }
     bool invalid = p2 < FP_MIN_DEPTH;

@@ -206,9 +206,14 @@ void set_raster_strip_threads(int threads);  // 0 = by batch size; 256 / 512 / 1
 #endif
 // the frame a replayed hipGraph reads: kernels inside graphs take the frame through this device-resident record, so a caller's
 // device frame is used in place (no copy into model-owned buffers) and the graph stays valid when the pointers change
+// how the kernels of a (replayed) graph find the current frame.  Whole frames: pitch = 0 (rows are W pixels apart), window = all.
+// [r4] Track's packed crop window of a host frame: rgb / depth are VIRTUAL origins (the address pixel (0, 0) would have if the packed
+// window were part of a frame with rows `pitch` pixels apart), and only pixels inside [wx0, wx1) x [wy0, wy1) exist.
 struct FrameRef {
   const uint8_t *rgb;
   const float *depth;
+  int pitch = 0;
+  int wx0 = 0, wy0 = 0, wx1 = 0x7fffffff, wy1 = 0x7fffffff;
 };
 void launch_crop(hipStream_t s, const FrameRef *frame_dev, int H, int W, const float *K9_host,
                  const PoseRec *recs, int N, float diameter, OutMode mode, void *out);

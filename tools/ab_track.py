@@ -14,7 +14,7 @@ L = _lib.lib()
 for v in values:
     getattr(L, hook)(v)
     m = FoundationPose(mesh, scene.K, rp, sp)      # fresh model: the Track graph is captured under this setting
-    rgb, depth = scene.rgb, scene.depth              # host frame: a constant ~115 us H2D rides on every number
+    rgb, depth = scene.rgb, scene.depth              # host frame: the upload of the crop window rides on every number
     for _ in range(10):
         m.Track(rgb, depth, hyp, mesh.name)
     t0 = time.perf_counter()
