@@ -43,7 +43,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_FP16_TFLOPS = 2500.0   # MI355X dense fp16/bf16 MFMA peak (MI355X_MICROARCH.md)
 PEAK_FP8_TFLOPS = 5000.0    # dense FP8 (v_mfma_f32_16x16x128_f8f6f4), same guide
-PMC_FILE = "r04e_register_n252_pmc_hbm.json"   # committed FETCH_SIZE / WRITE_SIZE passes of this round
+PMC_FILE = "r04i_register_n252_pmc_hbm.json"   # committed FETCH_SIZE / WRITE_SIZE passes of this round
 BASELINE_HYP_S = 705.6      # reference README.md:37-41: Register 2.8 fps x 252 on RTX 4060 (TensorRT fp16)
 
 

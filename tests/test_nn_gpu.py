@@ -555,6 +555,47 @@ def test_track_partial_row_upload_random_windows(nets, syn_mesh):
         m2.close()
 
 
+def test_track_window_upload_alternates_with_whole_frames(nets, syn_mesh):
+    """[r4] ONE model served in turn from host frames (the packed crop window + its own frame record, one copy), from frames resident
+    in device memory, from host frames whose window is too wide to be packed (whole rows), and by a Register in between: every Track
+    equals the Track of a second model that only ever reads whole device frames -- the frame record the replayed graph reads is
+    re-published whenever the source changes"""
+    rng = np.random.default_rng(5)
+    K = syn.intrinsics()
+    m1 = FoundationPose(syn_mesh, K, nets[0], nets[1])
+    m2 = FoundationPose(syn_mesh, K, nets[0], nets[1])
+    scene = syn.make_scene(syn_mesh)
+    base = syn.perturb_pose(syn.pose_matrix(syn.random_rotation(3), [0, 0, 0.7]).astype(np.float32))
+    out = np.zeros(16, np.float32)
+
+    def device_track(m, rgb, depth, hyp):
+        r_d, d_d = torch.from_numpy(rgb).cuda(), torch.from_numpy(depth).cuda()
+        m._must(m._L.fp_track_ex(m.handle, C.c_void_p(r_d.data_ptr()), C.c_void_p(d_d.data_ptr()), 1, 480, 640,
+                                 _p(syn.to_colmajor(hyp[None])[0]), syn_mesh.name.encode(), 1, _p(out)))
+        return syn.from_colmajor(out[None])[0].copy()
+
+    try:
+        for k, kind in enumerate(["host", "host", "device", "host", "wide", "host", "register", "host", "device", "wide", "host", "host"]):
+            rgb = rng.integers(0, 256, (480, 640, 3), dtype=np.uint8)
+            depth = rng.uniform(0.2, 2.0, (480, 640)).astype(np.float32)
+            hyp = base.copy()
+            tz = 0.25 if kind == "wide" else rng.uniform(0.5, 1.2)      # 0.25 m: the crop window is wider than half the frame
+            hyp[:3, 3] = [rng.uniform(-0.2, 0.2) * tz, rng.uniform(-0.2, 0.2) * tz, tz]
+            if kind == "register":
+                ok, _ = m1.Register(scene.rgb, scene.depth, scene.mask, syn_mesh.name)
+                assert ok, m1.last_error
+                continue
+            if kind == "device":
+                p1 = device_track(m1, rgb, depth, hyp)
+            else:
+                ok, p1 = m1.Track(rgb, depth, hyp, syn_mesh.name)
+                assert ok, m1.last_error
+            np.testing.assert_array_equal(p1, device_track(m2, rgb, depth, hyp), err_msg=f"step {k} ({kind})")
+    finally:
+        m1.close()
+        m2.close()
+
+
 def test_native_sharded_register_world_1(model, syn_mesh, syn_scene):
     """fp_register_sharded through the Python host: an RCCL communicator of size 1 made with the process's librccl (NativeRcclComm), the
     library's own begin -> exchange -> finish on its stream; the result is the unsharded Register's, bit for bit.  (The C++ twin with
