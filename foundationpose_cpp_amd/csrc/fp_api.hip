@@ -835,7 +835,7 @@ fp_model *fp_create_on(int device, const fp_mesh *meshes, int n_meshes, const fl
   if (stream_acquire(&m->stream) != hipSuccess) { set_error("[FoundationPose] Failed to create stream"); return nullptr; }
   static_assert(sizeof(FrameRef) <= 64, "the packed window starts 64 bytes into the frame block");
   m->win_cap = 64 + (size_t)m->max_h * m->max_w * 7 / 2 + 256;   // a window that takes this path is at most half the frame wide
-  if (hipMalloc((void **)&m->frame_dev, m->win_cap) != hipSuccess ||
+  if (hipMalloc((void **)&m->frame_dev, m->win_cap) != hipSuccess || hipHostMalloc((void **)&m->win_stage, m->win_cap, hipHostMallocDefault) != hipSuccess ||
       hipHostMalloc((void **)&m->frame_pinned, 8 * sizeof(FrameRef), hipHostMallocDefault) != hipSuccess) {
     set_error("[FoundationPose] Failed to allocate the frame record");
     return nullptr;
@@ -978,14 +978,13 @@ static int upload_frame_async(fp_model *m, const void *rgb, const void *depth, i
       m->frame_partial = true;
       const size_t oc = o + col0, nr = (size_t)(row1 - row0);
       const size_t rgb_bytes = (nr * cw * 3 + 63) & ~(size_t)63, total = 64 + rgb_bytes + nr * cw * 4;
-      if (g_upload_cols == 1 && total <= m->win_cap) {
+      if (g_upload_cols == 1 && m->win_stage && total <= m->win_cap) {
         // [r4] The caller's frame is pageable: a 2-D copy from it is staged inside the runtime and holds the calling thread until it
         // is done (two of them: ~48 us of a 260 us Track).  The window is packed here into the model's own pinned block instead (a
         // few hundred short memcpys, ~0.2 MB) TOGETHER with the frame record that describes it, and leaves with ONE asynchronous
         // 1-D copy (2-D copies from pinned memory are no alternative: 1.07 ms per Track); crop_body reads the packed window through
         // the record's pitch and virtual origins.  The caller's buffers are free again when this function returns.  The pinned
         // block is reused by the next call: a model's Track is waited for (fp_track_wait) before its next submission.
-        if (!m->win_stage) FP_HIP_OK(hipHostMalloc((void **)&m->win_stage, m->win_cap, hipHostMallocDefault));
         uint8_t *dev_block = reinterpret_cast<uint8_t *>(m->frame_dev);
         uint8_t *sr = m->win_stage + 64;
         float *sd = reinterpret_cast<float *>(m->win_stage + 64 + rgb_bytes);
@@ -997,8 +996,9 @@ static int upload_frame_async(fp_model *m, const void *rgb, const void *depth, i
         }
         FrameRef rec;
         const long long org = (long long)row0 * (long long)cw + col0;   // packed index of frame pixel (0, 0)
-        rec.rgb = dev_block + 64 - org * 3;
-        rec.depth = reinterpret_cast<const float *>(dev_block + 64 + rgb_bytes) - org;
+        // (virtual origins lie outside the block: formed as integers, only ever dereferenced inside the window)
+        rec.rgb = reinterpret_cast<const uint8_t *>(reinterpret_cast<uintptr_t>(dev_block) + 64 - (uintptr_t)(org * 3));
+        rec.depth = reinterpret_cast<const float *>(reinterpret_cast<uintptr_t>(dev_block) + 64 + rgb_bytes - (uintptr_t)(org * 4));
         rec.pitch = (int)cw;
         rec.wx0 = col0; rec.wx1 = col1; rec.wy0 = row0; rec.wy1 = row1;
         std::memcpy(m->win_stage, &rec, sizeof(rec));
