@@ -163,7 +163,7 @@ const RoctxApi &roctx_api() {
 void roctx_push(const char *name) { if (roctx_api().push) (void)roctx_api().push(name); }
 void roctx_pop() { if (roctx_api().pop) (void)roctx_api().pop(); }
 #ifdef FP_TEST_HOOKS
-static int g_upload_cols = 1;   // A/B (fpt_set_upload_cols): Track from host frames uploads the crop window's rectangle, not whole rows (1: packed into pinned memory with its frame record, one 1-D copy; 2: two 2-D copies straight from the caller's pageable frame)
+static int g_upload_cols = 1;   // A/B (fpt_set_upload_cols): Track from host frames uploads the crop window's rectangle, not whole rows (1: packed into pinned memory with its frame record and fetched by a kernel; 3: the same with one 1-D copy command; 2: two 2-D copies straight from the caller's pageable frame)
 #else
 static constexpr int g_upload_cols = 1;
 #endif
@@ -340,7 +340,7 @@ struct fp_model {
   FrameRef *frame_dev = nullptr, *frame_pinned = nullptr;  // what kernels inside graphs read the frame through
   // [r4] frame_dev heads a device block [FrameRef | 64 | packed window]: Track's crop window of a host frame is packed (record, rgb
   // rows, depth rows) into the pinned twin win_stage and arrives with ONE copy, record included
-  uint8_t *win_stage = nullptr;
+  uint8_t *win_stage = nullptr, *win_stage_dev = nullptr;   // (host address / the device's mapping of it)
   size_t win_cap = 0;             // bytes of either block (0: no window path)
   FrameRef frame_pub = {nullptr, nullptr};                 // last published value
   unsigned frame_pub_count = 0;
@@ -835,7 +835,8 @@ fp_model *fp_create_on(int device, const fp_mesh *meshes, int n_meshes, const fl
   if (stream_acquire(&m->stream) != hipSuccess) { set_error("[FoundationPose] Failed to create stream"); return nullptr; }
   static_assert(sizeof(FrameRef) <= 64, "the packed window starts 64 bytes into the frame block");
   m->win_cap = 64 + (size_t)m->max_h * m->max_w * 7 / 2 + 256;   // a window that takes this path is at most half the frame wide
-  if (hipMalloc((void **)&m->frame_dev, m->win_cap) != hipSuccess || hipHostMalloc((void **)&m->win_stage, m->win_cap, hipHostMallocDefault) != hipSuccess ||
+  if (hipMalloc((void **)&m->frame_dev, m->win_cap) != hipSuccess || hipHostMalloc((void **)&m->win_stage, m->win_cap, hipHostMallocCoherent) != hipSuccess ||
+      hipHostGetDevicePointer((void **)&m->win_stage_dev, m->win_stage, 0) != hipSuccess ||
       hipHostMalloc((void **)&m->frame_pinned, 8 * sizeof(FrameRef), hipHostMallocDefault) != hipSuccess) {
     set_error("[FoundationPose] Failed to allocate the frame record");
     return nullptr;
@@ -978,13 +979,14 @@ static int upload_frame_async(fp_model *m, const void *rgb, const void *depth, i
       m->frame_partial = true;
       const size_t oc = o + col0, nr = (size_t)(row1 - row0);
       const size_t rgb_bytes = (nr * cw * 3 + 63) & ~(size_t)63, total = 64 + rgb_bytes + nr * cw * 4;
-      if (g_upload_cols == 1 && m->win_stage && total <= m->win_cap) {
+      if ((g_upload_cols == 1 || g_upload_cols == 3) && m->win_stage && total <= m->win_cap) {
         // [r4] The caller's frame is pageable: a 2-D copy from it is staged inside the runtime and holds the calling thread until it
         // is done (two of them: ~48 us of a 260 us Track).  The window is packed here into the model's own pinned block instead (a
-        // few hundred short memcpys, ~0.2 MB) TOGETHER with the frame record that describes it, and leaves with ONE asynchronous
-        // 1-D copy (2-D copies from pinned memory are no alternative: 1.07 ms per Track); crop_body reads the packed window through
-        // the record's pitch and virtual origins.  The caller's buffers are free again when this function returns.  The pinned
-        // block is reused by the next call: a model's Track is waited for (fp_track_wait) before its next submission.
+        // few hundred short memcpys, ~0.1 MB) TOGETHER with the frame record that describes it, and a small kernel fetches the block
+        // over PCIe (window_fetch_kernel: a copy command of this size costs ~27 us before the graph behind it can start, the kernel
+        // ~6; 2-D copies from pinned memory are no alternative at all: 1.07 ms per Track); crop_body reads the packed window
+        // through the record's pitch and virtual origins.  The caller's buffers are free again when this function returns.  The
+        // pinned block is reused by the next call: a model's Track is waited for (fp_track_wait) before its next submission.
         uint8_t *dev_block = reinterpret_cast<uint8_t *>(m->frame_dev);
         uint8_t *sr = m->win_stage + 64;
         float *sd = reinterpret_cast<float *>(m->win_stage + 64 + rgb_bytes);
@@ -1002,7 +1004,11 @@ static int upload_frame_async(fp_model *m, const void *rgb, const void *depth, i
         rec.pitch = (int)cw;
         rec.wx0 = col0; rec.wx1 = col1; rec.wy0 = row0; rec.wy1 = row1;
         std::memcpy(m->win_stage, &rec, sizeof(rec));
-        FP_HIP_OK(hipMemcpyAsync(dev_block, m->win_stage, total, hipMemcpyHostToDevice, m->stream));
+        if (g_upload_cols == 3) FP_HIP_OK(hipMemcpyAsync(dev_block, m->win_stage, total, hipMemcpyHostToDevice, m->stream));   // A/B: a copy command
+        else {
+          launch_window_fetch(m->stream, m->win_stage_dev, dev_block, total);
+          FP_HIP_OK(hipGetLastError());
+        }
         m->frame_pub = rec;
         m->rgb = m->rgb_own; m->depth = m->depth_own;   // (hold nothing of this frame: frame_partial)
         return 0;

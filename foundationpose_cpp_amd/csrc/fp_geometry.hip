@@ -1146,6 +1146,18 @@ __global__ void depth_to_xyz_kernel(const float *__restrict__ depth, int H, int 
   xyz[(size_t)p * 3] = x; xyz[(size_t)p * 3 + 1] = y; xyz[(size_t)p * 3 + 2] = z;
 }
 
+// [r4] Track's packed crop window (frame record + rgb rows + depth rows, 8-330 KB) from the model's host-pinned block into its device
+// block: 16 bytes per lane, 1 KB per wave instruction straight over PCIe.  A copy COMMAND of this size costs ~27 us before the graph
+// behind it can start, whatever its size above ~16 KB (tools/track_window_sweep.py); a kernel dispatch costs what a kernel costs.
+__global__ __launch_bounds__(256) void window_fetch_kernel(const uint4 *__restrict__ src_host, uint4 *__restrict__ dst, unsigned n16) {
+  for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < n16; i += gridDim.x * 256) dst[i] = src_host[i];
+}
+void launch_window_fetch(hipStream_t s, const void *src_host_mapped, void *dst, size_t bytes) {
+  const unsigned n16 = (unsigned)((bytes + 15) / 16);
+  const unsigned blocks = std::min(256u, (n16 + 255) / 256);
+  hipLaunchKernelGGL(window_fetch_kernel, dim3(blocks), dim3(256), 0, s, (const uint4 *)src_host_mapped, (uint4 *)dst, n16);
+}
+
 void launch_depth_to_xyz(hipStream_t s, const float *depth, int H, int W, const float *K, float *xyz) {
   hipLaunchKernelGGL(depth_to_xyz_kernel, dim3((H * W + 255) / 256), dim3(256), 0, s, depth, H, W, K[0], K[4], K[2],
                      K[5], xyz);

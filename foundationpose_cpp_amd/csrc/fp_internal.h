@@ -218,6 +218,8 @@ struct FrameRef {
 void launch_crop(hipStream_t s, const FrameRef *frame_dev, int H, int W, const float *K9_host,
                  const PoseRec *recs, int N, float diameter, OutMode mode, void *out);
 void launch_depth_to_xyz(hipStream_t s, const float *depth, int H, int W, const float *K9_host, float *xyz);
+// copies `bytes` (rounded up to 16) from a host-pinned, device-mapped block into device memory with a kernel
+void launch_window_fetch(hipStream_t s, const void *src_host_mapped, void *dst, size_t bytes);
 void launch_erode(hipStream_t s, const float *depth, float *out, int H, int W);
 void launch_bilateral(hipStream_t s, const float *depth, float *out, int H, int W);
 // device-side refine post process: poses updated in place from trans/rot [N,3] (foundationpose.cpp:360-406)
