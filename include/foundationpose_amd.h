@@ -90,8 +90,9 @@ int fp_num_hypotheses(const fp_model *m);
 /* ---- Base6DofDetectionModel::Register / Track (D6F/include/.../foundationpose.hpp:36-41,59-64; src/foundationpose.cpp:181-265). */
 int fp_register(fp_model *m, const uint8_t *rgb, const float *depth, const uint8_t *mask, int H, int W,
                 const char *target_name, int refine_itr, float out_pose[16]);
-/* Track with refine_itr == 1 reads the frame only inside the observed-crop window of the hypothesis: from a host frame only those
- * rows are uploaded (the stage operators below refuse the resulting partial copy until the next fp_upload_frame / Register). */
+/* Track with refine_itr == 1 reads the frame only inside the observed-crop window of the hypothesis: from a host frame only that
+ * window is uploaded -- packed into a pinned block of the model and fetched from there when it is at most half the frame wide,
+ * whole rows otherwise (the stage operators below refuse the resulting partial copy until the next fp_upload_frame / Register). */
 int fp_track(fp_model *m, const uint8_t *rgb, const float *depth, int H, int W, const float hyp_pose[16],
              const char *target_name, int refine_itr, float out_pose[16]);
 /* Track in two halves for pipelined serving (one host thread, several models / objects in flight; the reference's un-vendored
