@@ -481,7 +481,7 @@ def main():
                                                     "weights": "discriminating synthetic set"},
                         "accuracy": {"pose_delta_vs_f16_track": {"deg": round(float(rot_deg(p8[None], p16[None])[0]), 3),
                                                                  "mm": round(float(np.linalg.norm(p8[:3, 3] - p16[:3, 3]) * 1e3), 3)}},
-                        "graph": "26 kernels (the triangles' row ranges are computed inside the vertex + crop launch); the INT8 graph spanned 194 us before the row-range rasteriser (profiles/r04d_track_int8_timeline.txt), the f16 graph spans ~207 us (profiles/r04i_track_timeline.txt)"}
+                        "graph": "26 kernels (the triangles' row ranges are computed inside the vertex + crop launch); the INT8 graph spanned 194 us before the row-range rasteriser (profiles/r04d_track_int8_timeline.txt), the f16 graph spans 203.4 us (profiles/r04i_track_timeline.txt)"}
             finally:
                 m.close()
         extras["track_int8"] = track_leg_int8(max(args.steps * 10, 100))
