@@ -321,7 +321,16 @@ def main():
                 for mm in fleet:
                     mm._must(mm._L.fp_track_wait(mm.handle, outs.ctypes.data_as(C.c_void_p)))
             tp = timed(submit_all, max(ksteps // K_OBJ, 20), 5)
+
+            def submit_all_host():      # the same from HOST frames: every submission packs its crop window into the model's pinned block
+                for mm in fleet:
+                    mm._must(mm._L.fp_track_submit(mm.handle, scene.rgb.ctypes.data_as(C.c_void_p), scene.depth.ctypes.data_as(C.c_void_p), 0, H, Wd,
+                                                   hyp16.ctypes.data_as(C.c_void_p), mesh.name.encode(), 1))
+                for mm in fleet:
+                    mm._must(mm._L.fp_track_wait(mm.handle, outs.ctypes.data_as(C.c_void_p)))
+            tph = timed(submit_all_host, max(ksteps // K_OBJ, 20), 5)
             pipelined = {"objects_in_flight": K_OBJ, "value": round(K_OBJ * max(ksteps // K_OBJ, 20) / tp, 1), "unit": "tracks/s",
+                         "host_frame_value": round(K_OBJ * max(ksteps // K_OBJ, 20) / tph, 1),
                          "what": "one host thread, fp_track_submit for every object then fp_track_wait for every object"}
             for mm in others:
                 mm.close()
