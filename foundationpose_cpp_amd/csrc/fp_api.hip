@@ -834,7 +834,7 @@ fp_model *fp_create_on(int device, const fp_mesh *meshes, int n_meshes, const fl
   // non-blocking: no implicit synchronisation with the legacy null stream (other models' threads, the caller's framework)
   if (stream_acquire(&m->stream) != hipSuccess) { set_error("[FoundationPose] Failed to create stream"); return nullptr; }
   static_assert(sizeof(FrameRef) <= 64, "the packed window starts 64 bytes into the frame block");
-  m->win_cap = 64 + (size_t)m->max_h * m->max_w * 7 / 2 + 256;   // a window that takes this path is at most half the frame wide
+  m->win_cap = (64 + (size_t)m->max_h * m->max_w * 7 / 2 + 256 + 15) & ~(size_t)15;   // a window that takes this path is at most half the frame wide; whole 16-byte units for window_fetch_kernel
   if (hipMalloc((void **)&m->frame_dev, m->win_cap) != hipSuccess || hipHostMalloc((void **)&m->win_stage, m->win_cap, hipHostMallocCoherent) != hipSuccess ||
       hipHostGetDevicePointer((void **)&m->win_stage_dev, m->win_stage, 0) != hipSuccess ||
       hipHostMalloc((void **)&m->frame_pinned, 8 * sizeof(FrameRef), hipHostMallocDefault) != hipSuccess) {
