@@ -338,8 +338,8 @@ struct fp_model {
   uint8_t *rgb_own = nullptr;
   float *depth_own = nullptr;
   FrameRef *frame_dev = nullptr, *frame_pinned = nullptr;  // what kernels inside graphs read the frame through
-  // [r4] frame_dev heads a device block [FrameRef | 64 | packed window]: Track's crop window of a host frame is packed (record, rgb
-  // rows, depth rows) into the pinned twin win_stage and arrives with ONE copy, record included
+  // [r4] frame_dev heads a device block [FrameRef, padded to 64 bytes | packed window]: Track's crop window of a host frame is packed
+  // (record, rgb rows, depth rows) into the pinned twin win_stage and fetched from there by window_fetch_kernel, record included
   uint8_t *win_stage = nullptr, *win_stage_dev = nullptr;   // (host address / the device's mapping of it)
   size_t win_cap = 0;             // bytes of either block (0: no window path)
   FrameRef frame_pub = {nullptr, nullptr};                 // last published value
