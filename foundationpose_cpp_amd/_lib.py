@@ -22,7 +22,7 @@ SYMBOLS = [
     "fp_profile_enable", "fp_profile_reset", "fp_profile_report", "fp_stream", "fp_synchronize",
     "fp_mesh_load_obj", "fp_mesh_free", "fp_mesh_view", "fp_mesh_orient_bounds",
     "fp_image_read_png", "fp_frame_size", "fp_read_rgb_depth_mask", "fp_read_cam_k", "fp_image_write_png_rgb",
-    "fp_draw_bbox3d", "fp_set_precision", "fp_get_precision", "fp_calibrate_fp8", "fp_calibrate", "fp_calibration_size", "fp_get_calibration_blob", "fp_set_calibration_blob", "fp_get_calibration", "fp_set_calibration", "fp_set_float_model", "fp_get_float_model", "fp_net_create", "fp_net_destroy", "fp_net_max_batch", "fp_net_blob", "fp_net_infer",
+    "fp_draw_bbox3d", "fp_set_precision", "fp_get_precision", "fp_calibrate_fp8", "fp_calibrate", "fp_calibrate_begin", "fp_calibrate_add_frame", "fp_calibrate_finish", "fp_calibrate_abort", "fp_calibrate_frames", "fp_calibration_size", "fp_get_calibration_blob", "fp_set_calibration_blob", "fp_get_calibration", "fp_set_calibration", "fp_set_float_model", "fp_get_float_model", "fp_net_create", "fp_net_destroy", "fp_net_max_batch", "fp_net_blob", "fp_net_infer",
 ]
 
 
@@ -112,7 +112,8 @@ def lib() -> C.CDLL:
         "fp_profile_enable": [vp, ci], "fp_profile_reset": [vp], "fp_profile_report": [vp, vp, ci],
         "fp_synchronize": [vp], "fp_mesh_orient_bounds": [vp, vp, vp],
         "fp_set_precision": [vp, ci], "fp_get_precision": [vp], "fp_calibrate_fp8": [vp, vp, vp, vp, ci, ci, ci, cs],
-        "fp_calibrate": [vp, vp, vp, vp, ci, ci, ci, cs, ci], "fp_get_calibration_blob": [vp, ci, vp, C.c_size_t], "fp_set_calibration_blob": [vp, vp, C.c_size_t],
+        "fp_calibrate": [vp, vp, vp, vp, ci, ci, ci, cs, ci], "fp_calibrate_begin": [vp, ci], "fp_calibrate_add_frame": [vp, vp, vp, vp, ci, ci, ci, cs],
+        "fp_calibrate_finish": [vp], "fp_calibrate_abort": [vp], "fp_calibrate_frames": [vp], "fp_get_calibration_blob": [vp, ci, vp, C.c_size_t], "fp_set_calibration_blob": [vp, vp, C.c_size_t],
         "fp_get_calibration": [vp, vp], "fp_set_calibration": [vp, vp], "fp_set_float_model": [vp, ci], "fp_get_float_model": [vp],
     }
     for name, at in sigs.items():

@@ -318,6 +318,24 @@ class FoundationPose:
         self._must(self._L.fp_calibrate(self._h, _p(rgb), _p(depth), _p(mask), FP_HOST, depth.shape[0], depth.shape[1],
                                         target_name.encode(), precision))
 
+    def calibrate_frames(self, frames, target_name: str, precision: int = FP_PREC_INT8):
+        """Post-training quantisation over several frames (fp_calibrate_begin / _add_frame / _finish): `frames` = iterable of
+        (rgb, depth, mask) or of objects with .rgb / .depth / .mask.  K >= 8 frames of the deployment's scene family make the
+        common-mode part of the correction carry over to frames the calibration never saw."""
+        self._must(self._L.fp_calibrate_begin(self._h, precision))
+        try:
+            for f in frames:
+                rgb, depth, mask = (f.rgb, f.depth, f.mask) if hasattr(f, "rgb") else f
+                rgb, depth, mask = self._frame(rgb, depth, mask)
+                if rgb is None:
+                    raise FoundationPoseError(self.last_error)
+                self._must(self._L.fp_calibrate_add_frame(self._h, _p(rgb), _p(depth), _p(mask), FP_HOST, depth.shape[0], depth.shape[1],
+                                                          target_name.encode()))
+        except Exception:
+            self._L.fp_calibrate_abort(self._h)
+            raise
+        self._must(self._L.fp_calibrate_finish(self._h))
+
     def calibrate_fp8(self, rgb, depth, mask, target_name: str):
         self.calibrate(rgb, depth, mask, target_name, FP_PREC_FP8)
 

@@ -168,10 +168,12 @@ static int g_upload_cols = 1;   // A/B (fpt_set_upload_cols): Track from host fr
 static constexpr int g_upload_cols = 1;
 #endif
 #ifdef FP_TEST_HOOKS
+static int g_calib_sweeps = 2, g_calib_tok = 1, g_calib_out = 1;   // A/B (fpt_set_calib_opts): steps of the 8-bit calibration
 static int g_vertex_crop = 1;   // A/B (fpt_set_vertex_crop): Track's crop warp (and, unless 2, the triangles' row ranges) inside the vertex launch
 static int g_tri_rows_all_batches = 0;   // A/B (fpt_set_tri_rows(2)): size the buffer for large batches too
 static int g_tri_rows = 1;      // A/B (fpt_set_tri_rows): per-triangle row ranges, so that a strip of the rasteriser skips the triangles that miss it
 #else
+static constexpr int g_calib_sweeps = 2, g_calib_tok = 1, g_calib_out = 1;
 static constexpr int g_vertex_crop = 1;
 static constexpr int g_tri_rows = 1;
 static constexpr int g_tri_rows_all_batches = 0;
@@ -323,6 +325,14 @@ struct Target {
   DeviceMesh mesh;
 };
 
+// a calibration frame kept on the host between fp_calibrate_add_frame and fp_calibrate_finish
+struct CalibFrame {
+  std::vector<uint8_t> rgb, mask;
+  std::vector<float> depth;
+  int H = 0, W = 0;
+  std::string target;
+};
+
 struct fp_model {
   int device = 0;            // the HIP device the model lives on (fp_create_on); every entry point makes it current for its duration
   hipStream_t stream = nullptr;
@@ -401,14 +411,14 @@ struct fp_model {
   // calibration of the 8-bit precisions (fp_calibrate): [refiner, scorer] per-channel |max| / mean of the 15 trunk activations of
   // the f16 networks on the calibration frame ([15][512] each), and per 8-bit precision the solved corrections (bias [13][512], token
   // [512]); they are applied to a precision's networks when those are loaded / re-calibrated
-  std::vector<float> calib_amax[2], calib_mean[2];   // the statistics pass of the calibration in progress
+  int calib_session_prec = -1;                 // fp_calibrate_begin .. fp_calibrate_finish: the precision being calibrated (-1: no session)
+  std::vector<CalibFrame> calib_frames; // host copies of the session's frames
   // the |max| record each 8-bit precision was quantised with (empty = not calibrated).  Per precision: two precisions may have been
   // calibrated on different frames, and a blob must carry the statistics ITS corrections were solved against
   std::vector<float> calib_amax_q[N_PREC][2];
   bool calibrated(int prec) const { return prec >= 0 && prec < N_PREC && !calib_amax_q[prec][0].empty(); }
   std::vector<float> calib_bias_fix[N_PREC][2], calib_tok_fix[N_PREC][2];
   std::vector<float> calib_out_fix[N_PREC][2];   // output-layer correction: refiner [8] (trans 3 | rot 3 | 0 0), scorer [512]
-  std::vector<float> calib_out_mean[2];          // means of the f16 networks' outputs on the calibration frame (same shapes)
   // pinned staging for hypothesis poses: Register returns from its asynchronous section while the H2D copy may still be
   // queued, so the source must outlive the call (a local std::vector did not: found by the two-model serving test)
   float *track_io = nullptr, *track_io_dev = nullptr;  // host-pinned [hypothesis 16 | refined pose 16 | done flag] of Track and its device address
@@ -610,11 +620,15 @@ static int run_graphed(fp_model *m, fp_model::GraphSlot &g, Target *t, int H, in
 }
 
 // ---- packed exchange buffers of a sharded Register: row = [pooled score feature 512 | refined pose 16]
+// sampler_status: the device-side verdict word of THIS rank's sampler run (0 = poses valid): anything else poisons the rows with
+// NaNs, so that every rank's finish reports the failure -- a rank whose sampler failed must not feed garbage rows to ranks that
+// would otherwise succeed (the verdict itself reaches the host only with the finish half's single synchronisation)
 __global__ void pack_shard_kernel(const float *__restrict__ feat, const float *__restrict__ poses, int count, int per,
-                                  float *__restrict__ packed) {
+                                  float *__restrict__ packed, const int *__restrict__ sampler_status) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= per * 528) return;
   const int r = i / 528, c = i - r * 528;
+  if (sampler_status && *sampler_status != 0) { packed[i] = __int_as_float(0x7fc00000); return; }
   packed[i] = r >= count ? 0.f : (c < 512 ? feat[(size_t)r * 512 + c] : poses[(size_t)r * 16 + (c - 512)]);
 }
 // gathered rows are already in global hypothesis order (contiguous shards of `per` rows, padding only behind row n_total)
@@ -661,6 +675,11 @@ struct DeviceScope {
   DeviceScope(const DeviceScope &) = delete;
   DeviceScope &operator=(const DeviceScope &) = delete;
 };
+// fp_register_sharded with more than one rank runs WITHOUT the FP_SERIALIZE_MODELS lock: a host with one thread per rank would
+// deadlock on it (the thread inside the finish half's stream synchronisation holds the lock while its all-gather waits for ranks
+// whose threads cannot enqueue theirs), and the ranks of a collective live on different devices, where the co-residency the lock
+// exists to prevent cannot happen.
+static thread_local bool g_no_serial = false;
 struct SerialGuard {
   std::unique_lock<std::recursive_mutex> lk;
   bool shared_held = false;
@@ -669,7 +688,7 @@ struct SerialGuard {
     if (g_life_depth++ == 0) { g_life_rw.lock_shared(); shared_held = true; }
     static const bool on = [] { const char *e = std::getenv("FP_SERIALIZE_MODELS"); return e && *e && *e != '0'; }();
     static std::recursive_mutex mu;
-    if (on) lk = std::unique_lock<std::recursive_mutex>(mu);
+    if (on && !g_no_serial) lk = std::unique_lock<std::recursive_mutex>(mu);
   }
   ~SerialGuard() {
     if (lk.owns_lock()) lk.unlock();
@@ -698,6 +717,7 @@ static int caught_exception() noexcept {
 extern "C" {
 
 #ifdef FP_TEST_HOOKS
+void fpt_set_calib_opts(int sweeps, int tok, int out) { g_calib_sweeps = sweeps; g_calib_tok = tok; g_calib_out = out; }
 void fpt_set_vertex_crop(int v) { g_vertex_crop = v; }
 void fpt_set_tri_rows(int v) { g_tri_rows = v != 0; g_tri_rows_all_batches = v == 2; }
 void fpt_set_upload_cols(int v) { g_upload_cols = v; }
@@ -1441,7 +1461,7 @@ int fp_register_shard_begin_packed(fp_model *m, const void *rgb, const void *dep
     m->shard_sampler_pending = true;
   }
   const int n = rows_per_rank * 528;
-  hipLaunchKernelGGL(pack_shard_kernel, dim3((n + 255) / 256), dim3(256), 0, m->stream, feat, poses, shard_count, rows_per_rank, packed_dev);
+  hipLaunchKernelGGL(pack_shard_kernel, dim3((n + 255) / 256), dim3(256), 0, m->stream, feat, poses, shard_count, rows_per_rank, packed_dev, m->samp_state + 6);
   FP_HIP_OK(hipGetLastError());
   return 0;
 } FP_CATCH_INT
@@ -1475,7 +1495,9 @@ namespace {
 typedef int (*nccl_allgather_fn)(const void *, void *, size_t, int, void *, hipStream_t);
 typedef const char *(*nccl_errstr_fn)(int);
 typedef int (*nccl_count_fn)(void *, int *);
+typedef int (*nccl_abort_fn)(void *);
 struct RcclApi {
+  nccl_abort_fn abort = nullptr;   // optional: lets a rank that cannot join the collective release the others
   nccl_allgather_fn all_gather = nullptr;
   nccl_errstr_fn err = nullptr;
   nccl_count_fn count = nullptr, user_rank = nullptr;
@@ -1504,6 +1526,7 @@ const RcclApi &rccl_api() {
     a.err = (nccl_errstr_fn)dlsym(h, "ncclGetErrorString");
     a.count = (nccl_count_fn)dlsym(h, "ncclCommCount");
     a.user_rank = (nccl_count_fn)dlsym(h, "ncclCommUserRank");
+    a.abort = (nccl_abort_fn)dlsym(h, "ncclCommAbort");
     if (!a.all_gather || !a.err || !a.count || !a.user_rank) { a.why = "librccl lacks ncclAllGather / ncclCommCount / ncclCommUserRank"; a.all_gather = nullptr; }
     return a;
   }();
@@ -1517,7 +1540,6 @@ __global__ void poison_rows_kernel(float *p, size_t n) {
 
 int fp_register_sharded(fp_model *m, void *nccl_comm, const void *rgb, const void *depth, const void *mask, int memspace, int H, int W,
                         const char *target_name, int refine_itr, float out_pose[16], int *best_index) try {
-  SerialGuard serial(m ? m->device : -1);
   FP_CHECK(m && nccl_comm && out_pose, "[FoundationPose] fp_register_sharded: invalid arguments");
   const RcclApi &nccl = rccl_api();
   FP_CHECK(nccl.all_gather != nullptr, "[FoundationPose] fp_register_sharded: " + nccl.why);
@@ -1526,25 +1548,40 @@ int fp_register_sharded(fp_model *m, void *nccl_comm, const void *rgb, const voi
     set_error(std::string("[FoundationPose] fp_register_sharded: bad communicator: ") + (rc ? nccl.err(rc) : "rank / size out of range"));
     return 1;
   }
+  struct NoSerial {   // (see g_no_serial; restored on every return path)
+    bool prev = g_no_serial;
+    explicit NoSerial(bool off) { if (off) g_no_serial = true; }
+    ~NoSerial() { g_no_serial = prev; }
+  } no_serial(world > 1);
+  SerialGuard serial(m->device);
   const int n_total = m->n_hyp();
   const int per = (n_total + world - 1) / world;
   const int begin = std::min(rank * per, n_total), count = std::min(per, n_total - begin);
+  // Everything that can fail on THIS rank alone happens behind a promise to the other ranks: they are already heading for the
+  // collective.  A failure of the begin half joins it with NaN rows (every rank's finish reports them) and returns the error
+  // afterwards; a rank that cannot even hold its exchange buffers cannot join -- it aborts the communicator (ncclCommAbort: the
+  // others' collective returns an error instead of hanging) and says so.
+  auto cannot_join = [&](const std::string &why) {
+    const bool aborted = world > 1 && nccl.abort && nccl.abort(nccl_comm) == 0;
+    set_error("[FoundationPose] fp_register_sharded: " + why + (world > 1 ? (aborted ? " -- the communicator was aborted so that the other ranks do not wait for this one (it must be re-created)"
+                                                                                      : " -- this rank could not join the collective and ncclCommAbort is unavailable: the other ranks may wait") : ""));
+    return 1;
+  };
   // persistent exchange buffers (grown on demand; a Register never allocates in steady state)
   const size_t need_send = (size_t)per * 528, need_recv = (size_t)world * per * 528;
-  if (need_send > m->shard_send_cap) {
-    FP_HIP_OK(hipStreamSynchronize(m->stream));
-    dev_free(m->shard_send); m->shard_send_cap = 0;
-    if (dev_alloc(&m->shard_send, need_send)) return 1;
-    m->shard_send_cap = need_send;
+  if (need_send > m->shard_send_cap || need_recv > m->shard_recv_cap) {
+    if (hipStreamSynchronize(m->stream) != hipSuccess) return cannot_join("the model's stream is in an error state");
+    if (need_send > m->shard_send_cap) {
+      dev_free(m->shard_send); m->shard_send_cap = 0;
+      if (hipMalloc((void **)&m->shard_send, need_send * sizeof(float)) != hipSuccess) { m->shard_send = nullptr; return cannot_join("out of device memory for the exchange buffers"); }
+      m->shard_send_cap = need_send;
+    }
+    if (need_recv > m->shard_recv_cap) {
+      dev_free(m->shard_recv); m->shard_recv_cap = 0;
+      if (hipMalloc((void **)&m->shard_recv, need_recv * sizeof(float)) != hipSuccess) { m->shard_recv = nullptr; return cannot_join("out of device memory for the exchange buffers"); }
+      m->shard_recv_cap = need_recv;
+    }
   }
-  if (need_recv > m->shard_recv_cap) {
-    FP_HIP_OK(hipStreamSynchronize(m->stream));
-    dev_free(m->shard_recv); m->shard_recv_cap = 0;
-    if (dev_alloc(&m->shard_recv, need_recv)) return 1;
-    m->shard_recv_cap = need_recv;
-  }
-  // a failure on THIS rank must not leave the others inside the collective: join it with NaN rows (every rank's finish reports
-  // them) and return the error afterwards
   const int rc_begin = fp_register_shard_begin_packed(m, rgb, depth, mask, memspace, H, W, target_name, refine_itr, begin, count, m->shard_send, per);
   std::string begin_error;
   if (rc_begin) {
@@ -1556,7 +1593,7 @@ int fp_register_sharded(fp_model *m, void *nccl_comm, const void *rgb, const voi
     rc = nccl.all_gather(m->shard_send, m->shard_recv, need_send, 7 /* ncclFloat32 */, nccl_comm, m->stream);
     if (rc != 0) {
       (void)hipStreamSynchronize(m->stream);
-      set_error(std::string("[FoundationPose] ncclAllGather failed: ") + nccl.err(rc));
+      set_error(std::string("[FoundationPose] ncclAllGather failed: ") + nccl.err(rc) + (rc_begin ? " (after: " + begin_error + ")" : ""));
       return 1;
     }
   } else {
@@ -1813,126 +1850,247 @@ int fp_set_float_model(fp_model *m, int fmad) try {
 } FP_CATCH_INT
 int fp_get_float_model(const fp_model *m) { return m ? (m->fmad ? 1 : 0) : -1; }
 
-// Post-training static quantisation for the 8-bit precisions (FP_PREC_FP8 / FP_PREC_INT8):
-//   1. one Register of the frame in f16 records, per channel of the 15 trunk activations of both networks, |max| and the mean;
+// Post-training static quantisation for the 8-bit precisions (FP_PREC_FP8 / FP_PREC_INT8) over K >= 1 calibration frames
+// (fp_calibrate_begin / fp_calibrate_add_frame / fp_calibrate_finish; fp_calibrate = the three with one frame):
+//   1. one Register per frame in f16 records, per channel of the 15 trunk activations of both networks, |max| and the mean OVER ALL
+//      FRAMES (the statistics buffers accumulate across the Registers of a pass: integer atomics, so the result does not depend on order);
 //   2. the 8-bit networks are quantised with per-channel activation scales folded into their weights (net_apply_q8);
 //   3. bias correction (Nagel et al., "Data-free quantization through weight equalization and bias correction", 2019 -- here with
-//      data): layer by layer, in trunk order, a Register of the 8-bit model measures the per-channel mean of the layer's output and
-//      the difference to the f16 mean goes into its bias (two sweeps over the 13 layers);
-//   4. what is left of the mean shift of the TOKEN tensor goes into the positional table.
-// The pose is discarded; the model's precision is unchanged.  ~30 Registers, once per deployment (fp_get_calibration_blob).
-static int calibrate_impl(fp_model *m, const void *rgb, const void *depth, const void *mask, int memspace, int H, int W, const char *target_name,
-                          int precision) {
+//      data): layer by layer, in trunk order, a pass of the 8-bit model over the frames measures the per-channel mean of the layer's
+//      output and the difference to the f16 mean goes into its bias (two sweeps over the 13 layers);
+//   4. what is left of the mean shift of the TOKEN tensor goes into the positional table;
+//   5. what is left at the OUTPUTS (means over hypotheses and frames) goes into the output layers' biases.
+// Why several frames [r5]: the common-mode part of the correction (steps 4, 5) measured on ONE frame is partly that frame's own
+// (round 4: 0.6-0.7 mm of common-mode shift on other frames, 82-90 % of the refined poses within 1 mm / 1 deg); solved over frames of
+// the deployment's scene family it is the family's mean and carries over to frames the calibration never saw.
+// The record of the precision is replaced only when every step succeeded; a failure restores the previous record (or leaves the
+// precision uncalibrated).  The pose is discarded; the model's precision is unchanged.  ~30 Registers per frame, once per deployment.
+struct CalibRecord {   // what fp_get_calibration_blob carries for one precision
+  std::vector<float> amax[2], bias_fix[2], tok_fix[2], out_fix[2];
+  bool valid() const { return !amax[0].empty(); }
+};
+static CalibRecord record_of(const fp_model *m, int precision) {
+  CalibRecord r;
+  for (int k = 0; k < 2; k++) { r.amax[k] = m->calib_amax_q[precision][k]; r.bias_fix[k] = m->calib_bias_fix[precision][k]; r.tok_fix[k] = m->calib_tok_fix[precision][k]; r.out_fix[k] = m->calib_out_fix[precision][k]; }
+  return r;
+}
+static void commit_record(fp_model *m, int precision, const CalibRecord &r) {
+  for (int k = 0; k < 2; k++) { m->calib_amax_q[precision][k] = r.amax[k]; m->calib_bias_fix[precision][k] = r.bias_fix[k]; m->calib_tok_fix[precision][k] = r.tok_fix[k]; m->calib_out_fix[precision][k] = r.out_fix[k]; }
+}
+// (re-)quantises the LOADED networks of `precision` from a record (weights and corrections)
+static int apply_record(fp_model *m, int precision, const CalibRecord &r) {
+  Net *loaded[2] = {m->refiner_p[precision], m->scorer_p[precision]};
+  for (int k = 0; k < 2; k++)
+    if (loaded[k] && (net_apply_q8(loaded[k], r.amax[k].data(), r.bias_fix[k].data(), r.tok_fix[k].data(), true) || net_q8_set_out_fix(loaded[k], r.out_fix[k].data()))) return 1;
+  return 0;
+}
+
+static int calibrate_impl(fp_model *m, const std::vector<CalibFrame> &frames, int precision) {
   FP_CHECK(m != nullptr, "[FoundationPose] null model");
   FP_CHECK(precision == PREC_FP8 || precision == PREC_INT8, "[FoundationPose] fp_calibrate: precision must be FP_PREC_FP8 or FP_PREC_INT8");
   FP_CHECK(!m->refiner_path.empty() && !m->scorer_path.empty(), "[FoundationPose] fp_calibrate needs both networks");
+  FP_CHECK(!frames.empty(), "[FoundationPose] fp_calibrate_finish: no calibration frame was added");
+  FP_CHECK(m->refiner_p[precision] && m->scorer_p[precision] && m->refiner_p[PREC_F16] && m->scorer_p[PREC_F16], "[FoundationPose] fp_calibrate: networks not loaded");
   const int prev = m->prec;
   if (select_precision(m, PREC_F16)) return 1;
   float pose[16];
   constexpr size_t NS = (size_t)15 * 512;
+  const double inv_frames = 1.0 / (double)frames.size();
   // means over the hypotheses of what the networks hand to the pose update / the cross-hypothesis head (still in the model's buffers
-  // after a Register): refiner trans | rot, scorer pooled features
-  auto output_means = [&](std::vector<float> (&out)[2]) -> int {
+  // after a Register): refiner trans | rot, scorer pooled features; accumulated over the frames of a pass
+  auto add_output_means = [&](std::vector<double> (&acc)[2]) -> int {
     const int N = m->n_hyp();
     std::vector<float> t((size_t)N * 3), r((size_t)N * 3), f((size_t)N * 512);
     FP_HIP_OK(hipMemcpyAsync(t.data(), m->trans_dev, t.size() * 4, hipMemcpyDeviceToHost, m->stream));
     FP_HIP_OK(hipMemcpyAsync(r.data(), m->rot_dev, r.size() * 4, hipMemcpyDeviceToHost, m->stream));
     FP_HIP_OK(hipMemcpyAsync(f.data(), m->feat_dev, f.size() * 4, hipMemcpyDeviceToHost, m->stream));
     FP_HIP_OK(hipStreamSynchronize(m->stream));
-    out[0].assign(8, 0.f); out[1].assign(512, 0.f);
     for (int c = 0; c < 3; c++) {
       double a = 0, b = 0;
       for (int i = 0; i < N; i++) { a += t[(size_t)i * 3 + c]; b += r[(size_t)i * 3 + c]; }
-      out[0][c] = (float)(a / N); out[0][3 + c] = (float)(b / N);
+      acc[0][c] += a / N * inv_frames; acc[0][3 + c] += b / N * inv_frames;
     }
     for (int c = 0; c < 512; c++) {
       double a = 0;
       for (int i = 0; i < N; i++) a += f[(size_t)i * 512 + c];
-      out[1][c] = (float)(a / N);
+      acc[1][c] += a / N * inv_frames;
     }
     return 0;
   };
-  auto registered = [&](int mode, int only_act, std::vector<float> *amax, std::vector<float> (&mean)[2]) -> int {
+  // one pass over the frames: statistics of both networks (mode / only_act: net_calib_begin), optionally the output means
+  auto pass = [&](int mode, int only_act, std::vector<float> *amax, std::vector<float> (&mean)[2], std::vector<float> *out_mean) -> int {
     Net *nets[2] = {m->refiner, m->scorer};
     for (Net *n : nets) net_calib_begin(n, m->stream, mode, only_act);
-    m->calibrating = true;
-    int rc = fp_register_ex(m, rgb, depth, mask, memspace, H, W, target_name, 1, pose);
-    m->calibrating = false;
+    std::vector<double> acc[2] = {std::vector<double>(8, 0.0), std::vector<double>(512, 0.0)};
+    int rc = 0;
+    for (const CalibFrame &f : frames) {
+      m->calibrating = true;
+      rc = fp_register_ex(m, f.rgb.data(), f.depth.data(), f.mask.data(), FP_HOST, f.H, f.W, f.target.c_str(), 1, pose);
+      m->calibrating = false;
+      if (!rc && out_mean) rc = add_output_means(acc);
+      if (rc) break;
+    }
     for (int k = 0; k < 2; k++) {
       mean[k].assign(NS, 0.f);
       if (amax) amax[k].assign(NS, 0.f);
       rc |= net_calib_end(nets[k], m->stream, amax ? amax[k].data() : nullptr, mean[k].data());
+      if (out_mean) out_mean[k].assign(acc[k].begin(), acc[k].end());
     }
     return rc;
   };
-  if (registered(1, -1, m->calib_amax, m->calib_mean)) { (void)select_precision(m, (prev == PREC_FP8 || prev == PREC_INT8) ? PREC_F16 : prev); return 1; }
-  if (output_means(m->calib_out_mean)) return 1;
-  for (int k = 0; k < 2; k++) m->calib_amax_q[precision][k] = m->calib_amax[k];
+  std::vector<float> f16_mean[2], f16_out_mean[2];
+  CalibRecord rec;
+  if (pass(1, -1, rec.amax, f16_mean, f16_out_mean)) return 1;
+  for (int k = 0; k < 2; k++) { rec.bias_fix[k].assign((size_t)13 * 512, 0.f); rec.tok_fix[k].assign(512, 0.f); rec.out_fix[k].assign(k == 0 ? 8 : 512, 0.f); }
   // quantise (or re-quantise) this precision's networks without corrections
-  for (int k = 0; k < 2; k++) {
-    m->calib_bias_fix[precision][k].assign((size_t)13 * 512, 0.f); m->calib_tok_fix[precision][k].assign(512, 0.f);
-    m->calib_out_fix[precision][k].assign(k == 0 ? 8 : 512, 0.f);
-  }
-  {
-    Net *loaded[2] = {m->refiner_p[precision], m->scorer_p[precision]};
-    for (int k = 0; k < 2; k++)
-      if (loaded[k] && (net_apply_q8(loaded[k], m->calib_amax_q[precision][k].data(), m->calib_bias_fix[precision][k].data(), m->calib_tok_fix[precision][k].data(), true) ||
-                        net_q8_set_out_fix(loaded[k], m->calib_out_fix[precision][k].data()))) return 1;
-  }
-  if (select_precision(m, precision)) return 1;   // (loads and quantises them otherwise)
+  if (apply_record(m, precision, rec)) return 1;
   invalidate_graphs(m);
+  // (not select_precision: it would put the PREVIOUS record's output correction back on a network that is being re-calibrated)
+  if (!m->ws_p[precision]) m->ws_p[precision] = nn_scratch_create(precision);
+  m->prec = precision; m->refiner = m->refiner_p[precision]; m->scorer = m->scorer_p[precision]; m->ws = m->ws_p[precision];
   Net *qn[2] = {m->refiner, m->scorer};
   std::vector<float> mq[2];
   auto target = [&](int k, int a, int c) {   // f16 mean the output channel c of the layer writing activation a should have
-    const std::vector<float> &t = m->calib_mean[k];
+    const std::vector<float> &t = f16_mean[k];
     return a == 5 ? 0.5f * (t[a * 512 + c] + t[a * 512 + c + 128]) : t[a * 512 + c];
   };
-  constexpr int n_sweeps = 2;   // (tools/q8_check.py, round 4: 0 / 1 / 2 / 3 sweeps -> 88 / 93 / 95-100 / 98 % of the refined poses within 1 mm / 1 deg of the f16 path)
+  const int n_sweeps = g_calib_sweeps;   // 2 (tools/q8_check.py, round 4: 0 / 1 / 2 / 3 sweeps -> 88 / 93 / 95-100 / 98 % of the refined poses within 1 mm / 1 deg of the f16 path)
   for (int sweep = 0; sweep < n_sweeps; sweep++)
     for (int layer = 0; layer < 13; layer++) {
       const int a = layer + 2, C = net_q8_bias_channels(layer);
-      if (registered(2, a, nullptr, mq)) return 1;
+      if (pass(2, a, nullptr, mq, nullptr)) return 1;
       for (int k = 0; k < 2; k++) {
-        std::vector<float> &fix = m->calib_bias_fix[precision][k];
+        std::vector<float> &fix = rec.bias_fix[k];
         for (int c = 0; c < C; c++) {
           const float got = a == 5 ? 0.5f * (mq[k][a * 512 + c] + mq[k][a * 512 + c + 128]) : mq[k][a * 512 + c];
           fix[(size_t)layer * 512 + c] += target(k, a, c) - got;
         }
-        if (net_apply_q8(qn[k], m->calib_amax_q[precision][k].data(), fix.data(), m->calib_tok_fix[precision][k].data(), false)) return 1;
+        if (net_apply_q8(qn[k], rec.amax[k].data(), fix.data(), rec.tok_fix[k].data(), false)) return 1;
       }
     }
-  if (registered(2, 14, nullptr, mq)) return 1;
-  for (int k = 0; k < 2; k++) {
-    for (int c = 0; c < 512; c++) m->calib_tok_fix[precision][k][c] = m->calib_mean[k][14 * 512 + c] - mq[k][14 * 512 + c];
-    if (net_apply_q8(qn[k], m->calib_amax_q[precision][k].data(), m->calib_bias_fix[precision][k].data(), m->calib_tok_fix[precision][k].data(), false)) return 1;
+  if (g_calib_tok && pass(2, 14, nullptr, mq, nullptr)) return 1;
+  for (int k = 0; g_calib_tok && k < 2; k++) {
+    for (int c = 0; c < 512; c++) rec.tok_fix[k][c] = f16_mean[k][14 * 512 + c] - mq[k][14 * 512 + c];
+    if (net_apply_q8(qn[k], rec.amax[k].data(), rec.bias_fix[k].data(), rec.tok_fix[k].data(), false)) return 1;
   }
   // 5. what is left at the OUTPUTS (the heads are non-linear in the token mean): the mean refiner outputs / pooled score feature of
-  //    the 8-bit model on this frame are moved onto the f16 model's through the output layers' biases
-  {
-    if (registered(2, 14, nullptr, mq)) return 1;
+  //    the 8-bit model over the frames are moved onto the f16 model's through the output layers' biases
+  if (g_calib_out) {
     std::vector<float> om[2];
-    if (output_means(om)) return 1;
+    if (pass(2, 14, nullptr, mq, om)) return 1;
     for (int k = 0; k < 2; k++) {
-      for (size_t c = 0; c < om[k].size(); c++) m->calib_out_fix[precision][k][c] = m->calib_out_mean[k][c] - om[k][c];
-      if (net_q8_set_out_fix(qn[k], m->calib_out_fix[precision][k].data())) return 1;
+      for (size_t c = 0; c < om[k].size(); c++) rec.out_fix[k][c] = f16_out_mean[k][c] - om[k][c];
+      if (net_q8_set_out_fix(qn[k], rec.out_fix[k].data())) return 1;
     }
   }
+  for (int k = 0; k < 2; k++)
+    for (const std::vector<float> *v : {&rec.amax[k], &rec.bias_fix[k], &rec.tok_fix[k], &rec.out_fix[k]})
+      for (float x : *v) FP_CHECK(std::isfinite(x), "[FoundationPose] fp_calibrate: the solved record is not finite (broken weights or frames)");
+  commit_record(m, precision, rec);   // only now: every step succeeded
   invalidate_graphs(m);
   return select_precision(m, prev);
 }
-int fp_calibrate(fp_model *m, const void *rgb, const void *depth, const void *mask, int memspace, int H, int W, const char *target_name,
-                 int precision) try {
-  LifeExclusive life;   // loads networks; the Registers inside nest (depth > 0)
-  DeviceScope on_device(m ? m->device : -1);
-  const int prev = m ? m->prec : 0;
-  const int rc = calibrate_impl(m, rgb, depth, mask, memspace, H, W, target_name, precision);
-  if (rc && m) {   // leave the model usable
+
+// Locking [r5]: exclusive (against every other call of the process) only while networks are LOADED -- the Registers of the
+// calibration and the re-quantisation uploads into existing buffers run under the shared lifetime lock like any Register, so other
+// models keep serving while one calibrates.
+static int calibrate_locked(fp_model *m, const std::vector<CalibFrame> &frames, int precision) {
+  FP_CHECK(m != nullptr, "[FoundationPose] null model");
+  FP_CHECK(precision == PREC_FP8 || precision == PREC_INT8, "[FoundationPose] fp_calibrate: precision must be FP_PREC_FP8 or FP_PREC_INT8");
+  FP_CHECK(!m->refiner_path.empty() && !m->scorer_path.empty(), "[FoundationPose] fp_calibrate needs both networks");
+  const int prev = m->prec;
+  if (!m->refiner_p[precision] || !m->scorer_p[precision] || !m->refiner_p[PREC_F16] || !m->scorer_p[PREC_F16]) {
+    LifeExclusive life;   // loads networks (hundreds of allocations and uploads)
+    DeviceScope on_device(m->device);
+    FP_HIP_OK(hipStreamSynchronize(m->stream));
+    int rc = select_precision(m, precision) || select_precision(m, PREC_F16);
+    rc = select_precision(m, rc ? PREC_F16 : prev) || rc;
+    if (rc) return 1;
+  }
+  SerialGuard serial(m->device);
+  FP_HIP_OK(hipStreamSynchronize(m->stream));
+  const CalibRecord before = record_of(m, precision);
+  const int rc = calibrate_impl(m, frames, precision);
+  if (rc) {   // leave the model usable and the precision's networks consistent with its (previous) record
+    const std::string why = g_last_error;
     m->calibrating = false;
+    for (Net *n : {m->refiner_p[precision], m->scorer_p[precision], m->refiner_p[PREC_F16], m->scorer_p[PREC_F16]}) if (n) net_calib_abort(n);
     (void)hipStreamSynchronize(m->stream);
+    invalidate_graphs(m);
+    bool restored = before.valid() && apply_record(m, precision, before) == 0;
+    if (!restored) {   // uncalibrated: fp_set_precision refuses the precision until a calibration succeeds
+      for (int k = 0; k < 2; k++) { m->calib_amax_q[precision][k].clear(); m->calib_bias_fix[precision][k].clear(); m->calib_tok_fix[precision][k].clear(); m->calib_out_fix[precision][k].clear(); }
+      for (Net *n : {m->refiner_p[precision], m->scorer_p[precision]}) if (n) net_q8_unready(n);
+    }
     const bool q8_prev = prev == PREC_FP8 || prev == PREC_INT8;
-    (void)select_precision(m, q8_prev && !net_q8_ready(m->refiner_p[prev] ? m->refiner_p[prev] : m->scorer_p[prev]) ? PREC_F16 : prev);
+    (void)select_precision(m, (q8_prev && !m->calibrated(prev)) ? PREC_F16 : prev);
+    set_error(why);
   }
   return rc;
+}
+
+static int copy_frame_in(fp_model *m, CalibFrame &f, const void *rgb, const void *depth, const void *mask, int memspace, int H, int W) {
+  const size_t px = (size_t)H * W;
+  f.rgb.resize(px * 3); f.depth.resize(px); f.mask.resize(px);
+  if (memspace == FP_HOST) {
+    std::memcpy(f.rgb.data(), rgb, px * 3); std::memcpy(f.depth.data(), depth, px * 4); std::memcpy(f.mask.data(), mask, px);
+    return 0;
+  }
+  FP_HIP_OK(hipMemcpyAsync(f.rgb.data(), rgb, px * 3, hipMemcpyDeviceToHost, m->stream));
+  FP_HIP_OK(hipMemcpyAsync(f.depth.data(), depth, px * 4, hipMemcpyDeviceToHost, m->stream));
+  FP_HIP_OK(hipMemcpyAsync(f.mask.data(), mask, px, hipMemcpyDeviceToHost, m->stream));
+  FP_HIP_OK(hipStreamSynchronize(m->stream));
+  return 0;
+}
+
+int fp_calibrate_begin(fp_model *m, int precision) try {
+  SerialGuard serial(m ? m->device : -1);
+  FP_CHECK(m != nullptr, "[FoundationPose] null model");
+  FP_CHECK(precision == PREC_FP8 || precision == PREC_INT8, "[FoundationPose] fp_calibrate_begin: precision must be FP_PREC_FP8 or FP_PREC_INT8");
+  FP_CHECK(!m->refiner_path.empty() && !m->scorer_path.empty(), "[FoundationPose] fp_calibrate needs both networks");
+  m->calib_frames.clear();
+  m->calib_session_prec = precision;
+  return 0;
+} FP_CATCH_INT
+int fp_calibrate_add_frame(fp_model *m, const void *rgb, const void *depth, const void *mask, int memspace, int H, int W, const char *target_name) try {
+  SerialGuard serial(m ? m->device : -1);
+  FP_CHECK(m != nullptr, "[FoundationPose] null model");
+  FP_CHECK(m->calib_session_prec >= 0, "[FoundationPose] fp_calibrate_add_frame without fp_calibrate_begin");
+  FP_CHECK(rgb && depth && mask, "[FoundationPose] fp_calibrate_add_frame: a calibration frame needs rgb, depth and mask");
+  FP_CHECK(m->calib_frames.size() < 1024, "[FoundationPose] fp_calibrate_add_frame: too many frames (1024)");
+  Target *t = nullptr;
+  if (check_frame_args(m, H, W, target_name ? target_name : "", &t)) return 1;
+  CalibFrame f;
+  f.H = H; f.W = W; f.target = t->name;
+  if (copy_frame_in(m, f, rgb, depth, mask, memspace, H, W)) return 1;
+  m->calib_frames.push_back(std::move(f));
+  return 0;
+} FP_CATCH_INT
+int fp_calibrate_finish(fp_model *m) try {
+  FP_CHECK(m != nullptr, "[FoundationPose] null model");
+  FP_CHECK(m->calib_session_prec >= 0, "[FoundationPose] fp_calibrate_finish without fp_calibrate_begin");
+  std::vector<CalibFrame> frames;
+  frames.swap(m->calib_frames);
+  const int precision = m->calib_session_prec;
+  m->calib_session_prec = -1;
+  return calibrate_locked(m, frames, precision);
+} FP_CATCH_INT
+int fp_calibrate_abort(fp_model *m) try {
+  FP_CHECK(m != nullptr, "[FoundationPose] null model");
+  m->calib_frames.clear();
+  m->calib_frames.shrink_to_fit();
+  m->calib_session_prec = -1;
+  return 0;
+} FP_CATCH_INT
+int fp_calibrate_frames(const fp_model *m) { return m && m->calib_session_prec >= 0 ? (int)m->calib_frames.size() : -1; }
+
+int fp_calibrate(fp_model *m, const void *rgb, const void *depth, const void *mask, int memspace, int H, int W, const char *target_name,
+                 int precision) try {
+  FP_CHECK(m != nullptr, "[FoundationPose] null model");
+  FP_CHECK(m->calib_session_prec < 0, "[FoundationPose] fp_calibrate while a fp_calibrate_begin session is open (finish or abort it first)");
+  if (fp_calibrate_begin(m, precision)) return 1;
+  if (fp_calibrate_add_frame(m, rgb, depth, mask, memspace, H, W, target_name)) { (void)fp_calibrate_abort(m); return 1; }
+  return fp_calibrate_finish(m);
 } FP_CATCH_INT
 int fp_calibrate_fp8(fp_model *m, const void *rgb, const void *depth, const void *mask, int memspace, int H, int W,
                      const char *target_name) try {

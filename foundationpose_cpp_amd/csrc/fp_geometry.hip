@@ -772,9 +772,10 @@ static void launch_raster_shade_t(hipStream_t s, const DeviceMesh &m, const Pose
   }
   if constexpr (STRIP_ROWS >= 40) {   // (test-build strip heights: z-buffer + list exceed the 64 KB a kernel gets without asking)
     static PerDeviceOnce attr_once;
-    if (attr_once.first())
+    attr_once.run([] {
       (void)hipFuncSetAttribute((const void *)raster_shade_kernel<MODE, STRIP_ROWS, 256, FMAD>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)((size_t)STRIP_ROWS * CROP * sizeof(unsigned long long) + (size_t)TRI_LIST * 4 + 16));
+    });
   }
   hipLaunchKernelGGL((raster_shade_kernel<MODE, STRIP_ROWS, 256, FMAD>), grid, block, lds, s, m.faces, m.F, m.V, m.uvs, m.tex,
                      m.TH, m.TW, downscale, recs, clip, attr, out, tri_id_dbg, rast_dbg, t_tri_rows);
@@ -797,9 +798,10 @@ static void launch_raster_tall(hipStream_t s, const DeviceMesh &m, const PoseRec
   size_t lds = (size_t)STRIP_ROWS * CROP * sizeof(unsigned long long) + tri_list_lds();
   // once per instantiation and device: opt in to > 64 KB of dynamic LDS
   static PerDeviceOnce attr_once;
-  if (attr_once.first())
+  attr_once.run([lds_max] {
     (void)hipFuncSetAttribute((const void *)raster_shade_kernel<MODE, STRIP_ROWS, 1024, FMAD>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds_max);
+  });
   hipLaunchKernelGGL((raster_shade_kernel<MODE, STRIP_ROWS, 1024, FMAD>), dim3(CROP / STRIP_ROWS, N), dim3(1024), lds, s, m.faces, m.F,
                      m.V, m.uvs, m.tex, m.TH, m.TW, m.diameter / 2, recs, clip, attr, out, nullptr, nullptr, t_tri_rows);
 }

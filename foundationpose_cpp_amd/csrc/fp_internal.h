@@ -6,6 +6,7 @@
 #include <stdint.h>
 
 #include <atomic>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -31,16 +32,18 @@ bool load_texture_rgb(const std::string &path, std::vector<uint8_t> &rgb, int &H
 // legacy stream -- these go through a per-thread non-blocking utility stream and wait for it.
 hipError_t memcpy_sync(void *dst, const void *src, size_t bytes, hipMemcpyKind kind);
 hipError_t memset_sync(void *dst, int value, size_t bytes);
-// Per-DEVICE once flag for launch sites that opt a kernel into > 64 KB of dynamic LDS: hipFuncSetAttribute acts on the current
-// device's copy of the function, so a process that drives several GPUs (one model per device) has to repeat it on each.
+// Per-DEVICE once for launch sites that opt a kernel into > 64 KB of dynamic LDS: hipFuncSetAttribute acts on the current device's
+// copy of the function, so a process that drives several GPUs (one model per device) has to repeat it on each.  BLOCKING [r5]: a second
+// thread on the same device (another model: the documented concurrency model) waits until the first has applied the attribute --
+// a flag that is set before the attribute call would let it launch a > 64 KB kernel without the opt-in (std::call_once per device).
 struct PerDeviceOnce {
-  std::atomic<unsigned long long> done{0};
-  bool first() {   // true exactly for the first caller on each device (devices >= 64: always true, harmless)
+  std::once_flag once[64];
+  template <class F>
+  void run(F &&f) {   // f runs exactly once per device, and every caller returns only after it has (devices >= 64: every time, harmless)
     int d = 0;
     (void)hipGetDevice(&d);
-    if (d < 0 || d >= 64) return true;
-    const unsigned long long bit = 1ull << d;
-    return !(done.fetch_or(bit) & bit);
+    if (d < 0 || d >= 64) { f(); return; }
+    std::call_once(once[d], f);
   }
 };
 // bumped whenever a device buffer that kernels may have baked into a captured hipGraph is (re)allocated

@@ -40,6 +40,8 @@ void net_calib_begin(Net *net, hipStream_t s, int mode, int only_act = -1);   //
 int net_calib_end(Net *net, hipStream_t s, float *amax_out, float *mean_out);   // [15][512] each; means over the interior pixels
 int net_apply_q8(Net *q8_net, const float *amax /*[15][512]*/, const float *bias_fix /*[13][512]*/, const float *tok_fix /*[512]*/, bool weights);
 int net_q8_set_out_fix(Net *q8_net, const float *fix /* refiner: [6] trans | rot biases; scorer: [512] pooled-feature bias */);
+void net_calib_abort(Net *net);
+void net_q8_unready(Net *net);
 void net_q8_get_fix(const Net *q8_net, float *bias_fix /*[13][512]*/, float *tok_fix /*[512]*/);
 int net_q8_bias_channels(int layer);   // output channels of 8-bit layer 0..12 (layer i writes trunk activation i + 2)
 

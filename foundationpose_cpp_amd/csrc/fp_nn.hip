@@ -738,6 +738,11 @@ int net_precision(const Net *n) { return n->prec; }
 int net_input_dt(const Net *n) { return n->act_dt; }
 bool net_q8_ready(const Net *n) { return !(n->prec == PREC_FP8 || n->prec == PREC_INT8) || n->q8_ready; }
 
+#ifdef FP_TEST_HOOKS
+static float g_q8_headroom = 1.25f;   // INT8 activation scale = |max| * headroom / 255 (tools/q8_multi.py --headroom)
+#else
+static constexpr float g_q8_headroom = 1.25f;
+#endif
 // ---- calibration of the 8-bit networks ------------------------------------------------------------------
 // Statistics: while calib_mode != 0 the trunk records, per channel of each of its 15 activations, |max| (mode 1) and the sum of
 // the stored values (8-bit tensors: de-quantised) -- fp_api.hip turns the sums into means.
@@ -761,6 +766,8 @@ int net_calib_end(Net *net, hipStream_t s, float *amax_out /*[15][512] or null*/
         sum_out[a * 512 + c] = net->calib_count[a] > 0 ? (float)((double)sums[a * 512 + c] * (1.0 / 1048576.0) / net->calib_count[a]) : 0.f;
   return 0;
 }
+void net_calib_abort(Net *net) { net->calib_mode = 0; net->calib_only = -1; }   // a calibration pass that failed half-way
+void net_q8_unready(Net *net) { net->q8_ready = false; }                          // the precision's record was dropped: quantise again before use
 // the 13 8-bit layers in trunk order; layer i reads activation i + 1 and writes activation i + 2
 static void q8_layers(Net *n, ConvLayer *(&L)[13]) {
   ConvLayer *l[13] = {&n->ra[0][0], &n->ra[0][1], &n->ra[1][0], &n->ra[1][1], &n->rb[0][0], &n->rb[0][1], &n->rb[1][0],
@@ -823,7 +830,7 @@ int net_apply_q8(Net *net, const float *amax, const float *bias_fix, const float
         float m = amax[a * 512 + c];
         if (a == 5) m = std::max(amax[a * 512 + (c & 127)], amax[a * 512 + (c & 127) + 128]);
         m = std::max(m, tmax * (1.f / 1024.f));
-        sc[c] = dt == DT_FP8 ? m / 224.f : m * 1.25f / 255.f;
+        sc[c] = dt == DT_FP8 ? m / 224.f : m * g_q8_headroom / 255.f;
       }
       net->act_scale[a] = sc;
       std::vector<float> inv(C);
@@ -1012,6 +1019,7 @@ FP_HOOK g_gemm_wpack = 1;      // gemm_k32_kernel streams its weights from the s
 FP_HOOK g_deep_wpack = 1;      // conv_deep_kernel streams its weights from the stage-order copy
 FP_HOOK g_big_wpack = 1;       // conv_big_pp_kernel streams its weights from the stage-order copy
 FP_HOOK g_halo_wpack = 1;      // conv_halo_kernel streams its weights from the stage-order copy
+FP_HOOK g_halo_wreg = 0;       // [r5] 3x3 / 40x40 layers on conv_halo_wreg_kernel: weights global -> registers (fragment-order copy), no weight ring, 2 barriers per chunk
 FP_HOOK g_i8_stream = 0;       // test build A/B: 1 = INT8 networks with an 8-bit residual stream (run_trunk_i8; faster, but its common-mode error is frame-specific: DESIGN.md section 4.4)
 FP_HOOK g_smallx_pf = 0;       // A/B (test build): prefetch depth of conv_smallx_kernel<2,4> (4 or 2; 0 = the default 3)
 FP_HOOK g_smallm = 1;          // small problems (Track, a few objects) on conv_smallm_kernel: K split over the waves of a workgroup, no split-K slabs / reduce launch
@@ -1021,7 +1029,7 @@ FP_HOOK g_att_variant = 1;     // 1 = attention32_kernel (8 = without the XCD re
 #define FP_LAUNCH(KERN, grid, block, lds_bytes, stream, ...)                                                                        \
   do {                                                                                                                              \
     static fp::PerDeviceOnce fp_attr_once_;                                                                                         \
-    if (fp_attr_once_.first()) (void)hipFuncSetAttribute((const void *)(KERN), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+    fp_attr_once_.run([] { (void)hipFuncSetAttribute((const void *)(KERN), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }); \
     hipLaunchKernelGGL((KERN), grid, block, lds_bytes, stream, __VA_ARGS__);                                                        \
   } while (0)
 
@@ -1054,6 +1062,7 @@ static int run_conv_dt(const Ctx &c, const char *tag, const ConvLayer &L, ConvPa
   constexpr int LDS3_128 = 3 * (256 * 128 + 128 * 128);
   constexpr int LDS_BIG = 2 * (256 * 128 + 256 * 128);
   constexpr int LDS_HALO40 = ((10 * 42 + 7) / 8) * 1024 + 3 * 128 * 64;
+  constexpr int LDS_HALO40W = ((10 * 42 + 7) / 8) * 1024;
   constexpr int LDS_HALO8 = ((10 * 42 + 7) / 8) * 1024 + 128 * 128;
   constexpr int LDS_STEM_HALO = ((11 * 84 + 15) / 16) * 1024 + 3 * 64 * 64;
   constexpr int LDS_DEEP64 = 6 * (64 + 128) * 128, LDS_DEEP128 = 4 * (128 + 128) * 128;
@@ -1198,6 +1207,7 @@ static int run_conv_dt(const Ctx &c, const char *tag, const ConvLayer &L, ConvPa
       if (DT == DT_F16 && g_conv_ablate == 32) { FP_LAUNCH((conv_halo_kernel<40, 32, DT_F16>), grid, dim3(256), LDS_HALO40, c.s, p); return 0; }
 #endif
       if (!g_halo_wpack) p.wpack = nullptr;
+      if (g_halo_wreg && p.wfrag && g_conv_ablate == 0) { FP_LAUNCH((conv_halo_wreg_kernel<DT>), grid, dim3(256), LDS_HALO40W, c.s, p); return 0; }
       FP_LAUNCH((conv_halo_kernel<40, 0, DT>), grid, dim3(256), LDS_HALO40, c.s, p);
     } else if constexpr (odt_q(ODT) == DT) {
       ProfScope ps(c.prof, c.s, (tg + "/conv_halo8_kernel").c_str(), flops, bytes);

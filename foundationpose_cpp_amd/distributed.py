@@ -111,22 +111,32 @@ class NativeRcclComm:
     def __init__(self, dist, device):
         import os
         import torch
-        path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
-        self._lib = C.CDLL(path if os.path.exists(path) else "librccl.so.1")
-        L = self._lib
-        L.ncclGetUniqueId.argtypes = [C.POINTER(_NcclUniqueId)]
-        L.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, _NcclUniqueId, C.c_int]
-        L.ncclCommDestroy.argtypes = [C.c_void_p]
-        L.ncclGetErrorString.restype = C.c_char_p
         world = dist.get_world_size() if dist.is_initialized() else 1
         rank = dist.get_rank() if dist.is_initialized() else 0
         uid = _NcclUniqueId()
-        if rank == 0:
-            self._check(L.ncclGetUniqueId(C.byref(uid)), "ncclGetUniqueId")
+        err = None
+        try:    # everything that can fail on ONE rank happens before any rank enters ncclCommInitRank (a rendezvous: the others would wait for ever)
+            path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+            self._lib = C.CDLL(path if os.path.exists(path) else "librccl.so.1")
+            L = self._lib
+            L.ncclGetUniqueId.argtypes = [C.POINTER(_NcclUniqueId)]
+            L.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, _NcclUniqueId, C.c_int]
+            L.ncclCommDestroy.argtypes = [C.c_void_p]
+            L.ncclGetErrorString.restype = C.c_char_p
+            if rank == 0:
+                self._check(L.ncclGetUniqueId(C.byref(uid)), "ncclGetUniqueId")
+        except Exception as e:      # noqa: BLE001 -- reported below, on every rank
+            err = e
         if world > 1:
+            flag = torch.tensor([0 if err else 1], dtype=torch.int32, device=device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0:
+                raise RuntimeError(f"NativeRcclComm: a rank could not prepare its RCCL communicator (this rank: {err!r}); none was created")
             t = torch.tensor(list(bytes(uid)), dtype=torch.uint8, device=device)
             dist.broadcast(t, 0)
             C.memmove(C.byref(uid), bytes(t.cpu().tolist()), 128)
+        elif err is not None:
+            raise err
         torch.cuda.set_device(device)
         self.comm = C.c_void_p()
         self._check(L.ncclCommInitRank(C.byref(self.comm), world, uid, rank), "ncclCommInitRank")

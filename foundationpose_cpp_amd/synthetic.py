@@ -195,6 +195,25 @@ def make_scene(mesh: Mesh, W: int = 640, H: int = 480, t=(0.02, -0.01, 0.70), ro
                  pose_matrix(R, t))
 
 
+def _family_scene(mesh: Mesh, seed: int, W: int, H: int) -> Scene:
+    """one member of the synthetic 'deployment scene family': object 0.55-0.95 m away, up to +-6 cm off axis, any orientation, its own
+    depth noise / dropped pixels / background"""
+    rng = np.random.default_rng(seed)
+    z = rng.uniform(0.55, 0.95)
+    t = (rng.uniform(-0.06, 0.06), rng.uniform(-0.05, 0.05), z)
+    return make_scene(mesh, W=W, H=H, t=t, rot_seed=seed, noise_seed=seed + 1, drop_seed=seed + 2, bg_seed=seed + 3)
+
+
+def calibration_scenes(mesh: Mesh, k: int = 8, W: int = 640, H: int = 480):
+    """K seeded scenes for fp_calibrate_begin / _add_frame / _finish (seeds 1000, 1010, ...): disjoint from heldout_scenes."""
+    return [_family_scene(mesh, 1000 + 10 * i, W, H) for i in range(k)]
+
+
+def heldout_scenes(mesh: Mesh, k: int = 4, W: int = 640, H: int = 480):
+    """scenes no calibration has seen (seeds 5000, 5010, ...; same family, other positions / rotations / noise / background)"""
+    return [_family_scene(mesh, 5000 + 10 * i, W, H) for i in range(k)]
+
+
 def perturb_pose(pose: np.ndarray, deg: float = 5.0, trans: float = 0.01, seed: int = 5) -> np.ndarray:
     rng = np.random.default_rng(seed)
     axis = rng.normal(size=3)

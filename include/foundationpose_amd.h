@@ -17,7 +17,7 @@
  *   - not re-entrant per model (like the reference: one renderer / scratch set per target,
  *     D6F/src/foundationpose.cpp:103-105); DIFFERENT models may be driven from different threads concurrently, each runs
  *     on its own non-blocking stream and their kernels overlap on the GPU.  fp_create / fp_destroy (fp_net_create / fp_net_destroy) and the
- *     entry points that load or rebuild networks (fp_set_precision, fp_calibrate*, fp_set_calibration*, fp_set_float_model) are
+ *     entry points that load or rebuild networks (fp_set_precision, fp_set_calibration*, fp_set_float_model) are
  *     exclusive against every other call of the process: they wait for calls in progress and hold new ones back while they run.
  *   - memspace arguments: FP_HOST pointers are ordinary host memory, FP_DEVICE pointers are HIP device memory on
  *     the model's device (lets callers keep frames resident in HBM).
@@ -188,7 +188,10 @@ int fp_register_shard_finish_packed(fp_model *m, const float *gathered_dev, int 
  * no staging copies, persistent buffers), and every rank evaluates the cross-hypothesis head and the arg-max redundantly: all
  * ranks return the same pose / index without a second collective.  A rank whose own half fails still joins the collective (with
  * NaN rows, which every other rank reports) so that nobody hangs.  RCCL is bound at first use (dlopen: a copy already in the
- * process, else librccl.so.1): the library has no link-time RCCL dependency.  world == 1 works without RCCL traffic. */
+ * process, else librccl.so.1): the library has no link-time RCCL dependency.  world == 1 works without RCCL traffic.
+ * A rank that cannot even allocate its exchange buffers cannot join: it calls ncclCommAbort (the other ranks' collective returns an
+ * error instead of hanging; the communicator must be re-created) and reports that.  With more than one rank the call does not take
+ * the FP_SERIALIZE_MODELS lock (one thread per rank would deadlock on it; ranks live on different devices). */
 int fp_register_sharded(fp_model *m, void *nccl_comm, const void *rgb, const void *depth, const void *mask, int memspace, int H, int W,
                         const char *target_name, int refine_itr, float out_pose[16], int *best_index /* may be NULL */);
 
@@ -244,10 +247,23 @@ int fp_net_infer(fp_net *net, int batch, int render_loc, int transf_loc, int out
 #define FP_PREC_INT8 3
 int fp_set_precision(fp_model *m, int precision);
 int fp_get_precision(const fp_model *m);
-/* Post-training static quantisation for `precision` (FP_PREC_FP8 / FP_PREC_INT8) on one frame: a Register in f16 collects per-channel
- * |max| and mean of the 15 trunk activations of both networks, the 8-bit networks are quantised from them, then ~27 Registers of
- * the 8-bit model solve the bias correction layer by layer.  The pose is discarded; the model's precision is unchanged.
- * fp_calibrate_fp8 = fp_calibrate(..., FP_PREC_FP8) (the round-2 name). */
+/* Post-training static quantisation for `precision` (FP_PREC_FP8 / FP_PREC_INT8) over the frames of a calibration session:
+ *   fp_calibrate_begin(m, precision); fp_calibrate_add_frame(m, frame ...) x K; fp_calibrate_finish(m);
+ * finish runs one f16 Register per frame to collect per-channel |max| and mean of the 15 trunk activations of both networks OVER ALL
+ * FRAMES, quantises the 8-bit networks from them, then solves the bias / token / output correction layer by layer (~30 Registers per
+ * frame).  Use K >= 8 frames of the deployment's scene family (object distances, orientations, sensor noise): the common-mode part of
+ * the correction solved on ONE frame is partly that frame's own.  Frames are copied (host) when added; any
+ * target / size the model accepts.  The precision's record is replaced only if every step succeeds -- on failure the previous record
+ * (or "uncalibrated") stays; the pose is discarded; the model's precision is unchanged.  fp_calibrate_abort drops an open session;
+ * fp_calibrate_frames = number of frames added so far (-1: no session).  Only the loading of networks not yet in memory is
+ * exclusive against other calls of the process; the Registers of the calibration run like any Register.
+ * fp_calibrate(..., precision) = begin + one add_frame + finish; fp_calibrate_fp8 = fp_calibrate(..., FP_PREC_FP8) (the round-2 name). */
+int fp_calibrate_begin(fp_model *m, int precision);
+int fp_calibrate_add_frame(fp_model *m, const void *rgb, const void *depth, const void *mask, int memspace, int H, int W,
+                           const char *target_name);
+int fp_calibrate_finish(fp_model *m);
+int fp_calibrate_abort(fp_model *m);
+int fp_calibrate_frames(const fp_model *m);
 int fp_calibrate(fp_model *m, const void *rgb, const void *depth, const void *mask, int memspace, int H, int W,
                  const char *target_name, int precision);
 int fp_calibrate_fp8(fp_model *m, const void *rgb, const void *depth, const void *mask, int memspace, int H, int W,

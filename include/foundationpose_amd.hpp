@@ -133,6 +133,13 @@ public:
   bool Calibrate(const ImageU8 &rgb, const ImageF32 &depth, const ImageU8 &mask, const std::string &target_name, int precision) {
     return ok(fp_calibrate(h_, rgb.data, depth.data, mask.data, FP_HOST, depth.rows, depth.cols, target_name.c_str(), precision));
   }
+  // ... over several frames of the deployment's scene family (K >= 8 recommended: the common-mode correction then carries over to unseen frames)
+  bool CalibrateBegin(int precision) { return ok(fp_calibrate_begin(h_, precision)); }
+  bool CalibrateAddFrame(const ImageU8 &rgb, const ImageF32 &depth, const ImageU8 &mask, const std::string &target_name) {
+    return ok(fp_calibrate_add_frame(h_, rgb.data, depth.data, mask.data, FP_HOST, depth.rows, depth.cols, target_name.c_str()));
+  }
+  bool CalibrateFinish() { return ok(fp_calibrate_finish(h_)); }
+  void CalibrateAbort() { (void)fp_calibrate_abort(h_); }
   bool GetCalibrationBlob(int precision, std::vector<unsigned char> &blob) const {
     blob.resize(fp_calibration_size());
     return fp_get_calibration_blob(h_, precision, blob.data(), blob.size()) == 0;
