@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <chrono>
+#include <thread>
 #include <cstring>
 #include <dlfcn.h>
 #include <link.h>
@@ -54,11 +55,21 @@ static hipError_t staging(unsigned char **buf, size_t *half) {
   static unsigned char *p = nullptr;   // (under g_util_mu)
   constexpr size_t HALF = (size_t)4 << 20;
   if (!p) {
-    const hipError_t e = hipHostMalloc((void **)&p, 2 * HALF, hipHostMallocPortable);
+    const hipError_t e = hipHostMalloc((void **)&p, 2 * HALF, hipHostMallocPortable | hipHostMallocMapped);
     if (e != hipSuccess) { p = nullptr; return e; }
   }
   *buf = p; *half = HALF;
   return hipSuccess;
+}
+// Host -> device through a KERNEL that reads the pinned, device-mapped staging block [r5]: no copy command on the creation / loading /
+// calibration paths.  (The one native backtrace of the fp_create crash under a concurrent PyTorch stream -- DESIGN.md section 9 --
+// ends inside hipMemcpyAsync's signal wait in the HIP 7.0 runtime PyTorch bundles; a kernel launch does not take that path.  The same
+// trick carries Track's window upload, window_fetch_kernel.)
+__global__ __launch_bounds__(256) void staged_upload_kernel(const unsigned char *__restrict__ src_mapped, unsigned char *__restrict__ dst, size_t n) {
+  const size_t n16 = n / 16;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256)
+    reinterpret_cast<uint4 *>(dst)[i] = reinterpret_cast<const uint4 *>(src_mapped)[i];
+  if (blockIdx.x == 0 && threadIdx.x < (n & 15)) dst[n16 * 16 + threadIdx.x] = src_mapped[n16 * 16 + threadIdx.x];
 }
 hipError_t memcpy_sync(void *dst, const void *src, size_t bytes, hipMemcpyKind kind) {
   std::lock_guard<std::mutex> lk(g_util_mu);
@@ -84,7 +95,12 @@ hipError_t memcpy_sync(void *dst, const void *src, size_t bytes, hipMemcpyKind k
     if (e != hipSuccess) break;
     if (kind == hipMemcpyHostToDevice) {
       std::memcpy(h, (const unsigned char *)src + off, n);
-      e = hipMemcpyAsync((unsigned char *)dst + off, h, n, hipMemcpyHostToDevice, s);
+      unsigned char *h_dev = nullptr;
+      if (((uintptr_t)((unsigned char *)dst + off) & 15) == 0 && hipHostGetDevicePointer((void **)&h_dev, h, 0) == hipSuccess) {
+        const unsigned blocks = (unsigned)std::min<size_t>(1024, (n / 16 + 255) / 256 + 1);
+        hipLaunchKernelGGL(staged_upload_kernel, dim3(blocks), dim3(256), 0, s, h_dev, (unsigned char *)dst + off, n);
+        e = hipGetLastError();
+      } else e = hipMemcpyAsync((unsigned char *)dst + off, h, n, hipMemcpyHostToDevice, s);
       if (e == hipSuccess) e = hipEventRecord(done[slot], s);
       used[slot] = true;
     } else {   // device -> host: wait for the chunk, then hand it over
@@ -419,6 +435,10 @@ struct fp_model {
   bool calibrated(int prec) const { return prec >= 0 && prec < N_PREC && !calib_amax_q[prec][0].empty(); }
   std::vector<float> calib_bias_fix[N_PREC][2], calib_tok_fix[N_PREC][2];
   std::vector<float> calib_out_fix[N_PREC][2];   // output-layer correction: refiner [8] (trans 3 | rot 3 | 0 0), scorer [512]
+  // [r5] per-frame channel means of the f16 trunk activations ([slots][15][512], slots <= FP_CALIB_SLOTS: frame f goes to slot f % slots):
+  // the INT8 weights are rounded with error feedback against them (fp_nn.hip quantise_q8), so a record must carry them
+  std::vector<float> calib_fmeans[N_PREC][2];
+  int calib_slots[N_PREC] = {0};
   // pinned staging for hypothesis poses: Register returns from its asynchronous section while the H2D copy may still be
   // queued, so the source must outlive the call (a local std::vector did not: found by the two-model serving test)
   float *track_io = nullptr, *track_io_dev = nullptr;  // host-pinned [hypothesis 16 | refined pose 16 | done flag] of Track and its device address
@@ -798,6 +818,43 @@ long long fpt_read_buffer(fp_model *m, int which, void *dst, long long max_bytes
 
 const char *fp_last_error(void) { return g_last_error.c_str(); }
 
+// Host phase of loading the networks of a precision that are not in memory yet (file I/O + five weight re-layouts per layer: 0.3-1 s)
+// -- runs BEFORE the caller takes the exclusive lifetime lock, so other models keep serving meanwhile; adopt() (under the lock) does
+// the device phase (one allocation + upload per network) and hands them to the model.
+struct PreparedNets {
+  Net *r = nullptr, *s = nullptr;
+  int prec = -1;
+  PreparedNets() = default;
+  PreparedNets(const PreparedNets &) = delete;
+  PreparedNets &operator=(const PreparedNets &) = delete;
+  ~PreparedNets() { if (r) net_free(r); if (s) net_free(s); }
+  int prepare(const std::string &refiner_path, bool have_r, const std::string &scorer_path, bool have_s, int precision) {
+    prec = precision;
+    std::string err;
+    if (!refiner_path.empty() && !have_r) {
+      r = net_prepare(refiner_path.c_str(), false, precision, &err);
+      FP_CHECK(r != nullptr, "[FoundationPose] Failed to load refiner weights: " + err);
+    }
+    if (!scorer_path.empty() && !have_s) {
+      s = net_prepare(scorer_path.c_str(), true, precision, &err);
+      FP_CHECK(s != nullptr, "[FoundationPose] Failed to load scorer weights: " + err);
+    }
+    return 0;
+  }
+  int adopt(fp_model *m) {
+    std::string err;
+    if (r && !m->refiner_p[prec]) {
+      FP_CHECK(net_commit(r, &err) == 0, "[FoundationPose] Failed to load refiner weights: " + err);
+      m->refiner_p[prec] = r; r = nullptr;
+    }
+    if (s && !m->scorer_p[prec]) {
+      FP_CHECK(net_commit(s, &err) == 0, "[FoundationPose] Failed to load scorer weights: " + err);
+      m->scorer_p[prec] = s; s = nullptr;
+    }
+    return 0;
+  }
+};
+
 // networks of precision `prec` (loaded on first use) become the model's current ones
 static int select_precision(fp_model *m, int prec) {
   FP_CHECK(prec == PREC_F16 || prec == PREC_BF16 || prec == PREC_FP8 || prec == PREC_INT8, "[FoundationPose] unknown precision");
@@ -815,7 +872,8 @@ static int select_precision(fp_model *m, int prec) {
     for (int k = 0; k < 2; k++)
       if (nets[k] && !net_q8_ready(nets[k]) &&
           net_apply_q8(nets[k], m->calib_amax_q[prec][k].data(), m->calib_bias_fix[prec][k].empty() ? nullptr : m->calib_bias_fix[prec][k].data(),
-                       m->calib_tok_fix[prec][k].empty() ? nullptr : m->calib_tok_fix[prec][k].data(), true))
+                       m->calib_tok_fix[prec][k].empty() ? nullptr : m->calib_tok_fix[prec][k].data(), true,
+                       m->calib_slots[prec] ? m->calib_fmeans[prec][k].data() : nullptr, m->calib_slots[prec]))
         return 1;
     for (int k = 0; k < 2; k++)
       if (nets[k] && !m->calib_out_fix[prec][k].empty() && net_q8_set_out_fix(nets[k], m->calib_out_fix[prec][k].data())) return 1;
@@ -836,8 +894,11 @@ static OutMode nn_mode(const fp_model *m) {
 static void destroy_model_impl(fp_model *m);
 fp_model *fp_create_on(int device, const fp_mesh *meshes, int n_meshes, const float K[9], const char *refiner_weights,
                        const char *scorer_weights, int max_h, int max_w) try {
-  LifeExclusive life;   // not while another thread is inside a call (see SerialGuard)
   if (!meshes || n_meshes <= 0 || !K) { set_error("[FoundationPose] fp_create: invalid arguments"); return nullptr; }
+  // host phase first, WITHOUT the lock [r5]: reading both weight files and building every kernel layout is most of a creation's time
+  PreparedNets nets;
+  if (nets.prepare(refiner_weights ? refiner_weights : "", false, scorer_weights ? scorer_weights : "", false, PREC_F16)) return nullptr;
+  LifeExclusive life;   // device phase: not while another thread is inside a call (see SerialGuard)
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
     set_error("[FoundationPose] no HIP device available (this library has no CPU path)");
@@ -854,9 +915,10 @@ fp_model *fp_create_on(int device, const fp_mesh *meshes, int n_meshes, const fl
   // non-blocking: no implicit synchronisation with the legacy null stream (other models' threads, the caller's framework)
   if (stream_acquire(&m->stream) != hipSuccess) { set_error("[FoundationPose] Failed to create stream"); return nullptr; }
   static_assert(sizeof(FrameRef) <= 64, "the packed window starts 64 bytes into the frame block");
-  m->win_cap = (64 + (size_t)m->max_h * m->max_w * 7 / 2 + 256 + 15) & ~(size_t)15;   // a window that takes this path is at most half the frame wide; whole 16-byte units for window_fetch_kernel
-  if (hipMalloc((void **)&m->frame_dev, m->win_cap) != hipSuccess || hipHostMalloc((void **)&m->win_stage, m->win_cap, hipHostMallocCoherent) != hipSuccess ||
-      hipHostGetDevicePointer((void **)&m->win_stage_dev, m->win_stage, 0) != hipSuccess ||
+  // the frame record's device block [FrameRef, padded to 64 bytes | packed window]: the window part and its pinned twin are allocated
+  // on the first host-frame Track that needs them and grown on demand (ensure_window) [r5] -- a model that is only ever handed device
+  // frames, or never tracks, pins no host memory
+  if (hipMalloc((void **)&m->frame_dev, 64) != hipSuccess ||
       hipHostMalloc((void **)&m->frame_pinned, 8 * sizeof(FrameRef), hipHostMallocDefault) != hipSuccess) {
     set_error("[FoundationPose] Failed to allocate the frame record");
     return nullptr;
@@ -902,7 +964,7 @@ fp_model *fp_create_on(int device, const fp_mesh *meshes, int n_meshes, const fl
   if (set_rotation_grid(m.get(), m->inplane_steps)) { destroy_model_impl(m.release()); return nullptr; }
   if (refiner_weights) m->refiner_path = refiner_weights;
   if (scorer_weights) m->scorer_path = scorer_weights;
-  if (select_precision(m.get(), PREC_F16)) { destroy_model_impl(m.release()); return nullptr; }
+  if (nets.adopt(m.get()) || select_precision(m.get(), PREC_F16)) { destroy_model_impl(m.release()); return nullptr; }
   if (hipMalloc((void **)&m->argmax_dev, sizeof(int)) != hipSuccess) { destroy_model_impl(m.release()); return nullptr; }
   return m.release();
 } FP_CATCH_PTR
@@ -967,6 +1029,30 @@ int fp_synchronize(fp_model *m) try {
 // asynchronous: the caller of this helper synchronises m->stream before the host frame can go away
 // row0 / row1 (host frames): only rows [row0, row1) are needed by the caller (Track: the observed-crop window) -- the rest of the
 // model's copy keeps whatever an earlier frame left there
+// room for a packed window of `total` bytes in the model's pinned block and its device twin (both hold the frame record in front)
+static int ensure_window(fp_model *m, size_t total) {
+  if (total <= m->win_cap) return 0;
+  const size_t limit = (64 + (size_t)m->max_h * m->max_w * 7 / 2 + 256 + 15) & ~(size_t)15;   // a window that takes this path is at most half the frame wide
+  size_t cap = std::min(limit, std::max<size_t>(total + total / 2, (size_t)256 << 10));
+  cap = (cap + 15) & ~(size_t)15;   // whole 16-byte units for window_fetch_kernel
+  if (total > cap) return 1;        // (larger than any window of this model's frame limits: the caller falls back to the 2-D copies)
+  FP_HIP_OK(hipStreamSynchronize(m->stream));
+  uint8_t *stage = nullptr, *stage_dev = nullptr;
+  FrameRef *block = nullptr;
+  if (hipHostMalloc((void **)&stage, cap, hipHostMallocCoherent) != hipSuccess) { set_error("[FoundationPose] out of pinned host memory for the Track window"); return 1; }
+  if (hipHostGetDevicePointer((void **)&stage_dev, stage, 0) != hipSuccess || hipMalloc((void **)&block, cap) != hipSuccess) {
+    (void)hipHostFree(stage);
+    set_error("[FoundationPose] out of device memory for the Track window");
+    return 1;
+  }
+  if (m->win_stage) (void)hipHostFree(m->win_stage);
+  if (m->frame_dev) (void)hipFree(m->frame_dev);
+  m->win_stage = stage; m->win_stage_dev = stage_dev; m->frame_dev = block; m->win_cap = cap;
+  m->frame_pub = FrameRef{};   // the new block holds no record yet
+  g_alloc_epoch++;             // captured graphs read the frame through the old block's address
+  return 0;
+}
+
 static int upload_frame_async(fp_model *m, const void *rgb, const void *depth, int memspace, int H, int W, int row0, int row1, int col0, int col1) {
   Target *t = nullptr;
   if (check_frame_args(m, H, W, nullptr, &t)) return 1;
@@ -999,7 +1085,7 @@ static int upload_frame_async(fp_model *m, const void *rgb, const void *depth, i
       m->frame_partial = true;
       const size_t oc = o + col0, nr = (size_t)(row1 - row0);
       const size_t rgb_bytes = (nr * cw * 3 + 63) & ~(size_t)63, total = 64 + rgb_bytes + nr * cw * 4;
-      if ((g_upload_cols == 1 || g_upload_cols == 3) && m->win_stage && total <= m->win_cap) {
+      if ((g_upload_cols == 1 || g_upload_cols == 3) && ensure_window(m, total) == 0) {
         // [r4] The caller's frame is pageable: a 2-D copy from it is staged inside the runtime and holds the calling thread until it
         // is done (two of them: ~48 us of a 260 us Track).  The window is packed here into the model's own pinned block instead (a
         // few hundred short memcpys, ~0.1 MB) TOGETHER with the frame record that describes it, and a small kernel fetches the block
@@ -1729,9 +1815,23 @@ int fp_track_wait(fp_model *m, float out_pose[16]) try {
     volatile unsigned *flag = reinterpret_cast<volatile unsigned *>(m->track_io + 32);
     const auto t0 = std::chrono::steady_clock::now();
     unsigned spins = 0;
+    // (a raised flag IS the proof of success: the kernel that raises it is the last of the chain and a faulted stream never runs it;
+    // spin briefly -- a Track takes ~0.2 ms -- then yield the core between looks)
+    bool yielding = false;
     while (*flag == 0u) {
-      __builtin_ia32_pause();
-      if ((++spins & 1023u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) break;
+      if (yielding) std::this_thread::yield();
+      else {
+#if defined(__x86_64__) || defined(__i386__)
+        __builtin_ia32_pause();
+#elif defined(__aarch64__)
+        asm volatile("yield");
+#endif
+      }
+      if ((++spins & 1023u) == 0 || yielding) {
+        const auto waited = std::chrono::steady_clock::now() - t0;
+        if (waited > std::chrono::milliseconds(20)) break;
+        yielding = waited > std::chrono::microseconds(500);
+      }
     }
     if (*flag != 0u) {
       std::atomic_thread_fence(std::memory_order_acquire);
@@ -1829,9 +1929,13 @@ int fp_track(fp_model *m, const uint8_t *rgb, const float *depth, int H, int W, 
 } FP_CATCH_INT
 
 int fp_set_precision(fp_model *m, int precision) try {
-  LifeExclusive life;   // may load the networks of a precision: as exclusive as fp_create
   FP_CHECK(m != nullptr, "[FoundationPose] null model");
+  FP_CHECK(precision == PREC_F16 || precision == PREC_BF16 || precision == PREC_FP8 || precision == PREC_INT8, "[FoundationPose] unknown precision");
+  PreparedNets nets;   // (host phase of a first selection outside the lock)
+  if (nets.prepare(m->refiner_path, m->refiner_p[precision] != nullptr, m->scorer_path, m->scorer_p[precision] != nullptr, precision)) return 1;
+  LifeExclusive life;   // may load the networks of a precision: as exclusive as fp_create
   DeviceScope on_device(m->device);
+  if (nets.adopt(m)) return 1;
   FP_HIP_OK(hipStreamSynchronize(m->stream));
   FP_CHECK(!(precision == PREC_FP8 || precision == PREC_INT8) || m->calibrated(precision),
            "[FoundationPose] an 8-bit precision needs its calibration: call fp_calibrate for it (or fp_set_calibration_blob with its record) first");
@@ -1865,23 +1969,29 @@ int fp_get_float_model(const fp_model *m) { return m ? (m->fmad ? 1 : 0) : -1; }
 // the deployment's scene family it is the family's mean and carries over to frames the calibration never saw.
 // The record of the precision is replaced only when every step succeeded; a failure restores the previous record (or leaves the
 // precision uncalibrated).  The pose is discarded; the model's precision is unchanged.  ~30 Registers per frame, once per deployment.
+static constexpr int kCalibSlots = 16;   // frame-mean slots a record carries (more frames share slots: frame f -> slot f % 16)
 struct CalibRecord {   // what fp_get_calibration_blob carries for one precision
   std::vector<float> amax[2], bias_fix[2], tok_fix[2], out_fix[2];
+  std::vector<float> fmeans[2];   // [slots][15][512]
+  int slots = 0;
   bool valid() const { return !amax[0].empty(); }
 };
 static CalibRecord record_of(const fp_model *m, int precision) {
   CalibRecord r;
-  for (int k = 0; k < 2; k++) { r.amax[k] = m->calib_amax_q[precision][k]; r.bias_fix[k] = m->calib_bias_fix[precision][k]; r.tok_fix[k] = m->calib_tok_fix[precision][k]; r.out_fix[k] = m->calib_out_fix[precision][k]; }
+  for (int k = 0; k < 2; k++) { r.amax[k] = m->calib_amax_q[precision][k]; r.bias_fix[k] = m->calib_bias_fix[precision][k]; r.tok_fix[k] = m->calib_tok_fix[precision][k]; r.out_fix[k] = m->calib_out_fix[precision][k]; r.fmeans[k] = m->calib_fmeans[precision][k]; }
+  r.slots = m->calib_slots[precision];
   return r;
 }
 static void commit_record(fp_model *m, int precision, const CalibRecord &r) {
-  for (int k = 0; k < 2; k++) { m->calib_amax_q[precision][k] = r.amax[k]; m->calib_bias_fix[precision][k] = r.bias_fix[k]; m->calib_tok_fix[precision][k] = r.tok_fix[k]; m->calib_out_fix[precision][k] = r.out_fix[k]; }
+  for (int k = 0; k < 2; k++) { m->calib_amax_q[precision][k] = r.amax[k]; m->calib_bias_fix[precision][k] = r.bias_fix[k]; m->calib_tok_fix[precision][k] = r.tok_fix[k]; m->calib_out_fix[precision][k] = r.out_fix[k]; m->calib_fmeans[precision][k] = r.fmeans[k]; }
+  m->calib_slots[precision] = r.slots;
 }
 // (re-)quantises the LOADED networks of `precision` from a record (weights and corrections)
 static int apply_record(fp_model *m, int precision, const CalibRecord &r) {
   Net *loaded[2] = {m->refiner_p[precision], m->scorer_p[precision]};
   for (int k = 0; k < 2; k++)
-    if (loaded[k] && (net_apply_q8(loaded[k], r.amax[k].data(), r.bias_fix[k].data(), r.tok_fix[k].data(), true) || net_q8_set_out_fix(loaded[k], r.out_fix[k].data()))) return 1;
+    if (loaded[k] && (net_apply_q8(loaded[k], r.amax[k].data(), r.bias_fix[k].data(), r.tok_fix[k].data(), true, r.slots ? r.fmeans[k].data() : nullptr, r.slots) ||
+                      net_q8_set_out_fix(loaded[k], r.out_fix[k].data()))) return 1;
   return 0;
 }
 
@@ -1940,7 +2050,40 @@ static int calibrate_impl(fp_model *m, const std::vector<CalibFrame> &frames, in
   };
   std::vector<float> f16_mean[2], f16_out_mean[2];
   CalibRecord rec;
-  if (pass(1, -1, rec.amax, f16_mean, f16_out_mean)) return 1;
+  {   // 1. f16 statistics, frame by frame: |max| over all frames, the mean over all frames, and every frame's own channel means (slots)
+    rec.slots = (int)std::min<size_t>(frames.size(), kCalibSlots);
+    std::vector<double> acc_out[2] = {std::vector<double>(8, 0.0), std::vector<double>(512, 0.0)};
+    std::vector<double> mean_acc[2] = {std::vector<double>(NS, 0.0), std::vector<double>(NS, 0.0)};
+    std::vector<int> per_slot(rec.slots, 0);
+    for (int k = 0; k < 2; k++) { rec.amax[k].assign(NS, 0.f); rec.fmeans[k].assign((size_t)rec.slots * NS, 0.f); }
+    Net *nets[2] = {m->refiner, m->scorer};
+    for (size_t f = 0; f < frames.size(); f++) {
+      for (Net *n : nets) net_calib_begin(n, m->stream, 1, -1);
+      m->calibrating = true;
+      int rc = fp_register_ex(m, frames[f].rgb.data(), frames[f].depth.data(), frames[f].mask.data(), FP_HOST, frames[f].H, frames[f].W, frames[f].target.c_str(), 1, pose);
+      m->calibrating = false;
+      if (!rc) rc = add_output_means(acc_out);
+      const int slot = (int)(f % (size_t)rec.slots);
+      per_slot[slot]++;
+      for (int k = 0; k < 2; k++) {
+        std::vector<float> am(NS), mn(NS);
+        rc |= net_calib_end(nets[k], m->stream, am.data(), mn.data());
+        for (size_t i = 0; i < NS; i++) {
+          rec.amax[k][i] = std::max(rec.amax[k][i], am[i]);
+          mean_acc[k][i] += mn[i];
+          rec.fmeans[k][(size_t)slot * NS + i] += mn[i];
+        }
+      }
+      if (rc) return 1;
+    }
+    for (int k = 0; k < 2; k++) {
+      f16_mean[k].resize(NS);
+      for (size_t i = 0; i < NS; i++) f16_mean[k][i] = (float)(mean_acc[k][i] * inv_frames);
+      for (int sl = 0; sl < rec.slots; sl++)
+        for (size_t i = 0; i < NS; i++) rec.fmeans[k][(size_t)sl * NS + i] /= (float)per_slot[sl];
+      f16_out_mean[k].assign(acc_out[k].begin(), acc_out[k].end());
+    }
+  }
   for (int k = 0; k < 2; k++) { rec.bias_fix[k].assign((size_t)13 * 512, 0.f); rec.tok_fix[k].assign(512, 0.f); rec.out_fix[k].assign(k == 0 ? 8 : 512, 0.f); }
   // quantise (or re-quantise) this precision's networks without corrections
   if (apply_record(m, precision, rec)) return 1;
@@ -1984,7 +2127,7 @@ static int calibrate_impl(fp_model *m, const std::vector<CalibFrame> &frames, in
     }
   }
   for (int k = 0; k < 2; k++)
-    for (const std::vector<float> *v : {&rec.amax[k], &rec.bias_fix[k], &rec.tok_fix[k], &rec.out_fix[k]})
+    for (const std::vector<float> *v : {&rec.amax[k], &rec.bias_fix[k], &rec.tok_fix[k], &rec.out_fix[k], &rec.fmeans[k]})
       for (float x : *v) FP_CHECK(std::isfinite(x), "[FoundationPose] fp_calibrate: the solved record is not finite (broken weights or frames)");
   commit_record(m, precision, rec);   // only now: every step succeeded
   invalidate_graphs(m);
@@ -2000,8 +2143,12 @@ static int calibrate_locked(fp_model *m, const std::vector<CalibFrame> &frames, 
   FP_CHECK(!m->refiner_path.empty() && !m->scorer_path.empty(), "[FoundationPose] fp_calibrate needs both networks");
   const int prev = m->prec;
   if (!m->refiner_p[precision] || !m->scorer_p[precision] || !m->refiner_p[PREC_F16] || !m->scorer_p[PREC_F16]) {
-    LifeExclusive life;   // loads networks (hundreds of allocations and uploads)
+    PreparedNets q8, f16;   // host phase outside the lock
+    if (q8.prepare(m->refiner_path, m->refiner_p[precision] != nullptr, m->scorer_path, m->scorer_p[precision] != nullptr, precision) ||
+        f16.prepare(m->refiner_path, m->refiner_p[PREC_F16] != nullptr, m->scorer_path, m->scorer_p[PREC_F16] != nullptr, PREC_F16)) return 1;
+    LifeExclusive life;   // device phase: one allocation + upload per network
     DeviceScope on_device(m->device);
+    if (q8.adopt(m) || f16.adopt(m)) return 1;
     FP_HIP_OK(hipStreamSynchronize(m->stream));
     int rc = select_precision(m, precision) || select_precision(m, PREC_F16);
     rc = select_precision(m, rc ? PREC_F16 : prev) || rc;
@@ -2019,7 +2166,8 @@ static int calibrate_locked(fp_model *m, const std::vector<CalibFrame> &frames, 
     invalidate_graphs(m);
     bool restored = before.valid() && apply_record(m, precision, before) == 0;
     if (!restored) {   // uncalibrated: fp_set_precision refuses the precision until a calibration succeeds
-      for (int k = 0; k < 2; k++) { m->calib_amax_q[precision][k].clear(); m->calib_bias_fix[precision][k].clear(); m->calib_tok_fix[precision][k].clear(); m->calib_out_fix[precision][k].clear(); }
+      for (int k = 0; k < 2; k++) { m->calib_amax_q[precision][k].clear(); m->calib_bias_fix[precision][k].clear(); m->calib_tok_fix[precision][k].clear(); m->calib_out_fix[precision][k].clear(); m->calib_fmeans[precision][k].clear(); }
+      m->calib_slots[precision] = 0;
       for (Net *n : {m->refiner_p[precision], m->scorer_p[precision]}) if (n) net_q8_unready(n);
     }
     const bool q8_prev = prev == PREC_FP8 || prev == PREC_INT8;
@@ -2097,49 +2245,64 @@ int fp_calibrate_fp8(fp_model *m, const void *rgb, const void *depth, const void
   return fp_calibrate(m, rgb, depth, mask, memspace, H, W, target_name, PREC_FP8);
 } FP_CATCH_INT
 
-// ---- the calibration record: [magic "FPQ8", version, precision, 0] + amax [2][15][512] + bias_fix [2][13][512] + tok_fix [2][512] + out_fix [8 | 512] (f32)
+// ---- the calibration record, version 2: [magic "FPQ8", 2, precision, slots] + amax [2][15][512] + bias_fix [2][13][512] + tok_fix [2][512]
+// + out_fix [8 | 512] + frame means [2][16 slots][15][512] (f32; unused slots zero).  Version 1 (round 4: no frame means, weights rounded
+// to nearest) is still accepted.
 static constexpr uint32_t kCalibMagic = 0x38515046u;
 static constexpr size_t kCalibFloats = (size_t)2 * 15 * 512 + (size_t)2 * 13 * 512 + (size_t)2 * 512 + 8 + 512;
-size_t fp_calibration_size(void) { return 16 + kCalibFloats * sizeof(float); }
+static constexpr size_t kCalibMeanFloats = (size_t)2 * kCalibSlots * 15 * 512;
+static constexpr size_t kCalibSizeV1 = 16 + kCalibFloats * sizeof(float);
+size_t fp_calibration_size(void) { return 16 + (kCalibFloats + kCalibMeanFloats) * sizeof(float); }
 int fp_get_calibration_blob(const fp_model *m, int precision, void *out, size_t capacity) try {
   FP_CHECK(m && out && (precision == PREC_FP8 || precision == PREC_INT8), "[FoundationPose] fp_get_calibration_blob: invalid arguments");
   FP_CHECK(m->calibrated(precision) && !m->calib_bias_fix[precision][0].empty(), "[FoundationPose] no calibration available for this precision");
   FP_CHECK(capacity >= fp_calibration_size(), "[FoundationPose] fp_get_calibration_blob: buffer too small (fp_calibration_size)");
-  uint32_t hdr[4] = {kCalibMagic, 1u, (uint32_t)precision, 0u};
+  const int slots = m->calib_slots[precision];
+  uint32_t hdr[4] = {kCalibMagic, 2u, (uint32_t)precision, (uint32_t)slots};
   unsigned char *p = (unsigned char *)out;
   std::memcpy(p, hdr, 16); p += 16;
   for (int k = 0; k < 2; k++) { std::memcpy(p, m->calib_amax_q[precision][k].data(), 15 * 512 * 4); p += 15 * 512 * 4; }
   for (int k = 0; k < 2; k++) { std::memcpy(p, m->calib_bias_fix[precision][k].data(), 13 * 512 * 4); p += 13 * 512 * 4; }
   for (int k = 0; k < 2; k++) { std::memcpy(p, m->calib_tok_fix[precision][k].data(), 512 * 4); p += 512 * 4; }
   for (int k = 0; k < 2; k++) { const size_t n = k == 0 ? 8 : 512; std::memcpy(p, m->calib_out_fix[precision][k].data(), n * 4); p += n * 4; }
+  for (int k = 0; k < 2; k++) {
+    const size_t n = (size_t)kCalibSlots * 15 * 512, have = (size_t)slots * 15 * 512;
+    std::memset(p, 0, n * 4);
+    if (have) std::memcpy(p, m->calib_fmeans[precision][k].data(), have * 4);
+    p += n * 4;
+  }
   return 0;
 } FP_CATCH_INT
 int fp_set_calibration_blob(fp_model *m, const void *blob, size_t bytes) try {
   LifeExclusive life;
-  FP_CHECK(m && blob && bytes == fp_calibration_size(), "[FoundationPose] fp_set_calibration_blob: invalid arguments / size");
+  FP_CHECK(m && blob && (bytes == fp_calibration_size() || bytes == kCalibSizeV1), "[FoundationPose] fp_set_calibration_blob: invalid arguments / size");
   DeviceScope on_device(m->device);
   uint32_t hdr[4];
   const unsigned char *p = (const unsigned char *)blob;
   std::memcpy(hdr, p, 16); p += 16;
-  FP_CHECK(hdr[0] == kCalibMagic && hdr[1] == 1u && (hdr[2] == (uint32_t)PREC_FP8 || hdr[2] == (uint32_t)PREC_INT8), "[FoundationPose] not a calibration record of this library version");
-  const int precision = (int)hdr[2];
+  const bool v2 = hdr[1] == 2u && bytes == fp_calibration_size(), v1 = hdr[1] == 1u && bytes == kCalibSizeV1;
+  FP_CHECK(hdr[0] == kCalibMagic && (v1 || v2) && (hdr[2] == (uint32_t)PREC_FP8 || hdr[2] == (uint32_t)PREC_INT8) && (v1 ? hdr[3] == 0u : hdr[3] <= (uint32_t)kCalibSlots),
+           "[FoundationPose] not a calibration record of this library version");
+  const int precision = (int)hdr[2], slots = v2 ? (int)hdr[3] : 0;
+  const size_t n_floats = kCalibFloats + (v2 ? kCalibMeanFloats : 0);
   {   // every float of the record must be finite (and the |max| values non-negative) BEFORE anything of the model is touched
-    std::vector<float> tmp(kCalibFloats);   // (the caller's buffer need not be aligned)
-    std::memcpy(tmp.data(), p, kCalibFloats * sizeof(float));
+    std::vector<float> tmp(n_floats);   // (the caller's buffer need not be aligned)
+    std::memcpy(tmp.data(), p, n_floats * sizeof(float));
     const float *f = tmp.data();
-    for (size_t i = 0; i < kCalibFloats; i++) FP_CHECK(std::isfinite(f[i]), "[FoundationPose] calibration record holds non-finite values");
+    for (size_t i = 0; i < n_floats; i++) FP_CHECK(std::isfinite(f[i]), "[FoundationPose] calibration record holds non-finite values");
     for (size_t i = 0; i < (size_t)2 * 15 * 512; i++) FP_CHECK(f[i] >= 0.f, "[FoundationPose] calibration record holds a negative |max|");
   }
   FP_HIP_OK(hipStreamSynchronize(m->stream));
+  CalibRecord rec;
   auto take = [&](std::vector<float> &dst, size_t n) { dst.resize(n); std::memcpy(dst.data(), p, n * 4); p += n * 4; };
-  for (int k = 0; k < 2; k++) take(m->calib_amax_q[precision][k], 15 * 512);
-  for (int k = 0; k < 2; k++) take(m->calib_bias_fix[precision][k], 13 * 512);
-  for (int k = 0; k < 2; k++) take(m->calib_tok_fix[precision][k], 512);
-  for (int k = 0; k < 2; k++) take(m->calib_out_fix[precision][k], k == 0 ? 8 : 512);
-  Net *loaded[2] = {m->refiner_p[precision], m->scorer_p[precision]};
-  for (int k = 0; k < 2; k++)
-    if (loaded[k] && (net_apply_q8(loaded[k], m->calib_amax_q[precision][k].data(), m->calib_bias_fix[precision][k].data(), m->calib_tok_fix[precision][k].data(), true) ||
-                      net_q8_set_out_fix(loaded[k], m->calib_out_fix[precision][k].data()))) return 1;
+  for (int k = 0; k < 2; k++) take(rec.amax[k], 15 * 512);
+  for (int k = 0; k < 2; k++) take(rec.bias_fix[k], 13 * 512);
+  for (int k = 0; k < 2; k++) take(rec.tok_fix[k], 512);
+  for (int k = 0; k < 2; k++) take(rec.out_fix[k], k == 0 ? 8 : 512);
+  rec.slots = slots;
+  for (int k = 0; v2 && k < 2; k++) { take(rec.fmeans[k], (size_t)kCalibSlots * 15 * 512); rec.fmeans[k].resize((size_t)slots * 15 * 512); }
+  if (apply_record(m, precision, rec)) return 1;   // (re-quantises the networks of the precision that are already loaded)
+  commit_record(m, precision, rec);
   invalidate_graphs(m);
   return 0;
 } FP_CATCH_INT
@@ -2168,6 +2331,7 @@ int fp_set_calibration(fp_model *m, const float amax[32]) try {
     for (int pr : {PREC_FP8, PREC_INT8}) {
       m->calib_amax_q[pr][k] = rec;
       m->calib_bias_fix[pr][k].assign((size_t)13 * 512, 0.f); m->calib_tok_fix[pr][k].assign(512, 0.f); m->calib_out_fix[pr][k].assign(k == 0 ? 8 : 512, 0.f);
+      m->calib_fmeans[pr][k].clear(); m->calib_slots[pr] = 0;   // (per-tensor records carry no frame means: weights rounded to nearest)
     }
   }
   for (int pr : {PREC_FP8, PREC_INT8}) {
@@ -2215,17 +2379,19 @@ static int net_blob_index(const fp_net *n, const char *name, bool *out) {
 
 static void destroy_net_impl(fp_net *n);
 fp_net *fp_net_create(const char *weights_path, int is_scorer, int max_batch) try {
-  LifeExclusive life;   // (see SerialGuard)
   if (!weights_path || max_batch <= 0) { set_error("[FoundationPose] fp_net_create: invalid arguments"); return nullptr; }
+  std::string err;
+  std::unique_ptr<Net, void (*)(Net *)> prepared(net_prepare(weights_path, is_scorer != 0, PREC_F16, &err), net_free);   // host phase, outside the lock
+  if (!prepared) { set_error("[FoundationPose] Failed to load network weights: " + err); return nullptr; }
+  LifeExclusive life;   // (see SerialGuard)
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { set_error("[FoundationPose] no HIP device available (this library has no CPU path)"); return nullptr; }
   std::unique_ptr<fp_net> n(new fp_net());
   if (hipGetDevice(&n->device) != hipSuccess) { set_error("[FoundationPose] hipGetDevice failed"); return nullptr; }
   n->scorer = is_scorer != 0;
   n->max_batch = max_batch;
-  std::string err;
-  n->net = net_load(weights_path, n->scorer, PREC_F16, &err);
-  if (!n->net) { set_error("[FoundationPose] Failed to load network weights: " + err); return nullptr; }
+  if (net_commit(prepared.get(), &err)) { set_error("[FoundationPose] Failed to load network weights: " + err); return nullptr; }
+  n->net = prepared.release();
   n->ws = nn_scratch_create(PREC_F16);
   const size_t in_elems = (size_t)max_batch * FP_CROP_HW * FP_CROP_HW * 6;
   bool ok = stream_acquire(&n->stream) == hipSuccess;

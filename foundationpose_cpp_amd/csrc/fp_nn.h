@@ -25,7 +25,10 @@ struct NNScratch;  // activation buffers, grown on demand (one object per precis
 
 // Reads a packed weight file ("FPW1" format: fp32 tensors in PyTorch layout, BatchNorm already folded into conv
 // weight+bias), checks every tensor against the fixed architecture and re-lays it out for the MFMA kernels.
-Net *net_load(const char *path, bool is_scorer, int prec, std::string *err);
+Net *net_load(const char *path, bool is_scorer, int prec, std::string *err);   // = net_prepare + net_commit
+// two-phase loading: host work (file, layouts) without any HIP call, then one device allocation + upload
+Net *net_prepare(const char *path, bool is_scorer, int prec, std::string *err);
+int net_commit(Net *net, std::string *err);
 void net_free(Net *);
 int net_precision(const Net *);
 int net_input_dt(const Net *);   // element type the network expects for nn_in (DT_F16 or DT_BF16)
@@ -38,7 +41,8 @@ bool net_q8_ready(const Net *);  // false only for an 8-bit network (PREC_FP8 / 
 // weights = false rebuilds only the biases / the table (the correction sweeps).
 void net_calib_begin(Net *net, hipStream_t s, int mode, int only_act = -1);   // only_act >= 0: record that activation only
 int net_calib_end(Net *net, hipStream_t s, float *amax_out, float *mean_out);   // [15][512] each; means over the interior pixels
-int net_apply_q8(Net *q8_net, const float *amax /*[15][512]*/, const float *bias_fix /*[13][512]*/, const float *tok_fix /*[512]*/, bool weights);
+int net_apply_q8(Net *q8_net, const float *amax /*[15][512]*/, const float *bias_fix /*[13][512]*/, const float *tok_fix /*[512]*/, bool weights,
+                 const float *frame_means = nullptr /*[n_frames][15][512]: INT8 weights rounded with error feedback against them*/, int n_frames = 0);
 int net_q8_set_out_fix(Net *q8_net, const float *fix /* refiner: [6] trans | rot biases; scorer: [512] pooled-feature bias */);
 void net_calib_abort(Net *net);
 void net_q8_unready(Net *net);

@@ -286,7 +286,7 @@ struct Net {
   ConvLayer g_in_proj, g_out_proj, g_lin1, g_lin2;
   MHA att, att_cross;                // scorer
   LinearF32 score_lin;
-  void *pe = nullptr;                // [400,512], act_dt
+  unsigned char *pe = nullptr;       // [400,512], act_dt
   // 8-bit networks (PREC_FP8 / PREC_INT8), set by net_apply_q8: per-CHANNEL activation scales of the trunk tensors that feed an
   // 8-bit convolution (real = stored * scale, DT_I8: real = (stored + 128) * scale); act_oinv = 1 / scale on the device for the
   // producers that write an f16 stream tensor together with its 8-bit copy (DT_DUAL_*); bias_fix / tok_fix = the bias correction
@@ -307,19 +307,51 @@ struct Net {
   int calib_only = -1;                               // >= 0: record this activation only (the sequential correction sweeps)
   mutable double calib_count[N_TRUNK_ACT] = {0};     // interior pixels summed per activation (host side)
   std::vector<void *> allocs;
+  // Two-phase loading [r5]: net_prepare reads the file and builds every layout on the HOST (no HIP call: it runs outside the
+  // process-wide exclusive section); each device buffer it wants is recorded here as (address of the pointer field, bytes) and the
+  // field holds a placeholder until net_commit carves one arena, uploads, and patches the fields.
+  struct Pending {
+    void **slot;
+    std::vector<unsigned char> bytes;
+  };
+  std::vector<Pending> pending;
+  bool deferred = false;
+  const std::vector<unsigned char> *pending_bytes(const void *slot) const {
+    for (const Pending &q : pending)
+      if ((const void *)q.slot == slot) return &q.bytes;
+    return nullptr;
+  }
   ~Net() {
     for (void *p : allocs) (void)hipFree(p);
   }
 };
+static unsigned char g_placeholder;   // what a deferred pointer field holds between net_prepare and net_commit (never dereferenced)
 
 template <typename T>
 static T *upload(Net *net, const std::vector<T> &h) {
+  if (net->deferred) return nullptr;   // (every load-time buffer goes through put(): the field's address is what net_commit patches)
   T *d = nullptr;
   if (hipMalloc((void **)&d, std::max<size_t>(h.size(), 1) * sizeof(T)) != hipSuccess) return nullptr;
   net->allocs.push_back(d);
   if (fp::memcpy_sync(d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
   return d;
 }
+
+// device copy of a host vector: allocated the first time, overwritten in place afterwards (re-calibration of an 8-bit network)
+template <typename T>
+static bool put(Net *net, T *&dst, const std::vector<T> &h) {
+  if (net->deferred) {
+    const unsigned char *b = reinterpret_cast<const unsigned char *>(h.data());
+    for (Net::Pending &q : net->pending)
+      if (q.slot == (void **)&dst) { q.bytes.assign(b, b + h.size() * sizeof(T)); return true; }
+    net->pending.push_back({(void **)&dst, std::vector<unsigned char>(b, b + h.size() * sizeof(T))});
+    dst = reinterpret_cast<T *>(&g_placeholder);
+    return true;
+  }
+  if (!dst) { dst = upload(net, h); return dst != nullptr; }
+  return fp::memcpy_sync(dst, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice) == hipSuccess;
+}
+static bool put_bytes(Net *net, unsigned char *&dst, const std::vector<unsigned char> &h) { return put<unsigned char>(net, dst, h); }
 
 // ---- host-side element conversion (round to nearest even) ----
 static uint16_t f32_to_bf16_bits(float x) {
@@ -363,40 +395,31 @@ static std::vector<unsigned char> to_elems(const std::vector<float> &w, int rows
   return o;
 }
 
-// [a | b] device copy of two equally shaped Linear layers (weights already in kernel row order)
+// [a | b] copy of two equally shaped Linear layers (weights already in kernel row order), concatenated on the host from the
+// layers' pending uploads (net_prepare)
 static bool make_grouped(Net *net, const ConvLayer &a, const ConvLayer &b, ConvLayer *g) {
-  if (a.Cin != b.Cin || a.Cout != b.Cout || a.dt != b.dt) return false;
-  const size_t nw = (size_t)a.Cout * a.Cin * elem_bytes(a.dt), nb = (size_t)a.Cout;
-  unsigned char *w = nullptr;
-  float *bias = nullptr;
-  if (hipMalloc((void **)&w, 2 * nw) != hipSuccess) return false;
-  net->allocs.push_back(w);
-  if (hipMalloc((void **)&bias, 2 * nb * sizeof(float)) != hipSuccess) return false;
-  net->allocs.push_back(bias);
-  if (fp::memcpy_sync(w, a.w, nw, hipMemcpyDeviceToDevice) != hipSuccess || fp::memcpy_sync(w + nw, b.w, nw, hipMemcpyDeviceToDevice) != hipSuccess ||
-      fp::memcpy_sync(bias, a.bias, nb * 4, hipMemcpyDeviceToDevice) != hipSuccess || fp::memcpy_sync(bias + nb, b.bias, nb * 4, hipMemcpyDeviceToDevice) != hipSuccess)
-    return false;
+  if (a.Cin != b.Cin || a.Cout != b.Cout || a.dt != b.dt || !net->deferred) return false;
+  auto cat = [&](const void *sa, const void *sb, std::vector<unsigned char> *out) {
+    const std::vector<unsigned char> *pa = net->pending_bytes(sa), *pb = net->pending_bytes(sb);
+    if (!pa || !pb || pa->size() != pb->size()) return false;
+    *out = *pa;
+    out->insert(out->end(), pb->begin(), pb->end());
+    return true;
+  };
   *g = a;
-  g->w = w;
-  g->bias = bias;
-  g->wfrag = nullptr;
-  g->wpack = nullptr;   // (the grouped launch never runs on gemm_k32_kernel)
-  g->wpack128 = nullptr;
-  if (a.wfrag && b.wfrag) {  // (a group's fragment-order copy has the size of its row-major copy: the same group stride serves both)
-    unsigned char *wf = nullptr;
-    if (hipMalloc((void **)&wf, 2 * nw) != hipSuccess) return false;
-    net->allocs.push_back(wf);
-    if (fp::memcpy_sync(wf, a.wfrag, nw, hipMemcpyDeviceToDevice) != hipSuccess || fp::memcpy_sync(wf + nw, b.wfrag, nw, hipMemcpyDeviceToDevice) != hipSuccess) return false;
-    g->wfrag = wf;
+  g->w = nullptr; g->bias = nullptr; g->wfrag = nullptr; g->wpack = nullptr; g->wpack128 = nullptr; g->wdeep = nullptr;   // (the grouped launch never runs on gemm_k32_kernel)
+  std::vector<unsigned char> buf;
+  if (!cat(&a.w, &b.w, &buf) || !put_bytes(net, g->w, buf)) return false;
+  {
+    std::vector<unsigned char> bb;
+    if (!cat(&a.bias, &b.bias, &bb)) return false;
+    std::vector<float> bf(bb.size() / 4);
+    std::memcpy(bf.data(), bb.data(), bb.size());
+    if (!put(net, g->bias, bf)) return false;
   }
-  g->wdeep = nullptr;
-  if (a.wdeep && b.wdeep) {
-    unsigned char *wd = nullptr;
-    if (hipMalloc((void **)&wd, 2 * nw) != hipSuccess) return false;
-    net->allocs.push_back(wd);
-    if (fp::memcpy_sync(wd, a.wdeep, nw, hipMemcpyDeviceToDevice) != hipSuccess || fp::memcpy_sync(wd + nw, b.wdeep, nw, hipMemcpyDeviceToDevice) != hipSuccess) return false;
-    g->wdeep = wd;
-  }
+  // (a group's fragment-order / deep-ring copy has the size of its row-major copy: the same group stride serves them)
+  if (a.wfrag && b.wfrag && (!cat(&a.wfrag, &b.wfrag, &buf) || !put_bytes(net, g->wfrag, buf))) return false;
+  if (a.wdeep && b.wdeep && (!cat(&a.wdeep, &b.wdeep, &buf) || !put_bytes(net, g->wdeep, buf))) return false;
   return true;
 }
 
@@ -492,14 +515,6 @@ static std::vector<unsigned char> pack_stage_w128(const std::vector<unsigned cha
   return o;
 }
 
-// device copy of a host vector: allocated the first time, overwritten in place afterwards (re-calibration of an 8-bit network)
-template <typename T>
-static bool put(Net *net, T *&dst, const std::vector<T> &h) {
-  if (!dst) { dst = upload(net, h); return dst != nullptr; }
-  return fp::memcpy_sync(dst, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice) == hipSuccess;
-}
-static bool put_bytes(Net *net, unsigned char *&dst, const std::vector<unsigned char> &h) { return put<unsigned char>(net, dst, h); }
-
 // element bytes [Cout][tap][Cin] -> every device layout the layer's schedules stream from
 static bool upload_layouts(Net *net, const std::vector<unsigned char> &elems, int Cout, int ntaps, int Cin, int dt, ConvLayer *L) {
   const int K = ntaps * Cin, es = elem_bytes(dt);
@@ -526,14 +541,35 @@ static bool upload_layouts(Net *net, const std::vector<unsigned char> &elems, in
 }
 
 // 8-bit quantisation of a layer's rows with the per-INPUT-channel activation scales folded in first (w'[co][tap][ci] = w * s_in[ci];
-// s_in = null: all 1): per output row a scale sw (FP8: amax / 448, OCP e4m3, RNE, saturating; I8: amax / 127, RNE) and, for I8, the
+// s_in = null: all 1): per output row a scale sw (FP8: amax / 448, OCP e4m3, RNE, saturating; I8: amax / 127) and, for I8, the
 // row sum of the quantised integers (the -128 offset of the unsigned activations contributes 128 * sum to every accumulator).
-static std::vector<unsigned char> quantise_q8(const ConvLayer &L, int dt, const float *s_in, std::vector<float> *sw, std::vector<double> *qsum) {
+//
+// I8 rounding [r5]: ERROR-FEEDBACK rounding against the calibration frames' channel means (m_int: [J][Cin], the mean INTEGER
+// activation of every input channel in each of J calibration frames; null = round to nearest).  Why: with round-to-nearest the
+// weight errors d_k of a row are independent, so the row's mean output error sum_k d_k * mean(x_k) is a random walk over K = 1152-4608
+// terms -- a common-mode shift of every hypothesis' features that the discriminating heads amplify, and that differs from scene to
+// scene with the channel means (tools/q8_sim_cross.py: ALL of the cross-scene common-mode error of the INT8 trunk comes from the
+// weights, none from the 8-bit activations; a bias correction removes it only for the calibration frames' own means).  Here every
+// weight whose fraction lies within TAU of .5 (either neighbour costs almost the same rounding error) is rounded up or down so that
+// the running sums r_j = sum_k d_k m_j[c(k)] stay near zero for EVERY frame j: the mean error cancels by construction, also for
+// scenes whose channel means are (near) combinations of the calibration frames'.  Weights further from .5 round to nearest, which
+// keeps the per-pixel (de-meaned) error where it was.
+#ifdef FP_TEST_HOOKS
+static float g_q8_headroom = 1.25f;   // INT8 activation scale = |max| * headroom / 255 (tools/q8_multi.py --headroom)
+static int g_q8_wclip = 1, g_q8_efr = 1;   // A/B (tools/q8_multi.py --wq): the row-step search / the error-feedback rounding of quantise_q8
+#else
+static constexpr float g_q8_headroom = 1.25f;
+static constexpr int g_q8_wclip = 1, g_q8_efr = 1;
+#endif
+static constexpr float kEfrTau = 0.2f;
+static std::vector<unsigned char> quantise_q8(const ConvLayer &L, int dt, const float *s_in, std::vector<float> *sw, std::vector<double> *qsum,
+                                              const float *m_int = nullptr, int J = 0) {
   const int K = L.ntaps * L.Cin;
   std::vector<unsigned char> o((size_t)L.Cout * K);
   sw->assign(L.Cout, 1.f);
   qsum->assign(L.Cout, 0.0);
   std::vector<float> wf(K);
+  std::vector<double> r(std::max(J, 1));
   for (int co = 0; co < L.Cout; co++) {
     const float *src = &L.rows_f32[(size_t)co * K];
     float amax = 0.f;
@@ -541,16 +577,57 @@ static std::vector<unsigned char> quantise_q8(const ConvLayer &L, int dt, const 
       wf[k] = s_in ? src[k] * s_in[k % L.Cin] : src[k];
       amax = std::max(amax, std::fabs(wf[k]));
     }
-    const float sc = amax > 0.f ? amax / (dt == DT_FP8 ? 448.f : 127.f) : 1.f;
+    float sc = amax > 0.f ? amax / (dt == DT_FP8 ? 448.f : 127.f) : 1.f;
+    if (dt == DT_I8 && m_int && J > 0 && amax > 0.f && g_q8_wclip) {
+      // the row's step [r5]: the range that minimises the activation-weighted squared rounding + clipping error,
+      // sum_k (q_k sc - w_k)^2 E_j[m_j,c(k)^2], over amax * {1, .95, ..., .5} / 127 -- a row's few largest folded weights (large weight on a
+      // channel with a large activation scale) otherwise set the step of the thousands of ordinary ones
+      std::vector<double> m2(L.Cin, 0.0);
+      for (int j = 0; j < J; j++)
+        for (int c = 0; c < L.Cin; c++) m2[c] += (double)m_int[(size_t)j * L.Cin + c] * m_int[(size_t)j * L.Cin + c] / J;
+      double best = -1;
+      float best_sc = sc;
+      for (int step = 0; step <= 10; step++) {
+        const float cand = amax * (1.f - 0.05f * step) / 127.f;
+        double err = 0;
+        for (int k = 0; k < K; k++) {
+          const float q = std::max(-127.f, std::min(127.f, std::nearbyint(wf[k] / cand)));
+          const double d = (double)q * cand - wf[k];
+          err += d * d * (m2[k % L.Cin] + 1.0);
+        }
+        if (best < 0 || err < best) { best = err; best_sc = cand; }
+      }
+      sc = best_sc;
+    }
     (*sw)[co] = sc;
     double qs = 0;
+    std::fill(r.begin(), r.end(), 0.0);
     for (int k = 0; k < K; k++) {
-      if (dt == DT_FP8) o[(size_t)co * K + k] = f32_to_e4m3_bits(wf[k] / sc);
-      else {
-        const int q = (int)std::max(-127.f, std::min(127.f, std::nearbyint(wf[k] / sc)));
-        o[(size_t)co * K + k] = (unsigned char)(signed char)q;
-        qs += q;
+      if (dt == DT_FP8) { o[(size_t)co * K + k] = f32_to_e4m3_bits(wf[k] / sc); continue; }
+      const float v = wf[k] / sc;
+      int q;
+      if (m_int && J > 0) {
+        const float base = std::floor(v), frac = v - base;
+        bool up = frac >= 0.5f;
+        const int c = k % L.Cin;
+        const double e_dn = -(double)frac, e_up = 1.0 - (double)frac;
+        if (std::fabs(frac - 0.5f) < kEfrTau && std::fabs(v) < 126.f) {
+          double c_dn = 0, c_up = 0;
+          for (int j = 0; j < J; j++) {
+            const double m = m_int[(size_t)j * L.Cin + c];
+            const double a = r[j] + e_dn * m, b = r[j] + e_up * m;
+            c_dn += a * a; c_up += b * b;
+          }
+          up = c_up < c_dn;
+        }
+        q = std::max(-127, std::min(127, (int)base + (up ? 1 : 0)));
+        const double e = (double)q - (double)v;   // (the error actually made: a clipped weight's is larger than one step)
+        for (int j = 0; j < J; j++) r[j] += e * m_int[(size_t)j * L.Cin + c];
+      } else {
+        q = (int)std::max(-127.f, std::min(127.f, std::nearbyint(v)));
       }
+      o[(size_t)co * K + k] = (unsigned char)(signed char)q;
+      qs += q;
     }
     (*qsum)[co] = qs;
   }
@@ -631,10 +708,8 @@ static bool make_linear_f32(Net *net, const std::map<std::string, HostTensor> &m
   const HostTensor *w, *b;
   if (!get(m, wname, &w, err) || !get(m, bname, &b, err)) return false;
   if (!shape_is(w, {out, in}) || !shape_is(b, {out})) { *err = wname + ": unexpected Linear shape"; return false; }
-  L->w = upload(net, w->data);
-  L->b = upload(net, b->data);
   L->out = out; L->in = in;
-  return L->w && L->b;
+  return put(net, L->w, w->data) && put(net, L->b, b->data);
 }
 
 static bool make_ln(Net *net, const std::map<std::string, HostTensor> &m, const std::string &prefix, LNParams *L,
@@ -642,9 +717,7 @@ static bool make_ln(Net *net, const std::map<std::string, HostTensor> &m, const 
   const HostTensor *w, *b;
   if (!get(m, prefix + ".weight", &w, err) || !get(m, prefix + ".bias", &b, err)) return false;
   if (!shape_is(w, {EMBED}) || !shape_is(b, {EMBED})) { *err = prefix + ": unexpected LayerNorm shape"; return false; }
-  L->g = upload(net, w->data);
-  L->b = upload(net, b->data);
-  return L->g && L->b;
+  return put(net, L->g, w->data) && put(net, L->b, b->data);
 }
 
 static bool make_mha(Net *net, const std::map<std::string, HostTensor> &m, const std::string &prefix, int dt, MHA *a,
@@ -660,6 +733,7 @@ static Net *net_load_impl(const char *path, bool is_scorer, int prec, std::strin
   std::unique_ptr<Net> net(new Net());
   net->scorer = is_scorer;
   net->prec = prec;
+  net->deferred = true;   // host phase: every put() records a pending upload (net_commit makes the device copies)
   // PREC_FP8 / PREC_INT8: the 3x3 trunk convolutions from encodeA.2 on (91 % of the FLOPs) run on 8-bit operands; the stem and
   // encodeA.1 (bandwidth-bound, K = 294 / 576) and the transformer part stay in f16
   const int adt = prec == PREC_BF16 ? DT_BF16 : DT_F16;
@@ -706,25 +780,18 @@ static Net *net_load_impl(const char *path, bool is_scorer, int prec, std::strin
         pe[(size_t)t * EMBED + 2 * i] = std::sin((float)t * div);
         pe[(size_t)t * EMBED + 2 * i + 1] = std::cos((float)t * div);
       }
-    net->pe = upload(net.get(), to_elems(pe, 400, EMBED, adt, nullptr));
+    ok = put_bytes(net.get(), net->pe, to_elems(pe, 400, EMBED, adt, nullptr));
     net->pe_host = pe;
-    ok = net->pe != nullptr;
-    if (!ok) *err = "device allocation failed";
-  }
-  if (ok) {
-    unsigned char *c = nullptr;
-    const size_t nb = (size_t)N_TRUNK_ACT * 512 * (sizeof(float) + sizeof(long long));
-    ok = hipMalloc((void **)&c, nb) == hipSuccess && fp::memset_sync(c, 0, nb) == hipSuccess;
-    if (c) net->allocs.push_back(c);
-    net->calib_sum = reinterpret_cast<long long *>(c);
-    net->calib_amax = reinterpret_cast<float *>(c + (size_t)N_TRUNK_ACT * 512 * sizeof(long long));
     if (!ok) *err = "device allocation failed";
   }
   if (!ok) return nullptr;
   return net.release();
 }
 
-Net *net_load(const char *path, bool is_scorer, int prec, std::string *err) {
+static void q8_layers(Net *n, ConvLayer *(&L)[13]);
+// Host phase of loading: the weight file is read and every device layout is built in host memory.  No HIP call, no device needed:
+// callers run it OUTSIDE the process-wide exclusive section (fp_create, fp_set_precision, fp_calibrate: fp_api.hip).
+Net *net_prepare(const char *path, bool is_scorer, int prec, std::string *err) {
   try {  // a malformed file must not take the process down through the C ABI
     return net_load_impl(path, is_scorer, prec, err);
   } catch (const std::exception &e) {
@@ -732,17 +799,54 @@ Net *net_load(const char *path, bool is_scorer, int prec, std::string *err) {
     return nullptr;
   }
 }
+// Device phase: ONE allocation (every buffer a 256-byte-aligned slice of it), ONE staged upload, the pointer fields patched.  On
+// failure the network is unusable and the caller frees it.
+int net_commit(Net *net, std::string *err) {
+  if (!net->deferred) return 0;
+  auto slice = [](const Net::Pending &q) { return (std::max<size_t>(q.bytes.size(), 1) + 255) & ~(size_t)255; };
+  size_t total = 0;
+  for (const Net::Pending &q : net->pending) total += slice(q);
+  const size_t calib_off = total;
+  total += (size_t)N_TRUNK_ACT * 512 * (sizeof(float) + sizeof(long long));
+  unsigned char *arena = nullptr;
+  if (hipMalloc((void **)&arena, total) != hipSuccess) { *err = "device allocation failed"; return 1; }
+  net->allocs.push_back(arena);
+  std::vector<unsigned char> image(total, 0);   // host image of the arena (the calibration statistics start zeroed)
+  size_t off = 0;
+  for (const Net::Pending &q : net->pending) {
+    if (!q.bytes.empty()) std::memcpy(&image[off], q.bytes.data(), q.bytes.size());
+    off += slice(q);
+  }
+  if (fp::memcpy_sync(arena, image.data(), total, hipMemcpyHostToDevice) != hipSuccess) { *err = "device upload failed"; return 1; }
+  off = 0;
+  for (Net::Pending &q : net->pending) {
+    *q.slot = arena + off;
+    off += slice(q);
+  }
+  net->calib_sum = reinterpret_cast<long long *>(arena + calib_off);
+  net->calib_amax = reinterpret_cast<float *>(arena + calib_off + (size_t)N_TRUNK_ACT * 512 * sizeof(long long));
+  // fields that ALIAS another field's buffer were copied while both held the placeholder: ConvLayer::wdeep = wpack (8-bit 3x3 layers)
+  ConvLayer *q8l[13];
+  q8_layers(net, q8l);
+  for (ConvLayer *l : q8l)
+    if (l->wdeep == &g_placeholder) l->wdeep = l->wpack;
+  net->pending.clear();
+  net->pending.shrink_to_fit();
+  net->deferred = false;
+  return 0;
+}
+
+Net *net_load(const char *path, bool is_scorer, int prec, std::string *err) {
+  Net *n = net_prepare(path, is_scorer, prec, err);
+  if (n && net_commit(n, err)) { delete n; n = nullptr; }
+  return n;
+}
 
 void net_free(Net *n) { delete n; }
 int net_precision(const Net *n) { return n->prec; }
 int net_input_dt(const Net *n) { return n->act_dt; }
 bool net_q8_ready(const Net *n) { return !(n->prec == PREC_FP8 || n->prec == PREC_INT8) || n->q8_ready; }
 
-#ifdef FP_TEST_HOOKS
-static float g_q8_headroom = 1.25f;   // INT8 activation scale = |max| * headroom / 255 (tools/q8_multi.py --headroom)
-#else
-static constexpr float g_q8_headroom = 1.25f;
-#endif
 // ---- calibration of the 8-bit networks ------------------------------------------------------------------
 // Statistics: while calib_mode != 0 the trunk records, per channel of each of its 15 activations, |max| (mode 1) and the sum of
 // the stored values (8-bit tensors: de-quantised) -- fp_api.hip turns the sums into means.
@@ -783,12 +887,13 @@ int net_q8_bias_channels(int layer) { return layer < 4 ? 128 : layer < 8 ? 256 :
 // One 8-bit layer: (weights) quantise its rows with the input-channel scales s_in folded in and upload every layout; then the epilogue
 // tables.  accumulator -> real value: acc * sw (+ DT_I8: 128 * sw * sum_k q, the offset of the unsigned activations) + bias + fix;
 // s_out_fold != null (the output is 8-bit ONLY): the consumer's inverse scales multiply both (legal: no residual, ReLU).
-static int apply_q8_layer(Net *net, ConvLayer &l, int dt, const float *s_in, const float *bias_fix, const float *s_out_fold, bool weights) {
+static int apply_q8_layer(Net *net, ConvLayer &l, int dt, const float *s_in, const float *bias_fix, const float *s_out_fold, bool weights,
+                          const float *m_int = nullptr, int J = 0) {
   const int Cout = l.Cout;
   if (weights) {
     std::vector<float> sw;
     std::vector<double> qsum;
-    const auto elems = quantise_q8(l, dt, s_in, &sw, &qsum);
+    const auto elems = quantise_q8(l, dt, s_in, &sw, &qsum, dt == DT_I8 ? m_int : nullptr, J);
     if (!upload_layouts(net, elems, Cout, l.ntaps, l.Cin, dt, &l)) { set_error("net_apply_q8: device upload failed"); return 1; }
     l.q_sw = sw; l.q_sum = qsum;
   }
@@ -812,7 +917,9 @@ static int apply_q8_layer(Net *net, ConvLayer &l, int dt, const float *s_in, con
 //   (amax floored at 1/1024 of the tensor's largest channel)
 //   the concat tensor (activation 5) gets the SAME scale for channel c of its a-half and its b-half, so that its producer (128
 //   output channels, two image groups) indexes one table.
-int net_apply_q8(Net *net, const float *amax, const float *bias_fix, const float *tok_fix, bool weights) {
+// frame_means [n_frames][15][512] (weights = true only; null / 0 = round to nearest): per-channel means of the f16 network's trunk
+// activations in each calibration frame -- what the INT8 weights' error-feedback rounding cancels against (quantise_q8).
+int net_apply_q8(Net *net, const float *amax, const float *bias_fix, const float *tok_fix, bool weights, const float *frame_means, int n_frames) {
   FP_CHECK(net->prec == PREC_FP8 || net->prec == PREC_INT8, "net_apply_q8: not an 8-bit network");
   const int dt = net->qdt;
   ConvLayer *L[13];
@@ -845,9 +952,18 @@ int net_apply_q8(Net *net, const float *amax, const float *bias_fix, const float
     if (bias_fix) net->bias_fix[i].assign(bias_fix + (size_t)i * 512, bias_fix + (size_t)i * 512 + Cout);
     else if (net->bias_fix[i].empty()) net->bias_fix[i].assign(Cout, 0.f);
   }
-  for (int i = 0; i < 13; i++)
+  std::vector<float> m_int;
+  for (int i = 0; i < 13; i++) {
+    const int a = i + 1, Cin = L[i]->Cin;   // layer i reads activation i + 1
+    const bool efr = weights && dt == DT_I8 && frame_means && n_frames > 0 && g_q8_efr;
+    if (efr) {   // mean integer activation of every input channel per frame: f16 mean / scale
+      m_int.assign((size_t)n_frames * Cin, 0.f);
+      for (int j = 0; j < n_frames; j++)
+        for (int c = 0; c < Cin; c++) m_int[(size_t)j * Cin + c] = frame_means[((size_t)j * N_TRUNK_ACT + a) * 512 + c] / net->act_scale[a][c];
+    }
     if (apply_q8_layer(net, *L[i], dt, net->act_scale[i + 1].data(), net->bias_fix[i].data(),
-                       q8_folded_out(i) ? net->act_scale[i + 2].data() : nullptr, weights)) return 1;
+                       q8_folded_out(i) ? net->act_scale[i + 2].data() : nullptr, weights, efr ? m_int.data() : nullptr, efr ? n_frames : 0)) return 1;
+  }
   if (tok_fix) net->tok_fix.assign(tok_fix, tok_fix + EMBED);
   else if (net->tok_fix.empty()) net->tok_fix.assign(EMBED, 0.f);
   {  // positional table + token correction (the trunk's last epilogue adds the table to the rounded token)

@@ -268,7 +268,8 @@ int fp_calibrate(fp_model *m, const void *rgb, const void *depth, const void *ma
                  const char *target_name, int precision);
 int fp_calibrate_fp8(fp_model *m, const void *rgb, const void *depth, const void *mask, int memspace, int H, int W,
                      const char *target_name);
-/* The calibration record of a precision (scales + corrections, fp_calibration_size() bytes, versioned) so that a deployment
+/* The calibration record of a precision (scales + corrections + the calibration frames' channel means the INT8 weights were rounded
+ * against; fp_calibration_size() bytes, versioned: records written by the previous version are still accepted) so that a deployment
  * calibrates once and reuses it; fp_set_calibration_blob reads the precision from the record. */
 size_t fp_calibration_size(void);
 int fp_get_calibration_blob(const fp_model *m, int precision, void *out, size_t capacity);

@@ -386,7 +386,7 @@ def test_two_models_stay_exact_while_foreign_kernels_share_the_gpu(wpaths, syn_m
     (the reproducer for an upstream report)."""
     import os
     repro = os.environ.get("FP_TEST_FOREIGN_AND_CREATE") is not None
-    _concurrent_serving(wpaths, syn_mesh, syn_scene, 500, True, repro, in_process=repro)
+    _concurrent_serving(wpaths, syn_mesh, syn_scene, int(os.environ.get("FP_TEST_FOREIGN_ITERS", "500")), True, repro, in_process=repro)
 
 
 def test_models_are_created_and_destroyed_while_others_serve(wpaths, syn_mesh, syn_scene):
@@ -394,6 +394,83 @@ def test_models_are_created_and_destroyed_while_others_serve(wpaths, syn_mesh, s
     replay) and destroys three more models -- the lifetime lock (fp_create / fp_destroy exclusive against calls in progress), the
     recycled streams and the capture-safe copies of fp_api.hip at work"""
     _concurrent_serving(wpaths, syn_mesh, syn_scene, 200, False, True)
+
+
+def test_foreign_stream_and_creation_in_one_process_is_tracked():
+    """The in-process scenario that crashed inside the HIP 7.0 runtime PyTorch bundles (hipMemcpyAsync's signal wait on the creation path
+    while a PyTorch stream runs on another thread: docstring above) stays in the default suite -- in a CHILD pytest
+    process, because a SIGSEGV cannot be caught in-process.  Round 5 took every host -> device copy of the creation / loading /
+    calibration paths off hipMemcpyAsync (a kernel reads the pinned staging block: fp_api.hip staged_upload_kernel) and moved file I/O and
+    weight re-layouts out of the exclusive section; the Registers of the worker threads still use copy commands for the frame and the
+    result, so the crash is made rarer, not impossible.  A child that dies on a signal is reported as an expected failure with the
+    signal number (the limitation is stated in README.md / INTEGRATION.md section 5); any OTHER failure fails this test."""
+    import subprocess
+    import sys
+    env = dict(os.environ, FP_TEST_FOREIGN_AND_CREATE="1", FP_TEST_FOREIGN_ITERS="120")
+    res = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", os.path.abspath(__file__) + "::test_two_models_stay_exact_while_foreign_kernels_share_the_gpu"],
+                         capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    if res.returncode < 0 or res.returncode in (134, 139):
+        pytest.xfail(f"known upstream crash (HIP runtime bundled with PyTorch): child ended with {res.returncode}: {res.stderr[-400:]}")
+    assert res.returncode == 0, (res.returncode, res.stdout[-3000:], res.stderr[-2000:])
+
+
+def test_other_models_keep_serving_while_one_is_created_or_calibrated(wpaths, syn_mesh, syn_scene):
+    """Round-4 review: fp_create held the process-wide exclusive lock across file I/O and five weight re-layouts (0.3-1 s), fp_calibrate
+    across its ~30 Registers -- every other model's Track stalled that long.  Now the host phase of loading runs before the lock
+    (net_prepare / net_commit) and a calibration's Registers run under the shared lock: model B tracks in a loop while thread A creates,
+    calibrates and destroys models; B's 99th-percentile call latency stays below 2 ms (measured 1.1 ms: while A's calibration Registers
+    run, B's 26 small kernels share the CUs with 252-hypothesis convolutions -- GPU contention, not a lock) and its worst call far below
+    the old 0.3-1 s stalls."""
+    import threading
+    import time
+    from foundationpose_cpp_amd.api import FP_PREC_INT8
+    b = FoundationPose(syn_mesh, syn.intrinsics(), *wpaths)
+    hyp = syn.perturb_pose(syn_scene.gt_pose)
+    stop = threading.Event()
+    done = {"creates": 0, "calibrations": 0, "error": None}
+
+    def churn():
+        try:
+            while not stop.is_set():
+                m = FoundationPose(syn_mesh, syn.intrinsics(), *wpaths)
+                done["creates"] += 1
+                if done["creates"] % 2 == 1:
+                    m.calibrate(syn_scene.rgb, syn_scene.depth, syn_scene.mask, syn_mesh.name, FP_PREC_INT8)
+                    done["calibrations"] += 1
+                m.close()
+        except Exception as e:      # noqa: BLE001
+            done["error"] = e
+
+    try:
+        for _ in range(20):
+            ok, ref = b.Track(syn_scene.rgb, syn_scene.depth, hyp, syn_mesh.name)
+            assert ok, b.last_error
+        quiet = []
+        for _ in range(500):
+            t0 = time.perf_counter()
+            ok, p = b.Track(syn_scene.rgb, syn_scene.depth, hyp, syn_mesh.name)
+            quiet.append(time.perf_counter() - t0)
+        th = threading.Thread(target=churn)
+        th.start()
+        lat = []
+        t_end = time.perf_counter() + 8.0
+        while time.perf_counter() < t_end:
+            t0 = time.perf_counter()
+            ok, p = b.Track(syn_scene.rgb, syn_scene.depth, hyp, syn_mesh.name)
+            lat.append(time.perf_counter() - t0)
+            assert ok and np.array_equal(p, ref)
+        stop.set()
+        th.join()
+    finally:
+        stop.set()
+        b.close()
+    assert done["error"] is None, done["error"]
+    lat = np.array(lat) * 1e3
+    print(f"Track latency of model B: quiet p50 {np.median(quiet) * 1e3:.3f} ms; under {done['creates']} creations / {done['calibrations']} calibrations: "
+          f"p50 {np.median(lat):.3f} p99 {np.percentile(lat, 99):.3f} p99.9 {np.percentile(lat, 99.9):.3f} max {lat.max():.1f} ms over {len(lat)} calls")
+    assert done["creates"] >= 2 and done["calibrations"] >= 1
+    assert np.percentile(lat, 99) < 2.0, np.percentile(lat, 99)
+    assert lat.max() < 250.0, lat.max()      # (the exclusive section is the device phase of a creation only: one allocation + upload per network)
 
 
 _FUSION_SCRIPT = r"""

@@ -29,6 +29,11 @@ AMARGIN = float(os.environ.get("AMARGIN", "1.25"))
 POSTBC = int(os.environ.get("POSTBC", "0")); POSTGAIN = float(os.environ.get("POSTGAIN", "1.0"))
 CLIPK = float(os.environ.get("CLIPK", "0")); FLOOR = float(os.environ.get("FLOOR", "0"))
 SWEEPS = int(os.environ.get("SWEEPS", "1")); JACOBI = int(os.environ.get("JACOBI", "0"))
+WQ = int(os.environ.get("WQ", "1")); AQ = int(os.environ.get("AQ", "1"))   # [r5] int8c only: quantise the weights / the activations (0 = leave exact: which of the two carries the scene-dependent bias)
+DITHER = int(os.environ.get("DITHER", "0"))   # [r5] int8 activations: floor(x / s + u), u ~ U[0,1) from a fixed per-(pixel, channel) pattern (unbiased rounding)
+EFR = int(os.environ.get("EFR", "0"))         # [r5] error-feedback rounding of the folded weights against the per-scene channel means of the layer's input
+EFR_TAU = float(os.environ.get("EFR_TAU", "0.5")); EFR_LAM = float(os.environ.get("EFR_LAM", "0.0"))
+WBITS = int(os.environ.get("WBITS", "8"))     # [r5] bits of the (folded) weights: 8 = the kernels' int8 rows
 
 
 def q8(x, scale):
@@ -50,7 +55,39 @@ def qa(x, amax_t, amax_c):
         sc = amax_t * AMARGIN / 255.0
     else:
         sc = (amax_c * AMARGIN / 255.0).clamp_min(1e-8).view(1, -1, 1, 1)
+    if not AQ: return x
+    if DITHER:
+        g = torch.Generator().manual_seed(x.shape[1] * 7919 + x.shape[2])
+        u = torch.rand(x.shape[1:], generator=g)
+        return (x / sc + u).floor().clamp(0, 255) * sc
     return (x / sc).round().clamp(0, 255) * sc
+
+
+def efr_round(v, m, qmax):
+    """v [Cout,Cin,kh,kw] = folded weights in units of the row's step; m [J,Cin] = mean INTEGER activation of every input channel in
+    each of J calibration scenes.  Round every weight up or down (only where its fraction is within EFR_TAU of .5 is the choice free)
+    so that, per output row, sum_k (q_k - v_k) m_jc(k) stays near zero for every scene j: the part of the weight error that shifts the
+    layer's mean output -- and shifts it differently in every scene -- cancels instead of accumulating like a random walk."""
+    Cout, Cin, kh, kw = v.shape
+    base = v.floor(); frac = v - base
+    near = base + (frac >= 0.5).float()
+    q = near.clone()
+    r = torch.zeros(Cout, m.shape[0], dtype=torch.float64)
+    free = (frac - 0.5).abs() < EFR_TAU
+    md = m.double()
+    for c in range(Cin):
+        mc = md[:, c]                                     # [J]
+        for ky in range(kh):
+            for kx in range(kw):
+                f = frac[:, c, ky, kx].double()
+                e_dn, e_up = -f, 1.0 - f                  # error (q - v) of rounding down / up
+                c_dn = ((r + e_dn[:, None] * mc[None, :]) ** 2).sum(1) + EFR_LAM * e_dn ** 2
+                c_up = ((r + e_up[:, None] * mc[None, :]) ** 2).sum(1) + EFR_LAM * e_up ** 2
+                up = torch.where(free[:, c, ky, kx], c_up < c_dn, f >= 0.5)
+                e = torch.where(up, e_up, e_dn)
+                r += e[:, None] * mc[None, :]
+                q[:, c, ky, kx] = base[:, c, ky, kx] + up.float()
+    return q.clamp(-qmax, qmax)
 
 
 HALF = os.environ.get("HALF", "f16")   # storage type of the non-8-bit tensors: f16 | bf16 (the bf16 precision's arithmetic limit)
@@ -86,8 +123,13 @@ class Trunk:
             if key not in self.wq:
                 sc = (self.amax[("c", act_id)] * AMARGIN / 255.0).clamp_min(1e-8).view(1, -1, 1, 1)
                 wf = self.w[name + ".weight"] * sc
-                sw = wf.abs().amax(dim=(1, 2, 3), keepdim=True) / 127.0
-                self.wq[key] = (wf / sw).round().clamp(-127, 127) * sw / sc
+                qmax = float(2 ** (WBITS - 1) - 1)
+                sw = wf.abs().amax(dim=(1, 2, 3), keepdim=True) / qmax
+                if EFR and WQ and getattr(self, "scene_means", None) is not None:
+                    q = efr_round(wf / sw, self.scene_means[act_id] / sc.view(1, -1), qmax)
+                    self.wq[key] = q * sw / sc
+                else:
+                    self.wq[key] = ((wf / sw).round().clamp(-qmax, qmax) * sw / sc) if WQ else self.w[name + ".weight"]
             w = self.wq[key]
         b = self.w[name + ".bias"]
         if name in self.bias_fix: b = b + self.bias_fix[name]
@@ -130,6 +172,7 @@ class Trunk:
         x = torch.relu(self.conv("encodeA.1", x, 2))
         acts = {}
         def note(i, t):
+            if getattr(self, "means_out", None) is not None: self.means_out[i] = t.mean(dim=(0, 2, 3)).clone()
             if amax_out is not None:
                 amax_out[i] = max(amax_out.get(i, 0.0), float(t.abs().max()))
                 c = t.abs().amax(dim=(0, 2, 3))

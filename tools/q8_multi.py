@@ -21,14 +21,17 @@ ap.add_argument("--ks", default="1,4,8,16")
 ap.add_argument("--untextured", action="store_true")
 ap.add_argument("--opts", default="", help="test build: sweeps,tok,out of the calibration (default 2,1,1)")
 ap.add_argument("--headroom", type=float, default=0.0, help="test build: INT8 scale = |max| * headroom / 255 (default 1.25)")
+ap.add_argument("--wq", default="", help="test build: wclip,efr switches of the INT8 weight quantiser (default 1,1)")
 ap.add_argument("--amax", action="store_true", help="per-activation |max| of every held-out scene relative to the calibration record")
 args = ap.parse_args()
-if args.opts or args.headroom:
+if args.opts or args.headroom or args.wq:
     import ctypes
     _lib.use_test_lib()
     L = _lib.lib()
     if args.opts:
         L.fpt_set_calib_opts(*[int(x) for x in args.opts.split(",")])
+    if args.wq:
+        L.fpt_set_q8_wq(*[int(x) for x in args.wq.split(",")])
     if args.headroom:
         L.fpt_set_q8_headroom.argtypes = [ctypes.c_float]
         L.fpt_set_q8_headroom(args.headroom)
