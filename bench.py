@@ -148,6 +148,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-mfma-peak", action="store_true", help="skip the MFMA micro-benchmark (profiling runs)")
     ap.add_argument("--no-extras", action="store_true", help="skip the host-frame and Track legs (profiling runs)")
+    ap.add_argument("--fp8-legs", action="store_true", help="also run the two FP8 e4m3 720p legs (experimental: the precision fails the configs[4] parity bar)")
     ap.add_argument("--track", action="store_true", help="measure Track fps (N=1 hypothesis) as the headline instead of Register")
     args = ap.parse_args()
 
@@ -184,8 +185,8 @@ def main():
         states = (W.pack_synthetic("refiner", rp), W.pack_synthetic("scorer", sp))
         model = FoundationPose(mesh, scene.K, rp, sp, max_input_image_height=max(1080, args.height),
                                max_input_image_width=max(1920, args.width))
-        if args.dtype in Q8:         # post-training static quantisation on the bench frame itself (stated in config.calibration)
-            model.calibrate(scene.rgb, scene.depth, scene.mask, mesh.name, Q8_PREC[args.dtype])
+        if args.dtype in Q8:         # post-training static quantisation on 16 OTHER scenes (stated in config.calibration)
+            model.calibrate_frames(syn.calibration_scenes(mesh, 16, W=Wd, H=H), mesh.name, Q8_PREC[args.dtype])
             model.set_precision(Q8_PREC[args.dtype])
         elif args.dtype == "bf16":
             model.set_precision(FP_PREC_BF16)
@@ -394,15 +395,18 @@ def main():
             dR = np.einsum("nij,nkj->nik", a[:, :3, :3].astype(np.float64), b[:, :3, :3].astype(np.float64))
             return np.degrees(np.arccos(np.clip((np.trace(dR, axis1=1, axis2=2) - 1) / 2, -1, 1)))
 
+        N_CAL = 16
+
         def register_leg(textured, dtype, w, h, steps):
             mesh_l = syn.make_mesh(textured=textured)
-            scene_l = syn.make_scene(mesh_l, w, h)
+            # the MEASURED frame is a held-out scene of the synthetic scene family; the calibration sees 16 OTHER frames of it
+            scene_l = syn.heldout_scenes(mesh_l, 1, W=w, H=h)[0]
             m = FoundationPose(mesh_l, scene_l.K, rp_d, sp_d, max_input_image_height=max(1080, h), max_input_image_width=max(1920, w))
             try:
                 ok, p16, idx16, sc16, ref16, _ = m.register_detailed(scene_l.rgb, scene_l.depth, scene_l.mask, mesh_l.name)
                 assert ok, m.last_error
                 t0 = time.perf_counter()
-                m.calibrate(scene_l.rgb, scene_l.depth, scene_l.mask, mesh_l.name, Q8_PREC[dtype])
+                m.calibrate_frames(syn.calibration_scenes(mesh_l, N_CAL, W=w, H=h), mesh_l.name, Q8_PREC[dtype])
                 t_cal = time.perf_counter() - t0
                 m.set_precision(Q8_PREC[dtype])
                 ok, p8, idx8, sc8, ref8, _ = m.register_detailed(scene_l.rgb, scene_l.depth, scene_l.mask, mesh_l.name)
@@ -425,7 +429,10 @@ def main():
                     "score_corr_teacher_forced": round(float(np.corrcoef(sc8, sc_tf)[0, 1]), 4),
                     "winner_pose_delta_vs_f16_winner": {"deg": round(float(rot_deg(p8[None], p16[None])[0]), 3),
                                                         "mm": round(float(np.linalg.norm(p8[:3, 3] - p16[:3, 3]) * 1e3), 3)},
+                    "common_mode_mm": round(float(np.linalg.norm((ref8[:, :3, 3] - ref16[:, :3, 3]).mean(0)) * 1e3), 3),
+                    "winner_regret_teacher_forced": round(float((sc_tf.max() - sc_tf[idx8]) / (sc_tf.max() - np.median(sc_tf))), 4),
                     "meets_1deg_1mm_for_95pct": bool(np.mean((dmm < 1) & (ddeg < 1)) >= 0.95),
+                    "frame": "HELD OUT: a scene the calibration never saw (tests/test_precision_gpu.py measures six such scenes per mesh)",
                 }
                 r_, d_, k_ = (torch.from_numpy(x).to(dev) for x in (scene_l.rgb, scene_l.depth, scene_l.mask))
                 o_ = np.zeros(16, np.float32)
@@ -452,17 +459,22 @@ def main():
                         "config": {"workload": f"BASELINE configs[4]: Register N=252 {w}x{h} refine_itr=1, frame resident in HBM, "
                                                f"{'512x512 texture' if textured else '2x2 grey (untextured)'} mesh",
                                    "precision": PRECISION_TEXT[dtype],
-                                   "calibration": f"fp_calibrate on the bench frame itself ({t_cal:.2f} s: one f16 Register for per-channel statistics, "
-                                                  "27 8-bit Registers for the bias correction, output-layer correction)"},
+                                   "calibration": f"{N_CAL} held-out frames: fp_calibrate_begin / _add_frame x {N_CAL} / _finish on OTHER scenes of the synthetic scene "
+                                                  f"family ({t_cal:.1f} s: per-frame f16 statistics, INT8 weights rounded with error feedback against the frames' "
+                                                  "channel means, bias / token / output correction over all frames); the measured frame is not among them"},
+                        **({"experimental": True, "note": "FP8 e4m3 does not hold the configs[4] parity bar (tests/test_precision_gpu.py::"
+                                                          "test_register_720p_fp8_meets_the_bar is a strict xfail): not a headline leg"} if dtype == "fp8" else {}),
                         "accuracy": accuracy, "roofline": roof_l, "stage_ms": dict(list(stages_l.items())[:8])}
             finally:
                 m.close()
         lsteps = max(5, args.steps // 2)
-        # configs[4] ships INT8 (meets the 1 deg / 1 mm parity bar under the discriminating weights); FP8 e4m3 is measured beside it
+        # configs[4] ships INT8 (calibrated on other frames, measured on a held-out one).  FP8 e4m3 fails the parity bar and is not a leg of
+        # the default line any more: `--fp8-legs` adds its two legs, marked experimental
         extras["int8_720p"] = register_leg(True, "int8", 1280, 720, lsteps)
         extras["int8_720p_untextured"] = register_leg(False, "int8", 1280, 720, lsteps)
-        extras["fp8_720p"] = register_leg(True, "fp8", 1280, 720, lsteps)
-        extras["fp8_720p_untextured"] = register_leg(False, "fp8", 1280, 720, lsteps)
+        if args.fp8_legs:
+            extras["fp8_720p"] = register_leg(True, "fp8", 1280, 720, lsteps)
+            extras["fp8_720p_untextured"] = register_leg(False, "fp8", 1280, 720, lsteps)
         # Track in INT8 (discriminating weights, calibrated on the bench frame): the 8-bit weights halve the per-layer weight stream that
         # bounds a conv at N = 1
         def track_leg_int8(steps):
@@ -470,7 +482,7 @@ def main():
             scene_l = syn.make_scene(mesh_l, Wd, H)
             m = FoundationPose(mesh_l, scene_l.K, rp_d, sp_d)
             try:
-                m.calibrate(scene_l.rgb, scene_l.depth, scene_l.mask, mesh_l.name, FP_PREC_INT8)
+                m.calibrate_frames(syn.calibration_scenes(mesh_l, N_CAL, W=Wd, H=H), mesh_l.name, FP_PREC_INT8)   # (the tracked frame is not among them)
                 r_, d_ = (torch.from_numpy(x).to(dev) for x in (scene_l.rgb, scene_l.depth))
                 hyp_l = syn.to_colmajor(syn.perturb_pose(scene_l.gt_pose))
                 o_ = np.zeros(16, np.float32)
@@ -486,7 +498,7 @@ def main():
                 p8 = o_.reshape(4, 4).T.copy()
                 tl = timed(fn, steps, 10)
                 return {"metric": "Track fps (N=1)", "value": round(steps / tl, 1), "unit": "frames/s", "ms_per_frame": round(tl / steps * 1e3, 4), "steps": steps,
-                        "dtype": "int8", "config": {"workload": f"Track N=1 {Wd}x{H}, INT8 trunk convolutions (calibrated on the bench frame), frame resident in HBM",
+                        "dtype": "int8", "config": {"workload": f"Track N=1 {Wd}x{H}, INT8 trunk convolutions (calibrated on 16 OTHER frames), frame resident in HBM",
                                                     "weights": "discriminating synthetic set"},
                         "accuracy": {"pose_delta_vs_f16_track": {"deg": round(float(rot_deg(p8[None], p16[None])[0]), 3),
                                                                  "mm": round(float(np.linalg.norm(p8[:3, 3] - p16[:3, 3]) * 1e3), 3)}},
@@ -613,7 +625,7 @@ def main():
                 "mesh": f"synthetic ellipsoid V=2562 F=5120, {'2x2 grey (untextured)' if args.untextured else '512x512 texture'}",
                 "weights": "synthetic (seed 7)",
                 "precision": PRECISION_TEXT[args.dtype],
-                "calibration": "fp_calibrate on the bench frame itself" if args.dtype in Q8 else None,
+                "calibration": "16 frames of OTHER synthetic scenes (fp_calibrate_begin / _add_frame / _finish); the bench frame is not among them" if args.dtype in Q8 else None,
                 "parallelism": f"hyp-shard x{world}" if world > 1 else "single GPU",
                 "collective": ("1 ncclAllGather [n_local,528] f32 per Register, issued by the library on its own stream (fp_register_sharded)" if native_comm is not None
                                else "1 RCCL all-gather [n_local,528] f32 per Register (torch.distributed)") if world > 1 or force_shard else "none",

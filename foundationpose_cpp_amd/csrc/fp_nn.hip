@@ -44,6 +44,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <algorithm>
 #include <map>
@@ -249,6 +250,7 @@ struct ConvLayer {
   std::vector<float> rows_f32, bias_f32;
   std::vector<float> q_sw;     // per-row weight scale of the current quantisation
   std::vector<double> q_sum;   // DT_I8: per-row sum of the quantised weights
+  float *tmat_t = nullptr;     // DT_I8 [r5]: [Cin][Cout] tap sums of the weights' rounding errors, T[co][c] = sum_taps (q - v), transposed (q8_img_bias_kernel)
   int ntaps = 0;
   int Cin = 0, Cout = 0, KH = 0, KW = 0, stride = 1, pad = 0;
   int algo_K = 0;  // algorithmic reduction length for FLOP accounting (the s2d stem pads 7x7x6=294 to 512)
@@ -556,16 +558,22 @@ static bool upload_layouts(Net *net, const std::vector<unsigned char> &elems, in
 // keeps the per-pixel (de-meaned) error where it was.
 #ifdef FP_TEST_HOOKS
 static float g_q8_headroom = 1.25f;   // INT8 activation scale = |max| * headroom / 255 (tools/q8_multi.py --headroom)
-static int g_q8_wclip = 1, g_q8_efr = 1;   // A/B (tools/q8_multi.py --wq): the row-step search / the error-feedback rounding of quantise_q8
+static int g_q8_wclip = 1, g_q8_efr = 2, g_q8_imgbias = 1;   // (imgbias: the per-image first-order compensation, q8_img_bias_kernel)   // A/B (tools/q8_multi.py --wq): the row-step search / the error-feedback rounding of quantise_q8
 #else
 static constexpr float g_q8_headroom = 1.25f;
-static constexpr int g_q8_wclip = 1, g_q8_efr = 1;
+static constexpr int g_q8_wclip = 1, g_q8_efr = 2, g_q8_imgbias = 1;
 #endif
-static constexpr float kEfrTau = 0.2f;
+#ifdef FP_TEST_HOOKS
+static float env_float(const char *name, float dflt) { const char *e = std::getenv(name); return e && *e ? (float)std::atof(e) : dflt; }
+static const float kEfrTau = env_float("FP_Q8_TAU", 0.2f), kEfrLam = env_float("FP_Q8_LAM", 0.05f);   // A/B of the rounding knobs (tools/q8_multi.py)
+#else
+static constexpr float kEfrTau = 0.2f, kEfrLam = 0.05f;
+#endif
 static std::vector<unsigned char> quantise_q8(const ConvLayer &L, int dt, const float *s_in, std::vector<float> *sw, std::vector<double> *qsum,
-                                              const float *m_int = nullptr, int J = 0) {
+                                              const float *m_int = nullptr, int J = 0, std::vector<float> *tmat_t = nullptr) {
   const int K = L.ntaps * L.Cin;
   std::vector<unsigned char> o((size_t)L.Cout * K);
+  if (tmat_t) tmat_t->assign((size_t)L.Cin * L.Cout, 0.f);
   sw->assign(L.Cout, 1.f);
   qsum->assign(L.Cout, 0.0);
   std::vector<float> wf(K);
@@ -602,6 +610,75 @@ static std::vector<unsigned char> quantise_q8(const ConvLayer &L, int dt, const 
     (*sw)[co] = sc;
     double qs = 0;
     std::fill(r.begin(), r.end(), 0.0);
+    if (dt == DT_I8 && m_int && J > 0 && g_q8_efr == 2) {
+      // ---- per input channel: the TAP SUM of the rounding errors [r5, second form] ---------------------------------------------
+      // The mean output error of the row is sum_c T_c mean(x_c) with T_c = sum over the taps of channel c of its weights' rounding
+      // errors (every tap of a channel sees the same mean).  Cancelling it against the calibration frames' means (first form) leaves
+      // what a NEW scene's means add: mean(x_c) = m_c (1 + eps_c) with eps_c different per scene and channel, i.e. an error
+      // sum_c T_c m_c eps_c that no finite set of calibration frames spans.  It is small for EVERY scene when every |T_c| is small:
+      // round to nearest, then flip the weights closest to .5 (|fraction - .5| < TAU) until |T_c| <= .5 (from a standard deviation
+      // of 0.87 steps to <= 0.29), and use the last free choice per channel (T_c or T_c -+ 1 when |T_c| is near .5) to keep the
+      // running sums r_j = sum_c T_c m_jc of the calibration frames near zero.
+      const int nt = L.ntaps, Cin = L.Cin;
+      std::vector<int> qv(nt);
+      std::vector<float> fr(nt);
+      std::vector<char> can(nt);
+      for (int c = 0; c < Cin; c++) {
+        double T = 0;
+        for (int t = 0; t < nt; t++) {
+          const float v = wf[(size_t)t * Cin + c] / sc;
+          const float base = std::floor(v);
+          fr[t] = v - base;
+          qv[t] = std::max(-127, std::min(127, (int)base + (fr[t] >= 0.5f ? 1 : 0)));
+          can[t] = std::fabs(fr[t] - 0.5f) < kEfrTau && std::fabs(v) < 126.f;
+          T += (double)qv[t] - (double)v;
+        }
+        auto flip_toward = [&](int dir) -> bool {   // dir = +1: raise T by one (flip a rounded-down weight up), -1: lower it; cheapest eligible weight
+          int best = -1;
+          float best_cost = 1e9f;
+          for (int t = 0; t < nt; t++) {
+            if (!can[t]) continue;
+            const bool is_up = fr[t] >= 0.5f ? qv[t] == (int)std::floor(wf[(size_t)t * Cin + c] / sc) + 1 : false;
+            const int cur = qv[t] - (int)std::floor(wf[(size_t)t * Cin + c] / sc);   // 0 = down, 1 = up
+            (void)is_up;
+            if (dir > 0 && cur != 0) continue;
+            if (dir < 0 && cur != 1) continue;
+            const float cost = std::fabs(fr[t] - 0.5f);
+            if (cost < best_cost) { best_cost = cost; best = t; }
+          }
+          if (best < 0) return false;
+          qv[best] += dir;
+          can[best] = 0;   // a weight is moved at most once
+          T += dir;
+          return true;
+        };
+        while (T > 0.5 && flip_toward(-1)) {}
+        while (T < -0.5 && flip_toward(+1)) {}
+        // the free choice: T or T - sign(T) (|.| = 1 - |T|): take it when it serves the calibration frames' running sums more than it costs
+        {
+          const int dir = T > 0 ? -1 : +1;
+          double now = 0, alt = 0, mbar2 = 0;
+          for (int j = 0; j < J; j++) {
+            const double m = m_int[(size_t)j * Cin + c];
+            const double a = r[j] + T * m, b2 = r[j] + (T + dir) * m;
+            now += a * a; alt += b2 * b2; mbar2 += m * m;
+          }
+          const double lam = (double)kEfrLam * mbar2;   // what a unit of T_c^2 costs on unseen scenes: (scene-to-scene variation of a channel mean ~ 20 %)^2 x m^2
+          if (alt + lam * (T + dir) * (T + dir) < now + lam * T * T) {
+            const double keep = T;
+            if (!flip_toward(dir)) T = keep;
+          }
+        }
+        for (int j = 0; j < J; j++) r[j] += T * m_int[(size_t)j * Cin + c];
+        if (tmat_t) (*tmat_t)[(size_t)c * L.Cout + co] = (float)T;
+        for (int t = 0; t < nt; t++) {
+          o[(size_t)co * K + (size_t)t * Cin + c] = (unsigned char)(signed char)qv[t];
+          qs += qv[t];
+        }
+      }
+      (*qsum)[co] = qs;
+      continue;
+    }
     for (int k = 0; k < K; k++) {
       if (dt == DT_FP8) { o[(size_t)co * K + k] = f32_to_e4m3_bits(wf[k] / sc); continue; }
       const float v = wf[k] / sc;
@@ -628,6 +705,7 @@ static std::vector<unsigned char> quantise_q8(const ConvLayer &L, int dt, const 
       }
       o[(size_t)co * K + k] = (unsigned char)(signed char)q;
       qs += q;
+      if (tmat_t && dt == DT_I8) (*tmat_t)[(size_t)(k % L.Cin) * L.Cout + co] += (float)((double)q - (double)v);
     }
     (*qsum)[co] = qs;
   }
@@ -893,7 +971,9 @@ static int apply_q8_layer(Net *net, ConvLayer &l, int dt, const float *s_in, con
   if (weights) {
     std::vector<float> sw;
     std::vector<double> qsum;
-    const auto elems = quantise_q8(l, dt, s_in, &sw, &qsum, dt == DT_I8 ? m_int : nullptr, J);
+    std::vector<float> tmat;
+    const auto elems = quantise_q8(l, dt, s_in, &sw, &qsum, dt == DT_I8 ? m_int : nullptr, J, dt == DT_I8 ? &tmat : nullptr);
+    if (dt == DT_I8 && !put(net, l.tmat_t, tmat)) { set_error("net_apply_q8: device upload failed"); return 1; }
     if (!upload_layouts(net, elems, Cout, l.ntaps, l.Cin, dt, &l)) { set_error("net_apply_q8: device upload failed"); return 1; }
     l.q_sw = sw; l.q_sum = qsum;
   }
@@ -1024,7 +1104,10 @@ struct NNScratch {
   // threads never share it
   float *splitk = nullptr;
   size_t splitk_cap = 0;
+  float *img_sum = nullptr, *img_bias = nullptr;   // INT8 networks: [2 * cap][512] per-image channel sums / per-image bias (q8_img_*_kernel)
   ~NNScratch() {
+    if (img_sum) (void)hipFree(img_sum);
+    if (img_bias) (void)hipFree(img_bias);
     if (splitk) (void)hipFree(splitk);
     if (buf) (void)hipFree(buf);
     if (f32) (void)hipFree(f32);
@@ -1071,6 +1154,13 @@ static int ensure_scratch(NNScratch *ws, int N, hipStream_t s) {
   // carved by CAPACITY (not by the current N), so an image slot's border never moves
   FP_HIP_OK(hipMemsetAsync(ws->buf, 0, (size_t)cap * PER_HYP, s));
   if (ws->q8) FP_HIP_OK(hipMemsetAsync(ws->buf + (size_t)cap * PER_HYP, ws->q8 == DT_I8 ? 0x80 : 0, (size_t)cap * PER_HYP_Q8, s));
+  if (ws->q8 == DT_I8) {
+    if (ws->img_sum) (void)hipFree(ws->img_sum);
+    if (ws->img_bias) (void)hipFree(ws->img_bias);
+    ws->img_sum = ws->img_bias = nullptr;
+    FP_HIP_OK(hipMalloc((void **)&ws->img_sum, (size_t)2 * cap * 512 * sizeof(float)));
+    FP_HIP_OK(hipMalloc((void **)&ws->img_bias, (size_t)2 * cap * 512 * sizeof(float)));
+  }
   ws->cap = cap;
   return 0;
 }
@@ -1507,8 +1597,10 @@ static int run_conv_dt(const Ctx &c, const char *tag, const ConvLayer &L, ConvPa
 static int run_conv(const Ctx &c, const char *tag, const ConvLayer &L, const Act &in, int NB, int H, int W, int ipad,
                     const Act &out, int opad, bool relu, const Act *res = nullptr, int rpad = 0, int split_imgs = 0,
                     const ConvGroup *grp = nullptr, const void *post = nullptr, bool *post_fused = nullptr, const Act *out2 = nullptr,
-                    const float *oinv = nullptr, const float *rscale = nullptr) {
+                    const float *oinv = nullptr, const float *rscale = nullptr, const float *bias_img = nullptr) {
   ConvParams p;
+  p.bias_img = bias_img;
+  FP_CHECK(!bias_img || (L.dt == DT_I8 && !grp), "run_conv: a per-image bias belongs to an INT8 layer");
   p.out2 = out2 ? (unsigned char *)out2->p : nullptr;
   p.oinv = oinv;
   p.rscale = rscale;
@@ -1863,50 +1955,59 @@ static int run_trunk_q8(const Ctx &c, const Arena &a, const void *nn_in, int N, 
   const int NB2 = N + n_b, q = net->qdt;
   auto F = [&](void *p) { return Act{p, DT_F16, 1.f}; };
   auto Q = [&](void *p) { return Act{p, q, 1.f}; };
+  // INT8 [r5]: per-image bias of layer L for the 8-bit input tensor xq ([NBi, HW+2, HW+2, Cin] bytes): bias minus the first-order
+  // compensation of the weights' rounding error for that image's channel means (q8_img_sum_kernel / q8_img_bias_kernel); null when off
+  auto IB = [&](const ConvLayer &L, const void *xq, int NBi, int HW) -> const float * {
+    if (q != DT_I8 || !L.tmat_t || !c.ws || !c.ws->img_sum || !g_q8_imgbias) return nullptr;
+    ProfScope ps(c.prof, c.s, "q8_img_bias", 0, (double)NBi * (HW + 2) * (HW + 2) * L.Cin);
+    hipLaunchKernelGGL(q8_img_sum_kernel, dim3(NBi), dim3(256), 0, c.s, (const unsigned char *)xq, (HW + 2) * (HW + 2), L.Cin, c.ws->img_sum);
+    hipLaunchKernelGGL(q8_img_bias_kernel, dim3(NBi), dim3(256), 0, c.s, c.ws->img_sum, L.tmat_t, L.cscale, L.bias, 1.f / (float)(HW * HW), L.Cin, L.Cout, c.ws->img_bias);
+    return c.ws->img_bias;
+  };
   const size_t P1 = (size_t)NB2 * 42 * 42, P2 = (size_t)N * 42 * 42, P5 = (size_t)N * 22 * 22;
   const Act in = F(const_cast<void *>(nn_in)), stem = F(a.stem);
   if (run_conv(c, "conv_stem", net->a0, in, NB2, 80, 80, 2, stem, 1, true)) return 1;
   // encodeA.1 (f16 operands) starts the 128-channel stream: f16 x0 + 8-bit copy
   const Act x0 = F(a.x128[0]), x0q = Q(a.q128[0]), x1q = Q(a.q128[1]), x2 = F(a.x128[2]), x2q = Q(a.q128[2]);
   if (run_conv(c, "conv_a1", net->a1, stem, NB2, 80, 80, 1, x0, 1, true, nullptr, 0, 0, nullptr, nullptr, nullptr, &x0q, net->act_oinv[1])) return 1;
-  if (run_conv(c, "conv_128", net->ra[0][0], x0q, NB2, 40, 40, 1, x1q, 1, true)) return 1;
+  if (run_conv(c, "conv_128", net->ra[0][0], x0q, NB2, 40, 40, 1, x1q, 1, true, nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, IB(net->ra[0][0], a.q128[0], NB2, 40))) return 1;
   calib_record(c, 2, a.q128[1], P1, 128, q, net->act_scale_dev[2]);
-  if (run_conv(c, "conv_128", net->ra[0][1], x1q, NB2, 40, 40, 1, x2, 1, true, &x0, 1, 0, nullptr, nullptr, nullptr, &x2q, net->act_oinv[3])) return 1;
+  if (run_conv(c, "conv_128", net->ra[0][1], x1q, NB2, 40, 40, 1, x2, 1, true, &x0, 1, 0, nullptr, nullptr, nullptr, &x2q, net->act_oinv[3], nullptr, IB(net->ra[0][1], a.q128[1], NB2, 40))) return 1;
   calib_record(c, 3, a.x128[2], P1, 128, DT_F16);
-  if (run_conv(c, "conv_128", net->ra[1][0], x2q, NB2, 40, 40, 1, x1q, 1, true)) return 1;
+  if (run_conv(c, "conv_128", net->ra[1][0], x2q, NB2, 40, 40, 1, x1q, 1, true, nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, IB(net->ra[1][0], a.q128[2], NB2, 40))) return 1;
   calib_record(c, 4, a.q128[1], P1, 128, q, net->act_scale_dev[4]);
   // the last encodeA conv writes the a|b channel concat (f16 + 8-bit copy)
   const Act cat = F(a.x256[0]), catq = Q(a.q256[0]);
-  if (run_conv(c, "conv_128", net->ra[1][1], x1q, NB2, 40, 40, 1, cat, 1, true, &x2, 1, N, nullptr, nullptr, nullptr, &catq, net->act_oinv[5])) return 1;
+  if (run_conv(c, "conv_128", net->ra[1][1], x1q, NB2, 40, 40, 1, cat, 1, true, &x2, 1, N, nullptr, nullptr, nullptr, &catq, net->act_oinv[5], nullptr, IB(net->ra[1][1], a.q128[1], NB2, 40))) return 1;
   if (n_b == 1 && N > 1) {  // image N landed in cat[0][..,128:256]; replicate it for the other hypotheses (both copies)
     broadcast_b(c, a.x256[0], N, 256);
     broadcast_b(c, a.q256[0], N, 128);
   }
   calib_record(c, 5, a.x256[0], P2, 256, DT_F16);
   const Act y1q = Q(a.q256[1]), y2 = F(a.x256[2]), y2q = Q(a.q256[2]), y0 = F(a.x256[1]), y0q = Q(a.q256[0]);
-  if (run_conv(c, "conv_256", net->rb[0][0], catq, N, 40, 40, 1, y1q, 1, true)) return 1;
+  if (run_conv(c, "conv_256", net->rb[0][0], catq, N, 40, 40, 1, y1q, 1, true, nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, IB(net->rb[0][0], a.q256[0], N, 40))) return 1;
   calib_record(c, 6, a.q256[1], P2, 256, q, net->act_scale_dev[6]);
-  if (run_conv(c, "conv_256", net->rb[0][1], y1q, N, 40, 40, 1, y2, 1, true, &cat, 1, 0, nullptr, nullptr, nullptr, &y2q, net->act_oinv[7])) return 1;
+  if (run_conv(c, "conv_256", net->rb[0][1], y1q, N, 40, 40, 1, y2, 1, true, &cat, 1, 0, nullptr, nullptr, nullptr, &y2q, net->act_oinv[7], nullptr, IB(net->rb[0][1], a.q256[1], N, 40))) return 1;
   calib_record(c, 7, a.x256[2], P2, 256, DT_F16);
-  if (run_conv(c, "conv_256", net->rb[1][0], y2q, N, 40, 40, 1, y1q, 1, true)) return 1;
+  if (run_conv(c, "conv_256", net->rb[1][0], y2q, N, 40, 40, 1, y1q, 1, true, nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, IB(net->rb[1][0], a.q256[2], N, 40))) return 1;
   calib_record(c, 8, a.q256[1], P2, 256, q, net->act_scale_dev[8]);
   // y0 feeds only encodeAB.2: no f16 copy (0.2 GB per launch less); with a residual the consumer's scales cannot be folded into the
   // tables, so the epilogue scales (DT_QS_*)
   (void)y0;
-  if (run_conv(c, "conv_256", net->rb[1][1], y1q, N, 40, 40, 1, y0q, 1, true, &y2, 1, 0, nullptr, nullptr, nullptr, nullptr, net->act_oinv[9])) return 1;
+  if (run_conv(c, "conv_256", net->rb[1][1], y1q, N, 40, 40, 1, y0q, 1, true, &y2, 1, 0, nullptr, nullptr, nullptr, nullptr, net->act_oinv[9], nullptr, IB(net->rb[1][1], a.q256[1], N, 40))) return 1;
   calib_record(c, 9, a.q256[0], P2, 256, q, net->act_scale_dev[9]);
   const Act z0 = F(a.x512[0]), z0q = Q(a.q512[0]), z1q = Q(a.q512[1]), z2 = F(a.x512[2]), z2q = Q(a.q512[2]);
-  if (run_conv(c, "conv_b2", net->b2, y0q, N, 40, 40, 1, z0, 1, true, nullptr, 0, 0, nullptr, nullptr, nullptr, &z0q, net->act_oinv[10])) return 1;
+  if (run_conv(c, "conv_b2", net->b2, y0q, N, 40, 40, 1, z0, 1, true, nullptr, 0, 0, nullptr, nullptr, nullptr, &z0q, net->act_oinv[10], nullptr, IB(net->b2, a.q256[0], N, 40))) return 1;
   calib_record(c, 10, a.x512[0], P5, 512, DT_F16);
-  if (run_conv(c, "conv_512", net->rc[0][0], z0q, N, 20, 20, 1, z1q, 1, true)) return 1;
+  if (run_conv(c, "conv_512", net->rc[0][0], z0q, N, 20, 20, 1, z1q, 1, true, nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, IB(net->rc[0][0], a.q512[0], N, 20))) return 1;
   calib_record(c, 11, a.q512[1], P5, 512, q, net->act_scale_dev[11]);
-  if (run_conv(c, "conv_512", net->rc[0][1], z1q, N, 20, 20, 1, z2, 1, true, &z0, 1, 0, nullptr, nullptr, nullptr, &z2q, net->act_oinv[12])) return 1;
+  if (run_conv(c, "conv_512", net->rc[0][1], z1q, N, 20, 20, 1, z2, 1, true, &z0, 1, 0, nullptr, nullptr, nullptr, &z2q, net->act_oinv[12], nullptr, IB(net->rc[0][1], a.q512[1], N, 20))) return 1;
   calib_record(c, 12, a.x512[2], P5, 512, DT_F16);
-  if (run_conv(c, "conv_512", net->rc[1][0], z2q, N, 20, 20, 1, z1q, 1, true)) return 1;
+  if (run_conv(c, "conv_512", net->rc[1][0], z2q, N, 20, 20, 1, z1q, 1, true, nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, IB(net->rc[1][0], a.q512[2], N, 20))) return 1;
   calib_record(c, 13, a.q512[1], P5, 512, q, net->act_scale_dev[13]);
   const Act tok = F(a.tokens);
   bool pe_done = false;
-  if (run_conv(c, "conv_512", net->rc[1][1], z1q, N, 20, 20, 1, tok, 0, true, &z2, 1, 0, nullptr, net->pe, &pe_done)) return 1;
+  if (run_conv(c, "conv_512", net->rc[1][1], z1q, N, 20, 20, 1, tok, 0, true, &z2, 1, 0, nullptr, net->pe, &pe_done, nullptr, nullptr, nullptr, IB(net->rc[1][1], a.q512[1], N, 20))) return 1;
   if (!pe_done) add_pos_embed(c, a, N);
   calib_record(c, 14, a.tokens, (size_t)N * 400, 512, DT_F16);
   return 0;

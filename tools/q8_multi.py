@@ -21,7 +21,7 @@ ap.add_argument("--ks", default="1,4,8,16")
 ap.add_argument("--untextured", action="store_true")
 ap.add_argument("--opts", default="", help="test build: sweeps,tok,out of the calibration (default 2,1,1)")
 ap.add_argument("--headroom", type=float, default=0.0, help="test build: INT8 scale = |max| * headroom / 255 (default 1.25)")
-ap.add_argument("--wq", default="", help="test build: wclip,efr switches of the INT8 weight quantiser (default 1,1)")
+ap.add_argument("--wq", default="", help="test build: wclip,efr,imgbias switches of the INT8 weight quantiser / per-image compensation (default 1,2,1)")
 ap.add_argument("--amax", action="store_true", help="per-activation |max| of every held-out scene relative to the calibration record")
 args = ap.parse_args()
 if args.opts or args.headroom or args.wq:
@@ -51,8 +51,8 @@ def rot_deg(a, b):
     return np.degrees(np.arccos(np.clip((np.trace(dR, axis1=1, axis2=2) - 1) / 2, -1, 1)))
 
 
-calib = syn.calibration_scenes(mesh, 16, W=Wd, H=H)
-held = syn.heldout_scenes(mesh, W=Wd, H=H)
+calib = syn.calibration_scenes(mesh, max(16, max(int(x) for x in args.ks.split(","))), W=Wd, H=H)
+held = syn.heldout_scenes(mesh, int(os.environ.get("HELD", "4")), W=Wd, H=H)
 if (Wd, H) == (640, 480):      # the two "other scenes" of round 4's cross-frame test (same noise / background seeds as its calibration scene)
     held += [syn.make_scene(mesh, t=(-0.03, 0.02, 0.62), rot_seed=9), syn.make_scene(mesh, t=(0.04, -0.03, 0.80), rot_seed=4)]
 

@@ -35,7 +35,7 @@ Ac, Bc = (torch.cat(t) for t in zip(*[crops(s, PER, 3 + i) for i, s in enumerate
 tests = {"held0": syn.heldout_scenes(mesh)[0], "held1": syn.heldout_scenes(mesh)[1], "cal0(same-scene, other hyps)": cs[0]}
 T = {k: crops(s, 24, 0) for k, s in tests.items()}
 G = {'128': range(0, 4), '256': range(4, 8), 'b2': range(8, 9), '512': range(9, 13)}
-sel = os.environ.get('GROUPS', '128,256,b2,512').split(',')
+sel = os.environ.get('LGROUPS', '128,256,b2,512').split(',')
 ALL = [1 if any(i in G[g] for g in sel) else 0 for i in range(13)]
 with torch.no_grad():
     exact = S.Trunk(folded, [0] * 13, True, None, h16=False)
@@ -63,7 +63,7 @@ with torch.no_grad():
         t.record = None
     if int(os.environ.get("TOK", "1")):
         t.tokfix = fc.mean(dim=(0, 2, 3)) - t.forward(Ac, Bc).mean(dim=(0, 2, 3))
-    print(f"{kind} GROUPS={sel} MODE={S.MODE} WQ={S.WQ} AQ={S.AQ} DITHER={S.DITHER} WBITS={S.WBITS} sweeps={S.SWEEPS} K={K}x{PER} hyps ({time.time() - t0:.0f} s)", flush=True)
+    print(f"{kind} LGROUPS={sel} MODE={S.MODE} WQ={S.WQ} AQ={S.AQ} DITHER={S.DITHER} WBITS={S.WBITS} sweeps={S.SWEEPS} K={K}x{PER} hyps ({time.time() - t0:.0f} s)", flush=True)
     for k, v in T.items():
         out = S.heads(net, kind, t.forward(*v)).numpy()
         ref = refs[k]
