@@ -558,7 +558,8 @@ static bool upload_layouts(Net *net, const std::vector<unsigned char> &elems, in
 // keeps the per-pixel (de-meaned) error where it was.
 #ifdef FP_TEST_HOOKS
 static float g_q8_headroom = 1.25f;   // INT8 activation scale = |max| * headroom / 255 (tools/q8_multi.py --headroom)
-static int g_q8_wclip = 1, g_q8_efr = 2, g_q8_imgbias = 1;   // (imgbias: the per-image first-order compensation, q8_img_bias_kernel)   // A/B (tools/q8_multi.py --wq): the row-step search / the error-feedback rounding of quantise_q8
+// imgbias: the per-image first-order compensation (q8_img_bias_kernel); wclip / efr: the row-step search / rounding form of quantise_q8
+static int g_q8_wclip = 1, g_q8_efr = 2, g_q8_imgbias = 1;   // A/B (tools/q8_multi.py --wq): the row-step search / the error-feedback rounding of quantise_q8
 #else
 static constexpr float g_q8_headroom = 1.25f;
 static constexpr int g_q8_wclip = 1, g_q8_efr = 2, g_q8_imgbias = 1;
@@ -1104,7 +1105,8 @@ struct NNScratch {
   // threads never share it
   float *splitk = nullptr;
   size_t splitk_cap = 0;
-  float *img_sum = nullptr, *img_bias = nullptr;   // INT8 networks: [2 * cap][512] per-image channel sums / per-image bias (q8_img_*_kernel)
+  int *img_sum = nullptr;      // INT8 networks: [2 * cap][512] per-image channel sums (integer atomics; zero between uses) ...
+  float *img_bias = nullptr;   // ... and the per-image bias made from them (q8_img_*_kernel)
   ~NNScratch() {
     if (img_sum) (void)hipFree(img_sum);
     if (img_bias) (void)hipFree(img_bias);
@@ -1148,7 +1150,8 @@ static int ensure_scratch(NNScratch *ws, int N, hipStream_t s) {
   int cap = std::max(N, 8);
   g_alloc_epoch++;
   FP_HIP_OK(hipMalloc((void **)&ws->buf, (size_t)cap * per_hyp_bytes(ws)));
-  FP_HIP_OK(hipMalloc((void **)&ws->f32, ((size_t)cap * EMBED + 16) * sizeof(float)));   // + the arrival counter of token_mean_pose_kernel
+  // [cap][512] pooled features + the arrival counter of token_mean_pose_kernel + [2][16][512] partial sums of layernorm_pmean_kernel (Track)
+  FP_HIP_OK(hipMalloc((void **)&ws->f32, ((size_t)cap * EMBED + 16 + 2 * 16 * EMBED) * sizeof(float)));
   FP_HIP_OK(hipMemsetAsync(ws->f32 + (size_t)cap * EMBED, 0, 16 * sizeof(float), s));
   // the zero borders are written here once and never again: every producer stores interiors only, and the arena is
   // carved by CAPACITY (not by the current N), so an image slot's border never moves
@@ -1157,8 +1160,9 @@ static int ensure_scratch(NNScratch *ws, int N, hipStream_t s) {
   if (ws->q8 == DT_I8) {
     if (ws->img_sum) (void)hipFree(ws->img_sum);
     if (ws->img_bias) (void)hipFree(ws->img_bias);
-    ws->img_sum = ws->img_bias = nullptr;
-    FP_HIP_OK(hipMalloc((void **)&ws->img_sum, (size_t)2 * cap * 512 * sizeof(float)));
+    ws->img_sum = nullptr; ws->img_bias = nullptr;
+    FP_HIP_OK(hipMalloc((void **)&ws->img_sum, (size_t)2 * cap * 512 * sizeof(int)));
+    FP_HIP_OK(hipMemsetAsync(ws->img_sum, 0, (size_t)2 * cap * 512 * sizeof(int), s));
     FP_HIP_OK(hipMalloc((void **)&ws->img_bias, (size_t)2 * cap * 512 * sizeof(float)));
   }
   ws->cap = cap;
@@ -1225,6 +1229,7 @@ FP_HOOK g_gemm_wpack = 1;      // gemm_k32_kernel streams its weights from the s
 FP_HOOK g_deep_wpack = 1;      // conv_deep_kernel streams its weights from the stage-order copy
 FP_HOOK g_big_wpack = 1;       // conv_big_pp_kernel streams its weights from the stage-order copy
 FP_HOOK g_halo_wpack = 1;      // conv_halo_kernel streams its weights from the stage-order copy
+FP_HOOK g_ln_pmean = 1;        // [r5] Track: LayerNorm 2 + partial token sums in one launch (layernorm_pmean_kernel) instead of layernorm + token_mean
 FP_HOOK g_halo_wreg = 0;       // [r5] 3x3 / 40x40 layers on conv_halo_wreg_kernel: weights global -> registers (fragment-order copy), no weight ring, 2 barriers per chunk
 FP_HOOK g_i8_stream = 0;       // test build A/B: 1 = INT8 networks with an 8-bit residual stream (run_trunk_i8; faster, but its common-mode error is frame-specific: DESIGN.md section 4.4)
 FP_HOOK g_smallx_pf = 0;       // A/B (test build): prefetch depth of conv_smallx_kernel<2,4> (4 or 2; 0 = the default 3)
@@ -1958,10 +1963,13 @@ static int run_trunk_q8(const Ctx &c, const Arena &a, const void *nn_in, int N, 
   // INT8 [r5]: per-image bias of layer L for the 8-bit input tensor xq ([NBi, HW+2, HW+2, Cin] bytes): bias minus the first-order
   // compensation of the weights' rounding error for that image's channel means (q8_img_sum_kernel / q8_img_bias_kernel); null when off
   auto IB = [&](const ConvLayer &L, const void *xq, int NBi, int HW) -> const float * {
-    if (q != DT_I8 || !L.tmat_t || !c.ws || !c.ws->img_sum || !g_q8_imgbias) return nullptr;
+    // (batches of a few images -- Track -- run without it: the error-feedback rounding has already cancelled this term for the calibration
+    // frames' means, what the compensation adds is the image's deviation from them, and 26 more launches would double a Track)
+    if (q != DT_I8 || !L.tmat_t || !c.ws || !c.ws->img_sum || !g_q8_imgbias || NBi < 16) return nullptr;
     ProfScope ps(c.prof, c.s, "q8_img_bias", 0, (double)NBi * (HW + 2) * (HW + 2) * L.Cin);
-    hipLaunchKernelGGL(q8_img_sum_kernel, dim3(NBi), dim3(256), 0, c.s, (const unsigned char *)xq, (HW + 2) * (HW + 2), L.Cin, c.ws->img_sum);
-    hipLaunchKernelGGL(q8_img_bias_kernel, dim3(NBi), dim3(256), 0, c.s, c.ws->img_sum, L.tmat_t, L.cscale, L.bias, 1.f / (float)(HW * HW), L.Cin, L.Cout, c.ws->img_bias);
+    hipLaunchKernelGGL(q8_img_sum_kernel, dim3(NBi, HW == 40 ? 6 : 2), dim3(256), 0, c.s, (const unsigned char *)xq, (HW + 2) * (HW + 2), L.Cin, c.ws->img_sum);
+    hipLaunchKernelGGL(q8_img_bias_kernel, dim3(NBi, L.Cout / 64), dim3(256), 0, c.s, c.ws->img_sum, L.tmat_t, L.cscale, L.bias, 1.f / (float)(HW * HW), L.Cin, L.Cout, c.ws->img_bias);
+    (void)hipMemsetAsync(c.ws->img_sum, 0, (size_t)NBi * L.Cin * sizeof(int), c.s);   // zero for the next layer's atomics (a memset node in the captured graph)
     return c.ws->img_bias;
   };
   const size_t P1 = (size_t)NB2 * 42 * 42, P2 = (size_t)N * 42 * 42, P5 = (size_t)N * 22 * 22;
@@ -2095,8 +2103,21 @@ int refiner_forward(hipStream_t s, Profiler *prof, const Net *net, NNScratch *ws
     run_layernorm(c, dt, a.y1, T0.ln1, a.y2, 2 * G, &R0.ln1, G);
     if (run_gemm(c, "gemm_512", net->g_lin1, a.y2, 2 * G, a.y1, true, nullptr, &g_own)) return 1;
     if (run_gemm(c, "gemm_512", net->g_lin2, a.y1, 2 * G, a.att, false, a.y2, &g_own)) return 1;   // + residual x1
-    // (two sequences only: LayerNorm over 800 workgroup-rows + a 16-workgroup mean beat the one-workgroup-per-sequence fused kernel, 11 vs 20 us)
-    run_layernorm(c, dt, a.att, T0.ln2, a.y1, 2 * G, &R0.ln2, G);
+    // LayerNorm 2 feeds nothing but the token mean.  [r5] ONE launch: 2 x 16 workgroups normalise 25 rows each and leave partial column sums,
+    // which the heads kernel adds up (layernorm_pmean_kernel).  Before: LayerNorm over 800 workgroup-rows + a 16-workgroup mean, two
+    // dependent launches (11 us; the one-workgroup-per-sequence fused kernel of Register is a 20 us serial chain at two sequences)
+    constexpr int kParts = 16, kRowsPerPart = 25;
+    float *const psums = ws->f32 + (size_t)ws->cap * EMBED + 16;   // [2][kParts][512]
+    const bool pmean = g_ln_pmean != 0
+#ifdef FP_TEST_HOOKS
+                       && g_fuse_pose != 2
+#endif
+        ;
+    if (pmean) {
+      ProfScope ps(c.prof, c.s, "layernorm_pmean", 0, 2.0 * 400 * EMBED * 2.0);
+      if (dt == DT_BF16) hipLaunchKernelGGL(layernorm_pmean_kernel<DT_BF16>, dim3(2, kParts), dim3(256), 0, c.s, (const __bf16 *)a.att, T0.ln2.g, T0.ln2.b, R0.ln2.g, R0.ln2.b, 1, psums, 400, G, kRowsPerPart);
+      else hipLaunchKernelGGL(layernorm_pmean_kernel<DT_F16>, dim3(2, kParts), dim3(256), 0, c.s, (const _Float16 *)a.att, T0.ln2.g, T0.ln2.b, R0.ln2.g, R0.ln2.b, 1, psums, 400, G, kRowsPerPart);
+    } else run_layernorm(c, dt, a.att, T0.ln2, a.y1, 2 * G, &R0.ln2, G);
 #ifdef FP_TEST_HOOKS
     if (fuse && g_fuse_pose == 2 && T0.head.out == 3 && R0.head.out == 3 && T0.head.in == EMBED) {
       // A/B (test build): token mean + both heads + RefinePostProcess as one launch whose last workgroup runs the heads -- measured
@@ -2112,10 +2133,11 @@ int refiner_forward(hipStream_t s, Profiler *prof, const Net *net, NNScratch *ws
       return 0;
     }
 #endif
-    run_token_mean(c, dt, a.y1, ws->f32, 2, 400, G);
+    if (!pmean) run_token_mean(c, dt, a.y1, ws->f32, 2, 400, G);
     {
       ProfScope ps(c.prof, c.s, "small_linear", 2.0 * 2 * T0.head.out * T0.head.in, 0);
-      SmallLinear2 a{{ws->f32, ws->f32 + EMBED}, {T0.head.w, R0.head.w}, {T0.head.b, R0.head.b}, {trans_dev, rot_dev}};
+      SmallLinear2 a{{pmean ? psums : ws->f32, pmean ? psums + kParts * EMBED : ws->f32 + EMBED}, {T0.head.w, R0.head.w}, {T0.head.b, R0.head.b}, {trans_dev, rot_dev}};
+      if (pmean) { a.parts = kParts; a.tokens = 400.f; }
       if (fuse && g_fuse_pose && T0.head.out == 3 && R0.head.out == 3) {
         hipLaunchKernelGGL(small_linear2_pose_kernel, dim3(1), dim3(384), 0, c.s, a, T0.head.in, *fuse);
         if (fused_out) *fused_out = true;
