@@ -557,6 +557,15 @@ static bool upload_layouts(Net *net, const std::vector<unsigned char> &elems, in
 // scenes whose channel means are (near) combinations of the calibration frames'.  Weights further from .5 round to nearest, which
 // keeps the per-pixel (de-meaned) error where it was.
 #ifdef FP_TEST_HOOKS
+// [r5] A/B (fpt_set_rem_fork): the left-over rows of conv_512 / conv_b2 on a side stream next to the 256x256 rounds.  OFF: measured
+// SLOWER (tools/ab_wall.py fpt_set_rem_fork 0 1 0 1: Register 10.85 -> 11.20 ms) -- a deep-ring workgroup needs a whole CU (147 KB of
+// LDS), so it waits for a 256x256 tile to finish, then holds that CU out of the next round: the rounds lose their lock-step and end in
+// a tail longer than the 35 us the lone launch took.
+static int g_rem_fork = 0;
+#else
+static constexpr int g_rem_fork = 0;
+#endif
+#ifdef FP_TEST_HOOKS
 static float g_q8_headroom = 1.25f;   // INT8 activation scale = |max| * headroom / 255 (tools/q8_multi.py --headroom)
 // imgbias: the per-image first-order compensation (q8_img_bias_kernel); wclip / efr: the row-step search / rounding form of quantise_q8
 static int g_q8_wclip = 1, g_q8_efr = 2, g_q8_imgbias = 1;   // A/B (tools/q8_multi.py --wq): the row-step search / the error-feedback rounding of quantise_q8
@@ -1105,9 +1114,14 @@ struct NNScratch {
   // threads never share it
   float *splitk = nullptr;
   size_t splitk_cap = 0;
+  hipStream_t side = nullptr;                       // (Ctx::s2)
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   int *img_sum = nullptr;      // INT8 networks: [2 * cap][512] per-image channel sums (integer atomics; zero between uses) ...
   float *img_bias = nullptr;   // ... and the per-image bias made from them (q8_img_*_kernel)
   ~NNScratch() {
+    if (ev_fork) (void)hipEventDestroy(ev_fork);
+    if (ev_join) (void)hipEventDestroy(ev_join);
+    if (side) (void)hipStreamDestroy(side);
     if (img_sum) (void)hipFree(img_sum);
     if (img_bias) (void)hipFree(img_bias);
     if (splitk) (void)hipFree(splitk);
@@ -1143,6 +1157,11 @@ void nn_scratch_debug_info(const NNScratch *w, const void **buf, size_t *bytes, 
 }
 
 static int ensure_scratch(NNScratch *ws, int N, hipStream_t s) {
+  if (!ws->side && g_rem_fork) {   // (first call of a model is eager, never inside a capture)
+    FP_HIP_OK(hipStreamCreateWithFlags(&ws->side, hipStreamNonBlocking));
+    FP_HIP_OK(hipEventCreateWithFlags(&ws->ev_fork, hipEventDisableTiming));
+    FP_HIP_OK(hipEventCreateWithFlags(&ws->ev_join, hipEventDisableTiming));
+  }
   if (N <= ws->cap) return 0;
   if (ws->buf) (void)hipFree(ws->buf);
   if (ws->f32) (void)hipFree(ws->f32);
@@ -1191,6 +1210,9 @@ struct Ctx {
   Profiler *prof;
   const Net *net;
   NNScratch *ws = nullptr;  // owner of the split-K slab (null only in the single-threaded test hooks)
+  // [r5] side stream for the left-over rows of a long-K layer (fork before the 256x256 rounds, join behind them): nullptr = off
+  hipStream_t s2 = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };
 
 // A/B and ablation switches exist only in the test build (libfoundationpose_amd_test.so, -DFP_TEST_HOOKS); in the product
@@ -1230,7 +1252,7 @@ FP_HOOK g_deep_wpack = 1;      // conv_deep_kernel streams its weights from the 
 FP_HOOK g_big_wpack = 1;       // conv_big_pp_kernel streams its weights from the stage-order copy
 FP_HOOK g_halo_wpack = 1;      // conv_halo_kernel streams its weights from the stage-order copy
 FP_HOOK g_ln_pmean = 1;        // [r5] Track: LayerNorm 2 + partial token sums in one launch (layernorm_pmean_kernel) instead of layernorm + token_mean
-FP_HOOK g_halo_wreg = 0;       // [r5] 3x3 / 40x40 layers on conv_halo_wreg_kernel: weights global -> registers (fragment-order copy), no weight ring, 2 barriers per chunk
+FP_HOOK g_halo_wreg = 0;       // [r5] A/B, OFF (conv_256 -3 % in the stage profile, nothing on the wall clock: tools/ab_wall.py, EXPERIMENTS.md): 1 = 3x3 / 40x40 layers with >= 256 input channels on conv_halo_wreg_kernel: weights global -> registers (fragment-order copy), no weight ring, 2 barriers per chunk (2 = every such layer incl. the 128-channel ones, where it measures even)
 FP_HOOK g_i8_stream = 0;       // test build A/B: 1 = INT8 networks with an 8-bit residual stream (run_trunk_i8; faster, but its common-mode error is frame-specific: DESIGN.md section 4.4)
 FP_HOOK g_smallx_pf = 0;       // A/B (test build): prefetch depth of conv_smallx_kernel<2,4> (4 or 2; 0 = the default 3)
 FP_HOOK g_smallm = 1;          // small problems (Track, a few objects) on conv_smallm_kernel: K split over the waves of a workgroup, no split-K slabs / reduce launch
@@ -1267,6 +1289,7 @@ static int run_conv_dt(const Ctx &c, const char *tag, const ConvLayer &L, ConvPa
   constexpr bool QOUT = odt_q(ODT) >= 0;   // an 8-bit tensor is written (alone or next to the f16 stream tensor)
   const int KT = p.krow_b / 128;
   bool post_main = false;  // ConvParams::post handled by the 256x256 rounds + deep-ring left-over (see below)
+  bool fork_rem = false;   // the left-over launch goes to the side stream (forked before the 256x256 rounds)
   double flops = 2.0 * (double)p.M * p.Cout * (L.algo_K > 0 ? L.algo_K : p.Ktot);
   double bytes = ((double)NB * H * W * L.Cin + (double)p.M * p.Cout * (has_res ? 2 : 1) + (double)p.Cout * p.Ktot) * elem_bytes(DT);
   constexpr int LDS_IG128 = 2 * (128 * 128 + 128 * 128), LDS_IG64 = 2 * (128 * 128 + 64 * 128);
@@ -1418,7 +1441,7 @@ static int run_conv_dt(const Ctx &c, const char *tag, const ConvLayer &L, ConvPa
       if (DT == DT_F16 && g_conv_ablate == 32) { FP_LAUNCH((conv_halo_kernel<40, 32, DT_F16>), grid, dim3(256), LDS_HALO40, c.s, p); return 0; }
 #endif
       if (!g_halo_wpack) p.wpack = nullptr;
-      if (g_halo_wreg && p.wfrag && g_conv_ablate == 0) { FP_LAUNCH((conv_halo_wreg_kernel<DT>), grid, dim3(256), LDS_HALO40W, c.s, p); return 0; }
+      if (g_halo_wreg && p.wfrag && g_conv_ablate == 0 && (p.cin_b >= 512 || g_halo_wreg == 2)) { FP_LAUNCH((conv_halo_wreg_kernel<DT>), grid, dim3(256), LDS_HALO40W, c.s, p); return 0; }
       FP_LAUNCH((conv_halo_kernel<40, 0, DT>), grid, dim3(256), LDS_HALO40, c.s, p);
     } else if constexpr (odt_q(ODT) == DT) {
       ProfScope ps(c.prof, c.s, (tg + "/conv_halo8_kernel").c_str(), flops, bytes);
@@ -1463,7 +1486,16 @@ static int run_conv_dt(const Ctx &c, const char *tag, const ConvLayer &L, ConvPa
                   (rows_left == 0 || ((rows_left + 63) / 64) * (L.Cout / 128) <= 256);
       if (!post_main) p.post = nullptr;
     }
+    // [r5] the left-over rows run NEXT TO the full rounds, on the side stream: a lone deep-ring launch leaves 100 of the 256 CUs idle for
+    // 35-40 us behind every conv_512 / conv_b2; forked, its workgroups take CUs as the 256x256 tiles release them (disjoint rows, same inputs)
     if (mt_big > 0) {
+      const int rows_left = p.M - mt_big * 256;
+      fork_rem = g_rem_fork && c.s2 && !(c.prof && c.prof->on) && rows_left > 0 && g_rem_kernel == 3 && KT >= 16 && L.Cout % 128 == 0 &&
+                 ((rows_left + 63) / 64) * (L.Cout / 128) <= 256 && g_conv_variant == 0 && g_conv_ablate == 0 && !g_rem_splitk;
+      if (fork_rem) {
+        FP_HIP_OK(hipEventRecord(c.ev_fork, c.s));
+        FP_HIP_OK(hipStreamWaitEvent(c.s2, c.ev_fork, 0));
+      }
       ConvParams pb = p;
       pb.M = mt_big * 256;                                // rows [0, mt_big*256)
       const double frac = (double)pb.M / (double)p.M;
@@ -1534,13 +1566,19 @@ static int run_conv_dt(const Ctx &c, const char *tag, const ConvLayer &L, ConvPa
         rows = rest;
       }
       ProfScope ps(c.prof, c.s, (tg + "/conv_deep_kernel").c_str(), flops, bytes);
+      const hipStream_t ls = fork_rem ? c.s2 : c.s;
+      bool launched = false;
       if constexpr (!QOUT) {
         if (post_main) {
-          FP_LAUNCH((conv_deep_kernel<64, DT, ODT, true>), dim3(((rows + 63) / 64) * n128), dim3(256), LDS_DEEP64, c.s, p);
-          return 0;
+          FP_LAUNCH((conv_deep_kernel<64, DT, ODT, true>), dim3(((rows + 63) / 64) * n128), dim3(256), LDS_DEEP64, ls, p);
+          launched = true;
         }
       }
-      FP_LAUNCH((conv_deep_kernel<64, DT, ODT>), dim3(((rows + 63) / 64) * n128), dim3(256), LDS_DEEP64, c.s, p);
+      if (!launched) FP_LAUNCH((conv_deep_kernel<64, DT, ODT>), dim3(((rows + 63) / 64) * n128), dim3(256), LDS_DEEP64, ls, p);
+      if (fork_rem) {   // join: the layer's consumers wait for both parts
+        FP_HIP_OK(hipEventRecord(c.ev_join, c.s2));
+        FP_HIP_OK(hipStreamWaitEvent(c.s, c.ev_join, 0));
+      }
       return 0;
     }
     if (g_rem_kernel == 1) {
@@ -2082,7 +2120,7 @@ int refiner_forward(hipStream_t s, Profiler *prof, const Net *net, NNScratch *ws
   FP_CHECK(net && !net->scorer, "refiner_forward: wrong network");
   FP_CHECK(net_q8_ready(net), "[FoundationPose] the 8-bit precisions need a calibration: call fp_calibrate (fp_calibrate_fp8) first");
   if (ensure_scratch(ws, N, s)) return 1;
-  Ctx c{s, prof, net, ws};
+  Ctx c{s, prof, net, ws, ws->side, ws->ev_fork, ws->ev_join};
   const Arena a = carve(ws);
   if (run_trunk(c, a, nn_in, N, shared_b ? 1 : N)) return 1;
   const int dt = net->act_dt;
@@ -2171,7 +2209,7 @@ int scorer_features(hipStream_t s, Profiler *prof, const Net *net, NNScratch *ws
   FP_CHECK(net && net->scorer, "scorer_features: wrong network");
   FP_CHECK(net_q8_ready(net), "[FoundationPose] the 8-bit precisions need a calibration: call fp_calibrate (fp_calibrate_fp8) first");
   if (ensure_scratch(ws, N, s)) return 1;
-  Ctx c{s, prof, net, ws};
+  Ctx c{s, prof, net, ws, ws->side, ws->ev_fork, ws->ev_join};
   const Arena a = carve(ws);
   if (run_trunk(c, a, nn_in, N, N)) return 1;
   const size_t rows = (size_t)N * 400;
@@ -2187,7 +2225,7 @@ int scorer_features(hipStream_t s, Profiler *prof, const Net *net, NNScratch *ws
 int scorer_head(hipStream_t s, Profiler *prof, const Net *net, NNScratch *ws, const float *feats_dev, int n_total, float *scores_dev) {
   FP_CHECK(net && net->scorer, "scorer_head: wrong network");
   if (ensure_head_scratch(ws, n_total)) return 1;
-  Ctx c{s, prof, net, ws};
+  Ctx c{s, prof, net, ws, ws->side, ws->ev_fork, ws->ev_join};
   const int N = n_total, dt = net->act_dt;
   unsigned char *p = ws->head_buf;
   unsigned char *xf = p; p += (size_t)N * EMBED * 2;
