@@ -25,3 +25,4 @@ cp "$S" gpurun_out/${TAG}_kernel_stats.csv
 python tools/summarize_pmc.py "$F" "$W" gpurun_out/${TAG}_pmc_hbm.json
 python tools/summarize_mfma.py "$M" "$S" gpurun_out/${TAG}_pmc_mfma.json
 head -14 gpurun_out/${TAG}_kernel_stats.csv
+rm -rf $OUT   # (the raw traces of a run that calibrates are > 64 MiB: gpurun would not copy anything back)
