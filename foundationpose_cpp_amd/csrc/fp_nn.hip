@@ -626,8 +626,8 @@ static std::vector<unsigned char> quantise_q8(const ConvLayer &L, int dt, const 
       // errors (every tap of a channel sees the same mean).  Cancelling it against the calibration frames' means (first form) leaves
       // what a NEW scene's means add: mean(x_c) = m_c (1 + eps_c) with eps_c different per scene and channel, i.e. an error
       // sum_c T_c m_c eps_c that no finite set of calibration frames spans.  It is small for EVERY scene when every |T_c| is small:
-      // round to nearest, then flip the weights closest to .5 (|fraction - .5| < TAU) until |T_c| <= .5 (from a standard deviation
-      // of 0.87 steps to <= 0.29), and use the last free choice per channel (T_c or T_c -+ 1 when |T_c| is near .5) to keep the
+      // round to nearest, then flip the weights closest to .5 (|fraction - .5| < TAU) while that brings |T_c| towards <= .5 (standard
+      // deviation 0.86 -> 0.42 steps: not every channel has an eligible weight on the right side), and use the last free choice per channel (T_c or T_c -+ 1 when |T_c| is near .5) to keep the
       // running sums r_j = sum_c T_c m_jc of the calibration frames near zero.
       const int nt = L.ntaps, Cin = L.Cin;
       std::vector<int> qv(nt);
@@ -1251,6 +1251,7 @@ FP_HOOK g_gemm_wpack = 1;      // gemm_k32_kernel streams its weights from the s
 FP_HOOK g_deep_wpack = 1;      // conv_deep_kernel streams its weights from the stage-order copy
 FP_HOOK g_big_wpack = 1;       // conv_big_pp_kernel streams its weights from the stage-order copy
 FP_HOOK g_halo_wpack = 1;      // conv_halo_kernel streams its weights from the stage-order copy
+FP_HOOK g_att_tail = 0;        // [r5] A/B, OFF (measured slower: attention 0.555 -> 0.625 ms per Register): the 16-row tail of a 400-token sequence on attention32_skv_kernel instead of a 4th 128-row block
 FP_HOOK g_ln_pmean = 1;        // [r5] Track: LayerNorm 2 + partial token sums in one launch (layernorm_pmean_kernel) instead of layernorm + token_mean
 FP_HOOK g_halo_wreg = 0;       // [r5] A/B, OFF (conv_256 -3 % in the stage profile, nothing on the wall clock: tools/ab_wall.py, EXPERIMENTS.md): 1 = 3x3 / 40x40 layers with >= 256 input channels on conv_halo_wreg_kernel: weights global -> registers (fragment-order copy), no weight ring, 2 barriers per chunk (2 = every such layer incl. the 128-channel ones, where it measures even)
 FP_HOOK g_i8_stream = 0;       // test build A/B: 1 = INT8 networks with an 8-bit residual stream (run_trunk_i8; faster, but its common-mode error is frame-specific: DESIGN.md section 4.4)
@@ -1785,6 +1786,16 @@ static void launch_attention(const Ctx &c, const void *qkv, void *out, int B, in
   if (g_att_skv && nq * HEADS * B <= 64 && T > 32) {  // a small grid of long latency chains: split the keys over the waves instead
     const int nq32 = (T + 31) / 32;
     FP_LAUNCH((attention32_skv_kernel<true, DT>), dim3((unsigned)(nq32 * HEADS * B)), dim3(256), 4 * 2 * (32 * 256 + 8 * 1056), c.s, q, o, T, nq32, tstride, ld);
+    return;
+  }
+  // [r5] a sequence of 400 tokens is 3 query blocks of 128 rows + 16 rows: the 4th block's workgroup stages every key tile for one half-
+  // empty wave.  That tail goes to the split-KV kernel instead (its four waves share the 13 key blocks): one more launch, 25 % fewer
+  // workgroups in the main one.  (Small grids take the split-KV kernel for ALL rows, above: the tail rows come out the same either way.)
+  const int tail = T % 128;
+  if (g_att_tail && tail > 0 && tail <= 32 && T > 128) {
+    const int nq_main = T / 128;
+    hipLaunchKernelGGL((attention32_kernel<true, DT>), dim3((unsigned)(nq_main * HEADS * B)), dim3(256), 0, c.s, q, o, T, nq_main, tstride, ld);
+    FP_LAUNCH((attention32_skv_kernel<true, DT>), dim3((unsigned)(HEADS * B)), dim3(256), 4 * 2 * (32 * 256 + 8 * 1056), c.s, q, o, T, 1, tstride, ld, nq_main * 4);
     return;
   }
   hipLaunchKernelGGL((attention32_kernel<true, DT>), dim3((unsigned)(nq * HEADS * B)), dim3(256), 0, c.s, q, o, T, nq, tstride, ld);
