@@ -2016,9 +2016,14 @@ static int run_trunk_q8(const Ctx &c, const Arena &a, const void *nn_in, int N, 
     // frames' means, what the compensation adds is the image's deviation from them, and 26 more launches would double a Track)
     if (q != DT_I8 || !L.tmat_t || !c.ws || !c.ws->img_sum || !g_q8_imgbias || NBi < 16) return nullptr;
     ProfScope ps(c.prof, c.s, "q8_img_bias", 0, (double)NBi * (HW + 2) * (HW + 2) * L.Cin);
-    hipLaunchKernelGGL(q8_img_sum_kernel, dim3(NBi, HW == 40 ? 6 : 2), dim3(256), 0, c.s, (const unsigned char *)xq, (HW + 2) * (HW + 2), L.Cin, c.ws->img_sum);
-    hipLaunchKernelGGL(q8_img_bias_kernel, dim3(NBi, L.Cout / 64), dim3(256), 0, c.s, c.ws->img_sum, L.tmat_t, L.cscale, L.bias, 1.f / (float)(HW * HW), L.Cin, L.Cout, c.ws->img_bias);
-    (void)hipMemsetAsync(c.ws->img_sum, 0, (size_t)NBi * L.Cin * sizeof(int), c.s);   // zero for the next layer's atomics (a memset node in the captured graph)
+    if (g_q8_imgbias == 2) {   // A/B (test build): the three-launch form (sliced integer-atomic sums, 64-channel bias blocks, clear)
+      hipLaunchKernelGGL(q8_img_sum_kernel, dim3(NBi, HW == 40 ? 6 : 2), dim3(256), 0, c.s, (const unsigned char *)xq, (HW + 2) * (HW + 2), L.Cin, c.ws->img_sum);
+      hipLaunchKernelGGL(q8_img_bias_kernel, dim3(NBi, L.Cout / 64), dim3(256), 0, c.s, c.ws->img_sum, L.tmat_t, L.cscale, L.bias, 1.f / (float)(HW * HW), L.Cin, L.Cout, c.ws->img_bias);
+      (void)hipMemsetAsync(c.ws->img_sum, 0, (size_t)NBi * L.Cin * sizeof(int), c.s);
+    } else {
+      hipLaunchKernelGGL(q8_img_bias_fused_kernel, dim3(NBi), dim3(1024), 0, c.s, (const unsigned char *)xq, (HW + 2) * (HW + 2), L.tmat_t, L.cscale, L.bias,
+                         1.f / (float)(HW * HW), L.Cin, L.Cout, c.ws->img_bias);
+    }
     return c.ws->img_bias;
   };
   const size_t P1 = (size_t)NB2 * 42 * 42, P2 = (size_t)N * 42 * 42, P5 = (size_t)N * 22 * 22;
