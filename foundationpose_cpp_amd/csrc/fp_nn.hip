@@ -2021,8 +2021,10 @@ static int run_trunk_q8(const Ctx &c, const Arena &a, const void *nn_in, int N, 
       hipLaunchKernelGGL(q8_img_bias_kernel, dim3(NBi, L.Cout / 64), dim3(256), 0, c.s, c.ws->img_sum, L.tmat_t, L.cscale, L.bias, 1.f / (float)(HW * HW), L.Cin, L.Cout, c.ws->img_bias);
       (void)hipMemsetAsync(c.ws->img_sum, 0, (size_t)NBi * L.Cin * sizeof(int), c.s);
     } else {
-      hipLaunchKernelGGL(q8_img_bias_fused_kernel, dim3(NBi), dim3(1024), 0, c.s, (const unsigned char *)xq, (HW + 2) * (HW + 2), L.tmat_t, L.cscale, L.bias,
-                         1.f / (float)(HW * HW), L.Cin, L.Cout, c.ws->img_bias);
+      // even rows x even columns of the padded image (HW + 2 is even): (HW/2 + 1)^2 lattice points, (HW/2)^2 of them interior
+      const int wp2 = g_q8_imgbias == 3 ? 0 : (HW + 2) / 2;
+      hipLaunchKernelGGL(q8_img_bias_fused_kernel, dim3(NBi), dim3(1024), 0, c.s, (const unsigned char *)xq, wp2 ? wp2 * wp2 : (HW + 2) * (HW + 2), L.tmat_t, L.cscale,
+                         L.bias, wp2 ? 1.f / (float)((HW / 2) * (HW / 2)) : 1.f / (float)(HW * HW), L.Cin, L.Cout, c.ws->img_bias, wp2, (HW + 2) * (HW + 2));
     }
     return c.ws->img_bias;
   };
