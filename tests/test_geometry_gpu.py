@@ -230,3 +230,74 @@ def test_separately_rounded_float_model_parity(syn_mesh, syn_scene):
     finally:
         fo.set_fmad(True)
         m.close()
+
+
+# ---- seeded randomised sweep: meshes, intrinsics, frame sizes and poses nobody hand-picked --------------------------------------------
+_SWEEP_SIZES = [(640, 480), (641, 479), (333, 257), (1280, 720), (1920, 1080), (160, 120)]
+
+
+def _random_case(seed):
+    """one frame + one mesh + 6 poses: a dented icosphere (1-3 subdivisions, own axes, NOT centred at the origin, texture coordinates
+    beyond [0, 1] -> wrap addressing, odd texture size), fx != fy with the principal point off centre, an rgb frame of noise over a wavy depth surface with 10 % of
+    it missing, objects from 0.12 m (near-plane clipping) to 3 m and up to a diameter outside the image"""
+    rng = np.random.default_rng(1000 + seed)
+    W, H = _SWEEP_SIZES[seed % len(_SWEEP_SIZES)]
+    s, faces = syn._icosphere(1 + seed % 3)
+    ax = rng.uniform(0.02, 0.12, 3)
+    v = s * ax * (1.0 + 0.25 * rng.uniform(-1, 1, (len(s), 1))) + rng.uniform(-0.05, 0.05, 3)
+    n = s / ax
+    n /= np.linalg.norm(n, axis=1, keepdims=True)
+    uv = rng.uniform(-1.5, 2.5, (len(s), 2))
+    tex = rng.integers(0, 256, (int(rng.integers(2, 70)), int(rng.integers(2, 70)), 3), dtype=np.uint8)
+    mesh = syn.Mesh(f"rnd{seed}", v.astype(np.float32), n.astype(np.float32), uv.astype(np.float32), faces, tex).finalize()
+    f = rng.uniform(0.6, 1.4) * W
+    K = np.array([[f, 0, W * rng.uniform(0.3, 0.7)], [0, f * rng.uniform(0.8, 1.25), H * rng.uniform(0.3, 0.7)], [0, 0, 1]], np.float32)
+    rgb = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    yy, xx = np.mgrid[0:H, 0:W]
+    depth = (rng.uniform(0.3, 2.0) + 0.5 * np.sin(xx / W * rng.uniform(2, 9) + rng.uniform(0, 6)) * np.cos(yy / H * rng.uniform(2, 9)) * rng.uniform(0.1, 0.5)
+             + rng.normal(0, 0.002, (H, W))).astype(np.float32)      # a smooth surface (the sampler's erosion removes isolated pixels) + 2 mm of noise
+    depth[rng.uniform(size=(H, W)) < 0.1] = 0.0
+    depth[:H // 8, :W // 8] = rng.uniform(0.0005, 6.0, (H // 8, W // 8))   # one corner of pure noise incl. values under min_depth and over the 4 m cut
+    poses = []
+    for i in range(6):
+        z = float(rng.choice([0.12, 0.3, 0.7, 1.5, 3.0])) * rng.uniform(0.9, 1.1)
+        u, w = rng.uniform(-0.1, 1.1) * W, rng.uniform(-0.1, 1.1) * H      # the centre projects up to 10 % outside the frame
+        t = (z * (u - K[0, 2]) / K[0, 0], z * (w - K[1, 2]) / K[1, 1], z)
+        poses.append(syn.pose_matrix(syn.random_rotation(100 * seed + i), t))
+    return mesh, K, rgb, depth, np.stack(poses).astype(np.float32), (H, W)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_randomised_render_and_crop_sweep(seed):
+    mesh, K, rgb, depth, poses, hw = _random_case(seed)
+    m = FoundationPose(mesh, K)
+    m.upload_frame(rgb, depth)
+    np.testing.assert_array_equal(m.xyz_map(), fo.depth_to_xyz(depth, K))
+    # the sampler on a frame of noise: erosion bit-exact, bilateral filter to 2e-6 relative, translation guess (bounding box of a ragged mask,
+    # exact median of the filtered depth under it) bit-exact
+    e, bl = m.filter_depth()
+    np.testing.assert_array_equal(e, fo.erode_depth(depth))
+    np.testing.assert_allclose(bl, fo.bilateral_filter_depth(fo.erode_depth(depth)), rtol=2e-6, atol=0)
+    rng = np.random.default_rng(2000 + seed)
+    mask = np.zeros(hw, np.uint8)
+    y0, x0 = int(rng.integers(0, hw[0] // 2)), int(rng.integers(0, hw[1] // 2))
+    mask[y0:y0 + hw[0] // 3, x0:x0 + hw[1] // 3] = (rng.uniform(size=(hw[0] // 3, hw[1] // 3)) < 0.4) * int(rng.integers(1, 256))
+    hyp = m.get_hyp_poses(mask)
+    ref = fo.get_hyp_poses(depth, mask, K)
+    if ref is None:
+        assert hyp is None
+    else:
+        ref = syn.from_colmajor(ref)
+        np.testing.assert_allclose(hyp[:, :3, :3], ref[:, :3, :3], atol=1e-6)
+        np.testing.assert_array_equal(hyp[:, :3, 3], ref[:, :3, 3])
+    om = fo.OracleMesh(mesh)
+    for ratio in (1.2, 1.1):
+        tri, rast = m.debug_rasterize(mesh.name, poses, ratio)
+        a, b = m.render_and_transform(mesh.name, poses, ratio)
+        ra, rtri, rrast = fo.render(om, syn.to_colmajor(poses), K, hw, ratio, debug=True)
+        rb = fo.crop(rgb, depth, K, syn.to_colmajor(poses), ratio, mesh.diameter)
+        np.testing.assert_array_equal(tri, rtri)
+        np.testing.assert_allclose(rast, rrast, rtol=0, atol=2e-6)
+        np.testing.assert_allclose(a, ra, **F32_TOL)
+        np.testing.assert_allclose(b, rb, **F32_TOL)
+    m.close()
