@@ -351,6 +351,32 @@ def test_track_end_to_end(model, nets, syn_mesh, syn_scene):
     np.testing.assert_allclose(p12, p2, atol=1e-6)
 
 
+@pytest.mark.parametrize("case", range(6))
+def test_track_end_to_end_sweep(nets, syn_mesh, case):
+    """Track against the oracle chain on frames other than the default scene: the synthetic scene family (object 0.55-0.95 m away, off axis,
+    any orientation), a 1280x720 frame, a starting pose 12 deg / 3 cm off, two iterations"""
+    W, H = (1280, 720) if case == 4 else (640, 480)
+    scene = syn.heldout_scenes(syn_mesh, 6, W=W, H=H)[case]
+    hyp = syn.perturb_pose(scene.gt_pose, deg=12.0 if case == 5 else 5.0, trans=0.03 if case == 5 else 0.01, seed=50 + case)
+    itr = 2 if case == 3 else 1
+    m = FoundationPose(syn_mesh, scene.K, nets[0], nets[1])
+    try:
+        ok, pose = m.Track(scene.rgb, scene.depth, hyp, syn_mesh.name, refine_itr=itr)
+        assert ok, m.last_error
+    finally:
+        m.close()
+    om = fo.OracleMesh(syn_mesh)
+    p16 = syn.to_colmajor(hyp[None])
+    for _ in range(itr):
+        a = fo.render(om, p16, scene.K, (H, W), 1.2)
+        b = fo.crop(scene.rgb, scene.depth, scene.K, p16, 1.2, syn_mesh.diameter)
+        with torch.no_grad():
+            t, r = nets[2](torch.from_numpy(a), torch.from_numpy(b))
+        p16 = fo.refine_post_process(p16, t.numpy(), r.numpy(), syn_mesh.diameter)
+    ang, dist = _pose_err(pose, syn.from_colmajor(p16)[0])
+    assert ang < 0.1 * itr and dist < 1e-4 * itr, (ang, dist)      # (the second iteration renders from the first one's f16-rounded pose)
+
+
 def test_register_end_to_end_252(model, nets, syn_mesh, syn_scene):
     ok, pose = model.Register(syn_scene.rgb, syn_scene.depth, syn_scene.mask, syn_mesh.name)
     assert ok, model.last_error
