@@ -1297,7 +1297,7 @@ static int run_conv_dt(const Ctx &c, const char *tag, const ConvLayer &L, ConvPa
   constexpr int LDS3_128 = 3 * (256 * 128 + 128 * 128);
   constexpr int LDS_BIG = 2 * (256 * 128 + 256 * 128);
   constexpr int LDS_HALO40 = ((10 * 42 + 7) / 8) * 1024 + 3 * 128 * 64;
-  constexpr int LDS_HALO40W = ((10 * 42 + 7) / 8) * 1024;
+  [[maybe_unused]] constexpr int LDS_HALO40W = ((10 * 42 + 7) / 8) * 1024;
   constexpr int LDS_HALO8 = ((10 * 42 + 7) / 8) * 1024 + 128 * 128;
   constexpr int LDS_STEM_HALO = ((11 * 84 + 15) / 16) * 1024 + 3 * 64 * 64;
   constexpr int LDS_DEEP64 = 6 * (64 + 128) * 128, LDS_DEEP128 = 4 * (128 + 128) * 128;
@@ -1442,7 +1442,9 @@ static int run_conv_dt(const Ctx &c, const char *tag, const ConvLayer &L, ConvPa
       if (DT == DT_F16 && g_conv_ablate == 32) { FP_LAUNCH((conv_halo_kernel<40, 32, DT_F16>), grid, dim3(256), LDS_HALO40, c.s, p); return 0; }
 #endif
       if (!g_halo_wpack) p.wpack = nullptr;
+#ifdef FP_TEST_HOOKS
       if (g_halo_wreg && p.wfrag && g_conv_ablate == 0 && (p.cin_b >= 512 || g_halo_wreg == 2)) { FP_LAUNCH((conv_halo_wreg_kernel<DT>), grid, dim3(256), LDS_HALO40W, c.s, p); return 0; }
+#endif
       FP_LAUNCH((conv_halo_kernel<40, 0, DT>), grid, dim3(256), LDS_HALO40, c.s, p);
     } else if constexpr (odt_q(ODT) == DT) {
       ProfScope ps(c.prof, c.s, (tg + "/conv_halo8_kernel").c_str(), flops, bytes);
@@ -2016,11 +2018,14 @@ static int run_trunk_q8(const Ctx &c, const Arena &a, const void *nn_in, int N, 
     // frames' means, what the compensation adds is the image's deviation from them, and 26 more launches would double a Track)
     if (q != DT_I8 || !L.tmat_t || !c.ws || !c.ws->img_sum || !g_q8_imgbias || NBi < 16) return nullptr;
     ProfScope ps(c.prof, c.s, "q8_img_bias", 0, (double)NBi * (HW + 2) * (HW + 2) * L.Cin);
+#ifdef FP_TEST_HOOKS
     if (g_q8_imgbias == 2) {   // A/B (test build): the three-launch form (sliced integer-atomic sums, 64-channel bias blocks, clear)
       hipLaunchKernelGGL(q8_img_sum_kernel, dim3(NBi, HW == 40 ? 6 : 2), dim3(256), 0, c.s, (const unsigned char *)xq, (HW + 2) * (HW + 2), L.Cin, c.ws->img_sum);
       hipLaunchKernelGGL(q8_img_bias_kernel, dim3(NBi, L.Cout / 64), dim3(256), 0, c.s, c.ws->img_sum, L.tmat_t, L.cscale, L.bias, 1.f / (float)(HW * HW), L.Cin, L.Cout, c.ws->img_bias);
       (void)hipMemsetAsync(c.ws->img_sum, 0, (size_t)NBi * L.Cin * sizeof(int), c.s);
-    } else {
+    } else
+#endif
+    {
       // even rows x even columns of the padded image (HW + 2 is even): (HW/2 + 1)^2 lattice points, (HW/2)^2 of them interior
       const int wp2 = g_q8_imgbias == 3 ? 0 : (HW + 2) / 2;
       hipLaunchKernelGGL(q8_img_bias_fused_kernel, dim3(NBi), dim3(1024), 0, c.s, (const unsigned char *)xq, wp2 ? wp2 * wp2 : (HW + 2) * (HW + 2), L.tmat_t, L.cscale,
