@@ -193,6 +193,7 @@ __host__ __device__ constexpr int elem_bytes(int dt) { return (dt == DT_FP8 || d
 #include "fp_nn_conv_kernels.inc"
 #include "fp_nn_attention_kernels.inc"
 #include "fp_nn_small_kernels.inc"
+#include "fp_nn_enc_kernels.inc"
 
 // =================================================================================================
 // weights
@@ -1253,6 +1254,7 @@ FP_HOOK g_big_wpack = 1;       // conv_big_pp_kernel streams its weights from th
 FP_HOOK g_halo_wpack = 1;      // conv_halo_kernel streams its weights from the stage-order copy
 FP_HOOK g_att_tail = 0;        // [r5] A/B, OFF (measured slower: attention 0.555 -> 0.625 ms per Register): the 16-row tail of a 400-token sequence on attention32_skv_kernel instead of a 4th 128-row block
 FP_HOOK g_ln_pmean = 1;        // [r5] Track: LayerNorm 2 + partial token sums in one launch (layernorm_pmean_kernel) instead of layernorm + token_mean
+FP_HOOK g_enc_tail = 1;        // [r5] Register (N > 1): out_proj + LayerNorm 1 + FFN + LayerNorm 2 + token sums of BOTH heads as one launch (enc_tail_kernel) instead of five per head
 FP_HOOK g_halo_wreg = 0;       // [r5] A/B, OFF (conv_256 -3 % in the stage profile, nothing on the wall clock: tools/ab_wall.py, EXPERIMENTS.md): 1 = 3x3 / 40x40 layers with >= 256 input channels on conv_halo_wreg_kernel: weights global -> registers (fragment-order copy), no weight ring, 2 barriers per chunk (2 = every such layer incl. the 128-channel ones, where it measures even)
 FP_HOOK g_i8_stream = 0;       // test build A/B: 1 = INT8 networks with an 8-bit residual stream (run_trunk_i8; faster, but its common-mode error is frame-specific: DESIGN.md section 4.4)
 FP_HOOK g_smallx_pf = 0;       // A/B (test build): prefetch depth of conv_smallx_kernel<2,4> (4 or 2; 0 = the default 3)
@@ -2204,6 +2206,44 @@ int refiner_forward(hipStream_t s, Profiler *prof, const Net *net, NNScratch *ws
         if (fused_out) *fused_out = true;
       } else
         hipLaunchKernelGGL(small_linear2_kernel, dim3((unsigned)((T0.head.out + 3) / 4), 2), dim3(256), 0, c.s, a, 1, T0.head.out, T0.head.in);
+    }
+    FP_HIP_OK(hipGetLastError());
+    return 0;
+  }
+  const auto tail_ok = [&](const EncLayer &L) {
+    return L.att.out_proj.wfrag && L.lin1.wfrag && L.lin2.wfrag && L.head.in == EMBED && L.head.out <= 3 && L.att.out_proj.Cin == EMBED && L.lin1.Cin == EMBED &&
+           L.lin1.Cout == EMBED && L.lin2.Cin == EMBED && L.lin2.Cout == EMBED && L.att.out_proj.dt == dt && L.lin1.dt == dt && L.lin2.dt == dt;
+  };
+  if (g_enc_tail && N > 1 && (dt == DT_F16 || dt == DT_BF16) && tail_ok(net->trans) && tail_ok(net->rot) && net->trans.head.out == net->rot.head.out) {
+    // [r5] both heads: QKV projection + self-attention per head (the attention outputs in a.att / a.y1), then ONE launch for everything
+    // row-wise behind them (enc_tail_kernel, fp_nn_enc_kernels.inc) and one for the token mean + Linear(512,3) of both heads
+    void *att_out[2] = {a.att, a.y1};
+    for (int i = 0; i < 2; i++) {
+      if (run_gemm(c, "gemm_qkv", heads[i]->att.in_proj, x, (int)rows, a.qkv, false)) return 1;
+      if (run_attention(c, dt, a.qkv, att_out[i], N, 400)) return 1;
+    }
+    float *const psum = reinterpret_cast<float *>(a.y2);   // [2][N * 5][512] f32 = N * 20 KB of the N * 400 KB tensor
+    {
+      ProfScope ps(c.prof, c.s, "enc_tail", 2.0 * 3.0 * 2.0 * (double)rows * EMBED * EMBED, 2.0 * 2.0 * (double)rows * EMBED * 2.0);
+      EncTailParams q{};
+      q.x = (const unsigned char *)x;
+      q.psum = psum;
+      q.tiles = N * 5;
+      for (int i = 0; i < 2; i++) {
+        const EncLayer &L = *heads[i];
+        q.att[i] = (const unsigned char *)att_out[i];
+        q.w[i][0] = L.att.out_proj.wfrag; q.w[i][1] = L.lin1.wfrag; q.w[i][2] = L.lin2.wfrag;
+        q.bias[i][0] = L.att.out_proj.bias; q.bias[i][1] = L.lin1.bias; q.bias[i][2] = L.lin2.bias;
+        q.ln_g[i][0] = L.ln1.g; q.ln_b[i][0] = L.ln1.b; q.ln_g[i][1] = L.ln2.g; q.ln_b[i][1] = L.ln2.b;
+      }
+      constexpr unsigned kLds = 16 * 80 * 64 + 2 * 8 * 80 * 4;
+      if (dt == DT_BF16) FP_LAUNCH((enc_tail_kernel<DT_BF16>), dim3((unsigned)(2 * q.tiles)), dim3(512), kLds, c.s, q);
+      else FP_LAUNCH((enc_tail_kernel<DT_F16>), dim3((unsigned)(2 * q.tiles)), dim3(512), kLds, c.s, q);
+    }
+    {
+      ProfScope ps(c.prof, c.s, "small_linear", 2.0 * 2 * N * net->trans.head.out * EMBED, 0);
+      EncHeadsParams hp{psum, {net->trans.head.w, net->rot.head.w}, {net->trans.head.b, net->rot.head.b}, {trans_dev, rot_dev}, N, 5, net->trans.head.out, 400.f};
+      hipLaunchKernelGGL(enc_heads_kernel, dim3((unsigned)N), dim3(384), 0, c.s, hp);
     }
     FP_HIP_OK(hipGetLastError());
     return 0;
