@@ -2030,8 +2030,8 @@ static int run_trunk_q8(const Ctx &c, const Arena &a, const void *nn_in, int N, 
     {
       // even rows x even columns of the padded image (HW + 2 is even): (HW/2 + 1)^2 lattice points, (HW/2)^2 of them interior
       const int wp2 = g_q8_imgbias == 3 ? 0 : (HW + 2) / 2;
-      hipLaunchKernelGGL(q8_img_bias_fused_kernel, dim3(NBi), dim3(1024), 0, c.s, (const unsigned char *)xq, wp2 ? wp2 * wp2 : (HW + 2) * (HW + 2), L.tmat_t, L.cscale,
-                         L.bias, wp2 ? 1.f / (float)((HW / 2) * (HW / 2)) : 1.f / (float)(HW * HW), L.Cin, L.Cout, c.ws->img_bias, wp2, (HW + 2) * (HW + 2));
+      hipLaunchKernelGGL(q8_img_bias_fused_kernel, dim3((NBi + Q8_BIAS_IMGS - 1) / Q8_BIAS_IMGS), dim3(1024), 0, c.s, (const unsigned char *)xq, wp2 ? wp2 * wp2 : (HW + 2) * (HW + 2), L.tmat_t, L.cscale,
+                         L.bias, wp2 ? 1.f / (float)((HW / 2) * (HW / 2)) : 1.f / (float)(HW * HW), L.Cin, L.Cout, c.ws->img_bias, wp2, (HW + 2) * (HW + 2), NBi);
     }
     return c.ws->img_bias;
   };
@@ -2094,8 +2094,10 @@ static int run_trunk(const Ctx &c, const Arena &a, const void *nn_in, int N, int
   auto T = [&](void *p) { return Act{p, adt, 1.f}; };
   const size_t P1 = (size_t)NB2 * 42 * 42, P2 = (size_t)N * 42 * 42, P5 = (size_t)N * 22 * 22;
   const Act in = T(const_cast<void *>(nn_in)), stem = T(a.stem);
-  if (run_conv(c, "conv_stem", net->a0, in, NB2, 80, 80, 2, stem, 1, true)) return 1;
   const Act x0 = T(a.x128[0]), x1 = T(a.x128[1]), x2 = T(a.x128[2]), cat = T(a.x256[0]);
+  // ([r5] stem + encodeA.1 in chunks of 63 / 84 / 126 images, so that the stem's output would be read back from the 256 MB memory-side
+  // cache instead of HBM: 10.93 -> 11.24 / 11.13 / 11.00 ms per Register, slower with every extra launch -- EXPERIMENTS.md R5.4)
+  if (run_conv(c, "conv_stem", net->a0, in, NB2, 80, 80, 2, stem, 1, true)) return 1;
   if (run_conv(c, "conv_a1", net->a1, stem, NB2, 80, 80, 1, x0, 1, true)) return 1;
   calib_record(c, 1, a.x128[0], P1, 128, adt);
   // encodeA residual blocks @40x40x128; the last conv writes the a|b channel concat directly
