@@ -2155,6 +2155,10 @@ int refiner_forward(hipStream_t s, Profiler *prof, const Net *net, NNScratch *ws
   const size_t rows = (size_t)N * 400;
   const EncLayer *heads[2] = {&net->trans, &net->rot};
   float *outs[2] = {trans_dev, rot_dev};
+  const auto tail_ok = [&](const EncLayer &L) {
+    return L.att.out_proj.wfrag && L.lin1.wfrag && L.lin2.wfrag && L.head.in == EMBED && L.head.out <= 3 && L.att.out_proj.Cin == EMBED && L.lin1.Cin == EMBED &&
+           L.lin1.Cout == EMBED && L.lin2.Cin == EMBED && L.lin2.Cout == EMBED && L.att.out_proj.dt == dt && L.lin1.dt == dt && L.lin2.dt == dt;
+  };
   if (N == 1 && g_grouped_heads) {
     // Track: both heads in ONE launch per layer (Track is bound by its ~65 dependent launches, not by work).  Rows
     // [0,400) = translation head, [512,912) = rotation head (groups padded to the 128-row tile; the rows in between
@@ -2164,6 +2168,45 @@ int refiner_forward(hipStream_t s, Profiler *prof, const Net *net, NNScratch *ws
     const EncLayer &T0 = net->trans, &R0 = net->rot;
     if (run_gemm(c, "gemm_qkv", net->g_in_proj, x, 2 * G, a.qkv, false, nullptr, &g_x)) return 1;
     if (run_attention(c, dt, a.qkv, a.att, 2, 400, G)) return 1;
+    if (g_enc_tail && (dt == DT_F16 || dt == DT_BF16) && tail_ok(T0) && tail_ok(R0) && T0.head.out == 3 && R0.head.out == 3
+#ifdef FP_TEST_HOOKS
+        && g_fuse_pose != 2
+#endif
+    ) {
+      // [r5] everything row-wise behind the attention as ONE launch of 2 x 25 sixteen-token tiles (enc_tail_kernel<., 1>) instead of
+      // out_proj, LayerNorm 1, FFN1, FFN2, LayerNorm 2 + partial sums (five dependent launches, 33 us of the 202 us graph)
+      float *const psum = reinterpret_cast<float *>(a.y2);   // [2][25][512]
+      {
+        ProfScope ps(c.prof, c.s, "enc_tail", 2.0 * 3.0 * 2.0 * 400.0 * EMBED * EMBED, 2.0 * 2.0 * 400.0 * EMBED * 2.0);
+        EncTailParams q{};
+        q.x = (const unsigned char *)x;
+        q.psum = psum;
+        q.tiles = 25;
+        const EncLayer *hl[2] = {&T0, &R0};
+        for (int i = 0; i < 2; i++) {
+          const EncLayer &L = *hl[i];
+          q.att[i] = (const unsigned char *)a.att + (size_t)i * G * EMBED * 2;
+          q.w[i][0] = L.att.out_proj.wfrag; q.w[i][1] = L.lin1.wfrag; q.w[i][2] = L.lin2.wfrag;
+          q.bias[i][0] = L.att.out_proj.bias; q.bias[i][1] = L.lin1.bias; q.bias[i][2] = L.lin2.bias;
+          q.ln_g[i][0] = L.ln1.g; q.ln_b[i][0] = L.ln1.b; q.ln_g[i][1] = L.ln2.g; q.ln_b[i][1] = L.ln2.b;
+        }
+        constexpr unsigned kLds = 16 * 16 * 64 + 2 * 8 * 16 * 4;
+        if (dt == DT_BF16) FP_LAUNCH((enc_tail_kernel<DT_BF16, 1>), dim3(50), dim3(512), kLds, c.s, q);
+        else FP_LAUNCH((enc_tail_kernel<DT_F16, 1>), dim3(50), dim3(512), kLds, c.s, q);
+      }
+      {
+        ProfScope ps(c.prof, c.s, "small_linear", 2.0 * 2 * T0.head.out * T0.head.in, 0);
+        SmallLinear2 sl{{psum, psum + 25 * EMBED}, {T0.head.w, R0.head.w}, {T0.head.b, R0.head.b}, {trans_dev, rot_dev}};
+        sl.parts = 25; sl.tokens = 400.f;
+        if (fuse && g_fuse_pose) {
+          hipLaunchKernelGGL(small_linear2_pose_kernel, dim3(1), dim3(384), 0, c.s, sl, T0.head.in, *fuse);
+          if (fused_out) *fused_out = true;
+        } else
+          hipLaunchKernelGGL(small_linear2_kernel, dim3((unsigned)((T0.head.out + 3) / 4), 2), dim3(256), 0, c.s, sl, 1, T0.head.out, T0.head.in);
+      }
+      FP_HIP_OK(hipGetLastError());
+      return 0;
+    }
     if (run_gemm(c, "gemm_512", net->g_out_proj, a.att, 2 * G, a.y1, false, x, &g_in)) return 1;   // + residual x (shared)
     run_layernorm(c, dt, a.y1, T0.ln1, a.y2, 2 * G, &R0.ln1, G);
     if (run_gemm(c, "gemm_512", net->g_lin1, a.y2, 2 * G, a.y1, true, nullptr, &g_own)) return 1;
@@ -2212,10 +2255,6 @@ int refiner_forward(hipStream_t s, Profiler *prof, const Net *net, NNScratch *ws
     FP_HIP_OK(hipGetLastError());
     return 0;
   }
-  const auto tail_ok = [&](const EncLayer &L) {
-    return L.att.out_proj.wfrag && L.lin1.wfrag && L.lin2.wfrag && L.head.in == EMBED && L.head.out <= 3 && L.att.out_proj.Cin == EMBED && L.lin1.Cin == EMBED &&
-           L.lin1.Cout == EMBED && L.lin2.Cin == EMBED && L.lin2.Cout == EMBED && L.att.out_proj.dt == dt && L.lin1.dt == dt && L.lin2.dt == dt;
-  };
   if (g_enc_tail && N > 1 && (dt == DT_F16 || dt == DT_BF16) && tail_ok(net->trans) && tail_ok(net->rot) && net->trans.head.out == net->rot.head.out) {
     // [r5] both heads: QKV projection + self-attention per head (the attention outputs in a.att / a.y1), then ONE launch for everything
     // row-wise behind them (enc_tail_kernel, fp_nn_enc_kernels.inc) and one for the token mean + Linear(512,3) of both heads
@@ -2239,8 +2278,8 @@ int refiner_forward(hipStream_t s, Profiler *prof, const Net *net, NNScratch *ws
         q.ln_g[i][0] = L.ln1.g; q.ln_b[i][0] = L.ln1.b; q.ln_g[i][1] = L.ln2.g; q.ln_b[i][1] = L.ln2.b;
       }
       constexpr unsigned kLds = 16 * 80 * 64 + 2 * 8 * 80 * 4;
-      if (dt == DT_BF16) FP_LAUNCH((enc_tail_kernel<DT_BF16>), dim3((unsigned)(2 * q.tiles)), dim3(512), kLds, c.s, q);
-      else FP_LAUNCH((enc_tail_kernel<DT_F16>), dim3((unsigned)(2 * q.tiles)), dim3(512), kLds, c.s, q);
+      if (dt == DT_BF16) FP_LAUNCH((enc_tail_kernel<DT_BF16, 5>), dim3((unsigned)(2 * q.tiles)), dim3(512), kLds, c.s, q);
+      else FP_LAUNCH((enc_tail_kernel<DT_F16, 5>), dim3((unsigned)(2 * q.tiles)), dim3(512), kLds, c.s, q);
     }
     {
       ProfScope ps(c.prof, c.s, "small_linear", 2.0 * 2 * N * net->trans.head.out * EMBED, 0);
