@@ -2199,7 +2199,7 @@ int refiner_forward(hipStream_t s, Profiler *prof, const Net *net, NNScratch *ws
         SmallLinear2 sl{{psum, psum + 25 * EMBED}, {T0.head.w, R0.head.w}, {T0.head.b, R0.head.b}, {trans_dev, rot_dev}};
         sl.parts = 25; sl.tokens = 400.f;
         if (fuse && g_fuse_pose) {
-          hipLaunchKernelGGL(small_linear2_pose_kernel, dim3(1), dim3(384), 0, c.s, sl, T0.head.in, *fuse);
+          hipLaunchKernelGGL(small_linear2_pose_kernel, dim3(1), dim3(1024), 0, c.s, sl, T0.head.in, *fuse);
           if (fused_out) *fused_out = true;
         } else
           hipLaunchKernelGGL(small_linear2_kernel, dim3((unsigned)((T0.head.out + 3) / 4), 2), dim3(256), 0, c.s, sl, 1, T0.head.out, T0.head.in);
@@ -2247,7 +2247,7 @@ int refiner_forward(hipStream_t s, Profiler *prof, const Net *net, NNScratch *ws
       SmallLinear2 a{{pmean ? psums : ws->f32, pmean ? psums + kParts * EMBED : ws->f32 + EMBED}, {T0.head.w, R0.head.w}, {T0.head.b, R0.head.b}, {trans_dev, rot_dev}};
       if (pmean) { a.parts = kParts; a.tokens = 400.f; }
       if (fuse && g_fuse_pose && T0.head.out == 3 && R0.head.out == 3) {
-        hipLaunchKernelGGL(small_linear2_pose_kernel, dim3(1), dim3(384), 0, c.s, a, T0.head.in, *fuse);
+        hipLaunchKernelGGL(small_linear2_pose_kernel, dim3(1), dim3(1024), 0, c.s, a, T0.head.in, *fuse);
         if (fused_out) *fused_out = true;
       } else
         hipLaunchKernelGGL(small_linear2_kernel, dim3((unsigned)((T0.head.out + 3) / 4), 2), dim3(256), 0, c.s, a, 1, T0.head.out, T0.head.in);
@@ -2277,7 +2277,7 @@ int refiner_forward(hipStream_t s, Profiler *prof, const Net *net, NNScratch *ws
         q.bias[i][0] = L.att.out_proj.bias; q.bias[i][1] = L.lin1.bias; q.bias[i][2] = L.lin2.bias;
         q.ln_g[i][0] = L.ln1.g; q.ln_b[i][0] = L.ln1.b; q.ln_g[i][1] = L.ln2.g; q.ln_b[i][1] = L.ln2.b;
       }
-      constexpr unsigned kLds = 16 * 80 * 64 + 2 * 8 * 80 * 4;
+      constexpr unsigned kLds = 16 * 80 * 64 + 2 * 8 * 80 * 4 + 4 * 8192;   // tile + LayerNorm exchanges + the two parked x1 fragments
       if (dt == DT_BF16) FP_LAUNCH((enc_tail_kernel<DT_BF16, 5>), dim3((unsigned)(2 * q.tiles)), dim3(512), kLds, c.s, q);
       else FP_LAUNCH((enc_tail_kernel<DT_F16, 5>), dim3((unsigned)(2 * q.tiles)), dim3(512), kLds, c.s, q);
     }
