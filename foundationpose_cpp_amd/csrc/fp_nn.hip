@@ -240,6 +240,7 @@ static bool read_fpw(const char *path, std::map<std::string, HostTensor> &out, s
 struct ConvLayer {
   unsigned char *w = nullptr;  // kernel layout, element type dt
   unsigned char *wfrag = nullptr;  // 2-byte types: a second copy in MFMA-fragment order for conv_smallm_kernel (fragment_order)
+  unsigned char *wstep = nullptr;  // Linear layers: the fragment-order copy with the K-step OUTER (fragment_order_step_major; enc_tail_kernel, qkv_tile_kernel)
   unsigned char *wpack = nullptr;  // a copy in the LDS-stage order of gemm_k32_kernel (Linear layers) / conv_halo_kernel (3x3 layers) (pack_stage_w)
   unsigned char *wpack128 = nullptr;  // 3x3 layers with Cout % 256 == 0: a copy in conv_big_pp_kernel's stage order (pack_stage_w128)
   unsigned char *wdeep = nullptr;     // Cout % 128 == 0, 128-byte K-steps: a copy in conv_deep_kernel's stage order (FP8 3x3 layers: = wpack, the same order)
@@ -480,6 +481,20 @@ static std::vector<unsigned char> fragment_order(const std::vector<unsigned char
   return o;
 }
 
+// The same 1 KB fragments with the 64-byte K-step OUTER: fragment (16-row tile t, K-step s) at (s * Cout / 16 + t) KB.  The tile kernels of the
+// Linear layers (enc_tail_kernel, qkv_tile_kernel: eight waves x four row tiles per K-step) read 32 CONSECUTIVE KB per step this way; in
+// the tile-outer order the same 32 fragments lie 16 KB apart and fall on a few L2 channels, which every workgroup of an XCD -- they start
+// together and stream the same bytes in the same order -- then hammers at the same time.
+static std::vector<unsigned char> fragment_order_step_major(const std::vector<unsigned char> &w, int Cout, size_t row_bytes) {
+  const size_t S = row_bytes / 64, T = (size_t)Cout / 16;
+  std::vector<unsigned char> o(w.size());
+  for (size_t t = 0; t < T; t++)
+    for (size_t s = 0; s < S; s++)
+      for (int l = 0; l < 64; l++)
+        std::memcpy(&o[(s * T + t) * 1024 + (size_t)l * 16], &w[(t * 16 + (l & 15)) * row_bytes + s * 64 + (size_t)(l >> 4) * 16], 16);
+  return o;
+}
+
 // Stage order for the kernels that stream a [TILE rows][64 B] weight stage per K-step through LDS-DMA (gemm_k32_kernel: TILE = 256,
 // conv_halo_kernel: TILE = 128): the PW pieces (16 rows x 64 B each; lane -> row = lane >> 2, swizzled 16-byte chunk) wave `w` of a
 // workgroup stages for (row tile nt, 64-byte K-step st) are stored as ONE run at ((nt * S + st) * 4 + w) * PW KB -- the DMA then
@@ -525,6 +540,7 @@ static bool upload_layouts(Net *net, const std::vector<unsigned char> &elems, in
   if (!put_bytes(net, L->w, rows)) return false;
   if (((size_t)K * es) % 128 == 0 && Cout % 16 == 0) {   // (byte-level: every element type)
     if (!put_bytes(net, L->wfrag, fragment_order(rows, Cout, (size_t)K * es))) return false;
+    if (ntaps == 1 && es == 2 && !put_bytes(net, L->wstep, fragment_order_step_major(rows, Cout, (size_t)K * es))) return false;
   }
   if (!is_q8(dt) && ntaps == 1 && ((size_t)K * es) % 64 == 0 && Cout % 256 == 0) {
     if (!put_bytes(net, L->wpack, pack_stage_w(rows, Cout, (size_t)K * es, 256))) return false;      // gemm_k32_kernel
@@ -1254,6 +1270,7 @@ FP_HOOK g_big_wpack = 1;       // conv_big_pp_kernel streams its weights from th
 FP_HOOK g_halo_wpack = 1;      // conv_halo_kernel streams its weights from the stage-order copy
 FP_HOOK g_att_tail = 0;        // [r5] A/B, OFF (measured slower: attention 0.555 -> 0.625 ms per Register): the 16-row tail of a 400-token sequence on attention32_skv_kernel instead of a 4th 128-row block
 FP_HOOK g_ln_pmean = 1;        // [r5] Track: LayerNorm 2 + partial token sums in one launch (layernorm_pmean_kernel) instead of layernorm + token_mean
+FP_HOOK g_qkv_tile = 1;        // [r5] QKV projections of Register (N > 1) on qkv_tile_kernel (80-token tiles resident in LDS) instead of gemm_k32_kernel
 FP_HOOK g_enc_tail = 1;        // [r5] Register (N > 1): out_proj + LayerNorm 1 + FFN + LayerNorm 2 + token sums of BOTH heads as one launch (enc_tail_kernel) instead of five per head
 FP_HOOK g_halo_wreg = 0;       // [r5] A/B, OFF (conv_256 -3 % in the stage profile, nothing on the wall clock: tools/ab_wall.py, EXPERIMENTS.md): 1 = 3x3 / 40x40 layers with >= 256 input channels on conv_halo_wreg_kernel: weights global -> registers (fragment-order copy), no weight ring, 2 barriers per chunk (2 = every such layer incl. the 128-channel ones, where it measures even)
 FP_HOOK g_i8_stream = 0;       // test build A/B: 1 = INT8 networks with an 8-bit residual stream (run_trunk_i8; faster, but its common-mode error is frame-specific: DESIGN.md section 4.4)
@@ -1750,6 +1767,18 @@ static int run_gemm(const Ctx &c, const char *tag, const ConvLayer &L, const voi
   return run_conv(c, tag, L, ai, rows, 1, 1, 0, ao, 0, relu, res ? &ar : nullptr, 0, 0, grp);
 }
 
+// the QKV projection of `rows` tokens ([rows][512] -> [rows][1536]); rows % 80 == 0 and N > 1: qkv_tile_kernel, else the Linear schedule
+static int run_qkv(const Ctx &c, const ConvLayer &L, const void *x, int rows, void *qkv) {
+  if (g_qkv_tile && rows % 80 == 0 && rows >= 800 && L.wstep && L.Cin == EMBED && L.Cout == 3 * EMBED && (L.dt == DT_F16 || L.dt == DT_BF16)) {
+    ProfScope ps(c.prof, c.s, "gemm_qkv/qkv_tile_kernel", 2.0 * rows * EMBED * 3.0 * EMBED, (double)rows * EMBED * 2.0 * 4.0);
+    QkvTileParams q{(const unsigned char *)x, L.wstep, L.bias, (unsigned char *)qkv, rows / 80};
+    if (L.dt == DT_BF16) FP_LAUNCH((qkv_tile_kernel<DT_BF16>), dim3((unsigned)q.tiles), dim3(512), 16 * 80 * 64, c.s, q);
+    else FP_LAUNCH((qkv_tile_kernel<DT_F16>), dim3((unsigned)q.tiles), dim3(512), 16 * 80 * 64, c.s, q);
+    return 0;
+  }
+  return run_gemm(c, "gemm_qkv", L, x, rows, qkv, false);
+}
+
 template <int DT>
 static void launch_attention(const Ctx &c, const void *qkv, void *out, int B, int T, int tstride, int ld) {
   using E = typename ElemT<DT>::t;
@@ -2156,7 +2185,7 @@ int refiner_forward(hipStream_t s, Profiler *prof, const Net *net, NNScratch *ws
   const EncLayer *heads[2] = {&net->trans, &net->rot};
   float *outs[2] = {trans_dev, rot_dev};
   const auto tail_ok = [&](const EncLayer &L) {
-    return L.att.out_proj.wfrag && L.lin1.wfrag && L.lin2.wfrag && L.head.in == EMBED && L.head.out <= 3 && L.att.out_proj.Cin == EMBED && L.lin1.Cin == EMBED &&
+    return L.att.out_proj.wstep && L.lin1.wstep && L.lin2.wstep && L.head.in == EMBED && L.head.out <= 3 && L.att.out_proj.Cin == EMBED && L.lin1.Cin == EMBED &&
            L.lin1.Cout == EMBED && L.lin2.Cin == EMBED && L.lin2.Cout == EMBED && L.att.out_proj.dt == dt && L.lin1.dt == dt && L.lin2.dt == dt;
   };
   if (N == 1 && g_grouped_heads) {
@@ -2186,7 +2215,7 @@ int refiner_forward(hipStream_t s, Profiler *prof, const Net *net, NNScratch *ws
         for (int i = 0; i < 2; i++) {
           const EncLayer &L = *hl[i];
           q.att[i] = (const unsigned char *)a.att + (size_t)i * G * EMBED * 2;
-          q.w[i][0] = L.att.out_proj.wfrag; q.w[i][1] = L.lin1.wfrag; q.w[i][2] = L.lin2.wfrag;
+          q.w[i][0] = L.att.out_proj.wstep; q.w[i][1] = L.lin1.wstep; q.w[i][2] = L.lin2.wstep;
           q.bias[i][0] = L.att.out_proj.bias; q.bias[i][1] = L.lin1.bias; q.bias[i][2] = L.lin2.bias;
           q.ln_g[i][0] = L.ln1.g; q.ln_b[i][0] = L.ln1.b; q.ln_g[i][1] = L.ln2.g; q.ln_b[i][1] = L.ln2.b;
         }
@@ -2260,7 +2289,7 @@ int refiner_forward(hipStream_t s, Profiler *prof, const Net *net, NNScratch *ws
     // row-wise behind them (enc_tail_kernel, fp_nn_enc_kernels.inc) and one for the token mean + Linear(512,3) of both heads
     void *att_out[2] = {a.att, a.y1};
     for (int i = 0; i < 2; i++) {
-      if (run_gemm(c, "gemm_qkv", heads[i]->att.in_proj, x, (int)rows, a.qkv, false)) return 1;
+      if (run_qkv(c, heads[i]->att.in_proj, x, (int)rows, a.qkv)) return 1;
       if (run_attention(c, dt, a.qkv, att_out[i], N, 400)) return 1;
     }
     float *const psum = reinterpret_cast<float *>(a.y2);   // [2][N * 5][512] f32 = N * 20 KB of the N * 400 KB tensor
@@ -2273,7 +2302,7 @@ int refiner_forward(hipStream_t s, Profiler *prof, const Net *net, NNScratch *ws
       for (int i = 0; i < 2; i++) {
         const EncLayer &L = *heads[i];
         q.att[i] = (const unsigned char *)att_out[i];
-        q.w[i][0] = L.att.out_proj.wfrag; q.w[i][1] = L.lin1.wfrag; q.w[i][2] = L.lin2.wfrag;
+        q.w[i][0] = L.att.out_proj.wstep; q.w[i][1] = L.lin1.wstep; q.w[i][2] = L.lin2.wstep;
         q.bias[i][0] = L.att.out_proj.bias; q.bias[i][1] = L.lin1.bias; q.bias[i][2] = L.lin2.bias;
         q.ln_g[i][0] = L.ln1.g; q.ln_b[i][0] = L.ln1.b; q.ln_g[i][1] = L.ln2.g; q.ln_b[i][1] = L.ln2.b;
       }
@@ -2317,7 +2346,7 @@ int scorer_features(hipStream_t s, Profiler *prof, const Net *net, NNScratch *ws
   const Arena a = carve(ws);
   if (run_trunk(c, a, nn_in, N, N)) return 1;
   const size_t rows = (size_t)N * 400;
-  if (run_gemm(c, "gemm_qkv", net->att.in_proj, a.tokens, (int)rows, a.qkv, false)) return 1;
+  if (run_qkv(c, net->att.in_proj, a.tokens, (int)rows, a.qkv)) return 1;
   if (run_attention(c, net->act_dt, a.qkv, a.att, N, 400)) return 1;
   // feature = mean_t(out_proj(att)) = out_proj(mean_t(att))  (out_proj is affine) -> 512x512 GEMV per hypothesis
   run_token_mean(c, net->act_dt, a.att, ws->f32, N, 400);
