@@ -1270,6 +1270,7 @@ FP_HOOK g_big_wpack = 1;       // conv_big_pp_kernel streams its weights from th
 FP_HOOK g_halo_wpack = 1;      // conv_halo_kernel streams its weights from the stage-order copy
 FP_HOOK g_att_tail = 0;        // [r5] A/B, OFF (measured slower: attention 0.555 -> 0.625 ms per Register): the 16-row tail of a 400-token sequence on attention32_skv_kernel instead of a 4th 128-row block
 FP_HOOK g_ln_pmean = 1;        // [r5] Track: LayerNorm 2 + partial token sums in one launch (layernorm_pmean_kernel) instead of layernorm + token_mean
+FP_HOOK g_qkv_ablate = 0;      // timing-only ablations of qkv_tile_kernel (test build, wrong results)
 FP_HOOK g_qkv_tile = 1;        // [r5] QKV projections of Register (N > 1) on qkv_tile_kernel (80-token tiles resident in LDS) instead of gemm_k32_kernel
 FP_HOOK g_enc_tail = 1;        // [r5] Register (N > 1): out_proj + LayerNorm 1 + FFN + LayerNorm 2 + token sums of BOTH heads as one launch (enc_tail_kernel) instead of five per head
 FP_HOOK g_halo_wreg = 0;       // [r5] A/B, OFF (conv_256 -3 % in the stage profile, nothing on the wall clock: tools/ab_wall.py, EXPERIMENTS.md): 1 = 3x3 / 40x40 layers with >= 256 input channels on conv_halo_wreg_kernel: weights global -> registers (fragment-order copy), no weight ring, 2 barriers per chunk (2 = every such layer incl. the 128-channel ones, where it measures even)
@@ -1772,6 +1773,13 @@ static int run_qkv(const Ctx &c, const ConvLayer &L, const void *x, int rows, vo
   if (g_qkv_tile && rows % 80 == 0 && rows >= 800 && L.wstep && L.Cin == EMBED && L.Cout == 3 * EMBED && (L.dt == DT_F16 || L.dt == DT_BF16)) {
     ProfScope ps(c.prof, c.s, "gemm_qkv/qkv_tile_kernel", 2.0 * rows * EMBED * 3.0 * EMBED, (double)rows * EMBED * 2.0 * 4.0);
     QkvTileParams q{(const unsigned char *)x, L.wstep, L.bias, (unsigned char *)qkv, rows / 80};
+#ifdef FP_TEST_HOOKS
+    if (g_qkv_ablate == 1) { FP_LAUNCH((qkv_tile_kernel<DT_F16, 1>), dim3((unsigned)q.tiles), dim3(512), 16 * 80 * 64, c.s, q); return 0; }
+    if (g_qkv_ablate == 2) { FP_LAUNCH((qkv_tile_kernel<DT_F16, 2>), dim3((unsigned)q.tiles), dim3(512), 16 * 80 * 64, c.s, q); return 0; }
+    if (g_qkv_ablate == 3) { FP_LAUNCH((qkv_tile_kernel<DT_F16, 3>), dim3((unsigned)q.tiles), dim3(512), 16 * 80 * 64, c.s, q); return 0; }
+    if (g_qkv_ablate == 4) { FP_LAUNCH((qkv_tile_kernel<DT_F16, 4>), dim3((unsigned)q.tiles), dim3(512), 16 * 80 * 64, c.s, q); return 0; }
+    if (g_qkv_ablate == 7) { FP_LAUNCH((qkv_tile_kernel<DT_F16, 7>), dim3((unsigned)q.tiles), dim3(512), 16 * 80 * 64, c.s, q); return 0; }
+#endif
     if (L.dt == DT_BF16) FP_LAUNCH((qkv_tile_kernel<DT_BF16>), dim3((unsigned)q.tiles), dim3(512), 16 * 80 * 64, c.s, q);
     else FP_LAUNCH((qkv_tile_kernel<DT_F16>), dim3((unsigned)q.tiles), dim3(512), 16 * 80 * 64, c.s, q);
     return 0;
