@@ -43,7 +43,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_FP16_TFLOPS = 2500.0   # MI355X dense fp16/bf16 MFMA peak (MI355X_MICROARCH.md)
 PEAK_FP8_TFLOPS = 5000.0    # dense FP8 (v_mfma_f32_16x16x128_f8f6f4), same guide
-PMC_FILE = "r05b_register_n252_pmc_hbm.json"   # committed FETCH_SIZE / WRITE_SIZE passes of this round
+PMC_FILE = "r05c_register_n252_pmc_hbm.json"   # committed FETCH_SIZE / WRITE_SIZE passes of this round
 BASELINE_HYP_S = 705.6      # reference README.md:37-41: Register 2.8 fps x 252 on RTX 4060 (TensorRT fp16)
 
 
@@ -78,7 +78,7 @@ FP8_LAYERS = {"conv_128", "conv_256", "conv_b2", "conv_512"}   # 3x3 trunk convo
 Q8 = ("fp8", "int8")
 _Q8_TEXT = ("operands for the 13 3x3 trunk convolutions from encodeA.2 on (91 % of the FLOPs): per-output-channel weight scales, per-input-channel "
             "activation scales folded into the weights, f16 residual stream (dual-output epilogues), calibrated bias correction; f16 elsewhere")
-_Q8_PMC = {"fp8": "r04", "int8": "r05"}   # profiles/<tag>_register_<dtype>_720p_pmc_hbm.json
+_Q8_PMC = {"fp8": "r04", "int8": "r05c"}   # profiles/<tag>_register_<dtype>_720p_pmc_hbm.json
 PRECISION_TEXT = {"f16": "f16 storage / f32 accumulate (the reference's TensorRT --fp16)", "bf16": "bf16 storage / f32 accumulate",
                   "fp8": "OCP e4m3 (v_mfma_f32_16x16x128_f8f6f4) " + _Q8_TEXT,
                   "int8": "8-bit integer (v_mfma_i32_16x16x64_i8; unsigned activations stored with an offset of -128) " + _Q8_TEXT}
@@ -502,7 +502,7 @@ def main():
                                                     "weights": "discriminating synthetic set"},
                         "accuracy": {"pose_delta_vs_f16_track": {"deg": round(float(rot_deg(p8[None], p16[None])[0]), 3),
                                                                  "mm": round(float(np.linalg.norm(p8[:3, 3] - p16[:3, 3]) * 1e3), 3)}},
-                        "graph": "21 kernels (row ranges inside the vertex + crop launch, the encoder tail of both heads in one launch); the f16 graph spans 193.9 us (profiles/r05b_track_timeline.txt)"}
+                        "graph": "21 kernels (row ranges inside the vertex + crop launch, the encoder tail of both heads in one launch); the f16 graph spans 193.9 us (profiles/r05c_track_timeline.txt)"}
             finally:
                 m.close()
         extras["track_int8"] = track_leg_int8(max(args.steps * 10, 100))
@@ -522,7 +522,7 @@ def main():
             "dtype": "bf16", "config": {"workload": f"BASELINE configs[1]: Track N=1 {Wd}x{H}, bf16 refine-net, frame resident in HBM"},
             "roofline": {"bound": "launch latency (one hipGraph of dependent kernels), not MFMA", "algorithmic_gflop_per_frame": round(bflops / 1e9, 2),
                          "achieved": round(bflops / (tb / kb) / 1e12, 1), "peak": PEAK_FP16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(bflops / (tb / kb) / 1e12 / PEAK_FP16_TFLOPS, 4), "launches_in_eager_profile": sum(v["calls"] for v in bprof.values()), "graph_kernels": 21, "note": "the profiled call runs eagerly with pose update and heads as separate launches; the replayed graph has 21 kernels (profiles/r05b_track_timeline.txt)"}}
+                         "frac": round(bflops / (tb / kb) / 1e12 / PEAK_FP16_TFLOPS, 4), "launches_in_eager_profile": sum(v["calls"] for v in bprof.values()), "graph_kernels": 21, "note": "the profiled call runs eagerly with pose update and heads as separate launches; the replayed graph has 21 kernels (profiles/r05c_track_timeline.txt)"}}
     if n1008 is not None:
         extras["n1008"] = n1008
 
