@@ -2212,13 +2212,14 @@ int refiner_forward(hipStream_t s, Profiler *prof, const Net *net, NNScratch *ws
     ) {
       // [r5] everything row-wise behind the attention as ONE launch of 2 x 25 sixteen-token tiles (enc_tail_kernel<., 1>) instead of
       // out_proj, LayerNorm 1, FFN1, FFN2, LayerNorm 2 + partial sums (five dependent launches, 33 us of the 202 us graph)
-      float *const psum = reinterpret_cast<float *>(a.y2);   // [2][25][512]
+      float *const pdot = reinterpret_cast<float *>(a.y2);   // [2][25][4]
       {
         ProfScope ps(c.prof, c.s, "enc_tail", 2.0 * 3.0 * 2.0 * 400.0 * EMBED * EMBED, 2.0 * 2.0 * 400.0 * EMBED * 2.0);
         EncTailParams q{};
         q.x = (const unsigned char *)x;
-        q.psum = psum;
+        q.pdot = pdot;
         q.tiles = 25;
+        q.head_out = 3;
         const EncLayer *hl[2] = {&T0, &R0};
         for (int i = 0; i < 2; i++) {
           const EncLayer &L = *hl[i];
@@ -2226,6 +2227,7 @@ int refiner_forward(hipStream_t s, Profiler *prof, const Net *net, NNScratch *ws
           q.w[i][0] = L.att.out_proj.wstep; q.w[i][1] = L.lin1.wstep; q.w[i][2] = L.lin2.wstep;
           q.bias[i][0] = L.att.out_proj.bias; q.bias[i][1] = L.lin1.bias; q.bias[i][2] = L.lin2.bias;
           q.ln_g[i][0] = L.ln1.g; q.ln_b[i][0] = L.ln1.b; q.ln_g[i][1] = L.ln2.g; q.ln_b[i][1] = L.ln2.b;
+          q.head_w[i] = L.head.w;
         }
         constexpr unsigned kLds = 16 * 16 * 64 + 2 * 8 * 16 * 4;
         if (dt == DT_BF16) FP_LAUNCH((enc_tail_kernel<DT_BF16, 1>), dim3(50), dim3(512), kLds, c.s, q);
@@ -2233,13 +2235,10 @@ int refiner_forward(hipStream_t s, Profiler *prof, const Net *net, NNScratch *ws
       }
       {
         ProfScope ps(c.prof, c.s, "small_linear", 2.0 * 2 * T0.head.out * T0.head.in, 0);
-        SmallLinear2 sl{{psum, psum + 25 * EMBED}, {T0.head.w, R0.head.w}, {T0.head.b, R0.head.b}, {trans_dev, rot_dev}};
-        sl.parts = 25; sl.tokens = 400.f;
-        if (fuse && g_fuse_pose) {
-          hipLaunchKernelGGL(small_linear2_pose_kernel, dim3(1), dim3(1024), 0, c.s, sl, T0.head.in, *fuse);
-          if (fused_out) *fused_out = true;
-        } else
-          hipLaunchKernelGGL(small_linear2_kernel, dim3((unsigned)((T0.head.out + 3) / 4), 2), dim3(256), 0, c.s, sl, 1, T0.head.out, T0.head.in);
+        EncHeadsParams hp{pdot, {T0.head.b, R0.head.b}, {trans_dev, rot_dev}, 1, 25, 3, 400.f};
+        const bool do_fuse = fuse && g_fuse_pose;
+        hipLaunchKernelGGL(enc_heads_kernel, dim3(1), dim3(64), 0, c.s, hp, do_fuse ? *fuse : PoseUpdateFuse{}, do_fuse ? 1 : 0);
+        if (do_fuse && fused_out) *fused_out = true;
       }
       FP_HIP_OK(hipGetLastError());
       return 0;
@@ -2300,19 +2299,21 @@ int refiner_forward(hipStream_t s, Profiler *prof, const Net *net, NNScratch *ws
       if (run_qkv(c, heads[i]->att.in_proj, x, (int)rows, a.qkv)) return 1;
       if (run_attention(c, dt, a.qkv, att_out[i], N, 400)) return 1;
     }
-    float *const psum = reinterpret_cast<float *>(a.y2);   // [2][N * 5][512] f32 = N * 20 KB of the N * 400 KB tensor
+    float *const pdot = reinterpret_cast<float *>(a.y2);   // [2][N * 5][4] f32
     {
       ProfScope ps(c.prof, c.s, "enc_tail", 2.0 * 3.0 * 2.0 * (double)rows * EMBED * EMBED, 2.0 * 2.0 * (double)rows * EMBED * 2.0);
       EncTailParams q{};
       q.x = (const unsigned char *)x;
-      q.psum = psum;
+      q.pdot = pdot;
       q.tiles = N * 5;
+      q.head_out = net->trans.head.out;
       for (int i = 0; i < 2; i++) {
         const EncLayer &L = *heads[i];
         q.att[i] = (const unsigned char *)att_out[i];
         q.w[i][0] = L.att.out_proj.wstep; q.w[i][1] = L.lin1.wstep; q.w[i][2] = L.lin2.wstep;
         q.bias[i][0] = L.att.out_proj.bias; q.bias[i][1] = L.lin1.bias; q.bias[i][2] = L.lin2.bias;
         q.ln_g[i][0] = L.ln1.g; q.ln_b[i][0] = L.ln1.b; q.ln_g[i][1] = L.ln2.g; q.ln_b[i][1] = L.ln2.b;
+        q.head_w[i] = L.head.w;
       }
       constexpr unsigned kLds = 16 * 80 * 64 + 2 * 8 * 80 * 4 + 4 * 8192;   // tile + LayerNorm exchanges + the two parked x1 fragments
       if (dt == DT_BF16) FP_LAUNCH((enc_tail_kernel<DT_BF16, 5>), dim3((unsigned)(2 * q.tiles)), dim3(512), kLds, c.s, q);
@@ -2320,8 +2321,8 @@ int refiner_forward(hipStream_t s, Profiler *prof, const Net *net, NNScratch *ws
     }
     {
       ProfScope ps(c.prof, c.s, "small_linear", 2.0 * 2 * N * net->trans.head.out * EMBED, 0);
-      EncHeadsParams hp{psum, {net->trans.head.w, net->rot.head.w}, {net->trans.head.b, net->rot.head.b}, {trans_dev, rot_dev}, N, 5, net->trans.head.out, 400.f};
-      hipLaunchKernelGGL(enc_heads_kernel, dim3((unsigned)N), dim3(384), 0, c.s, hp);
+      EncHeadsParams hp{pdot, {net->trans.head.b, net->rot.head.b}, {trans_dev, rot_dev}, N, 5, net->trans.head.out, 400.f};
+      hipLaunchKernelGGL(enc_heads_kernel, dim3((unsigned)N), dim3(64), 0, c.s, hp, PoseUpdateFuse{}, 0);
     }
     FP_HIP_OK(hipGetLastError());
     return 0;

@@ -12,7 +12,7 @@ for r in rows:
     if "vertex_crop_kernel" in n and cur is None: cur = [r]
     elif cur is not None:
         cur.append(r)
-        if "small_linear2_pose_kernel" in n or "token_mean_pose_kernel" in n: its.append(cur); cur = None
+        if "small_linear2_pose_kernel" in n or "token_mean_pose_kernel" in n or "enc_heads_kernel" in n: its.append(cur); cur = None
 it = its[len(its) // 2]
 t0 = prev = int(it[0]["Start_Timestamp"])
 agg = {}
