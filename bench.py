@@ -43,7 +43,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_FP16_TFLOPS = 2500.0   # MI355X dense fp16/bf16 MFMA peak (MI355X_MICROARCH.md)
 PEAK_FP8_TFLOPS = 5000.0    # dense FP8 (v_mfma_f32_16x16x128_f8f6f4), same guide
-PMC_FILE = "r05c_register_n252_pmc_hbm.json"   # committed FETCH_SIZE / WRITE_SIZE passes of this round
+PMC_FILE = "r05d_register_n252_pmc_hbm.json"   # committed FETCH_SIZE / WRITE_SIZE passes of this round
 BASELINE_HYP_S = 705.6      # reference README.md:37-41: Register 2.8 fps x 252 on RTX 4060 (TensorRT fp16)
 
 
@@ -502,7 +502,7 @@ def main():
                                                     "weights": "discriminating synthetic set"},
                         "accuracy": {"pose_delta_vs_f16_track": {"deg": round(float(rot_deg(p8[None], p16[None])[0]), 3),
                                                                  "mm": round(float(np.linalg.norm(p8[:3, 3] - p16[:3, 3]) * 1e3), 3)}},
-                        "graph": "21 kernels (row ranges inside the vertex + crop launch, the encoder tail of both heads in one launch); the f16 graph spans 193.9 us (profiles/r05c_track_timeline.txt)"}
+                        "graph": "21 kernels (row ranges inside the vertex + crop launch, the encoder tail of both heads in one launch); the f16 graph spans 192.5 us (profiles/r05d_track_timeline.txt)"}
             finally:
                 m.close()
         extras["track_int8"] = track_leg_int8(max(args.steps * 10, 100))
@@ -522,7 +522,7 @@ def main():
             "dtype": "bf16", "config": {"workload": f"BASELINE configs[1]: Track N=1 {Wd}x{H}, bf16 refine-net, frame resident in HBM"},
             "roofline": {"bound": "launch latency (one hipGraph of dependent kernels), not MFMA", "algorithmic_gflop_per_frame": round(bflops / 1e9, 2),
                          "achieved": round(bflops / (tb / kb) / 1e12, 1), "peak": PEAK_FP16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(bflops / (tb / kb) / 1e12 / PEAK_FP16_TFLOPS, 4), "launches_in_eager_profile": sum(v["calls"] for v in bprof.values()), "graph_kernels": 21, "note": "the profiled call runs eagerly with pose update and heads as separate launches; the replayed graph has 21 kernels (profiles/r05c_track_timeline.txt)"}}
+                         "frac": round(bflops / (tb / kb) / 1e12 / PEAK_FP16_TFLOPS, 4), "launches_in_eager_profile": sum(v["calls"] for v in bprof.values()), "graph_kernels": 21, "note": "the profiled call runs eagerly with pose update and heads as separate launches; the replayed graph has 21 kernels (profiles/r05d_track_timeline.txt)"}}
     if n1008 is not None:
         extras["n1008"] = n1008
 
