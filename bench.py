@@ -7,18 +7,21 @@ with the frame (rgb, depth, mask) already resident in HBM when the timed region 
 carries `host_frame` (the reference's calling convention: host frames, H2D inside the call) and `track` (Track fps, N = 1).
 
   N = 1  : workload = BASELINE.json configs[2] "Register, N=252 hypotheses, 640x480, single MI355X, fp16".
-  N > 1  : one process per GPU (torch.distributed.run), the SAME workload strong-scaled -- BASELINE.json's metric is "Register
+  N > 1  : one process per GPU -- `python bench.py --gpus N` spawns its own N ranks; under `python -m torch.distributed.run ...
+           bench.py --gpus N` each process is one rank -- the SAME workload strong-scaled: BASELINE.json's metric is "Register
            N=252 ... at 1/2/4/8 GPUs": the 252 hypotheses are sharded in contiguous slices of ceil(252/N) per GPU, ONE RCCL
            all-gather of one row per hypothesis [pooled score feature 512 | pose 16] f32 -- issued by the LIBRARY on its own
-           stream (fp_register_sharded; torch.distributed only broadcasts the ncclUniqueId and is the fall-back exchange) --
-           then every rank runs the cross-hypothesis attention + arg-max redundantly.  The line also carries `n1008` = BASELINE configs[3] (1008
+           stream (fp_register_sharded) -- then every rank runs the cross-hypothesis attention + arg-max redundantly.  The ranks
+           are torch-free: RCCL and HIP are /opt/rocm's through ctypes, the control plane (ncclUniqueId, barriers, max over ranks)
+           is a localhost socket (foundationpose_cpp_amd/rendezvous.py).  Fewer devices than ranks is an error, never a smaller run.  The line also carries `n1008` = BASELINE configs[3] (1008
            hypotheses sharded the same way).  `--weak` keeps 252 hypotheses PER GPU (252*N in total) instead; `--hyps M` picks
            any total.
   Extra legs of the default N = 1 run (outside the headline's timed region, a few steps each, every one with its own roofline):
-           `host_frame`, `track` (incl. pipelined / batched serving), `track_bf16` (configs[1]), `track_int8`, and configs[4] at 1280x720 in both
-           8-bit precisions: `int8_720p`, `int8_720p_untextured`, `fp8_720p`, `fp8_720p_untextured` (8-bit trunk convolutions,
-           calibrated on the bench frame, DISCRIMINATING synthetic weights) -- each with an `accuracy` object: refined-pose deltas
-           against the f16 path, winner, teacher-forced rank, whether the 1 deg / 1 mm bar is met for >= 95 % of the hypotheses.
+           `host_frame`, `track` (incl. pipelined / batched serving), `track_bf16` (configs[1]), `track_int8`, and configs[4] at 1280x720:
+           `f16_720p`, `f16_720p_untextured` (the configs[4] path: f16) and the EXPERIMENTAL 8-bit legs `int8_720p`,
+           `int8_720p_untextured` (8-bit trunk convolutions calibrated on 16 OTHER frames, measured on a held-out one, DISCRIMINATING synthetic
+           weights; `--fp8-legs` adds the FP8 e4m3 pair) -- each 8-bit leg with an `accuracy` object: refined-pose deltas against the f16
+           path, winner, teacher-forced rank, whether the 1 deg / 1 mm bar is met for >= 95 % of the hypotheses.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
   roofline     -- dominant kernel (the conv/linear implicit-GEMM kernel with the largest share of the step, MFMA-bound):
@@ -43,7 +46,8 @@ sys.path.insert(0, ROOT)
 
 PEAK_FP16_TFLOPS = 2500.0   # MI355X dense fp16/bf16 MFMA peak (MI355X_MICROARCH.md)
 PEAK_FP8_TFLOPS = 5000.0    # dense FP8 (v_mfma_f32_16x16x128_f8f6f4), same guide
-PMC_FILE = "r05d_register_n252_pmc_hbm.json"   # committed FETCH_SIZE / WRITE_SIZE passes of this round
+PMC_FILE = "r06_register_n252_pmc_hbm.json"    # committed FETCH_SIZE / WRITE_SIZE passes of this round
+STATS_FILE = "r06_register_n252_kernel_stats.csv"   # committed `rocprofv3 --kernel-trace --stats` summary of the same command
 BASELINE_HYP_S = 705.6      # reference README.md:37-41: Register 2.8 fps x 252 on RTX 4060 (TensorRT fp16)
 
 
@@ -132,6 +136,240 @@ def analyse_profile(prof, dtype, n_hyp, stages_per_hyp):
     return roof, stages, dom, dv
 
 
+# =====================================================================================================================================
+# N > 1: one process per GPU.  The data plane is the LIBRARY's: fp_register_sharded issues the one ncclAllGather per Register on the
+# model's own stream.  The control plane is foundationpose_cpp_amd/rendezvous.py (a localhost socket: the
+# 128-byte ncclUniqueId, barriers, the max over ranks).  The ranks import neither torch nor a second HIP runtime: RCCL and HIP are
+# /opt/rocm's, bound through ctypes -- the same runtime the library links.
+# =====================================================================================================================================
+def _hip_device_count():
+    try:
+        hip = C.CDLL("libamdhip64.so")
+        n = C.c_int(0)
+        return n.value if hip.hipGetDeviceCount(C.byref(n)) == 0 else 0
+    except OSError:
+        return 0
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher: spawn the N ranks (RANK / LOCAL_RANK / WORLD_SIZE set, HIP_VISIBLE_DEVICES untouched),
+    serve the rendezvous from this process, relay their output, exit non-zero unless every rank succeeded."""
+    import subprocess
+    from foundationpose_cpp_amd import rendezvous
+    n = args.gpus
+    stub = os.environ.get("FP_BENCH_STUB_RANK") == "1"      # tests/test_bench_launcher_cpu.py: the launcher and control plane without a GPU
+    have = n if stub else _hip_device_count()
+    if have < n:
+        print(f"bench.py: --gpus {n} needs {n} HIP devices, this box has {have}: refusing to run fewer ranks than asked for", file=sys.stderr)
+        return 2
+    server = rendezvous.Server(n)
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), FP_RDV_ADDR=server.address, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    try:
+        pending = set(range(n))
+        while pending:
+            for r in list(pending):
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                pending.discard(r)
+                if code != 0 and rc == 0:
+                    rc = code if code > 0 else 1
+                    print(f"bench.py: rank {r} exited with {code}; stopping the other ranks", file=sys.stderr)
+                    for o in pending:
+                        procs[o].terminate()          # the exact children started above
+            time.sleep(0.05)
+    finally:
+        for pr in procs:
+            if pr.poll() is None:
+                pr.kill()
+    if rc == 0 and server.error is not None:
+        print(f"bench.py: rendezvous server: {server.error}", file=sys.stderr)
+        rc = 3
+    return rc
+
+
+class _NcclUniqueId(C.Structure):
+    _fields_ = [("internal", C.c_char * 128)]
+
+
+def rank_main(args, world):
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
+    stub = os.environ.get("FP_BENCH_STUB_RANK") == "1"
+    assert "torch" not in sys.modules, "the rank processes are torch-free"
+    from foundationpose_cpp_amd import rendezvous
+    client, server = rendezvous.connect(rank, world)
+    n_total = args.hyps if args.hyps > 0 else (252 * world if args.weak else 252)
+    assert n_total % 42 == 0, "--hyps must be a multiple of 42 (icosphere views)"
+    per = -(-n_total // world)
+
+    def finish(res):
+        sys.stdout.flush()
+        try:
+            C.CDLL(None).fflush(None)       # RCCL's banner goes through C stdio: out before the JSON line
+        except OSError:
+            pass
+        client.barrier()
+        if rank == 0:
+            print(json.dumps(res), flush=True)
+        client.barrier()
+        client.close()
+        if server is not None:
+            server.join(5)
+        return 0
+
+    if stub:     # the control plane alone: every collective of the real body, no GPU work
+        uid = client.broadcast(bytes(range(128)) if rank == 0 else None)
+        assert uid == bytes(range(128))
+        assert client.all_min_int(1) == 1
+        client.barrier()
+        t0 = time.perf_counter()
+        time.sleep(0.01 * (rank + 1))
+        dt = client.all_max(time.perf_counter() - t0)
+        per_rank = client.gather_floats(0.01 * (rank + 1))
+        winners = client.all_gather(str(7).encode())
+        assert len(set(winners)) == 1
+        return finish({"metric": f"pose-hypotheses/sec (Register N={n_total}, stub)", "value": round(n_total / dt, 2), "unit": "hypotheses/s", "n_gpus": world,
+                       "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt * 1e3, 3), "higher_is_better": True, "scaling": "strong",
+                       "vs_baseline": None, "dtype": args.dtype, "data": "stub", "config": {"workload": "launcher / control-plane stub (no GPU work)"},
+                       "rccl_ranks_seen": len(per_rank), "per_rank_ms": [round(x * 1e3, 3) for x in per_rank]})
+
+    # ---- RCCL first (RTLD_GLOBAL): the library binds "a copy already in the process" at its first sharded call
+    err = None
+    try:
+        rccl = C.CDLL("librccl.so.1", mode=C.RTLD_GLOBAL)
+        hip = C.CDLL("libamdhip64.so")
+        ndev = C.c_int(0)
+        if hip.hipGetDeviceCount(C.byref(ndev)) != 0 or ndev.value <= local_rank:
+            err = f"rank {rank}: HIP device {local_rank} does not exist ({ndev.value} devices): --gpus {world} needs {world} GPUs"
+        elif hip.hipSetDevice(local_rank) != 0:
+            err = f"rank {rank}: hipSetDevice({local_rank}) failed"
+    except OSError as e:
+        err = f"rank {rank}: {e}"
+    if client.all_min_int(0 if err else 1) == 0:      # every rank leaves together: nobody waits in a collective for a rank that never comes
+        raise SystemExit(err or f"rank {rank}: another rank has no device; not running with fewer than {world} ranks")
+    from foundationpose_cpp_amd import FoundationPose, synthetic as syn, weights as W
+    from foundationpose_cpp_amd.api import FP_PREC_BF16
+    if args.dtype not in ("f16", "bf16"):
+        raise SystemExit("bench.py --gpus N > 1 runs the f16 / bf16 networks (the 8-bit precisions are single-GPU legs)")
+    mesh = syn.make_mesh(textured=not args.untextured)
+    scene = syn.make_scene(mesh, args.width, args.height)
+    H, Wd = scene.depth.shape
+    wdir = tempfile.mkdtemp()
+    import atexit, shutil
+    atexit.register(shutil.rmtree, wdir, True)
+    rp, sp = os.path.join(wdir, "r.fpw"), os.path.join(wdir, "s.fpw")
+    W.pack_synthetic("refiner", rp)
+    W.pack_synthetic("scorer", sp)
+    model = FoundationPose(mesh, scene.K, rp, sp, max_input_image_height=max(1080, args.height), max_input_image_width=max(1920, args.width), device=local_rank)
+    if args.dtype == "bf16":
+        model.set_precision(FP_PREC_BF16)
+    model.set_inplane_steps(n_total // 42)
+
+    # the frame resident in HBM (value's definition): device buffers of the runtime the library itself uses
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+
+    def to_device(a):
+        a = np.ascontiguousarray(a)
+        d = C.c_void_p()
+        assert hip.hipMalloc(C.byref(d), a.nbytes) == 0 and hip.hipMemcpy(d, a.ctypes.data_as(C.c_void_p), a.nbytes, 1) == 0, "hipMalloc / hipMemcpy failed"
+        return d
+    d_rgb, d_depth, d_mask = to_device(scene.rgb), to_device(scene.depth), to_device(scene.mask)
+
+    # ---- the communicator: rank 0 draws the id, the rendezvous carries its 128 bytes
+    rccl.ncclGetUniqueId.argtypes = [C.POINTER(_NcclUniqueId)]
+    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, _NcclUniqueId, C.c_int]
+    rccl.ncclCommCount.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+    rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+    rccl.ncclGetErrorString.restype = C.c_char_p
+    uid = _NcclUniqueId()
+    ok = 1
+    if rank == 0:
+        ok = 1 if rccl.ncclGetUniqueId(C.byref(uid)) == 0 else 0
+    raw = client.broadcast(bytes(uid) if rank == 0 and ok else None)
+    if len(raw) != 128:
+        raise SystemExit(f"rank {rank}: rank 0 could not draw a ncclUniqueId")
+    C.memmove(C.byref(uid), raw, 128)
+    comm = C.c_void_p()
+    rc = rccl.ncclCommInitRank(C.byref(comm), world, uid, rank)
+    if client.all_min_int(1 if rc == 0 else 0) == 0:
+        raise SystemExit(f"rank {rank}: ncclCommInitRank: {rccl.ncclGetErrorString(rc).decode() if rc else 'failed on another rank'}")
+    seen = C.c_int(0)
+    rccl.ncclCommCount(comm, C.byref(seen))
+
+    out_pose = np.zeros(16, np.float32)
+    idx = C.c_int(-1)
+
+    def step():
+        model._must(model._L.fp_register_sharded(model.handle, comm, d_rgb, d_depth, d_mask, 1, H, Wd, mesh.name.encode(), 1,
+                                                 out_pose.ctypes.data_as(C.c_void_p), C.byref(idx)))
+
+    def barrier():
+        client.barrier()
+        hip.hipDeviceSynchronize()
+
+    def timed(fn, steps, warmup):
+        for _ in range(warmup):
+            fn()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        barrier()
+        return time.perf_counter() - t0
+
+    dt_own = timed(step, args.steps, args.warmup)
+    dt = client.all_max(dt_own)                              # the job is as slow as its slowest rank
+    per_rank_ms = client.gather_floats(dt_own / args.steps * 1e3)
+    winners = [int(x) for x in client.all_gather(str(idx.value).encode())]
+    poses = client.all_gather(out_pose.tobytes())
+    if len(set(winners)) != 1 or len(set(poses)) != 1:
+        raise SystemExit(f"rank {rank}: the ranks disagree on the winner / pose ({winners}): the redundant finish must be bit-identical")
+    model.profile(True)
+    model.profile_reset()
+    step()
+    prof = model.profile_report()
+    model.profile(False)
+    n1008 = None
+    if not args.no_extras and args.hyps == 0 and not args.weak:      # BASELINE configs[3]: 1008 hypotheses sharded the same way
+        model.set_inplane_steps(24)
+        k8 = max(3, args.steps // 4)
+        t8 = client.all_max(timed(step, k8, 1))
+        model.set_inplane_steps(n_total // 42)
+        n1008 = {"metric": f"pose-hypotheses/sec (Register N=1008, {Wd}x{H})", "value": round(1008 * k8 / t8, 2), "unit": "hypotheses/s",
+                 "ms_per_step": round(t8 / k8 * 1e3, 3), "steps": k8, "n_gpus": world, "scaling": "strong",
+                 "workload": f"BASELINE configs[3]: Register N=1008 sharded, {-(-1008 // world)}/GPU, {Wd}x{H}, refine_itr=1, {args.dtype}"}
+    res = None
+    if rank == 0:
+        roof, stages, dom, dv = analyse_profile(prof, args.dtype, min(per, n_total), 2)
+        res = {
+            "metric": f"pose-hypotheses/sec (Register N={n_total}, {Wd}x{H})", "value": round(n_total * args.steps / dt, 2), "unit": "hypotheses/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak" if args.weak and args.hyps == 0 else "strong",
+            "vs_baseline": round(n_total * args.steps / dt / BASELINE_HYP_S, 3), "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"Register N={n_total} hypotheses sharded, {per}/GPU, {Wd}x{H} refine_itr=1, frame resident in HBM",
+                       "mesh": f"synthetic ellipsoid V=2562 F=5120, {'2x2 grey (untextured)' if args.untextured else '512x512 texture'}",
+                       "weights": "synthetic (seed 7)", "precision": PRECISION_TEXT[args.dtype], "calibration": None,
+                       "parallelism": f"hyp-shard x{world}: contiguous slices of {per} hypotheses, one process per GPU",
+                       "collective": "1 ncclAllGather [n_local,528] f32 per Register, issued by the library on its own stream (fp_register_sharded); "
+                                     "control plane: localhost socket rendezvous (ncclUniqueId, barriers, max over ranks), no torch in the ranks",
+                       "baseline": "reference README.md:37-41 Register 2.8 fps x 252 = 705.6 hyp/s on RTX 4060 (TensorRT fp16)"},
+            "rccl_ranks_seen": int(seen.value), "per_rank_ms": [round(x, 3) for x in per_rank_ms], "winner": winners[0],
+            "roofline": dict(roof, what=f"rank 0's slice of {min(per, n_total)} hypotheses"), "stage_ms": stages,
+        }
+        if n1008 is not None:
+            res["n1008"] = n1008
+    model.close()
+    rccl.ncclCommDestroy(comm)
+    return finish(res)
+
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -152,26 +390,27 @@ def main():
     ap.add_argument("--track", action="store_true", help="measure Track fps (N=1 hypothesis) as the headline instead of Register")
     args = ap.parse_args()
 
+    # ---- who am I?  (contract: `python bench.py --gpus N` alone, or one rank of `python -m torch.distributed.run ... bench.py --gpus N`)
+    world_env = os.environ.get("WORLD_SIZE")
+    if args.gpus > 1 and world_env is None:
+        sys.exit(launch_ranks(args))            # spawn the N ranks ourselves; rank 0 prints the JSON line
+    world = int(world_env or "1")
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU (or run `python bench.py --gpus {args.gpus}` "
+                         "without a launcher, it spawns its own ranks)")
+    if world > 1 or os.environ.get("FP_BENCH_FORCE_SHARD", "0") == "1":
+        sys.exit(rank_main(args, world))        # torch-free: RCCL + HIP through ctypes, control plane = foundationpose_cpp_amd/rendezvous.py
+
     import torch
-    import torch.distributed as dist
     from foundationpose_cpp_amd import FoundationPose, synthetic as syn, weights as W
     from foundationpose_cpp_amd.api import FP_PREC_BF16, FP_PREC_F16, FP_PREC_FP8, FP_PREC_INT8
     Q8_PREC = {"fp8": FP_PREC_FP8, "int8": FP_PREC_INT8}
-    from foundationpose_cpp_amd.distributed import HipShardBackend, NativeRcclComm, sharded_register, sharded_register_native
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    rank, local_rank, force_shard, native_comm = 0, 0, False, None
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP library has no CPU path")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    force_shard = os.environ.get("FP_BENCH_FORCE_SHARD", "0") == "1"   # exercise the N>1 code path on one GPU
-    if world > 1 or force_shard:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     mesh = syn.make_mesh(textured=not args.untextured)
     scene = syn.make_scene(mesh, args.width, args.height)
@@ -198,15 +437,6 @@ def main():
     depth = torch.from_numpy(scene.depth).to(dev)
     mask = torch.from_numpy(scene.mask).to(dev)
     H, Wd = scene.depth.shape
-    backend = HipShardBackend(model, dev)
-    # N > 1: the library's own collective (fp_register_sharded: ncclAllGather on the model's stream); the torch.distributed exchange
-    # (HipShardBackend) stays as the fall-back if a communicator cannot be made
-    native_comm = None
-    if (world > 1 or force_shard) and os.environ.get("FP_BENCH_TORCH_COLLECTIVE", "0") != "1":
-        try:
-            native_comm = NativeRcclComm(dist, dev)
-        except Exception as e:   # noqa: BLE001
-            print(f"[bench] native RCCL communicator unavailable ({e}); using torch.distributed for the all-gather", file=sys.stderr)
     out_pose = np.zeros(16, np.float32)
     hyp16 = syn.to_colmajor(syn.perturb_pose(scene.gt_pose))
     hyp44 = syn.perturb_pose(scene.gt_pose)
@@ -221,37 +451,13 @@ def main():
                                             C.c_void_p(mask.data_ptr()), 1, H, Wd, mesh.name.encode(), 1,
                                             out_pose.ctypes.data_as(C.c_void_p)))
 
-    # the native collective must give what the torch.distributed exchange gives, on every rank; otherwise all ranks fall back together
-    if native_comm is not None and not args.track:
-        agree = 1
-        try:
-            p_n, i_n = sharded_register_native(model, native_comm, rgb, depth, mask, H, Wd, mesh.name, 1)
-        except Exception as e:   # noqa: BLE001
-            print(f"[bench] rank {rank}: fp_register_sharded failed ({e})", file=sys.stderr)
-            agree = 0
-        p_t, i_t = sharded_register(backend, dist, n_total, rgb, depth, mask, H, Wd, mesh.name, 1)
-        if agree and (i_n != i_t or not np.array_equal(p_n, p_t)):
-            print(f"[bench] rank {rank}: native and torch.distributed sharded Registers disagree (winner {i_n} vs {i_t})", file=sys.stderr)
-            agree = 0
-        flag = torch.tensor([agree], dtype=torch.int32, device=dev)
-        if world > 1:
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag.item()) == 0:
-            native_comm = None
-
     def step():
         if args.track:
             track_dev()
-        elif world == 1 and not force_shard:
-            register_dev()
-        elif native_comm is not None:
-            sharded_register_native(model, native_comm, rgb, depth, mask, H, Wd, mesh.name, 1)
         else:
-            sharded_register(backend, dist, n_total, rgb, depth, mask, H, Wd, mesh.name, 1)
+            register_dev()
 
     def barrier():
-        if world > 1:
-            dist.barrier()
         torch.cuda.synchronize()
 
     def timed(fn, steps, warmup):
@@ -265,10 +471,6 @@ def main():
         return time.perf_counter() - t0
 
     dt = timed(step, args.steps, args.warmup)
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
 
     # per-kernel-family event timing of ONE extra step (outside the timed region)
     model.profile(True)
@@ -362,19 +564,8 @@ def main():
     if not args.track and not args.no_extras and args.hyps == 0 and not args.weak:
         model.set_inplane_steps(24)
 
-        def step1008():
-            if world == 1 and not force_shard:
-                register_dev()
-            elif native_comm is not None:
-                sharded_register_native(model, native_comm, rgb, depth, mask, H, Wd, mesh.name, 1)
-            else:
-                sharded_register(backend, dist, 1008, rgb, depth, mask, H, Wd, mesh.name, 1)
         k8 = max(3, args.steps // 4)
-        t8 = timed(step1008, k8, 1)
-        if world > 1:
-            t = torch.tensor([t8], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            t8 = float(t.item())
+        t8 = timed(register_dev, k8, 1)
         model.set_inplane_steps(n_total // 42)
         n1008 = {"metric": f"pose-hypotheses/sec (Register N=1008, {Wd}x{H})", "value": round(1008 * k8 / t8, 2), "unit": "hypotheses/s",
                  "ms_per_step": round(t8 / k8 * 1e3, 3), "steps": k8, "n_gpus": world, "scaling": "strong",
@@ -405,10 +596,12 @@ def main():
             try:
                 ok, p16, idx16, sc16, ref16, _ = m.register_detailed(scene_l.rgb, scene_l.depth, scene_l.mask, mesh_l.name)
                 assert ok, m.last_error
-                t0 = time.perf_counter()
-                m.calibrate_frames(syn.calibration_scenes(mesh_l, N_CAL, W=w, H=h), mesh_l.name, Q8_PREC[dtype])
-                t_cal = time.perf_counter() - t0
-                m.set_precision(Q8_PREC[dtype])
+                t_cal = 0.0
+                if dtype in Q8:
+                    t0 = time.perf_counter()
+                    m.calibrate_frames(syn.calibration_scenes(mesh_l, N_CAL, W=w, H=h), mesh_l.name, Q8_PREC[dtype])
+                    t_cal = time.perf_counter() - t0
+                    m.set_precision(Q8_PREC[dtype])
                 ok, p8, idx8, sc8, ref8, _ = m.register_detailed(scene_l.rgb, scene_l.depth, scene_l.mask, mesh_l.name)
                 assert ok, m.last_error
                 dmm = np.linalg.norm(ref8[:, :3, 3] - ref16[:, :3, 3], axis=1) * 1e3
@@ -417,8 +610,12 @@ def main():
                 m.set_precision(FP_PREC_F16)
                 m.upload_frame(scene_l.rgb, scene_l.depth)
                 sc_tf = m.scorer_infer(*m.render_and_transform(mesh_l.name, ref8, 1.1))
-                m.set_precision(Q8_PREC[dtype])
-                accuracy = {
+                if dtype in Q8:
+                    m.set_precision(Q8_PREC[dtype])
+                accuracy = {"what": "the f16 path IS the 16-bit reference of this comparison: a second Register of the same model reproduces the first bit for bit",
+                            "deterministic": bool(np.array_equal(ref8, ref16) and idx8 == idx16),
+                            "parity": "tests/test_precision_gpu.py::test_configs4_f16_720p_follows_the_oracle holds this path to >= 95 % within 1 mm / 1 deg of the fp32 "
+                                      "oracle chain (common mode < 0.3 mm) on held-out 1280x720 scenes, textured and untextured"} if dtype not in Q8 else {
                     "weights": "discriminating synthetic set (seed 9 + tests/golden/disc_calib_seed9.npz): score spread ~1, unique maximum",
                     "pose_delta_vs_f16": {"what": "the 252 refined poses against the f16 path's refined pose of the same hypothesis",
                                           "mm_p95": round(float(np.percentile(dmm, 95)), 3), "mm_max": round(float(dmm.max()), 3),
@@ -447,7 +644,7 @@ def main():
                 pr = m.profile_report()
                 m.profile(False)
                 roof_l, stages_l, dom_l, _ = analyse_profile(pr, dtype, 252, 2)
-                pmc_l = os.path.join(ROOT, "profiles", f"{_Q8_PMC[dtype]}_register_{dtype}_720p_pmc_hbm.json")
+                pmc_l = os.path.join(ROOT, "profiles", f"{_Q8_PMC.get(dtype, 'none')}_register_{dtype}_720p_pmc_hbm.json")
                 if textured and os.path.exists(pmc_l):
                     for name, rec in json.load(open(pmc_l)).items():
                         if dom_l.split("<")[0].split("[")[0] in name:
@@ -459,17 +656,22 @@ def main():
                         "config": {"workload": f"BASELINE configs[4]: Register N=252 {w}x{h} refine_itr=1, frame resident in HBM, "
                                                f"{'512x512 texture' if textured else '2x2 grey (untextured)'} mesh",
                                    "precision": PRECISION_TEXT[dtype],
-                                   "calibration": f"{N_CAL} held-out frames: fp_calibrate_begin / _add_frame x {N_CAL} / _finish on OTHER scenes of the synthetic scene "
-                                                  f"family ({t_cal:.1f} s: per-frame f16 statistics, INT8 weights rounded with error feedback against the frames' "
-                                                  "channel means, bias / token / output correction over all frames); the measured frame is not among them"},
-                        **({"experimental": True, "note": "FP8 e4m3 does not hold the configs[4] parity bar (tests/test_precision_gpu.py::"
-                                                          "test_register_720p_fp8_meets_the_bar is a strict xfail): not a headline leg"} if dtype == "fp8" else {}),
+                                   "calibration": (f"{N_CAL} held-out frames: fp_calibrate_begin / _add_frame x {N_CAL} / _finish on OTHER scenes of the synthetic scene "
+                                                   f"family ({t_cal:.1f} s: per-frame f16 statistics, INT8 weights rounded with error feedback against the frames' "
+                                                   "channel means, bias / token / output correction over all frames); the measured frame is not among them") if dtype in Q8 else None},
+                        **({"experimental": True, "note": "the 8-bit precisions do NOT hold the configs[4] parity bar (>= 95 % within 1 mm / 1 deg of f16 on every unseen "
+                                                          "scene, common mode < 0.3 mm) for any subset of trunk stages (tools/q8_blocks.py, profiles/r06_q8_blocks_*.log; the "
+                                                          "bar is a strict xfail in tests/test_precision_gpu.py): configs[4] ships in f16 (legs f16_720p*), this leg is "
+                                                          "what the experimental precision costs and reaches"} if dtype in Q8 else
+                           {"configs4": "this is the configs[4] path: f16 (DESIGN.md section 4.4: no 8-bit stage subset holds the bar)"}),
                         "accuracy": accuracy, "roofline": roof_l, "stage_ms": dict(list(stages_l.items())[:8])}
             finally:
                 m.close()
         lsteps = max(5, args.steps // 2)
-        # configs[4] ships INT8 (calibrated on other frames, measured on a held-out one).  FP8 e4m3 fails the parity bar and is not a leg of
-        # the default line any more: `--fp8-legs` adds its two legs, marked experimental
+        # configs[4] ships in F16 [r6]: legs f16_720p / f16_720p_untextured.  INT8 (calibrated on other frames, measured on a held-out one) is
+        # EXPERIMENTAL -- its two legs stay in the line, marked so, with their accuracy objects; FP8 e4m3 is further off: `--fp8-legs` adds its legs
+        extras["f16_720p"] = register_leg(True, "f16", 1280, 720, lsteps)
+        extras["f16_720p_untextured"] = register_leg(False, "f16", 1280, 720, lsteps)
         extras["int8_720p"] = register_leg(True, "int8", 1280, 720, lsteps)
         extras["int8_720p_untextured"] = register_leg(False, "int8", 1280, 720, lsteps)
         if args.fp8_legs:
@@ -539,6 +741,21 @@ def main():
             for name, rec in pmc.items():
                 if dom.split("<")[0].split("[")[0] in name:
                     traffic, traffic_src = round(rec["traffic_bytes_per_launch"]), os.path.relpath(pmc_path, ROOT)
+        # the same fraction recomputed from the committed rocprofv3 kernel-stats summary (its average duration of the dominant kernel x this
+        # run's algorithmic FLOPs per launch): the HIP-event figure above and the profiler's must agree
+        recomputed = None
+        stats_path = os.path.join(ROOT, "profiles", STATS_FILE)
+        if os.path.exists(stats_path) and not args.track and args.dtype == "f16" and (Wd, H) == (640, 480) and n_total == 252:
+            import csv
+            key = dom.split("<")[0].split("[")[0]
+            rows = [r for r in csv.DictReader(open(stats_path)) if key in r["Name"]]
+            if rows:
+                top = max(rows, key=lambda r: float(r["TotalDurationNs"]))
+                avg_ms = float(top["AverageNs"]) * 1e-6
+                ach = roof["algorithmic_gflop_per_launch"] / avg_ms / 1e3
+                recomputed = {"source": os.path.relpath(stats_path, ROOT), "kernel": top["Name"], "calls": int(top["Calls"]), "avg_launch_ms": round(avg_ms, 4),
+                              "achieved": round(ach, 1), "frac": round(ach / roof["peak"], 4),
+                              "what": "rocprofv3 --kernel-trace --stats average of the dominant kernel (a committed run on another box of the pool) x this run's algorithmic GFLOP per launch"}
         # what the matrix pipes sustain on THIS box with every SIMD busy (register-resident MFMAs, random operands): the
         # datasheet 2.5 PFLOP/s assumes 2.4 GHz, under MFMA load the power limit holds the clock near 2.0 GHz
         measured_peak, measured_mhz, peak_detail = None, None, None
@@ -627,8 +844,7 @@ def main():
                 "precision": PRECISION_TEXT[args.dtype],
                 "calibration": "16 frames of OTHER synthetic scenes (fp_calibrate_begin / _add_frame / _finish); the bench frame is not among them" if args.dtype in Q8 else None,
                 "parallelism": f"hyp-shard x{world}" if world > 1 else "single GPU",
-                "collective": ("1 ncclAllGather [n_local,528] f32 per Register, issued by the library on its own stream (fp_register_sharded)" if native_comm is not None
-                               else "1 RCCL all-gather [n_local,528] f32 per Register (torch.distributed)") if world > 1 or force_shard else "none",
+                "collective": "none",
                 "baseline": "reference README.md:37-41 Register 2.8 fps x 252 = 705.6 hyp/s on RTX 4060 (TensorRT fp16), timed around the host-frame "
                             "call; vs_baseline = host_frame.value / 705.6 when that leg ran (N=1 default run), else value / 705.6",
             },
@@ -637,6 +853,7 @@ def main():
                 "peak_measured_what": "register-resident f16 MFMA micro-benchmark on this box (fp8 MFMAs: 2x)",
                 "frac_of_measured": round(roof["achieved"] / (measured_peak * (2 if dv.get("fp8") else 1)), 4) if measured_peak else None,
                 "clock_probe": clock_probe,
+                "recomputed_from_profiles": recomputed,
                 "traffic": traffic, "traffic_source": traffic_src,
                 "traffic_kind": "committed rocprofv3 PMC passes of the same command (profiles/), NOT measured by this run" if traffic else None,
             }),
@@ -655,12 +872,8 @@ def main():
         C.CDLL(None).fflush(None)
     except OSError:
         pass
-    if world > 1 or force_shard:
-        dist.barrier()
     if res is not None:
         print(json.dumps(res), flush=True)
-    if world > 1 or force_shard:
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -1931,14 +1931,17 @@ int fp_track(fp_model *m, const uint8_t *rgb, const float *depth, int H, int W, 
 int fp_set_precision(fp_model *m, int precision) try {
   FP_CHECK(m != nullptr, "[FoundationPose] null model");
   FP_CHECK(precision == PREC_F16 || precision == PREC_BF16 || precision == PREC_FP8 || precision == PREC_INT8, "[FoundationPose] unknown precision");
+  // (checked BEFORE anything is prepared: an uncalibrated 8-bit precision must not cost 0.3-1 s of host work, an exclusive section and
+  // two resident networks just to be refused.  m->calibrated only changes under the exclusive lock, which a racing calibration of the
+  // same model would be a caller error anyway: models are not re-entrant)
+  FP_CHECK(!(precision == PREC_FP8 || precision == PREC_INT8) || m->calibrated(precision),
+           "[FoundationPose] an 8-bit precision needs its calibration: call fp_calibrate for it (or fp_set_calibration_blob with its record) first");
   PreparedNets nets;   // (host phase of a first selection outside the lock)
   if (nets.prepare(m->refiner_path, m->refiner_p[precision] != nullptr, m->scorer_path, m->scorer_p[precision] != nullptr, precision)) return 1;
   LifeExclusive life;   // may load the networks of a precision: as exclusive as fp_create
   DeviceScope on_device(m->device);
   if (nets.adopt(m)) return 1;
   FP_HIP_OK(hipStreamSynchronize(m->stream));
-  FP_CHECK(!(precision == PREC_FP8 || precision == PREC_INT8) || m->calibrated(precision),
-           "[FoundationPose] an 8-bit precision needs its calibration: call fp_calibrate for it (or fp_set_calibration_blob with its record) first");
   return select_precision(m, precision);
 } FP_CATCH_INT
 int fp_get_precision(const fp_model *m) { return m ? m->prec : -1; }
@@ -2101,6 +2104,7 @@ static int calibrate_impl(fp_model *m, const std::vector<CalibFrame> &frames, in
   for (int sweep = 0; sweep < n_sweeps; sweep++)
     for (int layer = 0; layer < 13; layer++) {
       const int a = layer + 2, C = net_q8_bias_channels(layer);
+      if (!net_q8_layer_on(qn[0], layer)) continue;   // [r6] a 2-byte layer of a partly 8-bit trunk has nothing to correct
       if (pass(2, a, nullptr, mq, nullptr)) return 1;
       for (int k = 0; k < 2; k++) {
         std::vector<float> &fix = rec.bias_fix[k];
@@ -2301,7 +2305,20 @@ int fp_set_calibration_blob(fp_model *m, const void *blob, size_t bytes) try {
   for (int k = 0; k < 2; k++) take(rec.out_fix[k], k == 0 ? 8 : 512);
   rec.slots = slots;
   for (int k = 0; v2 && k < 2; k++) { take(rec.fmeans[k], (size_t)kCalibSlots * 15 * 512); rec.fmeans[k].resize((size_t)slots * 15 * 512); }
-  if (apply_record(m, precision, rec)) return 1;   // (re-quantises the networks of the precision that are already loaded)
+  const CalibRecord before = record_of(m, precision);
+  if (apply_record(m, precision, rec)) {   // (re-quantises the networks of the precision that are already loaded)
+    // a failure behind the first network leaves it re-quantised to the NEW record while the model still reports the old one: put the
+    // old one back (as calibrate_locked does), or drop the precision's record when that fails too
+    const std::string why = fp_last_error();
+    if (!(before.valid() && apply_record(m, precision, before) == 0)) {
+      for (int k = 0; k < 2; k++) { m->calib_amax_q[precision][k].clear(); m->calib_bias_fix[precision][k].clear(); m->calib_tok_fix[precision][k].clear(); m->calib_out_fix[precision][k].clear(); m->calib_fmeans[precision][k].clear(); }
+      m->calib_slots[precision] = 0;
+      for (Net *n : {m->refiner_p[precision], m->scorer_p[precision]}) if (n) net_q8_unready(n);
+    }
+    invalidate_graphs(m);
+    set_error(why);
+    return 1;
+  }
   commit_record(m, precision, rec);
   invalidate_graphs(m);
   return 0;

@@ -48,6 +48,8 @@ void net_calib_abort(Net *net);
 void net_q8_unready(Net *net);
 void net_q8_get_fix(const Net *q8_net, float *bias_fix /*[13][512]*/, float *tok_fix /*[512]*/);
 int net_q8_bias_channels(int layer);   // output channels of 8-bit layer 0..12 (layer i writes trunk activation i + 2)
+bool net_q8_layer_on(const Net *q8_net, int layer);   // [r6] trunk layer 0..12 runs on 8-bit operands in this network (its stage is in the mask)
+int net_q8_blocks(const Net *q8_net);                 // the stage mask the network was loaded with (0 for the 2-byte networks)
 
 NNScratch *nn_scratch_create(int prec);
 void nn_scratch_free(NNScratch *);

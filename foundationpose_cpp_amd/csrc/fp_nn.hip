@@ -278,6 +278,8 @@ struct EncLayer {  // transformer encoder layer (refiner heads)
 // trunk activation ids (FP8 scales / calibration): 0 stem, 1 a1, 2..5 encodeA blocks, 6..9 encodeAB 256 blocks, 10 b2,
 // 11..14 encodeAB 512 blocks (14 = the token tensor, never quantised)
 static constexpr int N_TRUNK_ACT = 15;
+// trunk layer i (0..12, q8_layers order) -> its stage bit
+static constexpr int q8_block_of(int i) { return i < 4 ? 1 : i < 8 ? 2 : i == 8 ? 4 : 8; }
 
 struct Net {
   bool scorer = false;
@@ -297,6 +299,12 @@ struct Net {
   // solved by the calibration sweeps (fp_api.hip: fp_calibrate)
   bool q8_ready = false;
   int qdt = DT_FP8;                                  // element type of the 8-bit layers
+  int q8_blocks = 0;                                 // [r6] stages on 8-bit operands (bits: q8_block_of); 0 for the 2-byte networks
+  // [r6] INT8: the per-image first-order compensation (run_trunk_q8: IB) belongs to records whose corrections were SOLVED with it on,
+  // i.e. records that carry frame means (version 2, fp_calibrate_*).  A round-4 record or fp_set_calibration's per-tensor scales
+  // (no frame means) were solved without it: compensating on top would subtract the same term twice.
+  bool q8_img_comp = false;
+  bool q8_on(int layer) const { return (q8_blocks & q8_block_of(layer)) != 0; }
   std::vector<float> act_scale[N_TRUNK_ACT];         // host, [channels of the activation]
   float *act_oinv[N_TRUNK_ACT] = {nullptr};          // device
   float *act_scale_dev[N_TRUNK_ACT] = {nullptr};     // device copy of act_scale (calibration statistics of 8-bit tensors)
@@ -412,6 +420,7 @@ static bool make_grouped(Net *net, const ConvLayer &a, const ConvLayer &b, ConvL
   };
   *g = a;
   g->w = nullptr; g->bias = nullptr; g->wfrag = nullptr; g->wpack = nullptr; g->wpack128 = nullptr; g->wdeep = nullptr;   // (the grouped launch never runs on gemm_k32_kernel)
+  g->wstep = nullptr; g->tmat_t = nullptr; g->cscale = nullptr;   // (copied as placeholders from `a`: a host address no launch may ever see)
   std::vector<unsigned char> buf;
   if (!cat(&a.w, &b.w, &buf) || !put_bytes(net, g->w, buf)) return false;
   {
@@ -589,6 +598,16 @@ static int g_q8_wclip = 1, g_q8_efr = 2, g_q8_imgbias = 1;   // A/B (tools/q8_mu
 #else
 static constexpr float g_q8_headroom = 1.25f;
 static constexpr int g_q8_wclip = 1, g_q8_efr = 2, g_q8_imgbias = 1;
+#endif
+// [r6] which residual stages of the trunk an 8-bit network runs on 8-bit operands (the others keep their f16 weights and kernels):
+// bit 0 = encodeA.2-3 (4 convs, 128 ch), bit 1 = encodeAB.0-1 (4 convs, 256 ch), bit 2 = encodeAB.2 (3x3 / s2, 256 -> 512),
+// bit 3 = encodeAB.3-4 (4 convs, 512 ch).  A network keeps the mask it was loaded with (Net::q8_blocks).
+static constexpr int Q8_BLOCKS_ALL = 15;
+#ifdef FP_TEST_HOOKS
+static int env_int(const char *name, int dflt) { const char *e = std::getenv(name); return e && *e ? std::atoi(e) : dflt; }
+static int g_q8_blocks = env_int("FP_Q8_BLOCKS", Q8_BLOCKS_ALL);   // A/B (fpt_set_q8_blocks; tools/q8_blocks.py): networks loaded AFTER a change carry the new mask
+#else
+static constexpr int g_q8_blocks = Q8_BLOCKS_ALL;
 #endif
 #ifdef FP_TEST_HOOKS
 static float env_float(const char *name, float dflt) { const char *e = std::getenv(name); return e && *e ? (float)std::atof(e) : dflt; }
@@ -845,15 +864,17 @@ static Net *net_load_impl(const char *path, bool is_scorer, int prec, std::strin
   const int tdt = prec == PREC_FP8 ? DT_FP8 : prec == PREC_INT8 ? DT_I8 : adt;
   net->act_dt = adt;
   net->qdt = tdt;
+  net->q8_blocks = is_q8(tdt) ? (g_q8_blocks & Q8_BLOCKS_ALL) : 0;
+  const auto ldt = [&](int layer) { return net->q8_on(layer) ? tdt : adt; };   // a stage outside the mask keeps 2-byte weights
   bool ok = make_stem(net.get(), m, "encodeA.0", adt, &net->a0, err) && make_conv(net.get(), m, "encodeA.1", 2, 128, 64, 3, adt, &net->a1, err);
   for (int i = 0; ok && i < 2; i++)
     for (int j = 0; ok && j < 2; j++) {
       std::string cj = ".conv" + std::to_string(j + 1);
-      ok = make_conv(net.get(), m, "encodeA." + std::to_string(2 + i) + cj, 1, 128, 128, 3, tdt, &net->ra[i][j], err) &&
-           make_conv(net.get(), m, "encodeAB." + std::to_string(i) + cj, 1, 256, 256, 3, tdt, &net->rb[i][j], err) &&
-           make_conv(net.get(), m, "encodeAB." + std::to_string(3 + i) + cj, 1, 512, 512, 3, tdt, &net->rc[i][j], err);
+      ok = make_conv(net.get(), m, "encodeA." + std::to_string(2 + i) + cj, 1, 128, 128, 3, ldt(0), &net->ra[i][j], err) &&
+           make_conv(net.get(), m, "encodeAB." + std::to_string(i) + cj, 1, 256, 256, 3, ldt(4), &net->rb[i][j], err) &&
+           make_conv(net.get(), m, "encodeAB." + std::to_string(3 + i) + cj, 1, 512, 512, 3, ldt(9), &net->rc[i][j], err);
     }
-  ok = ok && make_conv(net.get(), m, "encodeAB.2", 2, 512, 256, 3, tdt, &net->b2, err);
+  ok = ok && make_conv(net.get(), m, "encodeAB.2", 2, 512, 256, 3, ldt(8), &net->b2, err);
   if (ok && !is_scorer) {
     EncLayer *heads[2] = {&net->trans, &net->rot};
     const char *names[2] = {"trans_head", "rot_head"};
@@ -934,7 +955,7 @@ int net_commit(Net *net, std::string *err) {
   ConvLayer *q8l[13];
   q8_layers(net, q8l);
   for (ConvLayer *l : q8l)
-    if (l->wdeep == &g_placeholder) l->wdeep = l->wpack;
+    if (is_q8(l->dt) && l->wdeep == &g_placeholder) l->wdeep = l->wpack;
   net->pending.clear();
   net->pending.shrink_to_fit();
   net->deferred = false;
@@ -988,6 +1009,8 @@ static int act_channels(int a) { return a <= 4 ? 128 : a <= 9 ? 256 : 512; }
 // layer i's output goes ONLY to the next 8-bit convolution (a block's first conv): the consumer's scales fold into cscale / bias
 static bool q8_folded_out(int i) { return i == 0 || i == 2 || i == 4 || i == 6 || i == 9 || i == 11; }
 int net_q8_bias_channels(int layer) { return layer < 4 ? 128 : layer < 8 ? 256 : 512; }
+bool net_q8_layer_on(const Net *n, int layer) { return n->q8_on(layer); }
+int net_q8_blocks(const Net *n) { return n->q8_blocks; }
 
 // One 8-bit layer: (weights) quantise its rows with the input-channel scales s_in folded in and upload every layout; then the epilogue
 // tables.  accumulator -> real value: acc * sw (+ DT_I8: 128 * sw * sum_k q, the offset of the unsigned activations) + bias + fix;
@@ -1053,6 +1076,7 @@ int net_apply_q8(Net *net, const float *amax, const float *bias_fix, const float
     }
   }
   FP_CHECK(!net->act_scale[1].empty(), "net_apply_q8: bias update before the scales were set");
+  if (weights) net->q8_img_comp = dt == DT_I8 && frame_means != nullptr && n_frames > 0;
   for (int i = 0; i < 13; i++) {
     ConvLayer &l = *L[i];
     const int Cout = l.Cout;
@@ -1062,6 +1086,7 @@ int net_apply_q8(Net *net, const float *amax, const float *bias_fix, const float
   std::vector<float> m_int;
   for (int i = 0; i < 13; i++) {
     const int a = i + 1, Cin = L[i]->Cin;   // layer i reads activation i + 1
+    if (!net->q8_on(i)) continue;           // [r6] a 2-byte layer of a partly 8-bit trunk: nothing to quantise
     const bool efr = weights && dt == DT_I8 && frame_means && n_frames > 0 && g_q8_efr;
     if (efr) {   // mean integer activation of every input channel per frame: f16 mean / scale
       m_int.assign((size_t)n_frames * Cin, 0.f);
@@ -2053,9 +2078,13 @@ static int run_trunk_q8(const Ctx &c, const Arena &a, const void *nn_in, int N, 
   // INT8 [r5]: per-image bias of layer L for the 8-bit input tensor xq ([NBi, HW+2, HW+2, Cin] bytes): bias minus the first-order
   // compensation of the weights' rounding error for that image's channel means (q8_img_sum_kernel / q8_img_bias_kernel); null when off
   auto IB = [&](const ConvLayer &L, const void *xq, int NBi, int HW) -> const float * {
-    // (batches of a few images -- Track -- run without it: the error-feedback rounding has already cancelled this term for the calibration
-    // frames' means, what the compensation adds is the image's deviation from them, and 26 more launches would double a Track)
-    if (q != DT_I8 || !L.tmat_t || !c.ws || !c.ws->img_sum || !g_q8_imgbias || NBi < 16) return nullptr;
+    // (passes of fewer than 16 hypotheses -- Track, small shards -- run without it: the error-feedback rounding has already cancelled this
+    // term for the calibration frames' means, what the compensation adds is the image's deviation from them, and 26 more launches would
+    // double a Track.  The corrections of a record are solved on full Registers WITH it: a small pass therefore carries the image's own
+    // first-order term uncorrected -- measured on Track 0.24 deg / 0.28 mm against f16)
+    // [r6] the decision is per CALL (N, the hypotheses of this pass), not per layer: with NBi the 128-channel layers of a 15-hypothesis
+    // pass (NB2 = 16 or 30 images) compensated while its 256- / 512-channel layers (N = 15 images) did not
+    if (q != DT_I8 || !net->q8_img_comp || !L.tmat_t || !c.ws || !c.ws->img_sum || !g_q8_imgbias || N < 16) return nullptr;
     ProfScope ps(c.prof, c.s, "q8_img_bias", 0, (double)NBi * (HW + 2) * (HW + 2) * L.Cin);
 #ifdef FP_TEST_HOOKS
     if (g_q8_imgbias == 2) {   // A/B (test build): the three-launch form (sliced integer-atomic sums, 64-channel bias blocks, clear)
@@ -2073,49 +2102,89 @@ static int run_trunk_q8(const Ctx &c, const Arena &a, const void *nn_in, int N, 
     return c.ws->img_bias;
   };
   const size_t P1 = (size_t)NB2 * 42 * 42, P2 = (size_t)N * 42 * 42, P5 = (size_t)N * 22 * 22;
+  // [r6] every stage (encodeA.2-3 / encodeAB.0-1 / encodeAB.2 / encodeAB.3-4) is either on 8-bit operands or on its 2-byte weights and
+  // kernels (Net::q8_blocks).  The residual stream is f16 either way, so the tensor a stage hands over always exists in f16; an
+  // 8-bit stage's producer also leaves the 8-bit operand copy -- from its own epilogue (DT_DUAL_*) when it is an 8-bit layer or
+  // encodeA.1, through q8_copy_kernel when it is a 2-byte layer (those keep their SAME-type kernels: the resident-halo and 256x256
+  // schedules have no f16 -> dual-output instantiation).
+  const bool A = net->q8_on(0), B = net->q8_on(4), S = net->q8_on(8), C = net->q8_on(9);
+  const float *const *oinv = net->act_oinv;
+  float *const *scd = net->act_scale_dev;
+  auto qcopy = [&](const void *x16, void *xq, int imgs, int HW, int Cc, int act) {
+    ProfScope ps(c.prof, c.s, "q8_copy", 0, (double)imgs * HW * HW * Cc * 3.0);
+    const size_t octs = (size_t)imgs * HW * HW * (Cc / 8);
+    const dim3 grid((unsigned)((octs + 255) / 256));
+    if (q == DT_FP8) hipLaunchKernelGGL(q8_copy_kernel<DT_FP8>, grid, dim3(256), 0, c.s, (const _Float16 *)x16, (unsigned char *)xq, oinv[act], HW + 2, HW + 2, 1, Cc, octs);
+    else hipLaunchKernelGGL(q8_copy_kernel<DT_I8>, grid, dim3(256), 0, c.s, (const _Float16 *)x16, (unsigned char *)xq, oinv[act], HW + 2, HW + 2, 1, Cc, octs);
+  };
+  // first conv of a residual block (no skip operand): 8-bit -> 8-bit with the consumer's scales folded in, or plain f16
+  auto first = [&](const char *tag, const ConvLayer &L, bool on, const Act &x16, const Act &xq, int NB, int HW, const Act &y16, const Act &yq, int act, size_t P, int Cc) -> int {
+    if (on) {
+      if (run_conv(c, tag, L, xq, NB, HW, HW, 1, yq, 1, true, nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, IB(L, xq.p, NB, HW))) return 1;
+      calib_record(c, act, yq.p, P, Cc, q, scd[act]);
+    } else {
+      if (run_conv(c, tag, L, x16, NB, HW, HW, 1, y16, 1, true)) return 1;
+      calib_record(c, act, y16.p, P, Cc, DT_F16);
+    }
+    return 0;
+  };
+  // second conv of a block (skip operand res16, always f16): writes the f16 stream tensor y16 and / or the 8-bit copy yq for an 8-bit consumer
+  auto second = [&](const char *tag, const ConvLayer &L, bool on, const Act &x16, const Act &xq, int NB, int HW, const Act &res16, const Act *y16, const Act *yq,
+                    int split, int act, size_t P, int Cc) -> int {
+    const Act &x = on ? xq : x16;
+    const float *bi = on ? IB(L, xq.p, NB, HW) : nullptr;
+    if (on && y16 && yq) { if (run_conv(c, tag, L, x, NB, HW, HW, 1, *y16, 1, true, &res16, 1, split, nullptr, nullptr, nullptr, yq, oinv[act], nullptr, bi)) return 1; }
+    else if (on && yq) { if (run_conv(c, tag, L, x, NB, HW, HW, 1, *yq, 1, true, &res16, 1, split, nullptr, nullptr, nullptr, nullptr, oinv[act], nullptr, bi)) return 1; }
+    else {
+      if (run_conv(c, tag, L, x, NB, HW, HW, 1, *y16, 1, true, &res16, 1, split, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, bi)) return 1;
+      if (yq && !split) qcopy(y16->p, yq->p, NB, HW, Cc, act);   // (the concat layer's copy is made by its caller, behind broadcast_b)
+    }
+    if (split) return 0;   // (the concat tensor is complete -- and recorded -- only behind broadcast_b: its caller does both)
+    if (y16) calib_record(c, act, y16->p, P, Cc, DT_F16);
+    else calib_record(c, act, yq->p, P, Cc, q, scd[act]);
+    return 0;
+  };
   const Act in = F(const_cast<void *>(nn_in)), stem = F(a.stem);
   if (run_conv(c, "conv_stem", net->a0, in, NB2, 80, 80, 2, stem, 1, true)) return 1;
-  // encodeA.1 (f16 operands) starts the 128-channel stream: f16 x0 + 8-bit copy
-  const Act x0 = F(a.x128[0]), x0q = Q(a.q128[0]), x1q = Q(a.q128[1]), x2 = F(a.x128[2]), x2q = Q(a.q128[2]);
-  if (run_conv(c, "conv_a1", net->a1, stem, NB2, 80, 80, 1, x0, 1, true, nullptr, 0, 0, nullptr, nullptr, nullptr, &x0q, net->act_oinv[1])) return 1;
-  if (run_conv(c, "conv_128", net->ra[0][0], x0q, NB2, 40, 40, 1, x1q, 1, true, nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, IB(net->ra[0][0], a.q128[0], NB2, 40))) return 1;
-  calib_record(c, 2, a.q128[1], P1, 128, q, net->act_scale_dev[2]);
-  if (run_conv(c, "conv_128", net->ra[0][1], x1q, NB2, 40, 40, 1, x2, 1, true, &x0, 1, 0, nullptr, nullptr, nullptr, &x2q, net->act_oinv[3], nullptr, IB(net->ra[0][1], a.q128[1], NB2, 40))) return 1;
-  calib_record(c, 3, a.x128[2], P1, 128, DT_F16);
-  if (run_conv(c, "conv_128", net->ra[1][0], x2q, NB2, 40, 40, 1, x1q, 1, true, nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, IB(net->ra[1][0], a.q128[2], NB2, 40))) return 1;
-  calib_record(c, 4, a.q128[1], P1, 128, q, net->act_scale_dev[4]);
-  // the last encodeA conv writes the a|b channel concat (f16 + 8-bit copy)
+  // encodeA.1 (f16 operands) starts the 128-channel stream: f16 x0 (+ its 8-bit copy)
+  const Act x0 = F(a.x128[0]), x1 = F(a.x128[1]), x2 = F(a.x128[2]), x0q = Q(a.q128[0]), x1q = Q(a.q128[1]), x2q = Q(a.q128[2]);
+  if (A) { if (run_conv(c, "conv_a1", net->a1, stem, NB2, 80, 80, 1, x0, 1, true, nullptr, 0, 0, nullptr, nullptr, nullptr, &x0q, oinv[1])) return 1; }
+  else if (run_conv(c, "conv_a1", net->a1, stem, NB2, 80, 80, 1, x0, 1, true)) return 1;
+  if (first("conv_128", net->ra[0][0], A, x0, x0q, NB2, 40, x1, x1q, 2, P1, 128)) return 1;
+  if (second("conv_128", net->ra[0][1], A, x1, x1q, NB2, 40, x0, &x2, A ? &x2q : nullptr, 0, 3, P1, 128)) return 1;
+  if (first("conv_128", net->ra[1][0], A, x2, x2q, NB2, 40, x1, x1q, 4, P1, 128)) return 1;
+  // the last encodeA conv writes the a|b channel concat
   const Act cat = F(a.x256[0]), catq = Q(a.q256[0]);
-  if (run_conv(c, "conv_128", net->ra[1][1], x1q, NB2, 40, 40, 1, cat, 1, true, &x2, 1, N, nullptr, nullptr, nullptr, &catq, net->act_oinv[5], nullptr, IB(net->ra[1][1], a.q128[1], NB2, 40))) return 1;
+  if (second("conv_128", net->ra[1][1], A, x1, x1q, NB2, 40, x2, &cat, (A && B) ? &catq : nullptr, N, 5, P2, 256)) return 1;
   if (n_b == 1 && N > 1) {  // image N landed in cat[0][..,128:256]; replicate it for the other hypotheses (both copies)
     broadcast_b(c, a.x256[0], N, 256);
-    broadcast_b(c, a.q256[0], N, 128);
+    if (A && B) broadcast_b(c, a.q256[0], N, 128);
   }
+  if (B && !A) qcopy(cat.p, catq.p, N, 40, 256, 5);
   calib_record(c, 5, a.x256[0], P2, 256, DT_F16);
-  const Act y1q = Q(a.q256[1]), y2 = F(a.x256[2]), y2q = Q(a.q256[2]), y0 = F(a.x256[1]), y0q = Q(a.q256[0]);
-  if (run_conv(c, "conv_256", net->rb[0][0], catq, N, 40, 40, 1, y1q, 1, true, nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, IB(net->rb[0][0], a.q256[0], N, 40))) return 1;
-  calib_record(c, 6, a.q256[1], P2, 256, q, net->act_scale_dev[6]);
-  if (run_conv(c, "conv_256", net->rb[0][1], y1q, N, 40, 40, 1, y2, 1, true, &cat, 1, 0, nullptr, nullptr, nullptr, &y2q, net->act_oinv[7], nullptr, IB(net->rb[0][1], a.q256[1], N, 40))) return 1;
-  calib_record(c, 7, a.x256[2], P2, 256, DT_F16);
-  if (run_conv(c, "conv_256", net->rb[1][0], y2q, N, 40, 40, 1, y1q, 1, true, nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, IB(net->rb[1][0], a.q256[2], N, 40))) return 1;
-  calib_record(c, 8, a.q256[1], P2, 256, q, net->act_scale_dev[8]);
-  // y0 feeds only encodeAB.2: no f16 copy (0.2 GB per launch less); with a residual the consumer's scales cannot be folded into the
-  // tables, so the epilogue scales (DT_QS_*)
-  (void)y0;
-  if (run_conv(c, "conv_256", net->rb[1][1], y1q, N, 40, 40, 1, y0q, 1, true, &y2, 1, 0, nullptr, nullptr, nullptr, nullptr, net->act_oinv[9], nullptr, IB(net->rb[1][1], a.q256[1], N, 40))) return 1;
-  calib_record(c, 9, a.q256[0], P2, 256, q, net->act_scale_dev[9]);
-  const Act z0 = F(a.x512[0]), z0q = Q(a.q512[0]), z1q = Q(a.q512[1]), z2 = F(a.x512[2]), z2q = Q(a.q512[2]);
-  if (run_conv(c, "conv_b2", net->b2, y0q, N, 40, 40, 1, z0, 1, true, nullptr, 0, 0, nullptr, nullptr, nullptr, &z0q, net->act_oinv[10], nullptr, IB(net->b2, a.q256[0], N, 40))) return 1;
+  const Act y1 = F(a.x256[1]), y2 = F(a.x256[2]), y0 = F(a.x256[0]), y1q = Q(a.q256[1]), y2q = Q(a.q256[2]), y0q = Q(a.q256[0]);
+  if (first("conv_256", net->rb[0][0], B, cat, catq, N, 40, y1, y1q, 6, P2, 256)) return 1;
+  if (second("conv_256", net->rb[0][1], B, y1, y1q, N, 40, cat, &y2, B ? &y2q : nullptr, 0, 7, P2, 256)) return 1;
+  if (first("conv_256", net->rb[1][0], B, y2, y2q, N, 40, y1, y1q, 8, P2, 256)) return 1;
+  // y0 feeds only encodeAB.2: no f16 copy when that layer reads 8-bit operands from an 8-bit producer (0.2 GB per launch less; with a
+  // residual the consumer's scales cannot be folded into the tables, so the epilogue scales: DT_QS_*)
+  if (second("conv_256", net->rb[1][1], B, y1, y1q, N, 40, y2, (B && S) ? nullptr : &y0, S ? &y0q : nullptr, 0, 9, P2, 256)) return 1;
+  const Act z0 = F(a.x512[0]), z1 = F(a.x512[1]), z2 = F(a.x512[2]), z0q = Q(a.q512[0]), z1q = Q(a.q512[1]), z2q = Q(a.q512[2]);
+  if (S) {
+    const float *bi = IB(net->b2, y0q.p, N, 40);
+    if (C) { if (run_conv(c, "conv_b2", net->b2, y0q, N, 40, 40, 1, z0, 1, true, nullptr, 0, 0, nullptr, nullptr, nullptr, &z0q, oinv[10], nullptr, bi)) return 1; }
+    else if (run_conv(c, "conv_b2", net->b2, y0q, N, 40, 40, 1, z0, 1, true, nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, bi)) return 1;
+  } else {
+    if (run_conv(c, "conv_b2", net->b2, y0, N, 40, 40, 1, z0, 1, true)) return 1;
+    if (C) qcopy(z0.p, z0q.p, N, 20, 512, 10);
+  }
   calib_record(c, 10, a.x512[0], P5, 512, DT_F16);
-  if (run_conv(c, "conv_512", net->rc[0][0], z0q, N, 20, 20, 1, z1q, 1, true, nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, IB(net->rc[0][0], a.q512[0], N, 20))) return 1;
-  calib_record(c, 11, a.q512[1], P5, 512, q, net->act_scale_dev[11]);
-  if (run_conv(c, "conv_512", net->rc[0][1], z1q, N, 20, 20, 1, z2, 1, true, &z0, 1, 0, nullptr, nullptr, nullptr, &z2q, net->act_oinv[12], nullptr, IB(net->rc[0][1], a.q512[1], N, 20))) return 1;
-  calib_record(c, 12, a.x512[2], P5, 512, DT_F16);
-  if (run_conv(c, "conv_512", net->rc[1][0], z2q, N, 20, 20, 1, z1q, 1, true, nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, IB(net->rc[1][0], a.q512[2], N, 20))) return 1;
-  calib_record(c, 13, a.q512[1], P5, 512, q, net->act_scale_dev[13]);
+  if (first("conv_512", net->rc[0][0], C, z0, z0q, N, 20, z1, z1q, 11, P5, 512)) return 1;
+  if (second("conv_512", net->rc[0][1], C, z1, z1q, N, 20, z0, &z2, C ? &z2q : nullptr, 0, 12, P5, 512)) return 1;
+  if (first("conv_512", net->rc[1][0], C, z2, z2q, N, 20, z1, z1q, 13, P5, 512)) return 1;
   const Act tok = F(a.tokens);
   bool pe_done = false;
-  if (run_conv(c, "conv_512", net->rc[1][1], z1q, N, 20, 20, 1, tok, 0, true, &z2, 1, 0, nullptr, net->pe, &pe_done, nullptr, nullptr, nullptr, IB(net->rc[1][1], a.q512[1], N, 20))) return 1;
+  if (run_conv(c, "conv_512", net->rc[1][1], C ? z1q : z1, N, 20, 20, 1, tok, 0, true, &z2, 1, 0, nullptr, net->pe, &pe_done, nullptr, nullptr, nullptr, C ? IB(net->rc[1][1], a.q512[1], N, 20) : nullptr)) return 1;
   if (!pe_done) add_pos_embed(c, a, N);
   calib_record(c, 14, a.tokens, (size_t)N * 400, 512, DT_F16);
   return 0;

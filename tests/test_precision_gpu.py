@@ -415,7 +415,16 @@ def _rot_deg(a, b):
     return np.degrees(np.arccos(np.clip((np.trace(dR, axis1=1, axis2=2) - 1) / 2, -1, 1)))
 
 
-# ---- BASELINE configs[4] end to end, under the DISCRIMINATING weights, on frames the calibration NEVER saw ----------------------------
+# ---- BASELINE configs[4] (1280x720, textured + untextured mesh, N = 252) -------------------------------------------------------------
+# [r6] configs[4] runs in F16.  Its text says "fp8 MFMA conv path"; neither 8-bit precision holds the north-star bar (>= 95 % of the refined
+# poses within 1 mm / 1 deg of the 16-bit path on EVERY frame the calibration never saw, common-mode shift < 0.3 mm) under the
+# discriminating weights, for ANY subset of trunk stages: tools/q8_blocks.py (profiles/r06_q8_blocks_*.log) ran INT8 on every single
+# stage and on the combinations -- the best single stage (encodeAB.2 alone, 4 % of the FLOPs, no speed-up) reaches 100 % with 0.31-0.40 mm
+# of common mode, the 256- or 512-channel stage alone 94-100 % / 0.4-0.9 mm for 8-9 % of speed, all 13 layers 85-90 % / 0.7-1.0 mm for 22 %.
+# So (round-5 review, item 1): the row is "f16 only"; FP_PREC_INT8 and FP_PREC_FP8 stay selectable, kernel-tested and Track-tested but
+# EXPERIMENTAL, and what this section asserts about them is (a) the f16 path itself against the fp32 ORACLE at the configs[4] size -- the
+# parity statement of the row -- and (b) regression guards of the experimental precisions at their measured level, named as such, with
+# the bar itself recorded as a STRICT xfail for each.
 # Calibration: fp_calibrate_begin / _add_frame x 16 / _finish on syn.calibration_scenes (the synthetic "deployment scene family":
 # object 0.55-0.95 m away, up to 6 cm off axis, any orientation, own noise / dropped pixels / background); measurement on
 # syn.heldout_scenes (same family, other seeds).  Per held-out scene, N = 252:
@@ -423,13 +432,6 @@ def _rot_deg(a, b):
 #   cm       common-mode shift: length of the mean translation difference over the 252 hypotheses
 #   corr     correlation of the refiner's pose deltas with the f16 path's
 #   regret   teacher-forced: the f16 model scores the 8-bit model's refined poses; (best - winner's) / (best - median)
-# What INT8 reaches (DESIGN.md section 4.4 has the derivation and the measurements): the de-meaned error is ~0.8 mm p95 whatever the
-# scene; the common mode is 0.15-0.45 mm on most scenes and 0.6-0.9 mm on one or two of eight -- second-order in the 8-bit error (a ReLU
-# turns error VARIANCE into a mean shift) and therefore scene-dependent beyond what the first-order machinery removes (error-feedback
-# rounding of the weights, per-image compensation, bias correction over the calibration frames).  So: >= 95 % on most held-out scenes,
-# 65-90 % on the others; the bars below are that level (mean and worst scene), and the 95 %-on-EVERY-scene bar is recorded as a
-# non-strict xfail so that the day it holds is noticed.  Round 4 calibrated on the measured frame itself (100 %) and reached 0-48 % on
-# these scenes.
 _CAL = {}
 
 
@@ -491,35 +493,78 @@ def _heldout_table(disc_nets, Wd, H, textured, prec, n_scenes):
 
 
 @pytest.mark.parametrize("textured", [True, False])
-def test_register_720p_int8_on_heldout_scenes(disc_nets, textured):
-    """BASELINE configs[4]: 1280x720, textured + untextured mesh, N = 252, the 8-bit (INT8) MFMA conv path, calibrated on 16 frames of the
-    scene family and measured on 6 OTHER frames of it, against the f16 path of the same model."""
+def test_configs4_f16_720p_follows_the_oracle(disc_nets, textured):
+    """BASELINE configs[4] as it ships: 1280x720, textured + untextured mesh, N = 252, F16.  Under the discriminating weights, on two
+    held-out scenes: the f16 path's 252 refined poses against the fp32 ORACLE chain (oracle/fp_oracle.c geometry + torch networks on the
+    same hypotheses) hold the north-star bar -- >= 95 % within 1 mm / 1 deg, common-mode shift < 0.3 mm -- with a wide margin (measured:
+    100 %, p95 ~0.1 mm), and the pose the Register returns is one of the oracle's refined poses whose oracle score is within the f16
+    score noise of the oracle's maximum (teacher-forced like every end-to-end comparison here: rendering is discontinuous in the pose)."""
+    mesh = syn.make_mesh(textured=textured)
+    om = fo.OracleMesh(mesh)
+    m = FoundationPose(mesh, syn.intrinsics(1280, 720), disc_nets[0], disc_nets[1])
+    try:
+        for k, scene in enumerate(syn.heldout_scenes(mesh, 2, W=1280, H=720)):
+            ok, pose, idx, scores, refined, _ = m.register_detailed(scene.rgb, scene.depth, scene.mask, mesh.name)
+            assert ok, m.last_error
+            p16 = fo.get_hyp_poses(scene.depth, scene.mask, scene.K)
+            a = fo.render(om, p16, scene.K, scene.depth.shape, 1.2)
+            b = fo.crop(scene.rgb, scene.depth, scene.K, p16, 1.2, mesh.diameter)
+            with torch.no_grad():
+                t, r = disc_nets[2](torch.from_numpy(a), torch.from_numpy(b))
+            ref = syn.from_colmajor(fo.refine_post_process(p16, t.numpy(), r.numpy(), mesh.diameter))
+            dmm = np.linalg.norm(refined[:, :3, 3] - ref[:, :3, 3], axis=1) * 1e3
+            ddeg = _rot_deg(refined, ref)
+            cm = float(np.linalg.norm((refined[:, :3, 3] - ref[:, :3, 3]).mean(0)) * 1e3)
+            frac = float(np.mean((dmm < 1.0) & (ddeg < 1.0)))
+            print(f"f16 1280x720 textured={textured} held-out scene {k}: within 1 mm / 1 deg of the fp32 oracle {frac * 100:.1f} %, mm p95 {np.percentile(dmm, 95):.3f} "
+                  f"max {dmm.max():.3f} (common-mode {cm:.3f}), deg p95 {np.percentile(ddeg, 95):.3f}")
+            assert frac >= 0.95 and cm < 0.3, (frac, cm)
+            assert np.percentile(dmm, 95) < 0.5 and np.percentile(ddeg, 95) < 0.5
+            # the winner, teacher-forced: the ORACLE scores the library's own refined poses
+            r16 = syn.to_colmajor(refined)
+            a = fo.render(om, r16, scene.K, scene.depth.shape, 1.1)
+            b = fo.crop(scene.rgb, scene.depth, scene.K, r16, 1.1, mesh.diameter)
+            with torch.no_grad():
+                s_ref = disc_nets[3](torch.from_numpy(a), torch.from_numpy(b)).numpy()
+            assert np.array_equal(pose, refined[idx])
+            # the scores: on these scenes the discriminating head sits far from its calibration point (scores 26-27 with a spread of 0.65:
+            # the head was centred on the 640x480 default scene), so the f16 noise -- relative to the MAGNITUDE -- is ~15 % of the spread
+            # instead of the 2-3 % of tests/test_discriminative_gpu.py.  What is asserted: the two score vectors correlate, and the
+            # hypothesis the library picked is near the top of the oracle's ranking of the same refined poses (teacher-forced regret)
+            corr = float(np.corrcoef(scores, s_ref)[0, 1])
+            rank = int((s_ref > s_ref[idx]).sum())
+            regret = float((s_ref.max() - s_ref[idx]) / (s_ref.max() - np.median(s_ref)))
+            print(f"    scores vs the oracle's (teacher-forced): corr {corr:.4f}, the library's winner {idx} has oracle rank {rank} (regret {regret:.3f}); "
+                  f"score spread {s_ref.std():.3f} around {s_ref.mean():.2f}")
+            assert idx == int(np.argmax(scores))
+            assert corr > 0.95 and rank < 8 and regret < 0.3, (corr, rank, regret)
+    finally:
+        m.close()
+
+
+@pytest.mark.parametrize("textured", [True, False])
+def test_int8_720p_experimental_level_on_heldout_scenes(disc_nets, textured):
+    """FP_PREC_INT8 is EXPERIMENTAL (it does not hold the configs[4] bar: the strict xfail below).  This is a REGRESSION GUARD of its
+    measured level, not a parity claim: 1280x720, N = 252, calibrated on 16 frames of the scene family, measured on 6 OTHER frames
+    against the f16 path of the same model.  Measured (round 6, profiles/r06_q8_blocks_*.log): share within 1 mm / 1 deg 85-90 % on
+    average, 39-74 % on the worst scene, common mode 0.1-1.0 mm, de-meaned p95 0.8-1.6 mm, delta correlation > 0.99.  Guards: the run is
+    deterministic (_heldout_stats), and the continuous quantities stay inside twice their measured range -- a broken kernel or a
+    mis-applied record is off by orders of magnitude (round 4 calibrated on the measured frame: 1-12 mm on these scenes)."""
     rows = _heldout_table(disc_nets, 1280, 720, textured, FP_PREC_INT8, 6)
     frac = np.array([r["frac"] for r in rows]); cm = np.array([r["cm"] for r in rows])
-    print(f"INT8 1280x720 textured={textured}: share within 1 mm / 1 deg mean {frac.mean() * 100:.1f} % (worst scene {frac.min() * 100:.1f} %, "
+    print(f"INT8 (experimental) 1280x720 textured={textured}: share within 1 mm / 1 deg mean {frac.mean() * 100:.1f} % (worst scene {frac.min() * 100:.1f} %, "
           f"{int((frac >= 0.95).sum())} of {len(rows)} scenes >= 95 %), common-mode mean {cm.mean():.2f} mm max {cm.max():.2f} mm")
-    # the share is a THRESHOLD statistic: a scene whose common-mode shift happens to sit at 1.0 mm has ~40 % of its poses inside 1 mm with the
-    # same error cloud that gives 95 % at 0.4 mm, and which scene that is changes with any change of the arithmetic anywhere in the pipeline
-    # (the fused encoder tail of round 5 moved it from scene 0 / 79 % to scene 3 / 39 %).  So: the mean, the median, at most one scene
-    # below 60 % -- and the worst scene is held by the continuous quantities below (common mode, p95)
-    assert frac.mean() >= 0.80 and np.median(frac) >= 0.90 and (frac < 0.60).sum() <= 1, frac
-    assert cm.mean() < 0.7 and cm.max() < 1.3, cm
     for r in rows:
-        assert r["mm_p95"] < 2.0 and r["deg_p95"] < 1.0, r
-        assert r["corr"] > 0.95 and r["score_corr"] > 0.50, r      # (score correlation: 0.70-0.99; rendering is discontinuous in the pose, a 0.1 mm shift moves a score by ~30 % of the spread)
-    assert np.median([r["score_corr"] for r in rows]) > 0.90
-    # the winner: teacher-forced regret 0 (rank 0) on most scenes; the scores are so sensitive to the pose (0.1 mm ~ 30 % of their spread)
-    # that an occasional scene lands on a runner-up with a large regret (0.14, once 0.68, with 98 % of its refined poses inside the bar):
-    # the median and the count are the stable statistics
-    regret = np.array([r["regret"] for r in rows])
-    assert np.median(regret) < 0.03 and (regret < 0.20).sum() >= len(rows) - 2, regret
+        assert r["mm_p95"] < 3.0 and r["deg_p95"] < 1.0 and r["cm"] < 2.0, r
+        assert r["corr"] > 0.95, r
 
 
-@pytest.mark.xfail(strict=False, reason="the north-star bar on EVERY unseen scene: >= 95 % of the refined poses within 1 mm / 1 deg of f16 and a common-mode "
-                                        "shift < 0.3 mm; INT8 holds it on most held-out scenes, not on all (second-order error of 8-bit weights under the "
-                                        "discriminating heads, DESIGN.md section 4.4)")
-def test_int8_holds_95_percent_on_every_heldout_scene(disc_nets):
-    rows = _heldout_table(disc_nets, 1280, 720, True, FP_PREC_INT8, 6)
+@pytest.mark.xfail(strict=True, reason="INT8 does not hold the configs[4] bar on EVERY unseen scene (>= 95 % of the refined poses within 1 mm / 1 deg of f16 and a "
+                                       "common-mode shift < 0.3 mm): 85-90 % on average, one or two of six scenes at 40-80 %, common mode up to 1 mm -- and no "
+                                       "subset of trunk stages holds it either (tools/q8_blocks.py).  configs[4] ships in f16; INT8 is experimental.")
+@pytest.mark.parametrize("textured", [True, False])
+def test_int8_holds_95_percent_on_every_heldout_scene(disc_nets, textured):
+    rows = _heldout_table(disc_nets, 1280, 720, textured, FP_PREC_INT8, 6)
     assert all(r["frac"] >= 0.95 and r["cm"] < 0.3 for r in rows), [(round(r["frac"], 3), round(r["cm"], 2)) for r in rows]
 
 
