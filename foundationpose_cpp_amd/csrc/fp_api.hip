@@ -71,6 +71,18 @@ __global__ __launch_bounds__(256) void staged_upload_kernel(const unsigned char 
     reinterpret_cast<uint4 *>(dst)[i] = reinterpret_cast<const uint4 *>(src_mapped)[i];
   if (blockIdx.x == 0 && threadIdx.x < (n & 15)) dst[n16 * 16 + threadIdx.x] = src_mapped[n16 * 16 + threadIdx.x];
 }
+// [r6] the Register's read-back {winner index, sampler status, pose} written straight into the model's pinned, device-mapped result
+// block: one 18-lane kernel instead of three device -> host copy commands in front of the call's only synchronisation
+__global__ void publish_result_kernel(const int *__restrict__ argmax, const int *__restrict__ sampler_status, const float *__restrict__ best_pose,
+                                      int *__restrict__ out_mapped) {
+  const int i = threadIdx.x;
+  int v = 0;
+  if (i == 0) v = argmax[0];
+  else if (i == 1) v = sampler_status ? sampler_status[0] : 0;
+  else if (i < 18) v = __float_as_int(best_pose[i - 2]);
+  if (i < 18) out_mapped[i] = v;
+  __threadfence_system();
+}
 hipError_t memcpy_sync(void *dst, const void *src, size_t bytes, hipMemcpyKind kind) {
   std::lock_guard<std::mutex> lk(g_util_mu);
   hipStream_t s = nullptr;
@@ -363,7 +375,17 @@ struct fp_model {
   int H = 0, W = 0;
   uint8_t *rgb_own = nullptr;
   float *depth_own = nullptr;
-  FrameRef *frame_dev = nullptr, *frame_pinned = nullptr;  // what kernels inside graphs read the frame through
+  FrameRef *frame_dev = nullptr;   // what kernels inside graphs read the frame through
+  // [r6] a ring of 8 pinned, device-MAPPED record slots of 64 bytes each: a changed record reaches frame_dev through a kernel
+  // (window_fetch_kernel), not a copy command
+  uint8_t *frame_pinned = nullptr, *frame_pinned_dev = nullptr;
+  // [r6] Register from HOST frames: rgb | depth | mask are packed into this pinned, device-mapped block (grown on demand) and fetched by
+  // staged_upload_kernel -- no copy command and no runtime-internal staging of the caller's pageable pages on a serving path
+  uint8_t *host_stage = nullptr, *host_stage_dev = nullptr;
+  size_t host_stage_cap = 0;
+  hipEvent_t host_stage_done = nullptr;   // recorded behind the last fetch: the block is rewritten only after it
+  bool host_stage_pending = false;
+  bool host_stage_fresh = false;   // this call's frame upload has just claimed the block (the mask goes behind it without waiting again)
   // [r4] frame_dev heads a device block [FrameRef, padded to 64 bytes | packed window]: Track's crop window of a host frame is packed
   // (record, rgb rows, depth rows) into the pinned twin win_stage and fetched from there by window_fetch_kernel, record included
   uint8_t *win_stage = nullptr, *win_stage_dev = nullptr;   // (host address / the device's mapping of it)
@@ -400,7 +422,7 @@ struct fp_model {
   int *argmax_dev = nullptr;
   // one read-back per Register: device [pose16] + pinned host mirror {idx, sampler status, pose16}
   float *best_pose_dev = nullptr;
-  int *result_pinned = nullptr;  // 18 words
+  int *result_pinned = nullptr, *result_pinned_dev = nullptr;  // 18 words, device-mapped [r6]: publish_result_kernel writes them (no D2H copy command)
   bool defer_begin_sync = false;  // fp_register_ex: shard_begin leaves its synchronisation to shard_finish
   bool shard_sampler_pending = false;  // packed shard protocol: begin ran the sampler, finish reports its verdict
   float *scores_all = nullptr;  // scores of the gathered hypotheses of every rank (sharded Register)
@@ -919,7 +941,8 @@ fp_model *fp_create_on(int device, const fp_mesh *meshes, int n_meshes, const fl
   // on the first host-frame Track that needs them and grown on demand (ensure_window) [r5] -- a model that is only ever handed device
   // frames, or never tracks, pins no host memory
   if (hipMalloc((void **)&m->frame_dev, 64) != hipSuccess ||
-      hipHostMalloc((void **)&m->frame_pinned, 8 * sizeof(FrameRef), hipHostMallocDefault) != hipSuccess) {
+      hipHostMalloc((void **)&m->frame_pinned, 8 * 64, hipHostMallocMapped) != hipSuccess ||
+      hipHostGetDevicePointer((void **)&m->frame_pinned_dev, m->frame_pinned, 0) != hipSuccess) {
     set_error("[FoundationPose] Failed to allocate the frame record");
     return nullptr;
   }
@@ -995,6 +1018,8 @@ static void destroy_model_impl(fp_model *m) {
   if (m->track_io) (void)hipHostFree(m->track_io);
   if (m->frame_pinned) (void)hipHostFree(m->frame_pinned);
   if (m->win_stage) (void)hipHostFree(m->win_stage);
+  if (m->host_stage) (void)hipHostFree(m->host_stage);
+  if (m->host_stage_done) (void)hipEventDestroy(m->host_stage_done);
   if (m->frame_dev) (void)hipFree(m->frame_dev);
   dev_free(m->grid_dev); dev_free(m->samp_state); dev_free(m->samp_vals); dev_free(m->mask_dev);
   if (m->digests) (void)hipFree(m->digests);
@@ -1029,6 +1054,40 @@ int fp_synchronize(fp_model *m) try {
 // asynchronous: the caller of this helper synchronises m->stream before the host frame can go away
 // row0 / row1 (host frames): only rows [row0, row1) are needed by the caller (Track: the observed-crop window) -- the rest of the
 // model's copy keeps whatever an earlier frame left there
+// [r6] host -> device on a SERVING path without a copy command: the bytes are packed into the model's pinned, device-mapped block at
+// `stage_off` and a kernel fetches them (staged_upload_kernel; dst must be 16-byte aligned).  The block is rewritten only after the fetches of
+// the previous call have run (host_stage_done), so the asynchronous shard entry points may return before the GPU has read it; the caller's
+// buffer is free on return.
+static int ensure_host_stage(fp_model *m, size_t bytes) {
+  if (m->host_stage_pending) {   // the last call's fetch kernels have read the block
+    FP_HIP_OK(hipEventSynchronize(m->host_stage_done));
+    m->host_stage_pending = false;
+  }
+  if (bytes <= m->host_stage_cap) return 0;
+  const size_t cap = (bytes + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);
+  uint8_t *stage = nullptr, *stage_dev = nullptr;
+  if (hipHostMalloc((void **)&stage, cap, hipHostMallocMapped) != hipSuccess) { set_error("[FoundationPose] out of pinned host memory for the frame"); return 1; }
+  if (hipHostGetDevicePointer((void **)&stage_dev, stage, 0) != hipSuccess) { (void)hipHostFree(stage); set_error("[FoundationPose] the pinned frame block is not device-mapped"); return 1; }
+  if (m->host_stage) (void)hipHostFree(m->host_stage);
+  m->host_stage = stage; m->host_stage_dev = stage_dev; m->host_stage_cap = cap;
+  if (!m->host_stage_done) FP_HIP_OK(hipEventCreateWithFlags(&m->host_stage_done, hipEventDisableTiming));
+  return 0;
+}
+static int stage_fetch(fp_model *m, void *dst_dev, const void *src_host, size_t bytes, size_t stage_off) {
+  FP_CHECK(stage_off % 16 == 0 && stage_off + bytes <= m->host_stage_cap && ((uintptr_t)dst_dev & 15) == 0, "[FoundationPose] internal: misaligned staged upload");
+  std::memcpy(m->host_stage + stage_off, src_host, bytes);
+  const unsigned blocks = (unsigned)std::min<size_t>(1024, (bytes / 16 + 255) / 256 + 1);
+  hipLaunchKernelGGL(fp::staged_upload_kernel, dim3(blocks), dim3(256), 0, m->stream, m->host_stage_dev + stage_off, (unsigned char *)dst_dev, bytes);
+  FP_HIP_OK(hipGetLastError());
+  return 0;
+}
+static int stage_fetch_done(fp_model *m) {
+  FP_HIP_OK(hipEventRecord(m->host_stage_done, m->stream));
+  m->host_stage_pending = true;
+  return 0;
+}
+static size_t stage_mask_offset(size_t px) { return ((px * 3 + 63) & ~(size_t)63) + ((px * 4 + 63) & ~(size_t)63); }   // [rgb | depth | mask]
+
 // room for a packed window of `total` bytes in the model's pinned block and its device twin (both hold the frame record in front)
 static int ensure_window(fp_model *m, size_t total) {
   if (total <= m->win_cap) return 0;
@@ -1067,6 +1126,7 @@ static int upload_frame_async(fp_model *m, const void *rgb, const void *depth, i
     m->frame_cap = px;
   }
   m->H = H; m->W = W;
+  m->host_stage_fresh = false;
   if (memspace == FP_DEVICE) {
     m->rgb = (const uint8_t *)rgb;
     m->depth = (const float *)depth;
@@ -1124,18 +1184,28 @@ static int upload_frame_async(fp_model *m, const void *rgb, const void *depth, i
       FP_HIP_OK(hipMemcpy2DAsync(m->depth_own + oc, (size_t)W * 4, (const float *)depth + oc, (size_t)W * 4, cw * 4, nr,
                                  hipMemcpyHostToDevice, m->stream));
     } else if (n) {
-      FP_HIP_OK(hipMemcpyAsync(m->rgb_own + o * 3, (const uint8_t *)rgb + o * 3, n * 3, hipMemcpyHostToDevice, m->stream));
-      FP_HIP_OK(hipMemcpyAsync(m->depth_own + o, (const float *)depth + o, n * 4, hipMemcpyHostToDevice, m->stream));
+      // [r6] whole rows [row0', row1) through the pinned block + a fetch kernel (row0 rounded down so that both device offsets are
+      // 16-byte aligned: row0' * W % 16 == 0)
+      int ra = row0;
+      while (ra > 0 && ((size_t)ra * W) % 16 != 0) ra--;
+      const size_t oa = (size_t)ra * W, na = (size_t)(row1 - ra) * W;
+      if (ensure_host_stage(m, stage_mask_offset(px) + px)) return 1;
+      if (stage_fetch(m, m->rgb_own + oa * 3, (const uint8_t *)rgb + oa * 3, na * 3, 0)) return 1;
+      if (stage_fetch(m, m->depth_own + oa, (const float *)depth + oa, na * 4, (px * 3 + 63) & ~(size_t)63)) return 1;
+      if (stage_fetch_done(m)) return 1;
+      m->host_stage_fresh = true;
     }
     m->rgb = m->rgb_own;
     m->depth = m->depth_own;
   }
   if (m->frame_pub.rgb != m->rgb || m->frame_pub.depth != m->depth) {
     // (a ring of pinned records: the asynchronous shard entry points return before the copy has run)
-    FrameRef *slot = m->frame_pinned + (m->frame_pub_count++ & 7);
+    const unsigned k = m->frame_pub_count++ & 7;
+    FrameRef *slot = reinterpret_cast<FrameRef *>(m->frame_pinned + 64 * k);
     *slot = FrameRef{};   // whole frame: no pitch, no window
     slot->rgb = m->rgb; slot->depth = m->depth;
-    FP_HIP_OK(hipMemcpyAsync(m->frame_dev, slot, sizeof(FrameRef), hipMemcpyHostToDevice, m->stream));
+    launch_window_fetch(m->stream, m->frame_pinned_dev + 64 * k, m->frame_dev, 64);   // [r6] 64 bytes by a kernel, not a copy command
+    FP_HIP_OK(hipGetLastError());
     m->frame_pub = *slot;
   }
   return 0;
@@ -1220,7 +1290,12 @@ static int sample_hypotheses_async(fp_model *m, Target *t, const void *mask, int
   run_depth_filters(m);
   const uint8_t *mask_d = (const uint8_t *)mask;
   if (memspace != FP_DEVICE) {  // the caller's host mask stays valid until the entry point returns (it synchronises)
-    FP_HIP_OK(hipMemcpyAsync(m->mask_dev, mask, px, hipMemcpyHostToDevice, m->stream));
+    // [r6] through the pinned block (behind the frame's rgb | depth, which a host-frame call has just staged; a host mask over a DEVICE
+    // frame finds the block free or waits for its last use)
+    if (!m->host_stage_fresh && ensure_host_stage(m, stage_mask_offset(px) + px)) return 1;   // (fresh: this call's frame upload sized the block and waited for its last use)
+    m->host_stage_fresh = false;
+    if (stage_fetch(m, m->mask_dev, mask, px, stage_mask_offset(px))) return 1;
+    if (stage_fetch_done(m)) return 1;
     mask_d = m->mask_dev;
   }
   ProfScope ps(&m->prof, m->stream, "sampler", 0, (double)px * 5);
@@ -1481,7 +1556,10 @@ int fp_register_shard_finish(fp_model *m, const float *all_feat_dev, const float
     scores = m->scores_all;
   }
   if (!m->best_pose_dev && dev_alloc(&m->best_pose_dev, 16)) return 1;
-  if (!m->result_pinned) FP_HIP_OK(hipHostMalloc((void **)&m->result_pinned, 18 * sizeof(int), hipHostMallocDefault));
+  if (!m->result_pinned) {
+    FP_HIP_OK(hipHostMalloc((void **)&m->result_pinned, 64 * sizeof(int), hipHostMallocMapped));
+    FP_HIP_OK(hipHostGetDevicePointer((void **)&m->result_pinned_dev, m->result_pinned, 0));
+  }
   int rc = scorer_head(m->stream, &m->prof, m->scorer, m->ws, all_feat_dev, N_total, scores);
   if (!rc) checkpoint(m, 13, scores, (size_t)N_total * 4);
   if (!rc) {
@@ -1489,11 +1567,13 @@ int fp_register_shard_finish(fp_model *m, const float *all_feat_dev, const float
     launch_argmax(m->stream, scores, N_total, m->argmax_dev, all_poses_dev, m->best_pose_dev);
   }
   // ONE synchronisation: winner index, the sampler's status word (when this call also ran the sampler) and the pose
+  // [r6] written by a kernel into the pinned, device-mapped block: no device -> host copy command in front of the synchronisation
   int *res = m->result_pinned;
-  res[1] = 0;
-  if (!rc && hipMemcpyAsync(&res[0], m->argmax_dev, 4, hipMemcpyDeviceToHost, m->stream) != hipSuccess) rc = 1;
-  if (!rc && m->defer_begin_sync && hipMemcpyAsync(&res[1], m->samp_state + 6, 4, hipMemcpyDeviceToHost, m->stream) != hipSuccess) rc = 1;
-  if (!rc && hipMemcpyAsync(&res[2], m->best_pose_dev, 64, hipMemcpyDeviceToHost, m->stream) != hipSuccess) rc = 1;
+  res[0] = -3; res[1] = 3;   // (overwritten by the kernel; what a kernel that never ran would leave is an error, not a stale winner)
+  if (!rc) {
+    hipLaunchKernelGGL(fp::publish_result_kernel, dim3(1), dim3(64), 0, m->stream, m->argmax_dev, m->defer_begin_sync ? m->samp_state + 6 : nullptr, m->best_pose_dev, m->result_pinned_dev);
+    if (hipGetLastError() != hipSuccess) rc = 1;
+  }
   if (!rc && scores_host &&
       hipMemcpyAsync(scores_host, scores, (size_t)N_total * 4, hipMemcpyDeviceToHost, m->stream) != hipSuccess)
     rc = 1;

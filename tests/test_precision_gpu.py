@@ -6,10 +6,13 @@ SAME quantised operands -- products of e4m3 / bf16 values are exact in fp32, so 
 rounding of the output.  End to end: poses against the f16 path and the oracle pipeline, tolerances stated per test.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
 import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 from foundationpose_cpp_amd import FoundationPose, _lib, synthetic as syn, weights as W
 from foundationpose_cpp_amd.api import FP_PREC_BF16, FP_PREC_F16, FP_PREC_FP8, FP_PREC_INT8
@@ -575,6 +578,66 @@ def test_int8_holds_95_percent_on_every_heldout_scene(disc_nets, textured):
 def test_register_720p_fp8_meets_the_bar(disc_nets):
     rows = _heldout_table(disc_nets, 1280, 720, True, FP_PREC_FP8, 2)
     assert all(r["frac"] >= 0.95 for r in rows), [round(r["frac"], 3) for r in rows]
+
+
+def test_stage_mask_of_the_8bit_trunk(disc_nets, syn_mesh, syn_scene):
+    """[r6] run_trunk_q8 runs every residual stage either on 8-bit operands or on its 2-byte weights and kernels (Net::q8_blocks; test
+    build: fpt_set_q8_blocks).  Invariants that do not need an error budget:
+      * mask 0 -- an "INT8" network none of whose stages is 8-bit -- IS the f16 network: Track and a 42-hypothesis Register return the
+        f16 path's poses bit for bit (same weights, same kernels, same buffers; run without the calibration's correction steps, whose
+        arithmetic -- a mean of per-frame means against a pooled mean -- leaves ~1e-8 instead of 0);
+      * every mask runs (all boundary forms: dual-output epilogues, q8_copy_kernel behind a 2-byte producer, 8-bit -> f16 only), is
+        deterministic, and lands within the experimental precision's level of the f16 path;
+      * a single 8-bit stage is closer to f16 than all four together."""
+    def run(mask):
+        # (a model of the TEST library: the product has no hook -- its mask is a compile-time constant)
+        import subprocess, sys, json, textwrap
+        code = textwrap.dedent(f"""
+            import json, sys, numpy as np
+            sys.path.insert(0, {ROOT!r})
+            import torch
+            from foundationpose_cpp_amd import FoundationPose, _lib, synthetic as syn
+            from foundationpose_cpp_amd.api import FP_PREC_F16, FP_PREC_INT8
+            _lib.use_test_lib()
+            L = _lib.lib()
+            L.fpt_set_q8_blocks({mask})
+            if {mask} == 0:      # no correction steps: the calibration averages per-frame means where the 8-bit passes pool all frames, so its
+                L.fpt_set_calib_opts(0, 0, 0)   # token / output corrections are ~1e-8 instead of 0 and flip an occasional f16 ulp of the positional table
+            mesh = syn.make_mesh(); scene = syn.make_scene(mesh)
+            m = FoundationPose(mesh, syn.intrinsics(), {disc_nets[0]!r}, {disc_nets[1]!r})
+            hyp = syn.perturb_pose(scene.gt_pose)
+            held = syn.heldout_scenes(mesh, 1)[0]
+            out = {{}}
+            m.set_inplane_steps(1)
+            for prec, name in ((FP_PREC_F16, "f16"), (FP_PREC_INT8, "int8")):
+                if prec == FP_PREC_INT8:
+                    m.calibrate_frames(syn.calibration_scenes(mesh, 4), mesh.name, prec)
+                m.set_precision(prec)
+                ok, t = m.Track(scene.rgb, scene.depth, hyp, mesh.name); assert ok, m.last_error
+                ok, t2 = m.Track(scene.rgb, scene.depth, hyp, mesh.name); assert ok and np.array_equal(t, t2)
+                ok, p, idx, sc, ref, _ = m.register_detailed(held.rgb, held.depth, held.mask, mesh.name); assert ok, m.last_error
+                ok, p2, idx2, _, ref2, _ = m.register_detailed(held.rgb, held.depth, held.mask, mesh.name); assert ok and idx == idx2 and np.array_equal(ref, ref2)
+                out[name] = dict(track=t.tolist(), refined=ref.tolist(), idx=int(idx))
+            m.close()
+            print("RESULT" + json.dumps(out))
+        """)
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("RESULT")][-1][6:])
+        return {k: dict(track=np.array(v["track"], np.float32), refined=np.array(v["refined"], np.float32), idx=v["idx"]) for k, v in d.items()}
+
+    res = {mask: run(mask) for mask in (0, 4, 6, 9, 15)}
+    r0 = res[0]
+    assert np.array_equal(r0["int8"]["track"], r0["f16"]["track"]) and np.array_equal(r0["int8"]["refined"], r0["f16"]["refined"]) and r0["int8"]["idx"] == r0["f16"]["idx"]
+    cm = {}
+    for mask, r in res.items():
+        d = r["int8"]["refined"][:, :3, 3] - r["f16"]["refined"][:, :3, 3]
+        cm[mask] = (float(np.linalg.norm(d, axis=1).max() * 1e3), float(_rot_deg(r["int8"]["refined"], r["f16"]["refined"]).max()))
+        ang, dist = _pose_err(r["int8"]["track"], r["f16"]["track"])
+        print(f"stage mask {mask:2d}: 42 refined poses vs f16 max {cm[mask][0]:.3f} mm / {cm[mask][1]:.3f} deg; Track vs f16 {dist * 1e3:.3f} mm / {ang:.3f} deg")
+        assert cm[mask][0] < 4.0 and cm[mask][1] < 1.5 and dist < 1e-3 and ang < 1.0, (mask, cm[mask], ang, dist)
+    assert cm[0][0] == 0.0 and cm[0][1] < 1e-3      # (bit-identical above; the angle of R R^T evaluated in floating point is ~1e-6 deg, not 0)
+    assert cm[4][0] < cm[15][0], cm
 
 
 def test_int8_refiner_rows_follow_the_oracle_on_a_heldout_scene(disc_nets, syn_mesh):

@@ -401,8 +401,10 @@ def test_foreign_stream_and_creation_in_one_process_is_tracked():
     while a PyTorch stream runs on another thread: docstring above) stays in the default suite -- in a CHILD pytest
     process, because a SIGSEGV cannot be caught in-process.  Round 5 took every host -> device copy of the creation / loading /
     calibration paths off hipMemcpyAsync (a kernel reads the pinned staging block: fp_api.hip staged_upload_kernel) and moved file I/O and
-    weight re-layouts out of the exclusive section; the Registers of the worker threads still use copy commands for the frame and the
-    result, so the crash is made rarer, not impossible.  A child that dies on a signal is reported as an expected failure with the
+    weight re-layouts out of the exclusive section.  Round 6 did the same for the SERVING paths: fp_register* / fp_track* upload host frames
+    and masks through the model's pinned block + a fetch kernel, publish a changed frame record by a kernel and read the result back through
+    a kernel that writes pinned, device-mapped memory -- no copy command is left on them (the diagnostics this test's workers use,
+    register_detailed -> fp_download, still copy).  The crash was rare to begin with, so "not seen again" is all a test can say.  A child that dies on a signal is reported as an expected failure with the
     signal number (the limitation is stated in README.md / INTEGRATION.md section 5); any OTHER failure fails this test."""
     import subprocess
     import sys

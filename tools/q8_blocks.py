@@ -6,7 +6,7 @@ Per mask and mesh (textured / untextured), 1280x720, N = 252: calibrate on 16 fr
 against the f16 path of the same model: share of the 252 refined poses within 1 mm / 1 deg, p95, common-mode shift, winner index;
 and the Register wall time (host frames) next to f16's.  STRICT bar: every scene >= 95 % and common mode < 0.3 mm.
 
-   python tools/q8_blocks.py [--masks 15,2,8,10] [--prec int8|fp8] [--held 6] [--size 1280 720] [--weights disc|fit]"""
+   python tools/q8_blocks.py [--masks 15,2,8,10] [--prec int8|fp8] [--held 6] [--size 1280 720] [--weights disc|RECORD.npz]"""
 import argparse
 import os
 import sys
@@ -26,7 +26,7 @@ ap.add_argument("--held", type=int, default=6)
 ap.add_argument("--k", type=int, default=16)
 ap.add_argument("--size", nargs=2, type=int, default=[1280, 720])
 ap.add_argument("--meshes", default="textured,untextured")
-ap.add_argument("--weights", default="disc", help="disc = the discriminating synthetic set; fit = the fitted-readout set (tests/golden/fit_readouts_seed9.npz)")
+ap.add_argument("--weights", default="disc", help="disc = the discriminating synthetic set; a path = a calibration record (.npz) applied instead, e.g. the output of oracle/fit_readouts.py")
 args = ap.parse_args()
 _lib.use_test_lib()
 L = _lib.lib()
@@ -36,13 +36,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 cal = W.load_calibration(os.path.join(ROOT, "tests/golden/disc_calib_seed9.npz"))
 d = tempfile.mkdtemp()
 rp, sp = os.path.join(d, "r.fpw"), os.path.join(d, "s.fpw")
-if args.weights == "fit":
-    fit = W.load_fitted_readouts(os.path.join(ROOT, "tests/golden/fit_readouts_seed9.npz"))
-    W.pack_synthetic("refiner", rp, 9, cal, fit)
-    W.pack_synthetic("scorer", sp, 9, cal, fit)
-else:
-    W.pack_synthetic("refiner", rp, 9, cal)
-    W.pack_synthetic("scorer", sp, 9, cal)
+if args.weights != "disc":
+    cal = W.load_calibration(args.weights)
+W.pack_synthetic("refiner", rp, 9, cal)
+W.pack_synthetic("scorer", sp, 9, cal)
 NAMES = {1: "128", 2: "256", 4: "b2", 8: "512"}
 
 
