@@ -752,7 +752,7 @@ def main():
             if rows:
                 top = max(rows, key=lambda r: float(r["TotalDurationNs"]))
                 avg_ms = float(top["AverageNs"]) * 1e-6
-                ach = roof["algorithmic_gflop_per_launch"] / avg_ms / 1e3
+                ach = roof["algorithmic_gflop_per_launch"] / avg_ms      # GFLOP / ms = TFLOP/s
                 recomputed = {"source": os.path.relpath(stats_path, ROOT), "kernel": top["Name"], "calls": int(top["Calls"]), "avg_launch_ms": round(avg_ms, 4),
                               "achieved": round(ach, 1), "frac": round(ach / roof["peak"], 4),
                               "what": "rocprofv3 --kernel-trace --stats average of the dominant kernel (a committed run on another box of the pool) x this run's algorithmic GFLOP per launch"}
