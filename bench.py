@@ -406,7 +406,7 @@ def main():
     from foundationpose_cpp_amd.api import FP_PREC_BF16, FP_PREC_F16, FP_PREC_FP8, FP_PREC_INT8
     Q8_PREC = {"fp8": FP_PREC_FP8, "int8": FP_PREC_INT8}
 
-    rank, local_rank, force_shard, native_comm = 0, 0, False, None
+    rank, local_rank = 0, 0      # (the single-GPU body: N > 1 and FP_BENCH_FORCE_SHARD left through rank_main above)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP library has no CPU path")
     torch.cuda.set_device(local_rank)
@@ -482,7 +482,7 @@ def main():
     # ---- extra legs on one GPU (outside the headline's timed region): the reference's calling convention (host frames,
     # H2D inside the call: speed_register / speed_track, simple_tests/src/test_foundationpose.cpp:118-127,145-154) and Track
     extras = {}
-    if world == 1 and not force_shard and not args.no_extras and rank == 0:
+    if not args.no_extras:
         def register_host():
             ok, _ = model.Register(scene.rgb, scene.depth, scene.mask, mesh.name)
             assert ok, model.last_error
@@ -573,7 +573,7 @@ def main():
 
     # ---- the other BASELINE configs as short legs of the one default run (one GPU): configs[4] FP8 1280x720 textured + untextured,
     # configs[1] bf16 Track -- each on its own model / precision, each with its own roofline
-    if world == 1 and not force_shard and not args.no_extras and rank == 0 and not args.track and args.dtype == "f16" and (Wd, H) == (640, 480):
+    if not args.no_extras and not args.track and args.dtype == "f16" and (Wd, H) == (640, 480):
         # The 8-bit legs run the DISCRIMINATING synthetic weight set (tests/golden/disc_calib_seed9.npz applied to the seed-9 draws, numpy
         # only): under the headline's plain seed-7 draws the 252 scores agree to 3e-5 and "winner matches" says nothing.  Same
         # architecture, same FLOPs -- the timing does not depend on the weight values.
