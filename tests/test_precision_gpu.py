@@ -635,7 +635,8 @@ def test_stage_mask_of_the_8bit_trunk(disc_nets, syn_mesh, syn_scene):
         cm[mask] = (float(np.linalg.norm(d, axis=1).max() * 1e3), float(_rot_deg(r["int8"]["refined"], r["f16"]["refined"]).max()))
         ang, dist = _pose_err(r["int8"]["track"], r["f16"]["track"])
         print(f"stage mask {mask:2d}: 42 refined poses vs f16 max {cm[mask][0]:.3f} mm / {cm[mask][1]:.3f} deg; Track vs f16 {dist * 1e3:.3f} mm / {ang:.3f} deg")
-        assert cm[mask][0] < 4.0 and cm[mask][1] < 1.5 and dist < 1e-3 and ang < 1.0, (mask, cm[mask], ang, dist)
+        # (regression guards of an experimental precision at twice the measured level -- measured: refined poses <= 2.2 mm / 0.31 deg, Track <= 0.91 mm / 0.27 deg)
+        assert cm[mask][0] < 4.5 and cm[mask][1] < 1.0 and dist < 2e-3 and ang < 1.0, (mask, cm[mask], ang, dist)
     assert cm[0][0] == 0.0      # (bit-identical above; the ANGLE of R R^T evaluated in float32 is sqrt(2 eps) ~ 0.03 deg for identical matrices, not 0)
     assert cm[4][0] < cm[15][0], cm
 
